@@ -1,0 +1,114 @@
+"""Deterministic weights, graphs and synthetic inputs (TEST INFRASTRUCTURE, oracle/__init__.py).
+
+Everything is drawn from numpy's PCG64 ``default_rng(seed)`` streams, which are stable
+across machines and numpy versions, so fixtures only need to store seeds + outputs and
+the GPU box regenerates bit-identical weights/inputs without /root/reference.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def _uniform(rng, shape, bound):
+    return torch.from_numpy(rng.uniform(-bound, bound, size=shape).astype(np.float32))
+
+
+def _linear(rng, sd, name, fan_in, fan_out, gain=1.0):
+    b = 1.0 / math.sqrt(fan_in)
+    sd[name + ".weight"] = _uniform(rng, (fan_out, fan_in), b) * gain
+    sd[name + ".bias"] = _uniform(rng, (fan_out,), b) * gain
+
+
+def make_denoiser_state(steps, c_in, c_out=None, D=1152, hidden=128, variant="2d",
+                        arch="transformer", virt_nodes=4, n_layers=4, heads=8, seed=0,
+                        qk_gain=1.0):
+    """State dict with the reference's ``Eff_GAT`` / ``Eff_GAT_3d`` key layout (live
+    params only; the dead ``linear1/linear2`` and the encoders are not on the path).
+    Linear: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (torch's default scale); embeddings N(0,1).
+    ``qk_gain`` multiplies the query/key projections to make the softmax peaky (the
+    default init gives near-uniform attention, which hides indexing bugs)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    sd["time_emb.weight"] = torch.from_numpy(rng.standard_normal((steps, 32)).astype(np.float32))
+    _linear(rng, sd, "pos_mlp.0", c_in, 16)
+    _linear(rng, sd, "pos_mlp.2", 16, 32)
+    _linear(rng, sd, "mlp.0", D, hidden)
+    _linear(rng, sd, "mlp.2", hidden, D)
+    dims = [D] + [32 * heads] * (n_layers - 1)
+    outs = [32 * heads] * (n_layers - 1) + [heads * (D // heads)]
+    for l in range(n_layers):
+        p = f"gnn_backbone.module_list.{l}."
+        _linear(rng, sd, p + "lin_key", dims[l], outs[l], qk_gain)
+        _linear(rng, sd, p + "lin_query", dims[l], outs[l], qk_gain)
+        _linear(rng, sd, p + "lin_value", dims[l], outs[l])
+        _linear(rng, sd, p + "lin_skip", dims[l], outs[l])
+    if arch == "exophormer" and virt_nodes > 0:
+        sd["gnn_backbone.virt_node_embedding.weight"] = torch.from_numpy(
+            rng.standard_normal((virt_nodes, D)).astype(np.float32))
+    if variant == "2d":
+        _linear(rng, sd, "final_mlp.0", D, 32)
+        _linear(rng, sd, "final_mlp.2", 32, c_out)
+    else:
+        _linear(rng, sd, "mlp_t.0", D, 256)
+        _linear(rng, sd, "mlp_t.2", 256, 3)
+        _linear(rng, sd, "mlp_r.0", D, 256)
+        _linear(rng, sd, "mlp_r.2", 256, 3)
+    return sd
+
+
+# ------------------------------------------------------------------------- graphs
+def dense_edge_index(n, self_loops=True):
+    """pyg.utils.dense_to_sparse(ones(n, n)) order (puzzle_dataset.py:609-614): row-major
+    nonzero, edge_index[0] = row, [1] = col.  ``self_loops=False`` is the K_n the
+    non-rotation dataset builds (puzzle_dataset.py:47-64 via generate_random_expander
+    with degree >= n-1... `num_nodes <= 10` branch and the roll construction never emit
+    i == j)."""
+    r = torch.arange(n).repeat_interleave(n)
+    c = torch.arange(n).repeat(n)
+    if not self_loops:
+        m = r != c
+        r, c = r[m], c[m]
+    return torch.stack([r, c])
+
+
+def random_regular_edge_index(n, degree, rng):
+    """generate_random_regular_graph, puzzle_dataset.py:115-152, restated: a random
+    permutation rolled 1..degree//2 (+ a perfect matching when degree is odd),
+    symmetrised.  Returns int64 [2, n*degree] with row 0 = senders, row 1 = receivers."""
+    if (n * degree) % 2 != 0:
+        raise TypeError("nodes * degree must be even")
+    nodes = rng.permutation(np.arange(n))
+    reps = degree // 2
+    ns = np.hstack([np.roll(nodes, i + 1) for i in range(reps)]) if reps else np.zeros(0, np.int64)
+    ei = np.vstack((np.tile(nodes, reps), ns))
+    if degree % 2 == 1:
+        ei = np.hstack((ei, np.vstack((nodes[: n // 2], nodes[n // 2:]))))
+    s = np.concatenate([ei[0], ei[1]])
+    r = np.concatenate([ei[1], ei[0]])
+    return torch.from_numpy(np.stack([s, r]).astype(np.int64))
+
+
+def collate(edge_indices, sizes):
+    """PyG Batch collation of per-graph edge_index + the ``batch`` vector."""
+    off, eis, batch = 0, [], []
+    for g, (ei, n) in enumerate(zip(edge_indices, sizes)):
+        eis.append(ei + off)
+        batch.append(torch.full((n,), g, dtype=torch.long))
+        off += n
+    return torch.cat(eis, 1), torch.cat(batch)
+
+
+# ------------------------------------------------------------------------- inputs
+def make_inputs(n_nodes, c_in, feat_dim, seed=0, rot=None):
+    """Synthetic puzzle: piece features ~ N(0,1) [N, feat_dim], x_T ~ N(0,1) [N, c_in]
+    (no datasets; encoder bypassed)."""
+    rng = np.random.default_rng(seed + 1_000_003)
+    feats = torch.from_numpy(rng.standard_normal((n_nodes, feat_dim)).astype(np.float32))
+    x = torch.from_numpy(rng.standard_normal((n_nodes, c_in)).astype(np.float32))
+    return x, feats
+
+
+def randn(shape, seed):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))

@@ -1,0 +1,209 @@
+"""The CPU oracle against the fixtures produced from the reference's own glue code
+(tests/golden/make_golden.py) and against independent cross-checks at the PyG boundary.
+CPU-only; fp32; tolerances written per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases as C
+from oracle import denoiser as D
+from oracle import diffusion as DF
+from oracle import pyg_restatement as R
+from oracle import so3
+from oracle import weights as W
+
+RTOL = 1e-4     # north star: 1e-4 relative fp32
+
+
+def rel_err(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def stats(t):
+    t = t.double()
+    return torch.stack([t.sum(), t.abs().sum(), (t * t).sum()]).float()
+
+
+# ------------------------------------------------------------------ PyG boundary (unpinned)
+@pytest.mark.parametrize("n,H,C", [(36, 8, 32), (50, 8, 144)])
+def test_transformer_conv_equals_sdpa_on_complete_graph(n, H, C):
+    """On a complete graph with self loops TransformerConv == softmax(QK^T/sqrt(C))V + skip."""
+    torch.manual_seed(0)
+    Din = 64
+    x = torch.randn(n, Din)
+    ws = [torch.randn(H * C, Din) / math.sqrt(Din) for _ in range(4)]
+    bs = [torch.randn(H * C) * 0.1 for _ in range(4)]
+    ei = W.dense_edge_index(n, True)
+    out, alpha = R.transformer_conv(x, ei, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], ws[3], bs[3], H)
+    q = F.linear(x, ws[0], bs[0]).view(n, H, C).transpose(0, 1)
+    k = F.linear(x, ws[1], bs[1]).view(n, H, C).transpose(0, 1)
+    v = F.linear(x, ws[2], bs[2]).view(n, H, C).transpose(0, 1)
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(0, 1).reshape(n, H * C) + F.linear(x, ws[3], bs[3])
+    assert rel_err(out, ref) < 1e-5
+    # alpha rows sum to one per target node and head
+    s = torch.zeros(n, H).index_add_(0, ei[1], alpha)
+    assert torch.allclose(s, torch.ones(n, H), atol=1e-5)
+
+
+def test_segment_softmax_multi_edges_and_isolated_nodes():
+    src = torch.tensor([[0.0], [0.0], [1.0], [5.0]])
+    index = torch.tensor([0, 0, 0, 2])                   # node 1 has no incoming edge
+    a = R.segment_softmax(src, index, 3)
+    e = math.e
+    assert torch.allclose(a[:3, 0], torch.tensor([1, 1, e]) / (2 + e), atol=1e-6)
+    assert abs(float(a[3, 0]) - 1.0) < 1e-6
+
+
+def test_quaternion_roundtrip():
+    torch.manual_seed(1)
+    q = F.normalize(torch.randn(64, 4), dim=-1)
+    m = R.quaternion_to_matrix(q)
+    q2 = R.matrix_to_quaternion(m)
+    assert torch.allclose(R.standardize_quaternion(q), q2, atol=1e-5)
+    assert torch.allclose(m @ m.transpose(-1, -2), torch.eye(3).expand(64, 3, 3), atol=1e-5)
+
+
+def test_so3_scale_is_matrix_power():
+    torch.manual_seed(2)
+    r = so3.skew_to_rmat(torch.randn(16, 3) * 0.7)
+    half = so3.so3_scale(r, torch.full((16,), 0.5))
+    assert torch.allclose(half @ half, r, atol=1e-5)
+    assert torch.allclose(so3.so3_scale(r, torch.ones(16)), r, atol=1e-5)
+
+
+# ------------------------------------------------------------------ schedules (a-1)
+@pytest.mark.parametrize("T", C.SCHEDULE_T)
+def test_schedule_buffers_bit_exact(golden, T):
+    sch = DF.make_schedule(T)
+    for k, v in sch.items():
+        ref = golden[f"schedule_T{T}/{k}"]
+        assert np.array_equal(v.numpy(), ref), k
+
+
+# ------------------------------------------------------------------ 2D forward (a-3..a-8)
+@pytest.mark.parametrize("spec", C.FWD2D, ids=lambda s: s["name"])
+def test_forward_2d_matches_reference(golden, spec):
+    case = C.build_case(spec)
+    acts = []
+    out, att = D.eff_gat_forward_with_feats(
+        case["sd"], case["x"], case["t"], case["edge_index"], case["feats"], case["batch"],
+        spec["arch"], spec["V"], collect=acts)
+    n = spec["name"]
+    assert rel_err(out, golden[f"{n}/out"]) < RTOL
+    assert len(att) == int(golden[f"{n}/n_att"])
+    ei, alpha = att[-1]
+    assert list(ei.shape) == list(golden[f"{n}/ei_last_shape"])
+    assert np.array_equal(ei[:, -4096:].numpy(), golden[f"{n}/ei_last_tail"])
+    chk = [int(ei[0].sum()), int(ei[1].sum()), int((ei[0] * 7 + ei[1] * 13).remainder(1000003).sum())]
+    assert chk == list(golden[f"{n}/ei_last_checksum"])
+    assert rel_err(alpha[:256], golden[f"{n}/alpha_last_head"]) < RTOL
+    assert rel_err(alpha[-256:], golden[f"{n}/alpha_last_tail"]) < RTOL
+    assert rel_err(stats(alpha), golden[f"{n}/alpha_last_stats"]) < RTOL
+    for i, a in enumerate(acts):
+        assert rel_err(stats(a), golden[f"{n}/act{i}_stats"]) < RTOL, i
+        assert rel_err(a[:: max(1, a.shape[0] // 8), :64], golden[f"{n}/act{i}_rows"]) < RTOL, i
+
+
+# ------------------------------------------------------------------ 2D loops (a-9..a-11)
+@pytest.mark.parametrize("lp", C.LOOPS2D, ids=lambda s: s["name"])
+def test_ddim_trajectory_matches_reference(golden, lp):
+    spec = C.by_name(lp["base"])
+    case = C.build_case(spec)
+    sch = DF.make_schedule(lp["T"])
+    x0 = torch.from_numpy(golden[f"{lp['name']}/x_init"])
+    imgs, _ = DF.p_sample_loop(case["sd"], sch, x0, case["edge_index"], case["feats"], case["batch"],
+                               lp["T"], lp["ratio"], lp["mean"], spec["arch"], spec["V"],
+                               max_iters=lp.get("max_iters"))
+    ref = golden[f"{lp['name']}/imgs"]
+    assert len(imgs) == ref.shape[0]
+    # trajectories compound rounding differences; 5e-4 on the whole trajectory
+    assert rel_err(torch.stack(imgs), ref) < 5e-4
+    assert rel_err(imgs[0], ref[0]) < RTOL
+
+
+def test_ddpm_direct_and_loop_failure_mode(golden):
+    spec = C.by_name("k36_noloop_eps")
+    case = C.build_case(spec)
+    sch = DF.make_schedule(spec["steps"])
+    t = torch.full((36,), 17, dtype=torch.long)
+    out, _ = D.eff_gat_forward_with_feats(case["sd"], case["x"], t, case["edge_index"],
+                                          case["feats"], case["batch"])
+    noise = torch.from_numpy(golden["ddpm_direct/noise"])
+    y = DF.ddpm_update(sch, case["x"], t, 17, out, noise)
+    assert rel_err(y, golden["ddpm_direct/out_t17"]) < RTOL
+    out0, _ = D.eff_gat_forward_with_feats(case["sd"], case["x"], t * 0, case["edge_index"],
+                                           case["feats"], case["batch"])
+    y0 = DF.ddpm_update(sch, case["x"], t * 0, 0, out0, None)
+    assert rel_err(y0, golden["ddpm_direct/out_t0"]) < RTOL
+    # the reference's own loop cannot run DDPM (spatial_diffusion.py:504-510 vs :663)
+    assert "too many values to unpack" in str(golden["ddpm_direct/loop_raises"])
+
+
+def test_classifier_free_branch(golden):
+    spec = C.by_name("k36_loop_sharp")
+    case = C.build_case(spec)
+    sch = DF.make_schedule(spec["steps"])
+    t = torch.full((36,), 30, dtype=torch.long)
+    c, _ = D.eff_gat_forward_with_feats(case["sd"], case["x"], t, case["edge_index"], case["feats"], case["batch"])
+    u, _ = D.eff_gat_forward_with_feats(case["sd"], case["x"], t, case["edge_index"],
+                                        torch.zeros_like(case["feats"]), case["batch"])
+    y = DF.ddim_update(sch, case["x"], t, 1.5 * c - 0.5 * u, 1, "START_X")
+    assert rel_err(y, golden["cfg_ddim/out_t30"]) < RTOL
+
+
+# ------------------------------------------------------------------ 3D (a-13, a-14)
+@pytest.mark.parametrize("spec", C.FWD3D, ids=lambda s: s["name"])
+def test_forward_3d_matches_reference(golden, spec):
+    case = C.build_case(spec, "3d")
+    acts = []
+    out, att = D.eff_gat_3d_forward_with_feats(
+        case["sd"], case["x"], case["t"], case["edge_index"], case["feats"], case["batch"],
+        spec["arch"], spec["V"], collect=acts)
+    n = spec["name"]
+    assert rel_err(out, golden[f"{n}/out"]) < RTOL
+    assert rel_err(stats(att[-1][1]), golden[f"{n}/alpha_last_stats"]) < RTOL
+    for i in range(5):
+        assert rel_err(stats(acts[i]), golden[f"{n}/act{i}_stats"]) < RTOL, i
+
+
+@pytest.mark.parametrize("lp", C.LOOPS3D, ids=lambda s: s["name"])
+def test_ddim_3d_trajectory_matches_reference(golden, lp):
+    spec = C.by_name(lp["base"])
+    case = C.build_case(spec, "3d")
+    sch = DF.make_schedule(lp["T"])
+    x0 = torch.from_numpy(golden[f"{lp['name']}/x_init"])
+    imgs, _ = DF.p_sample_loop_3d(case["sd"], sch, x0, case["edge_index"], case["feats"], case["batch"],
+                                  lp["T"], lp["ratio"], lp["mean"], max_iters=lp["max_iters"])
+    ref = torch.from_numpy(golden[f"{lp['name']}/imgs"])
+    got = torch.stack(imgs)
+    assert rel_err(got[..., 4:], ref[..., 4:]) < 5e-4
+    # rotations compared modulo q == -q (pytorch3d sign convention is version dependent)
+    dq = torch.minimum((got[..., :4] - ref[..., :4]).abs().amax(-1), (got[..., :4] + ref[..., :4]).abs().amax(-1))
+    assert float(dq.max()) < 5e-4
+
+
+# ------------------------------------------------------------------ training (a-12)
+@pytest.mark.parametrize("tr", C.TRAIN2D, ids=lambda s: s["name"])
+def test_p_losses_and_gradients_match_reference(golden, tr):
+    spec = C.by_name(tr["base"])
+    case = C.build_case(spec)
+    sd = {k: v.clone().requires_grad_(True) for k, v in case["sd"].items()}
+    sch = DF.make_schedule(spec["steps"])
+    rng = np.random.default_rng(tr["seed"])
+    noise = torch.from_numpy(rng.standard_normal(tuple(case["x"].shape)).astype(np.float32))
+    loss = DF.p_losses(sd, sch, case["x"], case["t"], noise, case["edge_index"], case["feats"],
+                       case["batch"], tr["mean"], spec["arch"], spec["V"])
+    loss.backward()
+    assert rel_err(loss.detach(), golden[f"{tr['name']}/loss"]) < 1e-5
+    n = 0
+    for k, p in sd.items():
+        key = f"{tr['name']}/grad_head/{k}"
+        if key in golden.files:
+            assert rel_err(p.grad.flatten()[:64], golden[key]) < 1e-3, k
+            assert rel_err(stats(p.grad), golden[f"{tr['name']}/grad_stats/{k}"]) < 1e-3, k
+            n += 1
+    assert n >= 28
