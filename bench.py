@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoising steps/sec on 900-piece dense puzzles, T = 100 (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one p_sample_ddim call of the reference (spatial_diffusion.py:548-627): one denoiser
+forward over the whole batch + the DDIM pose update.  Every rank holds its own batch of
+``--puzzles`` independent 30x30 puzzles (N = 900 pieces, E = 810 000 edges each, dense with self
+loops: BASELINE config 3'); puzzles shard across GPUs with NO data-path collective (weak scaling,
+SURVEY 8e).  Inputs (piece features, x_T, weights) are synthetic, seeded, and resident in HBM
+before the timed region.  The K timed steps are consecutive iterations of the T = 100 DDIM loop,
+replayed as hipGraph launches; timing is barrier + synchronize on both sides, MAX over ranks.
+
+value = puzzle-level denoising steps per second over the whole job
+      = n_gpus * puzzles_per_gpu * K / seconds          (also reported: batch steps/s, ms/step).
+
+roofline: per-kernel-class time is measured live with HIP events on the launch stream
+(da_profile_*), in a separate eager pass over the same steps; the dominant kernel is the
+last-layer graph attention (C = 144, 60 % of the attention FLOPs).
+cpu_baseline: the CPU oracle (pure-torch fp32 restatement of the reference, oracle/) timed on
+this box's host cores on ONE puzzle for ONE step (~15-30 s of CPU work) -- baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+N_PIECES, T_STEPS = 900, 100
+F_NODE = 6_432_128          # FLOP per piece per step (SURVEY 8d / BASELINE.md)
+F_EDGE = 7_680              # FLOP per edge per step, all 4 layers
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def dense_batch(G, n, device):
+    """edge_index / batch of G complete graphs with self loops, built on the device."""
+    r = torch.arange(n, device=device).repeat_interleave(n)
+    c = torch.arange(n, device=device).repeat(n)
+    one = torch.stack([r, c])
+    ei = torch.cat([one + g * n for g in range(G)], 1)
+    batch = torch.arange(G, device=device).repeat_interleave(n)
+    return ei, batch
+
+
+def cpu_baseline(sd, seed, threads):
+    from oracle import diffusion as ODF
+    from oracle import weights as W
+    torch.set_num_threads(threads)
+    x, feats = W.make_inputs(N_PIECES, 4, 1088, seed)
+    ei, batch = W.collate([W.dense_edge_index(N_PIECES, True)], [N_PIECES])
+    sch = ODF.make_schedule(T_STEPS)
+    t0 = time.perf_counter()
+    ODF.p_sample_loop(sd, sch, x, ei, feats, batch, T_STEPS, 1, "START_X", max_iters=1)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "puzzle-steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 DDIM step of 1 puzzle (N=900, E=810000), oracle/ torch fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--puzzles", type=int, default=int(os.environ.get("BENCH_PUZZLES", 8)),
+                    help="independent 900-piece puzzles per GPU (the batch of one step)")
+    ap.add_argument("--precision", default=os.environ.get("BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        assert world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from diffassemble_amd import DenoiserEngine, Schedule, _lib
+    from oracle import diffusion as ODF          # schedule tables only (host constants)
+    from oracle import weights as W
+
+    G, K, Wm = args.puzzles, args.steps, args.warmup
+    sd = W.make_denoiser_state(T_STEPS, 4, 4, seed=0)
+    eng = DenoiserEngine(sd, variant="2d", arch="transformer", precision=args.precision, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    feats = torch.randn((G * N_PIECES, 1088), generator=gen, device=dev)
+    x_T = torch.randn((G * N_PIECES, 4), generator=gen, device=dev)
+    ei, batch = dense_batch(G, N_PIECES, dev)
+    plan = eng.plan(ei, batch)
+    del ei
+    sch = Schedule(ODF.make_schedule(T_STEPS), dev)
+    mt = _lib.MEAN_START_X
+
+    def run(n_iters, graph):
+        return eng.sample_loop(plan, sch, x_T, feats, ratio=1, mean_type=mt, max_iters=n_iters,
+                               keep_trajectory=False, use_graph=graph, restage=False)
+
+    eng.set_features(plan, feats)
+    chunks = [T_STEPS] * (K // T_STEPS) + ([K % T_STEPS] if K % T_STEPS else [])
+    if Wm > 0:
+        run(min(Wm, T_STEPS), False)                       # W untimed eager steps
+    for c in sorted(set(chunks)):
+        run(c, True)                                       # capture + instantiate (+ one untimed replay)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in chunks:
+        _, x_final = run(c, True)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    assert torch.isfinite(x_final).all(), "non-finite poses"
+
+    roof = None
+    kernels = None
+    if not args.no_roofline:
+        eng.profile(True)
+        kp = min(K, 20)
+        run(kp, False)
+        prof = eng.profile_read()
+        eng.profile(False)
+        kernels = {k: {"ms_per_launch": (ms / n if n else 0.0), "launches_per_step": n / kp} for k, (ms, n) in prof.items()}
+        ms_last, n_last = prof["attn_last"]
+        flop_last = G * N_PIECES * N_PIECES * 4 * 1152             # QK^T + PV, mul+add, C*H = 1152
+        ach = flop_last / (ms_last / n_last * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        roof = {"bound": "mfma", "kernel": "attn_last (graph attention, conv 3, C=144)", "achieved": ach,
+                "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "flop_per_launch": flop_last, "avg_launch_ms": ms_last / n_last}
+        ms_all = sum(ms for ms, _ in prof.values()) / kp
+        flop_step = G * (N_PIECES * F_NODE + N_PIECES * N_PIECES * F_EDGE)
+        roof["whole_step_tflops_in_kernels"] = flop_step / (ms_all * 1e-3) / 1e12
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(sd, 1234, os.cpu_count() or 1)
+        value = world * G * K / dt
+        line = {
+            "metric": "denoising steps/sec (900-piece dense graph, T=100)",
+            "value": value, "unit": "puzzle-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "30x30 dense puzzle (N=900, E=810000 incl. self loops), DDIM eta=0, T=100, "
+                                   "START_X, rot+trans c=4, transformer arch",
+                       "puzzles_per_gpu": G, "global_puzzles": world * G, "parallelism": f"puzzle-sharded x{world}",
+                       "loop": "hipGraph replay"},
+            "batch_steps_per_s": world * K / dt,
+            "algorithmic_tflops": world * G * (N_PIECES * F_NODE + N_PIECES ** 2 * F_EDGE) * K / dt / 1e12,
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

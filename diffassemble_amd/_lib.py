@@ -1,0 +1,120 @@
+"""ctypes binding of libdiffassemble_hip.so (C ABI: include/diffassemble_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, every
+operator raises.  ``import torch`` happens first on purpose -- PyTorch-ROCm bundles its own
+libamdhip64 (SONAME libamdhip64.so.7); loading ours afterwards makes the dynamic loader
+bind our DT_NEEDED entry to that already-loaded runtime, so streams and device pointers are
+shared with torch instead of living in a second HIP runtime.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
+DA_MAX_LAYERS = 8
+PREC_F32, PREC_BF16 = 0, 1
+VARIANT_2D, VARIANT_3D = 0, 1
+ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
+MEAN_EPSILON, MEAN_START_X = 0, 1
+ACT_NONE, ACT_GELU, ACT_LEAKY02 = 0, 1, 2
+PROF_CLASSES = ("embed", "linear_mlp", "linear_qkvs", "attn_hidden", "attn_last", "head", "update")
+
+_fp = C.c_void_p        # device pointers travel as integers
+_FPL = _fp * DA_MAX_LAYERS
+
+
+class DaWeights(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int32), ("arch", C.c_int32), ("steps", C.c_int32), ("c_in", C.c_int32),
+        ("c_out", C.c_int32), ("feat_dim", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32),
+        ("n_layers", C.c_int32), ("virt_nodes", C.c_int32),
+        ("time_emb", _fp),
+        ("pos_w0", _fp), ("pos_b0", _fp), ("pos_w1", _fp), ("pos_b1", _fp),
+        ("mlp_w0", _fp), ("mlp_b0", _fp), ("mlp_w1", _fp), ("mlp_b1", _fp),
+        ("conv_wq", _FPL), ("conv_bq", _FPL), ("conv_wk", _FPL), ("conv_bk", _FPL),
+        ("conv_wv", _FPL), ("conv_bv", _FPL), ("conv_ws", _FPL), ("conv_bs", _FPL),
+        ("virt_emb", _fp),
+        ("head_w0", _fp), ("head_b0", _fp), ("head_w1", _fp), ("head_b1", _fp),
+        ("head_r_w0", _fp), ("head_r_b0", _fp), ("head_r_w1", _fp), ("head_r_b1", _fp),
+    ]
+
+
+class DaGraph(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("n_real", C.c_int32), ("n_graphs", C.c_int32), ("dense", C.c_int32),
+        ("n_edges", C.c_int64),
+        ("row_ptr", _fp), ("col_src", _fp), ("edge_id", _fp), ("graph_ptr", _fp),
+        ("max_graph_nodes", C.c_int32),
+    ]
+
+
+class DaSchedule(C.Structure):
+    _fields_ = [
+        ("steps", C.c_int32),
+        ("betas", _fp), ("alphas_cumprod", _fp), ("sqrt_recip_alphas", _fp),
+        ("sqrt_recip_alphas_cumprod", _fp), ("sqrt_recipm1_alphas_cumprod", _fp),
+        ("sqrt_one_minus_alphas_cumprod", _fp), ("posterior_variance", _fp),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/diffassemble_hip.h declares
+PROTOTYPES = {
+    "da_abi_version": (C.c_int, []),
+    "da_last_error": (C.c_char_p, []),
+    "da_denoiser_create": (C.c_int, [C.POINTER(DaWeights), C.c_int, _fp, C.POINTER(_fp)]),
+    "da_denoiser_destroy": (None, [_fp]),
+    "da_denoiser_workspace_bytes": (C.c_size_t, [_fp, C.POINTER(DaGraph)]),
+    "da_denoiser_set_features": (C.c_int, [_fp, C.POINTER(DaGraph), _fp, _fp, C.c_size_t, _fp]),
+    "da_denoiser_forward": (C.c_int, [_fp, C.POINTER(DaGraph), _fp, _fp, C.c_int64, _fp, _fp, C.c_int, _fp, _fp,
+                                      C.c_size_t, _fp]),
+    "da_ddim_step": (C.c_int, [C.POINTER(DaSchedule), C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp,
+                               C.c_int64, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp]),
+    "da_ddpm_step": (C.c_int, [C.POINTER(DaSchedule), C.c_int, C.c_int, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp]),
+    "da_sample_loop": (C.c_int, [_fp, C.POINTER(DaGraph), C.POINTER(DaSchedule), C.c_int, C.c_int, C.c_int,
+                                 _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
+    "da_profile_enable": (C.c_int, [_fp, C.c_int]),
+    "da_profile_read": (C.c_int, [_fp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "da_linear": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp,
+                            C.c_int, _fp]),
+    "da_attn_csr": (C.c_int, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp, _fp]),
+}
+
+_lib = None
+
+
+class DaError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DaError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  diffassemble_amd has no CPU / eager fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        if h.da_abi_version() != 1:
+            raise DaError(f"ABI mismatch: library reports {h.da_abi_version()}")
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise DaError(f"libdiffassemble_hip error {rc}: {lib().da_last_error().decode(errors='replace')}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

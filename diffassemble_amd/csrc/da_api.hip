@@ -1,0 +1,447 @@
+// C-ABI entry points of libdiffassemble_hip.so (include/diffassemble_hip.h).
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "da_common.h"
+#include "da_internal.h"
+
+namespace da {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct ConvW {
+    void *w = nullptr;     // [4*HC, Din] act dtype, rows = Q | K | V | skip
+    float *b = nullptr;    // [4*HC] fp32
+    int din = 0, hc = 0, C = 0;
+};
+
+struct LoopKey {
+    da_graph g;
+    da_schedule s;
+    int mean_type, ratio, max_iters;
+    const float *x_init;
+    float *traj, *x_final;
+    void *ws;
+    size_t ws_bytes;
+};
+
+}  // namespace da
+
+using namespace da;
+
+struct da_denoiser {
+    int prec = 0, variant = 0, arch = 0, steps = 0, c_in = 0, c_out = 0, F = 0, D = 0, hidden = 0, heads = 0,
+        n_layers = 0, V = 0, head_hidden = 0;
+    float *time_emb = nullptr, *pos_w0 = nullptr, *pos_b0 = nullptr, *pos_w1 = nullptr, *pos_b1 = nullptr;
+    void *mlp_w0 = nullptr, *mlp_w1 = nullptr;
+    float *mlp_b0 = nullptr, *mlp_b1 = nullptr;
+    ConvW conv[DA_MAX_LAYERS];
+    void *virt_emb = nullptr;
+    void *head_w0 = nullptr;
+    float *head_b0 = nullptr;
+    float *head_w1 = nullptr, *head_b1 = nullptr, *head_r_w1 = nullptr, *head_r_b1 = nullptr;
+    std::vector<void *> owned;
+    // optional per-kernel-class timing with HIP events (da_profile_*)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;      // pairs (start, stop)
+    std::vector<int> prof_cls;
+    size_t prof_used = 0;
+    // cached sampling-loop graphs (a few distinct loops, e.g. a full loop and a remainder)
+    struct LoopEntry { LoopKey key; hipGraphExec_t exec; };
+    std::vector<LoopEntry> loops;
+};
+
+namespace da {
+
+struct Workspace {
+    char *comb_in, *h, *combined, *qkvs, *xa, *xb, *z, *hh;
+    float *model_out, *xbuf0, *xbuf1;
+    size_t total;
+};
+
+static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
+    const size_t s = esize(d->prec);
+    const size_t n = (size_t)g->n_nodes, nr = (size_t)g->n_real;
+    const size_t nrp = nr + 64, np = n + 64;          // slack rows so tile kernels may over-read
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *q = p ? p + off : nullptr;
+        off += align_up(bytes, 256);
+        return q;
+    };
+    Workspace w;
+    int hcmax = 0;
+    for (int l = 0; l < d->n_layers; ++l) hcmax = d->conv[l].hc > hcmax ? d->conv[l].hc : hcmax;
+    w.comb_in = take(nrp * d->D * s);
+    w.h = take(nrp * d->hidden * s);
+    w.combined = take(np * d->D * s);
+    w.qkvs = take(np * 4 * (size_t)hcmax * s);
+    w.xa = take(np * 256 * s);
+    w.xb = take(np * 256 * s);
+    w.z = take(np * d->D * s);
+    w.hh = take(nrp * d->head_hidden * s);
+    const int cpose = d->variant == DA_VARIANT_3D ? 7 : d->c_out;
+    w.model_out = (float *)take(nr * cpose * sizeof(float));
+    w.xbuf0 = (float *)take(nr * 8 * sizeof(float));
+    w.xbuf1 = (float *)take(nr * 8 * sizeof(float));
+    w.total = off;
+    return w;
+}
+
+int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, int act,
+           const void *res, void *out, int ldo, hipStream_t st) {
+    return launch_gemm_simple(prec, M, K, Nout, A, lda, W, bias, act, res, out, ldo, st);
+}
+
+static int check_graph(const da_denoiser *d, const da_graph *g) {
+    DA_REQUIRE(g && g->n_real > 0 && g->n_nodes >= g->n_real, "da_graph: bad node counts");
+    DA_REQUIRE(g->row_ptr && (g->col_src || g->n_edges == 0), "da_graph: CSR arrays missing");
+    DA_REQUIRE(d->V == 0 || g->n_nodes == g->n_real + d->V * g->n_graphs,
+               "da_graph: exophormer expects n_nodes = n_real + V*G (%d vs %d + %d*%d)", g->n_nodes, g->n_real,
+               d->V, g->n_graphs);
+    return 0;
+}
+
+static DeviceSchedule to_dev(const da_schedule *s) {
+    DeviceSchedule r;
+    r.steps = s->steps;
+    r.betas = s->betas;
+    r.alphas_cumprod = s->alphas_cumprod;
+    r.sqrt_recip_alphas = s->sqrt_recip_alphas;
+    r.sqrt_recip_alphas_cumprod = s->sqrt_recip_alphas_cumprod;
+    r.sqrt_recipm1_alphas_cumprod = s->sqrt_recipm1_alphas_cumprod;
+    r.sqrt_one_minus_alphas_cumprod = s->sqrt_one_minus_alphas_cumprod;
+    r.posterior_variance = s->posterior_variance;
+    return r;
+}
+
+// Bracket one launch with a (start, stop) event pair on the launch stream when profiling.
+template <typename F>
+static int timed(da_denoiser *d, int cls, hipStream_t st, F &&launch) {
+    if (!d->prof_on) return launch();
+    if (d->prof_used + 2 > d->prof_ev.size()) {
+        for (int k = 0; k < 2; ++k) {
+            hipEvent_t e;
+            DA_CHECK_HIP(hipEventCreate(&e));
+            d->prof_ev.push_back(e);
+        }
+    }
+    hipEvent_t a = d->prof_ev[d->prof_used], b = d->prof_ev[d->prof_used + 1];
+    DA_CHECK_HIP(hipEventRecord(a, st));
+    int rc = launch();
+    DA_CHECK_HIP(hipEventRecord(b, st));
+    d->prof_used += 2;
+    d->prof_cls.push_back(cls);
+    return rc;
+}
+
+static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const int64_t *t, int64_t t_scalar,
+                        float *out, float *alpha, int alpha_all, float *pre_head, const Workspace &w,
+                        hipStream_t st) {
+    const int prec = d->prec, nr = g->n_real, n = g->n_nodes, D = d->D;
+    int rc;
+    // (a-3) embedding: pose MLP + learned timestep lookup into the concat buffer, then mlp
+    if ((rc = timed(d, DA_PROF_EMBED, st, [&] {
+             return launch_embed_pos_time(prec, nr, d->c_in, d->F, D, x, t, t_scalar, d->steps, d->time_emb,
+                                          d->pos_w0, d->pos_b0, d->pos_w1, d->pos_b1, w.comb_in, st); }))) return rc;
+    const int act1 = d->variant == DA_VARIANT_3D ? DA_ACT_LEAKY02 : DA_ACT_GELU;
+    const int act2 = d->variant == DA_VARIANT_3D ? DA_ACT_LEAKY02 : DA_ACT_NONE;
+    if ((rc = timed(d, DA_PROF_LINEAR_MLP, st, [&] {
+             return linear(prec, nr, D, d->hidden, w.comb_in, D, d->mlp_w0, d->mlp_b0, act1, nullptr, w.h, d->hidden, st); }))) return rc;
+    if ((rc = timed(d, DA_PROF_LINEAR_MLP, st, [&] {
+             return linear(prec, nr, d->hidden, D, w.h, d->hidden, d->mlp_w1, d->mlp_b1, act2, nullptr, w.combined, D, st); }))) return rc;
+    // (a-4..a-6) graph transformer: fused Q|K|V|skip projection + attention per layer
+    const void *xin = w.combined;
+    int ldx = D;
+    for (int l = 0; l < d->n_layers; ++l) {
+        const ConvW &c = d->conv[l];
+        const bool last = l == d->n_layers - 1;
+        if ((rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
+                 return linear(prec, n, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, w.qkvs, 4 * c.hc, st); }))) return rc;
+        void *dst = last ? (void *)w.z : (void *)((l & 1) ? w.xb : w.xa);
+        const int act = (!last && d->arch == DA_ARCH_TRANSFORMER) ? DA_ACT_GELU : DA_ACT_NONE;
+        // last layer: the residual `feats + combined_feats` (efficient_gat.py:144) is fused here
+        float *al = !alpha ? nullptr
+                           : (alpha_all ? alpha + (size_t)l * g->n_edges * d->heads : (last ? alpha : nullptr));
+        if ((rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
+                 return launch_attn_csr(prec, n, g->row_ptr, g->col_src, g->edge_id, d->heads, c.C, w.qkvs,
+                                        last ? w.combined : nullptr, act, dst, al, st); }))) return rc;
+        xin = dst;
+        ldx = c.hc;
+    }
+    // (a-7 / a-13) pose head
+    if ((rc = timed(d, DA_PROF_HEAD, st, [&] {
+             return linear(prec, nr, D, d->head_hidden, w.z, D, d->head_w0, d->head_b0, DA_ACT_GELU, nullptr, w.hh,
+                           d->head_hidden, st); }))) return rc;
+    return timed(d, DA_PROF_HEAD, st, [&] {
+        if (d->variant == DA_VARIANT_3D)
+            return launch_head3d(prec, nr, w.hh, d->head_w1, d->head_b1, d->head_r_w1, d->head_r_b1, out, pre_head, st);
+        return launch_head2d(prec, nr, d->c_out, w.hh, d->head_w1, d->head_b1, out, st);
+    });
+}
+
+}  // namespace da
+
+extern "C" {
+
+int da_abi_version(void) { return DA_ABI_VERSION; }
+const char *da_last_error(void) { return da::g_err; }
+
+int da_denoiser_create(const da_weights *w, int precision, void *stream, da_denoiser **out) {
+    DA_REQUIRE(w && out, "da_denoiser_create: null argument");
+    DA_REQUIRE(precision == DA_PREC_F32 || precision == DA_PREC_BF16, "bad precision %d", precision);
+    DA_REQUIRE(w->n_layers >= 2 && w->n_layers <= DA_MAX_LAYERS, "n_layers out of range");
+    DA_REQUIRE(w->heads == 8, "heads must be 8");
+    hipStream_t st = (hipStream_t)stream;
+    da_denoiser *d = new da_denoiser();
+    d->prec = precision; d->variant = w->variant; d->arch = w->arch; d->steps = w->steps; d->c_in = w->c_in;
+    d->c_out = w->c_out; d->F = w->feat_dim; d->D = w->feat_dim + 64; d->hidden = w->hidden; d->heads = w->heads;
+    d->n_layers = w->n_layers; d->V = w->arch == DA_ARCH_EXOPHORMER ? w->virt_nodes : 0;
+    d->head_hidden = w->variant == DA_VARIANT_3D ? 512 : 32;
+    const int D = d->D, H = d->heads;
+    const size_t s = esize(precision);
+    int rc = 0;
+    auto fail = [&](int code) { da_denoiser_destroy(d); return code; };
+    auto alloc = [&](size_t bytes) -> void * {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes < 256 ? 256 : bytes) != hipSuccess) { set_error("hipMalloc(%zu) failed", bytes); return nullptr; }
+        d->owned.push_back(p);
+        return p;
+    };
+    auto copy_f32 = [&](const float *src, size_t n) -> float * {
+        float *p = (float *)alloc(n * 4);
+        if (!p || hipMemcpyAsync(p, src, n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = 2; return nullptr; }
+        return p;
+    };
+    auto pack = [&](const float *src, size_t n) -> void * {
+        void *p = alloc(n * s + 4096);       // slack: tile kernels may over-read a partial tile
+        if (!p || launch_convert(precision, n, src, p, st)) { rc = 2; return nullptr; }
+        return p;
+    };
+    d->time_emb = copy_f32(w->time_emb, (size_t)w->steps * 32);
+    d->pos_w0 = copy_f32(w->pos_w0, 16 * (size_t)w->c_in); d->pos_b0 = copy_f32(w->pos_b0, 16);
+    d->pos_w1 = copy_f32(w->pos_w1, 32 * 16); d->pos_b1 = copy_f32(w->pos_b1, 32);
+    d->mlp_w0 = pack(w->mlp_w0, (size_t)d->hidden * D); d->mlp_b0 = copy_f32(w->mlp_b0, d->hidden);
+    d->mlp_w1 = pack(w->mlp_w1, (size_t)D * d->hidden); d->mlp_b1 = copy_f32(w->mlp_b1, D);
+    if (rc) return fail(rc);
+    for (int l = 0; l < d->n_layers; ++l) {
+        ConvW &c = d->conv[l];
+        c.din = l == 0 ? D : 32 * H;
+        c.C = l == d->n_layers - 1 ? D / H : 32;
+        c.hc = c.C * H;
+        const size_t blk = (size_t)c.hc * c.din;
+        char *wp = (char *)alloc(4 * blk * s + 4096);
+        c.b = (float *)alloc(4 * (size_t)c.hc * 4);
+        if (!wp || !c.b) return fail(2);
+        c.w = wp;
+        const float *ws[4] = {w->conv_wq[l], w->conv_wk[l], w->conv_wv[l], w->conv_ws[l]};
+        const float *bs[4] = {w->conv_bq[l], w->conv_bk[l], w->conv_bv[l], w->conv_bs[l]};
+        for (int k = 0; k < 4; ++k) {
+            if (!ws[k] || !bs[k]) { set_error("conv %d: missing weight pointer", l); return fail(1); }
+            if (launch_convert(precision, blk, ws[k], wp + k * blk * s, st)) return fail(2);
+            if (hipMemcpyAsync(c.b + (size_t)k * c.hc, bs[k], (size_t)c.hc * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+        }
+    }
+    if (d->V > 0) {
+        if (!w->virt_emb) { set_error("exophormer: virt_emb missing"); return fail(1); }
+        d->virt_emb = pack(w->virt_emb, (size_t)d->V * D);
+    }
+    if (d->variant == DA_VARIANT_3D) {
+        char *hp = (char *)alloc(512 * (size_t)D * s + 4096);
+        d->head_b0 = (float *)alloc(512 * 4);
+        if (!hp || !d->head_b0) return fail(2);
+        d->head_w0 = hp;
+        if (launch_convert(precision, 256 * (size_t)D, w->head_w0, hp, st)) return fail(2);
+        if (launch_convert(precision, 256 * (size_t)D, w->head_r_w0, hp + 256 * (size_t)D * s, st)) return fail(2);
+        if (hipMemcpyAsync(d->head_b0, w->head_b0, 256 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+        if (hipMemcpyAsync(d->head_b0 + 256, w->head_r_b0, 256 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+        d->head_w1 = copy_f32(w->head_w1, 3 * 256); d->head_b1 = copy_f32(w->head_b1, 3);
+        d->head_r_w1 = copy_f32(w->head_r_w1, 3 * 256); d->head_r_b1 = copy_f32(w->head_r_b1, 3);
+    } else {
+        d->head_w0 = pack(w->head_w0, 32 * (size_t)D); d->head_b0 = copy_f32(w->head_b0, 32);
+        d->head_w1 = copy_f32(w->head_w1, (size_t)w->c_out * 32); d->head_b1 = copy_f32(w->head_b1, w->c_out);
+    }
+    if (rc) return fail(rc);
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("da_denoiser_create: sync failed"); return fail(2); }
+    *out = d;
+    return 0;
+}
+
+void da_denoiser_destroy(da_denoiser *d) {
+    if (!d) return;
+    for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);
+    for (auto &e : d->loops) (void)hipGraphExecDestroy(e.exec);
+    for (void *p : d->owned) (void)hipFree(p);
+    delete d;
+}
+
+size_t da_denoiser_workspace_bytes(const da_denoiser *d, const da_graph *g) {
+    if (!d || !g) return 0;
+    return da::carve(d, g, nullptr).total;
+}
+
+int da_denoiser_set_features(da_denoiser *d, const da_graph *g, const float *feats, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+    DA_REQUIRE(d && g && feats && workspace, "da_denoiser_set_features: null argument");
+    int rc = check_graph(d, g);
+    if (rc) return rc;
+    Workspace w = carve(d, g, workspace);
+    DA_REQUIRE(workspace_bytes >= w.total, "workspace too small: %zu < %zu", workspace_bytes, w.total);
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = launch_set_feats(d->prec, g->n_real, d->F, d->D, feats, w.comb_in, st))) return rc;
+    if (d->V > 0) {
+        char *dst = w.combined + (size_t)g->n_real * d->D * esize(d->prec);
+        if ((rc = launch_set_virtual_rows(d->prec, g->n_nodes - g->n_real, d->V, d->D, d->virt_emb, dst, st))) return rc;
+    }
+    return 0;
+}
+
+int da_denoiser_forward(da_denoiser *d, const da_graph *g, const float *x, const int64_t *t, int64_t t_scalar,
+                        float *out, float *alpha, int alpha_all_layers, float *pre_head, void *workspace,
+                        size_t workspace_bytes, void *stream) {
+    DA_REQUIRE(d && g && x && out && workspace, "da_denoiser_forward: null argument");
+    int rc = check_graph(d, g);
+    if (rc) return rc;
+    DA_REQUIRE(!alpha || g->edge_id, "alpha requested but graph has no edge_id");
+    Workspace w = carve(d, g, workspace);
+    DA_REQUIRE(workspace_bytes >= w.total, "workspace too small: %zu < %zu", workspace_bytes, w.total);
+    return forward_impl(d, g, x, t, t_scalar, out, alpha, alpha_all_layers, pre_head, w, (hipStream_t)stream);
+}
+
+int da_ddim_step(const da_schedule *s, int variant, int mean_type, int n, int c, const float *x,
+                 const float *model_out, const int64_t *t, int64_t t_scalar, int inference_ratio,
+                 int prev_all_nonneg, float eta, const float *noise, float *x_prev, void *stream) {
+    DA_REQUIRE(s && x && model_out && x_prev, "da_ddim_step: null argument");
+    DA_REQUIRE(eta == 0.f || noise, "da_ddim_step: eta > 0 needs noise");
+    if (variant == DA_VARIANT_3D) {
+        DA_REQUIRE(c == 7, "da_ddim_step(3D): c must be 7");
+        DA_REQUIRE(eta == 0.f, "da_ddim_step(3D): eta must be 0 (the reference binds DDIM only)");
+        return launch_ddim3d(to_dev(s), mean_type, n, x, model_out, t, t_scalar, inference_ratio, prev_all_nonneg,
+                             x_prev, (hipStream_t)stream);
+    }
+    return launch_ddim2d(to_dev(s), mean_type, n, c, x, model_out, t, t_scalar, inference_ratio, prev_all_nonneg, eta,
+                         noise, x_prev, (hipStream_t)stream);
+}
+
+int da_ddpm_step(const da_schedule *s, int n, int c, const float *x, const float *model_out, const int64_t *t,
+                 int64_t t_scalar, const float *noise, float *x_prev, void *stream) {
+    DA_REQUIRE(s && x && model_out && x_prev, "da_ddpm_step: null argument");
+    return launch_ddpm2d(to_dev(s), n, c, x, model_out, t, t_scalar, noise, x_prev, (hipStream_t)stream);
+}
+
+static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int mean_type, int ratio,
+                        int n_iters, const float *x_init, float *traj, float *x_final, const Workspace &w,
+                        hipStream_t st) {
+    const int nr = g->n_real;
+    const int c = d->variant == DA_VARIANT_3D ? 7 : d->c_in;
+    const size_t bytes = (size_t)nr * c * sizeof(float);
+    const DeviceSchedule ds = to_dev(s);
+    const float *cur = x_init;
+    int it = 0, rc;
+    const int first = ((s->steps - 1) / ratio) * ratio;            // reversed(range(0, steps, ratio))[0]
+    for (int i = first; i >= 0 && it < n_iters; i -= ratio, ++it) {
+        if ((rc = forward_impl(d, g, cur, nullptr, i, w.model_out, nullptr, 0, nullptr, w, st))) return rc;
+        float *nxt = traj ? traj + (size_t)it * nr * c : ((it & 1) ? w.xbuf1 : w.xbuf0);
+        const int nonneg = (i - ratio) >= 0;
+        rc = timed(d, DA_PROF_UPDATE, st, [&] {
+            if (d->variant == DA_VARIANT_3D)
+                return launch_ddim3d(ds, mean_type, nr, cur, w.model_out, nullptr, i, ratio, nonneg, nxt, st);
+            return launch_ddim2d(ds, mean_type, nr, c, cur, w.model_out, nullptr, i, ratio, nonneg, 0.f, nullptr, nxt, st);
+        });
+        if (rc) return rc;
+        cur = nxt;
+    }
+    if (x_final && cur != x_final) DA_CHECK_HIP(hipMemcpyAsync(x_final, cur, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int mean_type, int inference_ratio,
+                   int max_iters, const float *x_init, float *traj, float *x_final, void *workspace,
+                   size_t workspace_bytes, int use_graph, void *stream) {
+    DA_REQUIRE(d && g && s && x_init && workspace, "da_sample_loop: null argument");
+    DA_REQUIRE(inference_ratio >= 1 && s->steps >= 1, "da_sample_loop: bad ratio/steps");
+    DA_REQUIRE(d->variant == DA_VARIANT_3D || d->c_in == d->c_out, "da_sample_loop: c_in != c_out");
+    int rc = check_graph(d, g);
+    if (rc) return rc;
+    Workspace w = carve(d, g, workspace);
+    DA_REQUIRE(workspace_bytes >= w.total, "workspace too small: %zu < %zu", workspace_bytes, w.total);
+    hipStream_t st = (hipStream_t)stream;
+    int total = (s->steps + inference_ratio - 1) / inference_ratio;
+    const int n_iters = (max_iters > 0 && max_iters < total) ? max_iters : total;
+    if (d->prof_on) use_graph = 0;       // event bracketing is not capturable
+    if (!use_graph) return enqueue_loop(d, g, s, mean_type, inference_ratio, n_iters, x_init, traj, x_final, w, st);
+
+    LoopKey key;
+    memset(&key, 0, sizeof(key));
+    key.g = *g; key.s = *s; key.mean_type = mean_type; key.ratio = inference_ratio; key.max_iters = n_iters;
+    key.x_init = x_init; key.traj = traj; key.x_final = x_final; key.ws = workspace; key.ws_bytes = workspace_bytes;
+    hipGraphExec_t exec = nullptr;
+    for (auto &e : d->loops)
+        if (memcmp(&key, &e.key, sizeof(key)) == 0) exec = e.exec;
+    if (!exec) {
+        if (d->loops.size() >= 4) {                       // small LRU-less cache: drop the oldest
+            (void)hipGraphExecDestroy(d->loops.front().exec);
+            d->loops.erase(d->loops.begin());
+        }
+        hipGraph_t graph = nullptr;
+        DA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        rc = enqueue_loop(d, g, s, mean_type, inference_ratio, n_iters, x_init, traj, x_final, w, st);
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess || !graph) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return 2; }
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return 2; }
+        d->loops.push_back({key, exec});
+    }
+    DA_CHECK_HIP(hipGraphLaunch(exec, st));
+    return 0;
+}
+
+int da_profile_enable(da_denoiser *d, int on) {
+    DA_REQUIRE(d, "da_profile_enable: null denoiser");
+    d->prof_on = on != 0;
+    d->prof_used = 0;
+    d->prof_cls.clear();
+    return 0;
+}
+
+int da_profile_read(da_denoiser *d, float *ms, int32_t *counts) {
+    DA_REQUIRE(d && ms && counts, "da_profile_read: null argument");
+    for (int k = 0; k < DA_PROF_NCLASS; ++k) { ms[k] = 0.f; counts[k] = 0; }
+    for (size_t k = 0; k < d->prof_cls.size(); ++k) {
+        DA_CHECK_HIP(hipEventSynchronize(d->prof_ev[2 * k + 1]));
+        float t = 0.f;
+        DA_CHECK_HIP(hipEventElapsedTime(&t, d->prof_ev[2 * k], d->prof_ev[2 * k + 1]));
+        ms[d->prof_cls[k]] += t;
+        counts[d->prof_cls[k]] += 1;
+    }
+    d->prof_used = 0;
+    d->prof_cls.clear();
+    return 0;
+}
+
+int da_linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, int act,
+              const void *residual, void *out, int ldo, void *stream) {
+    DA_REQUIRE(A && W && out, "da_linear: null argument");
+    return da::linear(prec, M, K, Nout, A, lda, W, bias, act, residual, out, ldo, (hipStream_t)stream);
+}
+
+int da_attn_csr(int prec, const da_graph *g, int heads, int C, const void *qkvs, const void *residual, int act,
+                void *out, float *alpha, void *stream) {
+    DA_REQUIRE(g && qkvs && out, "da_attn_csr: null argument");
+    return launch_attn_csr(prec, g->n_nodes, g->row_ptr, g->col_src, g->edge_id, heads, C, qkvs, residual, act, out,
+                           alpha, (hipStream_t)stream);
+}
+
+}  // extern "C"

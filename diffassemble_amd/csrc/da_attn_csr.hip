@@ -1,0 +1,115 @@
+// Sparse graph attention: one PyG TransformerConv message/aggregate pass over a CSR-by-
+// destination graph (Transformer_GNN.py:32,38; exophormer_gnn.py:203,205).
+//
+// One 64-lane wavefront owns one destination node and ALL heads: lane l holds the
+// contiguous slice [l*EPL, (l+1)*EPL) of the H*C-wide q/k/v rows (EPL = C/8, so the 8 lanes
+// [8h, 8h+8) are head h).  Per incoming edge the wave reads one K row and one V row of the
+// source node -- two fully coalesced H*C*sizeof(T) segments -- reduces the per-head dot
+// product with three xor-shuffles inside the 8-lane group, and folds it into an online
+// softmax (running max / sum per head, replicated across the group) and the V accumulator.
+// Multi-edges are separate softmax terms and nodes without incoming edges yield 0 + skip,
+// exactly as torch_geometric.utils.softmax + scatter-add do (oracle/pyg_restatement.py).
+// HBM-bound: algorithmic bytes per edge = 2*H*C*sizeof(T) (+ 4 B index).
+#include "da_common.h"
+#include "da_internal.h"
+
+namespace da {
+
+template <typename T, int EPL>
+__global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__restrict__ row_ptr,
+                                                  const int32_t *__restrict__ col_src,
+                                                  const int32_t *__restrict__ edge_id, int H, int HC,
+                                                  const T *__restrict__ qkvs, const T *__restrict__ residual,
+                                                  int act, T *__restrict__ out, float *__restrict__ alpha,
+                                                  float scale) {
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (i >= n_nodes) return;
+    const size_t ld = (size_t)4 * HC;
+    const int off = lane * EPL;
+    float q[EPL], acc[EPL];
+    const T *qp = qkvs + (size_t)i * ld + off;
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) { q[x] = ldf(qp + x) * scale; acc[x] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const int beg = row_ptr[i], end = row_ptr[i + 1];
+    const int head = lane >> 3;
+    for (int e = beg; e < end; ++e) {
+        const int j = col_src[e];
+        const T *kp = qkvs + (size_t)j * ld + HC + off;
+        const T *vp = kp + HC;
+        float kk[EPL], vv[EPL];
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { kk[x] = ldf(kp + x); vv[x] = ldf(vp + x); }
+        float s = 0.f;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[x], s);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (alpha && (lane & 7) == 0) {
+            const size_t eid = edge_id ? (size_t)edge_id[e] : (size_t)e;
+            alpha[eid * H + head] = s;            // raw score; normalised in the second pass
+        }
+        const float mn = fmaxf(m, s);
+        const float corr = expf(m - mn);
+        const float p = expf(s - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) acc[x] = fmaf(p, vv[x], acc[x] * corr);
+        m = mn;
+    }
+    const float inv = (end > beg) ? 1.0f / (l + 1e-16f) : 0.f;
+    const T *sp = qkvs + (size_t)i * ld + 3 * (size_t)HC + off;
+    T *op = out + (size_t)i * HC + off;
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        float v = acc[x] * inv + ldf(sp + x);
+        if (residual) v += ldf(residual + (size_t)i * HC + off + x);
+        stf(op + x, apply_act(v, act));
+    }
+    if (alpha && (lane & 7) == 0) {
+        for (int e = beg; e < end; ++e) {
+            const size_t eid = edge_id ? (size_t)edge_id[e] : (size_t)e;
+            const float s = alpha[eid * H + head];
+            alpha[eid * H + head] = expf(s - m) * inv;
+        }
+    }
+}
+
+template <typename T>
+static int launch_t(int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id, int H,
+                    int C, const T *qkvs, const T *residual, int act, T *out, float *alpha, hipStream_t st) {
+    const int HC = H * C;
+    const float scale = 1.0f / sqrtf((float)C);
+    const int grid = (int)(((size_t)n_nodes * 64 + 255) / 256);
+#define DA_CSR_CASE(E)                                                                                   \
+    case E:                                                                                              \
+        k_attn_csr<T, E><<<grid, 256, 0, st>>>(n_nodes, row_ptr, col_src, edge_id, H, HC, qkvs, residual, act, \
+                                               out, alpha, scale);                                       \
+        break;
+    switch (C / 8) {
+        DA_CSR_CASE(1) DA_CSR_CASE(2) DA_CSR_CASE(4) DA_CSR_CASE(8) DA_CSR_CASE(13) DA_CSR_CASE(16) DA_CSR_CASE(18)
+        default:
+            set_error("da_attn_csr: unsupported head width C=%d", C);
+            return 1;
+    }
+#undef DA_CSR_CASE
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_attn_csr(int prec, int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id,
+                    int heads, int C, const void *qkvs, const void *residual, int act, void *out, float *alpha,
+                    hipStream_t st) {
+    if (n_nodes <= 0) return 0;
+    DA_REQUIRE(heads == 8, "da_attn_csr: heads must be 8 (got %d)", heads);
+    DA_REQUIRE(C % 8 == 0, "da_attn_csr: C %% 8 != 0 (C=%d)", C);
+    if (prec == DA_PREC_BF16)
+        return launch_t<bf16_t>(n_nodes, row_ptr, col_src, edge_id, heads, C, (const bf16_t *)qkvs,
+                                (const bf16_t *)residual, act, (bf16_t *)out, alpha, st);
+    return launch_t<float>(n_nodes, row_ptr, col_src, edge_id, heads, C, (const float *)qkvs,
+                           (const float *)residual, act, (float *)out, alpha, st);
+}
+
+}  // namespace da

@@ -1,0 +1,281 @@
+// Small / simple kernels of the denoiser path: feature staging, pose+timestep embedding,
+// the reference-grade (VALU, fp32-accumulate) linear kernel, the 2D pose head and the
+// DDIM / DDPM update.  All are HBM- or latency-bound helpers around the two hot kernels
+// (MFMA linear: da_gemm_mfma.hip, attention: da_attn_*.hip).
+#include "da_common.h"
+#include "da_internal.h"
+
+namespace da {
+
+// ------------------------------------------------------------------------------------------
+// comb_in[r, 0:F] = feats[r, :]  (once per Batch; features are loop invariant)
+template <typename T>
+__global__ __launch_bounds__(256) void k_set_feats(int n, int F, int D, const float *__restrict__ feats,
+                                                   T *__restrict__ comb_in) {
+    size_t total = (size_t)n * F;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        size_t r = idx / F;
+        int c = (int)(idx - r * F);
+        stf(comb_in + r * D + c, feats[idx]);
+    }
+}
+
+// dst[r, :] = virt_emb[r % V, :] for the V*G appended virtual rows (exophormer_gnn.py:169-178:
+// index vector arange(V).repeat(G))
+template <typename T>
+__global__ __launch_bounds__(256) void k_set_virtual_rows(int rows, int V, int D, const T *__restrict__ emb,
+                                                          T *__restrict__ dst) {
+    size_t total = (size_t)rows * D;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        size_t r = idx / D;
+        int c = (int)(idx - r * D);
+        dst[idx] = emb[(size_t)(r % V) * D + c];
+    }
+}
+
+// comb_in[r, F:F+32] = pos_mlp(x[r]) ; comb_in[r, F+32:F+64] = time_emb[t[r]]
+// (efficient_gat.py:131-134).  One wave per node, 4 nodes per block.
+template <typename T>
+__global__ __launch_bounds__(256) void k_embed_pos_time(int n, int c_in, int F, int D, const float *__restrict__ x,
+                                                        const int64_t *__restrict__ t, int64_t t_scalar, int steps,
+                                                        const float *__restrict__ time_emb,
+                                                        const float *__restrict__ w0, const float *__restrict__ b0,
+                                                        const float *__restrict__ w1, const float *__restrict__ b1,
+                                                        T *__restrict__ comb_in) {
+    __shared__ float hid[4][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    const bool ok = r < n;
+    if (ok && lane < 16) {
+        float a = b0[lane];
+        for (int k = 0; k < c_in; ++k) a += w0[lane * c_in + k] * x[(size_t)r * c_in + k];
+        hid[wv][lane] = gelu_erf(a);
+    }
+    __syncthreads();
+    if (!ok) return;
+    T *dst = comb_in + (size_t)r * D + F;
+    if (lane < 32) {
+        float a = b1[lane];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += w1[lane * 16 + k] * hid[wv][k];
+        stf(dst + lane, a);
+    } else {
+        int64_t ti = t ? t[r] : t_scalar;
+        ti = ti < 0 ? 0 : (ti >= steps ? steps - 1 : ti);
+        stf(dst + lane, time_emb[ti * 32 + (lane - 32)]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Reference-grade linear: out = act(A @ W^T + bias) + residual.  64x64 tile, BK = 16,
+// fp32 accumulate on the VALU.  Used for odd shapes and as the parity cross-check of the
+// MFMA kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gemm_simple(int M, int K, int Nout, const T *__restrict__ A, int lda,
+                                                     const T *__restrict__ W, const float *__restrict__ bias,
+                                                     int act, const T *__restrict__ res, T *__restrict__ out,
+                                                     int ldo) {
+    __shared__ float As[16][68];
+    __shared__ float Ws[16][68];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const int ar = row0 + lr, wr = col0 + lr;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + lk + i;
+            As[lk + i][lr] = (ar < M && k < K) ? ldf(A + (size_t)ar * lda + k) : 0.f;
+            Ws[lk + i][lr] = (wr < Nout && k < K) ? ldf(W + (size_t)wr * K + k) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Ws[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + ty * 4 + i;
+        if (r >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = col0 + tx * 4 + j;
+            if (c >= Nout) continue;
+            float v = acc[i][j] + (bias ? bias[c] : 0.f);
+            v = apply_act(v, act);
+            if (res) v += ldf(res + (size_t)r * ldo + c);
+            stf(out + (size_t)r * ldo + c, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 2D head tail: out[r, :] = W2 @ hh[r, :32] + b2  (final_mlp.2, efficient_gat.py:88-92,145)
+template <typename T>
+__global__ __launch_bounds__(256) void k_head2d(int n, int c_out, const T *__restrict__ hh,
+                                                const float *__restrict__ w2, const float *__restrict__ b2,
+                                                float *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * c_out) return;
+    const int r = idx / c_out, c = idx - r * c_out;
+    float a = b2[c];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) a += w2[c * 32 + k] * ldf(hh + (size_t)r * 32 + k);
+    out[idx] = a;
+}
+
+// ------------------------------------------------------------------------------------------
+// DDIM update, p_sample_ddim spatial_diffusion.py:555-566,603-627 (fp32, op order kept).
+__global__ __launch_bounds__(256) void k_ddim2d(DeviceSchedule s, int mean_type, int n, int c,
+                                                const float *__restrict__ x, const float *__restrict__ mo,
+                                                const int64_t *__restrict__ t, int64_t t_scalar, int ratio,
+                                                int prev_all_nonneg, float eta, const float *__restrict__ noise,
+                                                float *__restrict__ x_prev) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * c) return;
+    const int r = idx / c;
+    int64_t ti = t ? t[r] : t_scalar;
+    ti = ti < 0 ? 0 : (ti >= s.steps ? s.steps - 1 : ti);
+    int64_t tp = ti - ratio;
+    const float ap = s.alphas_cumprod[ti];
+    const float ap_prev = (prev_all_nonneg && tp >= 0) ? s.alphas_cumprod[tp] : 1.0f;
+    const float beta = 1.0f - ap;
+    const float xv = x[idx], m = mo[idx];
+    const float x0 = mean_type == DA_MEAN_START_X ? m : (xv - sqrtf(beta) * m) / sqrtf(ap);
+    const float eps = (s.sqrt_recip_alphas_cumprod[ti] * xv - x0) / s.sqrt_recipm1_alphas_cumprod[ti];
+    const float var = ((1.0f - ap_prev) / (1.0f - ap)) * (1.0f - ap / ap_prev);
+    const float std_eta = eta * sqrtf(var);
+    float prev = sqrtf(ap_prev) * x0 + sqrtf(1.0f - ap_prev - std_eta * std_eta) * eps;
+    if (eta > 0.f && noise) prev += std_eta * noise[idx];
+    x_prev[idx] = prev;
+}
+
+// DDPM update, p_sample_ddpm spatial_diffusion.py:485-510.
+__global__ __launch_bounds__(256) void k_ddpm2d(DeviceSchedule s, int n, int c, const float *__restrict__ x,
+                                                const float *__restrict__ mo, const int64_t *__restrict__ t,
+                                                int64_t t_scalar, const float *__restrict__ noise,
+                                                float *__restrict__ x_prev) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * c) return;
+    const int r = idx / c;
+    int64_t ti = t ? t[r] : t_scalar;
+    ti = ti < 0 ? 0 : (ti >= s.steps ? s.steps - 1 : ti);
+    float mean = s.sqrt_recip_alphas[ti] * (x[idx] - s.betas[ti] * mo[idx] / s.sqrt_one_minus_alphas_cumprod[ti]);
+    if (noise) mean += sqrtf(s.posterior_variance[ti]) * noise[idx];
+    x_prev[idx] = mean;
+}
+
+// fp32 -> act dtype conversion (weight packing)
+template <typename T>
+__global__ __launch_bounds__(256) void k_convert(size_t n, const float *__restrict__ src, T *__restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        stf(dst + i, src[i]);
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+static inline int grid_for(size_t total, int block = 256, int cap = 4096) {
+    size_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
+}
+
+template <typename T>
+static int launch_set_feats_t(int n, int F, int D, const float *feats, void *comb_in, hipStream_t st) {
+    if (n <= 0) return 0;
+    k_set_feats<T><<<grid_for((size_t)n * F), 256, 0, st>>>(n, F, D, feats, (T *)comb_in);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+int launch_set_feats(int prec, int n, int F, int D, const float *feats, void *comb_in, hipStream_t st) {
+    return prec == DA_PREC_BF16 ? launch_set_feats_t<bf16_t>(n, F, D, feats, comb_in, st)
+                                : launch_set_feats_t<float>(n, F, D, feats, comb_in, st);
+}
+
+int launch_set_virtual_rows(int prec, int rows, int V, int D, const void *emb, void *dst, hipStream_t st) {
+    if (rows <= 0) return 0;
+    if (prec == DA_PREC_BF16)
+        k_set_virtual_rows<bf16_t><<<grid_for((size_t)rows * D), 256, 0, st>>>(rows, V, D, (const bf16_t *)emb, (bf16_t *)dst);
+    else
+        k_set_virtual_rows<float><<<grid_for((size_t)rows * D), 256, 0, st>>>(rows, V, D, (const float *)emb, (float *)dst);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_embed_pos_time(int prec, int n, int c_in, int F, int D, const float *x, const int64_t *t, int64_t t_scalar,
+                          int steps, const float *time_emb, const float *w0, const float *b0, const float *w1,
+                          const float *b1, void *comb_in, hipStream_t st) {
+    if (n <= 0) return 0;
+    const int grid = (n + 3) / 4;
+    if (prec == DA_PREC_BF16)
+        k_embed_pos_time<bf16_t><<<grid, 256, 0, st>>>(n, c_in, F, D, x, t, t_scalar, steps, time_emb, w0, b0, w1, b1, (bf16_t *)comb_in);
+    else
+        k_embed_pos_time<float><<<grid, 256, 0, st>>>(n, c_in, F, D, x, t, t_scalar, steps, time_emb, w0, b0, w1, b1, (float *)comb_in);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemm_simple(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
+                       int act, const void *res, void *out, int ldo, hipStream_t st) {
+    if (M <= 0 || Nout <= 0) return 0;
+    dim3 grid((Nout + 63) / 64, (M + 63) / 64);
+    if (prec == DA_PREC_BF16)
+        k_gemm_simple<bf16_t><<<grid, 256, 0, st>>>(M, K, Nout, (const bf16_t *)A, lda, (const bf16_t *)W, bias, act, (const bf16_t *)res, (bf16_t *)out, ldo);
+    else
+        k_gemm_simple<float><<<grid, 256, 0, st>>>(M, K, Nout, (const float *)A, lda, (const float *)W, bias, act, (const float *)res, (float *)out, ldo);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_head2d(int prec, int n, int c_out, const void *hh, const float *w2, const float *b2, float *out, hipStream_t st) {
+    if (n <= 0) return 0;
+    const int grid = (n * c_out + 255) / 256;
+    if (prec == DA_PREC_BF16)
+        k_head2d<bf16_t><<<grid, 256, 0, st>>>(n, c_out, (const bf16_t *)hh, w2, b2, out);
+    else
+        k_head2d<float><<<grid, 256, 0, st>>>(n, c_out, (const float *)hh, w2, b2, out);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_ddim2d(const DeviceSchedule &s, int mean_type, int n, int c, const float *x, const float *mo,
+                  const int64_t *t, int64_t t_scalar, int ratio, int prev_all_nonneg, float eta, const float *noise,
+                  float *x_prev, hipStream_t st) {
+    if (n <= 0) return 0;
+    k_ddim2d<<<(n * c + 255) / 256, 256, 0, st>>>(s, mean_type, n, c, x, mo, t, t_scalar, ratio, prev_all_nonneg, eta, noise, x_prev);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_ddpm2d(const DeviceSchedule &s, int n, int c, const float *x, const float *mo, const int64_t *t,
+                  int64_t t_scalar, const float *noise, float *x_prev, hipStream_t st) {
+    if (n <= 0) return 0;
+    k_ddpm2d<<<(n * c + 255) / 256, 256, 0, st>>>(s, n, c, x, mo, t, t_scalar, noise, x_prev);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_convert(int prec, size_t n, const float *src, void *dst, hipStream_t st) {
+    if (n == 0) return 0;
+    if (prec == DA_PREC_BF16)
+        k_convert<bf16_t><<<grid_for(n), 256, 0, st>>>(n, src, (bf16_t *)dst);
+    else
+        k_convert<float><<<grid_for(n), 256, 0, st>>>(n, src, (float *)dst);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace da

@@ -1,0 +1,44 @@
+// Internal launcher declarations shared by the translation units of libdiffassemble_hip.so.
+#pragma once
+#include "da_common.h"
+
+namespace da {
+
+struct DeviceSchedule {
+    int steps;
+    const float *betas, *alphas_cumprod, *sqrt_recip_alphas, *sqrt_recip_alphas_cumprod,
+        *sqrt_recipm1_alphas_cumprod, *sqrt_one_minus_alphas_cumprod, *posterior_variance;
+};
+
+// da_basic.hip
+int launch_set_feats(int prec, int n, int F, int D, const float *feats, void *comb_in, hipStream_t st);
+int launch_set_virtual_rows(int prec, int rows, int V, int D, const void *emb, void *dst, hipStream_t st);
+int launch_embed_pos_time(int prec, int n, int c_in, int F, int D, const float *x, const int64_t *t, int64_t t_scalar,
+                          int steps, const float *time_emb, const float *w0, const float *b0, const float *w1,
+                          const float *b1, void *comb_in, hipStream_t st);
+int launch_gemm_simple(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
+                       int act, const void *res, void *out, int ldo, hipStream_t st);
+int launch_head2d(int prec, int n, int c_out, const void *hh, const float *w2, const float *b2, float *out, hipStream_t st);
+int launch_ddim2d(const DeviceSchedule &s, int mean_type, int n, int c, const float *x, const float *mo,
+                  const int64_t *t, int64_t t_scalar, int ratio, int prev_all_nonneg, float eta, const float *noise,
+                  float *x_prev, hipStream_t st);
+int launch_ddpm2d(const DeviceSchedule &s, int n, int c, const float *x, const float *mo, const int64_t *t,
+                  int64_t t_scalar, const float *noise, float *x_prev, hipStream_t st);
+int launch_convert(int prec, size_t n, const float *src, void *dst, hipStream_t st);
+
+// da_attn_csr.hip
+int launch_attn_csr(int prec, int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id,
+                    int heads, int C, const void *qkvs, const void *residual, int act, void *out, float *alpha,
+                    hipStream_t st);
+
+// da_so3.hip (3D head + SO(3) DDIM)
+int launch_head3d(int prec, int n, const void *hh, const float *wt, const float *bt, const float *wr, const float *br,
+                  float *out7, float *pre_head, hipStream_t st);
+int launch_ddim3d(const DeviceSchedule &s, int mean_type, int n, const float *x, const float *mo, const int64_t *t,
+                  int64_t t_scalar, int ratio, int prev_all_nonneg, float *x_prev, hipStream_t st);
+
+// generic linear dispatch (MFMA when the shape allows, else simple)
+int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, int act,
+           const void *res, void *out, int ldo, hipStream_t st);
+
+}  // namespace da

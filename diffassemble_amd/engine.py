@@ -1,0 +1,264 @@
+"""Python owner of one ``da_denoiser`` (packed weights) + its workspaces.
+
+This is plumbing around the C ABI (include/diffassemble_hip.h): PyTorch provides device
+memory and the stream, every arithmetic op of the denoiser / sampling loop runs in
+libdiffassemble_hip.so.  No fallback: tensors must live on a ROCm device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .graph_plan import GraphPlan, build_plan
+
+_PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
+
+
+def _f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class Schedule:
+    """Device copies of the registered diffusion buffers (spatial_diffusion.py:282-321)."""
+
+    KEYS = ("betas", "alphas_cumprod", "sqrt_recip_alphas", "sqrt_recip_alphas_cumprod",
+            "sqrt_recipm1_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "posterior_variance")
+
+    def __init__(self, buffers, device):
+        self.t = {k: _f32(buffers[k], device) for k in self.KEYS}
+        self.steps = int(self.t["betas"].numel())
+        self.c = _lib.DaSchedule()
+        self.c.steps = self.steps
+        for k in self.KEYS:
+            setattr(self.c, k, self.t[k].data_ptr())
+
+
+class DenoiserEngine:
+    """Packs an ``Eff_GAT`` / ``Eff_GAT_3d`` state dict (reference key layout, see
+    oracle/denoiser.py) into the HIP library and runs forward / sampling on it."""
+
+    def __init__(self, sd, *, variant="2d", arch="transformer", virt_nodes=0, precision="bf16",
+                 device=None):
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise _lib.DaError("DenoiserEngine needs a ROCm device (no CPU path in diffassemble_amd)")
+        self.lib = _lib.lib()
+        self.precision = precision
+        self.prec = _PREC[precision]
+        self.variant, self.arch = variant, arch
+        self.virt_nodes = int(virt_nodes) if arch == "exophormer" else 0
+        w = _lib.DaWeights()
+        keep = []
+
+        def P(name):
+            t = _f32(sd[name], self.device)
+            keep.append(t)
+            return t.data_ptr()
+
+        layers = sorted({int(k.split(".")[2]) for k in sd if k.startswith("gnn_backbone.module_list.")})
+        self.n_layers = len(layers)
+        D = sd["mlp.0.weight"].shape[1]
+        self.D, self.F = D, D - 64
+        self.c_in = sd["pos_mlp.0.weight"].shape[1]
+        self.steps = sd["time_emb.weight"].shape[0]
+        w.variant = _lib.VARIANT_3D if variant == "3d" else _lib.VARIANT_2D
+        w.arch = _lib.ARCH_EXOPHORMER if arch == "exophormer" else _lib.ARCH_TRANSFORMER
+        w.steps, w.c_in, w.feat_dim = self.steps, self.c_in, self.F
+        w.hidden = sd["mlp.0.weight"].shape[0]
+        w.heads, w.n_layers, w.virt_nodes = 8, self.n_layers, self.virt_nodes
+        w.time_emb = P("time_emb.weight")
+        w.pos_w0, w.pos_b0 = P("pos_mlp.0.weight"), P("pos_mlp.0.bias")
+        w.pos_w1, w.pos_b1 = P("pos_mlp.2.weight"), P("pos_mlp.2.bias")
+        w.mlp_w0, w.mlp_b0 = P("mlp.0.weight"), P("mlp.0.bias")
+        w.mlp_w1, w.mlp_b1 = P("mlp.2.weight"), P("mlp.2.bias")
+        for l in layers:
+            p = f"gnn_backbone.module_list.{l}."
+            w.conv_wq[l], w.conv_bq[l] = P(p + "lin_query.weight"), P(p + "lin_query.bias")
+            w.conv_wk[l], w.conv_bk[l] = P(p + "lin_key.weight"), P(p + "lin_key.bias")
+            w.conv_wv[l], w.conv_bv[l] = P(p + "lin_value.weight"), P(p + "lin_value.bias")
+            w.conv_ws[l], w.conv_bs[l] = P(p + "lin_skip.weight"), P(p + "lin_skip.bias")
+        if self.virt_nodes > 0:
+            w.virt_emb = P("gnn_backbone.virt_node_embedding.weight")
+        if variant == "3d":
+            self.c_out, self.c_pose = 6, 7
+            w.c_out = 6
+            w.head_w0, w.head_b0 = P("mlp_t.0.weight"), P("mlp_t.0.bias")
+            w.head_w1, w.head_b1 = P("mlp_t.2.weight"), P("mlp_t.2.bias")
+            w.head_r_w0, w.head_r_b0 = P("mlp_r.0.weight"), P("mlp_r.0.bias")
+            w.head_r_w1, w.head_r_b1 = P("mlp_r.2.weight"), P("mlp_r.2.bias")
+        else:
+            self.c_out = sd["final_mlp.2.weight"].shape[0]
+            self.c_pose = self.c_out
+            w.c_out = self.c_out
+            w.head_w0, w.head_b0 = P("final_mlp.0.weight"), P("final_mlp.0.bias")
+            w.head_w1, w.head_b1 = P("final_mlp.2.weight"), P("final_mlp.2.bias")
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.da_denoiser_create(C.byref(w), self.prec, _lib.stream_ptr(self.device),
+                                                   C.byref(handle)))
+        self.handle = handle
+        del keep                      # create() synchronised: the fp32 staging copies may go
+        self._ws = {}
+        self._loop_bufs = {}
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                self.lib.da_denoiser_destroy(h)
+            except Exception:  # noqa: BLE001
+                pass
+            self.handle = None
+
+    # ------------------------------------------------------------------ graph + workspace
+    def plan(self, edge_index, batch):
+        return build_plan(edge_index.to(self.device), batch.to(self.device), self.virt_nodes)
+
+    def _workspace(self, plan: GraphPlan):
+        g = plan.c_struct()
+        need = int(self.lib.da_denoiser_workspace_bytes(self.handle, C.byref(g)))
+        key = (plan.n_nodes, plan.n_real)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = {key: ws}           # one live workspace per engine
+        return g, ws
+
+    def set_features(self, plan, feats):
+        g, ws = self._workspace(plan)
+        feats = _f32(feats, self.device)
+        assert feats.shape == (plan.n_real, self.F), (feats.shape, plan.n_real, self.F)
+        _lib.check(self.lib.da_denoiser_set_features(self.handle, C.byref(g), _lib.ptr(feats), _lib.ptr(ws),
+                                                     ws.numel(), _lib.stream_ptr(self.device)))
+        return g, ws
+
+    # ------------------------------------------------------------------ operators
+    def forward(self, plan, x, t, feats=None, return_alpha=False, return_pre_head=False, alpha_all_layers=False):
+        """Eff_GAT(.._3d).forward_with_feats.  ``feats=None`` reuses the features already staged
+        for this plan (sampling loop).  t: int64 [N] tensor or python int."""
+        if feats is not None:
+            g, ws = self.set_features(plan, feats)
+        else:
+            g, ws = self._workspace(plan)
+        x = _f32(x, self.device)
+        out = torch.empty((plan.n_real, self.c_pose), dtype=torch.float32, device=self.device)
+        ashape = (self.n_layers, plan.n_edges, 8) if alpha_all_layers else (plan.n_edges, 8)
+        alpha = torch.empty(ashape, dtype=torch.float32, device=self.device) if return_alpha else None
+        pre = (torch.empty((plan.n_real, 6), dtype=torch.float32, device=self.device)
+               if return_pre_head and self.variant == "3d" else None)
+        if torch.is_tensor(t):
+            tt, ts = t.to(device=self.device, dtype=torch.int64).contiguous(), 0
+        else:
+            tt, ts = None, int(t)
+        _lib.check(self.lib.da_denoiser_forward(
+            self.handle, C.byref(g), _lib.ptr(x), _lib.ptr(tt), ts, _lib.ptr(out), _lib.ptr(alpha),
+            int(bool(alpha_all_layers)), _lib.ptr(pre), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self.device)))
+        res = [out]
+        if return_alpha:
+            res.append(alpha)
+        if return_pre_head:
+            res.append(pre)
+        return res[0] if len(res) == 1 else tuple(res)
+
+    def ddim_step(self, sched: Schedule, x, model_out, t, ratio, mean_type, eta=0.0, noise=None):
+        x, model_out = _f32(x, self.device), _f32(model_out, self.device)
+        out = torch.empty_like(x)
+        if torch.is_tensor(t):
+            tt, ts = t.to(device=self.device, dtype=torch.int64).contiguous(), 0
+            nonneg = int(bool((tt - ratio >= 0).all()))        # the reference's host branch (:560)
+        else:
+            tt, ts = None, int(t)
+            nonneg = int(ts - ratio >= 0)
+        nz = None if noise is None else _f32(noise, self.device)
+        variant = _lib.VARIANT_3D if self.variant == "3d" else _lib.VARIANT_2D
+        _lib.check(self.lib.da_ddim_step(C.byref(sched.c), variant, mean_type, x.shape[0], x.shape[1],
+                                         _lib.ptr(x), _lib.ptr(model_out), _lib.ptr(tt), ts, int(ratio), nonneg,
+                                         float(eta), _lib.ptr(nz), _lib.ptr(out), _lib.stream_ptr(self.device)))
+        return out
+
+    def ddpm_step(self, sched: Schedule, x, model_out, t, noise=None):
+        x, model_out = _f32(x, self.device), _f32(model_out, self.device)
+        out = torch.empty_like(x)
+        if torch.is_tensor(t):
+            tt, ts = t.to(device=self.device, dtype=torch.int64).contiguous(), 0
+        else:
+            tt, ts = None, int(t)
+        nz = None if noise is None else _f32(noise, self.device)
+        _lib.check(self.lib.da_ddpm_step(C.byref(sched.c), x.shape[0], x.shape[1], _lib.ptr(x),
+                                         _lib.ptr(model_out), _lib.ptr(tt), ts, _lib.ptr(nz), _lib.ptr(out),
+                                         _lib.stream_ptr(self.device)))
+        return out
+
+    def sample_loop(self, plan, sched: Schedule, x_init, feats, *, ratio=1, mean_type=_lib.MEAN_START_X,
+                    max_iters=0, keep_trajectory=True, use_graph=True, restage=True):
+        """p_sample_loop: all DDIM iterations in one C call (one hipGraph launch when use_graph).
+        Returns (traj [n_iters, N, c] or None, x_final [N, c]) -- engine-owned buffers that the next
+        call with the same loop shape overwrites (clone to keep).  Note the cached graph also
+        borrows ``plan``'s arrays and the workspace."""
+        if restage:
+            g, ws = self.set_features(plan, feats)
+        else:
+            g, ws = self._workspace(plan)
+        total = (sched.steps + ratio - 1) // ratio
+        n_iters = min(max_iters, total) if max_iters and max_iters > 0 else total
+        c = x_init.shape[1]
+        # persistent I/O buffers: the cached hipGraph is keyed on these pointers, so replays of the
+        # same loop shape reuse them (results are overwritten by the next call of that shape)
+        key = (plan.n_real, c, n_iters, bool(keep_trajectory))
+        bufs = self._loop_bufs.get(key)
+        if bufs is None:
+            xi = torch.empty((plan.n_real, c), dtype=torch.float32, device=self.device)
+            traj = (torch.empty((n_iters, plan.n_real, c), dtype=torch.float32, device=self.device)
+                    if keep_trajectory else None)
+            bufs = self._loop_bufs[key] = (xi, traj, torch.empty_like(xi))
+        xi, traj, x_final = bufs
+        xi.copy_(x_init)
+        self._loop_keep = plan                                 # the cached hipGraph borrows its arrays
+        _lib.check(self.lib.da_sample_loop(
+            self.handle, C.byref(g), C.byref(sched.c), int(mean_type), int(ratio), int(n_iters),
+            _lib.ptr(xi), _lib.ptr(traj), _lib.ptr(x_final), _lib.ptr(ws), ws.numel(),
+            int(bool(use_graph)), _lib.stream_ptr(self.device)))
+        return traj, x_final
+
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, on=True):
+        _lib.check(self.lib.da_profile_enable(self.handle, int(bool(on))))
+
+    def profile_read(self):
+        """-> {class: (total_ms, launches)} measured with HIP events on the launch stream."""
+        n = len(_lib.PROF_CLASSES)
+        ms, cnt = (C.c_float * n)(), (C.c_int32 * n)()
+        _lib.check(self.lib.da_profile_read(self.handle, ms, cnt))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(_lib.PROF_CLASSES)}
+
+
+# ---------------------------------------------------------------------- kernel-level helpers
+def linear(x, weight, bias=None, act=_lib.ACT_NONE, residual=None, precision="fp32"):
+    """out = act(x @ weight^T + bias) + residual through da_linear (x, weight: [M,K], [N,K])."""
+    prec = _PREC[precision]
+    dt = torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32
+    x = x.to(dt).contiguous()
+    weight = weight.to(dt).contiguous()
+    M, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N), dtype=dt, device=x.device)
+    b = None if bias is None else bias.float().contiguous()
+    r = None if residual is None else residual.to(dt).contiguous()
+    _lib.check(_lib.lib().da_linear(prec, M, K, N, _lib.ptr(x), K, _lib.ptr(weight), _lib.ptr(b), int(act),
+                                    _lib.ptr(r), _lib.ptr(out), N, _lib.stream_ptr(x.device)))
+    return out
+
+
+def attn_csr(plan: GraphPlan, qkvs, heads, C_head, residual=None, act=_lib.ACT_NONE, return_alpha=False,
+             precision="fp32"):
+    prec = _PREC[precision]
+    dt = torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32
+    qkvs = qkvs.to(dt).contiguous()
+    out = torch.empty((plan.n_nodes, heads * C_head), dtype=dt, device=qkvs.device)
+    alpha = torch.empty((plan.n_edges, heads), dtype=torch.float32, device=qkvs.device) if return_alpha else None
+    r = None if residual is None else residual.to(dt).contiguous()
+    g = plan.c_struct()
+    _lib.check(_lib.lib().da_attn_csr(prec, C.byref(g), heads, C_head, _lib.ptr(qkvs), _lib.ptr(r), int(act),
+                                      _lib.ptr(out), _lib.ptr(alpha), _lib.stream_ptr(qkvs.device)))
+    return (out, alpha) if return_alpha else out

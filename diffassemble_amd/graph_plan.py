@@ -1,0 +1,119 @@
+"""Host-side plan of a PyG ``Batch``'s piece graph for the HIP kernels.
+
+Turns the reference's operator inputs -- ``edge_index[2, E]`` int64 (row 0 = source j,
+row 1 = target i, per-graph offsets already applied by PyG collation) and the sorted
+``batch[N]`` vector (efficient_gat.py:121-129) -- into the ``da_graph`` of
+include/diffassemble_hip.h: int32 CSR-by-destination with multi-edges kept, the slot->edge
+permutation for the ``alpha[E, H]`` output, per-graph node offsets, and a ``dense`` flag
+when every graph is complete (so the block-diagonal MFMA attention kernel applies).
+
+For ``architecture='exophormer'`` the V*G virtual rows and the extra edges are appended
+exactly as backbones/exophormer_gnn.py:164-200 builds them, including its pairing quirk
+(``src = cat[arange(N), virt_edges]``, ``dst = cat[virt_edges, arange(N)]`` paired
+position by position), but vectorised: no per-graph Python loop, no ``batch.unique()``.
+
+Index plumbing only (torch sort/bincount on whatever device the inputs live on); the plan
+is built once per Batch and reused for all T sampling steps.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+
+def exophormer_edge_index(edge_index, batch, virt_nodes, n_graphs=None):
+    """Extended edge_index of exophormer_gnn.py:183-200 (see module docstring)."""
+    N = batch.numel()
+    V = int(virt_nodes)
+    dev = batch.device
+    G = int(batch.max()) + 1 if n_graphs is None else int(n_graphs)
+    counts = torch.bincount(batch, minlength=G) + V                 # nodes of graph i in the EXTENDED batch
+    seg = counts * V                                                # len(virt_edge_i) = V * (n_i + V)
+    gid = torch.repeat_interleave(torch.arange(G, device=dev), seg)
+    start = torch.cumsum(seg, 0) - seg
+    k = torch.arange(int(seg.sum()), device=dev) - start[gid]
+    virt_edges = N + gid * V + k % V
+    ar = torch.arange(N, device=dev)
+    src = torch.cat([ar, virt_edges])
+    dst = torch.cat([virt_edges, ar])
+    return torch.hstack((edge_index, torch.stack((src, dst))))
+
+
+@dataclass
+class GraphPlan:
+    n_nodes: int
+    n_real: int
+    n_graphs: int
+    dense: int
+    n_edges: int
+    max_graph_nodes: int
+    row_ptr: torch.Tensor      # int32 [n_nodes + 1]
+    col_src: torch.Tensor      # int32 [E]
+    edge_id: torch.Tensor      # int32 [E]
+    graph_ptr: torch.Tensor    # int32 [G + 1]
+    edge_index: torch.Tensor   # int64 [2, E] (extended for exophormer) -- returned with alpha
+
+    def c_struct(self):
+        g = _lib.DaGraph()
+        g.n_nodes, g.n_real, g.n_graphs, g.dense = self.n_nodes, self.n_real, self.n_graphs, self.dense
+        g.n_edges = self.n_edges
+        g.row_ptr = self.row_ptr.data_ptr()
+        g.col_src = self.col_src.data_ptr()
+        g.edge_id = self.edge_id.data_ptr()
+        g.graph_ptr = self.graph_ptr.data_ptr()
+        g.max_graph_nodes = self.max_graph_nodes
+        return g
+
+
+def build_plan(edge_index, batch, virt_nodes=0, detect_dense=True):
+    """edge_index [2,E] int64, batch [N] int64 (sorted graph ids) -> GraphPlan."""
+    assert edge_index.dim() == 2 and edge_index.shape[0] == 2, "edge_index must be [2, E]"
+    N = batch.numel()
+    dev = batch.device
+    G = int(batch.max()) + 1 if N > 0 else 0
+    counts = torch.bincount(batch, minlength=G)
+    graph_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    graph_ptr[1:] = torch.cumsum(counts, 0)
+    n_nodes = N
+    dense = 0
+    if detect_dense and virt_nodes == 0 and edge_index.shape[1] > 0:
+        dense = _detect_dense(edge_index, batch, counts)
+    if virt_nodes > 0:
+        edge_index = exophormer_edge_index(edge_index, batch, virt_nodes, G)
+        n_nodes = N + virt_nodes * G
+    E = edge_index.shape[1]
+    assert n_nodes < 2 ** 31 and E < 2 ** 31
+    src, dst = edge_index[0], edge_index[1]
+    perm = torch.argsort(dst, stable=True)          # keeps the caller's order inside a segment
+    row_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
+    row_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_nodes), 0)
+    return GraphPlan(
+        n_nodes=n_nodes, n_real=N, n_graphs=G, dense=dense, n_edges=E,
+        max_graph_nodes=int(counts.max()) if G else 0,
+        row_ptr=row_ptr.to(torch.int32), col_src=src[perm].to(torch.int32).contiguous(),
+        edge_id=perm.to(torch.int32).contiguous(), graph_ptr=graph_ptr.to(torch.int32),
+        edge_index=edge_index)
+
+
+def _detect_dense(edge_index, batch, counts):
+    """1 = every graph is complete WITH self loops (rotation dataset, puzzle_dataset.py:609-614),
+    2 = complete WITHOUT self loops (non-rotation dataset default), 0 = anything else.
+    Exact: edges unique, inside their graph, and the count matches."""
+    src, dst = edge_index[0], edge_index[1]
+    E = edge_index.shape[1]
+    N = batch.numel()
+    full = int((counts * counts).sum())
+    if E != full and E != full - N:
+        return 0
+    if not bool((batch[src] == batch[dst]).all()):
+        return 0
+    if torch.unique(src * N + dst).numel() != E:
+        return 0
+    loops = int((src == dst).sum())
+    if E == full and loops == N:
+        return 1
+    if E == full - N and loops == 0:
+        return 2
+    return 0

@@ -1,0 +1,69 @@
+"""Shared engine plumbing of ``Eff_GAT`` / ``Eff_GAT_3d``: lazily packs the module's
+parameters into a ``DenoiserEngine`` (HIP library), caches the graph plan of the current
+Batch and the staged piece features so the T sampling steps of one Batch re-use them."""
+import os
+
+import torch
+import torch.nn as nn
+
+from ...engine import DenoiserEngine
+
+
+def default_precision():
+    return os.environ.get("DIFFASSEMBLE_PRECISION", "bf16")
+
+
+class DenoiserBase(nn.Module):
+    variant = "2d"
+
+    def _denoiser_state(self):
+        skip = ("visual_backbone.", "pcd_backbone.", "linear1.", "linear2.", "mean", "std")
+        return {k: v for k, v in self.state_dict().items() if not k.startswith(skip)}
+
+    def _param_version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def engine(self, device=None, precision=None) -> DenoiserEngine:
+        """The packed HIP denoiser for the module's CURRENT parameters (rebuilt when a
+        parameter was modified in place, moved, or the precision changed)."""
+        precision = precision or getattr(self, "precision", None) or default_precision()
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        key = (self._param_version(), precision, str(device))
+        if getattr(self, "_engine_key", None) != key:
+            gnn = self.gnn_backbone
+            self._engine = DenoiserEngine(self._denoiser_state(), variant=self.variant, arch=gnn.arch,
+                                          virt_nodes=getattr(gnn, "virt_nodes", 0), precision=precision,
+                                          device=device)
+            self._engine_key = key
+            self._plan_key = self._feat_key = None
+        return self._engine
+
+    def _plan_for(self, eng, edge_index, batch):
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
+               batch.data_ptr(), batch.numel(), batch._version, id(eng))
+        if getattr(self, "_plan_key", None) != key:
+            self._plan = eng.plan(edge_index, batch)
+            self._plan_key = key
+            self._feat_key = None
+        return self._plan
+
+    def _stage_features(self, eng, plan, feats):
+        key = (feats.data_ptr(), tuple(feats.shape), feats._version, id(plan))
+        if getattr(self, "_feat_key", None) != key:
+            eng.set_features(plan, feats)
+            self._feat_key = key
+
+    @torch.no_grad()
+    def _run(self, xy_pos, time, edge_index, feats, batch, return_attentions=True):
+        eng = self.engine(xy_pos.device)
+        plan = self._plan_for(eng, edge_index, batch)
+        self._stage_features(eng, plan, feats)
+        all_layers = self.gnn_backbone.arch == "transformer"
+        if return_attentions:
+            out, alpha = eng.forward(plan, xy_pos, time, None, return_alpha=True, alpha_all_layers=all_layers)
+            attentions = ([(plan.edge_index, alpha[l]) for l in range(alpha.shape[0])] if all_layers
+                          else [(plan.edge_index, alpha)])
+        else:
+            out = eng.forward(plan, xy_pos, time, None)
+            attentions = None
+        return out, attentions

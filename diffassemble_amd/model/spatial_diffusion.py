@@ -1,0 +1,343 @@
+"""Counterpart of puzzle_diff/model/spatial_diffusion.py: ``GNN_Diffusion`` with the same
+constructor kwargs, mutable attributes, state-dict keys (``betas`` ... ``posterior_variance``,
+``model.*``) and Lightning hooks, with the per-timestep denoiser and the
+sampling loop running in the HIP library:
+
+* ``forward_with_feats``  -> one ``da_denoiser_forward`` call
+* ``p_sample_ddim/ddpm``  -> forward + ``da_ddim_step`` / ``da_ddpm_step``
+* ``p_sample_loop``       -> ``da_sample_loop``: all T iterations enqueued by one C call and
+                            replayed as ONE hipGraph launch (no per-step host syncs; the
+                            reference's ``(prev_timestep >= 0).all()`` branches, :535,560, are
+                            resolved on the host per iteration index at capture time).
+
+Differences from the reference, on purpose:
+* attention weights are returned per step only when ``self.return_attentions`` is True
+  (the reference keeps T x 4 x [E, 8] floats that no caller reads; ~10 GB at 900 pieces);
+* ``sampling="DDPM"`` works in ``p_sample_loop`` (the reference raises ``ValueError: too
+  many values to unpack``, :504-510 vs :663; tests/golden pins that failure mode).
+"""
+import enum
+import math
+from functools import partial
+from typing import Any
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import _lib
+from ..engine import Schedule
+from ._lightning_compat import LightningModule, MeanMetric, SumMetric
+from .backbones import Eff_GAT
+
+
+class ModelMeanType(enum.Enum):
+    """spatial_diffusion.py:58-66 (same members and values, so pickled hparams load)."""
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelScheduler(enum.Enum):
+    """spatial_diffusion.py:69-73."""
+    LINEAR = enum.auto()
+    COSINE = enum.auto()
+    COSINE_DISCRETE = enum.auto()
+
+
+def cosine_discrete_beta_schedule(timesteps, s=0.08):
+    steps = timesteps + 1
+    t = torch.linspace(0, timesteps, steps)
+    ac = lambda t: torch.cos(((t / timesteps) + s) / (1 + s) + np.pi / 2)  # noqa: E731
+    betas = 1 - ac(t + 1) / ac(t)
+    return torch.clip(betas, 0.0001, 0.9999)
+
+
+def cosine_beta_schedule(timesteps, s=0.08):
+    steps = timesteps + 1
+    x = torch.linspace(0, timesteps, steps)
+    ac = torch.cos(((x / timesteps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    return torch.clip(1 - (ac[1:] / ac[:-1]), 0.0001, 0.9999)
+
+
+def linear_beta_schedule(timesteps):
+    return torch.linspace(0.0001, 0.02, timesteps)
+
+
+def extract(a, t, x_shape=None):
+    return a.gather(-1, t)[:, None]
+
+
+def greedy_cost_assignment(pos1: torch.Tensor, pos2: torch.Tensor) -> torch.Tensor:
+    """Same result as the reference's TorchScript loop (spatial_diffusion.py:179-216: repeatedly
+    take the globally smallest remaining distance, retire its row and column) without the
+    per-assignment ``.item()`` syncs: one stable sort of all pairs, then a single pass.
+    Caller-side glue, not on the accelerated path."""
+    dist = torch.norm(pos1[:, None] - pos2, dim=2)
+    n, m = dist.shape
+    # the reference's dist[mask].min() returns the FIRST minimum in row-major order: stable sort
+    order = torch.sort(dist.flatten(), stable=True)[1].cpu().numpy()
+    dist_c = dist.flatten().cpu()
+    row_used, col_used = np.zeros(n, bool), np.zeros(m, bool)
+    out = []
+    for f in order:
+        i, j = divmod(int(f), m)
+        if row_used[i] or col_used[j]:
+            continue
+        row_used[i] = col_used[j] = True
+        out.append((i, j, int(dist_c[f])))          # assignments tensor is int64: value truncated
+        if len(out) == min(n, m):
+            break
+    return torch.tensor(out, dtype=torch.int64).reshape(-1, 3)
+
+
+class GNN_Diffusion(LightningModule):
+    def __init__(self, steps=600, inference_ratio=1, sampling="DDPM", learning_rate=1e-4,
+                 save_and_sample_every=1000, bb=None, classifier_free_prob=0, classifier_free_w=0,
+                 noise_weight=0.0, rotation=False, model_mean_type: ModelMeanType = ModelMeanType.EPSILON,
+                 input_channels=2, output_channels=2, scheduler: ModelScheduler = ModelScheduler.LINEAR,
+                 visual_pretrained: bool = True, freeze_backbone: bool = True, backbone: str = "efficientnet_b0",
+                 n_layers: int = 4, architecture: str = "transformer", virt_nodes: int = 4,
+                 all_equivariant=False, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.visual_pretrained = visual_pretrained
+        self.free_backbone = freeze_backbone
+        self.model_mean_type = model_mean_type
+        self.learning_rate = learning_rate
+        self.save_and_sample_every = save_and_sample_every
+        self.classifier_free_prob = classifier_free_prob
+        self.classifier_free_w = classifier_free_w
+        self.noise_weight = noise_weight
+        self.rotation = rotation
+        self.virt_nodes = virt_nodes
+        self.all_equivariant = all_equivariant
+        self.save_eval_images = False
+        self.return_attentions = False      # see module docstring
+        self.use_hip_graph = True
+        self.sampling = sampling
+        if sampling == "DDPM":
+            self.inference_ratio = inference_ratio
+            self.p_sample = partial(self.p_sample, sampling_func=self.p_sample_ddpm)
+            self.eta = 1
+        elif sampling == "DDIM":
+            self.inference_ratio = inference_ratio
+            self.p_sample = partial(self.p_sample, sampling_func=self.p_sample_ddim)
+            self.eta = 0
+        betas = {ModelScheduler.LINEAR: linear_beta_schedule, ModelScheduler.COSINE: cosine_beta_schedule,
+                 ModelScheduler.COSINE_DISCRETE: cosine_discrete_beta_schedule}[scheduler](timesteps=steps)
+        # buffers: same op order as spatial_diffusion.py:282-321 so fp32 values are bit-identical
+        self.register_buffer("betas", betas)
+        alphas = 1.0 - self.betas
+        self.register_buffer("alphas", alphas)
+        alphas_cumprod = torch.cumprod(self.alphas, axis=0)
+        self.register_buffer("alphas_cumprod", alphas_cumprod)
+        self.register_buffer("alphas_cumprod_prev", F.pad(self.alphas_cumprod[:-1], (1, 0), value=1.0))
+        self.register_buffer("sqrt_recip_alphas", torch.sqrt(1.0 / self.alphas))
+        self.register_buffer("sqrt_alphas_cumprod", torch.sqrt(self.alphas_cumprod))
+        self.register_buffer("sqrt_recip_alphas_cumprod",
+                             torch.from_numpy(np.sqrt((1.0 / self.alphas_cumprod).numpy())))
+        self.register_buffer("sqrt_recipm1_alphas_cumprod",
+                             torch.from_numpy(np.sqrt((1.0 / self.alphas_cumprod - 1).numpy())))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", torch.sqrt(1.0 - self.alphas_cumprod))
+        self.register_buffer("posterior_variance",
+                             self.betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod))
+        self.steps = steps
+        self.input_channels = input_channels
+        self.output_channels = output_channels
+        self.backbone = backbone
+        self.n_layers = n_layers
+        self.architecture = architecture
+        self.init_backbone()
+        self.save_hyperparameters()
+
+    def init_backbone(self):
+        """spatial_diffusion.py:334-357."""
+        extra = 2 if self.rotation else 0
+        kw = dict(steps=self.steps, input_channels=self.input_channels + extra,
+                  output_channels=self.output_channels + extra, model=self.backbone,
+                  architecture=self.architecture, n_layers=self.n_layers, virt_nodes=self.virt_nodes)
+        if self.rotation:
+            self.model = Eff_GAT(all_equivariant=self.all_equivariant, **kw)
+        else:
+            self.model = Eff_GAT(visual_pretrained=self.visual_pretrained, freeze_backbone=self.free_backbone, **kw)
+
+    def initialize_torchmetrics(self, n_patches):
+        metrics = {}
+        for i in n_patches:
+            metrics[f"{i}_acc"] = MeanMetric()
+            metrics[f"{i}__piece_acc"] = MeanMetric()
+            metrics[f"{i}_nImages"] = SumMetric()
+        metrics["overall_acc"] = MeanMetric()
+        metrics["overall__piece_acc"] = MeanMetric()
+        metrics["overall_nImages"] = SumMetric()
+        self.metrics = nn.ModuleDict(metrics)
+
+    # ------------------------------------------------------------------ operators
+    def _mean_type(self):
+        return _lib.MEAN_START_X if self.model_mean_type == ModelMeanType.START_X else _lib.MEAN_EPSILON
+
+    def _schedule(self):
+        key = (self.betas.data_ptr(), str(self.betas.device), self.steps)
+        if getattr(self, "_sched_key", None) != key:
+            self._sched = Schedule({k: getattr(self, k) for k in Schedule.KEYS}, self.betas.device)
+            self._sched_key = key
+        return self._sched
+
+    def forward(self, xy_pos, time, patch_rgb, edge_index, batch) -> Any:
+        return self.model(xy_pos, time, patch_rgb, edge_index, batch)
+
+    def forward_with_feats(self, xy_pos: Tensor, time: Tensor, patch_rgb: Tensor, edge_index: Tensor,
+                           patch_feats: Tensor, batch, return_attentions=False) -> Any:
+        """spatial_diffusion.py:393-408."""
+        self.model.return_attentions = bool(return_attentions)
+        out, attentions = self.model.forward_with_feats(xy_pos, time, patch_rgb, edge_index, patch_feats, batch)
+        if return_attentions:
+            return out, attentions
+        return out
+
+    def visual_features(self, patch_rgb):
+        return self.model.visual_features(patch_rgb)
+
+    def q_sample(self, x_start, t, noise=None):
+        """spatial_diffusion.py:421-430 (training-side elementwise glue)."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return (extract(self.sqrt_alphas_cumprod, t) * x_start
+                + extract(self.sqrt_one_minus_alphas_cumprod, t) * noise)
+
+    def p_losses(self, x_start, t, noise=None, loss_type="l1", cond=None, edge_index=None, batch=None):
+        raise NotImplementedError(
+            "training (p_losses -> denoiser backward) is not built yet: DESIGN.md, 'what comes next'")
+
+    @torch.no_grad()
+    def p_sample_ddpm(self, x, t, t_index, cond, edge_index, patch_feats, batch):
+        """spatial_diffusion.py:485-510 (returns a bare tensor, like the reference)."""
+        out = self.forward_with_feats(x, t, cond, edge_index, patch_feats=patch_feats, batch=batch)
+        noise = None if t_index == 0 else torch.randn_like(x)
+        return self.model.engine(x.device).ddpm_step(self._schedule(), x, out, t, noise)
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, t, t_index, cond, edge_index, patch_feats, batch):
+        """spatial_diffusion.py:548-627."""
+        want_att = self.return_attentions
+        r = self.forward_with_feats(x, t, cond, edge_index, patch_feats=patch_feats, batch=batch,
+                                    return_attentions=want_att)
+        model_output, attentions = r if want_att else (r, None)
+        if self.classifier_free_prob > 0.0:
+            unc = self.forward_with_feats(x, t, cond, edge_index, patch_feats=torch.zeros_like(patch_feats),
+                                          batch=batch)
+            model_output = (1 + self.classifier_free_w) * model_output - self.classifier_free_w * unc
+        noise = torch.randn_like(x) if self.eta > 0 else None
+        prev = self.model.engine(x.device).ddim_step(self._schedule(), x, model_output, t, self.inference_ratio,
+                                                     self._mean_type(), float(self.eta), noise)
+        return prev, attentions
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, cond, edge_index, batch, patch_feats=None):
+        """spatial_diffusion.py:635-676.  ``patch_feats`` may be passed to bypass the encoder."""
+        device = self.device
+        img = torch.randn(shape, device=device) * self.noise_weight
+        if patch_feats is None:
+            patch_feats = self.visual_features(cond)
+        its = list(reversed(range(0, self.steps, self.inference_ratio)))
+        fast = (self.sampling == "DDIM" and self.eta == 0 and not self.return_attentions
+                and not self.classifier_free_prob > 0.0)
+        if fast:
+            eng = self.model.engine(device)
+            plan = self.model._plan_for(eng, edge_index, batch)
+            self.model._feat_key = None
+            traj, _ = eng.sample_loop(plan, self._schedule(), img, patch_feats, ratio=self.inference_ratio,
+                                      mean_type=self._mean_type(), keep_trajectory=True,
+                                      use_graph=self.use_hip_graph)
+            return list(traj.clone().unbind(0)), [None] * len(its)
+        imgs, attentions = [], []
+        b = shape[0]
+        for i in its:
+            t = torch.full((b,), i, device=device, dtype=torch.long)
+            if self.sampling == "DDPM":
+                img, atts = self.p_sample_ddpm(img, t, i, cond, edge_index, patch_feats, batch), None
+            else:
+                img, atts = self.p_sample_ddim(img, t, i, cond, edge_index, patch_feats, batch)
+            attentions.append(atts)
+            imgs.append(img)
+        return imgs, attentions
+
+    @torch.no_grad()
+    def p_sample(self, x, t, t_index, cond, edge_index, sampling_func, patch_feats, batch):
+        return sampling_func(x, t, t_index, cond, edge_index, patch_feats, batch)
+
+    @torch.no_grad()
+    def sample(self, image_size, batch_size=16, channels=3, cond=None, edge_index=None, batch=None):
+        return self.p_sample_loop(shape=(batch_size, channels, image_size, image_size), cond=cond,
+                                  edge_index=edge_index, batch=batch)
+
+    # ------------------------------------------------------------------ Lightning hooks (callers)
+    def configure_optimizers(self):
+        from transformers.optimization import Adafactor
+        return Adafactor(self.parameters())
+
+    def training_step(self, batch, batch_idx):
+        """spatial_diffusion.py:707-766 (image dumps omitted)."""
+        batch_size = batch.batch.max().item() + 1
+        t = torch.randint(0, self.steps, (batch_size,), device=self.device).long()
+        new_t = torch.gather(t, 0, batch.batch)
+        loss = self.p_losses(batch.x, new_t, loss_type="huber", cond=batch.patches,
+                             edge_index=batch.edge_index, batch=batch.batch)
+        self.log("loss", loss)
+        return loss
+
+    @torch.no_grad()
+    def prediction_step(self, batch, batch_idx):
+        return self.p_sample_loop(batch.x.shape, batch.patches, batch.edge_index, batch=batch.batch)
+
+    def predict_step(self, batch, batch_idx, dataloader_idx=0):
+        return self.prediction_step(batch, batch_idx)
+
+    @torch.no_grad()
+    def _eval_step(self, batch, batch_idx):
+        """validation_step / test_step, spatial_diffusion.py:775-903,915-: sampling loop, greedy
+        assignment of predicted positions to the grid, puzzle / piece accuracy."""
+        imgs, _ = self.p_sample_loop(batch.x.shape, batch.patches, batch.edge_index, batch=batch.batch,
+                                     patch_feats=getattr(batch, "patch_feats", None))
+        img = imgs[-1]
+        for i in range(int(batch.batch.max()) + 1):
+            idx = torch.where(batch.batch == i)[0]
+            gt_pos, pos = batch.x[idx, :2], img[idx, :2]
+            n_patches = batch.patches_dim[i].tolist()
+            y = torch.linspace(-1, 1, n_patches[0], device=self.device)
+            x = torch.linspace(-1, 1, n_patches[1], device=self.device)
+            real_grid = torch.stack(torch.meshgrid(x, y, indexing="xy"), -1).reshape(-1, 2)
+            gt_ass = greedy_cost_assignment(gt_pos, real_grid)
+            gt_ass = gt_ass[torch.sort(gt_ass[:, 0])[1]]
+            pred_ass = greedy_cost_assignment(pos, real_grid)
+            pred_ass = pred_ass[torch.sort(pred_ass[:, 0])[1]]
+            piece_accuracy = (gt_ass[:, 1] == pred_ass[:, 1]).to(self.device)
+            correct = bool(piece_accuracy.all())
+            if self.rotation:
+                rot_correct = torch.cosine_similarity(img[idx, 2:], batch.x[idx, 2:]) > math.cos(math.pi / 4)
+                correct = correct and bool(rot_correct.all())
+                piece_accuracy = rot_correct * piece_accuracy
+            if hasattr(self, "metrics"):
+                key = f"{tuple(n_patches)}"
+                for name, val in ((f"{key}_acc", float(correct)), (f"{key}__piece_acc", piece_accuracy.float()),
+                                  (f"{key}_nImages", 1), ("overall_acc", float(correct)),
+                                  ("overall__piece_acc", piece_accuracy.float()), ("overall_nImages", 1)):
+                    if name in self.metrics:
+                        self.metrics[name].update(val)
+        return img
+
+    def validation_step(self, batch, batch_idx):
+        return self._eval_step(batch, batch_idx)
+
+    def test_step(self, batch, batch_idx):
+        return self._eval_step(batch, batch_idx)
+
+    def validation_epoch_end(self, outputs) -> None:
+        if hasattr(self, "metrics"):
+            self.log_dict({k: m.compute() for k, m in self.metrics.items()})
+
+    def test_epoch_end(self, outputs) -> None:
+        return self.validation_epoch_end(outputs)

@@ -1,0 +1,213 @@
+/*
+ * diffassemble_hip.h -- C ABI of libdiffassemble_hip.so (gfx950 / MI355X).
+ *
+ * The reference (IIT-PAVIS/DiffAssemble) is 100 % Python and has NO FFI layer for this
+ * path: its "operator interface" is Python-level.  This header is therefore
+ * the boundary the build defines.  Each entry point cites the reference code it replaces
+ * (paths relative to /root/reference/puzzle_diff/model/).  Conventions:
+ *
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked "host";
+ *   - the library BORROWS caller (PyTorch) storage for the duration of a call and never
+ *     frees it; the only memory it owns are the packed weights of a da_denoiser;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises, nothing allocates inside a forward/step call (the caller passes a
+ *     workspace sized by da_denoiser_workspace_bytes), so calls are stream-capturable;
+ *   - every function returns 0 on success, nonzero on error (da_last_error() has the text);
+ *   - re-entrant per (denoiser, workspace, stream).
+ *
+ * Tensor layouts are row-major.  "act dtype" is fp32 in DA_PREC_F32 (parity mode,
+ * 1e-4 relative vs the fp32 oracle) and bf16 in DA_PREC_BF16 (perf mode, fp32 accumulate).
+ */
+#ifndef DIFFASSEMBLE_HIP_H
+#define DIFFASSEMBLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DA_ABI_VERSION 1
+
+enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
+enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
+enum { DA_ARCH_TRANSFORMER = 0, DA_ARCH_EXOPHORMER = 1 }; /* GELU between convs / none      */
+enum { DA_MEAN_EPSILON = 0, DA_MEAN_START_X = 1 };       /* spatial_diffusion.py:63-66      */
+enum { DA_ACT_NONE = 0, DA_ACT_GELU = 1, DA_ACT_LEAKY02 = 2 };
+enum { DA_MAX_LAYERS = 8 };
+
+int da_abi_version(void);
+const char *da_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Weights of one denoiser, fp32 device pointers in the reference's state-dict layout
+ * ([out, in] like nn.Linear).  Replaces: the parameters of backbones/efficient_gat.py:57-102
+ * (Eff_GAT) or backbones/efficient_gat_3d.py:99-152 (Eff_GAT_3d), incl. the PyG
+ * TransformerConv lin_{query,key,value,skip} of backbones/Transformer_GNN.py:9-25 and the
+ * virt_node_embedding of backbones/exophormer_gnn.py:158-159.
+ * ------------------------------------------------------------------------------------- */
+typedef struct da_weights {
+    int32_t variant;      /* DA_VARIANT_*                                                  */
+    int32_t arch;         /* DA_ARCH_*                                                     */
+    int32_t steps;        /* rows of time_emb                                              */
+    int32_t c_in;         /* pose channels in: 2 | 4 (2D), 7 (3D)                          */
+    int32_t c_out;        /* pose channels out: 2 | 4 (2D); 3D heads are 3 + 3             */
+    int32_t feat_dim;     /* piece-feature width F: 1088 (2D) / 768 (3D vn_dgcnn)          */
+    int32_t hidden;       /* mlp hidden width: 128 (2D) / 256 (3D)                         */
+    int32_t heads;        /* 8                                                             */
+    int32_t n_layers;     /* 4                                                             */
+    int32_t virt_nodes;   /* V (exophormer), else 0                                        */
+    const float *time_emb;                  /* [steps, 32]                                  */
+    const float *pos_w0, *pos_b0;           /* [16, c_in], [16]                             */
+    const float *pos_w1, *pos_b1;           /* [32, 16], [32]                               */
+    const float *mlp_w0, *mlp_b0;           /* [hidden, D], [hidden]      D = F + 64        */
+    const float *mlp_w1, *mlp_b1;           /* [D, hidden], [D]                             */
+    const float *conv_wq[DA_MAX_LAYERS], *conv_bq[DA_MAX_LAYERS];   /* [H*C_l, Din_l], [H*C_l] */
+    const float *conv_wk[DA_MAX_LAYERS], *conv_bk[DA_MAX_LAYERS];
+    const float *conv_wv[DA_MAX_LAYERS], *conv_bv[DA_MAX_LAYERS];
+    const float *conv_ws[DA_MAX_LAYERS], *conv_bs[DA_MAX_LAYERS];
+    const float *virt_emb;                  /* [V, D] or NULL                               */
+    const float *head_w0, *head_b0;         /* 2D final_mlp.0 [32, D]; 3D mlp_t.0 [256, D]  */
+    const float *head_w1, *head_b1;         /* 2D final_mlp.2 [c_out, 32]; 3D mlp_t.2 [3,256] */
+    const float *head_r_w0, *head_r_b0;     /* 3D mlp_r.0 [256, D] (NULL in 2D)             */
+    const float *head_r_w1, *head_r_b1;     /* 3D mlp_r.2 [3, 256]                          */
+} da_weights;
+
+/* ---------------------------------------------------------------------------------------
+ * Piece graph of one Batch.  Replaces: the PyG `edge_index` / `batch` arguments of
+ * Eff_GAT.forward_with_feats (efficient_gat.py:121-129).  Built once per Batch by the host
+ * (diffassemble_amd/graph_plan.py) from edge_index[2,E] (row 0 = source j, row 1 = target i):
+ *   CSR by destination: incoming edges of node i are col_src[row_ptr[i] .. row_ptr[i+1]),
+ *   multi-edges kept (PyG softmax semantics); edge_id[] maps a CSR slot to its position in
+ *   the caller's edge_index (for the alpha[E,H] output).  For the exophormer arch the
+ *   host appends the V*G virtual rows and the quirky virtual edges of
+ *   exophormer_gnn.py:167-200 before building the CSR: n_nodes counts them, n_real does not.
+ *   dense != 0 declares that every graph is complete (self loops iff dense == 1, none iff
+ *   dense == 2), which lets the library take the block-diagonal MFMA attention kernel;
+ *   graph_ptr[G+1] are the node offsets of the graphs (required when dense != 0).
+ * ------------------------------------------------------------------------------------- */
+typedef struct da_graph {
+    int32_t n_nodes;          /* rows processed by the convs (real + virtual)              */
+    int32_t n_real;           /* real pieces (rows of x / feats / out)                     */
+    int32_t n_graphs;
+    int32_t dense;            /* 0 = CSR only, 1 = complete + self loops, 2 = complete w/o */
+    int64_t n_edges;
+    const int32_t *row_ptr;   /* [n_nodes + 1]                                             */
+    const int32_t *col_src;   /* [n_edges]                                                 */
+    const int32_t *edge_id;   /* [n_edges] or NULL                                         */
+    const int32_t *graph_ptr; /* [n_graphs + 1] or NULL                                    */
+    int32_t max_graph_nodes;  /* largest graph (dense mode tiling)                         */
+} da_graph;
+
+typedef struct da_denoiser da_denoiser;
+
+/* Pack the weights into the library's own device buffers (act dtype; Q|K|V|skip fused per
+ * layer).  Allocates (hipMalloc) -- not capturable; call once per checkpoint load.          */
+int da_denoiser_create(const da_weights *w, int precision, void *stream, da_denoiser **out);
+void da_denoiser_destroy(da_denoiser *d);
+
+/* Bytes of caller-provided workspace needed for a graph of this size.                      */
+size_t da_denoiser_workspace_bytes(const da_denoiser *d, const da_graph *g);
+
+/* Once per Batch (features are loop-invariant: spatial_diffusion.py:653 computes them once
+ * per p_sample_loop): converts piece features [n_real, F] fp32 into the workspace and
+ * writes the virtual-node rows.  Must precede da_denoiser_forward on that workspace.       */
+int da_denoiser_set_features(da_denoiser *d, const da_graph *g, const float *feats,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* One denoiser forward == Eff_GAT.forward_with_feats (efficient_gat.py:121-146) or
+ * Eff_GAT_3d.forward_with_feats (efficient_gat_3d.py:173-220), encoder bypassed.
+ *   x      [n_real, c_in] fp32 noisy poses
+ *   t      [n_real] int64 per-node timestep (reference contract), or NULL => t_scalar
+ *   out    [n_real, c_out] fp32 (3D: [n_real, 7] = unit quaternion wxyz | translation)
+ *   alpha  NULL, or fp32 attention weights in the caller's edge order (needs g->edge_id):
+ *          alpha_all_layers == 0: [n_edges, heads] of the LAST conv (what Exophormer_GNN
+ *          returns, exophormer_gnn.py:205-215); != 0: [n_layers, n_edges, heads], every conv
+ *          (what Transformer_GNN returns, Transformer_GNN.py:32-41)
+ *   pre_head    NULL or [n_real, 6] fp32 (3D only): raw (r_pred, t_pred) before exp/quat   */
+int da_denoiser_forward(da_denoiser *d, const da_graph *g, const float *x, const int64_t *t,
+                        int64_t t_scalar, float *out, float *alpha, int alpha_all_layers,
+                        float *pre_head, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Diffusion schedule tables (fp32 [T] device pointers) == the registered buffers of
+ * GNN_Diffusion.__init__, spatial_diffusion.py:282-321.
+ * ------------------------------------------------------------------------------------- */
+typedef struct da_schedule {
+    int32_t steps;
+    const float *betas;
+    const float *alphas_cumprod;
+    const float *sqrt_recip_alphas;
+    const float *sqrt_recip_alphas_cumprod;
+    const float *sqrt_recipm1_alphas_cumprod;
+    const float *sqrt_one_minus_alphas_cumprod;
+    const float *posterior_variance;
+} da_schedule;
+
+/* DDIM update after the model call == p_sample_ddim, spatial_diffusion.py:555-566,603-627
+ * (2D) / spatial_diffusion_3d_test_double_diffusion.py:595-685 (3D: variant = DA_VARIANT_3D,
+ * c = 7, SO(3) algebra of utils_3d.py:1018-1061 for the quaternion part).
+ *   x, model_out, x_prev: [n, c] fp32.  t per node or NULL => t_scalar.
+ *   prev_all_nonneg: the host-evaluated `(t - ratio >= 0).all()` branch of :560.
+ *   eta: 0 for DDIM; > 0 adds eta*sqrt(var)*noise ([n, c] fp32, may be NULL when eta == 0). */
+int da_ddim_step(const da_schedule *s, int variant, int mean_type, int n, int c, const float *x,
+                 const float *model_out, const int64_t *t, int64_t t_scalar, int inference_ratio,
+                 int prev_all_nonneg, float eta, const float *noise, float *x_prev, void *stream);
+
+/* DDPM update == p_sample_ddpm, spatial_diffusion.py:485-510 (noise NULL <=> t_index == 0). */
+int da_ddpm_step(const da_schedule *s, int n, int c, const float *x, const float *model_out,
+                 const int64_t *t, int64_t t_scalar, const float *noise, float *x_prev,
+                 void *stream);
+
+/* The whole sampling loop == p_sample_loop, spatial_diffusion.py:635-676 /
+ * ...double_diffusion.py:688-731: for i in reversed(range(0, steps, ratio)): forward + DDIM
+ * update.  x_init [n_real, c] fp32; traj (nullable) [n_iters, n_real, c] receives every
+ * step's poses (the reference keeps them all), x_final (nullable) the last.  max_iters <= 0
+ * runs all iterations.  With use_graph != 0 the iterations are recorded once into a hipGraph
+ * (cached inside the denoiser, keyed on the arguments) and replayed with one launch.       */
+int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int mean_type,
+                   int inference_ratio, int max_iters, const float *x_init, float *traj,
+                   float *x_final, void *workspace, size_t workspace_bytes, int use_graph,
+                   void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Measurement aid (no reference counterpart: the reference has no profiler hooks).
+ * While enabled, every kernel launch of da_denoiser_forward / da_sample_loop is bracketed by
+ * a hipEvent pair on the launch stream (the loop then runs eagerly, not as a hipGraph).
+ * da_profile_read synchronises, returns the summed milliseconds and launch counts per class
+ * and resets the pool.
+ * ------------------------------------------------------------------------------------- */
+enum {
+    DA_PROF_EMBED = 0,        /* pose MLP + timestep lookup                                  */
+    DA_PROF_LINEAR_MLP = 1,   /* mlp.0 / mlp.2                                               */
+    DA_PROF_LINEAR_QKVS = 2,  /* fused Q|K|V|skip projections                                */
+    DA_PROF_ATTN_HIDDEN = 3,  /* attention of convs 0..n-2 (C = 32)                          */
+    DA_PROF_ATTN_LAST = 4,    /* attention of the last conv (C = D/8)                        */
+    DA_PROF_HEAD = 5,         /* pose head                                                   */
+    DA_PROF_UPDATE = 6,       /* DDIM / DDPM update                                          */
+    DA_PROF_NCLASS = 7
+};
+int da_profile_enable(da_denoiser *d, int on);
+int da_profile_read(da_denoiser *d, float *ms /* [DA_PROF_NCLASS] host */,
+                    int32_t *counts /* [DA_PROF_NCLASS] host */);
+
+/* ---------------------------------------------------------------------------------------
+ * Kernel-level entry points (used by the kernel parity tests and the training autograd).
+ * ------------------------------------------------------------------------------------- */
+/* out[M, ldo] = act(A[M, K] @ W[Nout, K]^T + bias) (+ residual[M, ldo]); A, W, out, residual
+ * in act dtype `prec`, bias fp32.  Replaces torch.nn.Linear on the path.                   */
+int da_linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W,
+              const float *bias, int act, const void *residual, void *out, int ldo, void *stream);
+
+/* One PyG TransformerConv attention (Transformer_GNN.py:32,38) over a CSR graph:
+ *   qkvs [n_nodes, 4*H*C] act dtype (Q | K | V | skip), out [n_nodes, H*C] act dtype
+ *   out_i = sum_e softmax_i(q_i.k_j / sqrt(C)) v_j + skip_i (+ residual_i) ; act applied last.
+ *   alpha (nullable) [n_edges, H] fp32 in caller edge order via g->edge_id.                */
+int da_attn_csr(int prec, const da_graph *g, int heads, int C, const void *qkvs, const void *residual,
+                int act, void *out, float *alpha, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFASSEMBLE_HIP_H */
