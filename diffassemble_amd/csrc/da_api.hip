@@ -58,6 +58,8 @@ struct da_denoiser {
     // cached sampling-loop graphs (a few distinct loops, e.g. a full loop and a remainder)
     struct LoopEntry { LoopKey key; hipGraphExec_t exec; };
     std::vector<LoopEntry> loops;
+    hipStream_t cap_stream = nullptr;     // private stream used only to RECORD graphs (the caller's
+                                          // stream may be the legacy null stream, which cannot capture)
 };
 
 namespace da {
@@ -281,6 +283,7 @@ void da_denoiser_destroy(da_denoiser *d) {
     if (!d) return;
     for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);
     for (auto &e : d->loops) (void)hipGraphExecDestroy(e.exec);
+    if (d->cap_stream) (void)hipStreamDestroy(d->cap_stream);
     for (void *p : d->owned) (void)hipFree(p);
     delete d;
 }
@@ -394,9 +397,11 @@ int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int 
             d->loops.erase(d->loops.begin());
         }
         hipGraph_t graph = nullptr;
-        DA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        rc = enqueue_loop(d, g, s, mean_type, inference_ratio, n_iters, x_init, traj, x_final, w, st);
-        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (!d->cap_stream) DA_CHECK_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
+        hipStream_t cs = d->cap_stream;
+        DA_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+        rc = enqueue_loop(d, g, s, mean_type, inference_ratio, n_iters, x_init, traj, x_final, w, cs);
+        hipError_t e = hipStreamEndCapture(cs, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess || !graph) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return 2; }
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
