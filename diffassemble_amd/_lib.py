@@ -45,7 +45,8 @@ class DaGraph(C.Structure):
         ("n_nodes", C.c_int32), ("n_real", C.c_int32), ("n_graphs", C.c_int32), ("dense", C.c_int32),
         ("n_edges", C.c_int64),
         ("row_ptr", _fp), ("col_src", _fp), ("edge_id", _fp), ("graph_ptr", _fp),
-        ("max_graph_nodes", C.c_int32),
+        ("max_graph_nodes", C.c_int32), ("n_pad", C.c_int32),
+        ("pad_ptr", _fp), ("row_map", _fp),
     ]
 
 
@@ -78,6 +79,9 @@ PROTOTYPES = {
     "da_linear": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp,
                             C.c_int, _fp]),
     "da_attn_csr": (C.c_int, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp, _fp]),
+    "da_attn_dense_scratch_bytes": (C.c_size_t, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int]),
+    "da_conv_dense": (C.c_int, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int,
+                                _fp, _fp, _fp]),
 }
 
 _lib = None

@@ -1,5 +1,6 @@
 // C-ABI entry points of libdiffassemble_hip.so (include/diffassemble_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -66,6 +67,8 @@ namespace da {
 
 struct Workspace {
     char *comb_in, *h, *combined, *qkvs, *xa, *xb, *z, *hh;
+    char *dq, *dk, *dvt, *dskip;      // dense path: head-major Q, K, transposed V, row-major skip
+    size_t dense_off, dense_bytes;    // [dq, dq + dense_bytes) is zero-filled once per Batch
     float *model_out, *xbuf0, *xbuf1;
     size_t total;
 };
@@ -92,6 +95,17 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     w.xb = take(np * 256 * s);
     w.z = take(np * d->D * s);
     w.hh = take(nrp * d->head_hidden * s);
+    w.dq = w.dk = w.dvt = w.dskip = nullptr;
+    w.dense_off = off;
+    w.dense_bytes = 0;
+    if (g->dense && g->n_pad > 0) {
+        const size_t hb = ((size_t)g->n_pad + 64) * hcmax * s;
+        w.dq = take(hb);
+        w.dk = take(hb);
+        w.dvt = take(hb);
+        w.dense_bytes = off - w.dense_off;
+        w.dskip = take(np * (size_t)hcmax * s);
+    }
     const int cpose = d->variant == DA_VARIANT_3D ? 7 : d->c_out;
     w.model_out = (float *)take(nr * cpose * sizeof(float));
     w.xbuf0 = (float *)take(nr * 8 * sizeof(float));
@@ -100,9 +114,24 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     return w;
 }
 
+static bool mfma_disabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_DISABLE_MFMA"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, int act,
            const void *res, void *out, int ldo, hipStream_t st) {
+    if (!mfma_disabled()) {
+        const int rc = launch_gemm_mfma(prec, M, K, Nout, A, lda, W, bias, act, res, out, ldo, nullptr, st);
+        if (rc >= 0) return rc;
+    }
     return launch_gemm_simple(prec, M, K, Nout, A, lda, W, bias, act, res, out, ldo, st);
+}
+
+static bool dense_ok(const da_graph *g, int heads, int C) {
+    return g->dense && g->n_pad > 0 && g->graph_ptr && g->pad_ptr && g->row_map && heads == 8 &&
+           (C == 32 || C == 144) && !mfma_disabled();
 }
 
 static int check_graph(const da_denoiser *d, const da_graph *g) {
@@ -168,16 +197,35 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
     for (int l = 0; l < d->n_layers; ++l) {
         const ConvW &c = d->conv[l];
         const bool last = l == d->n_layers - 1;
-        if ((rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
-                 return linear(prec, n, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, w.qkvs, 4 * c.hc, st); }))) return rc;
         void *dst = last ? (void *)w.z : (void *)((l & 1) ? w.xb : w.xa);
         const int act = (!last && d->arch == DA_ARCH_TRANSFORMER) ? DA_ACT_GELU : DA_ACT_NONE;
-        // last layer: the residual `feats + combined_feats` (efficient_gat.py:144) is fused here
         float *al = !alpha ? nullptr
                            : (alpha_all ? alpha + (size_t)l * g->n_edges * d->heads : (last ? alpha : nullptr));
+        // last layer: the residual `feats + combined_feats` (efficient_gat.py:144) is fused in the epilogue
+        const void *resid = last ? w.combined : nullptr;
+        if (!al && w.dq && dense_ok(g, d->heads, c.C)) {
+            // complete graphs: projection scattered into head-major Q/K/V^T, block-diagonal MFMA attention
+            QkvScatter qs;
+            qs.HC = c.hc; qs.C = c.C; qs.n_pad = g->n_pad; qs.row_map = g->row_map;
+            qs.Q = w.dq; qs.K = w.dk; qs.Vt = w.dvt; qs.S = w.dskip;
+            rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
+                return launch_gemm_mfma(prec, n, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st); });
+            if (rc > 0) return rc;
+            if (rc == 0) {
+                DenseLayout L;
+                L.Q = w.dq; L.K = w.dk; L.Vt = w.dvt; L.S = w.dskip; L.n_pad = g->n_pad;
+                rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
+                    return launch_attn_dense(prec, L, d->heads, c.C, g->n_graphs, g->max_graph_nodes, g->graph_ptr,
+                                             g->pad_ptr, g->dense == 2, resid, act, dst, st); });
+                if (rc > 0) return rc;
+                if (rc == 0) { xin = dst; ldx = c.hc; continue; }
+            }
+        }
+        if ((rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
+                 return linear(prec, n, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, w.qkvs, 4 * c.hc, st); }))) return rc;
         if ((rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
                  return launch_attn_csr(prec, n, g->row_ptr, g->col_src, g->edge_id, d->heads, c.C, w.qkvs,
-                                        last ? w.combined : nullptr, act, dst, al, st); }))) return rc;
+                                        resid, act, dst, al, st); }))) return rc;
         xin = dst;
         ldx = c.hc;
     }
@@ -302,6 +350,8 @@ int da_denoiser_set_features(da_denoiser *d, const da_graph *g, const float *fea
     DA_REQUIRE(workspace_bytes >= w.total, "workspace too small: %zu < %zu", workspace_bytes, w.total);
     hipStream_t st = (hipStream_t)stream;
     if ((rc = launch_set_feats(d->prec, g->n_real, d->F, d->D, feats, w.comb_in, st))) return rc;
+    if (w.dense_bytes)      // padded rows / columns of the head-major buffers must be finite
+        DA_CHECK_HIP(hipMemsetAsync((char *)workspace + w.dense_off, 0, w.dense_bytes, st));
     if (d->V > 0) {
         char *dst = w.combined + (size_t)g->n_real * d->D * esize(d->prec);
         if ((rc = launch_set_virtual_rows(d->prec, g->n_nodes - g->n_real, d->V, d->D, d->virt_emb, dst, st))) return rc;
@@ -410,6 +460,34 @@ int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int 
         d->loops.push_back({key, exec});
     }
     DA_CHECK_HIP(hipGraphLaunch(exec, st));
+    return 0;
+}
+
+size_t da_attn_dense_scratch_bytes(int prec, const da_graph *g, int heads, int C) {
+    if (!g) return 0;
+    const size_t s = esize(prec), hc = (size_t)heads * C;
+    return 3 * align_up(((size_t)g->n_pad + 64) * hc * s, 256) + align_up(((size_t)g->n_nodes + 64) * hc * s, 256);
+}
+
+int da_conv_dense(int prec, const da_graph *g, int heads, int C, int Din, const void *x, const void *w,
+                  const float *b, const void *residual, int act, void *out, void *scratch, void *stream) {
+    DA_REQUIRE(g && x && w && out && scratch, "da_conv_dense: null argument");
+    DA_REQUIRE(dense_ok(g, heads, C), "da_conv_dense: graph is not dense or head width %d unsupported", C);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t s = esize(prec), hc = (size_t)heads * C;
+    const size_t hb = align_up(((size_t)g->n_pad + 64) * hc * s, 256);
+    char *base = (char *)scratch;
+    QkvScatter qs;
+    qs.HC = (int)hc; qs.C = C; qs.n_pad = g->n_pad; qs.row_map = g->row_map;
+    qs.Q = base; qs.K = base + hb; qs.Vt = base + 2 * hb; qs.S = base + 3 * hb;
+    int rc = launch_gemm_mfma(prec, g->n_nodes, Din, 4 * (int)hc, x, Din, w, b, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st);
+    DA_REQUIRE(rc <= 0, "da_conv_dense: projection launch failed");
+    DA_REQUIRE(rc == 0, "da_conv_dense: projection shape (Din=%d, HC=%d) not supported by the MFMA kernel", Din, (int)hc);
+    DenseLayout L;
+    L.Q = qs.Q; L.K = qs.K; L.Vt = qs.Vt; L.S = qs.S; L.n_pad = g->n_pad;
+    rc = launch_attn_dense(prec, L, heads, C, g->n_graphs, g->max_graph_nodes, g->graph_ptr, g->pad_ptr,
+                           g->dense == 2, residual, act, out, st);
+    DA_REQUIRE(rc == 0, "da_conv_dense: attention launch failed (%d)", rc);
     return 0;
 }
 

@@ -37,6 +37,22 @@ int launch_head3d(int prec, int n, const void *hh, const float *wt, const float 
 int launch_ddim3d(const DeviceSchedule &s, int mean_type, int n, const float *x, const float *mo, const int64_t *t,
                   int64_t t_scalar, int ratio, int prev_all_nonneg, float *x_prev, hipStream_t st);
 
+// da_gemm_mfma.hip / da_attn_dense.hip (dense block-diagonal path)
+struct QkvScatter {            // where the fused projection scatters its four column blocks
+    int HC, C, n_pad;
+    const int32_t *row_map;    // node -> padded row
+    void *Q, *K, *Vt, *S;      // [H][n_pad][C], [H][n_pad][C], [H][C][n_pad], [M][H*C]
+};
+struct DenseLayout {
+    const void *Q, *K, *Vt, *S;
+    int n_pad;
+};
+int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
+                     int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st);
+int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes,
+                      const int32_t *graph_ptr, const int32_t *pad_ptr, int nodiag, const void *res, int act,
+                      void *out, hipStream_t st);
+
 // generic linear dispatch (MFMA when the shape allows, else simple)
 int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, int act,
            const void *res, void *out, int ldo, hipStream_t st);

@@ -262,3 +262,23 @@ def attn_csr(plan: GraphPlan, qkvs, heads, C_head, residual=None, act=_lib.ACT_N
     _lib.check(_lib.lib().da_attn_csr(prec, C.byref(g), heads, C_head, _lib.ptr(qkvs), _lib.ptr(r), int(act),
                                       _lib.ptr(out), _lib.ptr(alpha), _lib.stream_ptr(qkvs.device)))
     return (out, alpha) if return_alpha else out
+
+
+def conv_dense(plan: GraphPlan, x, weight, bias, heads, C_head, residual=None, act=_lib.ACT_NONE, precision="fp32"):
+    """One TransformerConv layer on COMPLETE graphs through the dense MFMA path (da_conv_dense):
+    x [N, Din], weight [4*H*C, Din] (rows Q|K|V|skip), bias [4*H*C]."""
+    prec = _PREC[precision]
+    dt = torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32
+    x = x.to(dt).contiguous()
+    weight = weight.to(dt).contiguous()
+    bias = bias.float().contiguous()
+    g = plan.c_struct()
+    lib = _lib.lib()
+    nbytes = int(lib.da_attn_dense_scratch_bytes(prec, C.byref(g), heads, C_head))
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty((plan.n_nodes, heads * C_head), dtype=dt, device=x.device)
+    r = None if residual is None else residual.to(dt).contiguous()
+    _lib.check(lib.da_conv_dense(prec, C.byref(g), heads, C_head, x.shape[1], _lib.ptr(x), _lib.ptr(weight),
+                                 _lib.ptr(bias), _lib.ptr(r), int(act), _lib.ptr(out), _lib.ptr(scratch),
+                                 _lib.stream_ptr(x.device)))
+    return out

@@ -53,6 +53,9 @@ class GraphPlan:
     col_src: torch.Tensor      # int32 [E]
     edge_id: torch.Tensor      # int32 [E]
     graph_ptr: torch.Tensor    # int32 [G + 1]
+    n_pad: int                 # dense mode: rows of the head-major Q/K/V^T buffers
+    pad_ptr: torch.Tensor      # int32 [G + 1] (64-aligned slot of each graph)
+    row_map: torch.Tensor      # int32 [n_nodes] node -> padded row
     edge_index: torch.Tensor   # int64 [2, E] (extended for exophormer) -- returned with alpha
 
     def c_struct(self):
@@ -64,6 +67,9 @@ class GraphPlan:
         g.edge_id = self.edge_id.data_ptr()
         g.graph_ptr = self.graph_ptr.data_ptr()
         g.max_graph_nodes = self.max_graph_nodes
+        g.n_pad = self.n_pad
+        g.pad_ptr = self.pad_ptr.data_ptr()
+        g.row_map = self.row_map.data_ptr()
         return g
 
 
@@ -89,7 +95,14 @@ def build_plan(edge_index, batch, virt_nodes=0, detect_dense=True):
     perm = torch.argsort(dst, stable=True)          # keeps the caller's order inside a segment
     row_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
     row_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_nodes), 0)
+    padded = (counts + 63) // 64 * 64
+    pad_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    pad_ptr[1:] = torch.cumsum(padded, 0)
+    row_map = torch.arange(N, device=dev) - graph_ptr[batch] + pad_ptr[batch]
+    if n_nodes > N:                                   # virtual rows (never on the dense path)
+        row_map = torch.cat([row_map, torch.zeros(n_nodes - N, dtype=row_map.dtype, device=dev)])
     return GraphPlan(
+        n_pad=int(pad_ptr[-1]), pad_ptr=pad_ptr.to(torch.int32), row_map=row_map.to(torch.int32).contiguous(),
         n_nodes=n_nodes, n_real=N, n_graphs=G, dense=dense, n_edges=E,
         max_graph_nodes=int(counts.max()) if G else 0,
         row_ptr=row_ptr.to(torch.int32), col_src=src[perm].to(torch.int32).contiguous(),

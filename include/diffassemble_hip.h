@@ -98,6 +98,12 @@ typedef struct da_graph {
     const int32_t *edge_id;   /* [n_edges] or NULL                                         */
     const int32_t *graph_ptr; /* [n_graphs + 1] or NULL                                    */
     int32_t max_graph_nodes;  /* largest graph (dense mode tiling)                         */
+    /* dense mode only: every graph gets a 64-aligned slot of rows in the head-major Q/K/V^T
+     * buffers: pad_ptr[g] = first padded row of graph g, n_pad = pad_ptr[G], row_map[i] =
+     * padded row of node i.                                                               */
+    int32_t n_pad;
+    const int32_t *pad_ptr;   /* [n_graphs + 1] or NULL                                    */
+    const int32_t *row_map;   /* [n_nodes] or NULL                                         */
 } da_graph;
 
 typedef struct da_denoiser da_denoiser;
@@ -206,6 +212,15 @@ int da_linear(int prec, int M, int K, int Nout, const void *A, int lda, const vo
  *   alpha (nullable) [n_edges, H] fp32 in caller edge order via g->edge_id.                */
 int da_attn_csr(int prec, const da_graph *g, int heads, int C, const void *qkvs, const void *residual,
                 int act, void *out, float *alpha, void *stream);
+
+/* The same layer through the dense block-diagonal MFMA path (g->dense != 0): fused projection
+ * qkvs = x[n_nodes, Din] @ w[4*H*C, Din]^T + b scattered into head-major Q / K / V^T, then the
+ * flash-style attention kernel.  scratch: caller memory of da_attn_dense_scratch_bytes(),
+ * zero-filled once by the caller before first use.  Returns nonzero (and an error text) if the
+ * shape is not supported by the dense kernels.                                              */
+size_t da_attn_dense_scratch_bytes(int prec, const da_graph *g, int heads, int C);
+int da_conv_dense(int prec, const da_graph *g, int heads, int C, int Din, const void *x, const void *w,
+                  const float *b, const void *residual, int act, void *out, void *scratch, void *stream);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,36 @@ def test_da_attn_csr_matches_pyg_semantics(dev, C_head, prec):
     assert rel(al, alpha) < (1e-5 if prec == "fp32" else 1e-2)
 
 
+@pytest.mark.parametrize("C_head,Din", [(32, 256), (144, 256), (32, 1152)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("loops", [True, False])
+def test_da_conv_dense_matches_pyg_semantics(dev, C_head, Din, prec, loops):
+    """Dense block-diagonal MFMA path (projection scattered head-major + flash attention) on ragged
+    complete graphs, including sizes that are not multiples of any tile (tail masking) and graphs
+    without self loops (diagonal masking), against the edge-list oracle."""
+    from diffassemble_amd import engine as E
+    from diffassemble_amd.graph_plan import build_plan
+    H = 8
+    sizes = [37, 130, 64, 1, 200] if loops else [37, 130, 64, 2, 200]
+    N = sum(sizes)
+    g = torch.Generator().manual_seed(C_head + Din)
+    ei, batch = W.collate([W.dense_edge_index(n, loops) for n in sizes], sizes)
+    x = torch.randn(N, Din, generator=g)
+    HC = H * C_head
+    ws = [torch.randn(HC, Din, generator=g) / Din ** 0.5 * (3.0 if k < 2 else 1.0) for k in range(4)]
+    bs = [torch.randn(HC, generator=g) * 0.1 for _ in range(4)]
+    res = torch.randn(N, HC, generator=g)
+    if prec == "bf16":
+        x, res = x.bfloat16().float(), res.bfloat16().float()
+        ws = [w.bfloat16().float() for w in ws]
+    ref, _ = R.transformer_conv(x, ei, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], ws[3], bs[3], H)
+    ref = torch.nn.functional.gelu(ref + res)
+    plan = build_plan(ei.to(dev), batch.to(dev), 0)
+    assert plan.dense == (1 if loops else 2)
+    out = E.conv_dense(plan, x.to(dev), torch.cat(ws).to(dev), torch.cat(bs).to(dev), H, C_head, res.to(dev), 1, prec)
+    assert rel(out.float(), ref) < (2e-5 if prec == "fp32" else 2e-2)
+
+
 # ---------------------------------------------------------------------------- 2D forward
 @pytest.mark.parametrize("spec", C.FWD2D, ids=lambda s: s["name"])
 def test_forward_2d_fp32_vs_oracle_and_golden(dev, golden, spec):
@@ -97,6 +127,10 @@ def test_forward_2d_fp32_vs_oracle_and_golden(dev, golden, spec):
     assert rel(out, ref) < RTOL32
     assert rel(out, golden[f"{n}/out"]) < RTOL32                    # the reference's own output
     assert torch.equal(plan.edge_index.cpu(), att[-1][0])
+    # without the alpha request complete graphs take the dense MFMA path: same answer
+    out_d = eng.forward(plan, case["x"].to(dev), case["t"].to(dev), None)
+    assert rel(out_d, golden[f"{n}/out"]) < RTOL32
+    assert plan.dense == {"dense": 1, "dense_noloop": 2}.get(spec["graph"], 0) * (spec["arch"] == "transformer")
     if all_layers:
         for l in range(4):
             assert rel(alpha[l], att[l][1]) < RTOL32, l

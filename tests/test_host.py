@@ -36,12 +36,28 @@ def test_single_hip_runtime_is_mapped():
     assert len(rts) == 1, rts        # ours binds to the runtime torch already loaded
 
 
-def test_struct_layouts_match_header_sizes():
+def test_struct_layouts_match_the_c_header(tmp_path):
+    """Compile the public header with plain gcc and compare sizeof / offsetof of every struct
+    with the ctypes mirror in diffassemble_amd/_lib.py."""
     import ctypes
+    import subprocess
     from diffassemble_amd import _lib
-    assert ctypes.sizeof(_lib.DaWeights) == 40 + 8 * (9 + 8 * 8 + 1 + 8)
-    assert ctypes.sizeof(_lib.DaGraph) == 16 + 8 + 4 * 8 + 8
-    assert ctypes.sizeof(_lib.DaSchedule) == 8 + 7 * 8
+    structs = {"da_weights": _lib.DaWeights, "da_graph": _lib.DaGraph, "da_schedule": _lib.DaSchedule}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "diffassemble_hip.h"\nint main(void){'
+                   + "".join(lines) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
 
 
 @pytest.mark.parametrize("sizes,V", [([144], 4), ([144, 144], 8), ([64, 36], 4), ([5, 9, 2], 3)])
