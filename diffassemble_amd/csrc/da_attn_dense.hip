@@ -7,24 +7,30 @@
 //
 // flash-style: the n x n score matrix never exists; per (graph, head, 128-query tile) workgroup the
 // K / V^T tiles stream through LDS and each of the 4 waves owns 32 queries.
-//   S^T = K_tile . Q^T      (32 keys x 32 queries per MFMA chain; A = K rows from LDS, B = Q rows
-//                            held in registers for the whole kernel)
-//   each lane then holds ONE query column: running max / sum are lane-local plus a single
-//   cross-half exchange, and P needs NO data movement to become the B operand of
-//   O^T += V^T_tile . P^T   (A = V^T rows from LDS: V is produced already transposed by the
-//                            projection GEMM, so these are plain 8/16-byte LDS reads)
-// with a consistent permutation of the k-slots (key (r&3)+8(r>>2)+4*half <-> slot) on both
-// operands.  bf16: v_mfma_f32_32x32x16_bf16; fp32 parity mode: v_mfma_f32_32x32x2_f32 (exact).
-// LDS rows are padded to an odd number of 16-B (K, read b128) / 8-B (V^T bf16, read b64) slots,
-// which makes every fragment read bank-conflict free.  Global -> LDS is register staged: tile t+1
-// is in flight while tile t is multiplied.  Workgroup ids are remapped so that the 8 query tiles of
-// one (graph, head) run back to back on ONE XCD and share its L2 copy of K / V^T.
+//   S^T = K_tile . Q^T      32 keys x 32 queries per MFMA chain; A = K rows from LDS, B = Q rows held
+//                           in registers for the whole kernel.  MFMA row rho of a 32-key block is fed
+//                           key pi(rho) = (rho&3) + 4((rho>>3)&3) + 16((rho>>2)&1), so that with the
+//                           32x32 accumulator layout lane (q, half) ends up holding the 16
+//                           CONSECUTIVE keys 16*half .. 16*half+15 of query q.
+//   softmax                 running max / sum are lane-local plus one cross-half exchange; the
+//                           accumulator rescale is skipped while the running max grows by < 2^8.
+//   O^T += V^T_tile . P^T   P needs NO data movement to become the B operand; A = V^T rows from LDS
+//                           (V is produced already transposed by the projection GEMM), one 16-byte
+//                           read per MFMA thanks to the key permutation above.
+// bf16: v_mfma_f32_32x32x16_bf16; fp32 parity mode: v_mfma_f32_32x32x2_f32 (exact fp32).
+// LDS rows are padded to an odd number of 16-byte slots (K: C*es + 16, V^T: 128 + 16), which makes
+// every ds_read_b128 fragment read conflict free.  Global -> LDS is LDS-DMA (global_load_lds_dwordx4):
+// the padded image is produced by per-lane SOURCE addresses (pad slots re-load a dummy piece), two
+// stages, tile t+1 in flight under the MFMAs of tile t, one barrier per tile.
+// Workgroup ids are remapped so that the query tiles of one (graph, head) run back to back on ONE
+// XCD and share its L2 copy of K / V^T.
 #include "da_common.h"
 #include "da_internal.h"
 
 namespace da {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -43,15 +49,18 @@ template <typename T, int C> struct Cfg {
     static constexpr int ES = (int)sizeof(T);
     static constexpr int ROWB = C * ES;                       // bytes of one K / Q row
     static constexpr int NCH = ROWB / 32;                     // 32-byte K-dim chunks
-    static constexpr int RS = ROWB + (((ROWB / 16) & 1) ? 0 : 16);
-    static constexpr int BKEYS = ES == 2 ? 64 : 32;           // keys per LDS tile
+    static constexpr int RS = ROWB + (((ROWB / 16) & 1) ? 0 : 16);   // odd number of 16-B slots
+    static constexpr int KSPR = RS / 16;                      // LDS slots per K row
+    static constexpr int KVALID = ROWB / 16;                  // of which carry data
+    static constexpr int BKEYS = ES == 2 ? 64 : 32;           // keys per LDS tile (128 B of a V^T row)
     static constexpr int KB = BKEYS / 32;
-    static constexpr int VROWB = BKEYS * ES;                  // 128 bytes
-    static constexpr int RSV = ES == 2 ? VROWB + 8 : VROWB + 16;
+    static constexpr int RSV = 144;                           // V^T row: 128 B data + 16 B pad (9 slots)
     static constexpr int NCB = (C + 31) / 32;
-    static constexpr int KBYTES = BKEYS * RS, VBYTES = C * RSV;
-    static constexpr int NPK = BKEYS * ROWB / 16, NPV = C * (VROWB / 16);
-    static constexpr int RPK = (NPK + 255) / 256, RPV = (NPV + 255) / 256;
+    static constexpr int NIK = (BKEYS * KSPR + 63) / 64;      // DMA instructions (1 KB each) per tile
+    static constexpr int NIV = (C * 9 + 63) / 64;
+    static constexpr int NI = NIK + NIV;
+    static constexpr int MAXI = (NI + 3) / 4;                 // per wave
+    static constexpr int KBYTES = NIK * 1024, VBYTES = NIV * 1024, STAGE = KBYTES + VBYTES;
     static_assert(ROWB % 32 == 0, "head width must be a multiple of 32 bytes");
 };
 
@@ -68,15 +77,12 @@ __device__ __forceinline__ f32x16 mma_chunk(float, const u32x4 &a, const u32x4 &
     return c;
 }
 
-// ---- O^T[cb] += V^T rows . P^T for one 32-key block.  p[16] are this lane's probabilities.
-template <int RSV>
-__device__ __forceinline__ f32x16 mma_pv(bf16_t, const unsigned char *vrow, int kb, int half, const float (&p)[16], f32x16 o) {
+// ---- O^T[cb] += V^T rows . P^T for one 32-key block; p[16] = this lane's probabilities for keys
+// 16*half + 0..15 of the block.  vrow points at the V^T row of this lane, key 0 of the block.
+__device__ __forceinline__ f32x16 mma_pv(bf16_t, const unsigned char *vrow, int half, const float (&p)[16], f32x16 o) {
 #pragma unroll
     for (int mm = 0; mm < 2; ++mm) {
-        const int e0 = kb * 32 + 16 * mm + 4 * half;
-        const u32x2 lo = *(const u32x2 *)(vrow + e0 * 2);
-        const u32x2 hi = *(const u32x2 *)(vrow + (e0 + 8) * 2);
-        const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+        const u32x4 vf = *(const u32x4 *)(vrow + (16 * half + 8 * mm) * 2);
         bf16x8 pf;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pf[e] = (__bf16)p[8 * mm + e];
@@ -84,35 +90,32 @@ __device__ __forceinline__ f32x16 mma_pv(bf16_t, const unsigned char *vrow, int 
     }
     return o;
 }
-template <int RSV>
-__device__ __forceinline__ f32x16 mma_pv(float, const unsigned char *vrow, int kb, int half, const float (&p)[16], f32x16 o) {
+__device__ __forceinline__ f32x16 mma_pv(float, const unsigned char *vrow, int half, const float (&p)[16], f32x16 o) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        const f32x4 v4 = *(const f32x4 *)(vrow + (kb * 32 + 8 * jj + 4 * half) * 4);
+        const f32x4 v4 = *(const f32x4 *)(vrow + (16 * half + 4 * jj) * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[e], p[4 * jj + e], o, 0, 0, 0);
     }
     return o;
 }
 
-__device__ __forceinline__ void ld4(const float *s, float v[4]) { const float4 f = *(const float4 *)s; v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+__device__ __forceinline__ void ld4(const float *s, float v[4]) { const f32x4 f = *(const f32x4 *)s; v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3]; }
 __device__ __forceinline__ void ld4(const bf16_t *s, float v[4]) {
-    const uint2 u = *(const uint2 *)s;
-    v[0] = bf2f((bf16_t)(u.x & 0xffff)); v[1] = bf2f((bf16_t)(u.x >> 16));
-    v[2] = bf2f((bf16_t)(u.y & 0xffff)); v[3] = bf2f((bf16_t)(u.y >> 16));
+    const u32x2 u = *(const u32x2 *)s;
+    v[0] = bf2f((bf16_t)(u[0] & 0xffff)); v[1] = bf2f((bf16_t)(u[0] >> 16));
+    v[2] = bf2f((bf16_t)(u[1] & 0xffff)); v[3] = bf2f((bf16_t)(u[1] >> 16));
 }
-__device__ __forceinline__ void st4(float *d, const float v[4]) { *(float4 *)d = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void st4(float *d, const float v[4]) { *(f32x4 *)d = (f32x4){v[0], v[1], v[2], v[3]}; }
 __device__ __forceinline__ void st4(bf16_t *d, const float v[4]) {
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-    bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-    *(uint2 *)d = __builtin_bit_cast(uint2, b);
+    const bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *(u32x2 *)d = __builtin_bit_cast(u32x2, b);
 }
 
 template <typename T, int C>
 __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     using CF = Cfg<T, C>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *sK = smem, *sV = smem + CF::KBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 stages x (K | V^T)
 
     // XCD-aware remap: hardware places workgroup b on XCD b % 8; give XCD x head x of every graph and
     // walk the query tiles of one (graph, head) consecutively.
@@ -122,7 +125,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
     if (qt * 128 >= n_g) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q0 = qt * 128 + wid * 32;
     const bool wave_on = q0 < n_g;
     const int HC = p.H * C;
@@ -143,58 +147,47 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
         for (int r = 0; r < 16; ++r) O[cb][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
+    // ---- LDS-DMA plan: instruction q (1 KB) of a tile is issued by wave q % 4; lane -> slot q*64+lane
     const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
     const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * C * np + pad0) * CF::ES;
-    u32x4 rk[CF::RPK], rv[CF::RPV];
-    auto gload = [&](int kt) {
+    unsigned soff[CF::MAXI];
 #pragma unroll
-        for (int x = 0; x < CF::RPK; ++x) {
-            const int pi = tid + x * 256;
-            if (pi < CF::NPK) rk[x] = *(const u32x4 *)(Kg + (size_t)kt * CF::BKEYS * CF::ROWB + (size_t)pi * 16);
+    for (int x = 0; x < CF::MAXI; ++x) {
+        const int q = wid + 4 * x;
+        unsigned o = 0;
+        if (q < CF::NIK) {
+            const int s = q * 64 + lane, row = s / CF::KSPR, col = s - row * CF::KSPR;
+            if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
+        } else {
+            const int s = (q - CF::NIK) * 64 + lane, row = s / 9, col = s - row * 9;
+            if (row < C && col < 8) o = (unsigned)(((size_t)row * np) * CF::ES + col * 16);
         }
+        soff[x] = o;
+    }
+    auto issue = [&](int kt, int stage) {
+        unsigned char *sb = smem + stage * CF::STAGE;
+        const unsigned char *kb_ = Kg + (size_t)kt * CF::BKEYS * CF::ROWB;
+        const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ES;
 #pragma unroll
-        for (int x = 0; x < CF::RPV; ++x) {
-            const int pi = tid + x * 256;
-            if (pi < CF::NPV) {
-                const int c = pi >> 3, c16 = pi & 7;
-                rv[x] = *(const u32x4 *)(Vg + ((size_t)c * np + (size_t)kt * CF::BKEYS) * CF::ES + c16 * 16);
-            }
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int x = 0; x < CF::RPK; ++x) {
-            const int pi = tid + x * 256;
-            if (pi < CF::NPK) {
-                const int row = pi / (CF::ROWB / 16), c16 = pi - row * (CF::ROWB / 16);
-                *(u32x4 *)(sK + row * CF::RS + c16 * 16) = rk[x];
-            }
-        }
-#pragma unroll
-        for (int x = 0; x < CF::RPV; ++x) {
-            const int pi = tid + x * 256;
-            if (pi < CF::NPV) {
-                const int c = pi >> 3, c16 = pi & 7;
-                unsigned char *d = sV + c * CF::RSV + c16 * 16;
-                if (CF::ES == 2) {                 // rows are only 8-byte aligned: two b64 writes
-                    *(u32x2 *)d = (u32x2){rv[x][0], rv[x][1]};
-                    *(u32x2 *)(d + 8) = (u32x2){rv[x][2], rv[x][3]};
-                } else {
-                    *(u32x4 *)d = rv[x];
-                }
+        for (int x = 0; x < CF::MAXI; ++x) {
+            const int q = wid + 4 * x;
+            if (q < CF::NI) {
+                const unsigned char *src = (q < CF::NIK ? kb_ : vb_) + soff[x];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
             }
         }
     };
 
     const int nkt = (n_g + CF::BKEYS - 1) / CF::BKEYS;
     const int qidx = q0 + i;                     // this lane's query (index inside the graph)
-    gload(0);
+    const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);     // key fed to MFMA row i
+    issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (kt + 1 < nkt) gload(kt + 1);
+        __syncthreads();                         // own DMA landed (vmcnt(0)) + everyone left the other stage
+        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
         if (!wave_on) continue;
+        const unsigned char *sK = smem + (kt & 1) * CF::STAGE, *sV = sK + CF::KBYTES;
 #pragma unroll
         for (int kb = 0; kb < CF::KB; ++kb) {
             const int key0 = kt * CF::BKEYS + kb * 32;
@@ -202,38 +195,45 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            const unsigned char *krow = sK + (kb * 32 + i) * CF::RS + half * 16;
+            const unsigned char *krow = sK + (kb * 32 + pi_i) * CF::RS + half * 16;
 #pragma unroll
             for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), *(const u32x4 *)(krow + ch * 32), qf[ch], s);
+            // this lane now holds keys key0 + 16*half + r, r = 0..15, of query qidx.
             // mask padded keys (last tile) and the diagonal (graphs without self loops)
+            const int kbase = key0 + 16 * half;
             const bool tail = key0 + 32 > n_g;
             const bool diag = p.nodiag && key0 < q0 + 32 && key0 + 32 > q0;
             if (tail || diag) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kidx = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (kidx >= n_g || (p.nodiag && kidx == qidx)) s[r] = -INFINITY;
-                }
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
             }
             float mloc = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            float mnew = fmaxf(m, mloc);
-            if (mnew == -INFINITY) mnew = 0.f;               // nothing but masked keys so far
-            const float corr = __builtin_amdgcn_exp2f((m - mnew) * p.sc);
-            m = mnew;
-            const float ms = mnew * p.sc;
+            // rescale only when the running max grows by more than 2^8 (softmax is shift invariant)
+            const bool grow = !(m > -INFINITY) || (mloc - m) * p.sc > 8.0f;
+            if (__any(grow)) {
+                float mnew = fmaxf(m, mloc);
+                if (mnew == -INFINITY) mnew = 0.f;               // nothing but masked keys so far
+                const float corr = __builtin_amdgcn_exp2f((m - mnew) * p.sc);
+                m = mnew;
+                l *= corr;
+#pragma unroll
+                for (int cb = 0; cb < CF::NCB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[cb][r] *= corr;
+            }
+            const float ms = m * p.sc;
             float pr[16], psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms)); psum += pr[r]; }
-            l = fmaf(l, corr, psum);
+            l += psum;
 #pragma unroll
             for (int cb = 0; cb < CF::NCB; ++cb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) O[cb][r] *= corr;
                 const int cr = min(cb * 32 + i, C - 1);
-                O[cb] = mma_pv<CF::RSV>(T(), sV + cr * CF::RSV, kb, half, pr, O[cb]);
+                O[cb] = mma_pv(T(), sV + cr * CF::RSV + kb * 32 * CF::ES, half, pr, O[cb]);
             }
         }
     }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
 template <typename T, int C>
 static int launch_tc(const AttnDenseParams &p, int nblocks, hipStream_t st) {
     using CF = Cfg<T, C>;
-    const int lds = CF::KBYTES + CF::VBYTES;
+    const int lds = 2 * CF::STAGE;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -287,6 +287,7 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
                       const int32_t *graph_ptr, const int32_t *pad_ptr, int nodiag, const void *res, int act,
                       void *out, hipStream_t st) {
     if (heads != 8 || (C != 32 && C != 144)) return -1;
+    if ((size_t)C * (size_t)L.n_pad * esize(prec) >= ((size_t)1 << 31)) return -1;      // 32-bit DMA offsets
     AttnDenseParams p;
     p.Q = L.Q; p.K = L.K; p.Vt = L.Vt; p.S = L.S; p.res = res; p.out = out;
     p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.n_graphs = n_graphs;

@@ -9,17 +9,20 @@
 // tiles.  Both operands are K-contiguous, so A and W tiles share one LDS layout: 128 rows x 128 B,
 // 16-byte chunks XOR-swizzled by (row & 7) -- conflict-free for the ds_write_b128 staging and for
 // the ds_read_b128 fragment reads (lane groups of 16 hit 16 distinct 16-B slots of the 256-B bank
-// row).  Global->LDS goes through registers: the loads of tile t+1 are issued before the MFMAs of
-// tile t and land in LDS after them (one LDS buffer, two barriers per K tile).
+// row).  Global->LDS is LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write): two
+// stages, the DMA of tile t+1 is in flight under the MFMAs of tile t, one barrier per K tile.  The
+// DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE address.
 //
 // Epilogue.  MFMA is issued as (W fragment) x (A fragment), so a lane owns ONE row of `out` and FOUR
-// consecutive output features: bias/activation are applied in registers and the store is one
-// 8-byte (bf16) / 16-byte (fp32) access.  In QKV mode (dense block-diagonal attention) the fused
+// consecutive output features: bias/activation are applied in registers, the tile is staged through
+// LDS and leaves as coalesced 16-byte stores of whole rows.  In QKV mode (dense block-diagonal attention) the fused
 // projection is scattered straight into the layouts the attention kernel consumes:
 //   Q, K  -> [H][n_pad][C]     head-major, rows at the graph's padded offset (row_map)
 //   V     -> [H][C][n_pad]     TRANSPOSED (blocks of V columns issue (A) x (W) so a lane owns four
 //                              consecutive nodes of one feature)
 //   skip  -> [M][H*C]          row-major
+#include <stdlib.h>
+
 #include "da_common.h"
 #include "da_internal.h"
 
@@ -47,28 +50,21 @@ template <> struct Mma16<float> {
     }
 };
 
-__device__ __forceinline__ void store4(float *dst, const float v[4]) {
-    if ((((size_t)dst) & 15) == 0) *(float4 *)dst = make_float4(v[0], v[1], v[2], v[3]);
-    else { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
-}
+// 4 consecutive elements; callers guarantee natural alignment (16 B fp32 / 8 B bf16)
+__device__ __forceinline__ void store4(float *dst, const float v[4]) { *(f32x4 *)dst = (f32x4){v[0], v[1], v[2], v[3]}; }
 __device__ __forceinline__ void store4(bf16_t *dst, const float v[4]) {
-    if ((((size_t)dst) & 7) == 0) {
-        uint2 u;
-        u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-        *(uint2 *)dst = u;
-    } else { dst[0] = f2bf(v[0]); dst[1] = f2bf(v[1]); dst[2] = f2bf(v[2]); dst[3] = f2bf(v[3]); }
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *(u32x2 *)dst = __builtin_bit_cast(u32x2, b);
 }
 __device__ __forceinline__ void load4(const float *src, float v[4]) {
-    if ((((size_t)src) & 15) == 0) { const float4 f = *(const float4 *)src; v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
-    else { v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3]; }
+    const f32x4 f = *(const f32x4 *)src;
+    v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
 }
 __device__ __forceinline__ void load4(const bf16_t *src, float v[4]) {
-    if ((((size_t)src) & 7) == 0) {
-        const uint2 u = *(const uint2 *)src;
-        v[0] = bf2f((bf16_t)(u.x & 0xffff)); v[1] = bf2f((bf16_t)(u.x >> 16));
-        v[2] = bf2f((bf16_t)(u.y & 0xffff)); v[3] = bf2f((bf16_t)(u.y >> 16));
-    } else { v[0] = bf2f(src[0]); v[1] = bf2f(src[1]); v[2] = bf2f(src[2]); v[3] = bf2f(src[3]); }
+    const u32x2 u = *(const u32x2 *)src;
+    v[0] = bf2f((bf16_t)(u[0] & 0xffff)); v[1] = bf2f((bf16_t)(u[0] >> 16));
+    v[2] = bf2f((bf16_t)(u[1] & 0xffff)); v[3] = bf2f((bf16_t)(u[1] >> 16));
 }
 
 struct GemmParams {
@@ -79,6 +75,8 @@ struct GemmParams {
     // QKV scatter mode (dense attention layouts)
     int qkv; int HC, C, n_pad; const int32_t *row_map;
     void *Q, *Kb, *Vt, *S;
+    int nct, nt;     // column tiles of this launch, column tiles per workgroup
+    int debug;   // DA_GEMM_DEBUG bits: 1 = no global stores, 2 = no MFMA, 4 = no DMA (timing experiments only)
 };
 
 template <typename T, bool VORIENT>
@@ -104,120 +102,187 @@ __device__ __forceinline__ void mma_block(const unsigned char *sA, const unsigne
     }
 }
 
-template <typename T, bool VORIENT>
+template <typename T, bool VORIENT, int ACT>
 __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * 128];
-    unsigned char *sA = smem, *sW = smem + 128 * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    // two stages x (A tile 16 KB + W tile 16 KB), filled by LDS-DMA (global_load_lds_dwordx4).  A
+    // workgroup owns one 128-row tile of A and walks `nt` consecutive 128-column tiles of W as ONE
+    // continuous stream of K stages, so the DMA of the next column tile's first stage is already in
+    // flight while the current tile's epilogue runs (the epilogue stages through the ring slot that
+    // was consumed last).
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 128 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.y * 128;
-    // QKV mode is issued as two launches: the V column blocks (VORIENT) and everything else
-    int cb = blockIdx.x;
-    if (p.qkv) {
-        const int per = p.HC / 128;
-        cb = VORIENT ? cb + 2 * per : (cb < 2 * per ? cb : cb + per);
-    }
-    const int col0 = cb * 128;
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr bool vorient = VORIENT;
+    const int t_beg = blockIdx.x * p.nt, t_end = min(t_beg + p.nt, p.nct);
+    const int per = p.qkv ? p.HC / 128 : 0;
+    // logical column tile -> 128-column block of the output (QKV mode is two launches: the V blocks,
+    // VORIENT, and everything else)
+    auto colblock = [&](int t) { return !p.qkv ? t : (VORIENT ? t + 2 * per : (t < 2 * per ? t : t + per)); };
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // staging: thread owns 16-byte chunk c of rows r0 + 32 i (i = 0..3) of both tiles
-    const int r0 = tid >> 3, c = tid & 7;
-    const int loff = r0 * 128 + ((c ^ (r0 & 7)) << 4);            // + i * 4096 for row r0 + 32 i
-    const char *Ab = (const char *)p.A + c * 16, *Wb = (const char *)p.W + c * 16;
+    // Staging by LDS-DMA: wave w fills rows [32w, 32w+32) of both tiles, 8 rows (1 KB) per instruction.
+    // The DMA writes lane l at (wave-uniform base) + 16 l, i.e. row (l >> 3), slot (l & 7); the XOR
+    // swizzle is therefore applied on the SOURCE: slot s of row r holds logical chunk s ^ (r & 7).
+    const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+    const char *Wb = (const char *)p.W + lc * 16;
     const size_t ldaB = (size_t)p.lda * sizeof(T), ldwB = (size_t)p.K * sizeof(T);
-    int arow[4], wrow[4];
+    const char *ap[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        arow[i] = min(row0 + r0 + 32 * i, p.M - 1);
-        wrow[i] = min(col0 + r0 + 32 * i, p.Nout - 1);
-    }
-    u32x4 ra[4], rw[4];
+    for (int j = 0; j < 4; ++j)
+        ap[j] = (const char *)p.A + lc * 16 + (size_t)min(row0 + 32 * wid + 8 * j + lr, p.M - 1) * ldaB;
     const int nk = p.K / BK;
+    const int S = (t_end - t_beg) * nk;                       // stages of this workgroup
+    auto issue = [&](int s) {
+        const int ti = s / nk, kt = s - ti * nk;
+        const int c0 = colblock(t_beg + ti) * 128;
+        unsigned char *sa = smem + (s & 1) * 32768 + (32 * wid) * 128, *sw = sa + 16384;
+        const size_t kb = (size_t)kt * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = *(const u32x4 *)(Ab + arow[i] * ldaB);
-        rw[i] = *(const u32x4 *)(Wb + wrow[i] * ldwB);
-    }
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(u32x4 *)(sA + loff + i * 4096) = ra[i];
-            *(u32x4 *)(sW + loff + i * 4096) = rw[i];
+        for (int j = 0; j < 4; ++j) {
+            const char *wsrc = Wb + (size_t)min(c0 + 32 * wid + 8 * j + lr, p.Nout - 1) * ldwB + kb;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ap[j] + kb),
+                                             (__attribute__((address_space(3))) void *)(sa + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)wsrc,
+                                             (__attribute__((address_space(3))) void *)(sw + j * 1024), 16, 0, 0);
         }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            const size_t kb = (size_t)(kt + 1) * 128;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = *(const u32x4 *)(Ab + arow[i] * ldaB + kb);
-                rw[i] = *(const u32x4 *)(Wb + wrow[i] * ldwB + kb);
-            }
-        }
-        mma_block<T, VORIENT>(sA, sW, wm, wn, lane, acc);
-    }
+    };
+    if (S > 0 && !(p.debug & 4)) issue(0);
 
-    // ------------------------------------------------------------------ epilogue
-    if (!vorient) {
+    constexpr int ES = (int)sizeof(T), EPC = 16 / ES;          // elements per 16-byte chunk
+    constexpr int RSO = 128 * ES + 16;                          // padded LDS row of the staged tile
+    constexpr int ROWS = ES == 4 ? 32 : 64, PASSES = 128 / ROWS; // staged rows per pass (fits one ring slot)
+    constexpr int CPR = 128 * ES / 16;                          // 16-byte chunks per staged row
+    constexpr int NIT = ROWS * CPR / 256;
+    static_assert(ROWS * RSO <= 32768, "epilogue staging must fit in one ring slot");
+
+    for (int ti = 0; ti < t_end - t_beg; ++ti) {
+        const int col0 = colblock(t_beg + ti) * 128;
         const int which = p.qkv ? col0 / p.HC : 0;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = row0 + wm * 64 + mi * 16 + (lane & 15);
-            if (m >= p.M) continue;
-            const int prow = (p.qkv && which < 2) ? p.row_map[m] : 0;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
-                if (f0 >= p.Nout) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + (p.bias ? p.bias[f0 + r] : 0.f), p.act);
-                if (!p.qkv) {
-                    if (p.res) {
-                        float rr[4];
-                        load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                    }
-                    store4((T *)p.out + (size_t)m * p.ldo + f0, v);
-                } else if (which == 3) {
-                    store4((T *)p.S + (size_t)m * p.HC + (f0 - 3 * p.HC), v);
-                } else {
-                    const int f = f0 - which * p.HC, h = f / p.C, c = f - h * p.C;
-                    T *dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + prow) * p.C + c;
-                    store4(dst, v);
-                }
-            }
-        }
-    } else {
-        // V columns: lane owns feature f and four consecutive nodes -> transposed store
+        // bias of this lane's output features, fetched under the MFMAs (the epilogue wants them in
+        // registers: dependent scalar loads there cost microseconds per tile)
+        float bz[4][4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int fcol = col0 + wn * 64 + ni * 16 + (lane & 15);
-            if (fcol >= p.Nout) continue;
-            const int f = fcol - 2 * p.HC, h = f / p.C, c = f - h * p.C;
-            const float b = p.bias ? p.bias[fcol] : 0.f;
-            T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * p.n_pad;
+            if (!vorient) {
+                const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
+                else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
+            } else {
+                const int fcol = col0 + wn * 64 + ni * 16 + (lane & 15);
+                bz[ni][0] = (p.bias && fcol < p.Nout) ? p.bias[fcol] : 0.f;
+                bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f;
+            }
+        }
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int s = ti * nk + kt;
+            __syncthreads();                   // own DMA landed (vmcnt(0)) + everyone done with the other slot
+            if (s + 1 < S && !(p.debug & 4)) issue(s + 1);
+            const unsigned char *sA = smem + (s & 1) * 32768;
+            if (!(p.debug & 2)) mma_block<T, VORIENT>(sA, sA + 16384, wm, wn, lane, acc);
+        }
+
+        // -------------------------------------------------------------- epilogue of this column tile
+        // Registers -> LDS (bias / activation / residual applied on the way) -> coalesced 16-byte global
+        // stores of whole tile rows.  The accumulator layout gives a lane 4 consecutive features of one
+        // row (or, for V columns, 4 consecutive nodes of one feature): 8-byte pieces scattered over 16
+        // rows per instruction, ~1 TB/s if written directly.  Staging area = the ring slot just consumed.
+        unsigned char *stg = smem + ((ti * nk + nk - 1) & 1) * 32768;
+        const int wrow = vorient ? wn : wm;                     // wave coordinate along the staged ROWS
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+            __syncthreads();                                    // slot free / previous pass read out
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const int m0 = row0 + wm * 64 + mi * 16 + (lane >> 4) * 4;
-                if (m0 >= p.M) continue;
-                float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + b;
-                const int p0 = p.row_map[m0];
-                if (m0 + 3 < p.M && p.row_map[m0 + 3] == p0 + 3) {
-                    store4(vrow + p0, v);
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int rg = wrow * 64 + (vorient ? ni : mi) * 16 + (lane & 15);   // row of the 128 x 128 image
+                    if (rg / ROWS != pass) continue;            // wave-uniform (16-row groups never straddle)
+                    float v[4];
+                    int cl;
+                    if (!vorient) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
+                        if (p.res) {
+                            const int m = row0 + wm * 64 + mi * 16 + (lane & 15);
+                            const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                            if (m < p.M && f0 + 3 < p.Nout) {
+                                float rr[4];
+                                load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                            }
+                        }
+                        cl = wn * 64 + ni * 16 + (lane >> 4) * 4;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + bz[ni][0];
+                        cl = wm * 64 + mi * 16 + (lane >> 4) * 4;
+                    }
+                    store4((T *)(stg + (rg % ROWS) * RSO) + cl, v);
+                }
+            }
+            __syncthreads();
+            u32x4 val[NIT];
+            int rmap[NIT], rmap2[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
+                val[it] = *(const u32x4 *)(stg + row * RSO + ch * 16);
+                rmap[it] = rmap2[it] = 0;
+                if (p.qkv) {
+                    if (!vorient) {
+                        const int m = row0 + row + pass * ROWS;
+                        if (which < 2 && m < p.M) rmap[it] = p.row_map[m];
+                    } else {
+                        const int m = row0 + ch * EPC;
+                        if (m < p.M) rmap[it] = p.row_map[m];
+                        if (m + EPC - 1 < p.M) rmap2[it] = p.row_map[m + EPC - 1];
+                    }
+                }
+            }
+            if (p.debug & 1) continue;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
+                const int grow = row + pass * ROWS;             // row of the 128 x 128 staged image
+                if (!vorient) {
+                    const int m = row0 + grow, col = col0 + ch * EPC;
+                    if (m >= p.M || col >= p.Nout) continue;
+                    T *dst;
+                    if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
+                    else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
+                    else {
+                        const int f = col - which * p.HC, h = f / p.C, c = f - h * p.C;
+                        dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + rmap[it]) * p.C + c;
+                    }
+                    *(u32x4 *)dst = val[it];
                 } else {
+                    const int fcol = col0 + grow, m = row0 + ch * EPC;
+                    if (fcol >= p.Nout || m >= p.M) continue;
+                    const int f = fcol - 2 * p.HC, h = f / p.C, c = f - h * p.C;
+                    T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * p.n_pad;
+                    const int p0 = rmap[it];
+                    const bool run = m + EPC - 1 < p.M && rmap2[it] == p0 + EPC - 1;     // 8 (4) consecutive rows
+                    if (run && (p0 & (EPC - 1)) == 0) {
+                        *(u32x4 *)(vrow + p0) = val[it];
+                    } else if (run && ES == 2 && (p0 & 3) == 0) {   // graph slot offset = 4 mod 8: two 8-byte stores
+                        const u32x4 vv = val[it];
+                        *(u32x2 *)(vrow + p0) = (u32x2){vv[0], vv[1]};
+                        *(u32x2 *)(vrow + p0 + 4) = (u32x2){vv[2], vv[3]};
+                    } else {                                    // chunk straddles a graph boundary / ragged
+                        const u32x4 vv = val[it];
+                        const T *e = (const T *)&vv;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (m0 + r < p.M) stf(vrow + p.row_map[m0 + r], v[r]);
+                        for (int r = 0; r < EPC; ++r)
+                            if (m + r < p.M) vrow[p.row_map[m + r]] = e[r];
+                    }
                 }
             }
         }
@@ -231,33 +296,53 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
                      int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st) {
     const int es = (int)esize(prec), BK = 128 / es;
     if (M <= 0 || Nout <= 0) return 0;
-    if (K % BK != 0 || (Nout & 3) || !aligned16(A) || !aligned16(W) || ((size_t)lda * es) % 16 != 0) return -1;
+    if (K % BK != 0 || (Nout % (16 / es)) || !aligned16(A) || !aligned16(W) || ((size_t)lda * es) % 16 != 0) return -1;
     GemmParams p;
     p.M = M; p.K = K; p.Nout = Nout; p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.act = act; p.res = res;
     p.out = out; p.ldo = ldo; p.qkv = 0; p.HC = 1; p.C = 1; p.n_pad = 0; p.row_map = nullptr;
     p.Q = p.Kb = p.Vt = p.S = nullptr;
+    { const char *e = getenv("DA_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
     if (qs) {
-        if (qs->HC % 128 != 0 || (qs->C & 3) || Nout != 4 * qs->HC || act != DA_ACT_NONE || res) return -1;
+        if (qs->HC % 128 != 0 || (qs->C & 7) || Nout != 4 * qs->HC || act != DA_ACT_NONE || res) return -1;
         p.qkv = 1; p.HC = qs->HC; p.C = qs->C; p.n_pad = qs->n_pad; p.row_map = qs->row_map;
         p.Q = qs->Q; p.Kb = qs->K; p.Vt = qs->Vt; p.S = qs->S;
-    } else if ((ldo & 3) != 0) {
+    } else if (((size_t)ldo * es) % 16 != 0 || !aligned16(out) || (res && !aligned16(res))) {
         return -1;
     }
-    dim3 grid((Nout + 127) / 128, (M + 127) / 128);
+    const int nrt = (M + 127) / 128;
+    // Column tiles per workgroup: 256 CUs x 2 resident workgroups = 512 slots.  Use as many column
+    // groups as keep the whole grid co-resident (one round, no tail) -- each workgroup then streams
+    // its share of the column tiles back to back.
+    auto plan2 = [&](int nct) {
+        int groups = 512 / nrt;
+        groups = groups > nct ? nct : (groups < 1 ? 1 : groups);
+        int ntile = (nct + groups - 1) / groups;
+        groups = (nct + ntile - 1) / ntile;
+        p.nct = nct; p.nt = ntile;
+        return dim3((unsigned)groups, (unsigned)nrt);
+    };
+#define DA_GEMM_LAUNCH(TT, VO, AC, GRID) k_gemm_mfma<TT, VO, AC><<<GRID, 256, 0, st>>>(p)
+#define DA_GEMM_ACT(TT, GRID)                                            \
+    do {                                                                  \
+        if (act == DA_ACT_GELU) DA_GEMM_LAUNCH(TT, false, DA_ACT_GELU, GRID);        \
+        else if (act == DA_ACT_LEAKY02) DA_GEMM_LAUNCH(TT, false, DA_ACT_LEAKY02, GRID); \
+        else DA_GEMM_LAUNCH(TT, false, DA_ACT_NONE, GRID);                \
+    } while (0)
     if (!qs) {
-        if (prec == DA_PREC_BF16) k_gemm_mfma<bf16_t, false><<<grid, 256, 0, st>>>(p);
-        else k_gemm_mfma<float, false><<<grid, 256, 0, st>>>(p);
+        const dim3 grid = plan2((Nout + 127) / 128);
+        if (prec == DA_PREC_BF16) DA_GEMM_ACT(bf16_t, grid);
+        else DA_GEMM_ACT(float, grid);
     } else {
         const int per = qs->HC / 128;
-        dim3 g_qks(3 * per, grid.y), g_v(per, grid.y);
-        if (prec == DA_PREC_BF16) {
-            k_gemm_mfma<bf16_t, false><<<g_qks, 256, 0, st>>>(p);
-            k_gemm_mfma<bf16_t, true><<<g_v, 256, 0, st>>>(p);
-        } else {
-            k_gemm_mfma<float, false><<<g_qks, 256, 0, st>>>(p);
-            k_gemm_mfma<float, true><<<g_v, 256, 0, st>>>(p);
-        }
+        const dim3 g1 = plan2(3 * per);
+        if (prec == DA_PREC_BF16) DA_GEMM_LAUNCH(bf16_t, false, DA_ACT_NONE, g1);
+        else DA_GEMM_LAUNCH(float, false, DA_ACT_NONE, g1);
+        const dim3 g2 = plan2(per);
+        if (prec == DA_PREC_BF16) DA_GEMM_LAUNCH(bf16_t, true, DA_ACT_NONE, g2);
+        else DA_GEMM_LAUNCH(float, true, DA_ACT_NONE, g2);
     }
+#undef DA_GEMM_ACT
+#undef DA_GEMM_LAUNCH
     DA_LAUNCH_CHECK();
     return 0;
 }
