@@ -24,6 +24,8 @@
 // stages, tile t+1 in flight under the MFMAs of tile t, one barrier per tile.
 // Workgroup ids are remapped so that the query tiles of one (graph, head) run back to back on ONE
 // XCD and share its L2 copy of K / V^T.
+#include <stdlib.h>
+
 #include "da_common.h"
 #include "da_internal.h"
 
@@ -43,6 +45,7 @@ struct AttnDenseParams {
     const int32_t *graph_ptr, *pad_ptr;
     int n_pad, H, n_graphs, nqt, act, nodiag;
     float sc;                       // log2(e) / sqrt(C)
+    int debug;                      // DA_ATTN_DEBUG bits (timing experiments): 1 no DMA, 2 no softmax, 4 no PV, 8 no QK
 };
 
 template <typename T, int C> struct Cfg {
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                         // own DMA landed (vmcnt(0)) + everyone left the other stage
-        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nkt && !(p.debug & 1)) issue(kt + 1, (kt + 1) & 1);
         if (!wave_on) continue;
         const unsigned char *sK = smem + (kt & 1) * CF::STAGE, *sV = sK + CF::KBYTES;
 #pragma unroll
@@ -196,8 +199,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
             const unsigned char *krow = sK + (kb * 32 + pi_i) * CF::RS + half * 16;
+            if (!(p.debug & 8)) {
 #pragma unroll
-            for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), *(const u32x4 *)(krow + ch * 32), qf[ch], s);
+                for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), *(const u32x4 *)(krow + ch * 32), qf[ch], s);
+            }
             // this lane now holds keys key0 + 16*half + r, r = 0..15, of query qidx.
             // mask padded keys (last tile) and the diagonal (graphs without self loops)
             const int kbase = key0 + 16 * half;
@@ -208,6 +213,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                 for (int r = 0; r < 16; ++r)
                     if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
             }
+            float pr[16];
+            if (p.debug & 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pr[r] = s[r];
+            } else {
             float mloc = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
@@ -226,14 +236,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                     for (int r = 0; r < 16; ++r) O[cb][r] *= corr;
             }
             const float ms = m * p.sc;
-            float pr[16], psum = 0.f;
+            float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms)); psum += pr[r]; }
             l += psum;
+            }
+            if (!(p.debug & 4)) {
 #pragma unroll
-            for (int cb = 0; cb < CF::NCB; ++cb) {
-                const int cr = min(cb * 32 + i, C - 1);
-                O[cb] = mma_pv(T(), sV + cr * CF::RSV + kb * 32 * CF::ES, half, pr, O[cb]);
+                for (int cb = 0; cb < CF::NCB; ++cb) {
+                    const int cr = min(cb * 32 + i, C - 1);
+                    O[cb] = mma_pv(T(), sV + cr * CF::RSV + kb * 32 * CF::ES, half, pr, O[cb]);
+                }
             }
         }
     }
@@ -293,6 +306,7 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.n_graphs = n_graphs;
     p.nqt = (max_graph_nodes + 127) / 128; p.act = act; p.nodiag = nodiag;
     p.sc = 1.4426950408889634f / sqrtf((float)C);
+    { const char *e = getenv("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
     const int nblocks = p.nqt * heads * n_graphs;
     if (nblocks <= 0) return 0;
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, nblocks, st) : launch_tc<bf16_t, 144>(p, nblocks, st);
