@@ -129,8 +129,14 @@ int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void 
     return launch_gemm_simple(prec, M, K, Nout, A, lda, W, bias, act, res, out, ldo, st);
 }
 
+static bool dense_disabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_DISABLE_DENSE"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 static bool dense_ok(const da_graph *g, int heads, int C) {
-    return g->dense && g->n_pad > 0 && g->graph_ptr && g->pad_ptr && g->row_map && heads == 8 &&
+    return !dense_disabled() && g->dense && g->n_pad > 0 && g->graph_ptr && g->pad_ptr && g->row_map && heads == 8 &&
            (C == 32 || C == 144) && !mfma_disabled();
 }
 

@@ -31,6 +31,13 @@
 
 namespace da {
 
+// DA_ATTN_PROBE builds keep the ablation switches of tools/attn_probe.py (DA_ATTN_DEBUG env)
+#ifdef DA_ATTN_PROBE
+#define DA_ATTN_DBG(...) __VA_ARGS__
+#else
+#define DA_ATTN_DBG(...)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -115,6 +122,21 @@ __device__ __forceinline__ void st4(bf16_t *d, const float v[4]) {
     *(u32x2 *)d = __builtin_bit_cast(u32x2, b);
 }
 
+// one 16-byte chunk: 4 fp32 or 8 bf16
+__device__ __forceinline__ void ldc(const float *s, float (&v)[4]) { const f32x4 f = *(const f32x4 *)s; v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3]; }
+__device__ __forceinline__ void ldc(const bf16_t *s, float (&v)[8]) {
+    const u32x4 u = *(const u32x4 *)s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = bf2f((bf16_t)(u[k] & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(u[k] >> 16)); }
+}
+__device__ __forceinline__ void stc(float *d, const float (&v)[4]) { *(f32x4 *)d = (f32x4){v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ void stc(bf16_t *d, const float (&v)[8]) {
+    bf16x8 b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b[k] = (__bf16)v[k];
+    *(u32x4 *)d = __builtin_bit_cast(u32x4, b);
+}
+
 template <typename T, int C>
 __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     using CF = Cfg<T, C>;
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
 #pragma unroll
         for (int x = 0; x < CF::MAXI; ++x) {
             const int q = wid + 4 * x;
-            if (q < CF::NI) {
+            if (4 * x + 3 < CF::NI || q < CF::NI) {            // compile-time true except for a partial last round
                 const unsigned char *src = (q < CF::NIK ? kb_ : vb_) + soff[x];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
@@ -182,26 +204,48 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
         }
     };
 
-    const int nkt = (n_g + CF::BKEYS - 1) / CF::BKEYS;
+    int nkt = (n_g + CF::BKEYS - 1) / CF::BKEYS;
+    DA_ATTN_DBG(if (p.debug & 32) nkt = 1;)
     const int qidx = q0 + i;                     // this lane's query (index inside the graph)
     const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);     // key fed to MFMA row i
+    // LDS byte offsets of this lane's fragments inside a stage (constant over the whole kernel)
+    const int koff = pi_i * CF::RS + half * 16;
+    int voff[CF::NCB];
+#pragma unroll
+    for (int cb = 0; cb < CF::NCB; ++cb) voff[cb] = CF::KBYTES + min(cb * 32 + i, C - 1) * CF::RSV + 16 * half * CF::ES;
     issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();                         // own DMA landed (vmcnt(0)) + everyone left the other stage
-        if (kt + 1 < nkt && !(p.debug & 1)) issue(kt + 1, (kt + 1) & 1);
+        dma_barrier();                         // own DMA landed (vmcnt(0)) + everyone left the other stage
+        if (kt + 1 < nkt DA_ATTN_DBG(&& !(p.debug & 1))) issue(kt + 1, (kt + 1) & 1);
         if (!wave_on) continue;
-        const unsigned char *sK = smem + (kt & 1) * CF::STAGE, *sV = sK + CF::KBYTES;
+        const unsigned char *stg = smem + (kt & 1) * CF::STAGE;
 #pragma unroll
         for (int kb = 0; kb < CF::KB; ++kb) {
             const int key0 = kt * CF::BKEYS + kb * 32;
             if (key0 >= n_g) break;
+            // ---- all LDS fragment reads of this 32-key block are issued up front (K for QK^T now, V^T
+            // for PV later): the compiler otherwise pairs every two reads with a full lgkmcnt(0) wait
+            // and the MFMA chain idles ~100 cycles per pair
+            u32x4 kf[CF::NCH];
+#pragma unroll
+            for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + koff + kb * 32 * CF::RS + ch * 32);
+            __builtin_amdgcn_sched_barrier(0);       // keep the K read batch ahead of the MFMA chain
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            const unsigned char *krow = sK + (kb * 32 + pi_i) * CF::RS + half * 16;
-            if (!(p.debug & 8)) {
+            DA_ATTN_DBG(if (!(p.debug & 8)))
+            {
 #pragma unroll
-                for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), *(const u32x4 *)(krow + ch * 32), qf[ch], s);
+                for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), kf[ch], qf[ch], s);
+            }
+            // V^T fragments: issued behind the QK^T chain, they land under the softmax
+            u32x4 vf[CF::ES == 2 ? CF::NCB : 1][2];
+            if (CF::ES == 2) {
+#pragma unroll
+                for (int cb = 0; cb < CF::NCB; ++cb) {
+                    vf[cb][0] = *(const u32x4 *)(stg + voff[cb] + kb * 64);
+                    vf[cb][1] = *(const u32x4 *)(stg + voff[cb] + kb * 64 + 16);
+                }
             }
             // this lane now holds keys key0 + 16*half + r, r = 0..15, of query qidx.
             // mask padded keys (last tile) and the diagonal (graphs without self loops)
@@ -214,70 +258,98 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                     if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
             }
             float pr[16];
-            if (p.debug & 2) {
+            DA_ATTN_DBG(if (p.debug & 2) { _Pragma("unroll") for (int r = 0; r < 16; ++r) pr[r] = s[r]; } else)
+            {
+                float mloc = s[0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pr[r] = s[r];
-            } else {
-            float mloc = s[0];
+                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+                // rescale only when the running max grows by more than 2^8 (softmax is shift invariant)
+                const bool grow = !(m > -INFINITY) || (mloc - m) * p.sc > 8.0f;
+                if (__any(grow)) {
+                    float mnew = fmaxf(m, mloc);
+                    if (mnew == -INFINITY) mnew = 0.f;           // nothing but masked keys so far
+                    const float corr = __builtin_amdgcn_exp2f((m - mnew) * p.sc);
+                    m = mnew;
+                    l *= corr;
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            // rescale only when the running max grows by more than 2^8 (softmax is shift invariant)
-            const bool grow = !(m > -INFINITY) || (mloc - m) * p.sc > 8.0f;
-            if (__any(grow)) {
-                float mnew = fmaxf(m, mloc);
-                if (mnew == -INFINITY) mnew = 0.f;               // nothing but masked keys so far
-                const float corr = __builtin_amdgcn_exp2f((m - mnew) * p.sc);
-                m = mnew;
-                l *= corr;
+                    for (int cb = 0; cb < CF::NCB; ++cb)
 #pragma unroll
-                for (int cb = 0; cb < CF::NCB; ++cb)
+                        for (int r = 0; r < 16; ++r) O[cb][r] *= corr;
+                }
+                const float ms = m * p.sc;
+                float psum = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) O[cb][r] *= corr;
+                for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms)); psum += pr[r]; }
+                l += psum;
             }
-            const float ms = m * p.sc;
-            float psum = 0.f;
+            DA_ATTN_DBG(if (!(p.debug & 4)))
+            {
+                if (CF::ES == 2) {
+                    bf16x8 pf0, pf1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms)); psum += pr[r]; }
-            l += psum;
-            }
-            if (!(p.debug & 4)) {
+                    for (int e = 0; e < 8; ++e) { pf0[e] = (__bf16)pr[e]; pf1[e] = (__bf16)pr[8 + e]; }
 #pragma unroll
-                for (int cb = 0; cb < CF::NCB; ++cb) {
-                    const int cr = min(cb * 32 + i, C - 1);
-                    O[cb] = mma_pv(T(), sV + cr * CF::RSV + kb * 32 * CF::ES, half, pr, O[cb]);
+                    for (int cb = 0; cb < CF::NCB; ++cb) {
+                        O[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[cb][0]), pf0, O[cb], 0, 0, 0);
+                        O[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[cb][1]), pf1, O[cb], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int cb = 0; cb < CF::NCB; ++cb)
+                        O[cb] = mma_pv(T(), stg + voff[cb] - 16 * half * CF::ES + kb * 32 * CF::ES, half, pr, O[cb]);
                 }
             }
         }
     }
-    if (!wave_on || qidx >= n_g) return;
-
-    // epilogue: normalise (PyG: sum + 1e-16), + skip (+ residual), activation, store
+    // ---- epilogue: normalise (PyG: sum + 1e-16) and stage O through LDS as [query][c] fp32, then all
+    // 256 threads stream whole output rows: 16-byte coalesced reads of skip (+ residual), activation,
+    // 16-byte coalesced stores.  (Written straight from the accumulator layout every access is an
+    // 8-byte piece in one of 32 different rows: that cost 25 % of the kernel.)
     const float lt = l + __shfl_xor(l, 32);
     const float inv = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
-    const size_t orow = ((size_t)node0 + qidx) * HC + (size_t)h * C;
-    const T *sp = (const T *)p.S + orow;
-    const T *rp = p.res ? (const T *)p.res + orow : nullptr;
-    T *op = (T *)p.out + orow;
+    constexpr int RSOF = C + 4;                                   // floats per staged row (16-B aligned, odd # of 16-B slots)
+    static_assert(128 * RSOF * 4 <= 2 * CF::STAGE, "O staging must fit in the K/V ring");
+    float *so = (float *)smem;
+    dma_barrier();                                              // ring no longer read by anyone
+    DA_ATTN_DBG(if (p.debug & 16) return;)
+    if (wave_on) {
+        float *orow = so + (wid * 32 + i) * RSOF;
 #pragma unroll
-    for (int cb = 0; cb < CF::NCB; ++cb) {
+        for (int cb = 0; cb < CF::NCB; ++cb) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int c0 = cb * 32 + 8 * jj + 4 * half;
-            if (c0 >= C) continue;
-            float v[4], sk[4];
-            ld4(sp + c0, sk);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(O[cb][4 * jj + e], inv, sk[e]);
-            if (rp) {
-                ld4(rp + c0, sk);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += sk[e];
+            for (int jj = 0; jj < 4; ++jj) {
+                const int c0 = cb * 32 + 8 * jj + 4 * half;
+                if (c0 >= C) continue;
+                *(f32x4 *)(orow + c0) = (f32x4){O[cb][4 * jj] * inv, O[cb][4 * jj + 1] * inv, O[cb][4 * jj + 2] * inv,
+                                               O[cb][4 * jj + 3] * inv};
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-            st4(op + c0, v);
         }
+    }
+    dma_barrier();
+    constexpr int EPC = 16 / CF::ES, CPR = C / EPC;              // elements per 16-B chunk, chunks per row
+    const int nq = min(128, n_g - qt * 128);                      // valid queries of this tile
+    for (int it = tid; it < nq * CPR; it += 256) {
+        const int q = it / CPR, ch = it - q * CPR;
+        const size_t off = ((size_t)node0 + qt * 128 + q) * HC + (size_t)h * C + ch * EPC;
+        const float *src = so + q * RSOF + ch * EPC;
+        float v[EPC], sk[EPC];
+        {
+            const f32x4 a = *(const f32x4 *)src;
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+            if (EPC == 8) { const f32x4 b2 = *(const f32x4 *)(src + 4); v[4] = b2[0]; v[5] = b2[1]; v[6] = b2[2]; v[7] = b2[3]; }
+        }
+        ldc((const T *)p.S + off, sk);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+        if (p.res) {
+            ldc((const T *)p.res + off, sk);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = apply_act(v[e], p.act);
+        stc((T *)p.out + off, v);
     }
 }
 

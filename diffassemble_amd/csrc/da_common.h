@@ -77,6 +77,15 @@ __device__ inline float apply_act(float x, int act) {
     return x;
 }
 
+// Barrier that also covers this wave's outstanding LDS-DMA (global_load_lds).  hipcc's waitcnt
+// insertion does NOT reliably put `s_waitcnt vmcnt(0)` in front of a __syncthreads() whose pending
+// DMA was issued in a previous loop iteration (observed: attention main loop compiled to
+// `s_waitcnt lgkmcnt(0); s_barrier`, tiles were read before they landed under load) -- so say it.
+__device__ __forceinline__ void dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 inline size_t esize(int prec) { return prec == DA_PREC_BF16 ? 2 : 4; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
 
         for (int kt = 0; kt < nk; ++kt) {
             const int s = ti * nk + kt;
-            __syncthreads();                   // own DMA landed (vmcnt(0)) + everyone done with the other slot
+            dma_barrier();                   // own DMA landed (vmcnt(0)) + everyone done with the other slot
             if (s + 1 < S && !(p.debug & 4)) issue(s + 1);
             const unsigned char *sA = smem + (s & 1) * 32768;
             if (!(p.debug & 2)) mma_block<T, VORIENT>(sA, sA + 16384, wm, wn, lane, acc);
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
         const int wrow = vorient ? wn : wm;                     // wave coordinate along the staged ROWS
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
-            __syncthreads();                                    // slot free / previous pass read out
+            dma_barrier();                                    // slot free / previous pass read out
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
                     store4((T *)(stg + (rg % ROWS) * RSO) + cl, v);
                 }
             }
-            __syncthreads();
+            dma_barrier();
             u32x4 val[NIT];
             int rmap[NIT], rmap2[NIT];
 #pragma unroll
