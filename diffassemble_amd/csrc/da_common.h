@@ -86,6 +86,20 @@ __device__ __forceinline__ void dma_barrier() {
     __syncthreads();
 }
 
+// s_waitcnt vmcnt(n) for a small runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 inline size_t esize(int prec) { return prec == DA_PREC_BF16 ? 2 : 4; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

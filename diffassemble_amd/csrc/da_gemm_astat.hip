@@ -1,0 +1,297 @@
+// A-stationary MFMA linear kernel for SHORT reductions (K * sizeof(T) <= 512 bytes: the K = 256
+// fused Q|K|V|skip projections of convs 1-3 and mlp.2), where the generic 128x128 kernel re-reads its
+// A tile for every column tile and the fused projection's outputs are 4-18x larger than its inputs:
+// measured there, TCC hit rate 47 % (64 resident workgroups x 64 KB of A tile = the whole 4 MB L2 of
+// an XCD) and ~1 GB of LDS-DMA traffic per launch for 17 MB of compulsory input.
+//
+// Here a workgroup (8 waves) loads its 128-row A panel ONCE (all of K, <= 64 KB of LDS) and streams
+// only W: one 128-column x 64-byte... 128-byte K-chunk tile (16 KB) per stage through a 4-slot ring,
+// three stages in flight (counted s_waitcnt vmcnt, never a drain: loads retire in order, so younger
+// stores only make the counted wait conservative).  Wave grid 4 (rows) x 2 (columns): 32 x 64 outputs per wave = 2 x 4
+// MFMA tiles; same XOR-swizzled 128-byte-row LDS images as da_gemm_mfma.hip.  The epilogue needs no
+// workgroup barrier: every wave stages its own 16 x 64 sub-tiles through a private 2.3 KB LDS strip
+// and writes 128-byte contiguous row segments.
+#include <stdlib.h>
+
+#include "da_gemm_common.h"
+
+namespace da {
+
+#ifdef DA_GEMM_PROBE
+#define DA_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define DA_PROBE(...) __VA_ARGS__
+#else
+#define DA_TICK(var)
+#define DA_PROBE(...)
+#endif
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, bool VORIENT, int ACT>
+__global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ES = (int)sizeof(T), EPC = 16 / ES, BK = 128 / ES;
+    const int nk = p.K / BK;                                     // 1..4 resident K chunks of A
+    unsigned char *sA = smem;                                    // [nk][128 rows][128 B]
+    unsigned char *sW = smem + nk * 16384;                       // 4-slot ring of [128 rows][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;                       // 4 x 2 waves: rows 32 wm, cols 64 wn
+    unsigned char *stg = smem + nk * 16384 + 65536 + wid * 2304; // private strip: 16 rows x 144 B
+    const int row0 = blockIdx.y * 128;
+    const int t_beg = blockIdx.x * p.nt, t_end = min(t_beg + p.nt, p.nct);
+    const int per = p.qkv ? p.HC / 128 : 0;
+    auto colblock = [&](int t) { return !p.qkv ? t : (VORIENT ? t + 2 * per : (t < 2 * per ? t : t + per)); };
+    const int S = (t_end - t_beg) * nk;                          // W stages of this workgroup
+    if (S <= 0) return;
+
+    // LDS-DMA lane mapping (lane -> row lr, swizzled 16-byte chunk lc), as in da_gemm_mfma.hip
+    const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+    const size_t ldaB = (size_t)p.lda * ES, ldwB = (size_t)p.K * ES;
+    // A panel: nk x 16 instructions of 8 rows; wave w issues instructions w and w + 8 of every chunk
+    {
+        const char *a0 = (const char *)p.A + lc * 16 + (size_t)min(row0 + 8 * wid + lr, p.M - 1) * ldaB;
+        const char *a1 = (const char *)p.A + lc * 16 + (size_t)min(row0 + 8 * (wid + 8) + lr, p.M - 1) * ldaB;
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a0 + (size_t)kt * 128),
+                                             (__attribute__((address_space(3))) void *)(sA + kt * 16384 + wid * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a1 + (size_t)kt * 128),
+                                             (__attribute__((address_space(3))) void *)(sA + kt * 16384 + (wid + 8) * 1024), 16, 0, 0);
+        }
+    }
+    const char *Wb = (const char *)p.W + lc * 16;
+    auto issue = [&](int s) {                                    // 2 DMA instructions per wave per stage
+        const int ti = s / nk, kt = s - ti * nk;
+        const int c0 = colblock(t_beg + ti) * 128;
+        unsigned char *dst = sW + (s & 3) * 16384;
+        const size_t kb = (size_t)kt * 128;
+        const char *w0 = Wb + (size_t)min(c0 + 8 * wid + lr, p.Nout - 1) * ldwB + kb;
+        const char *w1 = Wb + (size_t)min(c0 + 8 * (wid + 8) + lr, p.Nout - 1) * ldwB + kb;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)w0,
+                                         (__attribute__((address_space(3))) void *)(dst + wid * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)w1,
+                                         (__attribute__((address_space(3))) void *)(dst + (wid + 8) * 1024), 16, 0, 0);
+    };
+    DA_TICK(t_start);
+    DA_PROBE(unsigned long long c_wait = 0, c_mma = 0, c_epi = 0;)
+    issue(0);
+    if (S > 1) issue(1);
+    if (S > 2) issue(2);
+
+    // bias of this lane's output features, fetched ONE TILE AHEAD so that it is never the youngest
+    // outstanding load at a counted wait
+    auto load_bias = [&](int ti, float (&bz)[4][4]) {
+        const int col0 = colblock(t_beg + ti) * 128;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            if (!VORIENT) {
+                const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
+                else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
+            } else {
+                const int fcol = col0 + wn * 64 + ni * 16 + (lane & 15);
+                bz[ni][0] = (p.bias && fcol < p.Nout) ? p.bias[fcol] : 0.f;
+                bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f;
+            }
+        }
+    };
+    float bz[4][4], bzn[4][4];
+    load_bias(0, bz);
+    for (int ti = 0; ti < t_end - t_beg; ++ti) {
+        const int col0 = colblock(t_beg + ti) * 128;
+        const int which = p.qkv ? col0 / p.HC : 0;
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int s = ti * nk + kt;
+            // stage s must have landed; stages s+1, s+2 (2 DMA instructions each per wave) may stay in
+            // flight.  The bias loads above and the epilogue's stores also count, hence the drains.
+            DA_TICK(t_a);
+            // Counted wait: loads (incl. LDS-DMA) retire in order, so "at most 2*ahead VMEM ops outstanding"
+            // implies stage s has landed no matter how many younger stores / bias loads are pending (they
+            // only add to the counter: conservative, never early).  No drain -> the epilogue's stores of
+            // the previous tile stay in flight under this tile's MFMAs.
+            const int ahead = min(2, S - 1 - s);
+            if (ahead == 0) wait_vmcnt<0>();
+            else if (ahead == 1) wait_vmcnt<2>();
+            else wait_vmcnt<4>();
+            if (kt == (nk > 1 ? 1 : 0) && ti + 1 < t_end - t_beg) load_bias(ti + 1, bzn);
+            __syncthreads();                     // everyone's share landed; slot (s + 3) & 3 is free again
+            DA_TICK(t_b);
+            if (s + 3 < S) issue(s + 3);
+            const unsigned char *a = sA + kt * 16384, *w = sW + (s & 3) * 16384;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 fa[2], fw[4];
+                const int c = kk * 4 + (lane >> 4);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int R = wm * 32 + t * 16 + (lane & 15);
+                    fa[t] = *(const u32x4 *)(a + R * 128 + ((c ^ (R & 7)) << 4));
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int R = wn * 64 + t * 16 + (lane & 15);
+                    fw[t] = *(const u32x4 *)(w + R * 128 + ((c ^ (R & 7)) << 4));
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = VORIENT ? Mma16<T>::run(fa[mi], fw[ni], acc[mi][ni])
+                                              : Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);
+            }
+            DA_PROBE(asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][3])); { DA_TICK(t_c); c_wait += t_b - t_a; c_mma += t_c - t_b; })
+        }
+        DA_TICK(t_e0);
+
+        // ---------------------------------------------------------- epilogue (wave private, no barrier)
+        if (!VORIENT) {
+            // strip = 16 nodes x 128 bytes of features; fp32 needs two passes over the wave's 64 columns
+            constexpr int CPP = 128 / ES;                          // columns per pass: 64 (bf16) / 32 (fp32)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int ps = 0; ps < 64 / CPP; ++ps) {
+#pragma unroll
+                    for (int nj = 0; nj < CPP / 16; ++nj) {
+                        const int ni = ps * (CPP / 16) + nj;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
+                        if (p.res) {
+                            const int m = row0 + wm * 32 + mi * 16 + (lane & 15);
+                            const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                            if (m < p.M && f0 + 3 < p.Nout) {
+                                float rr[4];
+                                load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                            }
+                        }
+                        store4((T *)(stg + (lane & 15) * 144) + nj * 16 + (lane >> 4) * 4, v);
+                    }
+                    // 16 rows x 8 chunks of 16 bytes: two chunks per lane, 128 contiguous bytes per row
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int id = lane + 64 * k, row = id >> 3, ch = id & 7;
+                        const u32x4 val = *(const u32x4 *)(stg + row * 144 + ch * 16);
+                        const int m = row0 + wm * 32 + mi * 16 + row;
+                        const int col = col0 + wn * 64 + ps * CPP + ch * EPC;
+                        if (m >= p.M || col >= p.Nout) continue;
+                        T *dst;
+                        if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
+                        else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
+                        else {
+                            const int f = col - which * p.HC, h = f / p.C, c = f - h * p.C;
+                            dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + p.row_map[m]) * p.C + c;
+                        }
+                        *(u32x4 *)dst = val;
+                    }
+                }
+            }
+        } else {
+            // V columns: lane owns one feature and 4 consecutive nodes; strip = 16 features x 32 nodes
+            constexpr int RB = 32 * ES;                            // bytes of one strip row (64 / 128)
+            constexpr int NCHK = RB / 16;                          // 16-byte chunks per row (4 / 8)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + bz[ni][0];
+                    store4((T *)(stg + (lane & 15) * 144) + mi * 16 + (lane >> 4) * 4, v);
+                }
+#pragma unroll
+                for (int k = 0; k < (16 * NCHK + 63) / 64; ++k) {
+                    const int id = lane + 64 * k;
+                    if (id >= 16 * NCHK) continue;
+                    const int row = id / NCHK, ch = id - row * NCHK;
+                    const u32x4 val = *(const u32x4 *)(stg + row * 144 + ch * 16);
+                    const int fcol = col0 + wn * 64 + ni * 16 + row, m = row0 + wm * 32 + ch * EPC;
+                    if (fcol >= p.Nout || m >= p.M) continue;
+                    const int f = fcol - 2 * p.HC, h = f / p.C, c = f - h * p.C;
+                    T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * p.n_pad;
+                    const int p0 = p.row_map[m];
+                    const bool run = m + EPC - 1 < p.M && p.row_map[m + EPC - 1] == p0 + EPC - 1;
+                    if (run && (p0 & (EPC - 1)) == 0) {
+                        *(u32x4 *)(vrow + p0) = val;
+                    } else if (run && ES == 2 && (p0 & 3) == 0) {
+                        *(u32x2 *)(vrow + p0) = (u32x2){val[0], val[1]};
+                        *(u32x2 *)(vrow + p0 + 4) = (u32x2){val[2], val[3]};
+                    } else {
+                        const u32x4 vv = val;
+                        const T *e = (const T *)&vv;
+#pragma unroll
+                        for (int r = 0; r < EPC; ++r)
+                            if (m + r < p.M) vrow[p.row_map[m + r]] = e[r];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+            for (int b_ = 0; b_ < 4; ++b_) bz[a_][b_] = bzn[a_][b_];
+        DA_PROBE({ DA_TICK(t_e1); c_epi += t_e1 - t_e0; })
+    }
+    DA_PROBE(if (p.prof && tid == 0) { DA_TICK(t_end_); unsigned long long *o = p.prof + 4 * (blockIdx.y * gridDim.x + blockIdx.x); o[0] = t_end_ - t_start; o[1] = c_wait; o[2] = c_mma; o[3] = c_epi; })
+}
+
+// returns 0 = launched, -1 = not applicable
+int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st) {
+    GemmParams p = p0;
+    const int es = (int)esize(prec), BK = 128 / es;
+    const int nk = p.K / BK;
+    if (nk < 1 || nk > 4 || p.K % BK) return -1;
+    const int nrt = (p.M + 127) / 128;
+    const int lds = nk * 16384 + 65536 + 8 * 2304;
+    auto plan = [&](int nct) {                                    // one resident workgroup per CU
+        int groups = 256 / nrt;
+        groups = groups > nct ? nct : (groups < 1 ? 1 : groups);
+        int ntile = (nct + groups - 1) / groups;
+        groups = (nct + ntile - 1) / ntile;
+        p.nct = nct; p.nt = ntile;
+        return dim3((unsigned)groups, (unsigned)nrt);
+    };
+#define DA_ASTAT_LAUNCH(TT, VO, AC, GRID)                                                                 \
+    do {                                                                                                   \
+        static bool attr = false;                                                                          \
+        if (!attr) {                                                                                       \
+            DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_astat<TT, VO, AC>,                       \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384 + 65536 + 8 * 2304)); \
+            attr = true;                                                                                   \
+        }                                                                                                  \
+        k_gemm_astat<TT, VO, AC><<<GRID, 512, lds, st>>>(p);                                               \
+    } while (0)
+#define DA_ASTAT_ACT(TT, GRID)                                                \
+    do {                                                                       \
+        if (act == DA_ACT_GELU) DA_ASTAT_LAUNCH(TT, false, DA_ACT_GELU, GRID); \
+        else if (act == DA_ACT_LEAKY02) DA_ASTAT_LAUNCH(TT, false, DA_ACT_LEAKY02, GRID); \
+        else DA_ASTAT_LAUNCH(TT, false, DA_ACT_NONE, GRID);                    \
+    } while (0)
+    if (!qs) {
+        const dim3 grid = plan((p.Nout + 127) / 128);
+        if (prec == DA_PREC_BF16) DA_ASTAT_ACT(bf16_t, grid);
+        else DA_ASTAT_ACT(float, grid);
+    } else {
+        const int per = qs->HC / 128;
+        const dim3 g1 = plan(3 * per);
+        if (prec == DA_PREC_BF16) DA_ASTAT_LAUNCH(bf16_t, false, DA_ACT_NONE, g1);
+        else DA_ASTAT_LAUNCH(float, false, DA_ACT_NONE, g1);
+        const dim3 g2 = plan(per);
+        if (prec == DA_PREC_BF16) DA_ASTAT_LAUNCH(bf16_t, true, DA_ACT_NONE, g2);
+        else DA_ASTAT_LAUNCH(float, true, DA_ACT_NONE, g2);
+    }
+#undef DA_ASTAT_ACT
+#undef DA_ASTAT_LAUNCH
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace da

@@ -1,0 +1,60 @@
+// Pieces shared by the two MFMA linear kernels (da_gemm_mfma.hip, da_gemm_astat.hip).
+#pragma once
+#include "da_common.h"
+#include "da_internal.h"
+
+namespace da {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(const u32x4 &x, const u32x4 &y, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<float> {
+    static __device__ __forceinline__ f32x4 run(const u32x4 &x, const u32x4 &y, f32x4 c) {
+        const f32x4 a = __builtin_bit_cast(f32x4, x), b = __builtin_bit_cast(f32x4, y);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+};
+
+// 4 consecutive elements; callers guarantee natural alignment (16 B fp32 / 8 B bf16)
+__device__ __forceinline__ void store4(float *dst, const float v[4]) { *(f32x4 *)dst = (f32x4){v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ void store4(bf16_t *dst, const float v[4]) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *(u32x2 *)dst = __builtin_bit_cast(u32x2, b);
+}
+__device__ __forceinline__ void load4(const float *src, float v[4]) {
+    const f32x4 f = *(const f32x4 *)src;
+    v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+}
+__device__ __forceinline__ void load4(const bf16_t *src, float v[4]) {
+    const u32x2 u = *(const u32x2 *)src;
+    v[0] = bf2f((bf16_t)(u[0] & 0xffff)); v[1] = bf2f((bf16_t)(u[0] >> 16));
+    v[2] = bf2f((bf16_t)(u[1] & 0xffff)); v[3] = bf2f((bf16_t)(u[1] >> 16));
+}
+
+struct GemmParams {
+    int M, K, Nout;
+    const void *A; int lda;
+    const void *W; const float *bias;
+    int act; const void *res; void *out; int ldo;
+    // QKV scatter mode (dense attention layouts)
+    int qkv; int HC, C, n_pad; const int32_t *row_map;
+    void *Q, *Kb, *Vt, *S;
+    int nct, nt;     // column tiles of this launch, column tiles per workgroup
+    unsigned long long *prof;   // DA_GEMM_PROBE builds: per-workgroup cycle breakdown [total, wait, mma, epilogue]
+    int debug;   // DA_GEMM_DEBUG bits: 1 = no global stores, 2 = no MFMA, 4 = no DMA (timing experiments only)
+};
+
+}  // namespace da
