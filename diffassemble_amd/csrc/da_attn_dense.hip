@@ -34,8 +34,10 @@ namespace da {
 // DA_ATTN_PROBE builds keep the ablation switches of tools/attn_probe.py (DA_ATTN_DEBUG env)
 #ifdef DA_ATTN_PROBE
 #define DA_ATTN_DBG(...) __VA_ARGS__
+#define DA_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
 #else
 #define DA_ATTN_DBG(...)
+#define DA_TICK(var)
 #endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -52,6 +54,7 @@ struct AttnDenseParams {
     const int32_t *graph_ptr, *pad_ptr;
     int n_pad, H, n_graphs, nqt, act, nodiag;
     float sc;                       // log2(e) / sqrt(C)
+    unsigned long long *prof;       // DA_ATTN_PROBE: per-workgroup cycle breakdown of wave 0
     int debug;                      // DA_ATTN_DEBUG bits (timing experiments): 1 no DMA, 2 no softmax, 4 no PV, 8 no QK
 };
 
@@ -123,6 +126,14 @@ __device__ __forceinline__ void st4(bf16_t *d, const float v[4]) {
 }
 
 // one 16-byte chunk: 4 fp32 or 8 bf16
+__device__ __forceinline__ void unpack_chunk(float, const u32x4 &u, float (&v)[4]) {
+    const f32x4 f = __builtin_bit_cast(f32x4, u);
+    v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+}
+__device__ __forceinline__ void unpack_chunk(bf16_t, const u32x4 &u, float (&v)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = bf2f((bf16_t)(u[k] & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(u[k] >> 16)); }
+}
 __device__ __forceinline__ void ldc(const float *s, float (&v)[4]) { const f32x4 f = *(const f32x4 *)s; v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3]; }
 __device__ __forceinline__ void ldc(const bf16_t *s, float (&v)[8]) {
     const u32x4 u = *(const u32x4 *)s;
@@ -213,16 +224,23 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     int voff[CF::NCB];
 #pragma unroll
     for (int cb = 0; cb < CF::NCB; ++cb) voff[cb] = CF::KBYTES + min(cb * 32 + i, C - 1) * CF::RSV + 16 * half * CF::ES;
+    DA_ATTN_DBG(unsigned long long c_bar = 0, c_iss = 0, c_qk = 0, c_sm = 0, c_pv = 0;)
+    DA_TICK(t_start);
     issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
+        DA_TICK(t0_);
         dma_barrier();                         // own DMA landed (vmcnt(0)) + everyone left the other stage
+        DA_TICK(t1_);
         if (kt + 1 < nkt DA_ATTN_DBG(&& !(p.debug & 1))) issue(kt + 1, (kt + 1) & 1);
+        DA_TICK(t2_);
+        DA_ATTN_DBG(c_bar += t1_ - t0_; c_iss += t2_ - t1_;)
         if (!wave_on) continue;
         const unsigned char *stg = smem + (kt & 1) * CF::STAGE;
 #pragma unroll
         for (int kb = 0; kb < CF::KB; ++kb) {
             const int key0 = kt * CF::BKEYS + kb * 32;
             if (key0 >= n_g) break;
+            DA_TICK(tb_);
             // ---- all LDS fragment reads of this 32-key block are issued up front (K for QK^T now, V^T
             // for PV later): the compiler otherwise pairs every two reads with a full lgkmcnt(0) wait
             // and the MFMA chain idles ~100 cycles per pair
@@ -238,6 +256,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
 #pragma unroll
                 for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), kf[ch], qf[ch], s);
             }
+            DA_ATTN_DBG(asm volatile("" :: "v"(s[0]), "v"(s[15]));)
+            DA_TICK(t3_);
             // V^T fragments: issued behind the QK^T chain, they land under the softmax
             u32x4 vf[CF::ES == 2 ? CF::NCB : 1][2];
             if (CF::ES == 2) {
@@ -260,14 +280,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             float pr[16];
             DA_ATTN_DBG(if (p.debug & 2) { _Pragma("unroll") for (int r = 0; r < 16; ++r) pr[r] = s[r]; } else)
             {
-                float mloc = s[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+                // lane-local max as a tree (v_max3); the cross-half exchange is only needed when the
+                // running max actually moves, and the wave-wide ballot already sees both halves
+                const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
+                const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
+                const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+                const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
                 // rescale only when the running max grows by more than 2^8 (softmax is shift invariant)
                 const bool grow = !(m > -INFINITY) || (mloc - m) * p.sc > 8.0f;
                 if (__any(grow)) {
-                    float mnew = fmaxf(m, mloc);
+                    float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));
                     if (mnew == -INFINITY) mnew = 0.f;           // nothing but masked keys so far
                     const float corr = __builtin_amdgcn_exp2f((m - mnew) * p.sc);
                     m = mnew;
@@ -278,11 +300,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                         for (int r = 0; r < 16; ++r) O[cb][r] *= corr;
                 }
                 const float ms = m * p.sc;
-                float psum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms)); psum += pr[r]; }
-                l += psum;
+                for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms));
+                l += ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])) +
+                     (((pr[8] + pr[9]) + (pr[10] + pr[11])) + ((pr[12] + pr[13]) + (pr[14] + pr[15])));
             }
+            DA_ATTN_DBG(asm volatile("" :: "v"(pr[0]), "v"(pr[15]));)
+            DA_TICK(t4_);
             DA_ATTN_DBG(if (!(p.debug & 4)))
             {
                 if (CF::ES == 2) {
@@ -300,8 +324,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                         O[cb] = mma_pv(T(), stg + voff[cb] - 16 * half * CF::ES + kb * 32 * CF::ES, half, pr, O[cb]);
                 }
             }
+            DA_ATTN_DBG(asm volatile("" :: "v"(O[0][0]), "v"(O[CF::NCB - 1][15]));)
+            DA_TICK(t5_);
+            DA_ATTN_DBG(c_qk += t3_ - tb_; c_sm += t4_ - t3_; c_pv += t5_ - t4_;)
         }
     }
+    DA_TICK(t_loop_end);
     // ---- epilogue: normalise (PyG: sum + 1e-16) and stage O through LDS as [query][c] fp32, then all
     // 256 threads stream whole output rows: 16-byte coalesced reads of skip (+ residual), activation,
     // 16-byte coalesced stores.  (Written straight from the accumulator layout every access is an
@@ -329,28 +357,49 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     dma_barrier();
     constexpr int EPC = 16 / CF::ES, CPR = C / EPC;              // elements per 16-B chunk, chunks per row
     const int nq = min(128, n_g - qt * 128);                      // valid queries of this tile
-    for (int it = tid; it < nq * CPR; it += 256) {
-        const int q = it / CPR, ch = it - q * CPR;
-        const size_t off = ((size_t)node0 + qt * 128 + q) * HC + (size_t)h * C + ch * EPC;
-        const float *src = so + q * RSOF + ch * EPC;
-        float v[EPC], sk[EPC];
-        {
-            const f32x4 a = *(const f32x4 *)src;
-            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-            if (EPC == 8) { const f32x4 b2 = *(const f32x4 *)(src + 4); v[4] = b2[0]; v[5] = b2[1]; v[6] = b2[2]; v[7] = b2[3]; }
-        }
-        ldc((const T *)p.S + off, sk);
+    // batches of NB chunks per thread: all skip / residual loads of a batch are in flight before the
+    // first one is consumed (a rolled load -> add -> store loop pays one L2/HBM latency per chunk)
+    constexpr int NB = 3;
+    for (int it0 = tid; it0 < nq * CPR; it0 += 256 * NB) {
+        u32x4 skv[NB], rsv[NB];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] += sk[e];
-        if (p.res) {
-            ldc((const T *)p.res + off, sk);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+        for (int k = 0; k < NB; ++k) {
+            const int it = it0 + 256 * k;
+            if (it < nq * CPR) {
+                const int q = it / CPR, ch = it - q * CPR;
+                const size_t off = ((size_t)node0 + qt * 128 + q) * HC + (size_t)h * C + ch * EPC;
+                skv[k] = *(const u32x4 *)((const T *)p.S + off);
+                if (p.res) rsv[k] = *(const u32x4 *)((const T *)p.res + off);
+            }
         }
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] = apply_act(v[e], p.act);
-        stc((T *)p.out + off, v);
+        for (int k = 0; k < NB; ++k) {
+            const int it = it0 + 256 * k;
+            if (it < nq * CPR) {
+                const int q = it / CPR, ch = it - q * CPR;
+                const size_t off = ((size_t)node0 + qt * 128 + q) * HC + (size_t)h * C + ch * EPC;
+                const float *src = so + q * RSOF + ch * EPC;
+                float v[EPC], sk[EPC];
+                {
+                    const f32x4 a = *(const f32x4 *)src;
+                    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+                    if (EPC == 8) { const f32x4 b2 = *(const f32x4 *)(src + 4); v[4] = b2[0]; v[5] = b2[1]; v[6] = b2[2]; v[7] = b2[3]; }
+                }
+                unpack_chunk(T(), skv[k], sk);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+                if (p.res) {
+                    unpack_chunk(T(), rsv[k], sk);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = apply_act(v[e], p.act);
+                stc((T *)p.out + off, v);
+            }
+        }
     }
+    DA_ATTN_DBG(if (p.prof && tid == 0) { DA_TICK(t_end_); unsigned long long *o = p.prof + 8 * blockIdx.x; o[0] = t_end_ - t_start; o[1] = c_bar; o[2] = c_iss; o[3] = c_qk; o[4] = c_sm; o[5] = c_pv; o[6] = t_end_ - t_loop_end; o[7] = 1; })
 }
 
 template <typename T, int C>
@@ -379,6 +428,7 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.nqt = (max_graph_nodes + 127) / 128; p.act = act; p.nodiag = nodiag;
     p.sc = 1.4426950408889634f / sqrtf((float)C);
     { const char *e = getenv("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
+    { const char *e = getenv("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     const int nblocks = p.nqt * heads * n_graphs;
     if (nblocks <= 0) return 0;
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, nblocks, st) : launch_tc<bf16_t, 144>(p, nblocks, st);
