@@ -27,6 +27,99 @@ namespace da {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Wave-private epilogue of one 32 x 64 (per wave) output tile: bias / activation / residual in
+// registers, 16-row strips through this wave's own LDS strip, 128-byte contiguous global stores.
+template <typename T, bool VORIENT, int ACT>
+__device__ __forceinline__ void astat_epilogue(const GemmParams &p, const f32x4 (&acc)[2][4], const float (&bz)[4][4],
+                                               unsigned char *stg, int row0, int col0, int which, int wm, int wn,
+                                               int lane) {
+    constexpr int ES = (int)sizeof(T), EPC = 16 / ES;
+        if (!VORIENT) {
+            // strip = 16 nodes x 128 bytes of features; fp32 needs two passes over the wave's 64 columns
+            constexpr int CPP = 128 / ES;                          // columns per pass: 64 (bf16) / 32 (fp32)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int ps = 0; ps < 64 / CPP; ++ps) {
+#pragma unroll
+                    for (int nj = 0; nj < CPP / 16; ++nj) {
+                        const int ni = ps * (CPP / 16) + nj;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
+                        if (p.res) {
+                            const int m = row0 + wm * 32 + mi * 16 + (lane & 15);
+                            const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                            if (m < p.M && f0 + 3 < p.Nout) {
+                                float rr[4];
+                                load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                            }
+                        }
+                        store4((T *)(stg + (lane & 15) * 144) + nj * 16 + (lane >> 4) * 4, v);
+                    }
+                    // 16 rows x 8 chunks of 16 bytes: two chunks per lane, 128 contiguous bytes per row
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int id = lane + 64 * k, row = id >> 3, ch = id & 7;
+                        const u32x4 val = *(const u32x4 *)(stg + row * 144 + ch * 16);
+                        const int m = row0 + wm * 32 + mi * 16 + row;
+                        const int col = col0 + wn * 64 + ps * CPP + ch * EPC;
+                        if (m >= p.M || col >= p.Nout) continue;
+                        T *dst;
+                        if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
+                        else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
+                        else {
+                            const int f = col - which * p.HC, h = f / p.C, c = f - h * p.C;
+                            dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + p.row_map[m]) * p.C + c;
+                        }
+                        *(u32x4 *)dst = val;
+                    }
+                }
+            }
+        } else {
+            // V columns: lane owns one feature and 4 consecutive nodes; strip = 16 features x 32 nodes
+            constexpr int RB = 32 * ES;                            // bytes of one strip row (64 / 128)
+            constexpr int NCHK = RB / 16;                          // 16-byte chunks per row (4 / 8)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + bz[ni][0];
+                    store4((T *)(stg + (lane & 15) * 144) + mi * 16 + (lane >> 4) * 4, v);
+                }
+#pragma unroll
+                for (int k = 0; k < (16 * NCHK + 63) / 64; ++k) {
+                    const int id = lane + 64 * k;
+                    if (id >= 16 * NCHK) continue;
+                    const int row = id / NCHK, ch = id - row * NCHK;
+                    const u32x4 val = *(const u32x4 *)(stg + row * 144 + ch * 16);
+                    const int fcol = col0 + wn * 64 + ni * 16 + row, m = row0 + wm * 32 + ch * EPC;
+                    if (fcol >= p.Nout || m >= p.M) continue;
+                    const int f = fcol - 2 * p.HC, h = f / p.C, c = f - h * p.C;
+                    T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * p.n_pad;
+                    const int p0 = p.row_map[m];
+                    const bool run = m + EPC - 1 < p.M && p.row_map[m + EPC - 1] == p0 + EPC - 1;
+                    if (run && (p0 & (EPC - 1)) == 0) {
+                        *(u32x4 *)(vrow + p0) = val;
+                    } else if (run && ES == 2 && (p0 & 3) == 0) {
+                        *(u32x2 *)(vrow + p0) = (u32x2){val[0], val[1]};
+                        *(u32x2 *)(vrow + p0 + 4) = (u32x2){val[2], val[3]};
+                    } else {
+                        const u32x4 vv = val;
+                        const T *e = (const T *)&vv;
+#pragma unroll
+                        for (int r = 0; r < EPC; ++r)
+                            if (m + r < p.M) vrow[p.row_map[m + r]] = e[r];
+                    }
+                }
+            }
+        }
+}
+
 template <typename T, bool VORIENT, int ACT>
 __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -149,91 +242,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
         }
         DA_TICK(t_e0);
 
-        // ---------------------------------------------------------- epilogue (wave private, no barrier)
-        if (!VORIENT) {
-            // strip = 16 nodes x 128 bytes of features; fp32 needs two passes over the wave's 64 columns
-            constexpr int CPP = 128 / ES;                          // columns per pass: 64 (bf16) / 32 (fp32)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-                for (int ps = 0; ps < 64 / CPP; ++ps) {
-#pragma unroll
-                    for (int nj = 0; nj < CPP / 16; ++nj) {
-                        const int ni = ps * (CPP / 16) + nj;
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
-                        if (p.res) {
-                            const int m = row0 + wm * 32 + mi * 16 + (lane & 15);
-                            const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
-                            if (m < p.M && f0 + 3 < p.Nout) {
-                                float rr[4];
-                                load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                            }
-                        }
-                        store4((T *)(stg + (lane & 15) * 144) + nj * 16 + (lane >> 4) * 4, v);
-                    }
-                    // 16 rows x 8 chunks of 16 bytes: two chunks per lane, 128 contiguous bytes per row
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int id = lane + 64 * k, row = id >> 3, ch = id & 7;
-                        const u32x4 val = *(const u32x4 *)(stg + row * 144 + ch * 16);
-                        const int m = row0 + wm * 32 + mi * 16 + row;
-                        const int col = col0 + wn * 64 + ps * CPP + ch * EPC;
-                        if (m >= p.M || col >= p.Nout) continue;
-                        T *dst;
-                        if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
-                        else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
-                        else {
-                            const int f = col - which * p.HC, h = f / p.C, c = f - h * p.C;
-                            dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + p.row_map[m]) * p.C + c;
-                        }
-                        *(u32x4 *)dst = val;
-                    }
-                }
-            }
-        } else {
-            // V columns: lane owns one feature and 4 consecutive nodes; strip = 16 features x 32 nodes
-            constexpr int RB = 32 * ES;                            // bytes of one strip row (64 / 128)
-            constexpr int NCHK = RB / 16;                          // 16-byte chunks per row (4 / 8)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + bz[ni][0];
-                    store4((T *)(stg + (lane & 15) * 144) + mi * 16 + (lane >> 4) * 4, v);
-                }
-#pragma unroll
-                for (int k = 0; k < (16 * NCHK + 63) / 64; ++k) {
-                    const int id = lane + 64 * k;
-                    if (id >= 16 * NCHK) continue;
-                    const int row = id / NCHK, ch = id - row * NCHK;
-                    const u32x4 val = *(const u32x4 *)(stg + row * 144 + ch * 16);
-                    const int fcol = col0 + wn * 64 + ni * 16 + row, m = row0 + wm * 32 + ch * EPC;
-                    if (fcol >= p.Nout || m >= p.M) continue;
-                    const int f = fcol - 2 * p.HC, h = f / p.C, c = f - h * p.C;
-                    T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * p.n_pad;
-                    const int p0 = p.row_map[m];
-                    const bool run = m + EPC - 1 < p.M && p.row_map[m + EPC - 1] == p0 + EPC - 1;
-                    if (run && (p0 & (EPC - 1)) == 0) {
-                        *(u32x4 *)(vrow + p0) = val;
-                    } else if (run && ES == 2 && (p0 & 3) == 0) {
-                        *(u32x2 *)(vrow + p0) = (u32x2){val[0], val[1]};
-                        *(u32x2 *)(vrow + p0 + 4) = (u32x2){val[2], val[3]};
-                    } else {
-                        const u32x4 vv = val;
-                        const T *e = (const T *)&vv;
-#pragma unroll
-                        for (int r = 0; r < EPC; ++r)
-                            if (m + r < p.M) vrow[p.row_map[m + r]] = e[r];
-                    }
-                }
-            }
-        }
+        astat_epilogue<T, VORIENT, ACT>(p, acc, bz, stg, row0, col0, which, wm, wn, lane);
 #pragma unroll
         for (int a_ = 0; a_ < 4; ++a_)
 #pragma unroll
@@ -241,6 +250,129 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
         DA_PROBE({ DA_TICK(t_e1); c_epi += t_e1 - t_e0; })
     }
     DA_PROBE(if (p.prof && tid == 0) { DA_TICK(t_end_); unsigned long long *o = p.prof + 4 * (blockIdx.y * gridDim.x + blockIdx.x); o[0] = t_end_ - t_start; o[1] = c_wait; o[2] = c_mma; o[3] = c_epi; })
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register-staged variant (the default): W tiles travel global -> VGPR -> LDS with plain loads
+// issued TA column tiles (TA * NK stages = 128 KB per CU) ahead of their use.  Why: measured with the
+// phase probe, LDS-DMA requests take ~2.3 us from issue to landing under load, so the three 16 KB
+// stages the LDS budget allows in flight sustain only ~23 GB/s per CU; plain loads keep their data in
+// the (much larger) register file instead, and hipcc counts their vmcnt by itself.
+template <typename T, bool VORIENT, int ACT, int NK>
+__global__ __launch_bounds__(512, 2) void k_gemm_astat_rs(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ES = (int)sizeof(T), TA = 2;
+    unsigned char *sA = smem;                                    // [NK][128 rows][128 B]
+    unsigned char *sW = smem + NK * 16384;                       // 2 slots of [128 rows][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    unsigned char *stg = smem + NK * 16384 + 32768 + wid * 2304;
+    const int row0 = blockIdx.y * 128;
+    const int t_beg = blockIdx.x * p.nt, t_end = min(t_beg + p.nt, p.nct);
+    const int ntile = t_end - t_beg;
+    const int per = p.qkv ? p.HC / 128 : 0;
+    auto colblock = [&](int t) { return !p.qkv ? t : (VORIENT ? t + 2 * per : (t < 2 * per ? t : t + per)); };
+    if (ntile <= 0) return;
+
+    // staging role of this thread: 16-byte chunk c of rows r0 and r0 + 64 of a [128][128 B] tile
+    const int r0 = tid >> 3, c = tid & 7;
+    const int lo0 = r0 * 128 + ((c ^ (r0 & 7)) << 4), lo1 = lo0 + 64 * 128;     // (r0 + 64) & 7 == r0 & 7
+    const size_t ldaB = (size_t)p.lda * ES, ldwB = (size_t)p.K * ES;
+    {   // A panel, once
+        const char *a0 = (const char *)p.A + c * 16 + (size_t)min(row0 + r0, p.M - 1) * ldaB;
+        const char *a1 = (const char *)p.A + c * 16 + (size_t)min(row0 + r0 + 64, p.M - 1) * ldaB;
+        u32x4 ra[NK][2];
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) { ra[kt][0] = *(const u32x4 *)(a0 + kt * 128); ra[kt][1] = *(const u32x4 *)(a1 + kt * 128); }
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) { *(u32x4 *)(sA + kt * 16384 + lo0) = ra[kt][0]; *(u32x4 *)(sA + kt * 16384 + lo1) = ra[kt][1]; }
+    }
+    const char *Wb = (const char *)p.W + c * 16;
+    u32x4 wr[TA][NK][2];                                         // TA column tiles of W in flight
+    auto wload = [&](int ti, u32x4 (&dst)[NK][2]) {
+        if (ti < ntile) {
+            const int c0 = colblock(t_beg + ti) * 128;
+            const char *w0 = Wb + (size_t)min(c0 + r0, p.Nout - 1) * ldwB;
+            const char *w1 = Wb + (size_t)min(c0 + r0 + 64, p.Nout - 1) * ldwB;
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) { dst[kt][0] = *(const u32x4 *)(w0 + kt * 128); dst[kt][1] = *(const u32x4 *)(w1 + kt * 128); }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < TA; ++u) wload(u, wr[u]);
+    auto load_bias = [&](int ti, float (&bz)[4][4]) {
+        const int col0 = colblock(t_beg + min(ti, ntile - 1)) * 128;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            if (!VORIENT) {
+                const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
+                else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
+            } else {
+                const int fcol = col0 + wn * 64 + ni * 16 + (lane & 15);
+                bz[ni][0] = (p.bias && fcol < p.Nout) ? p.bias[fcol] : 0.f;
+                bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f;
+            }
+        }
+    };
+    // stage 0 of tile 0 into slot 0
+    *(u32x4 *)(sW + lo0) = wr[0][0][0];
+    *(u32x4 *)(sW + lo1) = wr[0][0][1];
+
+    for (int tb = 0; tb < ntile; tb += TA) {
+#pragma unroll
+        for (int u = 0; u < TA; ++u) {
+            const int ti = tb + u;
+            if (ti >= ntile) break;
+            const int col0 = colblock(t_beg + ti) * 128;
+            const int which = p.qkv ? col0 / p.HC : 0;
+            float bz[4][4];
+            load_bias(ti, bz);
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) {
+                const int s = ti * NK + kt;                         // global stage index; slot s & 1
+                __syncthreads();                                    // stage s is in LDS; slot (s + 1) & 1 is free
+                // hand the NEXT stage to LDS and immediately re-use its registers for the stage TA tiles later
+                if (kt + 1 < NK) {
+                    *(u32x4 *)(sW + ((s + 1) & 1) * 16384 + lo0) = wr[u][kt + 1][0];
+                    *(u32x4 *)(sW + ((s + 1) & 1) * 16384 + lo1) = wr[u][kt + 1][1];
+                } else if (ti + 1 < ntile) {
+                    *(u32x4 *)(sW + ((s + 1) & 1) * 16384 + lo0) = wr[(u + 1) % TA][0][0];
+                    *(u32x4 *)(sW + ((s + 1) & 1) * 16384 + lo1) = wr[(u + 1) % TA][0][1];
+                }
+                if (kt == NK - 1) wload(ti + TA, wr[u]);            // all of wr[u] has been handed over by now
+                const unsigned char *a = sA + kt * 16384, *w = sW + (s & 1) * 16384;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4 fa[2], fw[4];
+                    const int cc = kk * 4 + (lane >> 4);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int R = wm * 32 + t * 16 + (lane & 15);
+                        fa[t] = *(const u32x4 *)(a + R * 128 + ((cc ^ (R & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int R = wn * 64 + t * 16 + (lane & 15);
+                        fw[t] = *(const u32x4 *)(w + R * 128 + ((cc ^ (R & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            acc[mi][ni] = VORIENT ? Mma16<T>::run(fa[mi], fw[ni], acc[mi][ni])
+                                                  : Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);
+                }
+            }
+            astat_epilogue<T, VORIENT, ACT>(p, acc, bz, stg, row0, col0, which, wm, wn, lane);
+        }
+    }
 }
 
 // returns 0 = launched, -1 = not applicable
@@ -259,8 +391,24 @@ int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int 
         p.nct = nct; p.nt = ntile;
         return dim3((unsigned)groups, (unsigned)nrt);
     };
+    static int use_dma = -1;
+    if (use_dma < 0) { const char *e = getenv("DA_ASTAT_DMA"); use_dma = (e && e[0] == '1') ? 1 : 0; }
+    const bool rs = !use_dma && (nk == 2 || nk == 4);
+    const int lds_rs = nk * 16384 + 32768 + 8 * 2304;
+#define DA_ASTAT_RS(TT, VO, AC, NKK, GRID)                                                                 \
+    do {                                                                                                   \
+        static bool attr = false;                                                                          \
+        if (!attr) {                                                                                       \
+            DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_astat_rs<TT, VO, AC, NKK>,               \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, NKK * 16384 + 32768 + 8 * 2304)); \
+            attr = true;                                                                                   \
+        }                                                                                                  \
+        k_gemm_astat_rs<TT, VO, AC, NKK><<<GRID, 512, lds_rs, st>>>(p);                                    \
+    } while (0)
 #define DA_ASTAT_LAUNCH(TT, VO, AC, GRID)                                                                 \
     do {                                                                                                   \
+        if (rs && nk == 4) { DA_ASTAT_RS(TT, VO, AC, 4, GRID); break; }                                    \
+        if (rs && nk == 2) { DA_ASTAT_RS(TT, VO, AC, 2, GRID); break; }                                    \
         static bool attr = false;                                                                          \
         if (!attr) {                                                                                       \
             DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_astat<TT, VO, AC>,                       \
