@@ -29,10 +29,38 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // Wave-private epilogue of one 32 x 64 (per wave) output tile: bias / activation / residual in
 // registers, 16-row strips through this wave's own LDS strip, 128-byte contiguous global stores.
+// Padded-row slots (row_map) of the rows a lane stores in the epilogue, fetched once per workgroup:
+// the rows of an A-stationary workgroup never change, and a row_map load inside the epilogue is a
+// dependent global load in front of every store (measured +60 % on the conv-3 projection).
+struct AstatSlots {
+    int q[2][2];        // Q/K tiles: slot of row wm*32 + mi*16 + ((lane + 64 k) >> 3)
+    int v0[2], v1[2];   // V tiles: slots of the first / last node of chunk id = lane + 64 k
+};
+
+template <typename T>
+__device__ __forceinline__ AstatSlots astat_load_slots(const GemmParams &p, int row0, int wm, int lane) {
+    constexpr int ES = (int)sizeof(T), EPC = 16 / ES, NCHK = 32 * ES / 16;
+    AstatSlots rs;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int m = row0 + wm * 32 + mi * 16 + ((lane + 64 * k) >> 3);
+            rs.q[mi][k] = (p.qkv && m < p.M) ? p.row_map[m] : 0;
+        }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int id = lane + 64 * k, ch = id % NCHK, m = row0 + wm * 32 + ch * EPC;
+        rs.v0[k] = (p.qkv && m < p.M) ? p.row_map[m] : 0;
+        rs.v1[k] = (p.qkv && m + EPC - 1 < p.M) ? p.row_map[m + EPC - 1] : -1;
+    }
+    return rs;
+}
+
 template <typename T, bool VORIENT, int ACT>
 __device__ __forceinline__ void astat_epilogue(const GemmParams &p, const f32x4 (&acc)[2][4], const float (&bz)[4][4],
-                                               unsigned char *stg, int row0, int col0, int which, int wm, int wn,
-                                               int lane) {
+                                               unsigned char *stg, const AstatSlots &rs, int row0, int col0,
+                                               int which, int wm, int wn, int lane) {
     constexpr int ES = (int)sizeof(T), EPC = 16 / ES;
         if (!VORIENT) {
             // strip = 16 nodes x 128 bytes of features; fp32 needs two passes over the wave's 64 columns
@@ -67,12 +95,13 @@ __device__ __forceinline__ void astat_epilogue(const GemmParams &p, const f32x4 
                         const int m = row0 + wm * 32 + mi * 16 + row;
                         const int col = col0 + wn * 64 + ps * CPP + ch * EPC;
                         if (m >= p.M || col >= p.Nout) continue;
+                        if (p.qkv && (p.debug & (which == 3 ? 64 : 32))) continue;
                         T *dst;
                         if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
                         else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
                         else {
-                            const int f = col - which * p.HC, h = f / p.C, c = f - h * p.C;
-                            dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + p.row_map[m]) * p.C + c;
+                            const int f = col - which * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
+                            dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + rs.q[mi][k]) * p.C + c;
                         }
                         *(u32x4 *)dst = val;
                     }
@@ -99,10 +128,11 @@ __device__ __forceinline__ void astat_epilogue(const GemmParams &p, const f32x4 
                     const u32x4 val = *(const u32x4 *)(stg + row * 144 + ch * 16);
                     const int fcol = col0 + wn * 64 + ni * 16 + row, m = row0 + wm * 32 + ch * EPC;
                     if (fcol >= p.Nout || m >= p.M) continue;
-                    const int f = fcol - 2 * p.HC, h = f / p.C, c = f - h * p.C;
-                    T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * p.n_pad;
-                    const int p0 = p.row_map[m];
-                    const bool run = m + EPC - 1 < p.M && p.row_map[m + EPC - 1] == p0 + EPC - 1;
+                    const int f = fcol - 2 * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
+                    T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * (p.n_pad + ((p.debug & 16) ? 64 : 0));
+                    if (p.debug & 8) continue;
+                    const int p0 = rs.v0[k];
+                    const bool run = m + EPC - 1 < p.M && rs.v1[k] == p0 + EPC - 1;
                     if (run && (p0 & (EPC - 1)) == 0) {
                         *(u32x4 *)(vrow + p0) = val;
                     } else if (run && ES == 2 && (p0 & 3) == 0) {
@@ -132,6 +162,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
     const int wm = wid >> 1, wn = wid & 1;                       // 4 x 2 waves: rows 32 wm, cols 64 wn
     unsigned char *stg = smem + nk * 16384 + 65536 + wid * 2304; // private strip: 16 rows x 144 B
     const int row0 = blockIdx.y * 128;
+    const AstatSlots rs = astat_load_slots<T>(p, row0, wm, lane);
     const int t_beg = blockIdx.x * p.nt, t_end = min(t_beg + p.nt, p.nct);
     const int per = p.qkv ? p.HC / 128 : 0;
     auto colblock = [&](int t) { return !p.qkv ? t : (VORIENT ? t + 2 * per : (t < 2 * per ? t : t + per)); };
@@ -242,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
         }
         DA_TICK(t_e0);
 
-        astat_epilogue<T, VORIENT, ACT>(p, acc, bz, stg, row0, col0, which, wm, wn, lane);
+        astat_epilogue<T, VORIENT, ACT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane);
 #pragma unroll
         for (int a_ = 0; a_ < 4; ++a_)
 #pragma unroll
@@ -258,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
 // phase probe, LDS-DMA requests take ~2.3 us from issue to landing under load, so the three 16 KB
 // stages the LDS budget allows in flight sustain only ~23 GB/s per CU; plain loads keep their data in
 // the (much larger) register file instead, and hipcc counts their vmcnt by itself.
-template <typename T, bool VORIENT, int ACT, int NK>
+template <typename T, bool QKV, int ACT, int NK>
 __global__ __launch_bounds__(512, 2) void k_gemm_astat_rs(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ES = (int)sizeof(T), TA = 2;
@@ -269,10 +300,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat_rs(GemmParams p) {
     const int wm = wid >> 1, wn = wid & 1;
     unsigned char *stg = smem + NK * 16384 + 32768 + wid * 2304;
     const int row0 = blockIdx.y * 128;
+    const AstatSlots rs = astat_load_slots<T>(p, row0, wm, lane);
     const int t_beg = blockIdx.x * p.nt, t_end = min(t_beg + p.nt, p.nct);
     const int ntile = t_end - t_beg;
-    const int per = p.qkv ? p.HC / 128 : 0;
-    auto colblock = [&](int t) { return !p.qkv ? t : (VORIENT ? t + 2 * per : (t < 2 * per ? t : t + per)); };
+    auto colblock = [&](int t) { return t; };             // QKV mode: one launch walks Q | K | V | skip tiles
     if (ntile <= 0) return;
 
     // staging role of this thread: 16-byte chunk c of rows r0 and r0 + 64 of a [128][128 B] tile
@@ -303,9 +334,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat_rs(GemmParams p) {
     for (int u = 0; u < TA; ++u) wload(u, wr[u]);
     auto load_bias = [&](int ti, float (&bz)[4][4]) {
         const int col0 = colblock(t_beg + min(ti, ntile - 1)) * 128;
+        const bool vt = QKV && col0 / p.HC == 2;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            if (!VORIENT) {
+            if (!vt) {
                 const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
                 if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
                 else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
@@ -326,7 +358,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat_rs(GemmParams p) {
             const int ti = tb + u;
             if (ti >= ntile) break;
             const int col0 = colblock(t_beg + ti) * 128;
-            const int which = p.qkv ? col0 / p.HC : 0;
+            const int which = QKV ? col0 / p.HC : 0;
+            const bool vtile = QKV && which == 2;            // V columns: transposed store, swapped MFMA operands
             float bz[4][4];
             load_bias(ti, bz);
             f32x4 acc[2][4];
@@ -362,15 +395,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat_rs(GemmParams p) {
                         const int R = wn * 64 + t * 16 + (lane & 15);
                         fw[t] = *(const u32x4 *)(w + R * 128 + ((cc ^ (R & 7)) << 4));
                     }
+                    if (vtile) {
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-                            acc[mi][ni] = VORIENT ? Mma16<T>::run(fa[mi], fw[ni], acc[mi][ni])
-                                                  : Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);
+                            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Mma16<T>::run(fa[mi], fw[ni], acc[mi][ni]);
+                    } else {
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);
+                    }
                 }
             }
-            astat_epilogue<T, VORIENT, ACT>(p, acc, bz, stg, row0, col0, which, wm, wn, lane);
+            if (vtile) astat_epilogue<T, true, DA_ACT_NONE>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane);
+            else astat_epilogue<T, false, ACT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane);
         }
     }
 }
@@ -407,8 +446,8 @@ int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int 
     } while (0)
 #define DA_ASTAT_LAUNCH(TT, VO, AC, GRID)                                                                 \
     do {                                                                                                   \
-        if (rs && nk == 4) { DA_ASTAT_RS(TT, VO, AC, 4, GRID); break; }                                    \
-        if (rs && nk == 2) { DA_ASTAT_RS(TT, VO, AC, 2, GRID); break; }                                    \
+        if (rs && nk == 4) { DA_ASTAT_RS(TT, false, AC, 4, GRID); break; }                                 \
+        if (rs && nk == 2) { DA_ASTAT_RS(TT, false, AC, 2, GRID); break; }                                 \
         static bool attr = false;                                                                          \
         if (!attr) {                                                                                       \
             DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_astat<TT, VO, AC>,                       \
@@ -427,6 +466,10 @@ int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int 
         const dim3 grid = plan((p.Nout + 127) / 128);
         if (prec == DA_PREC_BF16) DA_ASTAT_ACT(bf16_t, grid);
         else DA_ASTAT_ACT(float, grid);
+    } else if (rs) {
+        const dim3 g = plan(4 * (qs->HC / 128));                     // Q | K | V | skip tiles in ONE launch
+        if (prec == DA_PREC_BF16) { if (nk == 4) DA_ASTAT_RS(bf16_t, true, DA_ACT_NONE, 4, g); else DA_ASTAT_RS(bf16_t, true, DA_ACT_NONE, 2, g); }
+        else { if (nk == 4) DA_ASTAT_RS(float, true, DA_ACT_NONE, 4, g); else DA_ASTAT_RS(float, true, DA_ACT_NONE, 2, g); }
     } else {
         const int per = qs->HC / 128;
         const dim3 g1 = plan(3 * per);

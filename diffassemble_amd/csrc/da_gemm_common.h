@@ -51,6 +51,7 @@ struct GemmParams {
     int act; const void *res; void *out; int ldo;
     // QKV scatter mode (dense attention layouts)
     int qkv; int HC, C, n_pad; const int32_t *row_map;
+    unsigned Cmagic;   // ceil(2^32 / C): f / C == __umulhi(f, Cmagic) for the f < 2^16 that occur here
     void *Q, *Kb, *Vt, *S;
     int nct, nt;     // column tiles of this launch, column tiles per workgroup
     unsigned long long *prof;   // DA_GEMM_PROBE builds: per-workgroup cycle breakdown [total, wait, mma, epilogue]

@@ -50,24 +50,121 @@ __device__ __forceinline__ void mma_block(const unsigned char *sA, const unsigne
     }
 }
 
-template <typename T, bool VORIENT, int ACT>
+// Padded-row positions of the rows this thread stores in the epilogue, fetched ONCE per workgroup (a
+// workgroup keeps its 128 rows for all its column tiles): a row_map load inside the epilogue is a
+// dependent global load on the critical path of every tile (measured: +60 % on the conv-3 projection).
+template <int PASSES, int NIT>
+struct RowSlots {
+    int q[PASSES][NIT];     // Q/K tiles: slot of row (tid + 256 it) / CPR + pass * ROWS
+    int v0, v1;             // V tiles: slots of the first / last node of this thread's 16-byte chunk
+};
+
+template <typename T, bool VORIENT, int ACT, int PASSES, int NIT>
+__device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (&acc)[4][4], const float (&bz)[4][4],
+                                              unsigned char *stg, const RowSlots<PASSES, NIT> &rs, int row0, int col0,
+                                              int which, int wm, int wn, int lane, int tid) {
+    constexpr int ES = (int)sizeof(T), EPC = 16 / ES;          // elements per 16-byte chunk
+    constexpr int RSO = 128 * ES + 16;                          // padded LDS row of the staged tile
+    constexpr int ROWS = ES == 4 ? 32 : 64;                     // staged rows per pass (fits one ring slot)
+    constexpr int CPR = 128 * ES / 16;                          // 16-byte chunks per staged row
+    static_assert(ROWS * RSO <= 32768 && PASSES == 128 / ROWS && NIT == ROWS * CPR / 256, "epilogue staging");
+    const int wrow = VORIENT ? wn : wm;                         // wave coordinate along the staged ROWS
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        dma_barrier();                                        // slot free / previous pass read out
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int rg = wrow * 64 + (VORIENT ? ni : mi) * 16 + (lane & 15);   // row of the 128 x 128 image
+                if (rg / ROWS != pass) continue;                // wave-uniform (16-row groups never straddle)
+                float v[4];
+                int cl;
+                if (!VORIENT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
+                    if (p.res) {
+                        const int m = row0 + wm * 64 + mi * 16 + (lane & 15);
+                        const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                        if (m < p.M && f0 + 3 < p.Nout) {
+                            float rr[4];
+                            load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                        }
+                    }
+                    cl = wn * 64 + ni * 16 + (lane >> 4) * 4;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + bz[ni][0];
+                    cl = wm * 64 + mi * 16 + (lane >> 4) * 4;
+                }
+                store4((T *)(stg + (rg % ROWS) * RSO) + cl, v);
+            }
+        }
+        dma_barrier();
+        u32x4 val[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
+            val[it] = *(const u32x4 *)(stg + row * RSO + ch * 16);
+        }
+        if (p.debug & 1) continue;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
+            const int grow = row + pass * ROWS;                 // row of the 128 x 128 staged image
+            if (!VORIENT) {
+                const int m = row0 + grow, col = col0 + ch * EPC;
+                if (m >= p.M || col >= p.Nout) continue;
+                T *dst;
+                if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
+                else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
+                else {
+                    const int f = col - which * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
+                    dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + rs.q[pass][it]) * p.C + c;
+                }
+                *(u32x4 *)dst = val[it];
+            } else {
+                const int fcol = col0 + grow, m = row0 + ch * EPC;
+                if (fcol >= p.Nout || m >= p.M) continue;
+                const int f = fcol - 2 * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
+                T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * p.n_pad;
+                const int p0 = rs.v0;
+                const bool run = m + EPC - 1 < p.M && rs.v1 == p0 + EPC - 1;             // 8 (4) consecutive rows
+                if (run && (p0 & (EPC - 1)) == 0) {
+                    *(u32x4 *)(vrow + p0) = val[it];
+                } else if (run && ES == 2 && (p0 & 3) == 0) {   // graph slot offset = 4 mod 8: two 8-byte stores
+                    const u32x4 vv = val[it];
+                    *(u32x2 *)(vrow + p0) = (u32x2){vv[0], vv[1]};
+                    *(u32x2 *)(vrow + p0 + 4) = (u32x2){vv[2], vv[3]};
+                } else {                                        // chunk straddles a graph boundary / ragged
+                    const u32x4 vv = val[it];
+                    const T *e = (const T *)&vv;
+#pragma unroll
+                    for (int r = 0; r < EPC; ++r)
+                        if (m + r < p.M) vrow[p.row_map[m + r]] = e[r];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, bool QKV, int ACT>
 __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     // two stages x (A tile 16 KB + W tile 16 KB), filled by LDS-DMA (global_load_lds_dwordx4).  A
     // workgroup owns one 128-row tile of A and walks `nt` consecutive 128-column tiles of W as ONE
     // continuous stream of K stages, so the DMA of the next column tile's first stage is already in
     // flight while the current tile's epilogue runs (the epilogue stages through the ring slot that
-    // was consumed last).
+    // was consumed last).  In QKV mode the walk covers Q | K | V | skip column blocks in one launch; the
+    // V blocks swap the MFMA operands and take the transposed epilogue (wave-uniform branch per tile).
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 128 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.y * 128;
-    constexpr int BK = 128 / (int)sizeof(T);
-    constexpr bool vorient = VORIENT;
+    constexpr int ES = (int)sizeof(T), EPC = 16 / ES, BK = 128 / ES;
+    constexpr int ROWS = ES == 4 ? 32 : 64, PASSES = 128 / ROWS, CPR = 128 * ES / 16, NIT = ROWS * CPR / 256;
     const int t_beg = blockIdx.x * p.nt, t_end = min(t_beg + p.nt, p.nct);
-    const int per = p.qkv ? p.HC / 128 : 0;
-    // logical column tile -> 128-column block of the output (QKV mode is two launches: the V blocks,
-    // VORIENT, and everything else)
-    auto colblock = [&](int t) { return !p.qkv ? t : (VORIENT ? t + 2 * per : (t < 2 * per ? t : t + per)); };
 
     // Staging by LDS-DMA: wave w fills rows [32w, 32w+32) of both tiles, 8 rows (1 KB) per instruction.
     // The DMA writes lane l at (wave-uniform base) + 16 l, i.e. row (l >> 3), slot (l & 7); the XOR
@@ -83,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     const int S = (t_end - t_beg) * nk;                       // stages of this workgroup
     auto issue = [&](int s) {
         const int ti = s / nk, kt = s - ti * nk;
-        const int c0 = colblock(t_beg + ti) * 128;
+        const int c0 = (t_beg + ti) * 128;
         unsigned char *sa = smem + (s & 1) * 32768 + (32 * wid) * 128, *sw = sa + 16384;
         const size_t kb = (size_t)kt * 128;
 #pragma unroll
@@ -97,22 +194,35 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     };
     if (S > 0 && !(p.debug & 4)) issue(0);
 
-    constexpr int ES = (int)sizeof(T), EPC = 16 / ES;          // elements per 16-byte chunk
-    constexpr int RSO = 128 * ES + 16;                          // padded LDS row of the staged tile
-    constexpr int ROWS = ES == 4 ? 32 : 64, PASSES = 128 / ROWS; // staged rows per pass (fits one ring slot)
-    constexpr int CPR = 128 * ES / 16;                          // 16-byte chunks per staged row
-    constexpr int NIT = ROWS * CPR / 256;
-    static_assert(ROWS * RSO <= 32768, "epilogue staging must fit in one ring slot");
+    RowSlots<PASSES, NIT> rs;
+    rs.v0 = rs.v1 = 0;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) rs.q[pass][it] = 0;
+    if (QKV) {
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int m = row0 + (tid + it * 256) / CPR + pass * ROWS;
+                if (m < p.M) rs.q[pass][it] = p.row_map[m];
+            }
+        const int mv = row0 + (tid % CPR) * EPC;              // (tid + 256 it) % CPR does not depend on it
+        if (mv < p.M) rs.v0 = p.row_map[mv];
+        if (mv + EPC - 1 < p.M) rs.v1 = p.row_map[mv + EPC - 1];
+    }
 
     for (int ti = 0; ti < t_end - t_beg; ++ti) {
-        const int col0 = colblock(t_beg + ti) * 128;
-        const int which = p.qkv ? col0 / p.HC : 0;
+        const int col0 = (t_beg + ti) * 128;
+        const int which = QKV ? col0 / p.HC : 0;
+        const bool vtile = QKV && which == 2;
         // bias of this lane's output features, fetched under the MFMAs (the epilogue wants them in
         // registers: dependent scalar loads there cost microseconds per tile)
         float bz[4][4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            if (!vorient) {
+            if (!vtile) {
                 const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
                 if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
                 else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
@@ -133,7 +243,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
             dma_barrier();                   // own DMA landed (vmcnt(0)) + everyone done with the other slot
             if (s + 1 < S && !(p.debug & 4)) issue(s + 1);
             const unsigned char *sA = smem + (s & 1) * 32768;
-            if (!(p.debug & 2)) mma_block<T, VORIENT>(sA, sA + 16384, wm, wn, lane, acc);
+            if (!(p.debug & 2)) {
+                if (vtile) mma_block<T, true>(sA, sA + 16384, wm, wn, lane, acc);
+                else mma_block<T, false>(sA, sA + 16384, wm, wn, lane, acc);
+            }
         }
 
         // -------------------------------------------------------------- epilogue of this column tile
@@ -142,98 +255,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
         // row (or, for V columns, 4 consecutive nodes of one feature): 8-byte pieces scattered over 16
         // rows per instruction, ~1 TB/s if written directly.  Staging area = the ring slot just consumed.
         unsigned char *stg = smem + ((ti * nk + nk - 1) & 1) * 32768;
-        const int wrow = vorient ? wn : wm;                     // wave coordinate along the staged ROWS
-#pragma unroll
-        for (int pass = 0; pass < PASSES; ++pass) {
-            dma_barrier();                                    // slot free / previous pass read out
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int rg = wrow * 64 + (vorient ? ni : mi) * 16 + (lane & 15);   // row of the 128 x 128 image
-                    if (rg / ROWS != pass) continue;            // wave-uniform (16-row groups never straddle)
-                    float v[4];
-                    int cl;
-                    if (!vorient) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
-                        if (p.res) {
-                            const int m = row0 + wm * 64 + mi * 16 + (lane & 15);
-                            const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
-                            if (m < p.M && f0 + 3 < p.Nout) {
-                                float rr[4];
-                                load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                            }
-                        }
-                        cl = wn * 64 + ni * 16 + (lane >> 4) * 4;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + bz[ni][0];
-                        cl = wm * 64 + mi * 16 + (lane >> 4) * 4;
-                    }
-                    store4((T *)(stg + (rg % ROWS) * RSO) + cl, v);
-                }
-            }
-            dma_barrier();
-            u32x4 val[NIT];
-            int rmap[NIT], rmap2[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
-                val[it] = *(const u32x4 *)(stg + row * RSO + ch * 16);
-                rmap[it] = rmap2[it] = 0;
-                if (p.qkv) {
-                    if (!vorient) {
-                        const int m = row0 + row + pass * ROWS;
-                        if (which < 2 && m < p.M) rmap[it] = p.row_map[m];
-                    } else {
-                        const int m = row0 + ch * EPC;
-                        if (m < p.M) rmap[it] = p.row_map[m];
-                        if (m + EPC - 1 < p.M) rmap2[it] = p.row_map[m + EPC - 1];
-                    }
-                }
-            }
-            if (p.debug & 1) continue;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
-                const int grow = row + pass * ROWS;             // row of the 128 x 128 staged image
-                if (!vorient) {
-                    const int m = row0 + grow, col = col0 + ch * EPC;
-                    if (m >= p.M || col >= p.Nout) continue;
-                    T *dst;
-                    if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
-                    else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
-                    else {
-                        const int f = col - which * p.HC, h = f / p.C, c = f - h * p.C;
-                        dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + rmap[it]) * p.C + c;
-                    }
-                    *(u32x4 *)dst = val[it];
-                } else {
-                    const int fcol = col0 + grow, m = row0 + ch * EPC;
-                    if (fcol >= p.Nout || m >= p.M) continue;
-                    const int f = fcol - 2 * p.HC, h = f / p.C, c = f - h * p.C;
-                    T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * p.n_pad;
-                    const int p0 = rmap[it];
-                    const bool run = m + EPC - 1 < p.M && rmap2[it] == p0 + EPC - 1;     // 8 (4) consecutive rows
-                    if (run && (p0 & (EPC - 1)) == 0) {
-                        *(u32x4 *)(vrow + p0) = val[it];
-                    } else if (run && ES == 2 && (p0 & 3) == 0) {   // graph slot offset = 4 mod 8: two 8-byte stores
-                        const u32x4 vv = val[it];
-                        *(u32x2 *)(vrow + p0) = (u32x2){vv[0], vv[1]};
-                        *(u32x2 *)(vrow + p0 + 4) = (u32x2){vv[2], vv[3]};
-                    } else {                                    // chunk straddles a graph boundary / ragged
-                        const u32x4 vv = val[it];
-                        const T *e = (const T *)&vv;
-#pragma unroll
-                        for (int r = 0; r < EPC; ++r)
-                            if (m + r < p.M) vrow[p.row_map[m + r]] = e[r];
-                    }
-                }
-            }
-        }
+        if (vtile) mfma_epilogue<T, true, DA_ACT_NONE, PASSES, NIT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
+        else mfma_epilogue<T, false, ACT, PASSES, NIT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
     }
 }
 
@@ -249,13 +272,14 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     if (K % BK != 0 || (Nout % (16 / es)) || !aligned16(A) || !aligned16(W) || ((size_t)lda * es) % 16 != 0) return -1;
     GemmParams p;
     p.M = M; p.K = K; p.Nout = Nout; p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.act = act; p.res = res;
-    p.out = out; p.ldo = ldo; p.qkv = 0; p.HC = 1; p.C = 1; p.n_pad = 0; p.row_map = nullptr;
+    p.out = out; p.ldo = ldo; p.qkv = 0; p.HC = 1; p.C = 1; p.n_pad = 0; p.row_map = nullptr; p.Cmagic = 0;
     p.Q = p.Kb = p.Vt = p.S = nullptr;
     { const char *e = getenv("DA_GEMM_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     { const char *e = getenv("DA_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
     if (qs) {
         if (qs->HC % 128 != 0 || (qs->C & 7) || Nout != 4 * qs->HC || act != DA_ACT_NONE || res) return -1;
         p.qkv = 1; p.HC = qs->HC; p.C = qs->C; p.n_pad = qs->n_pad; p.row_map = qs->row_map;
+        p.Cmagic = (unsigned)((((unsigned long long)1 << 32) + (unsigned)qs->C - 1) / (unsigned)qs->C);
         p.Q = qs->Q; p.Kb = qs->K; p.Vt = qs->Vt; p.S = qs->S;
     } else if (((size_t)ldo * es) % 16 != 0 || !aligned16(out) || (res && !aligned16(res))) {
         return -1;
@@ -292,13 +316,9 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
         if (prec == DA_PREC_BF16) DA_GEMM_ACT(bf16_t, grid);
         else DA_GEMM_ACT(float, grid);
     } else {
-        const int per = qs->HC / 128;
-        const dim3 g1 = plan2(3 * per);
-        if (prec == DA_PREC_BF16) DA_GEMM_LAUNCH(bf16_t, false, DA_ACT_NONE, g1);
-        else DA_GEMM_LAUNCH(float, false, DA_ACT_NONE, g1);
-        const dim3 g2 = plan2(per);
-        if (prec == DA_PREC_BF16) DA_GEMM_LAUNCH(bf16_t, true, DA_ACT_NONE, g2);
-        else DA_GEMM_LAUNCH(float, true, DA_ACT_NONE, g2);
+        const dim3 g = plan2(4 * (qs->HC / 128));                // Q | K | V | skip column blocks, one launch
+        if (prec == DA_PREC_BF16) DA_GEMM_LAUNCH(bf16_t, true, DA_ACT_NONE, g);
+        else DA_GEMM_LAUNCH(float, true, DA_ACT_NONE, g);
     }
 #undef DA_GEMM_ACT
 #undef DA_GEMM_LAUNCH
