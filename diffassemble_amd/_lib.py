@@ -13,6 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
+ABI_VERSION = 2
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -47,6 +48,7 @@ class DaGraph(C.Structure):
         ("row_ptr", _fp), ("col_src", _fp), ("edge_id", _fp), ("graph_ptr", _fp),
         ("max_graph_nodes", C.c_int32), ("n_pad", C.c_int32),
         ("pad_ptr", _fp), ("row_map", _fp),
+        ("out_ptr", _fp), ("out_dst", _fp),
     ]
 
 
@@ -82,6 +84,10 @@ PROTOTYPES = {
     "da_attn_dense_scratch_bytes": (C.c_size_t, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int]),
     "da_conv_dense": (C.c_int, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int,
                                 _fp, _fp, _fp]),
+    "da_train_workspace_bytes": (C.c_size_t, [C.POINTER(DaWeights), C.POINTER(DaGraph)]),
+    "da_train_forward": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "da_train_backward": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp,
+                                    _fp, C.c_size_t, _fp]),
 }
 
 _lib = None
@@ -104,7 +110,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.da_abi_version() != 1:
+        if h.da_abi_version() != ABI_VERSION:
             raise DaError(f"ABI mismatch: library reports {h.da_abi_version()}")
         _lib = h
     return _lib

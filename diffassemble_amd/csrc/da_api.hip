@@ -231,7 +231,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                  return linear(prec, n, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, w.qkvs, 4 * c.hc, st); }))) return rc;
         if ((rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
                  return launch_attn_csr(prec, n, g->row_ptr, g->col_src, g->edge_id, d->heads, c.C, w.qkvs,
-                                        resid, act, dst, al, st); }))) return rc;
+                                        resid, act, dst, al, nullptr, st); }))) return rc;
         xin = dst;
         ldx = c.hc;
     }
@@ -530,7 +530,7 @@ int da_attn_csr(int prec, const da_graph *g, int heads, int C, const void *qkvs,
                 void *out, float *alpha, void *stream) {
     DA_REQUIRE(g && qkvs && out, "da_attn_csr: null argument");
     return launch_attn_csr(prec, g->n_nodes, g->row_ptr, g->col_src, g->edge_id, heads, C, qkvs, residual, act, out,
-                           alpha, (hipStream_t)stream);
+                           alpha, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

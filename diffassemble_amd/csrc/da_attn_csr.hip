@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
                                                   const int32_t *__restrict__ edge_id, int H, int HC,
                                                   const T *__restrict__ qkvs, const T *__restrict__ residual,
                                                   int act, T *__restrict__ out, float *__restrict__ alpha,
-                                                  float scale) {
+                                                  float *__restrict__ stats, float scale) {
     const int lane = threadIdx.x & 63;
     const int i = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n_nodes) return;
@@ -60,6 +60,10 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
         m = mn;
     }
     const float inv = (end > beg) ? 1.0f / (l + 1e-16f) : 0.f;
+    if (stats && (lane & 7) == 0) {               // training: softmax statistics for the backward kernels
+        stats[((size_t)i * H + head) * 2] = m;
+        stats[((size_t)i * H + head) * 2 + 1] = inv;
+    }
     const T *sp = qkvs + (size_t)i * ld + 3 * (size_t)HC + off;
     T *op = out + (size_t)i * HC + off;
 #pragma unroll
@@ -79,14 +83,14 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
 
 template <typename T>
 static int launch_t(int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id, int H,
-                    int C, const T *qkvs, const T *residual, int act, T *out, float *alpha, hipStream_t st) {
+                    int C, const T *qkvs, const T *residual, int act, T *out, float *alpha, float *stats, hipStream_t st) {
     const int HC = H * C;
     const float scale = 1.0f / sqrtf((float)C);
     const int grid = (int)(((size_t)n_nodes * 64 + 255) / 256);
 #define DA_CSR_CASE(E)                                                                                   \
     case E:                                                                                              \
         k_attn_csr<T, E><<<grid, 256, 0, st>>>(n_nodes, row_ptr, col_src, edge_id, H, HC, qkvs, residual, act, \
-                                               out, alpha, scale);                                       \
+                                               out, alpha, stats, scale);                                \
         break;
     switch (C / 8) {
         DA_CSR_CASE(1) DA_CSR_CASE(2) DA_CSR_CASE(4) DA_CSR_CASE(8) DA_CSR_CASE(13) DA_CSR_CASE(16) DA_CSR_CASE(18)
@@ -101,15 +105,15 @@ static int launch_t(int n_nodes, const int32_t *row_ptr, const int32_t *col_src,
 
 int launch_attn_csr(int prec, int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id,
                     int heads, int C, const void *qkvs, const void *residual, int act, void *out, float *alpha,
-                    hipStream_t st) {
+                    float *stats, hipStream_t st) {
     if (n_nodes <= 0) return 0;
     DA_REQUIRE(heads == 8, "da_attn_csr: heads must be 8 (got %d)", heads);
     DA_REQUIRE(C % 8 == 0, "da_attn_csr: C %% 8 != 0 (C=%d)", C);
     if (prec == DA_PREC_BF16)
         return launch_t<bf16_t>(n_nodes, row_ptr, col_src, edge_id, heads, C, (const bf16_t *)qkvs,
-                                (const bf16_t *)residual, act, (bf16_t *)out, alpha, st);
+                                (const bf16_t *)residual, act, (bf16_t *)out, alpha, stats, st);
     return launch_t<float>(n_nodes, row_ptr, col_src, edge_id, heads, C, (const float *)qkvs,
-                           (const float *)residual, act, (float *)out, alpha, st);
+                           (const float *)residual, act, (float *)out, alpha, stats, st);
 }
 
 }  // namespace da

@@ -29,7 +29,7 @@ int launch_convert(int prec, size_t n, const float *src, void *dst, hipStream_t 
 // da_attn_csr.hip
 int launch_attn_csr(int prec, int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id,
                     int heads, int C, const void *qkvs, const void *residual, int act, void *out, float *alpha,
-                    hipStream_t st);
+                    float *stats /* [n, H, 2] running max and 1/(sum + 1e-16), or NULL */, hipStream_t st);
 
 // da_so3.hip (3D head + SO(3) DDIM)
 int launch_head3d(int prec, int n, const void *hh, const float *wt, const float *bt, const float *wr, const float *br,

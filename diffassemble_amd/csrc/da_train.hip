@@ -1,0 +1,601 @@
+// Training path of the denoiser: forward with saved activations + backward of every
+// live parameter, fp32 throughout (the parity mode; the gradient fixtures of the reference are fp32).
+//
+// Replaces torch autograd through Eff_GAT.forward_with_feats (efficient_gat.py:121-146) and the PyG
+// TransformerConv message/aggregate of Transformer_GNN.py:29-46 / exophormer_gnn.py:161-215.
+//
+// Attention backward works on the CSR graph for every graph type (complete puzzles, Exphander
+// expanders, the exophormer virtual-node edges, multi-edges), with NO atomics: one kernel walks the
+// incoming edges of each destination (dq, and the per-(node, head) term D = sum_e p_e dp_e), a second
+// walks the outgoing edges of each source (dk, dv) -- the host supplies both CSR orientations.
+//   p_e  = exp(a_e - m_i) / (sum + 1e-16)          (m_i, 1/(sum+1e-16) saved by the forward kernel)
+//   dp_e = <dO_i, v_j>,  ds_e = p_e (dp_e - D_i)
+//   dq_i = scale * sum_e ds_e k_j,  dk_j = scale * sum_e ds_e q_i,  dv_j = sum_e p_e dO_i
+// Linear layers: dX = dY @ W runs through the forward MFMA linear kernel with W transposed once per
+// step; dW = dY^T @ X is a dedicated fp32-MFMA kernel whose reduction runs over the node dimension,
+// split over node chunks with a deterministic second-pass reduction.
+#include <stdlib.h>
+
+#include "da_gemm_common.h"
+
+namespace da {
+
+__device__ inline float gelu_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return fmaf(x, pdf, cdf);
+}
+
+__global__ __launch_bounds__(256) void k_gelu_fwd(size_t n, const float *__restrict__ src, float *__restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = gelu_erf(src[i]);
+}
+
+// dx = dy * gelu'(pre)   (dx may alias dy)
+__global__ __launch_bounds__(256) void k_gelu_bwd(size_t n, const float *__restrict__ pre, const float *dy, float *dx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * gelu_grad(pre[i]);
+}
+
+// dst[c][r] = src[r][c]
+__global__ __launch_bounds__(256) void k_transpose(int rows, int cols, const float *__restrict__ src, float *__restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[(size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+// out[c] += sum_m A[m][c]      (bias gradients)
+__global__ __launch_bounds__(1024) void k_colsum_add(int M, int N, const float *__restrict__ A, int lda, float *out) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (c < N)
+        for (int m = ty; m < M; m += 16) s += A[(size_t)m * lda + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tx];
+        out[c] += t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW kernel: C[n][k] (+)= sum_m A[m][n] * B[m][k]   (A = dY [M, N], B = X [M, K], both row-major:
+// the reduction runs over ROWS, so both tiles are staged exactly as they lie in memory, [m][col], and
+// the fp32 MFMA fragments (one float per lane: row = lane & 15 of the output tile, k = lane >> 4) are
+// read with conflict-free 4-byte LDS reads -- no transposes anywhere).
+// Tile 64 (n) x 64 (k), 16 rows of m per stage, 4 waves as 2 x 2, v_mfma_f32_16x16x4_f32.
+// grid = (ceil(K/64), ceil(N/64), splits); split s reduces rows [s * Mc, (s + 1) * Mc).
+__device__ __forceinline__ f32x4 load_row4(const float *base, int ld, int row, int col, int rows, int cols, bool vec) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row >= rows) return v;
+    const float *p = base + (size_t)row * ld + col;
+    if (vec && col + 3 < cols) return *(const f32x4 *)p;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (col + r < cols) v[r] = p[r];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                 const float *__restrict__ B, int ldb, float *C, int ldc,
+                                                 float *partial, int Mc) {
+    constexpr int LS = 80;                                       // LDS row stride (floats): 4 rows -> banks 0,16,32,48
+    __shared__ __attribute__((aligned(16))) float As[16 * LS];
+    __shared__ __attribute__((aligned(16))) float Bs[16 * LS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int m_beg = blockIdx.z * Mc, m_end = min(M, m_beg + Mc);
+    const int lrow = tid >> 4, lc4 = (tid & 15) * 4;
+    const bool vecA = (lda % 4 == 0) && (((size_t)A & 15) == 0), vecB = (ldb % 4 == 0) && (((size_t)B & 15) == 0);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ra = load_row4(A, lda, m_beg + lrow, n0 + lc4, m_end, N, vecA);
+    f32x4 rb = load_row4(B, ldb, m_beg + lrow, k0 + lc4, m_end, K, vecB);
+    for (int m0 = m_beg; m0 < m_end; m0 += 16) {
+        *(f32x4 *)(As + lrow * LS + lc4) = ra;
+        *(f32x4 *)(Bs + lrow * LS + lc4) = rb;
+        __syncthreads();
+        if (m0 + 16 < m_end) {
+            ra = load_row4(A, lda, m0 + 16 + lrow, n0 + lc4, m_end, N, vecA);
+            rb = load_row4(B, ldb, m0 + 16 + lrow, k0 + lc4, m_end, K, vecB);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[(kk + (lane >> 4)) * LS + wr * 32 + i * 16 + (lane & 15)];
+                b[i] = Bs[(kk + (lane >> 4)) * LS + wc * 32 + i * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float *dst = partial ? partial + (size_t)blockIdx.z * N * K : C;
+    const int ldd = partial ? K : ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wr * 32 + i * 16 + 4 * (lane >> 4) + r, k = k0 + wc * 32 + j * 16 + (lane & 15);
+                if (n < N && k < K) {
+                    if (partial) dst[(size_t)n * ldd + k] = acc[i][j][r];
+                    else dst[(size_t)n * ldd + k] += acc[i][j][r];
+                }
+            }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partial(int splits, int N, int K, const float *__restrict__ partial,
+                                                        float *C, int ldc) {
+    const size_t NK = (size_t)N * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < NK; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(size_t)k * NK + i];
+        const size_t n = i / K, kk = i - n * K;
+        C[n * ldc + kk] += s;
+    }
+}
+
+constexpr size_t PART_CAP = (size_t)16 << 20;        // floats of split-reduction scratch (64 MB)
+
+static int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                          float *partial, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int tn = (N + 63) / 64, tk = (K + 63) / 64;
+    long splits = 2048 / ((long)tn * tk);
+    const long by_rows = (M + 255) / 256, by_cap = (long)(PART_CAP / ((size_t)N * K));
+    splits = splits > by_rows ? by_rows : splits;
+    splits = splits > by_cap ? by_cap : splits;
+    if (splits < 1) splits = 1;
+    int Mc = (int)(((M + splits - 1) / splits + 15) / 16 * 16);
+    splits = (M + Mc - 1) / Mc;
+    const dim3 grid((unsigned)tk, (unsigned)tn, (unsigned)splits);
+    if (splits == 1) {
+        k_gemm_tn<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, nullptr, Mc);
+    } else {
+        k_gemm_tn<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, partial, Mc);
+        const size_t NK = (size_t)N * K;
+        k_reduce_partial<<<(unsigned)((NK + 255) / 256 > 4096 ? 4096 : (NK + 255) / 256), 256, 0, st>>>((int)splits, N, K, partial, C, ldc);
+    }
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention backward, destination side: wave per destination node i, lane l holds the EPL = C / 8
+// contiguous channels [l * EPL, (l + 1) * EPL) of the H*C-wide rows (8 lanes per head), exactly the
+// decomposition of the forward kernel (da_attn_csr.hip).  Writes dq_i and the skip gradient into
+// the fused [n, 4 HC] gradient of the projection, and D_i per head.
+template <int EPL>
+__global__ __launch_bounds__(256) void k_attn_bwd_dst(int n_nodes, const int32_t *__restrict__ row_ptr,
+                                                      const int32_t *__restrict__ col_src, int H, int HC,
+                                                      const float *__restrict__ qkvs, const float *__restrict__ d_o,
+                                                      const float *__restrict__ stats, float *__restrict__ dY4,
+                                                      float *__restrict__ Dd, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (i >= n_nodes) return;
+    const size_t ld = (size_t)4 * HC;
+    const int off = lane * EPL, head = lane >> 3;
+    float q[EPL], g[EPL], a1[EPL], a2[EPL];
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        q[x] = qkvs[(size_t)i * ld + off + x] * scale;
+        g[x] = d_o[(size_t)i * HC + off + x];
+        a1[x] = a2[x] = 0.f;
+    }
+    const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
+    float D = 0.f;
+    const int beg = row_ptr[i], end = row_ptr[i + 1];
+    for (int e = beg; e < end; ++e) {
+        const int j = col_src[e];
+        const float *kp = qkvs + (size_t)j * ld + HC + off;
+        const float *vp = kp + HC;
+        float kk[EPL], vv[EPL];
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { kk[x] = kp[x]; vv[x] = vp[x]; }
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { s = fmaf(q[x], kk[x], s); dp = fmaf(g[x], vv[x], dp); }
+        s += __shfl_xor(s, 1); dp += __shfl_xor(dp, 1);
+        s += __shfl_xor(s, 2); dp += __shfl_xor(dp, 2);
+        s += __shfl_xor(s, 4); dp += __shfl_xor(dp, 4);
+        const float p = expf(s - m) * inv;
+        const float pd = p * dp;
+        D += pd;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { a1[x] = fmaf(pd, kk[x], a1[x]); a2[x] = fmaf(p, kk[x], a2[x]); }
+    }
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        dY4[(size_t)i * ld + off + x] = (a1[x] - D * a2[x]) * scale;
+        dY4[(size_t)i * ld + 3 * (size_t)HC + off + x] = g[x];
+    }
+    if ((lane & 7) == 0) Dd[(size_t)i * H + head] = D;
+}
+
+// Source side: wave per source node j over its OUTGOING edges (out_ptr / out_dst = CSR by source).
+template <int EPL>
+__global__ __launch_bounds__(256) void k_attn_bwd_src(int n_nodes, const int32_t *__restrict__ out_ptr,
+                                                      const int32_t *__restrict__ out_dst, int H, int HC,
+                                                      const float *__restrict__ qkvs, const float *__restrict__ d_o,
+                                                      const float *__restrict__ stats, const float *__restrict__ Dd,
+                                                      float *__restrict__ dY4, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int j = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (j >= n_nodes) return;
+    const size_t ld = (size_t)4 * HC;
+    const int off = lane * EPL, head = lane >> 3;
+    float kk[EPL], vv[EPL], dk[EPL], dv[EPL];
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        kk[x] = qkvs[(size_t)j * ld + HC + off + x];
+        vv[x] = qkvs[(size_t)j * ld + 2 * (size_t)HC + off + x];
+        dk[x] = dv[x] = 0.f;
+    }
+    const int beg = out_ptr[j], end = out_ptr[j + 1];
+    for (int e = beg; e < end; ++e) {
+        const int i = out_dst[e];
+        float q[EPL], g[EPL];
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { q[x] = qkvs[(size_t)i * ld + off + x] * scale; g[x] = d_o[(size_t)i * HC + off + x]; }
+        const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
+        const float D = Dd[(size_t)i * H + head];
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { s = fmaf(q[x], kk[x], s); dp = fmaf(g[x], vv[x], dp); }
+        s += __shfl_xor(s, 1); dp += __shfl_xor(dp, 1);
+        s += __shfl_xor(s, 2); dp += __shfl_xor(dp, 2);
+        s += __shfl_xor(s, 4); dp += __shfl_xor(dp, 4);
+        const float p = expf(s - m) * inv;
+        const float ds = p * (dp - D);
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { dk[x] = fmaf(ds, q[x], dk[x]); dv[x] = fmaf(p, g[x], dv[x]); }
+    }
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        dY4[(size_t)j * ld + HC + off + x] = dk[x];
+        dY4[(size_t)j * ld + 2 * (size_t)HC + off + x] = dv[x];
+    }
+}
+
+static int launch_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *stats,
+                           float *Dd, float *dY4, hipStream_t st) {
+    const int n = g->n_nodes, HC = H * C;
+    const float scale = 1.0f / sqrtf((float)C);
+    const int grid = (int)(((size_t)n * 64 + 255) / 256);
+#define DA_BWD_CASE(E)                                                                                              \
+    case E:                                                                                                         \
+        k_attn_bwd_dst<E><<<grid, 256, 0, st>>>(n, g->row_ptr, g->col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale); \
+        k_attn_bwd_src<E><<<grid, 256, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale); \
+        break;
+    switch (C / 8) {
+        DA_BWD_CASE(1) DA_BWD_CASE(2) DA_BWD_CASE(4) DA_BWD_CASE(8) DA_BWD_CASE(13) DA_BWD_CASE(16) DA_BWD_CASE(18)
+        default:
+            set_error("attention backward: unsupported head width C=%d", C);
+            return 1;
+    }
+#undef DA_BWD_CASE
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small pieces around the embedding
+// a[r][o] = b0[o] + sum_k W0[o][k] x[r][k]  (pos_mlp.0 pre-activation), p1 = gelu(a)
+__global__ __launch_bounds__(256) void k_pos_hidden(int n, int c_in, const float *__restrict__ x, const float *__restrict__ w0,
+                                                    const float *__restrict__ b0, float *__restrict__ a, float *__restrict__ p1) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * 16) return;
+    const int r = idx >> 4, o = idx & 15;
+    float v = b0[o];
+    for (int k = 0; k < c_in; ++k) v += w0[o * c_in + k] * x[(size_t)r * c_in + k];
+    a[idx] = v;
+    p1[idx] = gelu_erf(v);
+}
+
+// time_emb.grad[t[r]][c] += dcomb[r][F + 32 + c]
+__global__ __launch_bounds__(256) void k_time_scatter(int n, int D, int F, int steps, const int64_t *__restrict__ t,
+                                                      const float *__restrict__ dcomb, float *grad) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * 32) return;
+    const int r = idx >> 5, c = idx & 31;
+    int64_t ti = t[r];
+    ti = ti < 0 ? 0 : (ti >= steps ? steps - 1 : ti);
+    atomicAdd(grad + ti * 32 + c, dcomb[(size_t)r * D + F + 32 + c]);
+}
+
+__global__ __launch_bounds__(256) void k_copy_cols(int n, int cols, const float *__restrict__ src, int lds, float *__restrict__ dst) {
+    const size_t total = (size_t)n * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cols, c = i - r * cols;
+        dst[i] = src[r * lds + c];
+    }
+}
+
+// virt_node_embedding.grad[v][c] += sum_g dh[(g * V + v)][c]   (rows appended as arange(V).repeat(G))
+__global__ __launch_bounds__(256) void k_virt_grad(int rows, int V, int D, const float *__restrict__ dh, float *grad) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= V * D) return;
+    const int v = idx / D, c = idx - v * D;
+    float s = 0.f;
+    for (int r = v; r < rows; r += V) s += dh[(size_t)r * D + c];
+    grad[idx] += s;
+}
+
+static unsigned grid_for(size_t n) { const size_t b = (n + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+// ---------------------------------------------------------------------------------------------
+struct TrainWs {
+    float *comb_in, *m1pre, *m1, *h0;
+    float *qkvs[DA_MAX_LAYERS], *o[DA_MAX_LAYERS], *hact[DA_MAX_LAYERS], *stats[DA_MAX_LAYERS];
+    float *f1pre, *f1;
+    float *dz, *dh0, *dY4, *dxa, *dxb, *Dd, *dm1, *df1, *dcomb, *wt, *partial, *pa, *p1, *dp1;
+    size_t total;
+};
+
+struct Dims {
+    int nr, n, F, D, hid, H, L, V, c_in, c_out;
+    int din[DA_MAX_LAYERS], C[DA_MAX_LAYERS], hc[DA_MAX_LAYERS];
+    bool gelu_between;
+};
+
+static int dims_of(const da_weights *w, const da_graph *g, Dims &d) {
+    DA_REQUIRE(w && g, "training: null argument");
+    DA_REQUIRE(w->variant == DA_VARIANT_2D, "training: only the 2D denoiser is implemented");
+    DA_REQUIRE(w->heads == 8 && w->n_layers >= 2 && w->n_layers <= DA_MAX_LAYERS, "training: bad heads / n_layers");
+    d.nr = g->n_real; d.n = g->n_nodes; d.F = w->feat_dim; d.D = w->feat_dim + 64; d.hid = w->hidden; d.H = w->heads;
+    d.L = w->n_layers; d.V = w->arch == DA_ARCH_EXOPHORMER ? w->virt_nodes : 0; d.c_in = w->c_in; d.c_out = w->c_out;
+    d.gelu_between = w->arch == DA_ARCH_TRANSFORMER;
+    DA_REQUIRE(d.D % d.H == 0 && (d.D / d.H) % 8 == 0, "training: D / heads must be a multiple of 8");
+    for (int l = 0; l < d.L; ++l) {
+        d.din[l] = l == 0 ? d.D : 32 * d.H;
+        d.C[l] = l == d.L - 1 ? d.D / d.H : 32;
+        d.hc[l] = d.C[l] * d.H;
+    }
+    DA_REQUIRE(g->n_real > 0 && g->n_nodes >= g->n_real && g->row_ptr, "training: bad graph");
+    DA_REQUIRE(d.V == 0 || g->n_nodes == g->n_real + d.V * g->n_graphs, "training: exophormer expects n_nodes = n_real + V*G");
+    return 0;
+}
+
+static TrainWs carve_train(const Dims &d, void *base) {
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float *q = p ? (float *)(p + off) : nullptr;
+        off += align_up(floats * 4, 256);
+        return q;
+    };
+    const size_t n = (size_t)d.n + 64, nr = (size_t)d.nr + 64;
+    TrainWs w;
+    w.comb_in = take(nr * d.D);
+    w.m1pre = take(nr * d.hid);
+    w.m1 = take(nr * d.hid);
+    w.h0 = take(n * d.D);
+    int hcmax = 0;
+    size_t wmax = (size_t)d.D * d.hid;
+    for (int l = 0; l < d.L; ++l) {
+        w.qkvs[l] = take(n * 4 * d.hc[l]);
+        w.o[l] = take(n * d.hc[l]);
+        w.hact[l] = (l < d.L - 1 && d.gelu_between) ? take(n * d.hc[l]) : nullptr;
+        w.stats[l] = take(n * d.H * 2);
+        hcmax = d.hc[l] > hcmax ? d.hc[l] : hcmax;
+        const size_t ws = (size_t)4 * d.hc[l] * d.din[l];
+        wmax = ws > wmax ? ws : wmax;
+    }
+    w.f1pre = take(nr * 32);
+    w.f1 = take(nr * 32);
+    w.dz = take(n * d.D);
+    w.dh0 = take(n * d.D);
+    w.dY4 = take(n * 4 * hcmax);
+    w.dxa = take(n * d.D);
+    w.dxb = take(n * d.D);
+    w.Dd = take(n * d.H);
+    w.dm1 = take(nr * d.hid);
+    w.df1 = take(nr * 32);
+    w.dcomb = take(nr * d.D);
+    w.wt = take(wmax + 1024);
+    w.partial = take(PART_CAP);
+    w.pa = take(nr * 16);
+    w.p1 = take(nr * 16);
+    w.dp1 = take(nr * 16);
+    w.total = off;
+    return w;
+}
+
+static int check_fused(const da_weights *w, const Dims &d, const char *what) {
+    for (int l = 0; l < d.L; ++l) {
+        const size_t blk = (size_t)d.hc[l] * d.din[l];
+        DA_REQUIRE(w->conv_wq[l] && w->conv_bq[l], "%s: conv %d pointers missing", what, l);
+        DA_REQUIRE(w->conv_wk[l] == w->conv_wq[l] + blk && w->conv_wv[l] == w->conv_wq[l] + 2 * blk &&
+                       w->conv_ws[l] == w->conv_wq[l] + 3 * blk && w->conv_bk[l] == w->conv_bq[l] + d.hc[l] &&
+                       w->conv_bv[l] == w->conv_bq[l] + 2 * d.hc[l] && w->conv_bs[l] == w->conv_bq[l] + 3 * d.hc[l],
+                   "%s: conv %d needs lin_query|key|value|skip contiguous in that order (flat parameter buffer)", what, l);
+    }
+    return 0;
+}
+
+static int gelu_fwd(size_t n, const float *src, float *dst, hipStream_t st) {
+    k_gelu_fwd<<<grid_for(n), 256, 0, st>>>(n, src, dst);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+static int gelu_bwd(size_t n, const float *pre, const float *dy, float *dx, hipStream_t st) {
+    k_gelu_bwd<<<grid_for(n), 256, 0, st>>>(n, pre, dy, dx);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+static int transpose(int rows, int cols, const float *src, float *dst, hipStream_t st) {
+    k_transpose<<<dim3((cols + 31) / 32, (rows + 31) / 32), 256, 0, st>>>(rows, cols, src, dst);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+static int colsum_add(int M, int N, const float *A, int lda, float *out, hipStream_t st) {
+    k_colsum_add<<<(N + 63) / 64, 1024, 0, st>>>(M, N, A, lda, out);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// Linear backward: dW += dY^T X, db += colsum(dY), and (if dX) dX = dY @ W (+ res)
+static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, const float *W,
+                      float *dW, float *db, float *dX, int lddx, const float *res, TrainWs &ws, hipStream_t st) {
+    int rc;
+    if ((rc = launch_gemm_tn(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, st))) return rc;
+    if (db && (rc = colsum_add(M, N, dY, ldy, db, st))) return rc;
+    if (dX) {
+        if ((rc = transpose(N, K, W, ws.wt, st))) return rc;                      // W [N, K] -> W^T [K, N]
+        if ((rc = linear(DA_PREC_F32, M, N, K, dY, ldy, ws.wt, nullptr, DA_ACT_NONE, res, dX, lddx, st))) return rc;
+    }
+    return 0;
+}
+
+}  // namespace da
+
+using namespace da;
+
+extern "C" {
+
+size_t da_train_workspace_bytes(const da_weights *w, const da_graph *g) {
+    Dims d;
+    if (dims_of(w, g, d)) return 0;
+    return carve_train(d, nullptr).total;
+}
+
+int da_train_forward(const da_weights *w, const da_graph *g, const float *x, const int64_t *t, const float *feats,
+                     float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    Dims d;
+    int rc;
+    if ((rc = dims_of(w, g, d))) return rc;
+    DA_REQUIRE(x && t && feats && out && workspace, "da_train_forward: null argument");
+    if ((rc = check_fused(w, d, "da_train_forward"))) return rc;
+    TrainWs ws = carve_train(d, workspace);
+    DA_REQUIRE(workspace_bytes >= ws.total, "training workspace too small: %zu < %zu", workspace_bytes, ws.total);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = DA_PREC_F32, nr = d.nr, n = d.n, D = d.D;
+    if ((rc = launch_set_feats(P, nr, d.F, D, feats, ws.comb_in, st))) return rc;
+    if ((rc = launch_embed_pos_time(P, nr, d.c_in, d.F, D, x, t, 0, w->steps, w->time_emb, w->pos_w0, w->pos_b0, w->pos_w1,
+                                    w->pos_b1, ws.comb_in, st))) return rc;
+    if ((rc = linear(P, nr, D, d.hid, ws.comb_in, D, w->mlp_w0, w->mlp_b0, DA_ACT_NONE, nullptr, ws.m1pre, d.hid, st))) return rc;
+    if ((rc = gelu_fwd((size_t)nr * d.hid, ws.m1pre, ws.m1, st))) return rc;
+    if ((rc = linear(P, nr, d.hid, D, ws.m1, d.hid, w->mlp_w1, w->mlp_b1, DA_ACT_NONE, nullptr, ws.h0, D, st))) return rc;
+    if (d.V > 0) {
+        DA_REQUIRE(w->virt_emb, "exophormer: virt_emb missing");
+        if ((rc = launch_set_virtual_rows(P, n - nr, d.V, D, w->virt_emb, ws.h0 + (size_t)nr * D, st))) return rc;
+    }
+    const float *xin = ws.h0;
+    int ldx = D;
+    for (int l = 0; l < d.L; ++l) {
+        const bool last = l == d.L - 1;
+        if ((rc = linear(P, n, d.din[l], 4 * d.hc[l], xin, ldx, w->conv_wq[l], w->conv_bq[l], DA_ACT_NONE, nullptr,
+                         ws.qkvs[l], 4 * d.hc[l], st))) return rc;
+        if ((rc = launch_attn_csr(P, n, g->row_ptr, g->col_src, nullptr, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr,
+                                  DA_ACT_NONE, ws.o[l], nullptr, ws.stats[l], st))) return rc;
+        if (!last && d.gelu_between) {
+            if ((rc = gelu_fwd((size_t)n * d.hc[l], ws.o[l], ws.hact[l], st))) return rc;
+            xin = ws.hact[l];
+        } else {
+            xin = ws.o[l];
+        }
+        ldx = d.hc[l];
+    }
+    const float *z = ws.o[d.L - 1];                           // conv output + combined (efficient_gat.py:144)
+    if ((rc = linear(P, nr, D, 32, z, D, w->head_w0, w->head_b0, DA_ACT_NONE, nullptr, ws.f1pre, 32, st))) return rc;
+    if ((rc = gelu_fwd((size_t)nr * 32, ws.f1pre, ws.f1, st))) return rc;
+    return launch_head2d(P, nr, d.c_out, ws.f1, w->head_w1, w->head_b1, out, st);
+}
+
+int da_train_backward(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
+                      const int64_t *t, const float *d_out, float *d_feats, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+    Dims d;
+    int rc;
+    if ((rc = dims_of(w, g, d))) return rc;
+    DA_REQUIRE(grads && x && t && d_out && workspace, "da_train_backward: null argument");
+    DA_REQUIRE(g->out_ptr && g->out_dst, "da_train_backward: the graph needs the by-source CSR (out_ptr / out_dst)");
+    if ((rc = check_fused(w, d, "da_train_backward(weights)"))) return rc;
+    if ((rc = check_fused(grads, d, "da_train_backward(grads)"))) return rc;
+    TrainWs ws = carve_train(d, workspace);
+    DA_REQUIRE(workspace_bytes >= ws.total, "training workspace too small: %zu < %zu", workspace_bytes, ws.total);
+    hipStream_t st = (hipStream_t)stream;
+    const int nr = d.nr, n = d.n, D = d.D, L = d.L;
+    auto G = [](const float *p) { return (float *)p; };       // grads: same struct, written by the library
+
+    // ---- head: final_mlp.2, GELU, final_mlp.0 (efficient_gat.py:145)
+    if ((rc = linear_bwd(nr, d.c_out, 32, d_out, d.c_out, ws.f1, 32, w->head_w1, G(grads->head_w1), G(grads->head_b1),
+                         ws.df1, 32, nullptr, ws, st))) return rc;
+    if ((rc = gelu_bwd((size_t)nr * 32, ws.f1pre, ws.df1, ws.df1, st))) return rc;
+    const float *z = ws.o[L - 1];
+    if (n > nr) DA_CHECK_HIP(hipMemsetAsync(ws.dz + (size_t)nr * D, 0, (size_t)(n - nr) * D * 4, st));
+    if ((rc = linear_bwd(nr, 32, D, ws.df1, 32, z, D, w->head_w0, G(grads->head_w0), G(grads->head_b0), ws.dz, D, nullptr,
+                         ws, st))) return rc;
+    // residual: z = conv_out + h0  ->  both get dz
+    DA_CHECK_HIP(hipMemcpyAsync(ws.dh0, ws.dz, (size_t)n * D * 4, hipMemcpyDeviceToDevice, st));
+
+    // ---- graph transformer layers, last to first
+    const float *d_o = ws.dz;
+    for (int l = L - 1; l >= 0; --l) {
+        const int hc = d.hc[l], din = d.din[l];
+        if ((rc = launch_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.stats[l], ws.Dd, ws.dY4, st))) return rc;
+        const float *xin = l == 0 ? ws.h0 : (d.gelu_between ? ws.hact[l - 1] : ws.o[l - 1]);
+        float *dx = (l & 1) ? ws.dxa : ws.dxb;
+        // l == 0: the input is h0, whose gradient also carries the residual branch
+        if ((rc = linear_bwd(n, 4 * hc, din, ws.dY4, 4 * hc, xin, din, w->conv_wq[l], G(grads->conv_wq[l]), G(grads->conv_bq[l]),
+                             l == 0 ? ws.dh0 : dx, din, l == 0 ? ws.dh0 : nullptr, ws, st))) return rc;
+        if (l > 0) {
+            if (d.gelu_between && (rc = gelu_bwd((size_t)n * din, ws.o[l - 1], dx, dx, st))) return rc;
+            d_o = dx;
+        }
+    }
+    // ---- virtual-node embedding (exophormer_gnn.py:169-178)
+    if (d.V > 0) {
+        DA_REQUIRE(grads->virt_emb, "exophormer: virt_emb gradient pointer missing");
+        k_virt_grad<<<(d.V * D + 255) / 256, 256, 0, st>>>(n - nr, d.V, D, ws.dh0 + (size_t)nr * D, G(grads->virt_emb));
+        DA_LAUNCH_CHECK();
+    }
+    // ---- mlp.2, GELU, mlp.0 (efficient_gat.py:135)
+    if ((rc = linear_bwd(nr, D, d.hid, ws.dh0, D, ws.m1, d.hid, w->mlp_w1, G(grads->mlp_w1), G(grads->mlp_b1), ws.dm1, d.hid,
+                         nullptr, ws, st))) return rc;
+    if ((rc = gelu_bwd((size_t)nr * d.hid, ws.m1pre, ws.dm1, ws.dm1, st))) return rc;
+    if ((rc = linear_bwd(nr, d.hid, D, ws.dm1, d.hid, ws.comb_in, D, w->mlp_w0, G(grads->mlp_w0), G(grads->mlp_b0), ws.dcomb, D,
+                         nullptr, ws, st))) return rc;
+    // ---- concat pieces: [feats | pos | time]
+    if (d_feats) {
+        k_copy_cols<<<grid_for((size_t)nr * d.F), 256, 0, st>>>(nr, d.F, ws.dcomb, D, d_feats);
+        DA_LAUNCH_CHECK();
+    }
+    k_time_scatter<<<(nr * 32 + 255) / 256, 256, 0, st>>>(nr, D, d.F, w->steps, t, ws.dcomb, G(grads->time_emb));
+    DA_LAUNCH_CHECK();
+    // pos_mlp (efficient_gat.py:133): Linear(c,16) GELU Linear(16,32); the hidden layer is recomputed
+    k_pos_hidden<<<(nr * 16 + 255) / 256, 256, 0, st>>>(nr, d.c_in, x, w->pos_w0, w->pos_b0, ws.pa, ws.p1);
+    DA_LAUNCH_CHECK();
+    if ((rc = linear_bwd(nr, 32, 16, ws.dcomb + d.F, D, ws.p1, 16, w->pos_w1, G(grads->pos_w1), G(grads->pos_b1), ws.dp1, 16,
+                         nullptr, ws, st))) return rc;
+    if ((rc = gelu_bwd((size_t)nr * 16, ws.pa, ws.dp1, ws.dp1, st))) return rc;
+    return linear_bwd(nr, 16, d.c_in, ws.dp1, 16, x, d.c_in, w->pos_w0, G(grads->pos_w0), G(grads->pos_b0), nullptr, 0,
+                      nullptr, ws, st);
+}
+
+}  // extern "C"

@@ -57,6 +57,20 @@ class GraphPlan:
     pad_ptr: torch.Tensor      # int32 [G + 1] (64-aligned slot of each graph)
     row_map: torch.Tensor      # int32 [n_nodes] node -> padded row
     edge_index: torch.Tensor   # int64 [2, E] (extended for exophormer) -- returned with alpha
+    out_ptr: torch.Tensor = None   # int32 [n_nodes + 1] CSR by SOURCE (training backward), lazily built
+    out_dst: torch.Tensor = None   # int32 [E]
+
+    def with_source_csr(self):
+        """Add the by-source orientation of the same edge list (da_graph.out_ptr / out_dst), which
+        the attention backward walks to form dK / dV without atomics."""
+        if self.out_ptr is None:
+            src, dst = self.edge_index[0], self.edge_index[1]
+            perm = torch.argsort(src, stable=True)
+            ptr = torch.zeros(self.n_nodes + 1, dtype=torch.int64, device=src.device)
+            ptr[1:] = torch.cumsum(torch.bincount(src, minlength=self.n_nodes), 0)
+            self.out_ptr = ptr.to(torch.int32)
+            self.out_dst = dst[perm].to(torch.int32).contiguous()
+        return self
 
     def c_struct(self):
         g = _lib.DaGraph()
@@ -70,6 +84,8 @@ class GraphPlan:
         g.n_pad = self.n_pad
         g.pad_ptr = self.pad_ptr.data_ptr()
         g.row_map = self.row_map.data_ptr()
+        g.out_ptr = self.out_ptr.data_ptr() if self.out_ptr is not None else None
+        g.out_dst = self.out_dst.data_ptr() if self.out_dst is not None else None
         return g
 
 

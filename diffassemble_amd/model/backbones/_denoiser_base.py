@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from ...engine import DenoiserEngine
+from ...train import DenoiserTrainFn, TrainEngine
 
 
 def default_precision():
@@ -52,6 +53,33 @@ class DenoiserBase(nn.Module):
         if getattr(self, "_feat_key", None) != key:
             eng.set_features(plan, feats)
             self._feat_key = key
+
+    def train_engine(self, device=None) -> TrainEngine:
+        """Flat-buffer training engine (diffassemble_amd/train.py); rebinds the live parameters as views
+        of one flat fp32 buffer the first time (and again if their storage was replaced)."""
+        te = getattr(self, "_train_engine", None)
+        if te is None or not te.still_bound():
+            if self.variant != "2d":
+                raise NotImplementedError("training through the HIP backward covers the 2D denoiser only")
+            te = TrainEngine(self, device if device is not None else next(self.parameters()).device)
+            self._train_engine = te
+        return te
+
+    def _wants_grad(self):
+        return self.training and torch.is_grad_enabled() and self.time_emb.weight.requires_grad
+
+    def _run_train(self, xy_pos, time, edge_index, feats, batch):
+        """forward_with_feats under autograd: da_train_forward now, da_train_backward when the loss is
+        back-propagated (attention weights are not returned on this path, as p_losses asks)."""
+        te = self.train_engine(xy_pos.device)
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
+               batch.data_ptr(), batch.numel(), batch._version, "train")
+        if getattr(self, "_tplan_key", None) != key:
+            from ...graph_plan import build_plan
+            self._tplan = build_plan(edge_index.to(te.device), batch.to(te.device), te.virt_nodes).with_source_csr()
+            self._tplan_key = key
+        out = DenoiserTrainFn.apply(te, self._tplan, xy_pos, time, feats, *te.params)
+        return out, None
 
     @torch.no_grad()
     def _run(self, xy_pos, time, edge_index, feats, batch, return_attentions=True):

@@ -58,6 +58,8 @@ class Eff_GAT(DenoiserBase):
     def forward_with_feats(self, xy_pos: Tensor, time: Tensor, patch_rgb: Tensor, edge_index: Tensor,
                            patch_feats: Tensor, batch):
         """efficient_gat.py:121-146 -> (out [N, c_out] fp32, attentions)."""
+        if self._wants_grad():
+            return self._run_train(xy_pos, time, edge_index, patch_feats, batch)
         return self._run(xy_pos, time, edge_index, patch_feats, batch, self.return_attentions)
 
     def visual_features(self, patch_rgb):

@@ -208,9 +208,28 @@ class GNN_Diffusion(LightningModule):
         return (extract(self.sqrt_alphas_cumprod, t) * x_start
                 + extract(self.sqrt_one_minus_alphas_cumprod, t) * noise)
 
-    def p_losses(self, x_start, t, noise=None, loss_type="l1", cond=None, edge_index=None, batch=None):
-        raise NotImplementedError(
-            "training (p_losses -> denoiser backward) is not built yet: DESIGN.md, 'what comes next'")
+    def p_losses(self, x_start, t, noise=None, loss_type="l1", cond=None, edge_index=None, batch=None,
+                 patch_feats=None):
+        """spatial_diffusion.py:432-483.  The denoiser forward AND backward run in the HIP library
+        (da_train_forward / da_train_backward through ``DenoiserTrainFn``); the loss on [N, c] stays in
+        torch, like the reference.  ``patch_feats`` (extension) bypasses the piece encoder."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
+        if self.steps == 1:
+            x_noisy = torch.zeros_like(x_noisy)
+        if patch_feats is None:
+            patch_feats = self.visual_features(cond)
+        prediction = self.forward_with_feats(x_noisy, t, cond, edge_index, patch_feats=patch_feats, batch=batch,
+                                             return_attentions=False)
+        target = {ModelMeanType.START_X: x_start, ModelMeanType.EPSILON: noise}[self.model_mean_type]
+        if loss_type == "l1":
+            return F.l1_loss(target, prediction)
+        if loss_type == "l2":
+            return F.mse_loss(target, prediction)
+        if loss_type == "huber":
+            return F.smooth_l1_loss(target, prediction)
+        raise NotImplementedError()
 
     @torch.no_grad()
     def p_sample_ddpm(self, x, t, t_index, cond, edge_index, patch_feats, batch):

@@ -1,0 +1,185 @@
+"""Training side of the denoiser: flat fp32 parameter / gradient buffers bound to the
+module's own ``nn.Parameter``s, and the ``torch.autograd.Function`` that routes
+``Eff_GAT.forward_with_feats`` + its backward through ``da_train_forward`` / ``da_train_backward``.
+
+Layout.  All live denoiser parameters sit in ONE flat fp32 buffer (``flat``) and their gradients in a
+second one of the same layout (``flat_grad``); every ``nn.Parameter`` of the module becomes a view of
+its slot, so (a) the HIP kernels read the live weights with no packing or copy, (b) the four PyG
+``lin_query | lin_key | lin_value | lin_skip`` matrices of a conv are adjacent and run as one fused
+[4*H*C, Din] projection, (c) data-parallel training needs exactly one all-reduce -- of ``flat_grad`` --
+per optimizer step (``sharding.allreduce_gradients``: RCCL over xGMI on the GPU box), and (d) the
+reference's optimizer (``Adafactor(self.parameters())``, spatial_diffusion.py:701-705) keeps working on
+the parameters unchanged, in place.
+
+The kernels ADD into ``flat_grad``.  When a parameter's ``.grad`` is not (or no longer, after
+``zero_grad(set_to_none=True)``) the engine's view, the next backward starts from zero and re-attaches the
+views; otherwise it accumulates, like autograd does.
+
+fp32 only (the parity mode): the reference trains in fp32 and its gradient fixtures are fp32.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .graph_plan import GraphPlan
+
+
+def _param_order(module):
+    """(name, fused-group id or None) in flat-buffer order; names relative to the Eff_GAT module."""
+    names = ["time_emb.weight", "pos_mlp.0.weight", "pos_mlp.0.bias", "pos_mlp.2.weight", "pos_mlp.2.bias",
+             "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias"]
+    n_layers = len(module.gnn_backbone.module_list)
+    for l in range(n_layers):
+        p = f"gnn_backbone.module_list.{l}."
+        names += [p + f"lin_{k}.weight" for k in ("query", "key", "value", "skip")]
+        names += [p + f"lin_{k}.bias" for k in ("query", "key", "value", "skip")]
+    if hasattr(module.gnn_backbone, "virt_node_embedding"):
+        names.append("gnn_backbone.virt_node_embedding.weight")
+    names += ["final_mlp.0.weight", "final_mlp.0.bias", "final_mlp.2.weight", "final_mlp.2.bias"]
+    return names, n_layers
+
+
+class TrainEngine:
+    """Owns the flat buffers + training workspace of one ``Eff_GAT`` module on one GPU."""
+
+    def __init__(self, module, device=None):
+        self.lib = _lib.lib()
+        params = dict(module.named_parameters())
+        names, self.n_layers = _param_order(module)
+        dev = torch.device(device) if device is not None else params[names[0]].device
+        if dev.type != "cuda":
+            raise _lib.DaError("TrainEngine needs a ROCm device (no CPU path in diffassemble_amd)")
+        self.device = dev
+        self.names = names
+        self.params = [params[n] for n in names]
+        offs, off = [], 0
+        for n, p in zip(names, self.params):
+            fused_tail = any(n.endswith(f"lin_{k}.{w}") for k in ("key", "value", "skip") for w in ("weight", "bias"))
+            if not fused_tail:
+                off = (off + 63) // 64 * 64            # 256-byte aligned slots; fused groups stay gap-free
+            offs.append(off)
+            off += p.numel()
+        self.total = (off + 63) // 64 * 64
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.views, self.grad_views = [], []
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                v = self.flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.detach().to(device=dev, dtype=torch.float32))
+                p.data = v
+                self.views.append(v)
+                self.grad_views.append(self.flat_grad[o:o + p.numel()].view(p.shape))
+        gnn = module.gnn_backbone
+        self.arch = gnn.arch
+        self.virt_nodes = int(getattr(gnn, "virt_nodes", 0)) if self.arch == "exophormer" else 0
+        by = dict(zip(names, self.views))
+        self.D = by["mlp.0.weight"].shape[1]
+        self.F = self.D - 64
+        self.c_in = by["pos_mlp.0.weight"].shape[1]
+        self.c_out = by["final_mlp.2.weight"].shape[0]
+        self.steps = by["time_emb.weight"].shape[0]
+        self.hidden = by["mlp.0.weight"].shape[0]
+        self.w = self._weights_struct(dict(zip(names, self.views)))
+        self.gw = self._weights_struct(dict(zip(names, self.grad_views)))
+        self._ws = None
+        self._ws_key = None
+
+    def _weights_struct(self, by):
+        w = _lib.DaWeights()
+        w.variant = _lib.VARIANT_2D
+        w.arch = _lib.ARCH_EXOPHORMER if self.arch == "exophormer" else _lib.ARCH_TRANSFORMER
+        w.steps, w.c_in, w.c_out, w.feat_dim, w.hidden = self.steps, self.c_in, self.c_out, self.F, self.hidden
+        w.heads, w.n_layers, w.virt_nodes = 8, self.n_layers, self.virt_nodes
+        P = lambda n: by[n].data_ptr()  # noqa: E731
+        w.time_emb = P("time_emb.weight")
+        w.pos_w0, w.pos_b0, w.pos_w1, w.pos_b1 = (P("pos_mlp.0.weight"), P("pos_mlp.0.bias"), P("pos_mlp.2.weight"),
+                                                  P("pos_mlp.2.bias"))
+        w.mlp_w0, w.mlp_b0, w.mlp_w1, w.mlp_b1 = (P("mlp.0.weight"), P("mlp.0.bias"), P("mlp.2.weight"),
+                                                  P("mlp.2.bias"))
+        for l in range(self.n_layers):
+            p = f"gnn_backbone.module_list.{l}."
+            w.conv_wq[l], w.conv_bq[l] = P(p + "lin_query.weight"), P(p + "lin_query.bias")
+            w.conv_wk[l], w.conv_bk[l] = P(p + "lin_key.weight"), P(p + "lin_key.bias")
+            w.conv_wv[l], w.conv_bv[l] = P(p + "lin_value.weight"), P(p + "lin_value.bias")
+            w.conv_ws[l], w.conv_bs[l] = P(p + "lin_skip.weight"), P(p + "lin_skip.bias")
+        if self.virt_nodes > 0:
+            w.virt_emb = P("gnn_backbone.virt_node_embedding.weight")
+        w.head_w0, w.head_b0 = P("final_mlp.0.weight"), P("final_mlp.0.bias")
+        w.head_w1, w.head_b1 = P("final_mlp.2.weight"), P("final_mlp.2.bias")
+        return w
+
+    # ------------------------------------------------------------------ plumbing
+    def still_bound(self):
+        """False once somebody replaced a parameter's storage (``.to()``, ``load_state_dict`` with
+        assign, ...): the caller rebuilds the engine."""
+        return all(p.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
+
+    def _workspace(self, plan: GraphPlan):
+        g = plan.c_struct()
+        need = int(self.lib.da_train_workspace_bytes(C.byref(self.w), C.byref(g)))
+        if need == 0:
+            _lib.check(1)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, plan: GraphPlan, x, t, feats):
+        """da_train_forward: out [n_real, c_out] fp32; activations stay in the workspace for backward."""
+        x = x.detach().to(self.device, torch.float32).contiguous()
+        t = t.detach().to(self.device, torch.int64).contiguous()
+        feats = feats.detach().to(self.device, torch.float32).contiguous()
+        assert x.shape == (plan.n_real, self.c_in) and feats.shape == (plan.n_real, self.F), (x.shape, feats.shape)
+        out = torch.empty((plan.n_real, self.c_out), dtype=torch.float32, device=self.device)
+        ws = self._workspace(plan)
+        g = plan.c_struct()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.da_train_forward(C.byref(self.w), C.byref(g), _lib.ptr(x), _lib.ptr(t), _lib.ptr(feats),
+                                                 _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self.device)))
+        return out
+
+    def backward(self, plan: GraphPlan, x, t, d_out, want_dfeats=False):
+        """da_train_backward: adds every parameter gradient into ``flat_grad`` (and attaches the views
+        as ``.grad``); returns d_feats [n_real, F] or None."""
+        plan.with_source_csr()
+        attached = all(p.grad is not None and p.grad.data_ptr() == gv.data_ptr()
+                       for p, gv in zip(self.params, self.grad_views))
+        if not attached:
+            self.flat_grad.zero_()
+        x = x.detach().to(self.device, torch.float32).contiguous()
+        t = t.detach().to(self.device, torch.int64).contiguous()
+        d_out = d_out.detach().to(self.device, torch.float32).contiguous()
+        d_feats = torch.empty((plan.n_real, self.F), dtype=torch.float32, device=self.device) if want_dfeats else None
+        ws = self._workspace(plan)
+        g = plan.c_struct()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.da_train_backward(C.byref(self.w), C.byref(self.gw), C.byref(g), _lib.ptr(x), _lib.ptr(t),
+                                                  _lib.ptr(d_out), _lib.ptr(d_feats), _lib.ptr(ws), ws.numel(),
+                                                  _lib.stream_ptr(self.device)))
+        if not attached:
+            for p, gv in zip(self.params, self.grad_views):
+                p.grad = gv
+        return d_feats
+
+
+class DenoiserTrainFn(torch.autograd.Function):
+    """out = Eff_GAT.forward_with_feats(x, t, feats) with the backward in the HIP library.  The
+    parameters are passed so that ``out`` joins the autograd graph; their gradients are written
+    straight into ``TrainEngine.flat_grad`` (aliased by ``param.grad``), so ``None`` is returned for
+    them.  One forward must be followed by its backward before the next forward (shared workspace)."""
+
+    @staticmethod
+    def forward(ctx, eng, plan, x, t, feats, *params):
+        out = eng.forward(plan, x, t, feats)
+        ctx.eng, ctx.plan = eng, plan
+        ctx.want_dfeats = bool(feats.requires_grad)
+        ctx.save_for_backward(x, t)
+        ctx.n_params = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, t = ctx.saved_tensors
+        d_feats = ctx.eng.backward(ctx.plan, x, t, d_out, ctx.want_dfeats)
+        return (None, None, None, None, d_feats) + (None,) * ctx.n_params

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 1
+#define DA_ABI_VERSION 2
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -104,6 +104,10 @@ typedef struct da_graph {
     int32_t n_pad;
     const int32_t *pad_ptr;   /* [n_graphs + 1] or NULL                                    */
     const int32_t *row_map;   /* [n_nodes] or NULL                                         */
+    /* training only (da_train_backward): the same edges grouped by SOURCE node, i.e. the
+     * outgoing edges of node j are out_dst[out_ptr[j] .. out_ptr[j+1]); multi-edges kept.  */
+    const int32_t *out_ptr;   /* [n_nodes + 1] or NULL                                     */
+    const int32_t *out_dst;   /* [n_edges] or NULL                                         */
 } da_graph;
 
 typedef struct da_denoiser da_denoiser;
@@ -221,6 +225,29 @@ int da_attn_csr(int prec, const da_graph *g, int heads, int C, const void *qkvs,
 size_t da_attn_dense_scratch_bytes(int prec, const da_graph *g, int heads, int C);
 int da_conv_dense(int prec, const da_graph *g, int heads, int C, int Din, const void *x, const void *w,
                   const float *b, const void *residual, int act, void *out, void *scratch, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Training: the denoiser forward with saved activations and its backward, fp32.
+ * Replaces torch autograd through Eff_GAT.forward_with_feats (efficient_gat.py:121-146) as
+ * driven by GNN_Diffusion.p_losses / training_step (spatial_diffusion.py:432-483,707-721); the
+ * loss itself (smooth_l1 on [N, c]) and the optimizer stay with the caller, as in the reference.
+ *   w      LIVE fp32 parameters (no packing, no copy): per conv layer lin_query | lin_key |
+ *          lin_value | lin_skip weights must be contiguous in that order ([4*H*C, Din]), and so
+ *          must their biases -- the host keeps the parameters in one flat buffer.
+ *   grads  the same struct filled with the gradient pointers (same layout); the library ADDS
+ *          into them (zero them per optimizer step).
+ *   d_feats nullable [n_real, F]: gradient w.r.t. the piece features, for a trainable encoder.
+ * Only the 2D denoiser (arch transformer / exophormer) is implemented; any graph type, through
+ * the CSR attention kernels (needs g->out_ptr / g->out_dst).  The forward must precede the
+ * backward on the same workspace.
+ * ------------------------------------------------------------------------------------- */
+size_t da_train_workspace_bytes(const da_weights *w, const da_graph *g);
+int da_train_forward(const da_weights *w, const da_graph *g, const float *x, const int64_t *t,
+                     const float *feats, float *out, void *workspace, size_t workspace_bytes,
+                     void *stream);
+int da_train_backward(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
+                      const int64_t *t, const float *d_out, float *d_feats, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

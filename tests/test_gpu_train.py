@@ -1,0 +1,203 @@
+"""GPU parity of the training path: da_train_forward / da_train_backward through the
+reference-shaped modules, against autograd through the CPU oracle on the same seeded inputs and against
+the committed gradient fixture produced from the reference's own p_losses.
+
+Tolerances: forward 1e-4 (north star); gradients 1e-3 of each tensor's max-abs (fp32 sums over up to
+2 x 144 nodes x 144 edges in a different order than autograd's)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases as C
+from oracle import denoiser as OD
+from oracle import diffusion as ODF
+
+pytestmark = pytest.mark.gpu
+GTOL = 1e-3
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def make_module(spec, case, dev):
+    from diffassemble_amd.model.backbones import Eff_GAT
+    m = Eff_GAT(steps=spec["steps"], input_channels=spec["c"], output_channels=spec["c"], architecture=spec["arch"],
+                virt_nodes=spec["V"] or 4, visual_pretrained=False)
+    missing, unexpected = m.load_state_dict(case["sd"], strict=False)
+    assert not unexpected
+    return m.to(dev).train()
+
+
+def oracle_grads(spec, case, x_noisy, target, want_feats=True):
+    sd = {k: v.clone().requires_grad_(True) for k, v in case["sd"].items()}
+    feats = case["feats"].clone().requires_grad_(want_feats)
+    pred, _ = OD.eff_gat_forward_with_feats(sd, x_noisy, case["t"], case["edge_index"], feats, case["batch"],
+                                            spec["arch"], spec["V"])
+    loss = F.smooth_l1_loss(target, pred)
+    loss.backward()
+    return pred.detach(), loss.detach(), {k: v.grad for k, v in sd.items()}, feats.grad
+
+
+TRAIN_SPECS = ["k36_noloop_eps", "rot144_g2_sharp", "ragged_dense", "exo144_v8_g2", "exo_expander_d6", "tr_expander_d7"]
+
+
+@pytest.mark.parametrize("name", TRAIN_SPECS)
+def test_backward_matches_oracle_autograd(dev, name):
+    spec = C.by_name(name)
+    case = C.build_case(spec)
+    rng = np.random.default_rng(17)
+    target = torch.from_numpy(rng.standard_normal(tuple(case["x"].shape)).astype(np.float32))
+    x_noisy = case["x"]
+    pred_ref, loss_ref, g_ref, gf_ref = oracle_grads(spec, case, x_noisy, target)
+
+    m = make_module(spec, case, dev)
+    feats = case["feats"].to(dev).requires_grad_(True)
+    out, att = m.forward_with_feats(x_noisy.to(dev), case["t"].to(dev), None, case["edge_index"].to(dev), feats,
+                                    case["batch"].to(dev))
+    assert att is None and out.requires_grad
+    assert rel(out, pred_ref) < 1e-4
+    loss = F.smooth_l1_loss(target.to(dev), out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(loss, loss_ref) < 1e-5
+    params = dict(m.named_parameters())
+    checked = 0
+    # lin_key.bias has an identically-zero gradient (a constant added to every score of a softmax row):
+    # both sides hold rounding noise there, so errors are measured against a floor tied to the largest
+    # gradient of the model
+    floor = 1e-4 * max(float(g.abs().max()) for g in g_ref.values())
+    for k, gr in g_ref.items():
+        assert gr is not None, k
+        got = params[k].grad
+        assert got is not None, k
+        err = float((got.detach().double().cpu() - gr.double()).abs().max()) / max(float(gr.abs().max()), floor)
+        assert err < GTOL, (k, err)
+        checked += 1
+    assert checked == len(case["sd"])
+    assert rel(feats.grad, gf_ref) < GTOL
+    # the dead / encoder parameters of the reference never receive a gradient
+    assert params["linear1.weight"].grad is None
+    # all gradients alias ONE flat buffer (the data-parallel all-reduce bucket)
+    te = m.train_engine()
+    lo, hi = te.flat_grad.data_ptr(), te.flat_grad.data_ptr() + te.flat_grad.numel() * 4
+    assert all(lo <= params[k].grad.data_ptr() < hi for k in g_ref)
+
+
+def test_gradient_accumulation_and_zeroing(dev):
+    """Two backward passes accumulate like autograd; zero_grad(set_to_none=True) restarts from zero."""
+    spec = C.by_name("k36_loop_sharp")
+    case = C.build_case(spec)
+    m = make_module(spec, case, dev)
+    args = (case["x"].to(dev), case["t"].to(dev), None, case["edge_index"].to(dev), case["feats"].to(dev),
+            case["batch"].to(dev))
+    tgt = torch.zeros_like(args[0])
+
+    def step():
+        out, _ = m.forward_with_feats(*args)
+        F.smooth_l1_loss(tgt, out).backward()
+
+    step()
+    g1 = m.mlp[0].weight.grad.clone()
+    step()
+    assert rel(m.mlp[0].weight.grad, 2 * g1) < 1e-5
+    m.zero_grad(set_to_none=True)
+    assert m.mlp[0].weight.grad is None
+    step()
+    assert rel(m.mlp[0].weight.grad, g1) < 1e-5
+    m.zero_grad(set_to_none=False)
+    step()
+    assert rel(m.mlp[0].weight.grad, g1) < 1e-5
+
+
+@pytest.mark.parametrize("tr", C.TRAIN2D, ids=lambda s: s["name"])
+def test_p_losses_gradients_match_reference_fixture(dev, golden, tr):
+    """GNN_Diffusion.p_losses -> loss.backward() vs the fixture generated from the reference's own
+    p_losses (tests/golden/make_golden.py): loss value, first 64 entries and (sum, abs-sum, sum of squares) of every
+    live gradient."""
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    spec = C.by_name(tr["base"])
+    case = C.build_case(spec)
+    m = GNN_Diffusion(steps=spec["steps"], sampling="DDIM", rotation=True, visual_pretrained=False,
+                      model_mean_type=getattr(ModelMeanType, tr["mean"]), architecture=spec["arch"])
+    m.model.load_state_dict(case["sd"], strict=False)
+    m = m.to(dev).train()
+    rng = np.random.default_rng(tr["seed"])
+    noise = torch.from_numpy(rng.standard_normal(tuple(case["x"].shape)).astype(np.float32)).to(dev)
+    loss = m.p_losses(case["x"].to(dev), case["t"].to(dev), noise=noise, loss_type="huber", cond=None,
+                      edge_index=case["edge_index"].to(dev), batch=case["batch"].to(dev),
+                      patch_feats=case["feats"].to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(loss, golden[f"{tr['name']}/loss"]) < 1e-5
+
+    def stats(g):
+        g = g.double()
+        return torch.stack([g.sum(), g.abs().sum(), (g * g).sum()])
+
+    n = 0
+    for k, p in m.model.named_parameters():
+        key = f"{tr['name']}/grad_head/{k}"
+        if key in golden.files:
+            ref = torch.from_numpy(golden[key])
+            assert rel(p.grad.flatten()[: ref.numel()], ref) < GTOL, k
+            st_ref = golden[f"{tr['name']}/grad_stats/{k}"]
+            st = stats(p.grad.cpu())
+            assert abs(float(st[1]) - float(st_ref[1])) / float(st_ref[1]) < GTOL, k
+            assert abs(float(st[2]) - float(st_ref[2])) / float(st_ref[2]) < 2 * GTOL, k
+            n += 1
+    assert n >= 28
+
+
+def test_training_step_with_reference_optimizer_then_inference(dev):
+    """One optimizer step with the reference's optimizer (Adafactor, spatial_diffusion.py:701-705) on the
+    flat-buffer parameters lowers the loss of the same batch, and the packed inference engine picks the
+    updated weights up."""
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    spec = C.by_name("rot144_g1")
+    case = C.build_case(spec)
+    m = GNN_Diffusion(steps=spec["steps"], sampling="DDIM", rotation=True, visual_pretrained=False,
+                      model_mean_type=ModelMeanType.EPSILON)
+    m.model.load_state_dict(case["sd"], strict=False)
+    m = m.to(dev).train()
+    opt = m.configure_optimizers()
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(case["x"].shape, generator=g).to(dev)
+    kw = dict(noise=noise, loss_type="huber", cond=None, edge_index=case["edge_index"].to(dev),
+              batch=case["batch"].to(dev), patch_feats=case["feats"].to(dev))
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = m.p_losses(case["x"].to(dev), case["t"].to(dev), **kw)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[2] < losses[0], losses
+    # inference on the updated weights (engine repacks because the parameters changed in place)
+    m.eval()
+    m.model.precision = "fp32"
+    sd_now = {k: v.detach().cpu() for k, v in m.model.state_dict().items() if k in case["sd"]}
+    ref, _ = OD.eff_gat_forward_with_feats(sd_now, case["x"], case["t"], case["edge_index"], case["feats"], case["batch"])
+    with torch.no_grad():
+        out = m.forward_with_feats(case["x"].to(dev), case["t"].to(dev), None, case["edge_index"].to(dev),
+                                   patch_feats=case["feats"].to(dev), batch=case["batch"].to(dev))
+    assert rel(out, ref) < 1e-4
+
+
+def test_q_sample_matches_oracle(dev):
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion
+    m = GNN_Diffusion(steps=100, sampling="DDIM", rotation=True, visual_pretrained=False).to(dev)
+    g = torch.Generator().manual_seed(1)
+    x0, noise = torch.randn(50, 4, generator=g), torch.randn(50, 4, generator=g)
+    t = torch.randint(0, 100, (50,), generator=g)
+    ref = ODF.q_sample(ODF.make_schedule(100), x0, t, noise)
+    assert rel(m.q_sample(x0.to(dev), t.to(dev), noise.to(dev)), ref) < 1e-6
