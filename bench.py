@@ -61,14 +61,96 @@ def cpu_baseline(sd, seed, threads):
             "sample": f"1 DDIM step of 1 puzzle (N=900, E=810000), oracle/ torch fp32, {dt:.1f} s"}
 
 
+def train_bench(args, world, rank, dev):
+    """BASELINE config 5: 12x12 rot dense puzzles, 64 per GPU, Huber loss, one optimizer step per "step":
+    p_losses (q_sample + denoiser forward, HIP) -> backward (HIP) -> ONE all-reduce of the flat gradient
+    buffer (RCCL) -> the reference's optimizer (Adafactor).  fp32.  Piece features are synthetic (the
+    encoder is outside the path)."""
+    import torch.distributed as dist
+    from diffassemble_amd import sharding as S
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    from oracle import weights as W
+    n, G, K, Wm = 144, args.train_puzzles, args.steps, args.warmup
+    sd = W.make_denoiser_state(T_STEPS, 4, 4, seed=0)
+    m = GNN_Diffusion(steps=T_STEPS, sampling="DDIM", rotation=True, visual_pretrained=False,
+                      model_mean_type=ModelMeanType.EPSILON)
+    m.model.load_state_dict(sd, strict=False)
+    m = m.to(dev).train()
+    opt = m.configure_optimizers()
+    gen = torch.Generator(device=dev).manual_seed(99 + rank)
+    feats = torch.randn((G * n, 1088), generator=gen, device=dev)
+    x0 = torch.randn((G * n, 4), generator=gen, device=dev)
+    ei, batch = dense_batch(G, n, dev)
+    te = m.model.train_engine(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = [0.0, 0.0, 0.0]
+
+    def step(timed=False):
+        t = torch.randint(0, T_STEPS, (G,), generator=gen, device=dev)[batch]
+        opt.zero_grad(set_to_none=False)
+        if timed: ev[0].record()
+        loss = m.p_losses(x0, t, loss_type="huber", cond=None, edge_index=ei, batch=batch, patch_feats=feats)
+        loss.backward()
+        if timed: ev[1].record()
+        S.allreduce_gradients(te.flat_grad)
+        if timed: ev[2].record()
+        opt.step()
+        if timed:
+            ev[3].record()
+            torch.cuda.synchronize()
+            for k in range(3):
+                acc[k] += ev[k].elapsed_time(ev[k + 1])
+        return loss
+
+    for _ in range(max(Wm, 1)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = S.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(loss), "non-finite loss"
+    kp = min(K, 10)
+    for _ in range(kp):
+        step(True)
+    if rank == 0:
+        flop_fwd = G * (n * F_NODE + n * n * F_EDGE)
+        print(json.dumps({
+            "metric": "training steps/sec (12x12 rot dense, 64 puzzles/GPU, Huber, Adafactor)",
+            "value": world * G * K / dt, "unit": "puzzle-train-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5: 12x12 rot dense (N=144, E=20736), G per GPU below, huber, "
+                                   "EPSILON, one Adafactor step; denoiser only (piece features synthetic)",
+                       "puzzles_per_gpu": G, "global_puzzles": world * G,
+                       "parallelism": f"data parallel x{world}, one fused gradient all-reduce"},
+            "optimizer_steps_per_s": K / dt,
+            "algorithmic_tflops": 3 * world * flop_fwd * K / dt / 1e12,
+            "phases_ms": {"forward+backward": acc[0] / kp, "gradient_allreduce": acc[1] / kp, "optimizer": acc[2] / kp},
+            "roofline": None, "cpu_baseline": None,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--puzzles", type=int, default=int(os.environ.get("BENCH_PUZZLES", 8)),
+    ap.add_argument("--puzzles", type=int, default=int(os.environ.get("BENCH_PUZZLES", 32)),
                     help="independent 900-piece puzzles per GPU (the batch of one step)")
     ap.add_argument("--precision", default=os.environ.get("BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default=os.environ.get("BENCH_MODE", "sample"), choices=["sample", "train"],
+                    help="sample = the headline metric (default); train = BASELINE config 5 (one optimizer step)")
+    ap.add_argument("--train-puzzles", type=int, default=int(os.environ.get("BENCH_TRAIN_PUZZLES", 64)),
+                    help="--mode train: 12x12 puzzles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -83,6 +165,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.mode == "train":
+        return train_bench(args, world, rank, dev)
 
     from diffassemble_amd import DenoiserEngine, Schedule, _lib
     from oracle import diffusion as ODF          # schedule tables only (host constants)

@@ -54,6 +54,7 @@ struct GemmParams {
     unsigned Cmagic;   // ceil(2^32 / C): f / C == __umulhi(f, Cmagic) for the f < 2^16 that occur here
     void *Q, *Kb, *Vt, *S;
     int nct, nt;     // column tiles of this launch, column tiles per workgroup
+    int xcd_groups;  // > 0: 1-D grid, XCD-aware (row tile, column group) mapping with this many column groups
     unsigned long long *prof;   // DA_GEMM_PROBE builds: per-workgroup cycle breakdown [total, wait, mma, epilogue]
     int debug;   // DA_GEMM_DEBUG bits: 1 = no global stores, 2 = no MFMA, 4 = no DMA (timing experiments only)
 };

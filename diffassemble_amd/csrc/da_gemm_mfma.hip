@@ -161,10 +161,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 128 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.y * 128;
+    // Workgroup -> (row tile, column group).  With a long reduction (K = 1152) a row tile of A is 295 KB and
+    // every column group re-streams it: the groups of one row tile must therefore run on the SAME XCD at
+    // the same time so that only the first of them goes to HBM (measured before: FETCH_SIZE = 8.5x the
+    // size of A on the conv-0 projection).  Workgroups are dispatched round-robin over the 8 XCDs, so
+    // XCD x = id % 8 takes row tiles x, x + 8, ... and walks (row tile, column group) pairs column-fastest.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_groups > 0) {
+        const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
+        by = x + 8 * (s / p.xcd_groups);
+        bx = s % p.xcd_groups;
+        if (by * 128 >= p.M) return;
+    }
+    const int row0 = by * 128;
     constexpr int ES = (int)sizeof(T), EPC = 16 / ES, BK = 128 / ES;
     constexpr int ROWS = ES == 4 ? 32 : 64, PASSES = 128 / ROWS, CPR = 128 * ES / 16, NIT = ROWS * CPR / 256;
-    const int t_beg = blockIdx.x * p.nt, t_end = min(t_beg + p.nt, p.nct);
+    const int t_beg = bx * p.nt, t_end = min(t_beg + p.nt, p.nct);
 
     // Staging by LDS-DMA: wave w fills rows [32w, 32w+32) of both tiles, 8 rows (1 KB) per instruction.
     // The DMA writes lane l at (wave-uniform base) + 16 l, i.e. row (l >> 3), slot (l & 7); the XOR
@@ -273,6 +285,7 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     GemmParams p;
     p.M = M; p.K = K; p.Nout = Nout; p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.act = act; p.res = res;
     p.out = out; p.ldo = ldo; p.qkv = 0; p.HC = 1; p.C = 1; p.n_pad = 0; p.row_map = nullptr; p.Cmagic = 0;
+    p.xcd_groups = 0;
     p.Q = p.Kb = p.Vt = p.S = nullptr;
     { const char *e = getenv("DA_GEMM_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     { const char *e = getenv("DA_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
@@ -296,7 +309,15 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     // Column tiles per workgroup: 256 CUs x 2 resident workgroups = 512 slots.  Use as many column
     // groups as keep the whole grid co-resident (one round, no tail) -- each workgroup then streams
     // its share of the column tiles back to back.
+    static int xcd_off = -1;
+    if (xcd_off < 0) { const char *e = getenv("DA_GEMM_NO_XCD_MAP"); xcd_off = (e && e[0] == '1') ? 1 : 0; }
     auto plan2 = [&](int nct) {
+        p.xcd_groups = 0;
+        if (!xcd_off && nct > 1 && (size_t)K * es > 512) {
+            // long reduction: one column tile per workgroup, column groups of a row tile co-resident on one XCD
+            p.nct = nct; p.nt = 1; p.xcd_groups = nct;
+            return dim3((unsigned)(8 * ((nrt + 7) / 8) * nct), 1u);
+        }
         int groups = 512 / nrt;
         groups = groups > nct ? nct : (groups < 1 ? 1 : groups);
         int ntile = (nct + groups - 1) / groups;

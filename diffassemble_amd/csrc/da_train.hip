@@ -55,22 +55,27 @@ __global__ __launch_bounds__(256) void k_transpose(int rows, int cols, const flo
     }
 }
 
-// out[c] += sum_m A[m][c]      (bias gradients)
-__global__ __launch_bounds__(1024) void k_colsum_add(int M, int N, const float *__restrict__ A, int lda, float *out) {
-    __shared__ float red[16][64];
+// out[c] += sum_m A[m][c]      (bias gradients).  Two deterministic stages: grid (ceil(N/64), chunks)
+// column sums over row chunks into `partial[chunk][N]`, then one pass adds the chunks into out.
+__global__ __launch_bounds__(256) void k_colsum_partial(int M, int N, const float *__restrict__ A, int lda, int rows_per,
+                                                        float *__restrict__ partial) {
+    __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
     float s = 0.f;
     if (c < N)
-        for (int m = ty; m < M; m += 16) s += A[(size_t)m * lda + c];
+        for (int m = m0 + ty; m < m1; m += 4) s += A[(size_t)m * lda + c];
     red[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && c < N) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][tx];
-        out[c] += t;
-    }
+    if (ty == 0 && c < N) partial[(size_t)blockIdx.y * N + c] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+__global__ __launch_bounds__(256) void k_colsum_finish(int chunks, int N, const float *__restrict__ partial, float *out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += partial[(size_t)k * N + c];
+    out[c] += s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -353,7 +358,7 @@ struct TrainWs {
     float *comb_in, *m1pre, *m1, *h0;
     float *qkvs[DA_MAX_LAYERS], *o[DA_MAX_LAYERS], *hact[DA_MAX_LAYERS], *stats[DA_MAX_LAYERS];
     float *f1pre, *f1;
-    float *dz, *dh0, *dY4, *dxa, *dxb, *Dd, *dm1, *df1, *dcomb, *wt, *partial, *pa, *p1, *dp1;
+    float *dz, *dh0, *dY4, *dxa, *dxb, *Dd, *dm1, *df1, *dcomb, *wt, *partial, *csum, *pa, *p1, *dp1;
     size_t total;
 };
 
@@ -419,6 +424,7 @@ static TrainWs carve_train(const Dims &d, void *base) {
     w.dcomb = take(nr * d.D);
     w.wt = take(wmax + 1024);
     w.partial = take(PART_CAP);
+    w.csum = take(((size_t)d.n / 128 + 2) * 4 * (size_t)hcmax);
     w.pa = take(nr * 16);
     w.p1 = take(nr * 16);
     w.dp1 = take(nr * 16);
@@ -453,8 +459,10 @@ static int transpose(int rows, int cols, const float *src, float *dst, hipStream
     DA_LAUNCH_CHECK();
     return 0;
 }
-static int colsum_add(int M, int N, const float *A, int lda, float *out, hipStream_t st) {
-    k_colsum_add<<<(N + 63) / 64, 1024, 0, st>>>(M, N, A, lda, out);
+static int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch, hipStream_t st) {
+    const int rows_per = 128, chunks = (M + rows_per - 1) / rows_per;      // chunks * N floats of scratch
+    k_colsum_partial<<<dim3((N + 63) / 64, chunks), 256, 0, st>>>(M, N, A, lda, rows_per, scratch);
+    k_colsum_finish<<<(N + 255) / 256, 256, 0, st>>>(chunks, N, scratch, out);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -464,7 +472,7 @@ static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float
                       float *dW, float *db, float *dX, int lddx, const float *res, TrainWs &ws, hipStream_t st) {
     int rc;
     if ((rc = launch_gemm_tn(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, st))) return rc;
-    if (db && (rc = colsum_add(M, N, dY, ldy, db, st))) return rc;
+    if (db && (rc = colsum_add(M, N, dY, ldy, db, ws.csum, st))) return rc;
     if (dX) {
         if ((rc = transpose(N, K, W, ws.wt, st))) return rc;                      // W [N, K] -> W^T [K, N]
         if ((rc = linear(DA_PREC_F32, M, N, K, dY, ldy, ws.wt, nullptr, DA_ACT_NONE, res, dX, lddx, st))) return rc;
