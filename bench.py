@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-N_PIECES, T_STEPS = 900, 100
+N_PIECES, T_STEPS = int(os.environ.get("BENCH_N_EXPERIMENT", 900)), 100   # the metric is defined at 900; other values are for layout experiments only
 F_NODE = 6_432_128          # FLOP per piece per step (SURVEY 8d / BASELINE.md)
 F_EDGE = 7_680              # FLOP per edge per step, all 4 layers
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
@@ -227,8 +227,15 @@ def main():
         flop_last = G * N_PIECES * N_PIECES * 4 * 1152             # QK^T + PV, mul+add, C*H = 1152
         ach = flop_last / (ms_last / n_last * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
+        traffic, tsrc = None, None
+        try:        # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside this process)
+            ent = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))[args.precision][str(G)]
+            traffic = (2.0 * ent["fetch_kib"] + ent["write_kib"]) * 1024.0
+            tsrc = "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"bound": "mfma", "kernel": "attn_last (graph attention, conv 3, C=144)", "achieved": ach,
-                "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
                 "flop_per_launch": flop_last, "avg_launch_ms": ms_last / n_last}
         ms_all = sum(ms for ms, _ in prof.values()) / kp
         flop_step = G * (N_PIECES * F_NODE + N_PIECES * N_PIECES * F_EDGE)
