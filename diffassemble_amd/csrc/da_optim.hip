@@ -1,0 +1,209 @@
+// Fused Adafactor step over the flat parameter / gradient buffers of the training engine.
+//
+// Replaces, for the live denoiser parameters, the optimizer the reference configures
+// (spatial_diffusion.py:701-705: transformers.optimization.Adafactor(self.parameters()) with its
+// defaults: relative step, scale_parameter, eps = (1e-30, 1e-3), clip_threshold 1, decay_rate -0.8, no
+// first moment, no weight decay).  The torch implementation issues ~20 tiny kernels and two host syncs
+// per parameter (~700 launches, 6 ms per step); here the whole step is FOUR launches driven by device
+// tables, every reduction is two-stage and deterministic (all data-parallel ranks must apply
+// bit-identical updates to stay in sync), nothing returns to the host.
+//
+// Per parameter p with gradient g (fp32), step t:
+//   rho = min(1e-2, 1/sqrt(t)),  lr = max(eps2, rms(p)) * rho,  beta = 1 - t^decay
+//   matrices [R, C] (factored second moment):
+//     row_r <- beta row_r + (1-beta) mean_c(g^2 + eps1),  col_c <- beta col_c + (1-beta) mean_r(g^2 + eps1)
+//     u = g * rsqrt(row_r / mean(row)) * rsqrt(col_c)
+//   vectors:  v <- beta v + (1-beta)(g^2 + eps1),  u = g * rsqrt(v)
+//   p <- p - lr * u / max(1, rms(u) / clip)
+#include <math.h>
+
+#include "da_common.h"
+
+namespace da {
+
+struct AfParam {            // one entry per parameter tensor (device table)
+    long long off;          // offset (floats) into flat / flat_grad
+    int rows, cols;         // matrices: [rows, cols]; vectors: rows = 1, cols = numel
+    int factored;           // 1 = matrix
+    long long row_off, col_off;   // offsets into the state buffer (matrices: row[R], col[C]; vectors: v[numel] at row_off)
+    int blk0, nblk;         // its blocks in the block table
+    long long colpart_off;  // scratch: [nblk][cols] column partial sums (matrices)
+};
+struct AfBlock { int pid, row0, nrows; };     // matrices: a chunk of rows; vectors: a chunk of `nrows` ELEMENTS from row0
+constexpr int AF_CPT = 5;                     // columns per thread in phase A: matrices up to 1280 columns
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+    return s;
+}
+
+// Phase A: per block -- sum p^2, row EMA (matrices: final), column partial sums; vectors: v EMA + sum u^2
+__global__ __launch_bounds__(256) void k_af_a(const AfParam *__restrict__ P, const AfBlock *__restrict__ B, const float *__restrict__ flat,
+                                              const float *__restrict__ grad, float *__restrict__ state, float *__restrict__ colpart,
+                                              float *__restrict__ part_p2, float *__restrict__ part_u2, float beta, float eps1) {
+    __shared__ float red[4];
+    const AfBlock b = B[blockIdx.x];
+    const AfParam p = P[b.pid];
+    const float *w = flat + p.off, *g = grad + p.off;
+    float sp = 0.f, su = 0.f;
+    if (p.factored) {
+        float *row = state + p.row_off;
+        float *cp = colpart + p.colpart_off + (size_t)(blockIdx.x - p.blk0) * p.cols;
+        float ca[AF_CPT];                       // this thread's columns c = tid + 256 k (cols <= 256 * AF_CPT, host-checked)
+#pragma unroll
+        for (int k = 0; k < AF_CPT; ++k) ca[k] = 0.f;
+        for (int r = b.row0; r < b.row0 + b.nrows; ++r) {
+            float sr = 0.f;
+#pragma unroll
+            for (int k = 0; k < AF_CPT; ++k) {
+                const int c = threadIdx.x + 256 * k;
+                if (c < p.cols) {
+                    const float gv = g[(size_t)r * p.cols + c], wv = w[(size_t)r * p.cols + c];
+                    const float q = fmaf(gv, gv, eps1);
+                    sr += q;
+                    ca[k] += q;
+                    sp = fmaf(wv, wv, sp);
+                }
+            }
+            sr = block_sum(sr, red);
+            if (threadIdx.x == 0) row[r] = beta * row[r] + (1.0f - beta) * (sr / (float)p.cols);
+        }
+#pragma unroll
+        for (int k = 0; k < AF_CPT; ++k) {
+            const int c = threadIdx.x + 256 * k;
+            if (c < p.cols) cp[c] = ca[k];
+        }
+    } else {
+        float *v = state + p.row_off;
+        for (int i = b.row0 + threadIdx.x; i < b.row0 + b.nrows; i += 256) {
+            const float gv = g[i], wv = w[i];
+            const float vv = beta * v[i] + (1.0f - beta) * fmaf(gv, gv, eps1);
+            v[i] = vv;
+            const float u = gv * rsqrtf(vv);
+            su = fmaf(u, u, su);
+            sp = fmaf(wv, wv, sp);
+        }
+    }
+    sp = block_sum(sp, red);
+    su = block_sum(su, red);
+    if (threadIdx.x == 0) { part_p2[blockIdx.x] = sp; part_u2[blockIdx.x] = su; }
+}
+
+// Phase B: one block per parameter -- rms(p) -> lr, column EMA, mean of the row EMA
+__global__ __launch_bounds__(256) void k_af_b(const AfParam *__restrict__ P, float *__restrict__ state, const float *__restrict__ colpart,
+                                              const float *__restrict__ part_p2, float *__restrict__ scal /* [n][4]: lr, row_mean, -, - */,
+                                              float beta, float rho, float eps2) {
+    __shared__ float red[4];
+    const AfParam p = P[blockIdx.x];
+    float s = 0.f;
+    for (int k = threadIdx.x; k < p.nblk; k += 256) s += part_p2[p.blk0 + k];
+    s = block_sum(s, red);
+    const float numel = (float)p.rows * (float)p.cols;
+    const float rms = sqrtf(s) / sqrtf(numel);
+    float rm = 0.f;
+    if (p.factored) {
+        float *col = state + p.col_off;
+        for (int c = threadIdx.x; c < p.cols; c += 256) {
+            float t = 0.f;
+            for (int k = 0; k < p.nblk; ++k) t += colpart[p.colpart_off + (size_t)k * p.cols + c];
+            col[c] = beta * col[c] + (1.0f - beta) * (t / (float)p.rows);
+        }
+        const float *row = state + p.row_off;
+        for (int r = threadIdx.x; r < p.rows; r += 256) rm += row[r];
+        rm = block_sum(rm, red) / (float)p.rows;
+    }
+    if (threadIdx.x == 0) {
+        scal[blockIdx.x * 4 + 0] = fmaxf(eps2, rms) * rho;
+        scal[blockIdx.x * 4 + 1] = rm;
+    }
+}
+
+// Phase C (matrices): sum u^2 per block
+__global__ __launch_bounds__(256) void k_af_c(const AfParam *__restrict__ P, const AfBlock *__restrict__ B, const float *__restrict__ grad,
+                                              const float *__restrict__ state, const float *__restrict__ scal, float *__restrict__ part_u2) {
+    __shared__ float red[4];
+    const AfBlock b = B[blockIdx.x];
+    const AfParam p = P[b.pid];
+    if (!p.factored) return;                  // vectors were done in phase A (uniform per block)
+    const float *g = grad + p.off, *row = state + p.row_off, *col = state + p.col_off;
+    const float rm = scal[b.pid * 4 + 1];
+    float su = 0.f;
+    for (int r = b.row0; r < b.row0 + b.nrows; ++r) {
+        const float rf = rsqrtf(row[r] / rm);
+        for (int c = threadIdx.x; c < p.cols; c += 256) {
+            const float u = g[(size_t)r * p.cols + c] * (rf * rsqrtf(col[c]));
+            su = fmaf(u, u, su);
+        }
+    }
+    su = block_sum(su, red);
+    if (threadIdx.x == 0) part_u2[blockIdx.x] = su;
+}
+
+// Phase D: clip by rms(u), apply
+__global__ __launch_bounds__(256) void k_af_d(const AfParam *__restrict__ P, const AfBlock *__restrict__ B, float *__restrict__ flat,
+                                              const float *__restrict__ grad, const float *__restrict__ state, const float *__restrict__ scal,
+                                              const float *__restrict__ part_u2, float clip) {
+    __shared__ float red[4];
+    const AfBlock b = B[blockIdx.x];
+    const AfParam p = P[b.pid];
+    float s = 0.f;
+    for (int k = threadIdx.x; k < p.nblk; k += 256) s += part_u2[p.blk0 + k];
+    s = block_sum(s, red);
+    const float numel = (float)p.rows * (float)p.cols;
+    const float rms_u = sqrtf(s) / sqrtf(numel);
+    const float step = scal[b.pid * 4 + 0] / fmaxf(1.0f, rms_u / clip);
+    float *w = flat + p.off;
+    const float *g = grad + p.off;
+    if (p.factored) {
+        const float *row = state + p.row_off, *col = state + p.col_off;
+        const float rm = scal[b.pid * 4 + 1];
+        for (int r = b.row0; r < b.row0 + b.nrows; ++r) {
+            const float rf = rsqrtf(row[r] / rm);
+            for (int c = threadIdx.x; c < p.cols; c += 256) {
+                const size_t i = (size_t)r * p.cols + c;
+                w[i] -= step * (g[i] * (rf * rsqrtf(col[c])));
+            }
+        }
+    } else {
+        const float *v = state + p.row_off;
+        for (int i = b.row0 + threadIdx.x; i < b.row0 + b.nrows; i += 256) w[i] -= step * (g[i] * rsqrtf(v[i]));
+    }
+}
+
+}  // namespace da
+
+using namespace da;
+
+extern "C" {
+
+int da_adafactor_step(int n_params, const void *param_table, int n_blocks, const void *block_table, float *flat,
+                      const float *flat_grad, float *state, float *scratch, size_t scratch_floats, int step, float eps1,
+                      float eps2, float clip_threshold, float decay_rate, void *stream) {
+    DA_REQUIRE(n_params > 0 && n_blocks > 0 && param_table && block_table && flat && flat_grad && state && scratch,
+               "da_adafactor_step: null argument");
+    DA_REQUIRE(step >= 1, "da_adafactor_step: step counts from 1");
+    static_assert(sizeof(AfParam) == 56 && sizeof(AfBlock) == 12, "table layouts are part of the ABI (see _lib.py)");
+    hipStream_t st = (hipStream_t)stream;
+    const AfParam *P = (const AfParam *)param_table;
+    const AfBlock *B = (const AfBlock *)block_table;
+    // scratch: [n_blocks] p^2 partials | [n_blocks] u^2 partials | [n_params][4] scalars | column partials
+    const size_t head = 2 * (size_t)n_blocks + 4 * (size_t)n_params;
+    DA_REQUIRE(scratch_floats >= head, "da_adafactor_step: scratch too small");
+    float *part_p2 = scratch, *part_u2 = scratch + n_blocks, *scal = scratch + 2 * (size_t)n_blocks, *colpart = scratch + head;
+    const float beta = (float)(1.0 - pow((double)step, (double)decay_rate));
+    const float rho = (float)fmin(1e-2, 1.0 / sqrt((double)step));
+    k_af_a<<<n_blocks, 256, 0, st>>>(P, B, flat, flat_grad, state, colpart, part_p2, part_u2, beta, eps1);
+    k_af_b<<<n_params, 256, 0, st>>>(P, state, colpart, part_p2, scal, beta, rho, eps2);
+    k_af_c<<<n_blocks, 256, 0, st>>>(P, B, flat_grad, state, scal, part_u2);
+    k_af_d<<<n_blocks, 256, 0, st>>>(P, B, flat, flat_grad, state, scal, part_u2, clip_threshold);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -17,6 +17,7 @@ Differences from the reference, on purpose:
   many values to unpack``, :504-510 vs :663; tests/golden pins that failure mode).
 """
 import enum
+import os
 import math
 from functools import partial
 from typing import Any
@@ -295,6 +296,14 @@ class GNN_Diffusion(LightningModule):
 
     # ------------------------------------------------------------------ Lightning hooks (callers)
     def configure_optimizers(self):
+        """spatial_diffusion.py:701-705: Adafactor with transformers' defaults.  On a ROCm device, when only
+        the denoiser trains (no piece encoder attached), the same update runs as one library call over the
+        training engine's flat buffers (``FusedAdafactor`` -> da_adafactor_step); set
+        DIFFASSEMBLE_FUSED_OPTIMIZER=0 for transformers' own implementation."""
+        fused = os.environ.get("DIFFASSEMBLE_FUSED_OPTIMIZER", "1") != "0"
+        if fused and self.device.type == "cuda" and getattr(self.model, "visual_backbone", None) is None:
+            from ..train import FusedAdafactor
+            return FusedAdafactor(self.parameters(), self.model.train_engine(self.device))
         from transformers.optimization import Adafactor
         return Adafactor(self.parameters())
 

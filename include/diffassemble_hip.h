@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 2
+#define DA_ABI_VERSION 3
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -248,6 +248,23 @@ int da_train_forward(const da_weights *w, const da_graph *g, const float *x, con
 int da_train_backward(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
                       const int64_t *t, const float *d_out, float *d_feats, void *workspace,
                       size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused Adafactor step over the flat parameter / gradient buffers (one call = one optimizer
+ * step for every listed tensor, 4 launches, deterministic, no host sync).  Replaces, for the
+ * live denoiser parameters, transformers.optimization.Adafactor with the defaults the reference
+ * uses (spatial_diffusion.py:701-705): relative step, scale_parameter, no momentum, no decay.
+ *   param_table  device array of n_params records {int64 off; int32 rows, cols, factored, pad;
+ *                int64 row_off, col_off; int32 blk0, nblk; int64 colpart_off}  (56 bytes)
+ *   block_table  device array of n_blocks records {int32 pid, row0, nrows}       (12 bytes)
+ *   state        second-moment statistics (row/col EMAs of matrices, full EMA of vectors)
+ *   scratch      >= 2*n_blocks + 4*n_params + sum(nblk*cols over matrices) floats
+ *   step         1-based step count; matrices must have cols <= 1280.
+ * ------------------------------------------------------------------------------------- */
+int da_adafactor_step(int n_params, const void *param_table, int n_blocks, const void *block_table,
+                      float *flat, const float *flat_grad, float *state, float *scratch,
+                      size_t scratch_floats, int step, float eps1, float eps2, float clip_threshold,
+                      float decay_rate, void *stream);
 
 #ifdef __cplusplus
 }

@@ -160,7 +160,8 @@ def test_p_losses_gradients_match_reference_fixture(dev, golden, tr):
     assert n >= 28
 
 
-def test_training_step_with_reference_optimizer_then_inference(dev):
+@pytest.mark.parametrize("which", ["reference", "fused"])
+def test_training_step_with_optimizer_then_inference(dev, which):
     """One optimizer step with the reference's optimizer (Adafactor, spatial_diffusion.py:701-705) on the
     flat-buffer parameters lowers the loss of the same batch, and the packed inference engine picks the
     updated weights up."""
@@ -171,7 +172,9 @@ def test_training_step_with_reference_optimizer_then_inference(dev):
                       model_mean_type=ModelMeanType.EPSILON)
     m.model.load_state_dict(case["sd"], strict=False)
     m = m.to(dev).train()
-    opt = m.configure_optimizers()
+    from transformers.optimization import Adafactor
+    opt = Adafactor(m.parameters()) if which == "reference" else m.configure_optimizers()
+    assert type(opt).__name__ == ("Adafactor" if which == "reference" else "FusedAdafactor")
     g = torch.Generator().manual_seed(5)
     noise = torch.randn(case["x"].shape, generator=g).to(dev)
     kw = dict(noise=noise, loss_type="huber", cond=None, edge_index=case["edge_index"].to(dev),
@@ -203,3 +206,31 @@ def test_q_sample_matches_oracle(dev):
     t = torch.randint(0, 100, (50,), generator=g)
     ref = ODF.q_sample(ODF.make_schedule(100), x0, t, noise)
     assert rel(m.q_sample(x0.to(dev), t.to(dev), noise.to(dev)), ref) < 1e-6
+
+
+def test_fused_adafactor_matches_transformers(dev):
+    """da_adafactor_step against transformers.optimization.Adafactor (the reference's optimizer with its
+    defaults) on every live parameter tensor, three steps with fresh random gradients."""
+    import copy
+    from transformers.optimization import Adafactor
+    from diffassemble_amd.train import FusedAdafactor
+    spec = C.by_name("exo144_v4_g1")                    # exophormer: includes the virtual-node embedding
+    case = C.build_case(spec)
+    m = make_module(spec, case, dev)
+    te = m.train_engine()
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in te.params]
+    ref = Adafactor(ref_params)
+    opt = FusedAdafactor(m.parameters(), te)
+    g = torch.Generator(device=dev).manual_seed(7)
+    for step in range(3):
+        for p, gv, rp in zip(te.params, te.grad_views, ref_params):
+            gv.copy_(torch.randn(p.shape, generator=g, device=dev) * (0.1 + step))
+            p.grad = gv
+            rp.grad = gv.clone()
+        opt.step()
+        ref.step()
+        torch.cuda.synchronize()
+        for n, p, rp in zip(te.names, te.params, ref_params):
+            assert rel(p, rp) < 2e-6, (step, n, rel(p, rp))
+    # the step really moved the weights
+    assert rel(te.params[5], case["sd"]["mlp.0.weight"]) > 1e-3
