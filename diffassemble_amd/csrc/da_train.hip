@@ -351,6 +351,20 @@ __global__ __launch_bounds__(256) void k_virt_grad(int rows, int V, int D, const
     grad[idx] += s;
 }
 
+// da_train_dense.hip: complete graphs on the matrix cores (grouped GEMMs, attention matrix kept)
+size_t dense_pair_floats(const da_graph *g, int H);
+int dense_train_prepare(const da_graph *g, int H, long long *poff, int32_t *node_graph, hipStream_t st);
+int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P,
+                         const long long *poff, const int32_t *node_graph, hipStream_t st);
+int dense_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
+                         float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st);
+
+static bool train_dense_disabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_TRAIN_DISABLE_DENSE"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 static unsigned grid_for(size_t n) { const size_t b = (n + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
 // ---------------------------------------------------------------------------------------------
@@ -359,13 +373,18 @@ struct TrainWs {
     float *qkvs[DA_MAX_LAYERS], *o[DA_MAX_LAYERS], *hact[DA_MAX_LAYERS], *stats[DA_MAX_LAYERS];
     float *f1pre, *f1;
     float *dz, *dh0, *dY4, *dxa, *dxb, *Dd, *dm1, *df1, *dcomb, *wt, *partial, *csum, *pa, *p1, *dp1;
+    float *P[DA_MAX_LAYERS], *dP;      // dense path: attention matrices kept per layer, one gradient scratch
+    long long *poff;
+    int32_t *node_graph;
     size_t total;
 };
 
 struct Dims {
-    int nr, n, F, D, hid, H, L, V, c_in, c_out;
+    int nr, n, F, D, hid, H, L, V, c_in, c_out, G;
     int din[DA_MAX_LAYERS], C[DA_MAX_LAYERS], hc[DA_MAX_LAYERS];
     bool gelu_between;
+    bool dense;                // complete graphs: grouped-GEMM attention (da_train_dense.hip)
+    size_t pair_floats;
 };
 
 static int dims_of(const da_weights *w, const da_graph *g, Dims &d) {
@@ -375,6 +394,7 @@ static int dims_of(const da_weights *w, const da_graph *g, Dims &d) {
     d.nr = g->n_real; d.n = g->n_nodes; d.F = w->feat_dim; d.D = w->feat_dim + 64; d.hid = w->hidden; d.H = w->heads;
     d.L = w->n_layers; d.V = w->arch == DA_ARCH_EXOPHORMER ? w->virt_nodes : 0; d.c_in = w->c_in; d.c_out = w->c_out;
     d.gelu_between = w->arch == DA_ARCH_TRANSFORMER;
+    d.G = g->n_graphs;
     DA_REQUIRE(d.D % d.H == 0 && (d.D / d.H) % 8 == 0, "training: D / heads must be a multiple of 8");
     for (int l = 0; l < d.L; ++l) {
         d.din[l] = l == 0 ? d.D : 32 * d.H;
@@ -383,6 +403,8 @@ static int dims_of(const da_weights *w, const da_graph *g, Dims &d) {
     }
     DA_REQUIRE(g->n_real > 0 && g->n_nodes >= g->n_real && g->row_ptr, "training: bad graph");
     DA_REQUIRE(d.V == 0 || g->n_nodes == g->n_real + d.V * g->n_graphs, "training: exophormer expects n_nodes = n_real + V*G");
+    d.dense = !train_dense_disabled() && g->dense != 0 && g->graph_ptr && d.V == 0 && g->max_graph_nodes > 0;
+    d.pair_floats = d.dense ? dense_pair_floats(g, d.H) : 0;
     return 0;
 }
 
@@ -428,6 +450,14 @@ static TrainWs carve_train(const Dims &d, void *base) {
     w.pa = take(nr * 16);
     w.p1 = take(nr * 16);
     w.dp1 = take(nr * 16);
+    for (int l = 0; l < DA_MAX_LAYERS; ++l) w.P[l] = nullptr;
+    w.dP = nullptr; w.poff = nullptr; w.node_graph = nullptr;
+    if (d.dense) {
+        for (int l = 0; l < d.L; ++l) w.P[l] = take(d.pair_floats);
+        w.dP = take(d.pair_floats);
+        w.poff = (long long *)take(2 * ((size_t)d.G + 2));
+        w.node_graph = (int32_t *)take(n);
+    }
     w.total = off;
     return w;
 }
@@ -519,8 +549,12 @@ int da_train_forward(const da_weights *w, const da_graph *g, const float *x, con
         const bool last = l == d.L - 1;
         if ((rc = linear(P, n, d.din[l], 4 * d.hc[l], xin, ldx, w->conv_wq[l], w->conv_bq[l], DA_ACT_NONE, nullptr,
                          ws.qkvs[l], 4 * d.hc[l], st))) return rc;
-        if ((rc = launch_attn_csr(P, n, g->row_ptr, g->col_src, nullptr, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr,
-                                  DA_ACT_NONE, ws.o[l], nullptr, ws.stats[l], st))) return rc;
+        if (d.dense) {
+            if (l == 0 && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
+            if ((rc = dense_train_attn_fwd(g, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr, ws.o[l], ws.P[l], ws.poff,
+                                           ws.node_graph, st))) return rc;
+        } else if ((rc = launch_attn_csr(P, n, g->row_ptr, g->col_src, nullptr, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr,
+                                         DA_ACT_NONE, ws.o[l], nullptr, ws.stats[l], st))) return rc;
         if (!last && d.gelu_between) {
             if ((rc = gelu_fwd((size_t)n * d.hc[l], ws.o[l], ws.hact[l], st))) return rc;
             xin = ws.hact[l];
@@ -542,7 +576,7 @@ int da_train_backward(const da_weights *w, const da_weights *grads, const da_gra
     int rc;
     if ((rc = dims_of(w, g, d))) return rc;
     DA_REQUIRE(grads && x && t && d_out && workspace, "da_train_backward: null argument");
-    DA_REQUIRE(g->out_ptr && g->out_dst, "da_train_backward: the graph needs the by-source CSR (out_ptr / out_dst)");
+    DA_REQUIRE(d.dense || (g->out_ptr && g->out_dst), "da_train_backward: the graph needs the by-source CSR (out_ptr / out_dst)");
     if ((rc = check_fused(w, d, "da_train_backward(weights)"))) return rc;
     if ((rc = check_fused(grads, d, "da_train_backward(grads)"))) return rc;
     TrainWs ws = carve_train(d, workspace);
@@ -566,7 +600,9 @@ int da_train_backward(const da_weights *w, const da_weights *grads, const da_gra
     const float *d_o = ws.dz;
     for (int l = L - 1; l >= 0; --l) {
         const int hc = d.hc[l], din = d.din[l];
-        if ((rc = launch_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.stats[l], ws.Dd, ws.dY4, st))) return rc;
+        if (d.dense) {
+            if ((rc = dense_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.dY4, ws.poff, ws.node_graph, st))) return rc;
+        } else if ((rc = launch_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.stats[l], ws.Dd, ws.dY4, st))) return rc;
         const float *xin = l == 0 ? ws.h0 : (d.gelu_between ? ws.hact[l - 1] : ws.o[l - 1]);
         float *dx = (l & 1) ? ws.dxa : ws.dxb;
         // l == 0: the input is h0, whose gradient also carries the residual branch

@@ -234,3 +234,18 @@ def test_fused_adafactor_matches_transformers(dev):
             assert rel(p, rp) < 2e-6, (step, n, rel(p, rp))
     # the step really moved the weights
     assert rel(te.params[5], case["sd"]["mlp.0.weight"]) > 1e-3
+
+
+def test_csr_training_path_on_complete_graphs_subprocess():
+    """Complete graphs take the grouped-GEMM (MFMA) attention in training; DA_TRAIN_DISABLE_DENSE=1 forces
+    them through the CSR kernels instead -- both must match the oracle (the switch is read once per
+    process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DA_TRAIN_DISABLE_DENSE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
+                        "test_backward_matches_oracle_autograd and (rot144_g2_sharp or k36_noloop_eps or ragged_dense)"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "3 passed" in r.stdout
