@@ -87,7 +87,7 @@ def train_bench(args, world, rank, dev):
 
     def step(timed=False):
         t = torch.randint(0, T_STEPS, (G,), generator=gen, device=dev)[batch]
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad()
         if timed: ev[0].record()
         loss = m.p_losses(x0, t, loss_type="huber", cond=None, edge_index=ei, batch=batch, patch_feats=feats)
         loss.backward()

@@ -30,7 +30,7 @@ struct AfParam {            // one entry per parameter tensor (device table)
     long long colpart_off;  // scratch: [nblk][cols] column partial sums (matrices)
 };
 struct AfBlock { int pid, row0, nrows; };     // matrices: a chunk of rows; vectors: a chunk of `nrows` ELEMENTS from row0
-constexpr int AF_CPT = 5;                     // columns per thread in phase A: matrices up to 1280 columns
+constexpr int AF_CPL = 20;                    // columns per LANE in phase A: matrices up to 1280 columns
 
 __device__ __forceinline__ float block_sum(float v, float *red) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -53,32 +53,35 @@ __global__ __launch_bounds__(256) void k_af_a(const AfParam *__restrict__ P, con
     const float *w = flat + p.off, *g = grad + p.off;
     float sp = 0.f, su = 0.f;
     if (p.factored) {
+        // wave w takes rows row0 + w, row0 + w + 4, ...; lane l the columns l, l + 64, ... : row sums are
+        // wave reductions (no block barrier per row), column sums stay in registers until the end
+        __shared__ float colred[4][64 * AF_CPL];
         float *row = state + p.row_off;
         float *cp = colpart + p.colpart_off + (size_t)(blockIdx.x - p.blk0) * p.cols;
-        float ca[AF_CPT];                       // this thread's columns c = tid + 256 k (cols <= 256 * AF_CPT, host-checked)
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        float ca[AF_CPL];
 #pragma unroll
-        for (int k = 0; k < AF_CPT; ++k) ca[k] = 0.f;
-        for (int r = b.row0; r < b.row0 + b.nrows; ++r) {
+        for (int k = 0; k < AF_CPL; ++k) ca[k] = 0.f;
+        for (int r = b.row0 + wv; r < b.row0 + b.nrows; r += 4) {
             float sr = 0.f;
 #pragma unroll
-            for (int k = 0; k < AF_CPT; ++k) {
-                const int c = threadIdx.x + 256 * k;
+            for (int k = 0; k < AF_CPL; ++k) {
+                const int c = lane + 64 * k;
                 if (c < p.cols) {
-                    const float gv = g[(size_t)r * p.cols + c], wv = w[(size_t)r * p.cols + c];
+                    const float gv = g[(size_t)r * p.cols + c], wv2 = w[(size_t)r * p.cols + c];
                     const float q = fmaf(gv, gv, eps1);
                     sr += q;
                     ca[k] += q;
-                    sp = fmaf(wv, wv, sp);
+                    sp = fmaf(wv2, wv2, sp);
                 }
             }
-            sr = block_sum(sr, red);
-            if (threadIdx.x == 0) row[r] = beta * row[r] + (1.0f - beta) * (sr / (float)p.cols);
+            for (int o = 32; o > 0; o >>= 1) sr += __shfl_xor(sr, o);
+            if (lane == 0) row[r] = beta * row[r] + (1.0f - beta) * (sr / (float)p.cols);
         }
 #pragma unroll
-        for (int k = 0; k < AF_CPT; ++k) {
-            const int c = threadIdx.x + 256 * k;
-            if (c < p.cols) cp[c] = ca[k];
-        }
+        for (int k = 0; k < AF_CPL; ++k) colred[wv][lane + 64 * k] = ca[k];
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.cols; c += 256) cp[c] = (colred[0][c] + colred[1][c]) + (colred[2][c] + colred[3][c]);
     } else {
         float *v = state + p.row_off;
         for (int i = b.row0 + threadIdx.x; i < b.row0 + b.nrows; i += 256) {

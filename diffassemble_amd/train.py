@@ -240,6 +240,19 @@ class FusedAdafactor(torch.optim.Optimizer):
         self.scratch = torch.empty(2 * self.n_blocks + 4 * self.n_params + c_off + 64, dtype=torch.float32, device=dev)
         self.step_count = 0
 
+    def zero_grad(self, set_to_none: bool = True):
+        """One fill of the flat gradient buffer (the views stay attached as ``.grad``) instead of one
+        launch per parameter; parameters outside the engine are handled the usual way."""
+        mine = {id(p) for p in self.engine.params}
+        self.engine.flat_grad.zero_()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if id(p) not in mine and p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.zero_()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
