@@ -67,7 +67,7 @@ namespace da {
 
 struct Workspace {
     char *comb_in, *h, *combined, *qkvs, *xa, *xb, *z, *hh;
-    char *dq, *dk, *dvt, *dskip;      // dense path: head-major Q, K, transposed V, row-major skip
+    char *dq, *dk, *dvt, *dskip;      // dense path: head-major Q, K, V ([H][n_pad][C] each), row-major skip
     size_t dense_off, dense_bytes;    // [dq, dq + dense_bytes) is zero-filled once per Batch
     float *model_out, *xbuf0, *xbuf1;
     size_t total;
@@ -210,7 +210,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
         // last layer: the residual `feats + combined_feats` (efficient_gat.py:144) is fused in the epilogue
         const void *resid = last ? w.combined : nullptr;
         if (!al && w.dq && dense_ok(g, d->heads, c.C)) {
-            // complete graphs: projection scattered into head-major Q/K/V^T, block-diagonal MFMA attention
+            // complete graphs: projection scattered into head-major Q / K / V, block-diagonal MFMA attention
             QkvScatter qs;
             qs.HC = c.hc; qs.C = c.C; qs.n_pad = g->n_pad; qs.row_map = g->row_map;
             qs.Q = w.dq; qs.K = w.dk; qs.Vt = w.dvt; qs.S = w.dskip;

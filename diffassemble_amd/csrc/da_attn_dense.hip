@@ -6,7 +6,7 @@
 //   out[i, h*C:(h+1)*C] = act( sum_j softmax_j(q_i.k_j / sqrt(C)) v_j + skip_i (+ residual_i) )
 //
 // flash-style: the n x n score matrix never exists; per (graph, head, 128-query tile) workgroup the
-// K / V^T tiles stream through LDS and each of the 4 waves owns 32 queries.
+// K / V tiles stream through LDS and each of the 4 waves owns 32 queries.
 //   S^T = K_tile . Q^T      32 keys x 32 queries per MFMA chain; A = K rows from LDS, B = Q rows held
 //                           in registers for the whole kernel.  MFMA row rho of a 32-key block is fed
 //                           key pi(rho) = (rho&3) + 4((rho>>3)&3) + 16((rho>>2)&1), so that with the
@@ -14,16 +14,19 @@
 //                           CONSECUTIVE keys 16*half .. 16*half+15 of query q.
 //   softmax                 running max / sum are lane-local plus one cross-half exchange; the
 //                           accumulator rescale is skipped while the running max grows by < 2^8.
-//   O^T += V^T_tile . P^T   P needs NO data movement to become the B operand; A = V^T rows from LDS
-//                           (V is produced already transposed by the projection GEMM), one 16-byte
-//                           read per MFMA thanks to the key permutation above.
+//   O^T += V^T_tile . P^T   P needs NO data movement to become the B operand.  The A operand wants 8
+//                           consecutive KEYS of one channel per lane, while V lies row-major ([key][C],
+//                           the layout the projection GEMM can write with full cache lines): the
+//                           transposition happens on the LDS read, ds_read_b64_tr_b16 (bf16), two per
+//                           MFMA, fetched two channel blocks ahead of their MFMAs (a wave may only have
+//                           15 LDS operations in flight).
 // bf16: v_mfma_f32_32x32x16_bf16; fp32 parity mode: v_mfma_f32_32x32x2_f32 (exact fp32).
-// LDS rows are padded to an odd number of 16-byte slots (K: C*es + 16, V^T: 128 + 16), which makes
-// every ds_read_b128 fragment read conflict free.  Global -> LDS is LDS-DMA (global_load_lds_dwordx4):
-// the padded image is produced by per-lane SOURCE addresses (pad slots re-load a dummy piece), two
-// stages, tile t+1 in flight under the MFMAs of tile t, one barrier per tile.
-// Workgroup ids are remapped so that the query tiles of one (graph, head) run back to back on ONE
-// XCD and share its L2 copy of K / V^T.
+// LDS rows are padded: K to an odd number of 16-byte slots (conflict-free ds_read_b128), V to a stride of
+// 64 (mod 256) bytes (the 16-lane groups of a transposing read tile the 64 banks exactly).  Global -> LDS
+// is LDS-DMA (global_load_lds_dwordx4): the padded image is produced by per-lane SOURCE addresses (pad
+// slots re-load a dummy piece), two stages, tile t+1 in flight under the MFMAs of tile t, one barrier per
+// tile.  Workgroup ids are remapped so that the query tiles of one (graph, head) run back to back on ONE
+// XCD and share its L2 copy of K / V.
 #include <stdlib.h>
 
 #include "da_common.h"
@@ -48,7 +51,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct AttnDenseParams {
-    const void *Q, *K, *Vt, *S;     // [H][n_pad][C], [H][n_pad][C], [H][C][n_pad], [N][H*C]
+    const void *Q, *K, *Vt, *S;     // [H][n_pad][C] each (Vt holds V ROW-major since the tr_b16 rewrite), [N][H*C]
     const void *res;                // [N][H*C] or null
     void *out;                      // [N][H*C]
     const int32_t *graph_ptr, *pad_ptr;
@@ -65,12 +68,17 @@ template <typename T, int C> struct Cfg {
     static constexpr int RS = ROWB + (((ROWB / 16) & 1) ? 0 : 16);   // odd number of 16-B slots
     static constexpr int KSPR = RS / 16;                      // LDS slots per K row
     static constexpr int KVALID = ROWB / 16;                  // of which carry data
-    static constexpr int BKEYS = ES == 2 ? 64 : 32;           // keys per LDS tile (128 B of a V^T row)
+    static constexpr int BKEYS = ES == 2 ? 64 : 32;           // keys per LDS tile
     static constexpr int KB = BKEYS / 32;
-    static constexpr int RSV = 144;                           // V^T row: 128 B data + 16 B pad (9 slots)
+    // V rows (row-major, like K).  bf16: the PV operand is fetched with ds_read_b64_tr_b16, whose 16-lane
+    // groups read [4 keys][16 channels] blocks; two groups share an LDS cycle, and their 8 x 32-byte
+    // pieces tile all 64 banks exactly when the row stride is 64 (mod 256) bytes.  fp32: scalar reads,
+    // the two 32-lane halves sit 16 rows apart -> stride 32 (mod 64) bytes keeps them on disjoint banks.
+    static constexpr int RSV = ES == 2 ? ((ROWB - 64 + 255) / 256 * 256 + 64) : ((ROWB - 32 + 63) / 64 * 64 + 32);
+    static constexpr int VSPR = RSV / 16;
     static constexpr int NCB = (C + 31) / 32;
     static constexpr int NIK = (BKEYS * KSPR + 63) / 64;      // DMA instructions (1 KB each) per tile
-    static constexpr int NIV = (C * 9 + 63) / 64;
+    static constexpr int NIV = (BKEYS * VSPR + 63) / 64;
     static constexpr int NI = NIK + NIV;
     static constexpr int MAXI = (NI + 3) / 4;                 // per wave
     static constexpr int KBYTES = NIK * 1024, VBYTES = NIV * 1024, STAGE = KBYTES + VBYTES;
@@ -90,25 +98,27 @@ __device__ __forceinline__ f32x16 mma_chunk(float, const u32x4 &a, const u32x4 &
     return c;
 }
 
-// ---- O^T[cb] += V^T rows . P^T for one 32-key block; p[16] = this lane's probabilities for keys
-// 16*half + 0..15 of the block.  vrow points at the V^T row of this lane, key 0 of the block.
-__device__ __forceinline__ f32x16 mma_pv(bf16_t, const unsigned char *vrow, int half, const float (&p)[16], f32x16 o) {
-#pragma unroll
-    for (int mm = 0; mm < 2; ++mm) {
-        const u32x4 vf = *(const u32x4 *)(vrow + (16 * half + 8 * mm) * 2);
-        bf16x8 pf;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pf[e] = (__bf16)p[8 * mm + e];
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o, 0, 0, 0);
-    }
-    return o;
+// ---- PV operand fetch.  bf16: two transposing reads give this lane 8 consecutive keys of ONE channel
+// (the A operand of v_mfma_f32_32x32x16_bf16) out of the row-major [key][channel] tile: lane i' of a
+// 16-lane group supplies the address of key (i' >> 2), channels 4 (i' & 3)..+3, and receives channel i'
+// of keys 0..3 (measured with tools/tr_probe.hip).
+// Issued as inline asm: hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of the builtin form, i.e.
+// it waits for the LDS-DMA of the NEXT tile (just issued) before every V fetch and serialises the
+// pipeline.  The asm form is invisible to that pass, so the result must be fenced by hand: tr_fence()
+// (s_waitcnt lgkmcnt(0) carrying the fragment registers as operands) before the first MFMA that uses it.
+__device__ __forceinline__ u32x2 tr_read(unsigned lds_byte_addr, int imm) {      // imm folds to a constant after unrolling
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(imm));
+    return r;
 }
-__device__ __forceinline__ f32x16 mma_pv(float, const unsigned char *vrow, int half, const float (&p)[16], f32x16 o) {
+// fp32: O^T[cb] += V rows . P^T for one 32-key block with exact-fp32 MFMAs; vcol points at key 0 of the
+// block, this lane's channel; p[16] = this lane's probabilities for keys 16*half + 0..15.
+template <int RSV>
+__device__ __forceinline__ f32x16 mma_pv_f32(const unsigned char *vcol, int half, const float (&p)[16], f32x16 o) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const f32x4 v4 = *(const f32x4 *)(vrow + (16 * half + 4 * jj) * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[e], p[4 * jj + e], o, 0, 0, 0);
+    for (int e = 0; e < 16; ++e) {
+        const float v = *(const float *)(vcol + (16 * half + e) * RSV);
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(v, p[e], o, 0, 0, 0);
     }
     return o;
 }
@@ -151,7 +161,7 @@ __device__ __forceinline__ void stc(bf16_t *d, const float (&v)[8]) {
 template <typename T, int C>
 __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     using CF = Cfg<T, C>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 stages x (K | V^T)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 stages x (K | V)
 
     // XCD-aware remap: hardware places workgroup b on XCD b % 8; give XCD x head x of every graph and
     // walk the query tiles of one (graph, head) consecutively.
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
 
     // ---- LDS-DMA plan: instruction q (1 KB) of a tile is issued by wave q % 4; lane -> slot q*64+lane
     const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
-    const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * C * np + pad0) * CF::ES;
+    const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWB;
     unsigned soff[CF::MAXI];
 #pragma unroll
     for (int x = 0; x < CF::MAXI; ++x) {
@@ -195,15 +205,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             const int s = q * 64 + lane, row = s / CF::KSPR, col = s - row * CF::KSPR;
             if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
         } else {
-            const int s = (q - CF::NIK) * 64 + lane, row = s / 9, col = s - row * 9;
-            if (row < C && col < 8) o = (unsigned)(((size_t)row * np) * CF::ES + col * 16);
+            const int s = (q - CF::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
+            if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
         }
         soff[x] = o;
     }
     auto issue = [&](int kt, int stage) {
         unsigned char *sb = smem + stage * CF::STAGE;
         const unsigned char *kb_ = Kg + (size_t)kt * CF::BKEYS * CF::ROWB;
-        const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ES;
+        const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ROWB;
 #pragma unroll
         for (int x = 0; x < CF::MAXI; ++x) {
             const int q = wid + 4 * x;
@@ -221,9 +231,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);     // key fed to MFMA row i
     // LDS byte offsets of this lane's fragments inside a stage (constant over the whole kernel)
     const int koff = pi_i * CF::RS + half * 16;
-    int voff[CF::NCB];
-#pragma unroll
-    for (int cb = 0; cb < CF::NCB; ++cb) voff[cb] = CF::KBYTES + min(cb * 32 + i, C - 1) * CF::RSV + 16 * half * CF::ES;
+    // V fragment base inside a stage.  bf16 (transposing reads): key 16*half + (li >> 2), channel
+    // 16*((lane >> 4) & 1) + 4*(li & 3) with li = lane & 15; fp32: key 0, channel i.
+    const int li = lane & 15;
+    const int vbase = CF::ES == 2 ? CF::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2
+                                  : CF::KBYTES + i * 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     DA_ATTN_DBG(unsigned long long c_bar = 0, c_iss = 0, c_qk = 0, c_sm = 0, c_pv = 0;)
     DA_TICK(t_start);
     issue(0, 0);
@@ -258,13 +271,20 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             }
             DA_ATTN_DBG(asm volatile("" :: "v"(s[0]), "v"(s[15]));)
             DA_TICK(t3_);
-            // V^T fragments: issued behind the QK^T chain, they land under the softmax
-            u32x4 vf[CF::ES == 2 ? CF::NCB : 1][2];
+            // V fragments of the first channel blocks: issued behind the QK^T chain, they land under the softmax
+            u32x2 vlo[CF::ES == 2 ? CF::NCB : 1][2], vhi[CF::ES == 2 ? CF::NCB : 1][2];
+            const unsigned vb = lds0 + (unsigned)((kt & 1) * CF::STAGE + vbase + kb * 32 * CF::RSV);
             if (CF::ES == 2) {
+                // only the first two channel blocks now; the rest are fetched two blocks ahead inside the PV
+                // loop: a wave may have 15 LDS operations in flight (lgkmcnt is 4 bits) and the 9 K reads +
+                // 20 V reads of a C = 144 block stalled the issue stream when they were all queued here
 #pragma unroll
-                for (int cb = 0; cb < CF::NCB; ++cb) {
-                    vf[cb][0] = *(const u32x4 *)(stg + voff[cb] + kb * 64);
-                    vf[cb][1] = *(const u32x4 *)(stg + voff[cb] + kb * 64 + 16);
+                for (int cb = 0; cb < (CF::NCB < 2 ? CF::NCB : 2); ++cb) {
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) {
+                        vlo[cb][mm] = tr_read(vb, cb * 64 + (8 * mm) * CF::RSV);
+                        vhi[cb][mm] = tr_read(vb, cb * 64 + (8 * mm + 4) * CF::RSV);
+                    }
                 }
             }
             // this lane now holds keys key0 + 16*half + r, r = 0..15, of query qidx.
@@ -315,13 +335,30 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                     for (int e = 0; e < 8; ++e) { pf0[e] = (__bf16)pr[e]; pf1[e] = (__bf16)pr[8 + e]; }
 #pragma unroll
                     for (int cb = 0; cb < CF::NCB; ++cb) {
-                        O[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[cb][0]), pf0, O[cb], 0, 0, 0);
-                        O[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[cb][1]), pf1, O[cb], 0, 0, 0);
+                        if (cb + 2 < CF::NCB) {
+#pragma unroll
+                            for (int mm = 0; mm < 2; ++mm) {
+                                vlo[cb + 2][mm] = tr_read(vb, (cb + 2) * 64 + (8 * mm) * CF::RSV);
+                                vhi[cb + 2][mm] = tr_read(vb, (cb + 2) * 64 + (8 * mm + 4) * CF::RSV);
+                            }
+                        }
+                        // fence of the asm reads of block cb: LDS returns in order, so "at most N newer
+                        // operations outstanding" (N = 4 reads per block still in flight behind it) is enough
+                        if (cb + 2 < CF::NCB)
+                            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vlo[cb][0]), "+v"(vhi[cb][0]), "+v"(vlo[cb][1]), "+v"(vhi[cb][1]));
+                        else if (cb + 1 < CF::NCB)
+                            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vlo[cb][0]), "+v"(vhi[cb][0]), "+v"(vlo[cb][1]), "+v"(vhi[cb][1]));
+                        else
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[cb][0]), "+v"(vhi[cb][0]), "+v"(vlo[cb][1]), "+v"(vhi[cb][1]));
+                        const u32x4 v0 = {vlo[cb][0][0], vlo[cb][0][1], vhi[cb][0][0], vhi[cb][0][1]};
+                        const u32x4 v1 = {vlo[cb][1][0], vlo[cb][1][1], vhi[cb][1][0], vhi[cb][1][1]};
+                        O[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O[cb], 0, 0, 0);
+                        O[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O[cb], 0, 0, 0);
                     }
                 } else {
 #pragma unroll
                     for (int cb = 0; cb < CF::NCB; ++cb)
-                        O[cb] = mma_pv(T(), stg + voff[cb] - 16 * half * CF::ES + kb * 32 * CF::ES, half, pr, O[cb]);
+                        O[cb] = mma_pv_f32<CF::RSV>(stg + vbase + cb * 128 + kb * 32 * CF::RSV, half, pr, O[cb]);
                 }
             }
             DA_ATTN_DBG(asm volatile("" :: "v"(O[0][0]), "v"(O[CF::NCB - 1][15]));)

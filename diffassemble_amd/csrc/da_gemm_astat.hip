@@ -33,13 +33,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // the rows of an A-stationary workgroup never change, and a row_map load inside the epilogue is a
 // dependent global load in front of every store (measured +60 % on the conv-3 projection).
 struct AstatSlots {
-    int q[2][2];        // Q/K tiles: slot of row wm*32 + mi*16 + ((lane + 64 k) >> 3)
-    int v0[2], v1[2];   // V tiles: slots of the first / last node of chunk id = lane + 64 k
+    int q[2][2];        // Q/K/V tiles: slot of row wm*32 + mi*16 + ((lane + 64 k) >> 3)
 };
 
 template <typename T>
 __device__ __forceinline__ AstatSlots astat_load_slots(const GemmParams &p, int row0, int wm, int lane) {
-    constexpr int ES = (int)sizeof(T), EPC = 16 / ES, NCHK = 32 * ES / 16;
     AstatSlots rs;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -48,109 +46,61 @@ __device__ __forceinline__ AstatSlots astat_load_slots(const GemmParams &p, int 
             const int m = row0 + wm * 32 + mi * 16 + ((lane + 64 * k) >> 3);
             rs.q[mi][k] = (p.qkv && m < p.M) ? p.row_map[m] : 0;
         }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int id = lane + 64 * k, ch = id % NCHK, m = row0 + wm * 32 + ch * EPC;
-        rs.v0[k] = (p.qkv && m < p.M) ? p.row_map[m] : 0;
-        rs.v1[k] = (p.qkv && m + EPC - 1 < p.M) ? p.row_map[m + EPC - 1] : -1;
-    }
     return rs;
 }
 
-template <typename T, bool VORIENT, int ACT>
+template <typename T, int ACT>
 __device__ __forceinline__ void astat_epilogue(const GemmParams &p, const f32x4 (&acc)[2][4], const float (&bz)[4][4],
                                                unsigned char *stg, const AstatSlots &rs, int row0, int col0,
                                                int which, int wm, int wn, int lane) {
     constexpr int ES = (int)sizeof(T), EPC = 16 / ES;
-        if (!VORIENT) {
-            // strip = 16 nodes x 128 bytes of features; fp32 needs two passes over the wave's 64 columns
-            constexpr int CPP = 128 / ES;                          // columns per pass: 64 (bf16) / 32 (fp32)
+    // strip = 16 nodes x 128 bytes of features; fp32 needs two passes over the wave's 64 columns
+    constexpr int CPP = 128 / ES;                          // columns per pass: 64 (bf16) / 32 (fp32)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-                for (int ps = 0; ps < 64 / CPP; ++ps) {
+        for (int ps = 0; ps < 64 / CPP; ++ps) {
 #pragma unroll
-                    for (int nj = 0; nj < CPP / 16; ++nj) {
-                        const int ni = ps * (CPP / 16) + nj;
-                        float v[4];
+            for (int nj = 0; nj < CPP / 16; ++nj) {
+                const int ni = ps * (CPP / 16) + nj;
+                float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
-                        if (p.res) {
-                            const int m = row0 + wm * 32 + mi * 16 + (lane & 15);
-                            const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
-                            if (m < p.M && f0 + 3 < p.Nout) {
-                                float rr[4];
-                                load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
+                if (p.res) {
+                    const int m = row0 + wm * 32 + mi * 16 + (lane & 15);
+                    const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                    if (m < p.M && f0 + 3 < p.Nout) {
+                        float rr[4];
+                        load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                            }
-                        }
-                        store4((T *)(stg + (lane & 15) * 144) + nj * 16 + (lane >> 4) * 4, v);
-                    }
-                    // 16 rows x 8 chunks of 16 bytes: two chunks per lane, 128 contiguous bytes per row
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int id = lane + 64 * k, row = id >> 3, ch = id & 7;
-                        const u32x4 val = *(const u32x4 *)(stg + row * 144 + ch * 16);
-                        const int m = row0 + wm * 32 + mi * 16 + row;
-                        const int col = col0 + wn * 64 + ps * CPP + ch * EPC;
-                        if (m >= p.M || col >= p.Nout) continue;
-                        if (p.qkv && (p.debug & (which == 3 ? 64 : 32))) continue;
-                        T *dst;
-                        if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
-                        else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
-                        else {
-                            const int f = col - which * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
-                            dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + rs.q[mi][k]) * p.C + c;
-                        }
-                        *(u32x4 *)dst = val;
+                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
                     }
                 }
+                store4((T *)(stg + (lane & 15) * 144) + nj * 16 + (lane >> 4) * 4, v);
             }
-        } else {
-            // V columns: lane owns one feature and 4 consecutive nodes; strip = 16 features x 32 nodes
-            constexpr int RB = 32 * ES;                            // bytes of one strip row (64 / 128)
-            constexpr int NCHK = RB / 16;                          // 16-byte chunks per row (4 / 8)
+            // 16 rows x 8 chunks of 16 bytes: two chunks per lane, 128 contiguous bytes per row
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + bz[ni][0];
-                    store4((T *)(stg + (lane & 15) * 144) + mi * 16 + (lane >> 4) * 4, v);
+            for (int k = 0; k < 2; ++k) {
+                const int id = lane + 64 * k, row = id >> 3, ch = id & 7;
+                const u32x4 val = *(const u32x4 *)(stg + row * 144 + ch * 16);
+                const int m = row0 + wm * 32 + mi * 16 + row;
+                const int col = col0 + wn * 64 + ps * CPP + ch * EPC;
+                if (m >= p.M || col >= p.Nout) continue;
+                if (p.qkv && (p.debug & (which == 3 ? 64 : 32))) continue;
+                T *dst;
+                if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
+                else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
+                else {
+                    const int f = col - which * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
+                    dst = (T *)(which == 0 ? p.Q : (which == 1 ? p.Kb : p.Vt)) + ((size_t)h * p.n_pad + rs.q[mi][k]) * p.C + c;
                 }
-#pragma unroll
-                for (int k = 0; k < (16 * NCHK + 63) / 64; ++k) {
-                    const int id = lane + 64 * k;
-                    if (id >= 16 * NCHK) continue;
-                    const int row = id / NCHK, ch = id - row * NCHK;
-                    const u32x4 val = *(const u32x4 *)(stg + row * 144 + ch * 16);
-                    const int fcol = col0 + wn * 64 + ni * 16 + row, m = row0 + wm * 32 + ch * EPC;
-                    if (fcol >= p.Nout || m >= p.M) continue;
-                    const int f = fcol - 2 * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
-                    T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * (p.n_pad + ((p.debug & 16) ? 64 : 0));
-                    if (p.debug & 8) continue;
-                    const int p0 = rs.v0[k];
-                    const bool run = m + EPC - 1 < p.M && rs.v1[k] == p0 + EPC - 1;
-                    if (run && (p0 & (EPC - 1)) == 0) {
-                        *(u32x4 *)(vrow + p0) = val;
-                    } else if (run && ES == 2 && (p0 & 3) == 0) {
-                        *(u32x2 *)(vrow + p0) = (u32x2){val[0], val[1]};
-                        *(u32x2 *)(vrow + p0 + 4) = (u32x2){val[2], val[3]};
-                    } else {
-                        const u32x4 vv = val;
-                        const T *e = (const T *)&vv;
-#pragma unroll
-                        for (int r = 0; r < EPC; ++r)
-                            if (m + r < p.M) vrow[p.row_map[m + r]] = e[r];
-                    }
-                }
+                *(u32x4 *)dst = val;
             }
         }
+    }
 }
 
-template <typename T, bool VORIENT, int ACT>
+template <typename T, int ACT>
 __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ES = (int)sizeof(T), EPC = 16 / ES, BK = 128 / ES;
@@ -164,8 +114,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
     const int row0 = blockIdx.y * 128;
     const AstatSlots rs = astat_load_slots<T>(p, row0, wm, lane);
     const int t_beg = blockIdx.x * p.nt, t_end = min(t_beg + p.nt, p.nct);
-    const int per = p.qkv ? p.HC / 128 : 0;
-    auto colblock = [&](int t) { return !p.qkv ? t : (VORIENT ? t + 2 * per : (t < 2 * per ? t : t + per)); };
+    auto colblock = [&](int t) { return t; };
     const int S = (t_end - t_beg) * nk;                          // W stages of this workgroup
     if (S <= 0) return;
 
@@ -208,15 +157,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
         const int col0 = colblock(t_beg + ti) * 128;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            if (!VORIENT) {
-                const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
-                if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
-                else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
-            } else {
-                const int fcol = col0 + wn * 64 + ni * 16 + (lane & 15);
-                bz[ni][0] = (p.bias && fcol < p.Nout) ? p.bias[fcol] : 0.f;
-                bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f;
-            }
+            const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+            if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
+            else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
         }
     };
     float bz[4][4], bzn[4][4];
@@ -266,14 +209,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
-                        acc[mi][ni] = VORIENT ? Mma16<T>::run(fa[mi], fw[ni], acc[mi][ni])
-                                              : Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);
+                        acc[mi][ni] = Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);
             }
             DA_PROBE(asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][3])); { DA_TICK(t_c); c_wait += t_b - t_a; c_mma += t_c - t_b; })
         }
         DA_TICK(t_e0);
 
-        astat_epilogue<T, VORIENT, ACT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane);
+        astat_epilogue<T, ACT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane);
 #pragma unroll
         for (int a_ = 0; a_ < 4; ++a_)
 #pragma unroll
@@ -334,18 +276,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat_rs(GemmParams p) {
     for (int u = 0; u < TA; ++u) wload(u, wr[u]);
     auto load_bias = [&](int ti, float (&bz)[4][4]) {
         const int col0 = colblock(t_beg + min(ti, ntile - 1)) * 128;
-        const bool vt = QKV && col0 / p.HC == 2;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            if (!vt) {
-                const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
-                if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
-                else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
-            } else {
-                const int fcol = col0 + wn * 64 + ni * 16 + (lane & 15);
-                bz[ni][0] = (p.bias && fcol < p.Nout) ? p.bias[fcol] : 0.f;
-                bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f;
-            }
+            const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+            if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
+            else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
         }
     };
     // stage 0 of tile 0 into slot 0
@@ -359,7 +294,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat_rs(GemmParams p) {
             if (ti >= ntile) break;
             const int col0 = colblock(t_beg + ti) * 128;
             const int which = QKV ? col0 / p.HC : 0;
-            const bool vtile = QKV && which == 2;            // V columns: transposed store, swapped MFMA operands
             float bz[4][4];
             load_bias(ti, bz);
             f32x4 acc[2][4];
@@ -395,21 +329,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat_rs(GemmParams p) {
                         const int R = wn * 64 + t * 16 + (lane & 15);
                         fw[t] = *(const u32x4 *)(w + R * 128 + ((cc ^ (R & 7)) << 4));
                     }
-                    if (vtile) {
 #pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Mma16<T>::run(fa[mi], fw[ni], acc[mi][ni]);
-                    } else {
-#pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);
-                    }
+                        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);
                 }
             }
-            if (vtile) astat_epilogue<T, true, DA_ACT_NONE>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane);
-            else astat_epilogue<T, false, ACT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane);
+            astat_epilogue<T, ACT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane);
         }
     }
 }
@@ -450,11 +376,11 @@ int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int 
         if (rs && nk == 2) { DA_ASTAT_RS(TT, false, AC, 2, GRID); break; }                                 \
         static bool attr = false;                                                                          \
         if (!attr) {                                                                                       \
-            DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_astat<TT, VO, AC>,                       \
+            DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_astat<TT, AC>,                       \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384 + 65536 + 8 * 2304)); \
             attr = true;                                                                                   \
         }                                                                                                  \
-        k_gemm_astat<TT, VO, AC><<<GRID, 512, lds, st>>>(p);                                               \
+        k_gemm_astat<TT, AC><<<GRID, 512, lds, st>>>(p);                                               \
     } while (0)
 #define DA_ASTAT_ACT(TT, GRID)                                                \
     do {                                                                       \
@@ -471,13 +397,7 @@ int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int 
         if (prec == DA_PREC_BF16) { if (nk == 4) DA_ASTAT_RS(bf16_t, true, DA_ACT_NONE, 4, g); else DA_ASTAT_RS(bf16_t, true, DA_ACT_NONE, 2, g); }
         else { if (nk == 4) DA_ASTAT_RS(float, true, DA_ACT_NONE, 4, g); else DA_ASTAT_RS(float, true, DA_ACT_NONE, 2, g); }
     } else {
-        const int per = qs->HC / 128;
-        const dim3 g1 = plan(3 * per);
-        if (prec == DA_PREC_BF16) DA_ASTAT_LAUNCH(bf16_t, false, DA_ACT_NONE, g1);
-        else DA_ASTAT_LAUNCH(float, false, DA_ACT_NONE, g1);
-        const dim3 g2 = plan(per);
-        if (prec == DA_PREC_BF16) DA_ASTAT_LAUNCH(bf16_t, true, DA_ACT_NONE, g2);
-        else DA_ASTAT_LAUNCH(float, true, DA_ACT_NONE, g2);
+        return -1;             // QKV scatter is only built into the register-staged kernel; the caller falls back
     }
 #undef DA_ASTAT_ACT
 #undef DA_ASTAT_LAUNCH

@@ -17,17 +17,18 @@
 // consecutive output features: bias/activation are applied in registers, the tile is staged through
 // LDS and leaves as coalesced 16-byte stores of whole rows.  In QKV mode (dense block-diagonal attention) the fused
 // projection is scattered straight into the layouts the attention kernel consumes:
-//   Q, K  -> [H][n_pad][C]     head-major, rows at the graph's padded offset (row_map)
-//   V     -> [H][C][n_pad]     TRANSPOSED (blocks of V columns issue (A) x (W) so a lane owns four
-//                              consecutive nodes of one feature)
-//   skip  -> [M][H*C]          row-major
+//   Q, K, V -> [H][n_pad][C]   head-major, rows at the graph's padded offset (row_map)
+//   skip    -> [M][H*C]        row-major
+// (V used to leave TRANSPOSED for the attention's PV operand; its 64..256-byte runs at unaligned offsets
+// were partial-line writes that cost ~90 us per step -- the attention now transposes on the LDS read
+// side with ds_read_b64_tr_b16 instead.)
 #include <stdlib.h>
 
 #include "da_gemm_common.h"
 
 namespace da {
 
-template <typename T, bool VORIENT>
+template <typename T>
 __device__ __forceinline__ void mma_block(const unsigned char *sA, const unsigned char *sW, int wm, int wn, int lane,
                                           f32x4 (&acc)[4][4]) {
 #pragma unroll
@@ -45,8 +46,7 @@ __device__ __forceinline__ void mma_block(const unsigned char *sA, const unsigne
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = VORIENT ? Mma16<T>::run(fa[mi], fw[ni], acc[mi][ni])     // D[node][feature]
-                                      : Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);    // D[feature][node]
+                acc[mi][ni] = Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);    // a lane owns one row, 4 consecutive features
     }
 }
 
@@ -55,11 +55,10 @@ __device__ __forceinline__ void mma_block(const unsigned char *sA, const unsigne
 // dependent global load on the critical path of every tile (measured: +60 % on the conv-3 projection).
 template <int PASSES, int NIT>
 struct RowSlots {
-    int q[PASSES][NIT];     // Q/K tiles: slot of row (tid + 256 it) / CPR + pass * ROWS
-    int v0, v1;             // V tiles: slots of the first / last node of this thread's 16-byte chunk
+    int q[PASSES][NIT];     // Q/K/V tiles: slot of row (tid + 256 it) / CPR + pass * ROWS
 };
 
-template <typename T, bool VORIENT, int ACT, int PASSES, int NIT>
+template <typename T, int ACT, int PASSES, int NIT>
 __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (&acc)[4][4], const float (&bz)[4][4],
                                               unsigned char *stg, const RowSlots<PASSES, NIT> &rs, int row0, int col0,
                                               int which, int wm, int wn, int lane, int tid) {
@@ -68,7 +67,6 @@ __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (
     constexpr int ROWS = ES == 4 ? 32 : 64;                     // staged rows per pass (fits one ring slot)
     constexpr int CPR = 128 * ES / 16;                          // 16-byte chunks per staged row
     static_assert(ROWS * RSO <= 32768 && PASSES == 128 / ROWS && NIT == ROWS * CPR / 256, "epilogue staging");
-    const int wrow = VORIENT ? wn : wm;                         // wave coordinate along the staged ROWS
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         dma_barrier();                                        // slot free / previous pass read out
@@ -76,30 +74,22 @@ __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (
         for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                const int rg = wrow * 64 + (VORIENT ? ni : mi) * 16 + (lane & 15);   // row of the 128 x 128 image
+                const int rg = wm * 64 + mi * 16 + (lane & 15);  // row of the 128 x 128 image
                 if (rg / ROWS != pass) continue;                // wave-uniform (16-row groups never straddle)
                 float v[4];
-                int cl;
-                if (!VORIENT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
-                    if (p.res) {
-                        const int m = row0 + wm * 64 + mi * 16 + (lane & 15);
-                        const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
-                        if (m < p.M && f0 + 3 < p.Nout) {
-                            float rr[4];
-                            load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
+                if (p.res) {
+                    const int m = row0 + wm * 64 + mi * 16 + (lane & 15);
+                    const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                    if (m < p.M && f0 + 3 < p.Nout) {
+                        float rr[4];
+                        load4((const T *)p.res + (size_t)m * p.ldo + f0, rr);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                        }
+                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
                     }
-                    cl = wn * 64 + ni * 16 + (lane >> 4) * 4;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + bz[ni][0];
-                    cl = wm * 64 + mi * 16 + (lane >> 4) * 4;
                 }
-                store4((T *)(stg + (rg % ROWS) * RSO) + cl, v);
+                store4((T *)(stg + (rg % ROWS) * RSO) + wn * 64 + ni * 16 + (lane >> 4) * 4, v);
             }
         }
         dma_barrier();
@@ -113,39 +103,16 @@ __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
-            const int grow = row + pass * ROWS;                 // row of the 128 x 128 staged image
-            if (!VORIENT) {
-                const int m = row0 + grow, col = col0 + ch * EPC;
-                if (m >= p.M || col >= p.Nout) continue;
-                T *dst;
-                if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
-                else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
-                else {
-                    const int f = col - which * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
-                    dst = (T *)(which == 0 ? p.Q : p.Kb) + ((size_t)h * p.n_pad + rs.q[pass][it]) * p.C + c;
-                }
-                *(u32x4 *)dst = val[it];
-            } else {
-                const int fcol = col0 + grow, m = row0 + ch * EPC;
-                if (fcol >= p.Nout || m >= p.M) continue;
-                const int f = fcol - 2 * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
-                T *vrow = (T *)p.Vt + ((size_t)h * p.C + c) * p.n_pad;
-                const int p0 = rs.v0;
-                const bool run = m + EPC - 1 < p.M && rs.v1 == p0 + EPC - 1;             // 8 (4) consecutive rows
-                if (run && (p0 & (EPC - 1)) == 0) {
-                    *(u32x4 *)(vrow + p0) = val[it];
-                } else if (run && ES == 2 && (p0 & 3) == 0) {   // graph slot offset = 4 mod 8: two 8-byte stores
-                    const u32x4 vv = val[it];
-                    *(u32x2 *)(vrow + p0) = (u32x2){vv[0], vv[1]};
-                    *(u32x2 *)(vrow + p0 + 4) = (u32x2){vv[2], vv[3]};
-                } else {                                        // chunk straddles a graph boundary / ragged
-                    const u32x4 vv = val[it];
-                    const T *e = (const T *)&vv;
-#pragma unroll
-                    for (int r = 0; r < EPC; ++r)
-                        if (m + r < p.M) vrow[p.row_map[m + r]] = e[r];
-                }
+            const int m = row0 + row + pass * ROWS, col = col0 + ch * EPC;
+            if (m >= p.M || col >= p.Nout) continue;
+            T *dst;
+            if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
+            else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
+            else {
+                const int f = col - which * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
+                dst = (T *)(which == 0 ? p.Q : (which == 1 ? p.Kb : p.Vt)) + ((size_t)h * p.n_pad + rs.q[pass][it]) * p.C + c;
             }
+            *(u32x4 *)dst = val[it];
         }
     }
 }
@@ -156,8 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     // workgroup owns one 128-row tile of A and walks `nt` consecutive 128-column tiles of W as ONE
     // continuous stream of K stages, so the DMA of the next column tile's first stage is already in
     // flight while the current tile's epilogue runs (the epilogue stages through the ring slot that
-    // was consumed last).  In QKV mode the walk covers Q | K | V | skip column blocks in one launch; the
-    // V blocks swap the MFMA operands and take the transposed epilogue (wave-uniform branch per tile).
+    // was consumed last).  In QKV mode the walk covers Q | K | V | skip column blocks in one launch.
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 128 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,7 +173,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     if (S > 0 && !(p.debug & 4)) issue(0);
 
     RowSlots<PASSES, NIT> rs;
-    rs.v0 = rs.v1 = 0;
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass)
 #pragma unroll
@@ -220,29 +185,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
                 const int m = row0 + (tid + it * 256) / CPR + pass * ROWS;
                 if (m < p.M) rs.q[pass][it] = p.row_map[m];
             }
-        const int mv = row0 + (tid % CPR) * EPC;              // (tid + 256 it) % CPR does not depend on it
-        if (mv < p.M) rs.v0 = p.row_map[mv];
-        if (mv + EPC - 1 < p.M) rs.v1 = p.row_map[mv + EPC - 1];
     }
 
     for (int ti = 0; ti < t_end - t_beg; ++ti) {
         const int col0 = (t_beg + ti) * 128;
         const int which = QKV ? col0 / p.HC : 0;
-        const bool vtile = QKV && which == 2;
         // bias of this lane's output features, fetched under the MFMAs (the epilogue wants them in
         // registers: dependent scalar loads there cost microseconds per tile)
         float bz[4][4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            if (!vtile) {
-                const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
-                if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
-                else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
-            } else {
-                const int fcol = col0 + wn * 64 + ni * 16 + (lane & 15);
-                bz[ni][0] = (p.bias && fcol < p.Nout) ? p.bias[fcol] : 0.f;
-                bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f;
-            }
+            const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+            if (p.bias && f0 + 3 < p.Nout) { const f32x4 b4 = *(const f32x4 *)(p.bias + f0); bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3]; }
+            else { bz[ni][0] = bz[ni][1] = bz[ni][2] = bz[ni][3] = 0.f; }
         }
         f32x4 acc[4][4];
 #pragma unroll
@@ -255,10 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
             dma_barrier();                   // own DMA landed (vmcnt(0)) + everyone done with the other slot
             if (s + 1 < S && !(p.debug & 4)) issue(s + 1);
             const unsigned char *sA = smem + (s & 1) * 32768;
-            if (!(p.debug & 2)) {
-                if (vtile) mma_block<T, true>(sA, sA + 16384, wm, wn, lane, acc);
-                else mma_block<T, false>(sA, sA + 16384, wm, wn, lane, acc);
-            }
+            if (!(p.debug & 2)) mma_block<T>(sA, sA + 16384, wm, wn, lane, acc);
         }
 
         // -------------------------------------------------------------- epilogue of this column tile
@@ -267,8 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
         // row (or, for V columns, 4 consecutive nodes of one feature): 8-byte pieces scattered over 16
         // rows per instruction, ~1 TB/s if written directly.  Staging area = the ring slot just consumed.
         unsigned char *stg = smem + ((ti * nk + nk - 1) & 1) * 32768;
-        if (vtile) mfma_epilogue<T, true, DA_ACT_NONE, PASSES, NIT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
-        else mfma_epilogue<T, false, ACT, PASSES, NIT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
+        mfma_epilogue<T, ACT, PASSES, NIT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
     }
 }
 

@@ -41,7 +41,7 @@ int launch_ddim3d(const DeviceSchedule &s, int mean_type, int n, const float *x,
 struct QkvScatter {            // where the fused projection scatters its four column blocks
     int HC, C, n_pad;
     const int32_t *row_map;    // node -> padded row
-    void *Q, *K, *Vt, *S;      // [H][n_pad][C], [H][n_pad][C], [H][C][n_pad], [M][H*C]
+    void *Q, *K, *Vt, *S;      // [H][n_pad][C] x 3 (Vt keeps its name; V is row-major since the tr_b16 rewrite), [M][H*C]
 };
 struct DenseLayout {
     const void *Q, *K, *Vt, *S;

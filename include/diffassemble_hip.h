@@ -98,7 +98,7 @@ typedef struct da_graph {
     const int32_t *edge_id;   /* [n_edges] or NULL                                         */
     const int32_t *graph_ptr; /* [n_graphs + 1] or NULL                                    */
     int32_t max_graph_nodes;  /* largest graph (dense mode tiling)                         */
-    /* dense mode only: every graph gets a 64-aligned slot of rows in the head-major Q/K/V^T
+    /* dense mode only: every graph gets a 64-aligned slot of rows in the head-major Q / K / V
      * buffers: pad_ptr[g] = first padded row of graph g, n_pad = pad_ptr[G], row_map[i] =
      * padded row of node i.                                                               */
     int32_t n_pad;
@@ -218,7 +218,7 @@ int da_attn_csr(int prec, const da_graph *g, int heads, int C, const void *qkvs,
                 int act, void *out, float *alpha, void *stream);
 
 /* The same layer through the dense block-diagonal MFMA path (g->dense != 0): fused projection
- * qkvs = x[n_nodes, Din] @ w[4*H*C, Din]^T + b scattered into head-major Q / K / V^T, then the
+ * qkvs = x[n_nodes, Din] @ w[4*H*C, Din]^T + b scattered into head-major Q / K / V, then the
  * flash-style attention kernel.  scratch: caller memory of da_attn_dense_scratch_bytes(),
  * zero-filled once by the caller before first use.  Returns nonzero (and an error text) if the
  * shape is not supported by the dense kernels.                                              */
