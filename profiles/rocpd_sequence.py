@@ -7,6 +7,7 @@ import sys
 con = sqlite3.connect(sys.argv[1])
 per = int(sys.argv[2])
 rows = con.execute("select name, start, end, grid_x, grid_y from kernels order by start").fetchall()
+rows = [r for r in rows if "da::" in r[0]]            # the library's kernels only (torch helpers come and go)
 names = [r[0] for r in rows]
 # the steady state is the tail: take the last 10 full steps
 tail = rows[-per * 10:]
