@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -49,6 +49,8 @@ class DaGraph(C.Structure):
         ("max_graph_nodes", C.c_int32), ("n_pad", C.c_int32),
         ("pad_ptr", _fp), ("row_map", _fp),
         ("out_ptr", _fp), ("out_dst", _fp),
+        ("hybrid", C.c_int32), ("reserved0", C.c_int32),
+        ("mask", _fp), ("mask_ptr", _fp), ("irr_row_ptr", _fp), ("irr_col_src", _fp),
     ]
 
 

@@ -59,6 +59,11 @@ struct AttnDenseParams {
     float sc;                       // log2(e) / sqrt(C)
     unsigned long long *prof;       // DA_ATTN_PROBE: per-workgroup cycle breakdown of wave 0
     int debug;                      // DA_ATTN_DEBUG bits (timing experiments): 1 no DMA, 2 no softmax, 4 no PV, 8 no QK
+    // hybrid (MASKED) mode: adjacency bits of the regular edges, partial softmax state out
+    const unsigned char *mask;      // rows of graph g at mask_ptr[g], row stride (pad_ptr[g+1] - pad_ptr[g]) / 8 bytes
+    const long long *mask_ptr;
+    float *Op;                      // [H][n_pad][C] fp32 un-normalised sum_j p_ij v_j
+    float *Ms;                      // [H][n_pad][2] fp32: reference max (natural-log units of the scaled score), sum
 };
 
 template <typename T, int C> struct Cfg {
@@ -158,7 +163,7 @@ __device__ __forceinline__ void stc(bf16_t *d, const float (&v)[8]) {
     *(u32x4 *)d = __builtin_bit_cast(u32x4, b);
 }
 
-template <typename T, int C>
+template <typename T, int C, bool MASKED>
 __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     using CF = Cfg<T, C>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 stages x (K | V)
@@ -229,6 +234,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     DA_ATTN_DBG(if (p.debug & 32) nkt = 1;)
     const int qidx = q0 + i;                     // this lane's query (index inside the graph)
     const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);     // key fed to MFMA row i
+    // MASKED: this lane's row of the adjacency bit matrix (bit j = edge j -> this query)
+    const unsigned char *mrow = nullptr;
+    if (MASKED) mrow = p.mask + p.mask_ptr[g] + (size_t)min(qidx, n_g - 1) * (size_t)((p.pad_ptr[g + 1] - pad0) >> 3);
     // LDS byte offsets of this lane's fragments inside a stage (constant over the whole kernel)
     const int koff = pi_i * CF::RS + half * 16;
     // V fragment base inside a stage.  bf16 (transposing reads): key 16*half + (li >> 2), channel
@@ -257,6 +265,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             // ---- all LDS fragment reads of this 32-key block are issued up front (K for QK^T now, V^T
             // for PV later): the compiler otherwise pairs every two reads with a full lgkmcnt(0) wait
             // and the MFMA chain idles ~100 cycles per pair
+            unsigned mw = 0;
+            if (MASKED) mw = *(const unsigned short *)(mrow + ((key0 + 16 * half) >> 3));
             u32x4 kf[CF::NCH];
 #pragma unroll
             for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + koff + kb * 32 * CF::RS + ch * 32);
@@ -290,12 +300,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             // this lane now holds keys key0 + 16*half + r, r = 0..15, of query qidx.
             // mask padded keys (last tile) and the diagonal (graphs without self loops)
             const int kbase = key0 + 16 * half;
-            const bool tail = key0 + 32 > n_g;
-            const bool diag = p.nodiag && key0 < q0 + 32 && key0 + 32 > q0;
-            if (tail || diag) {
+            if (MASKED) {                       // only the edges of the graph (bits beyond n_g are 0)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
+                    if (!((mw >> r) & 1u)) s[r] = -INFINITY;
+            } else {
+                const bool tail = key0 + 32 > n_g;
+                const bool diag = p.nodiag && key0 < q0 + 32 && key0 + 32 > q0;
+                if (tail || diag) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
+                }
             }
             float pr[16];
             DA_ATTN_DBG(if (p.debug & 2) { _Pragma("unroll") for (int r = 0; r < 16; ++r) pr[r] = s[r]; } else)
@@ -372,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     // 16-byte coalesced stores.  (Written straight from the accumulator layout every access is an
     // 8-byte piece in one of 32 different rows: that cost 25 % of the kernel.)
     const float lt = l + __shfl_xor(l, 32);
-    const float inv = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+    const float inv = MASKED ? 1.0f : (lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f);
     constexpr int RSOF = C + 4;                                   // floats per staged row (16-B aligned, odd # of 16-B slots)
     static_assert(128 * RSOF * 4 <= 2 * CF::STAGE, "O staging must fit in the K/V ring");
     float *so = (float *)smem;
@@ -380,6 +396,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     DA_ATTN_DBG(if (p.debug & 16) return;)
     if (wave_on) {
         float *orow = so + (wid * 32 + i) * RSOF;
+        if (MASKED && half == 0) {            // partial softmax state rides in the row's 4 spare floats
+            orow[C] = (m > -INFINITY) ? m * (p.sc * 0.6931471805599453f) : 0.f;
+            orow[C + 1] = lt;
+        }
 #pragma unroll
         for (int cb = 0; cb < CF::NCB; ++cb) {
 #pragma unroll
@@ -394,6 +414,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     dma_barrier();
     constexpr int EPC = 16 / CF::ES, CPR = C / EPC;              // elements per 16-B chunk, chunks per row
     const int nq = min(128, n_g - qt * 128);                      // valid queries of this tile
+    if (MASKED) {
+        // un-normalised O and (max, sum) per (head, slot): da_attn_csr's continuation kernel adds the
+        // remaining edges (virtual nodes, duplicates), normalises and applies skip / activation
+        constexpr int CPR4 = C / 4;
+        for (int it = tid; it < nq * CPR4; it += 256) {
+            const int q = it / CPR4, ch = it - q * CPR4;
+            const size_t slot = (size_t)h * np + pad0 + qt * 128 + q;
+            *(f32x4 *)(p.Op + slot * C + ch * 4) = *(const f32x4 *)(so + q * RSOF + ch * 4);
+            if (ch == 0) { p.Ms[slot * 2] = so[q * RSOF + C]; p.Ms[slot * 2 + 1] = so[q * RSOF + C + 1]; }
+        }
+        return;
+    }
     // batches of NB chunks per thread: all skip / residual loads of a batch are in flight before the
     // first one is consumed (a rolled load -> add -> store loop pays one L2/HBM latency per chunk)
     constexpr int NB = 3;
@@ -439,24 +471,28 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     DA_ATTN_DBG(if (p.prof && tid == 0) { DA_TICK(t_end_); unsigned long long *o = p.prof + 8 * blockIdx.x; o[0] = t_end_ - t_start; o[1] = c_bar; o[2] = c_iss; o[3] = c_qk; o[4] = c_sm; o[5] = c_pv; o[6] = t_end_ - t_loop_end; o[7] = 1; })
 }
 
-template <typename T, int C>
-static int launch_tc(const AttnDenseParams &p, int nblocks, hipStream_t st) {
+template <typename T, int C, bool MASKED>
+static int launch_tcm(const AttnDenseParams &p, int nblocks, hipStream_t st) {
     using CF = Cfg<T, C>;
     const int lds = 2 * CF::STAGE;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    k_attn_dense<T, C><<<nblocks, 256, lds, st>>>(p);
+    k_attn_dense<T, C, MASKED><<<nblocks, 256, lds, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
+}
+template <typename T, int C>
+static int launch_tc(const AttnDenseParams &p, int nblocks, hipStream_t st) {
+    return p.mask ? launch_tcm<T, C, true>(p, nblocks, st) : launch_tcm<T, C, false>(p, nblocks, st);
 }
 
 // returns 0 = launched, -1 = configuration not supported (caller uses the CSR kernel)
 int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes,
                       const int32_t *graph_ptr, const int32_t *pad_ptr, int nodiag, const void *res, int act,
-                      void *out, hipStream_t st) {
+                      void *out, hipStream_t st, const DenseMask *mk) {
     if (heads != 8 || (C != 32 && C != 144)) return -1;
     if ((size_t)C * (size_t)L.n_pad * esize(prec) >= ((size_t)1 << 31)) return -1;      // 32-bit DMA offsets
     AttnDenseParams p;
@@ -464,6 +500,8 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.n_graphs = n_graphs;
     p.nqt = (max_graph_nodes + 127) / 128; p.act = act; p.nodiag = nodiag;
     p.sc = 1.4426950408889634f / sqrtf((float)C);
+    p.mask = mk ? mk->mask : nullptr; p.mask_ptr = mk ? (const long long *)mk->mask_ptr : nullptr;
+    p.Op = mk ? mk->Op : nullptr; p.Ms = mk ? mk->Ms : nullptr;
     { const char *e = getenv("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
     { const char *e = getenv("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     const int nblocks = p.nqt * heads * n_graphs;

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 3
+#define DA_ABI_VERSION 4
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -108,6 +108,20 @@ typedef struct da_graph {
      * outgoing edges of node j are out_dst[out_ptr[j] .. out_ptr[j+1]); multi-edges kept.  */
     const int32_t *out_ptr;   /* [n_nodes + 1] or NULL                                     */
     const int32_t *out_dst;   /* [n_edges] or NULL                                         */
+    /* hybrid mode (inference): for graphs that are neither complete nor small -- the Exphander
+     * expanders of puzzle_dataset.py:33-152 with the exophormer virtual nodes -- the host splits the
+     * edge list: edges whose two ends are real nodes of one graph and that occur once become one bit
+     * of a per-graph adjacency mask (bit j of row i of graph g = edge j -> i; rows start at byte
+     * mask_ptr[g], row stride = padded slot count / 8 bytes) and run through the masked MFMA attention;
+     * every other edge (virtual nodes, duplicates, cross-graph pairs) stays a CSR by destination that a
+     * second kernel merges into the same softmax.  Needs pad_ptr / row_map (virtual rows of a graph get
+     * the slots behind its real nodes) and graph_ptr.                                            */
+    int32_t hybrid;           /* 0 / 1                                                     */
+    int32_t reserved0;
+    const uint8_t *mask;      /* adjacency bits or NULL                                    */
+    const int64_t *mask_ptr;  /* [n_graphs + 1] byte offsets                               */
+    const int32_t *irr_row_ptr; /* [n_nodes + 1] remainder CSR                             */
+    const int32_t *irr_col_src; /* [remainder edges]                                       */
 } da_graph;
 
 typedef struct da_denoiser da_denoiser;

@@ -388,3 +388,65 @@ def test_900_piece_expander_vs_oracle_single_layer(dev):
     out, alpha = eng.forward(plan, case["x"].to(dev), case["t"].to(dev), case["feats"].to(dev), return_alpha=True)
     assert rel(out, ref) < RTOL32
     assert rel(alpha, att[-1][1]) < RTOL32
+
+
+# ---------------------------------------------------------------------------- hybrid path (sparse-but-heavy graphs)
+HYBRID_SPECS = ["exo144_v4_g1", "exo144_v8_g2", "exo_expander_d6", "tr_expander_d7"]
+
+
+@pytest.mark.parametrize("name", HYBRID_SPECS)
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_forward_hybrid_masked_dense_plus_csr_remainder(dev, golden, monkeypatch, name, prec):
+    """Non-complete graphs forced through the hybrid split (adjacency-masked MFMA attention over the unique
+    real->real edges + CSR continuation over virtual / duplicated edges): same poses as the reference."""
+    monkeypatch.setenv("DA_HYBRID", "force")
+    spec = C.by_name(name)
+    case = C.build_case(spec)
+    eng = make_engine(case, spec, prec, dev)
+    plan = eng.plan(case["edge_index"], case["batch"])
+    assert plan.hybrid == 1 and plan.dense == 0
+    out = eng.forward(plan, case["x"].to(dev), case["t"].to(dev), case["feats"].to(dev))
+    assert rel(out, golden[f"{name}/out"]) < (RTOL32 if prec == "fp32" else RTOLBF)
+    # the same engine with the split disabled takes the plain CSR path
+    monkeypatch.setenv("DA_HYBRID", "off")
+    plan2 = eng.plan(case["edge_index"], case["batch"])
+    assert plan2.hybrid == 0
+    out2 = eng.forward(plan2, case["x"].to(dev), case["t"].to(dev), case["feats"].to(dev))
+    assert rel(out, out2) < (2e-5 if prec == "fp32" else RTOLBF)
+
+
+def test_hybrid_ddim_loop_matches_reference_trajectory(dev, golden, monkeypatch):
+    monkeypatch.setenv("DA_HYBRID", "force")
+    lp = C.LOOPS2D[1]                                                # exophormer, T=300, ratio 10
+    spec = C.by_name(lp["base"])
+    case = C.build_case(spec)
+    from diffassemble_amd import Schedule, _lib
+    eng = make_engine(case, spec, "fp32", dev)
+    plan = eng.plan(case["edge_index"], case["batch"])
+    assert plan.hybrid == 1
+    sch = Schedule(ODF.make_schedule(lp["T"]), dev)
+    x0 = torch.from_numpy(golden[f"{lp['name']}/x_init"]).to(dev)
+    traj, _ = eng.sample_loop(plan, sch, x0, case["feats"].to(dev), ratio=lp["ratio"], mean_type=_lib.MEAN_START_X,
+                              use_graph=True)
+    assert rel(traj, golden[f"{lp['name']}/imgs"]) < TRAJ32
+
+
+def test_900_piece_exphander_exophormer_auto_hybrid(dev):
+    """BASELINE config 3 shape (30x30 Exphander d=90, exophormer V=8, two puzzles): the plan picks the hybrid
+    split by itself and the fp32 forward matches the oracle."""
+    rng = np.random.default_rng(5)
+    sizes = [900, 900]
+    ei, batch = W.collate([W.random_regular_edge_index(n, 90, rng) for n in sizes], sizes)
+    sd = W.make_denoiser_state(100, 4, 4, arch="exophormer", virt_nodes=8, seed=3, qk_gain=2.0)
+    x, feats = W.make_inputs(sum(sizes), 4, 1088, 9)
+    t = torch.full((sum(sizes),), 37, dtype=torch.long)
+    ref, _ = OD.eff_gat_forward_with_feats(sd, x, t, ei, feats, batch, "exophormer", 8)
+    from diffassemble_amd import DenoiserEngine
+    eng = DenoiserEngine(sd, variant="2d", arch="exophormer", virt_nodes=8, precision="fp32", device=dev)
+    plan = eng.plan(ei, batch)
+    assert plan.hybrid == 1
+    out = eng.forward(plan, x.to(dev), t.to(dev), feats.to(dev))
+    assert rel(out, ref) < RTOL32
+    engb = DenoiserEngine(sd, variant="2d", arch="exophormer", virt_nodes=8, precision="bf16", device=dev)
+    outb = engb.forward(engb.plan(ei, batch), x.to(dev), t.to(dev), feats.to(dev))
+    assert rel(outb, ref) < RTOLBF
