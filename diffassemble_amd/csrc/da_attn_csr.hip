@@ -111,6 +111,82 @@ static int launch_t(int n_nodes, const int32_t *row_ptr, const int32_t *col_src,
 // (PyG: sum + 1e-16; no incoming edge at all -> 0) and applies skip / residual / activation.  Virtual nodes
 // start from the empty state.  Same lane decomposition as k_attn_csr, but Q / K / V are read from the
 // head-major padded layouts the projection scattered for the dense kernel.
+constexpr int HEAVY_DEG = 128, HEAVY_WAVES = 16;
+
+// Rows with a long remainder list -- the exophormer virtual nodes: ~n_g incoming edges each, most of them
+// the duplicated virtual->virtual pairs -- get a whole 16-wave workgroup: wave w walks edges w, w+16, ...,
+// the 16 partial softmax states are merged through LDS.  (One wave per row made the 8 virtual rows of a
+// graph the critical path of the whole layer: 560 us at any batch size.)
+template <typename T, int EPL>
+__global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n_real, const int32_t *__restrict__ row_ptr,
+                                                              const int32_t *__restrict__ col_src,
+                                                              const int32_t *__restrict__ row_map, int H, int C,
+                                                              size_t n_pad, const T *__restrict__ Q,
+                                                              const T *__restrict__ K, const T *__restrict__ V,
+                                                              const T *__restrict__ skip, const T *__restrict__ residual,
+                                                              int act, T *__restrict__ out, float scale) {
+    extern __shared__ float hsm[];                       // [HEAVY_WAVES][64 * EPL] acc, then [HEAVY_WAVES][64][2] (m, l)
+    const int i = n_real + blockIdx.x;
+    if (i >= n_nodes) return;
+    const int beg = row_ptr[i], end = row_ptr[i + 1];
+    if (end - beg <= HEAVY_DEG) return;                  // light row: k_attn_csr_cont
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int head = lane >> 3, sub = (lane & 7) * EPL;
+    const size_t hb = (size_t)head * n_pad;
+    const size_t si = hb + (size_t)row_map[i];
+    float q[EPL], acc[EPL];
+    float m = -INFINITY, l = 0.f;
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) { q[x] = ldf(Q + si * C + sub + x) * scale; acc[x] = 0.f; }
+    for (int e = beg + wv; e < end; e += HEAVY_WAVES) {
+        const size_t sj = hb + (size_t)row_map[col_src[e]];
+        float kk[EPL], vv[EPL];
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { kk[x] = ldf(K + sj * C + sub + x); vv[x] = ldf(V + sj * C + sub + x); }
+        float s = 0.f;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[x], s);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        const float mn = fmaxf(m, s);
+        const float corr = expf(m - mn);
+        const float pr = expf(s - mn);
+        l = l * corr + pr;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pr, vv[x], acc[x] * corr);
+        m = mn;
+    }
+    float *sacc = hsm + (size_t)wv * 64 * EPL, *sml = hsm + (size_t)HEAVY_WAVES * 64 * EPL;
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) sacc[lane * EPL + x] = acc[x];
+    sml[(wv * 64 + lane) * 2] = m;
+    sml[(wv * 64 + lane) * 2 + 1] = l;
+    __syncthreads();
+    if (wv != 0) return;
+    float M = -INFINITY;
+    for (int w = 0; w < HEAVY_WAVES; ++w) M = fmaxf(M, sml[(w * 64 + lane) * 2]);
+    float L = 0.f;
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) acc[x] = 0.f;
+    for (int w = 0; w < HEAVY_WAVES; ++w) {
+        const float mw = sml[(w * 64 + lane) * 2], lw = sml[(w * 64 + lane) * 2 + 1];
+        if (!(lw > 0.f)) continue;
+        const float f = expf(mw - M);
+        L = fmaf(lw, f, L);
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) acc[x] = fmaf(hsm[(size_t)w * 64 * EPL + lane * EPL + x], f, acc[x]);
+    }
+    const float inv = L > 0.f ? 1.0f / (L + 1e-16f) : 0.f;
+    const size_t o = (size_t)i * H * C + (size_t)head * C + sub;
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        float v = acc[x] * inv + ldf(skip + o + x);
+        if (residual) v += ldf(residual + o + x);
+        stf(out + o + x, apply_act(v, act));
+    }
+}
+
 template <typename T, int EPL>
 __global__ __launch_bounds__(256) void k_attn_csr_cont(int n_nodes, int n_real, const int32_t *__restrict__ row_ptr,
                                                        const int32_t *__restrict__ col_src,
@@ -123,6 +199,7 @@ __global__ __launch_bounds__(256) void k_attn_csr_cont(int n_nodes, int n_real, 
     const int lane = threadIdx.x & 63;
     const int i = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n_nodes) return;
+    if (i >= n_real && row_ptr[i + 1] - row_ptr[i] > HEAVY_DEG) return;     // k_attn_csr_cont_heavy owns this row
     const int head = lane >> 3, sub = (lane & 7) * EPL;
     const size_t hb = (size_t)head * n_pad;
     const size_t si = hb + (size_t)row_map[i];
@@ -175,6 +252,18 @@ static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32
     const int grid = (int)(((size_t)n_nodes * 64 + 255) / 256);
 #define DA_CONT_CASE(E)                                                                                          \
     case E:                                                                                                      \
+        if (n_nodes > n_real) {                                                                                  \
+            const int lds = HEAVY_WAVES * 64 * (E + 2) * 4;                                                      \
+            static bool attr = false;                                                                            \
+            if (!attr && lds > 48 * 1024) {                                                                      \
+                DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_csr_cont_heavy<T, E>,                      \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));              \
+                attr = true;                                                                                     \
+            }                                                                                                    \
+            k_attn_csr_cont_heavy<T, E><<<n_nodes - n_real, 1024, lds, st>>>(                                    \
+                n_nodes, n_real, rp, cs, row_map, H, C, (size_t)n_pad, (const T *)L.Q, (const T *)L.K,           \
+                (const T *)L.Vt, (const T *)L.S, residual, act, out, scale);                                     \
+        }                                                                                                        \
         k_attn_csr_cont<T, E><<<grid, 256, 0, st>>>(n_nodes, n_real, rp, cs, row_map, H, C, (size_t)n_pad,       \
                                                     (const T *)L.Q, (const T *)L.K, (const T *)L.Vt, (const T *)L.S, \
                                                     Op, Ms, residual, act, out, scale);                          \
