@@ -237,6 +237,13 @@ def main():
         roof = {"bound": "mfma", "kernel": "attn_last (graph attention, conv 3, C=144)", "achieved": ach,
                 "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
                 "flop_per_launch": flop_last, "avg_launch_ms": ms_last / n_last}
+        try:        # measured ceiling of the box (tools/measure_peaks.py): hipBLASLt bf16 GEMM at 8192^3
+            mp = json.load(open(os.path.join(ROOT, "profiles", "r01", "measured_peaks.json")))
+            if args.precision == "bf16":
+                roof["peak_measured_library_gemm"] = mp["hipblaslt_bf16_gemm_8192_tflops"]
+                roof["frac_of_measured_library_gemm"] = ach / mp["hipblaslt_bf16_gemm_8192_tflops"]
+        except (OSError, KeyError, ValueError):
+            pass
         ms_all = sum(ms for ms, _ in prof.values()) / kp
         flop_step = G * (N_PIECES * F_NODE + N_PIECES * N_PIECES * F_EDGE)
         roof["whole_step_tflops_in_kernels"] = flop_step / (ms_all * 1e-3) / 1e12
