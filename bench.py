@@ -7,7 +7,7 @@ One "step" = one p_sample_ddim call of the reference (spatial_diffusion.py:548-6
 forward over the whole batch + the DDIM pose update.  Every rank holds its own batch of
 ``--puzzles`` independent 30x30 puzzles (N = 900 pieces, E = 810 000 edges each, dense with self
 loops: BASELINE config 3'); puzzles shard across GPUs with NO data-path collective (weak scaling,
-SURVEY 8e).  Inputs (piece features, x_T, weights) are synthetic, seeded, and resident in HBM
+SURVEY 8e).  Inputs (piece features, x_T; weights = the module's seeded default init) are synthetic and resident in HBM
 before the timed region.  The K timed steps are consecutive iterations of the T = 100 DDIM loop,
 replayed as hipGraph launches; timing is barrier + synchronize on both sides, MAX over ranks.
 
@@ -69,12 +69,10 @@ def train_bench(args, world, rank, dev):
     import torch.distributed as dist
     from diffassemble_amd import sharding as S
     from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
-    from oracle import weights as W
     n, G, K, Wm = 144, args.train_puzzles, args.steps, args.warmup
-    sd = W.make_denoiser_state(T_STEPS, 4, 4, seed=0)
+    torch.manual_seed(0)
     m = GNN_Diffusion(steps=T_STEPS, sampling="DDIM", rotation=True, visual_pretrained=False,
                       model_mean_type=ModelMeanType.EPSILON)
-    m.model.load_state_dict(sd, strict=False)
     m = m.to(dev).train()
     opt = m.configure_optimizers()
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
@@ -169,20 +167,25 @@ def main():
     if args.mode == "train":
         return train_bench(args, world, rank, dev)
 
-    from diffassemble_amd import DenoiserEngine, Schedule, _lib
-    from oracle import diffusion as ODF          # schedule tables only (host constants)
-    from oracle import weights as W
+    from diffassemble_amd import _lib
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
 
     G, K, Wm = args.puzzles, args.steps, args.warmup
-    sd = W.make_denoiser_state(T_STEPS, 4, 4, seed=0)
-    eng = DenoiserEngine(sd, variant="2d", arch="transformer", precision=args.precision, device=dev)
+    # the reference-shaped module with seeded default-initialised weights (no checkpoints here), exactly what
+    # viz_script.py would build: rotation=True -> c = 4, transformer arch, START_X, DDIM
+    torch.manual_seed(0)
+    model = GNN_Diffusion(steps=T_STEPS, sampling="DDIM", inference_ratio=1, rotation=True, noise_weight=1.0,
+                          model_mean_type=ModelMeanType.START_X, visual_pretrained=False).to(dev).eval()
+    model.model.precision = args.precision
+    eng = model.model.engine(dev)
+    sd = {k: v.detach().cpu() for k, v in model.model._denoiser_state().items()}        # for the CPU baseline leg
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     feats = torch.randn((G * N_PIECES, 1088), generator=gen, device=dev)
     x_T = torch.randn((G * N_PIECES, 4), generator=gen, device=dev)
     ei, batch = dense_batch(G, N_PIECES, dev)
     plan = eng.plan(ei, batch)
     del ei
-    sch = Schedule(ODF.make_schedule(T_STEPS), dev)
+    sch = model._schedule()
     mt = _lib.MEAN_START_X
 
     def run(n_iters, graph):

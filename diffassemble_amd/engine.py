@@ -35,7 +35,7 @@ class Schedule:
 
 class DenoiserEngine:
     """Packs an ``Eff_GAT`` / ``Eff_GAT_3d`` state dict (reference key layout, see
-    oracle/denoiser.py) into the HIP library and runs forward / sampling on it."""
+    the key list in DESIGN.md section 1) into the HIP library and runs forward / sampling on it."""
 
     def __init__(self, sd, *, variant="2d", arch="transformer", virt_nodes=0, precision="bf16",
                  device=None):

@@ -5,7 +5,7 @@ against the HBM roofline, and the CPU oracle timed on the host cores for the con
 lists (bounded samples).  One JSON line per configuration; the committed copy is
 profiles/r01/configs_v1.jsonl.
 
-  python tools/bench_configs.py [--no-cpu] [--only NAME]
+  python tests/tools/bench_configs.py [--no-cpu] [--only NAME]
 """
 import argparse
 import json
@@ -13,7 +13,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402

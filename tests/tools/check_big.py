@@ -1,6 +1,6 @@
 """Large-batch self-consistency: dense MFMA path vs CSR path on G puzzles of 900 pieces."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from diffassemble_amd import DenoiserEngine
 from oracle import weights as W
 dev = torch.device("cuda:0")

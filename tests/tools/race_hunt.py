@@ -1,6 +1,6 @@
 """Repeat one forward many times on identical inputs; count runs whose output differs / is non-finite."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from diffassemble_amd import DenoiserEngine
 from oracle import weights as W
 dev = torch.device("cuda:0")
