@@ -450,3 +450,44 @@ def test_900_piece_exphander_exophormer_auto_hybrid(dev):
     engb = DenoiserEngine(sd, variant="2d", arch="exophormer", virt_nodes=8, precision="bf16", device=dev)
     outb = engb.forward(engb.plan(ei, batch), x.to(dev), t.to(dev), feats.to(dev))
     assert rel(outb, ref) < RTOLBF
+
+
+# ---------------------------------------------------------------------------- ragged / degenerate batches
+@pytest.mark.parametrize("loops", [True, False])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_ragged_dense_batch_with_tiny_and_odd_puzzles(dev, loops, prec):
+    """Complete graphs of 1, 2, 37, 129 and 200 pieces in one Batch (a 1-piece puzzle without self loop has
+    no incoming edge at all: PyG gives 0 + skip): dense MFMA path vs oracle."""
+    sizes = [1, 2, 37, 129, 200]
+    ei, batch = W.collate([W.dense_edge_index(n, loops) for n in sizes], sizes)
+    N = sum(sizes)
+    sd = W.make_denoiser_state(50, 4, 4, seed=21, qk_gain=3.0)
+    x, feats = W.make_inputs(N, 4, 1088, 4)
+    t = torch.randint(0, 50, (len(sizes),), generator=torch.Generator().manual_seed(1))[batch]
+    ref, _ = OD.eff_gat_forward_with_feats(sd, x, t, ei, feats, batch)
+    from diffassemble_amd import DenoiserEngine
+    eng = DenoiserEngine(sd, variant="2d", arch="transformer", precision=prec, device=dev)
+    plan = eng.plan(ei, batch)
+    assert plan.dense == (1 if loops else 2)
+    out = eng.forward(plan, x.to(dev), t.to(dev), feats.to(dev))
+    assert rel(out, ref) < (RTOL32 if prec == "fp32" else RTOLBF)
+
+
+def test_ragged_exophormer_hybrid_with_cross_graph_virtual_edges(dev, monkeypatch):
+    """Three expander puzzles of different sizes with exophormer virtual nodes: the reference's position-wise
+    pairing sends real nodes to OTHER graphs' virtual nodes (exophormer_gnn.py:183-200); hybrid split forced."""
+    monkeypatch.setenv("DA_HYBRID", "force")
+    rng = np.random.default_rng(8)
+    sizes = [70, 130, 45]
+    ei, batch = W.collate([W.random_regular_edge_index(n, 10, rng) for n in sizes], sizes)
+    N = sum(sizes)
+    sd = W.make_denoiser_state(100, 4, 4, arch="exophormer", virt_nodes=8, seed=12, qk_gain=3.0)
+    x, feats = W.make_inputs(N, 4, 1088, 6)
+    t = torch.randint(0, 100, (len(sizes),), generator=torch.Generator().manual_seed(2))[batch]
+    ref, _ = OD.eff_gat_forward_with_feats(sd, x, t, ei, feats, batch, "exophormer", 8)
+    from diffassemble_amd import DenoiserEngine
+    eng = DenoiserEngine(sd, variant="2d", arch="exophormer", virt_nodes=8, precision="fp32", device=dev)
+    plan = eng.plan(ei, batch)
+    assert plan.hybrid == 1
+    out = eng.forward(plan, x.to(dev), t.to(dev), feats.to(dev))
+    assert rel(out, ref) < RTOL32
