@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -90,6 +90,7 @@ PROTOTYPES = {
     "da_train_forward": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
     "da_adafactor_step": (C.c_int, [C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_float,
                                     C.c_float, C.c_float, C.c_float, _fp]),
+    "da_greedy_assign": (C.c_int, [C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),
     "da_train_backward": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp,
                                     _fp, C.c_size_t, _fp]),
 }

@@ -282,3 +282,28 @@ def conv_dense(plan: GraphPlan, x, weight, bias, heads, C_head, residual=None, a
                                  _lib.ptr(bias), _lib.ptr(r), int(act), _lib.ptr(out), _lib.ptr(scratch),
                                  _lib.stream_ptr(x.device)))
     return out
+
+
+def greedy_assign(pos1, pos2, ptr1=None, ptr2=None):
+    """greedy_cost_assignment (spatial_diffusion.py:179-216) for one puzzle or a whole Batch in ONE launch
+    (da_greedy_assign): pos1 [N, >=2], pos2 [M, >=2] fp32 on a ROCm device; ptr1 / ptr2 int32 [G + 1] row
+    offsets of the puzzles (default: one puzzle).  Returns int64 [N', 3] rows (row, column, int(distance)) in
+    assignment order, indices local to each puzzle, puzzle g at rows ptr1[g] .. ptr1[g] + min(n_g, m_g)."""
+    lib = _lib.lib()
+    dev = pos1.device
+    if dev.type != "cuda":
+        raise _lib.DaError("greedy_assign needs ROCm tensors (no CPU path in diffassemble_amd)")
+    pos1 = pos1.detach().to(torch.float32).contiguous()
+    pos2 = pos2.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if ptr1 is None:
+        ptr1 = torch.tensor([0, pos1.shape[0]], dtype=torch.int32, device=dev)
+        ptr2 = torch.tensor([0, pos2.shape[0]], dtype=torch.int32, device=dev)
+    ptr1, ptr2 = ptr1.to(device=dev, dtype=torch.int32).contiguous(), ptr2.to(device=dev, dtype=torch.int32).contiguous()
+    G = ptr1.numel() - 1
+    n = (ptr1[1:] - ptr1[:-1])
+    m = (ptr2[1:] - ptr2[:-1])
+    out = torch.zeros((pos1.shape[0], 3), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.da_greedy_assign(G, _lib.ptr(pos1), pos1.shape[1], _lib.ptr(pos2), pos2.shape[1], _lib.ptr(ptr1),
+                                        _lib.ptr(ptr2), int(n.max()), int(m.max()), _lib.ptr(out), _lib.stream_ptr(dev)))
+    return out

@@ -75,8 +75,11 @@ def extract(a, t, x_shape=None):
 def greedy_cost_assignment(pos1: torch.Tensor, pos2: torch.Tensor) -> torch.Tensor:
     """Same result as the reference's TorchScript loop (spatial_diffusion.py:179-216: repeatedly
     take the globally smallest remaining distance, retire its row and column) without the
-    per-assignment ``.item()`` syncs: one stable sort of all pairs, then a single pass.
-    Caller-side glue, not on the accelerated path."""
+    per-assignment ``.item()`` syncs.  ROCm tensors: the device kernel; CPU tensors: one
+    stable sort of all pairs, then a single pass (host glue for tests).  int64 [min(n, m), 3]."""
+    if pos1.is_cuda:                                   # one launch, no host round trips (da_greedy_assign)
+        from ..engine import greedy_assign
+        return greedy_assign(pos1, pos2)[: min(pos1.shape[0], pos2.shape[0])]
     dist = torch.norm(pos1[:, None] - pos2, dim=2)
     n, m = dist.shape
     # the reference's dist[mask].min() returns the FIRST minimum in row-major order: stable sort
@@ -331,16 +334,32 @@ class GNN_Diffusion(LightningModule):
         imgs, _ = self.p_sample_loop(batch.x.shape, batch.patches, batch.edge_index, batch=batch.batch,
                                      patch_feats=getattr(batch, "patch_feats", None))
         img = imgs[-1]
-        for i in range(int(batch.batch.max()) + 1):
+        G = int(batch.batch.max()) + 1
+        dims = batch.patches_dim.tolist()
+        grids = []
+        for i in range(G):
+            y = torch.linspace(-1, 1, dims[i][0], device=self.device)
+            x = torch.linspace(-1, 1, dims[i][1], device=self.device)
+            grids.append(torch.stack(torch.meshgrid(x, y, indexing="xy"), -1).reshape(-1, 2))
+        counts = torch.bincount(batch.batch, minlength=G)
+        ptr = torch.zeros(G + 1, dtype=torch.int32, device=self.device)
+        ptr[1:] = torch.cumsum(counts, 0)
+        batched = img.is_cuda and all(g.shape[0] == int(c) for g, c in zip(grids, counts))
+        if batched:                                        # both assignments of every puzzle: two launches
+            from ..engine import greedy_assign
+            grid_all = torch.cat(grids)
+            gt_all = greedy_assign(batch.x[:, :2], grid_all, ptr, ptr)
+            pred_all = greedy_assign(img[:, :2], grid_all, ptr, ptr)
+        for i in range(G):
             idx = torch.where(batch.batch == i)[0]
-            gt_pos, pos = batch.x[idx, :2], img[idx, :2]
-            n_patches = batch.patches_dim[i].tolist()
-            y = torch.linspace(-1, 1, n_patches[0], device=self.device)
-            x = torch.linspace(-1, 1, n_patches[1], device=self.device)
-            real_grid = torch.stack(torch.meshgrid(x, y, indexing="xy"), -1).reshape(-1, 2)
-            gt_ass = greedy_cost_assignment(gt_pos, real_grid)
+            n_patches = dims[i]
+            if batched:
+                lo, hi = int(ptr[i]), int(ptr[i + 1])
+                gt_ass, pred_ass = gt_all[lo:hi], pred_all[lo:hi]
+            else:
+                gt_ass = greedy_cost_assignment(batch.x[idx, :2], grids[i])
+                pred_ass = greedy_cost_assignment(img[idx, :2], grids[i])
             gt_ass = gt_ass[torch.sort(gt_ass[:, 0])[1]]
-            pred_ass = greedy_cost_assignment(pos, real_grid)
             pred_ass = pred_ass[torch.sort(pred_ass[:, 0])[1]]
             piece_accuracy = (gt_ass[:, 1] == pred_ass[:, 1]).to(self.device)
             correct = bool(piece_accuracy.all())

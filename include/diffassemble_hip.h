@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 4
+#define DA_ABI_VERSION 5
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -279,6 +279,18 @@ int da_adafactor_step(int n_params, const void *param_table, int n_blocks, const
                       float *flat, const float *flat_grad, float *state, float *scratch,
                       size_t scratch_floats, int step, float eps1, float eps2, float clip_threshold,
                       float decay_rate, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Greedy assignment of predicted positions to grid cells, one workgroup per puzzle, no host sync.
+ * Replaces greedy_cost_assignment (spatial_diffusion.py:179-216) as called by validation_step /
+ * test_step (:931-955).  Puzzle g owns rows ptr1[g]..ptr1[g+1] of pos1 (row stride ld1 floats, x
+ * and y in the first two columns) and rows ptr2[g]..ptr2[g+1] of pos2.  out[ptr1[g] + k] =
+ * (row, column, (int64)distance) of the k-th assignment, in the order the reference makes them;
+ * indices are local to the puzzle.  Ties: first in row-major order, like the reference.
+ * ------------------------------------------------------------------------------------- */
+int da_greedy_assign(int n_puzzles, const float *pos1, int ld1, const float *pos2, int ld2,
+                     const int32_t *ptr1, const int32_t *ptr2, int max_n, int max_m, long long *out,
+                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -491,3 +491,88 @@ def test_ragged_exophormer_hybrid_with_cross_graph_virtual_edges(dev, monkeypatc
     assert plan.hybrid == 1
     out = eng.forward(plan, x.to(dev), t.to(dev), feats.to(dev))
     assert rel(out, ref) < RTOL32
+
+
+# ---------------------------------------------------------------------------- greedy assignment
+def _greedy_reference(a, b):
+    """Straight restatement of the TorchScript loop, spatial_diffusion.py:179-216."""
+    dist = torch.norm(a[:, None] - b, dim=2)
+    mask = torch.ones_like(dist, dtype=torch.bool)
+    exp = []
+    while mask.sum() > 0:
+        mv, mi = dist[mask].min(dim=0)
+        i, j = mask.nonzero()[int(mi)]
+        exp.append((int(i), int(j), int(mv)))
+        mask[i, :] = 0
+        mask[:, j] = 0
+    return exp
+
+
+def test_greedy_assignment_kernel_matches_reference_loop(dev):
+    from diffassemble_amd import engine as E
+    from diffassemble_amd.model.spatial_diffusion import greedy_cost_assignment
+    g = torch.Generator().manual_seed(3)
+    # a Batch of three puzzles (6x6, 12x12, 3x5 grid): noisy predictions against the exact grid, plus the exact
+    # ground-truth positions (every distance of the first n picks is an exact zero: pure tie-breaking)
+    grids, preds, gts = [], [], []
+    for (h, w) in ((6, 6), (12, 12), (3, 5)):
+        y, x = torch.linspace(-1, 1, h), torch.linspace(-1, 1, w)
+        grid = torch.stack(torch.meshgrid(x, y, indexing="xy"), -1).reshape(-1, 2)
+        perm = torch.randperm(h * w, generator=g)
+        grids.append(grid)
+        gts.append(grid[perm])
+        preds.append(grid[perm] + 0.3 * torch.randn(h * w, 2, generator=g))
+    sizes = [x.shape[0] for x in grids]
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
+    for cand in (preds, gts):
+        out = E.greedy_assign(torch.cat(cand).to(dev), torch.cat(grids).to(dev), ptr.to(dev), ptr.to(dev)).cpu()
+        for k, (c, gr) in enumerate(zip(cand, grids)):
+            exp = _greedy_reference(c, gr)
+            assert out[int(ptr[k]): int(ptr[k + 1])].tolist() == [list(e) for e in exp], k
+    # the reference-named function dispatches to the same kernel for device tensors
+    one = greedy_cost_assignment(preds[1].to(dev), grids[1].to(dev)).cpu()
+    assert one.tolist() == [list(e) for e in _greedy_reference(preds[1], grids[1])]
+    # 30 x 30: a permutation, and the sorted-pair host version agrees
+    y = torch.linspace(-1, 1, 30)
+    grid = torch.stack(torch.meshgrid(y, y, indexing="xy"), -1).reshape(-1, 2)
+    pred = grid[torch.randperm(900, generator=g)] + 0.05 * torch.randn(900, 2, generator=g)
+    big = greedy_cost_assignment(pred.to(dev), grid.to(dev)).cpu()
+    assert sorted(big[:, 0].tolist()) == list(range(900)) and sorted(big[:, 1].tolist()) == list(range(900))
+    assert big.tolist() == greedy_cost_assignment(pred, grid).tolist()
+
+
+def test_validation_step_accuracy_with_device_assignment(dev):
+    """validation_step end to end (sampling loop -> batched device greedy assignment -> accuracy metrics) on a
+    Batch of two 6x6 puzzles; the accuracy equals the one recomputed on the host from the returned poses."""
+    from types import SimpleNamespace
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType, greedy_cost_assignment
+    spec = C.by_name("k36_loop_sharp")
+    case = C.build_case(spec)
+    m = GNN_Diffusion(steps=50, sampling="DDIM", model_mean_type=ModelMeanType.START_X, visual_pretrained=False,
+                      noise_weight=1.0)
+    m.model.load_state_dict(case["sd"], strict=False)
+    m = m.to(dev).eval()
+    m.model.precision = "fp32"
+    sizes = [36, 36]
+    ei, bvec = W.collate([W.dense_edge_index(36, True)] * 2, sizes)
+    y = torch.linspace(-1, 1, 6)
+    grid = torch.stack(torch.meshgrid(y, y, indexing="xy"), -1).reshape(-1, 2)
+    g = torch.Generator().manual_seed(0)
+    x_gt = torch.cat([grid[torch.randperm(36, generator=g)] for _ in sizes])
+    feats = torch.cat([case["feats"], case["feats"].flip(0)])
+    batch = SimpleNamespace(x=x_gt.to(dev), patches=None, edge_index=ei.to(dev), batch=bvec.to(dev),
+                            patches_dim=torch.tensor([[6, 6], [6, 6]]), patch_feats=feats.to(dev))
+    m.initialize_torchmetrics([(6, 6)])
+    torch.manual_seed(4)
+    img = m.validation_step(batch, 0)
+    assert img.shape == (72, 2) and torch.isfinite(img).all()
+    accs = []
+    for k in range(2):
+        sl = slice(36 * k, 36 * (k + 1))
+        ga = greedy_cost_assignment(x_gt[sl], grid)
+        pa = greedy_cost_assignment(img[sl].cpu(), grid)
+        ga, pa = ga[torch.sort(ga[:, 0])[1]], pa[torch.sort(pa[:, 0])[1]]
+        accs.append((ga[:, 1] == pa[:, 1]).float())
+    got = float(m.metrics["overall__piece_acc"].compute())
+    assert abs(got - float(torch.cat(accs).mean())) < 1e-6
+    assert float(m.metrics["overall_nImages"].compute()) == 2
