@@ -68,7 +68,6 @@ namespace da {
 struct Workspace {
     char *comb_in, *h, *combined, *qkvs, *xa, *xb, *z, *hh;
     char *dq, *dk, *dvt, *dskip;      // dense path: head-major Q, K, V ([H][n_pad][C] each), row-major skip
-    float *hyb_op, *hyb_ms;           // hybrid path: partial softmax state of the masked attention
     size_t dense_off, dense_bytes;    // [dq, dq + dense_bytes) is zero-filled once per Batch
     float *model_out, *xbuf0, *xbuf1;
     size_t total;
@@ -99,7 +98,6 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     w.dq = w.dk = w.dvt = w.dskip = nullptr;
     w.dense_off = off;
     w.dense_bytes = 0;
-    w.hyb_op = w.hyb_ms = nullptr;
     if ((g->dense || g->hybrid) && g->n_pad > 0) {
         const size_t hb = ((size_t)g->n_pad + 64) * hcmax * s;
         w.dq = take(hb);
@@ -107,10 +105,6 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
         w.dvt = take(hb);
         w.dense_bytes = off - w.dense_off;
         w.dskip = take(np * (size_t)hcmax * s);
-        if (g->hybrid) {
-            w.hyb_op = (float *)take(((size_t)g->n_pad + 64) * hcmax * sizeof(float));
-            w.hyb_ms = (float *)take(((size_t)g->n_pad + 64) * d->heads * 2 * sizeof(float));
-        }
     }
     const int cpose = d->variant == DA_VARIANT_3D ? 7 : d->c_out;
     w.model_out = (float *)take(nr * cpose * sizeof(float));
@@ -231,13 +225,14 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                     // sparse-but-heavy graphs: masked MFMA attention over the regular edges (partial softmax
                     // state), then the remaining edges + normalisation + skip / activation on the CSR side
                     DenseMask mk;
-                    mk.mask = g->mask; mk.mask_ptr = g->mask_ptr; mk.Op = w.hyb_op; mk.Ms = w.hyb_ms;
+                    mk.mask = g->mask; mk.mask_ptr = g->mask_ptr; mk.irr_row_ptr = g->irr_row_ptr;
+                    mk.irr_col_src = g->irr_col_src; mk.row_map = g->row_map;
                     rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
                         int r2 = launch_attn_dense(prec, L, d->heads, c.C, g->n_graphs, g->max_graph_nodes, g->graph_ptr,
-                                                   g->pad_ptr, 0, nullptr, DA_ACT_NONE, nullptr, st, &mk);
+                                                   g->pad_ptr, 0, resid, act, dst, st, &mk);
                         if (r2) return r2;
                         return launch_attn_csr_cont(prec, n, nr, g->irr_row_ptr, g->irr_col_src, g->row_map, d->heads, c.C,
-                                                    g->n_pad, L, w.hyb_op, w.hyb_ms, resid, act, dst, st); });
+                                                    g->n_pad, L, resid, act, dst, st); });
                     if (rc) return rc < 0 ? 1 : rc;
                     xin = dst; ldx = c.hc;
                     continue;

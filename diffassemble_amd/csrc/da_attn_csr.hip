@@ -104,13 +104,10 @@ static int launch_t(int n_nodes, const int32_t *row_ptr, const int32_t *col_src,
 }
 
 // ------------------------------------------------------------------------------------------
-// Hybrid mode, second half: the masked MFMA attention (da_attn_dense.hip, MASKED) has accumulated the
-// regular edges of every real node into an un-normalised partial state (Op, max, sum) in slot order; this
-// kernel continues the SAME online softmax over the remaining edges of the node -- the exophormer
-// virtual-node edges, duplicated pairs, cross-graph pairs (exophormer_gnn.py:183-200) -- then normalises
-// (PyG: sum + 1e-16; no incoming edge at all -> 0) and applies skip / residual / activation.  Virtual nodes
-// start from the empty state.  Same lane decomposition as k_attn_csr, but Q / K / V are read from the
-// head-major padded layouts the projection scattered for the dense kernel.
+// Hybrid mode, the rows the masked MFMA attention does not own.  Real nodes are finished inside
+// k_attn_dense<.., MASKED> (its epilogue folds their few remainder edges into the same softmax); the virtual
+// nodes of the exophormer arch (exophormer_gnn.py:183-200) have NO regular edge and are attended here over
+// the remainder CSR, reading Q / K / V from the head-major padded layouts the projection scattered.
 constexpr int HEAVY_DEG = 128, HEAVY_WAVES = 16;
 
 // Rows with a long remainder list -- the exophormer virtual nodes: ~n_g incoming edges each, most of them
@@ -193,13 +190,12 @@ __global__ __launch_bounds__(256) void k_attn_csr_cont(int n_nodes, int n_real, 
                                                        const int32_t *__restrict__ row_map, int H, int C, size_t n_pad,
                                                        const T *__restrict__ Q, const T *__restrict__ K,
                                                        const T *__restrict__ V, const T *__restrict__ skip,
-                                                       const float *__restrict__ Op, const float *__restrict__ Ms,
                                                        const T *__restrict__ residual, int act, T *__restrict__ out,
                                                        float scale) {
     const int lane = threadIdx.x & 63;
-    const int i = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int i = n_real + (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n_nodes) return;
-    if (i >= n_real && row_ptr[i + 1] - row_ptr[i] > HEAVY_DEG) return;     // k_attn_csr_cont_heavy owns this row
+    if (row_ptr[i + 1] - row_ptr[i] > HEAVY_DEG) return;     // k_attn_csr_cont_heavy owns this row
     const int head = lane >> 3, sub = (lane & 7) * EPL;
     const size_t hb = (size_t)head * n_pad;
     const size_t si = hb + (size_t)row_map[i];
@@ -207,13 +203,6 @@ __global__ __launch_bounds__(256) void k_attn_csr_cont(int n_nodes, int n_real, 
     float m = -INFINITY, l = 0.f;
 #pragma unroll
     for (int x = 0; x < EPL; ++x) { q[x] = ldf(Q + si * C + sub + x) * scale; acc[x] = 0.f; }
-    if (i < n_real) {
-        m = Ms[si * 2];
-        l = Ms[si * 2 + 1];
-#pragma unroll
-        for (int x = 0; x < EPL; ++x) acc[x] = Op[si * C + sub + x];
-        if (!(l > 0.f)) { m = -INFINITY; l = 0.f; }          // no regular edge: start from the empty state
-    }
     const int beg = row_ptr[i], end = row_ptr[i + 1];
     for (int e = beg; e < end; ++e) {
         const size_t sj = hb + (size_t)row_map[col_src[e]];
@@ -246,10 +235,10 @@ __global__ __launch_bounds__(256) void k_attn_csr_cont(int n_nodes, int n_real, 
 
 template <typename T>
 static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32_t *cs, const int32_t *row_map, int H, int C,
-                         int n_pad, const DenseLayout &L, const float *Op, const float *Ms, const T *residual, int act,
-                         T *out, hipStream_t st) {
+                         int n_pad, const DenseLayout &L, const T *residual, int act, T *out, hipStream_t st) {
+    if (n_nodes <= n_real) return 0;
     const float scale = 1.0f / sqrtf((float)C);
-    const int grid = (int)(((size_t)n_nodes * 64 + 255) / 256);
+    const int grid = (int)(((size_t)(n_nodes - n_real) * 64 + 255) / 256);
 #define DA_CONT_CASE(E)                                                                                          \
     case E:                                                                                                      \
         if (n_nodes > n_real) {                                                                                  \
@@ -266,7 +255,7 @@ static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32
         }                                                                                                        \
         k_attn_csr_cont<T, E><<<grid, 256, 0, st>>>(n_nodes, n_real, rp, cs, row_map, H, C, (size_t)n_pad,       \
                                                     (const T *)L.Q, (const T *)L.K, (const T *)L.Vt, (const T *)L.S, \
-                                                    Op, Ms, residual, act, out, scale);                          \
+                                                    residual, act, out, scale);                                  \
         break;
     switch (C / 8) {
         DA_CONT_CASE(4) DA_CONT_CASE(18)
@@ -280,14 +269,14 @@ static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32
 }
 
 int launch_attn_csr_cont(int prec, int n_nodes, int n_real, const int32_t *irr_row_ptr, const int32_t *irr_col_src,
-                         const int32_t *row_map, int heads, int C, int n_pad, const DenseLayout &L, const float *Op,
-                         const float *Ms, const void *residual, int act, void *out, hipStream_t st) {
+                         const int32_t *row_map, int heads, int C, int n_pad, const DenseLayout &L,
+                         const void *residual, int act, void *out, hipStream_t st) {
     if (n_nodes <= 0) return 0;
     DA_REQUIRE(heads == 8 && C % 8 == 0, "da_attn_csr_cont: heads must be 8 and C a multiple of 8");
     if (prec == DA_PREC_BF16)
-        return launch_cont_t<bf16_t>(n_nodes, n_real, irr_row_ptr, irr_col_src, row_map, heads, C, n_pad, L, Op, Ms,
+        return launch_cont_t<bf16_t>(n_nodes, n_real, irr_row_ptr, irr_col_src, row_map, heads, C, n_pad, L,
                                      (const bf16_t *)residual, act, (bf16_t *)out, st);
-    return launch_cont_t<float>(n_nodes, n_real, irr_row_ptr, irr_col_src, row_map, heads, C, n_pad, L, Op, Ms,
+    return launch_cont_t<float>(n_nodes, n_real, irr_row_ptr, irr_col_src, row_map, heads, C, n_pad, L,
                                 (const float *)residual, act, (float *)out, st);
 }
 

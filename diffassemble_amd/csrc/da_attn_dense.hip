@@ -59,11 +59,12 @@ struct AttnDenseParams {
     float sc;                       // log2(e) / sqrt(C)
     unsigned long long *prof;       // DA_ATTN_PROBE: per-workgroup cycle breakdown of wave 0
     int debug;                      // DA_ATTN_DEBUG bits (timing experiments): 1 no DMA, 2 no softmax, 4 no PV, 8 no QK
-    // hybrid (MASKED) mode: adjacency bits of the regular edges, partial softmax state out
+    // hybrid (MASKED) mode: adjacency bits of the regular edges; the remainder edges are folded in by the epilogue
     const unsigned char *mask;      // rows of graph g at mask_ptr[g], row stride (pad_ptr[g+1] - pad_ptr[g]) / 8 bytes
     const long long *mask_ptr;
-    float *Op;                      // [H][n_pad][C] fp32 un-normalised sum_j p_ij v_j
-    float *Ms;                      // [H][n_pad][2] fp32: reference max (natural-log units of the scaled score), sum
+    const int32_t *irr_row_ptr;     // remainder edges (virtual nodes, duplicates, cross-graph pairs): CSR by destination
+    const int32_t *irr_col_src;
+    const int32_t *row_map;         // node -> padded slot (for the sources of remainder edges)
 };
 
 template <typename T, int C> struct Cfg {
@@ -415,16 +416,51 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     constexpr int EPC = 16 / CF::ES, CPR = C / EPC;              // elements per 16-B chunk, chunks per row
     const int nq = min(128, n_g - qt * 128);                      // valid queries of this tile
     if (MASKED) {
-        // un-normalised O and (max, sum) per (head, slot): da_attn_csr's continuation kernel adds the
-        // remaining edges (virtual nodes, duplicates), normalises and applies skip / activation
-        constexpr int CPR4 = C / 4;
-        for (int it = tid; it < nq * CPR4; it += 256) {
-            const int q = it / CPR4, ch = it - q * CPR4;
-            const size_t slot = (size_t)h * np + pad0 + qt * 128 + q;
-            *(f32x4 *)(p.Op + slot * C + ch * 4) = *(const f32x4 *)(so + q * RSOF + ch * 4);
-            if (ch == 0) { p.Ms[slot * 2] = so[q * RSOF + C]; p.Ms[slot * 2 + 1] = so[q * RSOF + C + 1]; }
+        // Remainder edges of this tile's queries (hybrid mode): the rows staged above hold the UN-normalised
+        // sum of the masked attention with (max, sum) in their spare floats; each query's few remaining
+        // incoming edges -- from virtual nodes, duplicated pairs -- continue the same online softmax right
+        // here, 8 lanes per query (C / 8 channels each), before the rows are normalised below.
+        constexpr int EPL = C / 8;
+        const int grp = lane >> 3, sub = lane & 7;
+        const float scale = p.sc * 0.6931471805599453f;          // 1 / sqrt(C)
+        if (wave_on) {
+            for (int qq = grp; qq < 32; qq += 8) {
+                const int ql = wid * 32 + qq, qg = qt * 128 + ql;
+                if (qg >= n_g) continue;
+                const int node = node0 + qg;
+                const int beg = p.irr_row_ptr[node], end = p.irr_row_ptr[node + 1];
+                if (end <= beg) continue;
+                float *orow = so + ql * RSOF;
+                float mm = orow[C], ll = orow[C + 1];
+                if (!(ll > 0.f)) { mm = -INFINITY; ll = 0.f; }
+                float qv[EPL], acc[EPL];
+                const T *qrow = (const T *)p.Q + ((size_t)h * np + pad0 + qg) * C + sub * EPL;
+#pragma unroll
+                for (int x = 0; x < EPL; ++x) { qv[x] = ldf(qrow + x) * scale; acc[x] = orow[sub * EPL + x]; }
+                for (int e = beg; e < end; ++e) {
+                    const size_t sj = ((size_t)h * np + (size_t)p.row_map[p.irr_col_src[e]]) * C + sub * EPL;
+                    float kk[EPL], vv[EPL];
+#pragma unroll
+                    for (int x = 0; x < EPL; ++x) { kk[x] = ldf((const T *)p.K + sj + x); vv[x] = ldf((const T *)p.Vt + sj + x); }
+                    float sc_ = 0.f;
+#pragma unroll
+                    for (int x = 0; x < EPL; ++x) sc_ = fmaf(qv[x], kk[x], sc_);
+                    sc_ += __shfl_xor(sc_, 1);
+                    sc_ += __shfl_xor(sc_, 2);
+                    sc_ += __shfl_xor(sc_, 4);
+                    const float mn = fmaxf(mm, sc_);
+                    const float corr = expf(mm - mn), pe = expf(sc_ - mn);
+                    ll = ll * corr + pe;
+#pragma unroll
+                    for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vv[x], acc[x] * corr);
+                    mm = mn;
+                }
+#pragma unroll
+                for (int x = 0; x < EPL; ++x) orow[sub * EPL + x] = acc[x];
+                if (sub == 0) { orow[C] = mm; orow[C + 1] = ll; }
+            }
         }
-        return;
+        __syncthreads();
     }
     // batches of NB chunks per thread: all skip / residual loads of a batch are in flight before the
     // first one is consumed (a rolled load -> add -> store loop pays one L2/HBM latency per chunk)
@@ -453,6 +489,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                     const f32x4 a = *(const f32x4 *)src;
                     v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
                     if (EPC == 8) { const f32x4 b2 = *(const f32x4 *)(src + 4); v[4] = b2[0]; v[5] = b2[1]; v[6] = b2[2]; v[7] = b2[3]; }
+                }
+                if (MASKED) {                                     // rows were staged un-normalised
+                    const float lr = so[q * RSOF + C + 1];
+                    const float ir = lr > 0.f ? 1.0f / (lr + 1e-16f) : 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] *= ir;
                 }
                 unpack_chunk(T(), skv[k], sk);
 #pragma unroll
@@ -501,7 +543,8 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.nqt = (max_graph_nodes + 127) / 128; p.act = act; p.nodiag = nodiag;
     p.sc = 1.4426950408889634f / sqrtf((float)C);
     p.mask = mk ? mk->mask : nullptr; p.mask_ptr = mk ? (const long long *)mk->mask_ptr : nullptr;
-    p.Op = mk ? mk->Op : nullptr; p.Ms = mk ? mk->Ms : nullptr;
+    p.irr_row_ptr = mk ? mk->irr_row_ptr : nullptr; p.irr_col_src = mk ? mk->irr_col_src : nullptr;
+    p.row_map = mk ? mk->row_map : nullptr;
     { const char *e = getenv("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
     { const char *e = getenv("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     const int nblocks = p.nqt * heads * n_graphs;

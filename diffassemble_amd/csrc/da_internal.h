@@ -49,18 +49,18 @@ struct DenseLayout {
 };
 int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
                      int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st);
-struct DenseMask {             // hybrid mode: adjacency bits in, partial softmax state out (da_attn_dense.hip)
+struct DenseMask {             // hybrid mode: adjacency bits of the regular edges + the remainder CSR (da_attn_dense.hip)
     const uint8_t *mask;
     const int64_t *mask_ptr;
-    float *Op, *Ms;
+    const int32_t *irr_row_ptr, *irr_col_src, *row_map;
 };
 int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes,
                       const int32_t *graph_ptr, const int32_t *pad_ptr, int nodiag, const void *res, int act,
                       void *out, hipStream_t st, const DenseMask *mk = nullptr);
-// continuation of the masked attention over the remaining (irregular) edges + normalise + skip + act
+// hybrid mode: the rows the masked kernel does not own (virtual nodes) over their remainder edges
 int launch_attn_csr_cont(int prec, int n_nodes, int n_real, const int32_t *irr_row_ptr, const int32_t *irr_col_src,
-                         const int32_t *row_map, int heads, int C, int n_pad, const DenseLayout &L, const float *Op,
-                         const float *Ms, const void *residual, int act, void *out, hipStream_t st);
+                         const int32_t *row_map, int heads, int C, int n_pad, const DenseLayout &L,
+                         const void *residual, int act, void *out, hipStream_t st);
 
 // generic linear dispatch (MFMA when the shape allows, else simple)
 int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, int act,
