@@ -67,6 +67,7 @@ namespace da {
 
 struct Workspace {
     char *comb_in, *h, *combined, *qkvs, *xa, *xb, *z, *hh;
+    char *feat_proj;                  // [n_real, hidden] act dtype: mlp.0 over the piece-feature columns (+ bias), once per Batch
     char *dq, *dk, *dvt, *dskip;      // dense path: head-major Q, K, V ([H][n_pad][C] each), row-major skip
     size_t dense_off, dense_bytes;    // [dq, dq + dense_bytes) is zero-filled once per Batch
     float *model_out, *xbuf0, *xbuf1;
@@ -89,6 +90,7 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     for (int l = 0; l < d->n_layers; ++l) hcmax = d->conv[l].hc > hcmax ? d->conv[l].hc : hcmax;
     w.comb_in = take(nrp * d->D * s);
     w.h = take(nrp * d->hidden * s);
+    w.feat_proj = take(nrp * d->hidden * s);
     w.combined = take(np * d->D * s);
     w.qkvs = take(np * 4 * (size_t)hcmax * s);
     w.xa = take(np * 256 * s);
@@ -194,7 +196,17 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                                           d->pos_w0, d->pos_b0, d->pos_w1, d->pos_b1, w.comb_in, st); }))) return rc;
     const int act1 = d->variant == DA_VARIANT_3D ? DA_ACT_LEAKY02 : DA_ACT_GELU;
     const int act2 = d->variant == DA_VARIANT_3D ? DA_ACT_LEAKY02 : DA_ACT_NONE;
+    // mlp.0 over [features | pose | time]: the feature columns (F of the D inputs) do not change inside a
+    // sampling loop, so their part of the product (+ bias) was computed once in da_denoiser_set_features;
+    // per step only the 64 pose / timestep columns are multiplied and the cached part is added before the
+    // activation (the reference recomputes the whole Linear(1152 -> 128) every step)
     if ((rc = timed(d, DA_PROF_LINEAR_MLP, st, [&] {
+             const size_t es_ = esize(prec);
+             int r2 = mfma_disabled() ? -1
+                                      : launch_gemm_mfma(prec, nr, D - d->F, d->hidden, w.comb_in + (size_t)d->F * es_, D,
+                                                         (const char *)d->mlp_w0 + (size_t)d->F * es_, nullptr, act1, nullptr,
+                                                         w.h, d->hidden, nullptr, st, D, w.feat_proj);
+             if (r2 >= 0) return r2;
              return linear(prec, nr, D, d->hidden, w.comb_in, D, d->mlp_w0, d->mlp_b0, act1, nullptr, w.h, d->hidden, st); }))) return rc;
     if ((rc = timed(d, DA_PROF_LINEAR_MLP, st, [&] {
              return linear(prec, nr, d->hidden, D, w.h, d->hidden, d->mlp_w1, d->mlp_b1, act2, nullptr, w.combined, D, st); }))) return rc;
@@ -373,6 +385,12 @@ int da_denoiser_set_features(da_denoiser *d, const da_graph *g, const float *fea
     DA_REQUIRE(workspace_bytes >= w.total, "workspace too small: %zu < %zu", workspace_bytes, w.total);
     hipStream_t st = (hipStream_t)stream;
     if ((rc = launch_set_feats(d->prec, g->n_real, d->F, d->D, feats, w.comb_in, st))) return rc;
+    if (!mfma_disabled()) {       // loop-invariant part of mlp.0 (see forward_impl); unsupported shapes fall back there
+        rc = launch_gemm_mfma(d->prec, g->n_real, d->F, d->hidden, w.comb_in, d->D, d->mlp_w0, d->mlp_b0, DA_ACT_NONE, nullptr,
+                              w.feat_proj, d->hidden, nullptr, st, d->D, nullptr);
+        if (rc > 0) return rc;
+        DA_REQUIRE(rc == 0, "da_denoiser_set_features: feature projection shape not supported (F=%d)", d->F);
+    }
     if (w.dense_bytes)      // padded rows / columns of the head-major buffers must be finite
         DA_CHECK_HIP(hipMemsetAsync((char *)workspace + w.dense_off, 0, w.dense_bytes, st));
     if (d->V > 0) {

@@ -65,7 +65,19 @@ __device__ __forceinline__ void astat_epilogue(const GemmParams &p, const f32x4 
                 const int ni = ps * (CPP / 16) + nj;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
+                for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + bz[ni][r];
+                if (p.pre) {
+                    const int m = row0 + wm * 32 + mi * 16 + (lane & 15);
+                    const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                    if (m < p.M && f0 + 3 < p.Nout) {
+                        float pp[4];
+                        load4((const T *)p.pre + (size_t)m * p.Nout + f0, pp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += pp[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], ACT);
                 if (p.res) {
                     const int m = row0 + wm * 32 + mi * 16 + (lane & 15);
                     const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat(GemmParams p) {
 
     // LDS-DMA lane mapping (lane -> row lr, swizzled 16-byte chunk lc), as in da_gemm_mfma.hip
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
-    const size_t ldaB = (size_t)p.lda * ES, ldwB = (size_t)p.K * ES;
+    const size_t ldaB = (size_t)p.lda * ES, ldwB = (size_t)p.ldw * ES;
     // A panel: nk x 16 instructions of 8 rows; wave w issues instructions w and w + 8 of every chunk
     {
         const char *a0 = (const char *)p.A + lc * 16 + (size_t)min(row0 + 8 * wid + lr, p.M - 1) * ldaB;
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_astat_rs(GemmParams p) {
     // staging role of this thread: 16-byte chunk c of rows r0 and r0 + 64 of a [128][128 B] tile
     const int r0 = tid >> 3, c = tid & 7;
     const int lo0 = r0 * 128 + ((c ^ (r0 & 7)) << 4), lo1 = lo0 + 64 * 128;     // (r0 + 64) & 7 == r0 & 7
-    const size_t ldaB = (size_t)p.lda * ES, ldwB = (size_t)p.K * ES;
+    const size_t ldaB = (size_t)p.lda * ES, ldwB = (size_t)p.ldw * ES;
     {   // A panel, once
         const char *a0 = (const char *)p.A + c * 16 + (size_t)min(row0 + r0, p.M - 1) * ldaB;
         const char *a1 = (const char *)p.A + c * 16 + (size_t)min(row0 + r0 + 64, p.M - 1) * ldaB;

@@ -48,6 +48,9 @@ struct GemmParams {
     int M, K, Nout;
     const void *A; int lda;
     const void *W; const float *bias;
+    int ldw;            // row stride of W in elements (>= K): lets a column slice of a wider weight be used in place
+    const void *pre;    // optional [M, Nout] (act dtype, row stride Nout) added BEFORE the activation: a loop-invariant
+                        // part of the product computed once (the piece-feature columns of mlp.0)
     int act; const void *res; void *out; int ldo;
     // QKV scatter mode (dense attention layouts)
     int qkv; int HC, C, n_pad; const int32_t *row_map;

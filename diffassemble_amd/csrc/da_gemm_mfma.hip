@@ -78,7 +78,19 @@ __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (
                 if (rg / ROWS != pass) continue;                // wave-uniform (16-row groups never straddle)
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[mi][ni][r] + bz[ni][r], ACT);
+                for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] + bz[ni][r];
+                if (p.pre) {
+                    const int m = row0 + wm * 64 + mi * 16 + (lane & 15);
+                    const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                    if (m < p.M && f0 + 3 < p.Nout) {
+                        float pp[4];
+                        load4((const T *)p.pre + (size_t)m * p.Nout + f0, pp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += pp[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], ACT);
                 if (p.res) {
                     const int m = row0 + wm * 64 + mi * 16 + (lane & 15);
                     const int f0 = col0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     // swizzle is therefore applied on the SOURCE: slot s of row r holds logical chunk s ^ (r & 7).
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
     const char *Wb = (const char *)p.W + lc * 16;
-    const size_t ldaB = (size_t)p.lda * sizeof(T), ldwB = (size_t)p.K * sizeof(T);
+    const size_t ldaB = (size_t)p.lda * sizeof(T), ldwB = (size_t)p.ldw * sizeof(T);
     const char *ap[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -229,12 +241,16 @@ int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int 
 
 // returns 0 = launched, -1 = shape not supported by this kernel (caller falls back), >0 error
 int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
-                     int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st) {
+                     int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st, int ldw,
+                     const void *pre) {
     const int es = (int)esize(prec), BK = 128 / es;
     if (M <= 0 || Nout <= 0) return 0;
-    if (K % BK != 0 || (Nout % (16 / es)) || !aligned16(A) || !aligned16(W) || ((size_t)lda * es) % 16 != 0) return -1;
+    if (ldw <= 0) ldw = K;
+    if (K % BK != 0 || (Nout % (16 / es)) || !aligned16(A) || !aligned16(W) || ((size_t)lda * es) % 16 != 0 ||
+        ((size_t)ldw * es) % 16 != 0 || (pre && (!aligned16(pre) || qs))) return -1;
     GemmParams p;
     p.M = M; p.K = K; p.Nout = Nout; p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.act = act; p.res = res;
+    p.ldw = ldw; p.pre = pre;
     p.out = out; p.ldo = ldo; p.qkv = 0; p.HC = 1; p.C = 1; p.n_pad = 0; p.row_map = nullptr; p.Cmagic = 0;
     p.xcd_groups = 0;
     p.Q = p.Kb = p.Vt = p.S = nullptr;

@@ -48,7 +48,8 @@ struct DenseLayout {
     int n_pad;
 };
 int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
-                     int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st);
+                     int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st, int ldw = 0,
+                     const void *pre = nullptr);
 struct DenseMask {             // hybrid mode: adjacency bits of the regular edges + the remainder CSR (da_attn_dense.hip)
     const uint8_t *mask;
     const int64_t *mask_ptr;
