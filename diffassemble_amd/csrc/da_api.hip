@@ -50,6 +50,14 @@ struct da_denoiser {
     void *head_w0 = nullptr;
     float *head_b0 = nullptr;
     float *head_w1 = nullptr, *head_b1 = nullptr, *head_r_w1 = nullptr, *head_r_b1 = nullptr;
+    // 2D transformer arch: mlp.2 has no activation, so it is composed into its two consumers once per
+    // checkpoint (see da_denoiser_create): conv-0 projection over the 128-wide hidden layer, and the residual's
+    // share of final_mlp.0 as a pre-activation addend -- `combined` [N, 1152] is never materialised
+    bool fused_mlp2 = false;
+    void *conv0c_w = nullptr;         // [4*HC0, hidden] act dtype = Wcat0 . W2
+    float *conv0c_b = nullptr;        // [4*HC0] = Wcat0 . b2 + bcat0
+    void *headc_w = nullptr;          // [32, hidden] act dtype = Wf0 . W2
+    float *headc_b = nullptr;         // [32] = Wf0 . b2
     std::vector<void *> owned;
     // optional per-kernel-class timing with HIP events (da_profile_*)
     bool prof_on = false;
@@ -67,6 +75,7 @@ namespace da {
 
 struct Workspace {
     char *comb_in, *h, *combined, *qkvs, *xa, *xb, *z, *hh;
+    char *head_pre;                   // [n_real, 32] act dtype: residual share of final_mlp.0 (fused_mlp2)
     char *feat_proj;                  // [n_real, hidden] act dtype: mlp.0 over the piece-feature columns (+ bias), once per Batch
     char *dq, *dk, *dvt, *dskip;      // dense path: head-major Q, K, V ([H][n_pad][C] each), row-major skip
     size_t dense_off, dense_bytes;    // [dq, dq + dense_bytes) is zero-filled once per Batch
@@ -91,6 +100,7 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     w.comb_in = take(nrp * d->D * s);
     w.h = take(nrp * d->hidden * s);
     w.feat_proj = take(nrp * d->hidden * s);
+    w.head_pre = take(nrp * 32 * s);
     w.combined = take(np * d->D * s);
     w.qkvs = take(np * 4 * (size_t)hcmax * s);
     w.xa = take(np * 256 * s);
@@ -208,20 +218,25 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                                                          w.h, d->hidden, nullptr, st, D, w.feat_proj);
              if (r2 >= 0) return r2;
              return linear(prec, nr, D, d->hidden, w.comb_in, D, d->mlp_w0, d->mlp_b0, act1, nullptr, w.h, d->hidden, st); }))) return rc;
-    if ((rc = timed(d, DA_PROF_LINEAR_MLP, st, [&] {
+    // mlp.2 (Linear(128 -> 1152), no activation in 2D) only feeds two linear consumers -- the conv-0 projection
+    // and, through the residual, final_mlp.0 -- so for the transformer arch it is folded into their weights at
+    // create time: the [N, 1152] `combined` tensor is never written, conv 0 reduces over 128 instead of 1152
+    const bool fused = d->fused_mlp2;
+    if (!fused && (rc = timed(d, DA_PROF_LINEAR_MLP, st, [&] {
              return linear(prec, nr, d->hidden, D, w.h, d->hidden, d->mlp_w1, d->mlp_b1, act2, nullptr, w.combined, D, st); }))) return rc;
     // (a-4..a-6) graph transformer: fused Q|K|V|skip projection + attention per layer
-    const void *xin = w.combined;
-    int ldx = D;
+    const void *xin = fused ? w.h : w.combined;
+    int ldx = fused ? d->hidden : D;
     for (int l = 0; l < d->n_layers; ++l) {
-        const ConvW &c = d->conv[l];
+        ConvW c = d->conv[l];
+        if (fused && l == 0) { c.w = d->conv0c_w; c.b = d->conv0c_b; c.din = d->hidden; }
         const bool last = l == d->n_layers - 1;
         void *dst = last ? (void *)w.z : (void *)((l & 1) ? w.xb : w.xa);
         const int act = (!last && d->arch == DA_ARCH_TRANSFORMER) ? DA_ACT_GELU : DA_ACT_NONE;
         float *al = !alpha ? nullptr
                            : (alpha_all ? alpha + (size_t)l * g->n_edges * d->heads : (last ? alpha : nullptr));
         // last layer: the residual `feats + combined_feats` (efficient_gat.py:144) is fused in the epilogue
-        const void *resid = last ? w.combined : nullptr;
+        const void *resid = (last && !fused) ? w.combined : nullptr;
         if (!al && w.dq && dense_ok(g, d->heads, c.C)) {
             // complete graphs: projection scattered into head-major Q / K / V, block-diagonal MFMA attention
             QkvScatter qs;
@@ -265,7 +280,16 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
         ldx = c.hc;
     }
     // (a-7 / a-13) pose head
-    if ((rc = timed(d, DA_PROF_HEAD, st, [&] {
+    if (fused) {
+        // final_mlp.0(conv_out + combined) = Wf . conv_out + (Wf W2) . h + (Wf b2 + bf): the second term first
+        if ((rc = timed(d, DA_PROF_HEAD, st, [&] {
+                 return linear(prec, nr, d->hidden, 32, w.h, d->hidden, d->headc_w, d->headc_b, DA_ACT_NONE, nullptr, w.head_pre, 32, st); }))) return rc;
+        rc = timed(d, DA_PROF_HEAD, st, [&] {
+            return launch_gemm_mfma(prec, nr, D, d->head_hidden, w.z, D, d->head_w0, d->head_b0, DA_ACT_GELU, nullptr, w.hh,
+                                    d->head_hidden, nullptr, st, D, w.head_pre); });
+        if (rc > 0) return rc;
+        DA_REQUIRE(rc == 0, "fused head GEMM: shape not supported");
+    } else if ((rc = timed(d, DA_PROF_HEAD, st, [&] {
              return linear(prec, nr, D, d->head_hidden, w.z, D, d->head_w0, d->head_b0, DA_ACT_GELU, nullptr, w.hh,
                            d->head_hidden, st); }))) return rc;
     return timed(d, DA_PROF_HEAD, st, [&] {
@@ -357,6 +381,37 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
         d->head_w1 = copy_f32(w->head_w1, (size_t)w->c_out * 32); d->head_b1 = copy_f32(w->head_b1, w->c_out);
     }
     if (rc) return fail(rc);
+    {
+        static int off = -1;
+        if (off < 0) { const char *e = getenv("DA_DISABLE_MLP2_FUSION"); off = (e && e[0] == '1') ? 1 : 0; }
+        if (!off && !mfma_disabled() && d->variant == DA_VARIANT_2D && d->arch == DA_ARCH_TRANSFORMER && d->hidden % 32 == 0) {
+            // compose in fp32 from the caller's fp32 weights, then pack
+            const int hid = d->hidden, hc0 = d->conv[0].hc;
+            float *w2t = (float *)alloc((size_t)hid * D * 4);                  // W2^T [hidden, D]
+            float *cw = (float *)alloc((size_t)4 * hc0 * hid * 4);             // Wcat0 . W2
+            float *hw = (float *)alloc((size_t)32 * hid * 4);                  // Wf0 . W2
+            d->conv0c_b = (float *)alloc((size_t)4 * hc0 * 4);
+            d->headc_b = (float *)alloc(32 * 4);
+            if (!w2t || !cw || !hw || !d->conv0c_b || !d->headc_b) return fail(2);
+            if (launch_transpose_f32(D, hid, w->mlp_w1, w2t, st)) return fail(2);
+            const float *ws[4] = {w->conv_wq[0], w->conv_wk[0], w->conv_wv[0], w->conv_ws[0]};
+            const float *bs[4] = {w->conv_bq[0], w->conv_bk[0], w->conv_bv[0], w->conv_bs[0]};
+            for (int k = 0; k < 4; ++k) {
+                // rows of block k: [hc0, D] . W2 [D, hid]  ==  A [hc0, D] @ (W2^T [hid, D])^T
+                if (launch_gemm_simple(DA_PREC_F32, hc0, D, hid, ws[k], D, w2t, nullptr, DA_ACT_NONE, nullptr,
+                                       cw + (size_t)k * hc0 * hid, hid, st)) return fail(2);
+                // bias: b2 [1, D] @ (W_k [hc0, D])^T + b_k
+                if (launch_gemm_simple(DA_PREC_F32, 1, D, hc0, w->mlp_b1, D, ws[k], bs[k], DA_ACT_NONE, nullptr,
+                                       d->conv0c_b + (size_t)k * hc0, hc0, st)) return fail(2);
+            }
+            if (launch_gemm_simple(DA_PREC_F32, 32, D, hid, w->head_w0, D, w2t, nullptr, DA_ACT_NONE, nullptr, hw, hid, st)) return fail(2);
+            if (launch_gemm_simple(DA_PREC_F32, 1, D, 32, w->mlp_b1, D, w->head_w0, nullptr, DA_ACT_NONE, nullptr, d->headc_b, 32, st)) return fail(2);
+            d->conv0c_w = pack(cw, (size_t)4 * hc0 * hid);
+            d->headc_w = pack(hw, (size_t)32 * hid);
+            if (rc) return fail(rc);
+            d->fused_mlp2 = true;
+        }
+    }
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("da_denoiser_create: sync failed"); return fail(2); }
     *out = d;
     return 0;

@@ -25,6 +25,7 @@ int launch_ddim2d(const DeviceSchedule &s, int mean_type, int n, int c, const fl
 int launch_ddpm2d(const DeviceSchedule &s, int n, int c, const float *x, const float *mo, const int64_t *t,
                   int64_t t_scalar, const float *noise, float *x_prev, hipStream_t st);
 int launch_convert(int prec, size_t n, const float *src, void *dst, hipStream_t st);
+int launch_transpose_f32(int rows, int cols, const float *src, float *dst, hipStream_t st);      // da_train.hip
 
 // da_attn_csr.hip
 int launch_attn_csr(int prec, int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id,

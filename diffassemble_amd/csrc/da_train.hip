@@ -484,7 +484,7 @@ static int gelu_bwd(size_t n, const float *pre, const float *dy, float *dx, hipS
     DA_LAUNCH_CHECK();
     return 0;
 }
-static int transpose(int rows, int cols, const float *src, float *dst, hipStream_t st) {
+int launch_transpose_f32(int rows, int cols, const float *src, float *dst, hipStream_t st) {
     k_transpose<<<dim3((cols + 31) / 32, (rows + 31) / 32), 256, 0, st>>>(rows, cols, src, dst);
     DA_LAUNCH_CHECK();
     return 0;
@@ -504,7 +504,7 @@ static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float
     if ((rc = launch_gemm_tn(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, st))) return rc;
     if (db && (rc = colsum_add(M, N, dY, ldy, db, ws.csum, st))) return rc;
     if (dX) {
-        if ((rc = transpose(N, K, W, ws.wt, st))) return rc;                      // W [N, K] -> W^T [K, N]
+        if ((rc = launch_transpose_f32(N, K, W, ws.wt, st))) return rc;                      // W [N, K] -> W^T [K, N]
         if ((rc = linear(DA_PREC_F32, M, N, K, dY, ldy, ws.wt, nullptr, DA_ACT_NONE, res, dX, lddx, st))) return rc;
     }
     return 0;
