@@ -58,6 +58,14 @@ struct da_denoiser {
     float *conv0c_b = nullptr;        // [4*HC0] = Wcat0 . b2 + bcat0
     void *headc_w = nullptr;          // [32, hidden] act dtype = Wf0 . W2
     float *headc_b = nullptr;         // [32] = Wf0 . b2
+    // ... and the LAST conv's value / skip projections are folded with final_mlp.0 (its consumer, linear up to
+    // the GELU): softmax(QK^T)(V Wf_h^T) == (softmax(QK^T) V) Wf_h^T per head, so the last attention runs with
+    // 32-wide value heads and the [N, 1152] tensor z is never formed either (dense path only)
+    bool lastfold = false;
+    void *convLf_w = nullptr;         // [2*HC + H*32, 256] act dtype: Wq | Wk | (Wf_h Wv_h)_h
+    float *convLf_b = nullptr;        // [2*HC + H*32]
+    void *skipc_w = nullptr;          // [32, 256] act dtype = Wf0 . Ws_last
+    float *skipc_b = nullptr;         // [32] = Wf0 . bs_last + bf0
     std::vector<void *> owned;
     // optional per-kernel-class timing with HIP events (da_profile_*)
     bool prof_on = false;
@@ -75,6 +83,7 @@ namespace da {
 
 struct Workspace {
     char *comb_in, *h, *combined, *qkvs, *xa, *xb, *z, *hh;
+    float *pz;                        // [H, n_real, 32] fp32 per-head outputs of the folded last attention
     char *head_pre;                   // [n_real, 32] act dtype: residual share of final_mlp.0 (fused_mlp2)
     char *feat_proj;                  // [n_real, hidden] act dtype: mlp.0 over the piece-feature columns (+ bias), once per Batch
     char *dq, *dk, *dvt, *dskip;      // dense path: head-major Q, K, V ([H][n_pad][C] each), row-major skip
@@ -101,6 +110,7 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     w.h = take(nrp * d->hidden * s);
     w.feat_proj = take(nrp * d->hidden * s);
     w.head_pre = take(nrp * 32 * s);
+    w.pz = (float *)take(nrp * 32 * (size_t)d->heads * sizeof(float));
     w.combined = take(np * d->D * s);
     w.qkvs = take(np * 4 * (size_t)hcmax * s);
     w.xa = take(np * 256 * s);
@@ -237,6 +247,35 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                            : (alpha_all ? alpha + (size_t)l * g->n_edges * d->heads : (last ? alpha : nullptr));
         // last layer: the residual `feats + combined_feats` (efficient_gat.py:144) is fused in the epilogue
         const void *resid = (last && !fused) ? w.combined : nullptr;
+        if (last && fused && d->lastfold && !al && w.dq && !g->hybrid && dense_ok(g, d->heads, c.C)) {
+            // folded last layer: Q | K | (V Wf_h^T) projection, 32-wide value heads, per-head outputs to pz
+            QkvScatter qs;
+            qs.HC = c.hc; qs.C = c.C; qs.Cv = 32; qs.n_pad = g->n_pad; qs.row_map = g->row_map;
+            qs.Q = w.dq; qs.K = w.dk; qs.Vt = w.dvt; qs.S = nullptr;
+            rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
+                return launch_gemm_mfma(prec, n, c.din, 2 * c.hc + d->heads * 32, xin, ldx, d->convLf_w, d->convLf_b, DA_ACT_NONE,
+                                        nullptr, nullptr, 0, &qs, st); });
+            if (rc > 0) return rc;
+            if (rc == 0) {
+                DenseLayout L;
+                L.Q = w.dq; L.K = w.dk; L.Vt = w.dvt; L.S = nullptr; L.n_pad = g->n_pad;
+                DenseFold fo;
+                fo.cv = 32; fo.out = w.pz; fo.n_rows = nr;
+                rc = timed(d, DA_PROF_ATTN_LAST, st, [&] {
+                    return launch_attn_dense(prec, L, d->heads, c.C, g->n_graphs, g->max_graph_nodes, g->graph_ptr,
+                                             g->pad_ptr, g->dense == 2, nullptr, DA_ACT_NONE, nullptr, st, nullptr, &fo); });
+                if (rc > 0) return rc;
+                if (rc == 0) {
+                    // pre-activation of final_mlp.0 from the hidden layer (mlp.2 share) and from this conv's input (skip share)
+                    if ((rc = timed(d, DA_PROF_HEAD, st, [&] {
+                             return linear(prec, nr, d->hidden, 32, w.h, d->hidden, d->headc_w, d->headc_b, DA_ACT_NONE, nullptr, w.head_pre, 32, st); }))) return rc;
+                    if ((rc = timed(d, DA_PROF_HEAD, st, [&] {
+                             return linear(prec, nr, c.din, 32, xin, ldx, d->skipc_w, d->skipc_b, DA_ACT_NONE, w.head_pre, w.head_pre, 32, st); }))) return rc;
+                    return timed(d, DA_PROF_HEAD, st, [&] {
+                        return launch_head_fold(prec, nr, d->heads, d->c_out, w.pz, w.head_pre, d->head_w1, d->head_b1, out, st); });
+                }
+            }
+        }
         if (!al && w.dq && dense_ok(g, d->heads, c.C)) {
             // complete graphs: projection scattered into head-major Q / K / V, block-diagonal MFMA attention
             QkvScatter qs;
@@ -410,6 +449,38 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
             d->headc_w = pack(hw, (size_t)32 * hid);
             if (rc) return fail(rc);
             d->fused_mlp2 = true;
+            // last conv: value heads and skip folded with final_mlp.0
+            const int L = d->n_layers - 1, hcL = d->conv[L].hc, CL = d->conv[L].C, dinL = d->conv[L].din;
+            static int off2 = -1;
+            if (off2 < 0) { const char *e = getenv("DA_DISABLE_LAST_FOLD"); off2 = (e && e[0] == '1') ? 1 : 0; }
+            if (!off2 && CL == 144 && hcL == D && dinL % 32 == 0) {
+                const int nf = 2 * hcL + H * 32;
+                float *lw = (float *)alloc((size_t)nf * dinL * 4);
+                float *sw = (float *)alloc((size_t)32 * dinL * 4);
+                d->convLf_b = (float *)alloc((size_t)nf * 4);
+                d->skipc_b = (float *)alloc(32 * 4);
+                float *tmpb = (float *)alloc(32 * 4);
+                if (!lw || !sw || !d->convLf_b || !d->skipc_b || !tmpb) return fail(2);
+                const size_t blk = (size_t)hcL * dinL;
+                if (hipMemcpyAsync(lw, w->conv_wq[L], blk * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+                if (hipMemcpyAsync(lw + blk, w->conv_wk[L], blk * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+                if (hipMemcpyAsync(d->convLf_b, w->conv_bq[L], (size_t)hcL * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+                if (hipMemcpyAsync(d->convLf_b + hcL, w->conv_bk[L], (size_t)hcL * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+                for (int h = 0; h < H; ++h) {
+                    // (Wf[:, hC:(h+1)C] [32, C]) . (Wv[hC:(h+1)C, :] [C, din]) and the same block of the bias
+                    if (launch_mm_nn_f32(32, dinL, CL, w->head_w0 + (size_t)h * CL, D, w->conv_wv[L] + (size_t)h * CL * dinL, dinL,
+                                         nullptr, lw + 2 * blk + (size_t)h * 32 * dinL, dinL, st)) return fail(2);
+                    if (launch_mm_nn_f32(32, 1, CL, w->head_w0 + (size_t)h * CL, D, w->conv_bv[L] + (size_t)h * CL, 1, nullptr,
+                                         d->convLf_b + 2 * hcL + h * 32, 1, st)) return fail(2);
+                }
+                // skip: Wf [32, D] . Ws [D, din];  bias: Wf . bs + bf0
+                if (launch_mm_nn_f32(32, dinL, D, w->head_w0, D, w->conv_ws[L], dinL, nullptr, sw, dinL, st)) return fail(2);
+                if (launch_mm_nn_f32(32, 1, D, w->head_w0, D, w->conv_bs[L], 1, w->head_b0, d->skipc_b, 1, st)) return fail(2);
+                d->convLf_w = pack(lw, (size_t)nf * dinL);
+                d->skipc_w = pack(sw, (size_t)32 * dinL);
+                if (rc) return fail(rc);
+                d->lastfold = true;
+            }
         }
     }
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("da_denoiser_create: sync failed"); return fail(2); }

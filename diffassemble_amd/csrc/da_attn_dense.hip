@@ -65,11 +65,15 @@ struct AttnDenseParams {
     const int32_t *irr_row_ptr;     // remainder edges (virtual nodes, duplicates, cross-graph pairs): CSR by destination
     const int32_t *irr_col_src;
     const int32_t *row_map;         // node -> padded slot (for the sources of remainder edges)
+    float *fold_out;                // CV != C: [H][n_rows][CV] fp32 normalised per-head outputs (no skip / activation here)
+    int n_rows;
 };
 
-template <typename T, int C> struct Cfg {
+template <typename T, int C, int CV = C> struct Cfg {
     static constexpr int ES = (int)sizeof(T);
     static constexpr int ROWB = C * ES;                       // bytes of one K / Q row
+    static constexpr int ROWBV = CV * ES;                     // bytes of one V row (CV != C: value heads folded with the
+                                                              // next linear layer, see launch_attn_dense)
     static constexpr int NCH = ROWB / 32;                     // 32-byte K-dim chunks
     static constexpr int RS = ROWB + (((ROWB / 16) & 1) ? 0 : 16);   // odd number of 16-B slots
     static constexpr int KSPR = RS / 16;                      // LDS slots per K row
@@ -80,9 +84,10 @@ template <typename T, int C> struct Cfg {
     // groups read [4 keys][16 channels] blocks; two groups share an LDS cycle, and their 8 x 32-byte
     // pieces tile all 64 banks exactly when the row stride is 64 (mod 256) bytes.  fp32: scalar reads,
     // the two 32-lane halves sit 16 rows apart -> stride 32 (mod 64) bytes keeps them on disjoint banks.
-    static constexpr int RSV = ES == 2 ? ((ROWB - 64 + 255) / 256 * 256 + 64) : ((ROWB - 32 + 63) / 64 * 64 + 32);
+    static constexpr int RSV = ES == 2 ? ((ROWBV - 64 + 255) / 256 * 256 + 64) : ((ROWBV - 32 + 63) / 64 * 64 + 32);
+    static constexpr int KVALIDV = ROWBV / 16;
     static constexpr int VSPR = RSV / 16;
-    static constexpr int NCB = (C + 31) / 32;
+    static constexpr int NCB = (CV + 31) / 32;
     static constexpr int NIK = (BKEYS * KSPR + 63) / 64;      // DMA instructions (1 KB each) per tile
     static constexpr int NIV = (BKEYS * VSPR + 63) / 64;
     static constexpr int NI = NIK + NIV;
@@ -164,9 +169,9 @@ __device__ __forceinline__ void stc(bf16_t *d, const float (&v)[8]) {
     *(u32x4 *)d = __builtin_bit_cast(u32x4, b);
 }
 
-template <typename T, int C, bool MASKED>
+template <typename T, int C, bool MASKED, int CV>
 __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
-    using CF = Cfg<T, C>;
+    using CF = Cfg<T, C, CV>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 stages x (K | V)
 
     // XCD-aware remap: hardware places workgroup b on XCD b % 8; give XCD x head x of every graph and
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
 
     // ---- LDS-DMA plan: instruction q (1 KB) of a tile is issued by wave q % 4; lane -> slot q*64+lane
     const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
-    const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWB;
+    const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWBV;
     unsigned soff[CF::MAXI];
 #pragma unroll
     for (int x = 0; x < CF::MAXI; ++x) {
@@ -212,14 +217,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
         } else {
             const int s = (q - CF::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
-            if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
+            if (row < CF::BKEYS && col < CF::KVALIDV) o = (unsigned)(row * CF::ROWBV + col * 16);
         }
         soff[x] = o;
     }
     auto issue = [&](int kt, int stage) {
         unsigned char *sb = smem + stage * CF::STAGE;
         const unsigned char *kb_ = Kg + (size_t)kt * CF::BKEYS * CF::ROWB;
-        const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ROWB;
+        const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ROWBV;
 #pragma unroll
         for (int x = 0; x < CF::MAXI; ++x) {
             const int q = wid + 4 * x;
@@ -390,8 +395,25 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     // 8-byte piece in one of 32 different rows: that cost 25 % of the kernel.)
     const float lt = l + __shfl_xor(l, 32);
     const float inv = MASKED ? 1.0f : (lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f);
+    if (CV != C) {
+        // folded value heads: the caller projected V with the next linear layer's weight block of this head
+        // (softmax(QK^T) (V W^T) == (softmax(QK^T) V) W^T), so the output is CV wide and goes out normalised,
+        // per head, for the tail kernel to sum over heads -- no skip, no activation, no LDS staging
+        static_assert(CV == C || CF::NCB == 1, "folded value heads are one 32-channel block");
+        if (wave_on && qidx < n_g) {
+            const float invf = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+            float *dst = p.fold_out + ((size_t)h * p.n_rows + node0 + qidx) * CV;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int c0 = 8 * jj + 4 * half;
+                if (c0 < CV)
+                    *(f32x4 *)(dst + c0) = (f32x4){O[0][4 * jj] * invf, O[0][4 * jj + 1] * invf, O[0][4 * jj + 2] * invf, O[0][4 * jj + 3] * invf};
+            }
+        }
+        return;
+    }
     constexpr int RSOF = C + 4;                                   // floats per staged row (16-B aligned, odd # of 16-B slots)
-    static_assert(128 * RSOF * 4 <= 2 * CF::STAGE, "O staging must fit in the K/V ring");
+    static_assert(CV != C || 128 * RSOF * 4 <= 2 * CF::STAGE, "O staging must fit in the K/V ring");
     float *so = (float *)smem;
     dma_barrier();                                              // ring no longer read by anyone
     DA_ATTN_DBG(if (p.debug & 16) return;)
@@ -513,28 +535,28 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     DA_ATTN_DBG(if (p.prof && tid == 0) { DA_TICK(t_end_); unsigned long long *o = p.prof + 8 * blockIdx.x; o[0] = t_end_ - t_start; o[1] = c_bar; o[2] = c_iss; o[3] = c_qk; o[4] = c_sm; o[5] = c_pv; o[6] = t_end_ - t_loop_end; o[7] = 1; })
 }
 
-template <typename T, int C, bool MASKED>
+template <typename T, int C, bool MASKED, int CV>
 static int launch_tcm(const AttnDenseParams &p, int nblocks, hipStream_t st) {
-    using CF = Cfg<T, C>;
+    using CF = Cfg<T, C, CV>;
     const int lds = 2 * CF::STAGE;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C, MASKED, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    k_attn_dense<T, C, MASKED><<<nblocks, 256, lds, st>>>(p);
+    k_attn_dense<T, C, MASKED, CV><<<nblocks, 256, lds, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
 }
 template <typename T, int C>
 static int launch_tc(const AttnDenseParams &p, int nblocks, hipStream_t st) {
-    return p.mask ? launch_tcm<T, C, true>(p, nblocks, st) : launch_tcm<T, C, false>(p, nblocks, st);
+    return p.mask ? launch_tcm<T, C, true, C>(p, nblocks, st) : launch_tcm<T, C, false, C>(p, nblocks, st);
 }
 
 // returns 0 = launched, -1 = configuration not supported (caller uses the CSR kernel)
 int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes,
                       const int32_t *graph_ptr, const int32_t *pad_ptr, int nodiag, const void *res, int act,
-                      void *out, hipStream_t st, const DenseMask *mk) {
+                      void *out, hipStream_t st, const DenseMask *mk, const DenseFold *fold) {
     if (heads != 8 || (C != 32 && C != 144)) return -1;
     if ((size_t)C * (size_t)L.n_pad * esize(prec) >= ((size_t)1 << 31)) return -1;      // 32-bit DMA offsets
     AttnDenseParams p;
@@ -549,6 +571,12 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     { const char *e = getenv("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     const int nblocks = p.nqt * heads * n_graphs;
     if (nblocks <= 0) return 0;
+    p.fold_out = nullptr; p.n_rows = 0;
+    if (fold) {           // value heads folded to 32 channels (last layer of the 2D transformer arch)
+        if (C != 144 || fold->cv != 32 || mk) return -1;
+        p.fold_out = fold->out; p.n_rows = fold->n_rows;
+        return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, false, 32>(p, nblocks, st) : launch_tcm<float, 144, false, 32>(p, nblocks, st);
+    }
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, nblocks, st) : launch_tc<bf16_t, 144>(p, nblocks, st);
     return C == 32 ? launch_tc<float, 32>(p, nblocks, st) : launch_tc<float, 144>(p, nblocks, st);
 }

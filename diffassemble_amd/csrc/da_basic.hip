@@ -278,4 +278,58 @@ int launch_convert(int prec, size_t n, const float *src, void *dst, hipStream_t 
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// C[m][n] = sum_k A[m * lda + k] * B[k * ldb + n] (+ bias[m]) -- naive fp32, only used at create time to
+// compose small weight matrices (a few MFLOP).
+__global__ __launch_bounds__(256) void k_mm_nn_f32(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                   const float *__restrict__ B, int ldb, const float *__restrict__ bias,
+                                                   float *__restrict__ Cm, int ldc) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * N) return;
+    const int m = idx / N, n = idx - m * N;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(A[(size_t)m * lda + k], B[(size_t)k * ldb + n], acc);
+    Cm[(size_t)m * ldc + n] = acc + (bias ? bias[m] : 0.f);
+}
+
+int launch_mm_nn_f32(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *Cm,
+                     int ldc, hipStream_t st) {
+    k_mm_nn_f32<<<(M * N + 255) / 256, 256, 0, st>>>(M, N, K, A, lda, B, ldb, bias, Cm, ldc);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tail of the folded last layer (2D): f = GELU(sum_h Pz[h][n][:] + pre[n][:]) ; out[n] = W2 f + b2
+// (final_mlp: efficient_gat.py:144-146 with the value heads and the residual already projected to 32 wide).
+template <typename T>
+__global__ __launch_bounds__(256) void k_head_fold(int n, int H, int c_out, const float *__restrict__ pz, const T *__restrict__ pre,
+                                                   const float *__restrict__ w2, const float *__restrict__ b2,
+                                                   float *__restrict__ out) {
+    __shared__ float f[8][33];
+    const int j = threadIdx.x & 31, ln = threadIdx.x >> 5;
+    const int r = blockIdx.x * 8 + ln;
+    if (r < n) {
+        float a = ldf(pre + (size_t)r * 32 + j);
+        for (int h = 0; h < H; ++h) a += pz[((size_t)h * n + r) * 32 + j];
+        f[ln][j] = gelu_erf(a);
+    }
+    __syncthreads();
+    if (r < n && j < c_out) {
+        float a = b2[j];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a = fmaf(w2[j * 32 + k], f[ln][k], a);
+        out[(size_t)r * c_out + j] = a;
+    }
+}
+
+int launch_head_fold(int prec, int n, int H, int c_out, const float *pz, const void *pre, const float *w2, const float *b2,
+                     float *out, hipStream_t st) {
+    if (n <= 0) return 0;
+    if (prec == DA_PREC_BF16) k_head_fold<bf16_t><<<(n + 7) / 8, 256, 0, st>>>(n, H, c_out, pz, (const bf16_t *)pre, w2, b2, out);
+    else k_head_fold<float><<<(n + 7) / 8, 256, 0, st>>>(n, H, c_out, pz, (const float *)pre, w2, b2, out);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace da

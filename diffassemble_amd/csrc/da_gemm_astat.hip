@@ -103,8 +103,14 @@ __device__ __forceinline__ void astat_epilogue(const GemmParams &p, const f32x4 
                 if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
                 else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
                 else {
-                    const int f = col - which * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
+                    const int f = col - which * p.HC;
+                        if (which == 2 && p.Cv > 0) {
+                            const int h = (int)__umulhi((unsigned)f, p.Cvmagic), c = f - h * p.Cv;
+                            dst = (T *)p.Vt + ((size_t)h * p.n_pad + rs.q[mi][k]) * p.Cv + c;
+                        } else {
+                        const int h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
                     dst = (T *)(which == 0 ? p.Q : (which == 1 ? p.Kb : p.Vt)) + ((size_t)h * p.n_pad + rs.q[mi][k]) * p.C + c;
+                        }
                 }
                 *(u32x4 *)dst = val;
             }
@@ -405,7 +411,7 @@ int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int 
         if (prec == DA_PREC_BF16) DA_ASTAT_ACT(bf16_t, grid);
         else DA_ASTAT_ACT(float, grid);
     } else if (rs) {
-        const dim3 g = plan(4 * (qs->HC / 128));                     // Q | K | V | skip tiles in ONE launch
+        const dim3 g = plan(p.Nout / 128);                           // Q | K | V (| skip) tiles in ONE launch
         if (prec == DA_PREC_BF16) { if (nk == 4) DA_ASTAT_RS(bf16_t, true, DA_ACT_NONE, 4, g); else DA_ASTAT_RS(bf16_t, true, DA_ACT_NONE, 2, g); }
         else { if (nk == 4) DA_ASTAT_RS(float, true, DA_ACT_NONE, 4, g); else DA_ASTAT_RS(float, true, DA_ACT_NONE, 2, g); }
     } else {

@@ -55,6 +55,7 @@ struct GemmParams {
     // QKV scatter mode (dense attention layouts)
     int qkv; int HC, C, n_pad; const int32_t *row_map;
     unsigned Cmagic;   // ceil(2^32 / C): f / C == __umulhi(f, Cmagic) for the f < 2^16 that occur here
+    int Cv; unsigned Cvmagic;   // Cv > 0: the V block holds heads of Cv channels (folded value heads) and there is no skip block
     void *Q, *Kb, *Vt, *S;
     int nct, nt;     // column tiles of this launch, column tiles per workgroup
     int xcd_groups;  // > 0: 1-D grid, XCD-aware (row tile, column group) mapping with this many column groups

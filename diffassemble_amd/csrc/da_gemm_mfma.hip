@@ -121,8 +121,14 @@ __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (
             if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
             else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
             else {
-                const int f = col - which * p.HC, h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
+                const int f = col - which * p.HC;
+                if (which == 2 && p.Cv > 0) {
+                    const int h = (int)__umulhi((unsigned)f, p.Cvmagic), c = f - h * p.Cv;
+                    dst = (T *)p.Vt + ((size_t)h * p.n_pad + rs.q[pass][it]) * p.Cv + c;
+                } else {
+                const int h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
                 dst = (T *)(which == 0 ? p.Q : (which == 1 ? p.Kb : p.Vt)) + ((size_t)h * p.n_pad + rs.q[pass][it]) * p.C + c;
+                }
             }
             *(u32x4 *)dst = val[it];
         }
@@ -250,15 +256,18 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
         ((size_t)ldw * es) % 16 != 0 || (pre && (!aligned16(pre) || qs))) return -1;
     GemmParams p;
     p.M = M; p.K = K; p.Nout = Nout; p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.act = act; p.res = res;
-    p.ldw = ldw; p.pre = pre;
+    p.ldw = ldw; p.pre = pre; p.Cv = 0; p.Cvmagic = 0;
     p.out = out; p.ldo = ldo; p.qkv = 0; p.HC = 1; p.C = 1; p.n_pad = 0; p.row_map = nullptr; p.Cmagic = 0;
     p.xcd_groups = 0;
     p.Q = p.Kb = p.Vt = p.S = nullptr;
     { const char *e = getenv("DA_GEMM_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     { const char *e = getenv("DA_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
     if (qs) {
-        if (qs->HC % 128 != 0 || (qs->C & 7) || Nout != 4 * qs->HC || act != DA_ACT_NONE || res) return -1;
+        const int nexp = qs->Cv > 0 ? 2 * qs->HC + (qs->HC / qs->C) * qs->Cv : 4 * qs->HC;
+        if (qs->HC % 128 != 0 || (qs->C & 7) || (qs->Cv & 7) || Nout != nexp || Nout % 128 != 0 || act != DA_ACT_NONE || res) return -1;
         p.qkv = 1; p.HC = qs->HC; p.C = qs->C; p.n_pad = qs->n_pad; p.row_map = qs->row_map;
+        p.Cv = qs->Cv;
+        p.Cvmagic = qs->Cv > 0 ? (unsigned)((((unsigned long long)1 << 32) + (unsigned)qs->Cv - 1) / (unsigned)qs->Cv) : 0;
         p.Cmagic = (unsigned)((((unsigned long long)1 << 32) + (unsigned)qs->C - 1) / (unsigned)qs->C);
         p.Q = qs->Q; p.Kb = qs->K; p.Vt = qs->Vt; p.S = qs->S;
     } else if (((size_t)ldo * es) % 16 != 0 || !aligned16(out) || (res && !aligned16(res))) {
@@ -304,7 +313,7 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
         if (prec == DA_PREC_BF16) DA_GEMM_ACT(bf16_t, grid);
         else DA_GEMM_ACT(float, grid);
     } else {
-        const dim3 g = plan2(4 * (qs->HC / 128));                // Q | K | V | skip column blocks, one launch
+        const dim3 g = plan2(Nout / 128);                        // Q | K | V (| skip) column blocks, one launch
         if (prec == DA_PREC_BF16) DA_GEMM_LAUNCH(bf16_t, true, DA_ACT_NONE, g);
         else DA_GEMM_LAUNCH(float, true, DA_ACT_NONE, g);
     }

@@ -26,6 +26,10 @@ int launch_ddpm2d(const DeviceSchedule &s, int n, int c, const float *x, const f
                   int64_t t_scalar, const float *noise, float *x_prev, hipStream_t st);
 int launch_convert(int prec, size_t n, const float *src, void *dst, hipStream_t st);
 int launch_transpose_f32(int rows, int cols, const float *src, float *dst, hipStream_t st);      // da_train.hip
+int launch_mm_nn_f32(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
+                     int ldc, hipStream_t st);
+int launch_head_fold(int prec, int n, int H, int c_out, const float *pz, const void *pre, const float *w2, const float *b2,
+                     float *out, hipStream_t st);
 
 // da_attn_csr.hip
 int launch_attn_csr(int prec, int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id,
@@ -41,6 +45,7 @@ int launch_ddim3d(const DeviceSchedule &s, int mean_type, int n, const float *x,
 // da_gemm_mfma.hip / da_attn_dense.hip (dense block-diagonal path)
 struct QkvScatter {            // where the fused projection scatters its four column blocks
     int HC, C, n_pad;
+    int Cv = 0;                // > 0: three blocks only (Q | K | V'), V' heads Cv wide (folded value heads), no skip
     const int32_t *row_map;    // node -> padded row
     void *Q, *K, *Vt, *S;      // [H][n_pad][C] x 3 (Vt keeps its name; V is row-major since the tr_b16 rewrite), [M][H*C]
 };
@@ -56,9 +61,14 @@ struct DenseMask {             // hybrid mode: adjacency bits of the regular edg
     const int64_t *mask_ptr;
     const int32_t *irr_row_ptr, *irr_col_src, *row_map;
 };
+struct DenseFold {             // value heads folded with the next linear layer: V is [H][n_pad][cv], output per head
+    int cv;
+    float *out;                // [H][n_rows][cv] fp32, normalised
+    int n_rows;
+};
 int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes,
                       const int32_t *graph_ptr, const int32_t *pad_ptr, int nodiag, const void *res, int act,
-                      void *out, hipStream_t st, const DenseMask *mk = nullptr);
+                      void *out, hipStream_t st, const DenseMask *mk = nullptr, const DenseFold *fold = nullptr);
 // hybrid mode: the rows the masked kernel does not own (virtual nodes) over their remainder edges
 int launch_attn_csr_cont(int prec, int n_nodes, int n_real, const int32_t *irr_row_ptr, const int32_t *irr_col_src,
                          const int32_t *row_map, int heads, int C, int n_pad, const DenseLayout &L,
