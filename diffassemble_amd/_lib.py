@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -69,6 +69,7 @@ PROTOTYPES = {
     "da_last_error": (C.c_char_p, []),
     "da_denoiser_create": (C.c_int, [C.POINTER(DaWeights), C.c_int, _fp, C.POINTER(_fp)]),
     "da_denoiser_destroy": (None, [_fp]),
+    "da_denoiser_flags": (C.c_int, [_fp]),
     "da_denoiser_workspace_bytes": (C.c_size_t, [_fp, C.POINTER(DaGraph)]),
     "da_denoiser_set_features": (C.c_int, [_fp, C.POINTER(DaGraph), _fp, _fp, C.c_size_t, _fp]),
     "da_denoiser_forward": (C.c_int, [_fp, C.POINTER(DaGraph), _fp, _fp, C.c_int64, _fp, _fp, C.c_int, _fp, _fp,

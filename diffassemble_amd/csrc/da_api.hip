@@ -488,6 +488,8 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
     return 0;
 }
 
+int da_denoiser_flags(const da_denoiser *d) { return d ? (d->fused_mlp2 ? 1 : 0) | (d->lastfold ? 2 : 0) : 0; }
+
 void da_denoiser_destroy(da_denoiser *d) {
     if (!d) return;
     for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 5
+#define DA_ABI_VERSION 6
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -130,6 +130,11 @@ typedef struct da_denoiser da_denoiser;
  * layer).  Allocates (hipMalloc) -- not capturable; call once per checkpoint load.          */
 int da_denoiser_create(const da_weights *w, int precision, void *stream, da_denoiser **out);
 void da_denoiser_destroy(da_denoiser *d);
+
+/* Which algebraic folds the packed denoiser uses (2D transformer arch): bit 0 = mlp.2 composed into the
+ * conv-0 projection and final_mlp.0; bit 1 = last conv's value / skip projections composed with final_mlp.0
+ * (32-wide value heads in the last attention).  For reporting executed vs algorithmic FLOPs.            */
+int da_denoiser_flags(const da_denoiser *d);
 
 /* Bytes of caller-provided workspace needed for a graph of this size.                      */
 size_t da_denoiser_workspace_bytes(const da_denoiser *d, const da_graph *g);
