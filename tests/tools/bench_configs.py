@@ -3,7 +3,7 @@
 (hipGraph DDIM loop, puzzle-steps/s, per-kernel-class times), the sparse path's achieved bandwidth
 against the HBM roofline, and the CPU oracle timed on the host cores for the configurations the survey
 lists (bounded samples).  One JSON line per configuration; the committed copy is
-profiles/r01/configs_v1.jsonl.
+profiles/r01/configs_v2.jsonl.
 
   python tests/tools/bench_configs.py [--no-cpu] [--only NAME]
 """
