@@ -576,3 +576,31 @@ def test_validation_step_accuracy_with_device_assignment(dev):
     got = float(m.metrics["overall__piece_acc"].compute())
     assert abs(got - float(torch.cat(accs).mean())) < 1e-6
     assert float(m.metrics["overall_nImages"].compute()) == 2
+
+
+def test_algebraic_folds_can_be_switched_off_subprocess(dev):
+    """The folds of DESIGN.md 3c (mlp.2 composed into its consumers, last conv folded with final_mlp.0) are on by
+    default; with them disabled the layer-by-layer path must still match the reference fixtures (the switches are
+    read once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DA_DISABLE_MLP2_FUSION="1", DA_DISABLE_LAST_FOLD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
+                        "test_forward_2d_fp32_vs_oracle_and_golden or test_forward_2d_bf16 or test_ddim_loop_vs_reference_trajectory"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    env2 = dict(os.environ, DA_DISABLE_LAST_FOLD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_forward_2d_fp32_vs_oracle_and_golden"],
+                       env=env2, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_fold_flags_reported(dev):
+    spec = C.by_name("rot144_g1")
+    case = C.build_case(spec)
+    eng = make_engine(case, spec, "bf16", dev)
+    assert int(eng.lib.da_denoiser_flags(eng.handle)) == 3            # 2D transformer arch: both folds
+    spec = C.by_name("exo144_v4_g1")
+    eng = make_engine(C.build_case(spec), spec, "bf16", dev)
+    assert int(eng.lib.da_denoiser_flags(eng.handle)) == 0            # exophormer keeps the layer-by-layer path
