@@ -15,6 +15,41 @@
 
 namespace da {
 
+typedef __attribute__((ext_vector_type(4))) unsigned int csr_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int csr_u32x2;
+
+// EPL contiguous channels of one lane as floats, fetched with the widest loads the slice allows (a lane's
+// slice starts at a multiple of its own size inside a 16-byte aligned row: 36-byte slices of a 144-wide bf16
+// head are 4-byte aligned, 8-byte slices of a 32-wide one 8-byte aligned, ...).  One 2-byte load per channel
+// made a K + V row cost 36 load instructions per edge.
+template <typename T, int EPL>
+__device__ __forceinline__ void ld_row(const T *p, float (&v)[EPL]) {
+    constexpr int B = EPL * (int)sizeof(T), NW = (B + 3) / 4;
+    if constexpr (B % 4 != 0) {                 // odd bf16 slices (EPL = 1, 13): one load per channel
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) v[i] = ldf(p + i);
+        return;
+    }
+    unsigned w[NW];
+    if constexpr (B % 16 == 0) {
+#pragma unroll
+        for (int i = 0; i < B / 16; ++i) { const csr_u32x4 t = *((const csr_u32x4 *)p + i); w[4 * i] = t[0]; w[4 * i + 1] = t[1]; w[4 * i + 2] = t[2]; w[4 * i + 3] = t[3]; }
+    } else if constexpr (B % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < B / 8; ++i) { const csr_u32x2 t = *((const csr_u32x2 *)p + i); w[2 * i] = t[0]; w[2 * i + 1] = t[1]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = *((const unsigned *)p + i);
+    }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) v[i] = __builtin_bit_cast(float, w[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < EPL / 2; ++i) { v[2 * i] = bf2f((bf16_t)(w[i] & 0xffff)); v[2 * i + 1] = bf2f((bf16_t)(w[i] >> 16)); }
+    }
+}
+
 template <typename T, int EPL>
 __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__restrict__ row_ptr,
                                                   const int32_t *__restrict__ col_src,
@@ -39,8 +74,8 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
         const T *kp = qkvs + (size_t)j * ld + HC + off;
         const T *vp = kp + HC;
         float kk[EPL], vv[EPL];
-#pragma unroll
-        for (int x = 0; x < EPL; ++x) { kk[x] = ldf(kp + x); vv[x] = ldf(vp + x); }
+        ld_row<T, EPL>(kp, kk);
+        ld_row<T, EPL>(vp, vv);
         float s = 0.f;
 #pragma unroll
         for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[x], s);
@@ -133,26 +168,41 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
     const size_t si = hb + (size_t)row_map[i];
     float q[EPL], acc[EPL];
     float m = -INFINITY, l = 0.f;
+    ld_row<T, EPL>(Q + si * C + sub, q);
 #pragma unroll
-    for (int x = 0; x < EPL; ++x) { q[x] = ldf(Q + si * C + sub + x) * scale; acc[x] = 0.f; }
-    for (int e = beg + wv; e < end; e += HEAVY_WAVES) {
-        const size_t sj = hb + (size_t)row_map[col_src[e]];
-        float kk[EPL], vv[EPL];
+    for (int x = 0; x < EPL; ++x) { q[x] *= scale; acc[x] = 0.f; }
+    // four edges per trip: their index -> slot -> K / V row loads are independent, so one round of memory
+    // latency serves four softmax updates (the walk used to be one dependent chain per edge)
+    constexpr int U = 4;
+    for (int e0 = beg + wv; e0 < end; e0 += HEAVY_WAVES * U) {
+        size_t sj[U];
+        bool ok[U];
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { kk[x] = ldf(K + sj * C + sub + x); vv[x] = ldf(V + sj * C + sub + x); }
-        float s = 0.f;
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * HEAVY_WAVES;
+            ok[u] = e < end;
+            sj[u] = hb + (size_t)row_map[col_src[ok[u] ? e : beg]];
+        }
+        float kk[U][EPL], vv[U][EPL];
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[x], s);
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        const float mn = fmaxf(m, s);
-        const float corr = expf(m - mn);
-        const float pr = expf(s - mn);
-        l = l * corr + pr;
+        for (int u = 0; u < U; ++u) { ld_row<T, EPL>(K + sj[u] * C + sub, kk[u]); ld_row<T, EPL>(V + sj[u] * C + sub, vv[u]); }
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pr, vv[x], acc[x] * corr);
-        m = mn;
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;                            // wave-uniform
+            float s = 0.f;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[u][x], s);
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            const float mn = fmaxf(m, s);
+            const float corr = expf(m - mn);
+            const float pr = expf(s - mn);
+            l = l * corr + pr;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pr, vv[u][x], acc[x] * corr);
+            m = mn;
+        }
     }
     float *sacc = hsm + (size_t)wv * 64 * EPL, *sml = hsm + (size_t)HEAVY_WAVES * 64 * EPL;
 #pragma unroll
@@ -201,14 +251,15 @@ __global__ __launch_bounds__(256) void k_attn_csr_cont(int n_nodes, int n_real, 
     const size_t si = hb + (size_t)row_map[i];
     float q[EPL], acc[EPL];
     float m = -INFINITY, l = 0.f;
+    ld_row<T, EPL>(Q + si * C + sub, q);
 #pragma unroll
-    for (int x = 0; x < EPL; ++x) { q[x] = ldf(Q + si * C + sub + x) * scale; acc[x] = 0.f; }
+    for (int x = 0; x < EPL; ++x) { q[x] *= scale; acc[x] = 0.f; }
     const int beg = row_ptr[i], end = row_ptr[i + 1];
     for (int e = beg; e < end; ++e) {
         const size_t sj = hb + (size_t)row_map[col_src[e]];
         float kk[EPL], vv[EPL];
-#pragma unroll
-        for (int x = 0; x < EPL; ++x) { kk[x] = ldf(K + sj * C + sub + x); vv[x] = ldf(V + sj * C + sub + x); }
+        ld_row<T, EPL>(K + sj * C + sub, kk);
+        ld_row<T, EPL>(V + sj * C + sub, vv);
         float s = 0.f;
 #pragma unroll
         for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[x], s);

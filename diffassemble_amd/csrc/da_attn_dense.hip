@@ -243,6 +243,20 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     // MASKED: this lane's row of the adjacency bit matrix (bit j = edge j -> this query)
     const unsigned char *mrow = nullptr;
     if (MASKED) mrow = p.mask + p.mask_ptr[g] + (size_t)min(qidx, n_g - 1) * (size_t)((p.pad_ptr[g + 1] - pad0) >> 3);
+    // MASKED: remainder-edge metadata of the four queries this 8-lane group finishes in the epilogue
+    int rm_beg[4] = {0, 0, 0, 0}, rm_end[4] = {0, 0, 0, 0}, rm_slot[4] = {0, 0, 0, 0};
+    if (MASKED && wave_on) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qg = qt * 128 + wid * 32 + (lane >> 3) + 8 * r;
+            if (qg < n_g) {
+                rm_beg[r] = p.irr_row_ptr[node0 + qg];
+                rm_end[r] = p.irr_row_ptr[node0 + qg + 1];
+            }
+            rm_slot[r] = pad0;                                       // any valid slot when there is no edge
+            if (rm_end[r] > rm_beg[r]) rm_slot[r] = p.row_map[p.irr_col_src[rm_beg[r]]];
+        }
+    }
     // LDS byte offsets of this lane's fragments inside a stage (constant over the whole kernel)
     const int koff = pi_i * CF::RS + half * 16;
     // V fragment base inside a stage.  bf16 (transposing reads): key 16*half + (li >> 2), channel
@@ -251,6 +265,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     const int vbase = CF::ES == 2 ? CF::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2
                                   : CF::KBYTES + i * 4;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    unsigned mw_nxt[CF::KB];
+#pragma unroll
+    for (int kb = 0; kb < CF::KB; ++kb) mw_nxt[kb] = 0;
+    if (MASKED && wave_on) {
+#pragma unroll
+        for (int kb = 0; kb < CF::KB; ++kb) mw_nxt[kb] = *(const unsigned short *)(mrow + ((kb * 32 + 16 * half) >> 3));
+    }
     DA_ATTN_DBG(unsigned long long c_bar = 0, c_iss = 0, c_qk = 0, c_sm = 0, c_pv = 0;)
     DA_TICK(t_start);
     issue(0, 0);
@@ -263,6 +284,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
         DA_ATTN_DBG(c_bar += t1_ - t0_; c_iss += t2_ - t1_;)
         if (!wave_on) continue;
         const unsigned char *stg = smem + (kt & 1) * CF::STAGE;
+        // MASKED: adjacency words of THIS tile were requested during the previous one; request the next tile's now
+        unsigned mw_cur[CF::KB];
+        if (MASKED) {
+#pragma unroll
+            for (int kb = 0; kb < CF::KB; ++kb) mw_cur[kb] = mw_nxt[kb];
+            if (kt + 1 < nkt) {
+#pragma unroll
+                for (int kb = 0; kb < CF::KB; ++kb)
+                    mw_nxt[kb] = *(const unsigned short *)(mrow + (((kt + 1) * CF::BKEYS + kb * 32 + 16 * half) >> 3));
+            }
+        }
 #pragma unroll
         for (int kb = 0; kb < CF::KB; ++kb) {
             const int key0 = kt * CF::BKEYS + kb * 32;
@@ -271,8 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             // ---- all LDS fragment reads of this 32-key block are issued up front (K for QK^T now, V^T
             // for PV later): the compiler otherwise pairs every two reads with a full lgkmcnt(0) wait
             // and the MFMA chain idles ~100 cycles per pair
-            unsigned mw = 0;
-            if (MASKED) mw = *(const unsigned short *)(mrow + ((key0 + 16 * half) >> 3));
+            const unsigned mw = MASKED ? mw_cur[kb] : 0u;        // fetched one tile ahead (see the top of the loop)
             u32x4 kf[CF::NCH];
 #pragma unroll
             for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + koff + kb * 32 * CF::RS + ch * 32);
@@ -441,32 +472,64 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
         // Remainder edges of this tile's queries (hybrid mode): the rows staged above hold the UN-normalised
         // sum of the masked attention with (max, sum) in their spare floats; each query's few remaining
         // incoming edges -- from virtual nodes, duplicated pairs -- continue the same online softmax right
-        // here, 8 lanes per query (C / 8 channels each), before the rows are normalised below.
-        constexpr int EPL = C / 8;
-        const int grp = lane >> 3, sub = lane & 7;
+        // here, 8 lanes per query, before the rows are normalised below.  A lane owns the 16-byte chunks
+        // sub, sub + 8, ... of the C-wide rows (vector loads); the CSR metadata of the four queries a lane
+        // group serves (rm_*) was fetched at kernel start, and the Q / K / V rows of all four first edges are
+        // requested before any is consumed: the pass used to be a chain of ~5 dependent global loads per query.
+        constexpr int NCK = CF::ROWB / 16, MAXT = (NCK + 7) / 8, EPK = 16 / CF::ES;
+        const int sub = lane & 7;
         const float scale = p.sc * 0.6931471805599453f;          // 1 / sqrt(C)
+        auto load_row = [&](const void *base, size_t row, u32x4 (&dst)[MAXT]) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const int ck = sub + 8 * t;
+                dst[t] = ck < NCK ? *(const u32x4 *)((const unsigned char *)base + row * CF::ROWB + ck * 16) : (u32x4){0u, 0u, 0u, 0u};
+            }
+        };
         if (wave_on) {
-            for (int qq = grp; qq < 32; qq += 8) {
-                const int ql = wid * 32 + qq, qg = qt * 128 + ql;
-                if (qg >= n_g) continue;
-                const int node = node0 + qg;
-                const int beg = p.irr_row_ptr[node], end = p.irr_row_ptr[node + 1];
-                if (end <= beg) continue;
+            u32x4 qr[4][MAXT], kr[4][MAXT], vr[4][MAXT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qg = min(qt * 128 + wid * 32 + (lane >> 3) + 8 * r, n_g - 1);
+                load_row(p.Q, (size_t)h * np + pad0 + qg, qr[r]);
+                load_row(p.K, (size_t)h * np + rm_slot[r], kr[r]);
+                load_row(p.Vt, (size_t)h * np + rm_slot[r], vr[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (rm_end[r] <= rm_beg[r]) continue;
+                const int ql = wid * 32 + (lane >> 3) + 8 * r;
                 float *orow = so + ql * RSOF;
                 float mm = orow[C], ll = orow[C + 1];
                 if (!(ll > 0.f)) { mm = -INFINITY; ll = 0.f; }
-                float qv[EPL], acc[EPL];
-                const T *qrow = (const T *)p.Q + ((size_t)h * np + pad0 + qg) * C + sub * EPL;
+                float qv[MAXT][EPK], acc[MAXT][EPK];
 #pragma unroll
-                for (int x = 0; x < EPL; ++x) { qv[x] = ldf(qrow + x) * scale; acc[x] = orow[sub * EPL + x]; }
-                for (int e = beg; e < end; ++e) {
-                    const size_t sj = ((size_t)h * np + (size_t)p.row_map[p.irr_col_src[e]]) * C + sub * EPL;
-                    float kk[EPL], vv[EPL];
+                for (int t = 0; t < MAXT; ++t) {
+                    unpack_chunk(T(), qr[r][t], qv[t]);
 #pragma unroll
-                    for (int x = 0; x < EPL; ++x) { kk[x] = ldf((const T *)p.K + sj + x); vv[x] = ldf((const T *)p.Vt + sj + x); }
+                    for (int x = 0; x < EPK; ++x) {
+                        qv[t][x] *= scale;
+                        acc[t][x] = (sub + 8 * t < NCK) ? orow[(sub + 8 * t) * EPK + x] : 0.f;
+                    }
+                }
+                for (int e = rm_beg[r]; e < rm_end[r]; ++e) {
+                    u32x4 k2[MAXT], v2[MAXT];
+                    if (e > rm_beg[r]) {                              // beyond the prefetched first edge (rare)
+                        const size_t sj = (size_t)h * np + (size_t)p.row_map[p.irr_col_src[e]];
+                        load_row(p.K, sj, k2);
+                        load_row(p.Vt, sj, v2);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < MAXT; ++t) { k2[t] = kr[r][t]; v2[t] = vr[r][t]; }
+                    }
                     float sc_ = 0.f;
 #pragma unroll
-                    for (int x = 0; x < EPL; ++x) sc_ = fmaf(qv[x], kk[x], sc_);
+                    for (int t = 0; t < MAXT; ++t) {
+                        float kk[EPK];
+                        unpack_chunk(T(), k2[t], kk);
+#pragma unroll
+                        for (int x = 0; x < EPK; ++x) sc_ = fmaf(qv[t][x], kk[x], sc_);
+                    }
                     sc_ += __shfl_xor(sc_, 1);
                     sc_ += __shfl_xor(sc_, 2);
                     sc_ += __shfl_xor(sc_, 4);
@@ -474,11 +537,20 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                     const float corr = expf(mm - mn), pe = expf(sc_ - mn);
                     ll = ll * corr + pe;
 #pragma unroll
-                    for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vv[x], acc[x] * corr);
+                    for (int t = 0; t < MAXT; ++t) {
+                        float vv[EPK];
+                        unpack_chunk(T(), v2[t], vv);
+#pragma unroll
+                        for (int x = 0; x < EPK; ++x) acc[t][x] = fmaf(pe, vv[x], acc[t][x] * corr);
+                    }
                     mm = mn;
                 }
 #pragma unroll
-                for (int x = 0; x < EPL; ++x) orow[sub * EPL + x] = acc[x];
+                for (int t = 0; t < MAXT; ++t)
+                    if (sub + 8 * t < NCK) {
+#pragma unroll
+                        for (int x = 0; x < EPK; ++x) orow[(sub + 8 * t) * EPK + x] = acc[t][x];
+                    }
                 if (sub == 0) { orow[C] = mm; orow[C + 1] = ll; }
             }
         }
