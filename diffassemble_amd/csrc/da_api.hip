@@ -58,6 +58,7 @@ struct da_denoiser {
     float *conv0c_b = nullptr;        // [4*HC0] = Wcat0 . b2 + bcat0
     void *headc_w = nullptr;          // [32, hidden] act dtype = Wf0 . W2
     float *headc_b = nullptr;         // [32] = Wf0 . b2
+    void *virt_qkvs = nullptr;        // exophormer: [V, 4*HC0] act dtype = virt_emb . Wcat0^T + bcat0 (constant per checkpoint)
     // ... and the LAST conv's value / skip projections are folded with final_mlp.0 (its consumer, linear up to
     // the GELU): softmax(QK^T)(V Wf_h^T) == (softmax(QK^T) V) Wf_h^T per head, so the last attention runs with
     // 32-wide value heads and the [N, 1152] tensor z is never formed either (dense path only)
@@ -240,6 +241,10 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
     for (int l = 0; l < d->n_layers; ++l) {
         ConvW c = d->conv[l];
         if (fused && l == 0) { c.w = d->conv0c_w; c.b = d->conv0c_b; c.din = d->hidden; }
+        // fused conv 0 of the exophormer arch: only the real rows go through the GEMM, the virtual rows'
+        // projections are constants that launch_scatter_virtual places behind them
+        const int nproj = (fused && l == 0) ? nr : n;
+        const bool virt0 = fused && l == 0 && n > nr;
         const bool last = l == d->n_layers - 1;
         void *dst = last ? (void *)w.z : (void *)((l & 1) ? w.xb : w.xa);
         const int act = (!last && d->arch == DA_ARCH_TRANSFORMER) ? DA_ACT_GELU : DA_ACT_NONE;
@@ -282,8 +287,11 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             qs.HC = c.hc; qs.C = c.C; qs.n_pad = g->n_pad; qs.row_map = g->row_map;
             qs.Q = w.dq; qs.K = w.dk; qs.Vt = w.dvt; qs.S = w.dskip;
             rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
-                return launch_gemm_mfma(prec, n, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st); });
+                return launch_gemm_mfma(prec, nproj, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st); });
             if (rc > 0) return rc;
+            if (rc == 0 && virt0 &&
+                (rc = launch_scatter_virtual(prec, n - nr, d->V, d->heads, c.C, d->virt_qkvs, nr, g->row_map, g->n_pad, w.dq, w.dk,
+                                             w.dvt, w.dskip, nullptr, st))) return rc;
             if (rc == 0) {
                 DenseLayout L;
                 L.Q = w.dq; L.K = w.dk; L.Vt = w.dvt; L.S = w.dskip; L.n_pad = g->n_pad;
@@ -311,7 +319,9 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             }
         }
         if ((rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
-                 return linear(prec, n, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, w.qkvs, 4 * c.hc, st); }))) return rc;
+                 return linear(prec, nproj, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, w.qkvs, 4 * c.hc, st); }))) return rc;
+        if (virt0 && (rc = launch_scatter_virtual(prec, n - nr, d->V, d->heads, c.C, d->virt_qkvs, nr, nullptr, 0, nullptr, nullptr,
+                                                  nullptr, nullptr, w.qkvs, st))) return rc;
         if ((rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
                  return launch_attn_csr(prec, n, g->row_ptr, g->col_src, g->edge_id, d->heads, c.C, w.qkvs,
                                         resid, act, dst, al, nullptr, st); }))) return rc;
@@ -423,7 +433,7 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
     {
         static int off = -1;
         if (off < 0) { const char *e = getenv("DA_DISABLE_MLP2_FUSION"); off = (e && e[0] == '1') ? 1 : 0; }
-        if (!off && !mfma_disabled() && d->variant == DA_VARIANT_2D && d->arch == DA_ARCH_TRANSFORMER && d->hidden % 32 == 0) {
+        if (!off && !mfma_disabled() && d->variant == DA_VARIANT_2D && d->hidden % 32 == 0) {
             // compose in fp32 from the caller's fp32 weights, then pack
             const int hid = d->hidden, hc0 = d->conv[0].hc;
             float *w2t = (float *)alloc((size_t)hid * D * 4);                  // W2^T [hidden, D]
@@ -447,13 +457,21 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
             if (launch_gemm_simple(DA_PREC_F32, 1, D, 32, w->mlp_b1, D, w->head_w0, nullptr, DA_ACT_NONE, nullptr, d->headc_b, 32, st)) return fail(2);
             d->conv0c_w = pack(cw, (size_t)4 * hc0 * hid);
             d->headc_w = pack(hw, (size_t)32 * hid);
+            if (d->V > 0) {            // exophormer: conv-0 projections of the virtual rows (they bypass mlp)
+                float *vq = (float *)alloc((size_t)d->V * 4 * hc0 * 4);
+                if (!vq) return fail(2);
+                for (int k = 0; k < 4; ++k)
+                    if (launch_gemm_simple(DA_PREC_F32, d->V, D, hc0, w->virt_emb, D, ws[k], bs[k], DA_ACT_NONE, nullptr,
+                                           vq + (size_t)k * hc0, 4 * hc0, st)) return fail(2);
+                d->virt_qkvs = pack(vq, (size_t)d->V * 4 * hc0);
+            }
             if (rc) return fail(rc);
             d->fused_mlp2 = true;
             // last conv: value heads and skip folded with final_mlp.0
             const int L = d->n_layers - 1, hcL = d->conv[L].hc, CL = d->conv[L].C, dinL = d->conv[L].din;
             static int off2 = -1;
             if (off2 < 0) { const char *e = getenv("DA_DISABLE_LAST_FOLD"); off2 = (e && e[0] == '1') ? 1 : 0; }
-            if (!off2 && CL == 144 && hcL == D && dinL % 32 == 0) {
+            if (!off2 && d->arch == DA_ARCH_TRANSFORMER && CL == 144 && hcL == D && dinL % 32 == 0) {
                 const int nf = 2 * hcL + H * 32;
                 float *lw = (float *)alloc((size_t)nf * dinL * 4);
                 float *sw = (float *)alloc((size_t)32 * dinL * 4);

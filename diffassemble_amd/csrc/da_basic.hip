@@ -332,4 +332,44 @@ int launch_head_fold(int prec, int n, int H, int c_out, const float *pz, const v
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// exophormer + folded mlp.2: the conv-0 projections of the virtual rows are constants of the checkpoint
+// (virt_emb . Wcat0^T + b, [V, 4*HC]); every step they are placed behind the real rows' projections.
+//   dense / hybrid layouts: Q, K, V head-major at the row's padded slot, skip row-major
+//   CSR layout: row-major qkvs[n][4*HC]
+template <typename T>
+__global__ __launch_bounds__(256) void k_scatter_virtual(int rows, int V, int H, int C, const T *__restrict__ src, int n_real,
+                                                         const int32_t *__restrict__ row_map, size_t n_pad, T *Q, T *K, T *Vt,
+                                                         T *S, T *qkvs) {
+    const int HC = H * C;
+    const size_t total = (size_t)rows * 4 * HC;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / (4 * (size_t)HC);
+        const int col = (int)(idx - r * 4 * HC), which = col / HC, f = col - which * HC;
+        const T v = src[(size_t)(r % V) * 4 * HC + col];
+        const size_t node = (size_t)n_real + r;
+        if (qkvs) { qkvs[node * 4 * HC + col] = v; continue; }
+        if (which == 3) { S[node * HC + f] = v; continue; }
+        const int h = f / C, c = f - h * C;
+        T *dstb = which == 0 ? Q : (which == 1 ? K : Vt);
+        dstb[((size_t)h * n_pad + (size_t)row_map[node]) * C + c] = v;
+    }
+}
+
+int launch_scatter_virtual(int prec, int rows, int V, int H, int C, const void *src, int n_real, const int32_t *row_map,
+                           int n_pad, void *Q, void *K, void *Vt, void *S, void *qkvs, hipStream_t st) {
+    if (rows <= 0) return 0;
+    const size_t total = (size_t)rows * 4 * H * C;
+    const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (prec == DA_PREC_BF16)
+        k_scatter_virtual<bf16_t><<<grid, 256, 0, st>>>(rows, V, H, C, (const bf16_t *)src, n_real, row_map, (size_t)n_pad,
+                                                        (bf16_t *)Q, (bf16_t *)K, (bf16_t *)Vt, (bf16_t *)S, (bf16_t *)qkvs);
+    else
+        k_scatter_virtual<float><<<grid, 256, 0, st>>>(rows, V, H, C, (const float *)src, n_real, row_map, (size_t)n_pad,
+                                                       (float *)Q, (float *)K, (float *)Vt, (float *)S, (float *)qkvs);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace da

@@ -28,6 +28,8 @@ int launch_convert(int prec, size_t n, const float *src, void *dst, hipStream_t 
 int launch_transpose_f32(int rows, int cols, const float *src, float *dst, hipStream_t st);      // da_train.hip
 int launch_mm_nn_f32(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
                      int ldc, hipStream_t st);
+int launch_scatter_virtual(int prec, int rows, int V, int H, int C, const void *src, int n_real, const int32_t *row_map,
+                           int n_pad, void *Q, void *K, void *Vt, void *S, void *qkvs, hipStream_t st);
 int launch_head_fold(int prec, int n, int H, int c_out, const float *pz, const void *pre, const float *w2, const float *b2,
                      float *out, hipStream_t st);
 
