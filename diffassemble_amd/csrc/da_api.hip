@@ -252,7 +252,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                            : (alpha_all ? alpha + (size_t)l * g->n_edges * d->heads : (last ? alpha : nullptr));
         // last layer: the residual `feats + combined_feats` (efficient_gat.py:144) is fused in the epilogue
         const void *resid = (last && !fused) ? w.combined : nullptr;
-        if (last && fused && d->lastfold && !al && w.dq && !g->hybrid && dense_ok(g, d->heads, c.C)) {
+        if (last && fused && d->lastfold && !al && w.dq && (g->hybrid || d->V == 0) && dense_ok(g, d->heads, c.C)) {
             // folded last layer: Q | K | (V Wf_h^T) projection, 32-wide value heads, per-head outputs to pz
             QkvScatter qs;
             qs.HC = c.hc; qs.C = c.C; qs.Cv = 32; qs.n_pad = g->n_pad; qs.row_map = g->row_map;
@@ -266,9 +266,16 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                 L.Q = w.dq; L.K = w.dk; L.Vt = w.dvt; L.S = nullptr; L.n_pad = g->n_pad;
                 DenseFold fo;
                 fo.cv = 32; fo.out = w.pz; fo.n_rows = nr;
+                // hybrid graphs: adjacency-masked, remainder edges of the real rows folded in the epilogue; the
+                // virtual rows' outputs of the LAST layer are dropped by the model (exophormer_gnn.py:209), so the
+                // CSR-side kernels are not needed here
+                DenseMask mk;
+                mk.mask = g->mask; mk.mask_ptr = g->mask_ptr; mk.irr_row_ptr = g->irr_row_ptr;
+                mk.irr_col_src = g->irr_col_src; mk.row_map = g->row_map;
                 rc = timed(d, DA_PROF_ATTN_LAST, st, [&] {
                     return launch_attn_dense(prec, L, d->heads, c.C, g->n_graphs, g->max_graph_nodes, g->graph_ptr,
-                                             g->pad_ptr, g->dense == 2, nullptr, DA_ACT_NONE, nullptr, st, nullptr, &fo); });
+                                             g->pad_ptr, g->dense == 2, nullptr, DA_ACT_NONE, nullptr, st,
+                                             g->hybrid ? &mk : nullptr, &fo); });
                 if (rc > 0) return rc;
                 if (rc == 0) {
                     // pre-activation of final_mlp.0 from the hidden layer (mlp.2 share) and from this conv's input (skip share)
@@ -471,7 +478,7 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
             const int L = d->n_layers - 1, hcL = d->conv[L].hc, CL = d->conv[L].C, dinL = d->conv[L].din;
             static int off2 = -1;
             if (off2 < 0) { const char *e = getenv("DA_DISABLE_LAST_FOLD"); off2 = (e && e[0] == '1') ? 1 : 0; }
-            if (!off2 && d->arch == DA_ARCH_TRANSFORMER && CL == 144 && hcL == D && dinL % 32 == 0) {
+            if (!off2 && CL == 144 && hcL == D && dinL % 32 == 0) {
                 const int nf = 2 * hcL + H * 32;
                 float *lw = (float *)alloc((size_t)nf * dinL * 4);
                 float *sw = (float *)alloc((size_t)32 * dinL * 4);

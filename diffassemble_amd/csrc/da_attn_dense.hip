@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     // 8-byte piece in one of 32 different rows: that cost 25 % of the kernel.)
     const float lt = l + __shfl_xor(l, 32);
     const float inv = MASKED ? 1.0f : (lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f);
-    if (CV != C) {
+    if (CV != C && !MASKED) {
         // folded value heads: the caller projected V with the next linear layer's weight block of this head
         // (softmax(QK^T) (V W^T) == (softmax(QK^T) V) W^T), so the output is CV wide and goes out normalised,
         // per head, for the tail kernel to sum over heads -- no skip, no activation, no LDS staging
@@ -443,23 +443,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
         }
         return;
     }
-    constexpr int RSOF = C + 4;                                   // floats per staged row (16-B aligned, odd # of 16-B slots)
-    static_assert(CV != C || 128 * RSOF * 4 <= 2 * CF::STAGE, "O staging must fit in the K/V ring");
+    constexpr int CO = CV;                                        // width of the staged rows (= C unless the value heads are folded)
+    constexpr int RSOF = CO + 4;                                  // floats per staged row (16-B aligned, odd # of 16-B slots)
+    static_assert(128 * RSOF * 4 <= 2 * CF::STAGE, "O staging must fit in the K/V ring");
     float *so = (float *)smem;
     dma_barrier();                                              // ring no longer read by anyone
     DA_ATTN_DBG(if (p.debug & 16) return;)
     if (wave_on) {
         float *orow = so + (wid * 32 + i) * RSOF;
         if (MASKED && half == 0) {            // partial softmax state rides in the row's 4 spare floats
-            orow[C] = (m > -INFINITY) ? m * (p.sc * 0.6931471805599453f) : 0.f;
-            orow[C + 1] = lt;
+            orow[CO] = (m > -INFINITY) ? m * (p.sc * 0.6931471805599453f) : 0.f;
+            orow[CO + 1] = lt;
         }
 #pragma unroll
         for (int cb = 0; cb < CF::NCB; ++cb) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int c0 = cb * 32 + 8 * jj + 4 * half;
-                if (c0 >= C) continue;
+                if (c0 >= CO) continue;
                 *(f32x4 *)(orow + c0) = (f32x4){O[cb][4 * jj] * inv, O[cb][4 * jj + 1] * inv, O[cb][4 * jj + 2] * inv,
                                                O[cb][4 * jj + 3] * inv};
             }
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
         // group serves (rm_*) was fetched at kernel start, and the Q / K / V rows of all four first edges are
         // requested before any is consumed: the pass used to be a chain of ~5 dependent global loads per query.
         constexpr int NCK = CF::ROWB / 16, MAXT = (NCK + 7) / 8, EPK = 16 / CF::ES;
+        constexpr int NCKV = CF::ROWBV / 16, MAXTV = (NCKV + 7) / 8;       // V rows may be narrower (folded heads)
         const int sub = lane & 7;
         const float scale = p.sc * 0.6931471805599453f;          // 1 / sqrt(C)
         auto load_row = [&](const void *base, size_t row, u32x4 (&dst)[MAXT]) {
@@ -486,41 +488,51 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                 dst[t] = ck < NCK ? *(const u32x4 *)((const unsigned char *)base + row * CF::ROWB + ck * 16) : (u32x4){0u, 0u, 0u, 0u};
             }
         };
+        auto load_vrow = [&](size_t row, u32x4 (&dst)[MAXTV]) {
+#pragma unroll
+            for (int t = 0; t < MAXTV; ++t) {
+                const int ck = sub + 8 * t;
+                dst[t] = ck < NCKV ? *(const u32x4 *)((const unsigned char *)p.Vt + row * CF::ROWBV + ck * 16) : (u32x4){0u, 0u, 0u, 0u};
+            }
+        };
         if (wave_on) {
-            u32x4 qr[4][MAXT], kr[4][MAXT], vr[4][MAXT];
+            u32x4 qr[4][MAXT], kr[4][MAXT], vr[4][MAXTV];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qg = min(qt * 128 + wid * 32 + (lane >> 3) + 8 * r, n_g - 1);
                 load_row(p.Q, (size_t)h * np + pad0 + qg, qr[r]);
                 load_row(p.K, (size_t)h * np + rm_slot[r], kr[r]);
-                load_row(p.Vt, (size_t)h * np + rm_slot[r], vr[r]);
+                load_vrow((size_t)h * np + rm_slot[r], vr[r]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (rm_end[r] <= rm_beg[r]) continue;
                 const int ql = wid * 32 + (lane >> 3) + 8 * r;
                 float *orow = so + ql * RSOF;
-                float mm = orow[C], ll = orow[C + 1];
+                float mm = orow[CO], ll = orow[CO + 1];
                 if (!(ll > 0.f)) { mm = -INFINITY; ll = 0.f; }
-                float qv[MAXT][EPK], acc[MAXT][EPK];
+                float qv[MAXT][EPK], acc[MAXTV][EPK];
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t) {
                     unpack_chunk(T(), qr[r][t], qv[t]);
 #pragma unroll
-                    for (int x = 0; x < EPK; ++x) {
-                        qv[t][x] *= scale;
-                        acc[t][x] = (sub + 8 * t < NCK) ? orow[(sub + 8 * t) * EPK + x] : 0.f;
-                    }
+                    for (int x = 0; x < EPK; ++x) qv[t][x] *= scale;
                 }
+#pragma unroll
+                for (int t = 0; t < MAXTV; ++t)
+#pragma unroll
+                    for (int x = 0; x < EPK; ++x) acc[t][x] = (sub + 8 * t < NCKV) ? orow[(sub + 8 * t) * EPK + x] : 0.f;
                 for (int e = rm_beg[r]; e < rm_end[r]; ++e) {
-                    u32x4 k2[MAXT], v2[MAXT];
+                    u32x4 k2[MAXT], v2[MAXTV];
                     if (e > rm_beg[r]) {                              // beyond the prefetched first edge (rare)
                         const size_t sj = (size_t)h * np + (size_t)p.row_map[p.irr_col_src[e]];
                         load_row(p.K, sj, k2);
-                        load_row(p.Vt, sj, v2);
+                        load_vrow(sj, v2);
                     } else {
 #pragma unroll
-                        for (int t = 0; t < MAXT; ++t) { k2[t] = kr[r][t]; v2[t] = vr[r][t]; }
+                        for (int t = 0; t < MAXT; ++t) k2[t] = kr[r][t];
+#pragma unroll
+                        for (int t = 0; t < MAXTV; ++t) v2[t] = vr[r][t];
                     }
                     float sc_ = 0.f;
 #pragma unroll
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                     const float corr = expf(mm - mn), pe = expf(sc_ - mn);
                     ll = ll * corr + pe;
 #pragma unroll
-                    for (int t = 0; t < MAXT; ++t) {
+                    for (int t = 0; t < MAXTV; ++t) {
                         float vv[EPK];
                         unpack_chunk(T(), v2[t], vv);
 #pragma unroll
@@ -546,15 +558,26 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                     mm = mn;
                 }
 #pragma unroll
-                for (int t = 0; t < MAXT; ++t)
-                    if (sub + 8 * t < NCK) {
+                for (int t = 0; t < MAXTV; ++t)
+                    if (sub + 8 * t < NCKV) {
 #pragma unroll
                         for (int x = 0; x < EPK; ++x) orow[(sub + 8 * t) * EPK + x] = acc[t][x];
                     }
-                if (sub == 0) { orow[C] = mm; orow[C + 1] = ll; }
+                if (sub == 0) { orow[CO] = mm; orow[CO + 1] = ll; }
             }
         }
         __syncthreads();
+    }
+    if (CV != C) {                // MASKED + folded value heads: normalised per-head rows for the tail kernel
+        constexpr int CQ = CV / 4;
+        for (int it = tid; it < nq * CQ; it += 256) {
+            const int q = it / CQ, ch = it - q * CQ;
+            const float lr = so[q * RSOF + CO + 1];
+            const float ir = lr > 0.f ? 1.0f / (lr + 1e-16f) : 0.f;
+            const f32x4 a = *(const f32x4 *)(so + q * RSOF + ch * 4);
+            *(f32x4 *)(p.fold_out + ((size_t)h * p.n_rows + node0 + qt * 128 + q) * CV + ch * 4) = (f32x4){a[0] * ir, a[1] * ir, a[2] * ir, a[3] * ir};
+        }
+        return;
     }
     // batches of NB chunks per thread: all skip / residual loads of a batch are in flight before the
     // first one is consumed (a rolled load -> add -> store loop pays one L2/HBM latency per chunk)
@@ -585,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                     if (EPC == 8) { const f32x4 b2 = *(const f32x4 *)(src + 4); v[4] = b2[0]; v[5] = b2[1]; v[6] = b2[2]; v[7] = b2[3]; }
                 }
                 if (MASKED) {                                     // rows were staged un-normalised
-                    const float lr = so[q * RSOF + C + 1];
+                    const float lr = so[q * RSOF + CO + 1];
                     const float ir = lr > 0.f ? 1.0f / (lr + 1e-16f) : 0.f;
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) v[e] *= ir;
@@ -645,8 +668,9 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     if (nblocks <= 0) return 0;
     p.fold_out = nullptr; p.n_rows = 0;
     if (fold) {           // value heads folded to 32 channels (last layer of the 2D transformer arch)
-        if (C != 144 || fold->cv != 32 || mk) return -1;
+        if (C != 144 || fold->cv != 32) return -1;
         p.fold_out = fold->out; p.n_rows = fold->n_rows;
+        if (mk) return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, true, 32>(p, nblocks, st) : launch_tcm<float, 144, true, 32>(p, nblocks, st);
         return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, false, 32>(p, nblocks, st) : launch_tcm<float, 144, false, 32>(p, nblocks, st);
     }
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, nblocks, st) : launch_tc<bf16_t, 144>(p, nblocks, st);
