@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             const int key0 = kt * CF::BKEYS + kb * 32;
             if (key0 >= n_g) break;
             DA_TICK(tb_);
-            // ---- all LDS fragment reads of this 32-key block are issued up front (K for QK^T now, V^T
+            // ---- all LDS fragment reads of this 32-key block are issued up front (K for QK^T now, V
             // for PV later): the compiler otherwise pairs every two reads with a full lgkmcnt(0) wait
             // and the MFMA chain idles ~100 cycles per pair
             const unsigned mw = MASKED ? mw_cur[kb] : 0u;        // fetched one tile ahead (see the top of the loop)

@@ -53,7 +53,7 @@ class GraphPlan:
     col_src: torch.Tensor      # int32 [E]
     edge_id: torch.Tensor      # int32 [E]
     graph_ptr: torch.Tensor    # int32 [G + 1]
-    n_pad: int                 # dense mode: rows of the head-major Q/K/V^T buffers
+    n_pad: int                 # dense mode: rows of the head-major Q / K / V buffers
     pad_ptr: torch.Tensor      # int32 [G + 1] (64-aligned slot of each graph)
     row_map: torch.Tensor      # int32 [n_nodes] node -> padded row
     edge_index: torch.Tensor   # int64 [2, E] (extended for exophormer) -- returned with alpha
