@@ -112,3 +112,54 @@ def make_inputs(n_nodes, c_in, feat_dim, seed=0, rot=None):
 def randn(shape, seed):
     rng = np.random.default_rng(seed)
     return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+
+
+# ------------------------------------------------------------------------- piece encoder
+ENCODER_PLANES = (32, 64, 64, 128)     # resnet_equivariant.py:77-81 (in_planes 32, then 64, 64, 128)
+
+
+def encoder_conv_specs():
+    """(state-dict prefix, in planes, out planes, input stabilizer size, kernel, stride) of every group
+    convolution of the reference's ``ResNet18()`` (resnet_equivariant.py:14-38,70-91,113-114), in
+    forward order; each is followed by a BatchNorm3d under ``bn_key``."""
+    specs = [dict(conv="conv1", bn="bn1", cin=3, cout=32, stab=1, k=3, stride=1)]
+    cin = 32
+    for li, planes in enumerate(ENCODER_PLANES, start=1):
+        for bi in range(2):
+            stride = (1 if li == 1 else 2) if bi == 0 else 1
+            p = f"layer{li}.{bi}."
+            specs.append(dict(conv=p + "conv1", bn=p + "bn1", cin=cin, cout=planes, stab=4, k=3, stride=stride))
+            specs.append(dict(conv=p + "conv2", bn=p + "bn2", cin=planes, cout=planes, stab=4, k=3, stride=1))
+            if stride != 1 or cin != planes:
+                specs.append(dict(conv=p + "shortcut.0", bn=p + "shortcut.1", cin=cin, cout=planes, stab=4, k=1,
+                                  stride=stride))
+            cin = planes
+    return specs
+
+
+def make_encoder_state(seed=0):
+    """State dict with the key layout of the reference's equivariant ``ResNet18()``
+    (``Eff_GAT.visual_backbone`` when ``model='resnet18equiv'``).  Group-conv weights follow the
+    reference's init scale U(+-1/sqrt(in*k*k)) (splitgconv2d.py:52-59); the BatchNorm affine and RUNNING
+    statistics are randomised so that the eval-mode normalisation is pinned (the defaults 0 / 1 would
+    make it an identity)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for s in encoder_conv_specs():
+        bound = 1.0 / math.sqrt(s["cin"] * s["k"] * s["k"])
+        sd[s["conv"] + ".weight"] = _uniform(rng, (s["cout"], s["cin"], s["stab"], s["k"], s["k"]), bound)
+        c = s["cout"]
+        sd[s["bn"] + ".weight"] = torch.from_numpy(rng.uniform(0.6, 1.4, size=c).astype(np.float32))
+        sd[s["bn"] + ".bias"] = torch.from_numpy((0.1 * rng.standard_normal(c)).astype(np.float32))
+        sd[s["bn"] + ".running_mean"] = torch.from_numpy((0.1 * rng.standard_normal(c)).astype(np.float32))
+        sd[s["bn"] + ".running_var"] = torch.from_numpy(rng.uniform(0.5, 1.5, size=c).astype(np.float32))
+        sd[s["bn"] + ".num_batches_tracked"] = torch.tensor(100, dtype=torch.int64)
+    _linear(rng, sd, "linear1", 64 * 4 * 8 * 8, 544)
+    _linear(rng, sd, "linear2", 128 * 4 * 4 * 4, 544)
+    return sd
+
+
+def make_patches(n, seed=0):
+    """[n, 3, 32, 32] fp32 in [0, 1] (puzzle_dataset.py:290-299 hands the model 32x32 RGB crops)."""
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.uniform(0.0, 1.0, size=(n, 3, 32, 32)).astype(np.float32))
