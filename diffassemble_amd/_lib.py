@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -63,6 +63,18 @@ class DaSchedule(C.Structure):
     ]
 
 
+ENCODER_CONVS, ENCODER_FEATS = 19, 1088
+
+
+class DaEncoderWeights(C.Structure):
+    _fields_ = [
+        ("n_convs", C.c_int32), ("reserved0", C.c_int32),
+        ("stem_w", _fp), ("stem_b", _fp),
+        ("conv_w", _fp * ENCODER_CONVS), ("conv_b", _fp * ENCODER_CONVS),
+        ("lin1_w", _fp), ("lin1_b", _fp), ("lin2_w", _fp), ("lin2_b", _fp),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/diffassemble_hip.h declares
 PROTOTYPES = {
     "da_abi_version": (C.c_int, []),
@@ -92,6 +104,9 @@ PROTOTYPES = {
     "da_adafactor_step": (C.c_int, [C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_float,
                                     C.c_float, C.c_float, C.c_float, _fp]),
     "da_greedy_assign": (C.c_int, [C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),
+    "da_encoder_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "da_encoder_forward": (C.c_int, [C.c_int, C.POINTER(DaEncoderWeights), C.c_int, _fp, _fp, C.c_int, _fp, C.c_size_t,
+                                     C.c_int, C.c_int, _fp]),
     "da_train_backward": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp,
                                     _fp, C.c_size_t, _fp]),
 }

@@ -44,6 +44,31 @@ __device__ __forceinline__ void load4(const bf16_t *src, float v[4]) {
     v[2] = bf2f((bf16_t)(u[1] & 0xffff)); v[3] = bf2f((bf16_t)(u[1] >> 16));
 }
 
+// One K stage (128 bytes of K) of the 128 x 128 tile: A and W tiles share one LDS layout (128 rows x 128 B, 16-byte
+// chunks XOR-swizzled by row & 7); waves 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles.  Used by the linear kernel
+// (da_gemm_mfma.hip) and the implicit-GEMM group convolution (da_encoder.hip).
+template <typename T>
+__device__ __forceinline__ void mma_block(const unsigned char *sA, const unsigned char *sW, int wm, int wn, int lane,
+                                          f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        u32x4 fa[4], fw[4];
+        const int c = kk * 4 + (lane >> 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int Ra = wm * 64 + t * 16 + (lane & 15);
+            const int Rw = wn * 64 + t * 16 + (lane & 15);
+            fa[t] = *(const u32x4 *)(sA + Ra * 128 + ((c ^ (Ra & 7)) << 4));
+            fw[t] = *(const u32x4 *)(sW + Rw * 128 + ((c ^ (Rw & 7)) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);    // a lane owns one row, 4 consecutive features
+    }
+}
+
 struct GemmParams {
     int M, K, Nout;
     const void *A; int lda;

@@ -28,28 +28,6 @@
 
 namespace da {
 
-template <typename T>
-__device__ __forceinline__ void mma_block(const unsigned char *sA, const unsigned char *sW, int wm, int wn, int lane,
-                                          f32x4 (&acc)[4][4]) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        u32x4 fa[4], fw[4];
-        const int c = kk * 4 + (lane >> 4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int Ra = wm * 64 + t * 16 + (lane & 15);
-            const int Rw = wn * 64 + t * 16 + (lane & 15);
-            fa[t] = *(const u32x4 *)(sA + Ra * 128 + ((c ^ (Ra & 7)) << 4));
-            fw[t] = *(const u32x4 *)(sW + Rw * 128 + ((c ^ (Rw & 7)) << 4));
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);    // a lane owns one row, 4 consecutive features
-    }
-}
-
 // Padded-row positions of the rows this thread stores in the epilogue, fetched ONCE per workgroup (a
 // workgroup keeps its 128 rows for all its column tiles): a row_map load inside the epilogue is a
 // dependent global load on the critical path of every tile (measured: +60 % on the conv-3 projection).

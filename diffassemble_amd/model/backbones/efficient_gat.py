@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from ._denoiser_base import DenoiserBase
+from ._denoiser_base import DenoiserBase, default_precision
 from .exophormer_gnn import Exophormer_GNN
 from .Transformer_GNN import Transformer_GNN
 
@@ -20,7 +20,10 @@ class Eff_GAT(DenoiserBase):
         # piece encoder (efficient_gat.py:37-42): NOT on the per-timestep path;
         # built only when timm is importable, otherwise callers must pass patch_feats.
         self.visual_backbone = None
-        if model != "resnet18equiv":
+        if model == "resnet18equiv":
+            from .resnet_equivariant import ResNet18
+            self.visual_backbone = ResNet18()          # P4-equivariant ResNet-18, HIP kernels (eval mode)
+        else:
             try:
                 import timm
                 self.visual_backbone = timm.create_model(model, pretrained=visual_pretrained, features_only=True)
@@ -69,6 +72,12 @@ class Eff_GAT(DenoiserBase):
             raise NotImplementedError(
                 "no piece encoder available (timm / equivariant ResNet are outside the hot path): "
                 "pass precomputed patch_feats [N, 1088]")
+        if self.model == "resnet18equiv":
+            if self.all_equivariant:
+                raise NotImplementedError("all_equivariant=True (4 rotated crops per piece) is not built")
+            self.visual_backbone.precision = getattr(self, "precision", None) or default_precision()
+            feats = self.visual_backbone.patch_features(patch_rgb)    # normalise + encoder + cat, all in HIP
+            return feats.float()
         patch_rgb = (patch_rgb - self.mean) / self.std
         if self.freeze_backbone:
             with torch.no_grad():

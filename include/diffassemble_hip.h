@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 6
+#define DA_ABI_VERSION 7
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -296,6 +296,46 @@ int da_adafactor_step(int n_params, const void *param_table, int n_blocks, const
 int da_greedy_assign(int n_puzzles, const float *pos1, int ld1, const float *pos2, int ld2,
                      const int32_t *ptr1, const int32_t *ptr2, int max_n, int max_m, long long *out,
                      void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * 2D piece encoder: the P4 group-equivariant ResNet-18 the reference builds
+ * for model='resnet18equiv', eval-mode BatchNorm.  Replaces Eff_GAT.visual_features
+ * (backbones/efficient_gat.py:149-189) = normalise + ResNet.forward (backbones/resnet_equivariant.py:
+ * 93-112) + cat(linear1(out3), linear2(out4)), whose convolutions are groupy's SplitGConv2D
+ * (backbones/groupy/gconv/pytorch_gconv/splitgconv2d.py:15-22,70-92).
+ *
+ * da_encoder_weights holds the PACKED weights (device pointers; built once per checkpoint by the
+ * host, diffassemble_amd/encoder.py, from the reference's state-dict tensors):
+ *   stem_w [128][27] fp32   rotated filter bank of conv1 (channel o*4+r; taps c*9+ky*3+kx), bn1 folded
+ *   stem_b [128]     fp32   folded bn1 bias
+ *   conv_w[i] [Cout*4][k*k*Cin*4] act dtype, i in state-dict order (layerL.B.conv1, conv2[, shortcut.0]):
+ *             filter bank with the BatchNorm scale folded, K ordered tap-major / channel-minor (NHWC)
+ *   conv_b[i] [Cout*4] fp32
+ *   lin1_w [544][10*10*256], lin2_w [544][6*6*512] act dtype: linear1 / linear2 re-indexed from the
+ *             reference's NCHW flatten to the zero-haloed NHWC maps (halo columns are zero); biases fp32.
+ * ------------------------------------------------------------------------------------- */
+enum { DA_ENCODER_CONVS = 19, DA_ENCODER_FEATS = 1088 };
+typedef struct da_encoder_weights {
+    int32_t n_convs;                         /* DA_ENCODER_CONVS                              */
+    int32_t reserved0;
+    const float *stem_w, *stem_b;
+    const void *conv_w[DA_ENCODER_CONVS];
+    const float *conv_b[DA_ENCODER_CONVS];
+    const void *lin1_w; const float *lin1_b;
+    const void *lin2_w; const float *lin2_b;
+} da_encoder_weights;
+
+/* Workspace for n_patches pieces processed `chunk` at a time (activations of one chunk + the
+ * layer-3 / layer-4 maps of all pieces). */
+size_t da_encoder_workspace_bytes(int precision, int n_patches, int chunk);
+
+/* patches [n_patches, 3, 32, 32] fp32 in [0, 1] -> feats [n_patches, 1088] (act dtype, row stride
+ * ld_feats elements).  The feature maps carry a zero halo that the kernels never write: pass
+ * zero_workspace != 0 on the first call with a (new or foreign-written) workspace, 0 afterwards
+ * as long as (precision, n_patches, chunk) stay the same.  Stream-capturable. */
+int da_encoder_forward(int precision, const da_encoder_weights *w, int n_patches, const float *patches,
+                       void *feats, int ld_feats, void *workspace, size_t workspace_bytes, int chunk,
+                       int zero_workspace, void *stream);
 
 #ifdef __cplusplus
 }
