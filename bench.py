@@ -137,6 +137,96 @@ def train_bench(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def encoder_flops_per_piece():
+    """Algorithmic FLOPs (mul + add = 2) of the reference's encoder for ONE 32x32 piece: the conv2d calls
+    SplitGConv2D issues on [B, C*4, H, W] (resnet_equivariant.py ResNet18: planes 32, 64, 64, 128; 4
+    rotations) + linear1 / linear2."""
+    f = 32 * 32 * 128 * 3 * 9 * 2                                    # stem P4ConvZ2(3 -> 32)
+    cin, h = 128, 32
+    for cout, stride in ((128, 1), (256, 2), (256, 2), (512, 2)):
+        ho = h // stride
+        f += ho * ho * cout * cin * 9 * 2                            # block 0 conv1
+        f += ho * ho * cout * cout * 9 * 2 * 3                       # block 0 conv2, block 1 conv1 / conv2
+        if stride != 1:
+            f += ho * ho * cout * cin * 2                            # 1x1 shortcut
+        cin, h = cout, ho
+    return f + 2 * 544 * (64 * 4 * 8 * 8 + 128 * 4 * 4 * 4)
+
+
+def encode_bench(args, world, rank, dev):
+    """the P4 ResNet-18 piece encoder (model='resnet18equiv'), eval mode: one "step" =
+    the 32x32 crops of `--puzzles` 900-piece puzzles -> patch_feats [N, 1088].  Runs once per sampling loop
+    in the reference (spatial_diffusion.py:653)."""
+    import torch.distributed as dist
+    from diffassemble_amd import sharding as S
+    from diffassemble_amd.model.backbones.resnet_equivariant import ResNet18
+    G, K, Wm = args.puzzles, args.steps, args.warmup
+    n = G * N_PIECES
+    torch.manual_seed(0)
+    net = ResNet18(precision=args.precision).to(dev).eval()
+    with torch.no_grad():                      # non-trivial running statistics (a fresh BatchNorm is an identity)
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm3d):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+    eng = net.engine()
+    if args.chunk:
+        eng.chunk = args.chunk
+    x = torch.rand((n, 3, 32, 32), generator=torch.Generator(device=dev).manual_seed(5 + rank), device=dev)
+    out = torch.empty((n, 1088), dtype=eng.act_dtype, device=dev)
+    for _ in range(max(Wm, 1)):
+        eng.forward(x, out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(K):
+        eng.forward(x, out)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = S.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(out.float()).all()
+    if rank == 0:
+        fl = encoder_flops_per_piece()
+        ms_dev = e0.elapsed_time(e1) / K
+        peak = 2500.0 if args.precision == "bf16" else 157.3
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import encoder as OE
+            sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+            threads = os.cpu_count() or 1
+            torch.set_num_threads(threads)
+            xs = x[:256].cpu()
+            OE.visual_features(sd, xs[:32])
+            tc = time.perf_counter()
+            OE.visual_features(sd, xs)
+            dc = time.perf_counter() - tc
+            cpu = {"value": 256 / dc, "unit": "pieces/s", "cores": threads, "kind": "port",
+                   "sample": f"256 pieces through oracle/encoder.py (torch fp32 conv2d), {dc:.1f} s"}
+        print(json.dumps({
+            "metric": "piece encoder throughput (P4 ResNet-18, 32x32 crops, eval)",
+            "value": world * n * K / dt, "unit": "pieces/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "32x32 RGB crops of 900-piece puzzles -> patch_feats [N, 1088], model='resnet18equiv'",
+                       "puzzles_per_gpu": G, "pieces_per_gpu": n, "chunk": eng._ws_key[1],
+                       "parallelism": f"puzzle-sharded x{world}"},
+            "gflop_per_piece": fl / 1e9,
+            "roofline": {"bound": "mfma", "achieved": n * fl / (ms_dev * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                         "frac": n * fl / (ms_dev * 1e-3) / 1e12 / peak, "traffic": None,
+                         "kernel": "whole encoder pass (19 k_conv_mfma launches per chunk dominate)",
+                         "ms_device": ms_dev},
+            "cpu_baseline": cpu,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,8 +235,11 @@ def main():
     ap.add_argument("--puzzles", type=int, default=int(os.environ.get("BENCH_PUZZLES", 32)),
                     help="independent 900-piece puzzles per GPU (the batch of one step)")
     ap.add_argument("--precision", default=os.environ.get("BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"])
-    ap.add_argument("--mode", default=os.environ.get("BENCH_MODE", "sample"), choices=["sample", "train"],
-                    help="sample = the headline metric (default); train = BASELINE config 5 (one optimizer step)")
+    ap.add_argument("--mode", default=os.environ.get("BENCH_MODE", "sample"), choices=["sample", "train", "encode"],
+                    help="sample = the headline metric (default); train = BASELINE config 5 (one optimizer step); "
+                         "encode = the piece encoder (SURVEY 8f rank 2)")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("BENCH_ENCODER_CHUNK", 0)),
+                    help="--mode encode: pieces per encoder chunk (0 = engine default)")
     ap.add_argument("--train-puzzles", type=int, default=int(os.environ.get("BENCH_TRAIN_PUZZLES", 64)),
                     help="--mode train: 12x12 puzzles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,6 +259,8 @@ def main():
 
     if args.mode == "train":
         return train_bench(args, world, rank, dev)
+    if args.mode == "encode":
+        return encode_bench(args, world, rank, dev)
 
     from diffassemble_amd import _lib
     from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType

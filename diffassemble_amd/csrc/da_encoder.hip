@@ -38,13 +38,15 @@ __device__ __forceinline__ u32x4 add_relu8(u32x4 a, u32x4 b, bool relu, float) {
     return __builtin_bit_cast(u32x4, x);
 }
 __device__ __forceinline__ u32x4 add_relu8(u32x4 a, u32x4 b, bool relu, bf16_t) {         // bf16: 8 values
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float lo = bf2f((bf16_t)(a[i] & 0xffff)) + bf2f((bf16_t)(b[i] & 0xffff));
-        float hi = bf2f((bf16_t)(a[i] >> 16)) + bf2f((bf16_t)(b[i] >> 16));
+        float lo = __builtin_bit_cast(float, a[i] << 16) + __builtin_bit_cast(float, b[i] << 16);
+        float hi = __builtin_bit_cast(float, a[i] & 0xffff0000u) + __builtin_bit_cast(float, b[i] & 0xffff0000u);
         if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-        o[i] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+        const bf16x2 pk = {(__bf16)lo, (__bf16)hi};              // v_cvt_pk_bf16_f32 (round to nearest even)
+        o[i] = __builtin_bit_cast(unsigned, pk);
     }
     return o;
 }
@@ -93,6 +95,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
     };
     issue(0);
 
+    // the residual tile is fetched NOW, in the layout of the coalesced store phase, and sits in registers
+    // under the whole K walk (fetched in the epilogue it was a serial 100+ us tail on the 32x32 layers)
+    const bool relu = p.relu != 0, has_res = p.res != nullptr;
+    size_t ooff[PASSES][NIT];
+    u32x4 rv[PASSES][NIT];
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
+            const int m = min(row0 + row + pass * ROWS, p.M - 1), col = col0 + ch * EPC;
+            const int b = m >> (p.lgHo + p.lgWo), y = (m >> p.lgWo) & (Ho - 1), x = m & (Wo - 1);
+            ooff[pass][it] = (((size_t)b * (Ho + 2) + (y + 1)) * (Wo + 2) + (x + 1)) * p.Cout + col;
+            rv[pass][it] = (u32x4){0u, 0u, 0u, 0u};
+            if (has_res) rv[pass][it] = *(const u32x4 *)((const T *)p.res + ooff[pass][it]);
+        }
+
     float bz[4][4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -106,7 +125,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int s = 0; s < nk; ++s) {
-        dma_barrier();                       // own DMA landed + everyone done with the other slot
+        // own DMA landed + everyone done with the other slot.  vmcnt retires in order and the residual loads
+        // were issued AFTER the stage-0 DMA: the first wait may leave exactly those in flight (they are
+        // covered by the wait of stage 1, a whole MFMA stage later).
+        if (s == 0 && has_res) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PASSES * NIT) : "memory");
+            __syncthreads();
+        } else {
+            dma_barrier();
+        }
         if (s + 1 < nk) issue(s + 1);
         const unsigned char *sA = smem + (s & 1) * 32768;
         mma_block<T>(sA, sA + 16384, wm, wn, lane, acc);
@@ -115,7 +142,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
     // epilogue: (+ folded BatchNorm bias) -> LDS -> coalesced 16-byte stores of whole pixel rows, the
     // residual is added (and the ReLU applied) on the coalesced side
     unsigned char *stg = smem + ((nk - 1) & 1) * 32768;
-    const bool relu = p.relu != 0, has_res = p.res != nullptr;
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         dma_barrier();
@@ -138,13 +164,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
-            const int m = row0 + row + pass * ROWS, col = col0 + ch * EPC;
-            if (m >= p.M) continue;
+            if (row0 + row + pass * ROWS >= p.M) continue;
             u32x4 val = *(const u32x4 *)(stg + row * RSO + ch * 16);
-            const int b = m >> (p.lgHo + p.lgWo), y = (m >> p.lgWo) & (Ho - 1), x = m & (Wo - 1);
-            const size_t off = (((size_t)b * (Ho + 2) + (y + 1)) * (Wo + 2) + (x + 1)) * p.Cout + col;
-            if (has_res) val = add_relu8(val, *(const u32x4 *)((const T *)p.res + off), relu, T());
-            *(u32x4 *)((T *)p.Y + off) = val;
+            if (has_res) val = add_relu8(val, rv[pass][it], relu, T());
+            *(u32x4 *)((T *)p.Y + ooff[pass][it]) = val;
         }
     }
 }
