@@ -98,3 +98,31 @@ def test_eff_gat_forward_from_pixels(dev):
             m.visual_features(patches.to(dev))
     finally:
         _os.environ.pop("DIFFASSEMBLE_PRECISION", None)
+
+
+def test_sampling_loop_from_pixels(dev):
+    """GNN_Diffusion(backbone='resnet18equiv').p_sample_loop(shape, cond = piece crops, ...): the encoder runs
+    once (spatial_diffusion.py:653), then the hipGraph DDIM loop; against oracle encoder + oracle loop."""
+    from oracle import diffusion as ODF
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    T, ratio, n = 100, 10, 64
+    m = GNN_Diffusion(steps=T, sampling="DDIM", inference_ratio=ratio, noise_weight=1.0, rotation=True,
+                      model_mean_type=ModelMeanType.START_X, visual_pretrained=False, backbone="resnet18equiv")
+    dsd, esd = W.make_denoiser_state(T, 4, 4, seed=21), W.make_encoder_state(21)
+    missing, unexpected = m.model.load_state_dict({**dsd, **{"visual_backbone." + k: v for k, v in esd.items()}}, strict=False)
+    assert not unexpected, unexpected
+    m = m.to(dev).eval()
+    m.model.precision = "fp32"
+    patches = W.make_patches(n, 3)
+    ei, batch = W.dense_edge_index(n, True), torch.zeros(n, dtype=torch.int64)
+    x0 = torch.from_numpy(np.random.default_rng(8).standard_normal((n, 4)).astype(np.float32))
+    _orig = torch.randn
+    torch.randn = lambda *a, **k: x0.to(dev)
+    try:
+        imgs, _ = m.p_sample_loop((n, 4), patches.to(dev), ei.to(dev), batch.to(dev))
+    finally:
+        torch.randn = _orig
+    feats = OE.visual_features(esd, patches)
+    ref, _ = ODF.p_sample_loop(dsd, ODF.make_schedule(T), x0, ei, feats, batch, T, inference_ratio=ratio)
+    assert len(imgs) == len(ref) == 10
+    assert rel(torch.stack(imgs), torch.stack(ref)) < 5e-4
