@@ -100,7 +100,7 @@ class EncoderEngine:
     def _chunk_for(self, n):
         if self.chunk:
             return int(self.chunk)
-        return 512 if n >= 512 else max(8, (n + 7) // 8 * 8)
+        return 1024 if n >= 1024 else max(8, (n + 7) // 8 * 8)
 
     def forward(self, patches, out=None):
         """patches [N, 3, 32, 32] fp32 in [0, 1] (device) -> patch_feats [N, 1088] in the act dtype."""
