@@ -17,6 +17,8 @@
 //   * the 3-channel stem is a VALU kernel (K = 27), the two 544-wide output linears run through the MFMA
 //     linear kernel straight on the haloed NHWC maps (halo columns of the packed weights are zero).
 // Patches are processed in chunks so the working set of the 32x32 stage stays near the Infinity Cache.
+#include <stdlib.h>
+
 #include "da_gemm_common.h"
 
 namespace da {
@@ -28,6 +30,8 @@ struct ConvParams {
     int Cout, lgHo, lgWo, stride, taps, relu;
     int M;                                  // B * Ho * Wo output pixels
     int nct, lgcpt;                         // column tiles; log2(K stages per tap)
+    int nvirt;                              // virtual tiles: 8 * ceil(pixel tiles / 8) * nct
+    int debug;                              // DA_ENCODER_DEBUG bits (timing experiments only): 1 = no A DMA, 2 = no W DMA, 4 = no MFMA
     long long tap0;                         // element offset of tap 0 from the pixel's base: 0 (3x3, pad 1) | (Wpi + 1) * Cin (1x1, pad 0)
 };
 
@@ -51,124 +55,171 @@ __device__ __forceinline__ u32x4 add_relu8(u32x4 a, u32x4 b, bool relu, bf16_t) 
     return o;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 128 * 128];
+// WM = waves along the pixel dimension: 2 -> 128-pixel tiles, 256 threads, two workgroups per CU (default);
+//      4 -> 256-pixel tiles, 512 threads, one workgroup per CU (same 2 waves per SIMD; experiment, slower).
+// What bounds it (ablation on the 32x32 layers, DA_ENCODER_DEBUG): DMA stream alone 325 us, MFMA + fragment
+// reads alone 241 us, everything 351 us, barriers + epilogue alone 102 us -- the K walk waits on the LATENCY
+// of the one DMA stage it has in flight (a stage is ~0.45 us of MFMA, an L2 round trip under load is longer),
+// not on the matrix pipe.  A third LDS slot does not fit twice per CU; see DESIGN.md 3d for what is next.
+template <typename T, int WM>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void k_conv_mfma(ConvParams p) {
+    constexpr int TM = WM * 64, NT = WM * 128, SB = (TM + 128) * 128;       // tile rows, threads, bytes per stage
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SB];
     const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware (pixel tile, channel tile) mapping: the channel tiles of one pixel tile re-read the same
-    // im2col rows, so they run on the same XCD (workgroups are dispatched round-robin over the 8 XCDs)
-    const int xc = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    const int by = xc + 8 * (sq / p.nct), bx = sq % p.nct;
-    if (by * 128 >= p.M) return;
-    const int row0 = by * 128, col0 = bx * 128;
     constexpr int ES = (int)sizeof(T), EPC = 16 / ES, BK = 128 / ES;
-    constexpr int ROWS = ES == 4 ? 32 : 64, PASSES = 128 / ROWS, CPR = 128 * ES / 16, NIT = ROWS * CPR / 256;
+    constexpr int ROWS = ES == 4 ? 32 : 64, PASSES = TM / ROWS, CPR = 128 * ES / 16, NIT = ROWS * CPR / NT;
+    constexpr int WJ = 128 / (2 * WM) / 8;       // W-tile DMA instructions per wave per stage (8 rows each)
     constexpr int RSO = 128 * ES + 16;
+    constexpr bool PREFETCH = ES == 2;           // fp32 (parity mode): 64 more registers would spill; fetched in the epilogue
     const int Ho = 1 << p.lgHo, Wo = 1 << p.lgWo;
     const int K = p.taps * p.Cin;
-
-    const int lr = lane >> 3, lc = (lane & 7) ^ lr;
-    const char *ap[4], *wp[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = min(row0 + 32 * wid + 8 * j + lr, p.M - 1);
-        const int b = m >> (p.lgHo + p.lgWo), y = (m >> p.lgWo) & (Ho - 1), x = m & (Wo - 1);
-        const size_t px = ((size_t)b * p.Hpi + (size_t)(y * p.stride)) * p.Wpi + (size_t)(x * p.stride);
-        ap[j] = (const char *)p.X + (px * p.Cin + (size_t)p.tap0) * ES + lc * 16;
-        wp[j] = (const char *)p.W + (size_t)min(col0 + 32 * wid + 8 * j + lr, p.Cout - 1) * K * ES + lc * 16;
-    }
     const int nk = p.taps << p.lgcpt;
+    const bool relu = p.relu != 0, has_res = p.res != nullptr;
+    const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+
+    // PERSISTENT workgroups: 2 per CU, each walks virtual tiles v, v + grid, ...  A tile's first K stage is put
+    // in flight BEFORE the previous tile's epilogue and its stores drain under the next tile's K walk; with one
+    // tile per workgroup all co-resident workgroups ran their (HBM-bound) prologue and epilogue phases in
+    // lock step and memory time simply added to MFMA time.
+    // Virtual tile -> (pixel tile, channel tile), XCD-aware: the channel tiles of one pixel tile re-read the same
+    // im2col rows, so they sit on the same XCD (workgroups are dispatched round-robin over the 8 XCDs and the
+    // grid is a multiple of 8 * nct, so a workgroup's XCD and channel tile never change).
+    const int V = p.nvirt;
+    auto valid = [&](int v) { const int sq = v >> 3; return ((v & 7) + 8 * (sq / p.nct)) * TM < p.M; };
+    int v = blockIdx.x;
+    while (v < V && !valid(v)) v += gridDim.x;
+    if (v >= V) return;
+    const int col0 = ((v >> 3) % p.nct) * 128;
+
+    unsigned ap[4], wp[WJ];                   // byte offsets from p.X / p.W (a chunk's maps stay below 4 GB, see launch_conv)
+    int row0 = 0;
+    auto setup = [&](int vv) {
+        row0 = ((vv & 7) + 8 * ((vv >> 3) / p.nct)) * TM;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = min(row0 + 32 * wid + 8 * j + lr, p.M - 1);
+            const int b = m >> (p.lgHo + p.lgWo), y = (m >> p.lgWo) & (Ho - 1), x = m & (Wo - 1);
+            const size_t px = ((size_t)b * p.Hpi + (size_t)(y * p.stride)) * p.Wpi + (size_t)(x * p.stride);
+            ap[j] = (unsigned)((px * p.Cin + (size_t)p.tap0) * ES + lc * 16);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < WJ; ++j)
+        wp[j] = (unsigned)((size_t)min(col0 + 8 * WJ * wid + 8 * j + lr, p.Cout - 1) * K * ES + lc * 16);
     auto issue = [&](int s) {
         const int tap = s >> p.lgcpt, cb = s - (tap << p.lgcpt);
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;              // tap / 3 for tap < 9
-        const size_t aoff = ((size_t)(ky * p.Wpi + kx) * p.Cin + (size_t)cb * BK) * ES;
-        const size_t woff = (size_t)s * 128;
-        unsigned char *sa = smem + (s & 1) * 32768 + (32 * wid) * 128, *sw = sa + 16384;
+        const char *xa = (const char *)p.X + ((size_t)(ky * p.Wpi + kx) * p.Cin + (size_t)cb * BK) * ES;
+        const char *xw = (const char *)p.W + (size_t)s * 128;
+        unsigned char *sa = smem + (s & 1) * SB + (32 * wid) * 128, *sw = smem + (s & 1) * SB + TM * 128 + (8 * WJ * wid) * 128;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ap[j] + aoff),
+        for (int j = 0; j < 4; ++j)
+            if (!(p.debug & 1))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xa + ap[j]),
                                              (__attribute__((address_space(3))) void *)(sa + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wp[j] + woff),
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+            if (!(p.debug & 2))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xw + wp[j]),
                                              (__attribute__((address_space(3))) void *)(sw + j * 1024), 16, 0, 0);
-        }
     };
-    issue(0);
-
-    // the residual tile is fetched NOW, in the layout of the coalesced store phase, and sits in registers
-    // under the whole K walk (fetched in the epilogue it was a serial 100+ us tail on the 32x32 layers)
-    const bool relu = p.relu != 0, has_res = p.res != nullptr;
-    size_t ooff[PASSES][NIT];
+    // output offsets / residual tile in the layout of the coalesced store phase; the residual is fetched at the
+    // START of a tile and sits in registers under its whole K walk
+    unsigned ooff[PASSES][NIT];              // element offsets into p.Y / p.res
     u32x4 rv[PASSES][NIT];
+    int orow0 = 0;
+    auto fetch_res = [&]() {
+        orow0 = row0;
 #pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass)
+        for (int pass = 0; pass < PASSES; ++pass)
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
-            const int m = min(row0 + row + pass * ROWS, p.M - 1), col = col0 + ch * EPC;
-            const int b = m >> (p.lgHo + p.lgWo), y = (m >> p.lgWo) & (Ho - 1), x = m & (Wo - 1);
-            ooff[pass][it] = (((size_t)b * (Ho + 2) + (y + 1)) * (Wo + 2) + (x + 1)) * p.Cout + col;
-            rv[pass][it] = (u32x4){0u, 0u, 0u, 0u};
-            if (has_res) rv[pass][it] = *(const u32x4 *)((const T *)p.res + ooff[pass][it]);
-        }
-
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * NT, row = idx / CPR, ch = idx - row * CPR;
+                const int m = min(row0 + row + pass * ROWS, p.M - 1), col = col0 + ch * EPC;
+                const int b = m >> (p.lgHo + p.lgWo), y = (m >> p.lgWo) & (Ho - 1), x = m & (Wo - 1);
+                ooff[pass][it] = (unsigned)((((size_t)b * (Ho + 2) + (y + 1)) * (Wo + 2) + (x + 1)) * p.Cout + col);
+                rv[pass][it] = (u32x4){0u, 0u, 0u, 0u};
+                if (PREFETCH && has_res) rv[pass][it] = *(const u32x4 *)((const T *)p.res + ooff[pass][it]);
+            }
+    };
     float bz[4][4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const f32x4 b4 = *(const f32x4 *)(p.bias + col0 + wn * 64 + ni * 16 + (lane >> 4) * 4);
         bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3];
     }
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int s = 0; s < nk; ++s) {
-        // own DMA landed + everyone done with the other slot.  vmcnt retires in order and the residual loads
-        // were issued AFTER the stage-0 DMA: the first wait may leave exactly those in flight (they are
-        // covered by the wait of stage 1, a whole MFMA stage later).
-        if (s == 0 && has_res) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PASSES * NIT) : "memory");
-            __syncthreads();
-        } else {
-            dma_barrier();
+    setup(v);
+    issue(0);
+    fetch_res();
+    const bool pre_issue = (nk & 1) == 0;        // stage 0 of the next tile lands in slot 0, the staging area is slot (nk - 1) & 1
+    for (;;) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int s = 0; s < nk; ++s) {
+            // own DMA landed + everyone done with the other slot.  vmcnt retires in order and the residual loads
+            // were issued AFTER the stage-0 DMA: the first wait may leave exactly those in flight (they are
+            // covered by the wait of stage 1, a whole MFMA stage later).
+            if (PREFETCH && s == 0 && has_res) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PASSES * NIT) : "memory");
+                __syncthreads();
+            } else {
+                dma_barrier();
+            }
+            if (s + 1 < nk) issue(s + 1);
+            const unsigned char *sA = smem + (s & 1) * SB;
+            if (!(p.debug & 4)) mma_block<T>(sA, sA + TM * 128, wm, wn, lane, acc);
         }
-        if (s + 1 < nk) issue(s + 1);
-        const unsigned char *sA = smem + (s & 1) * 32768;
-        mma_block<T>(sA, sA + 16384, wm, wn, lane, acc);
-    }
 
-    // epilogue: (+ folded BatchNorm bias) -> LDS -> coalesced 16-byte stores of whole pixel rows, the
-    // residual is added (and the ReLU applied) on the coalesced side
-    unsigned char *stg = smem + ((nk - 1) & 1) * 32768;
+        int vn = v + gridDim.x;
+        while (vn < V && !valid(vn)) vn += gridDim.x;
+        const bool more = vn < V;
+        if (more) {
+            setup(vn);                                   // every DMA of this tile has been issued: ap[] is free
+            if (pre_issue) { __syncthreads(); issue(0); }   // slot 0: everyone is past its last read (stage nk - 2)
+        }
+
+        // epilogue: (+ folded BatchNorm bias) -> LDS -> coalesced 16-byte stores of whole pixel rows, the
+        // residual is added (and the ReLU applied) on the coalesced side.  Plain barriers: the only DMA in
+        // flight is the next tile's stage 0, which must NOT be waited for here.
+        unsigned char *stg = smem + ((nk - 1) & 1) * SB;
 #pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        dma_barrier();
+        for (int pass = 0; pass < PASSES; ++pass) {
+            __syncthreads();
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+            for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int rg = wm * 64 + mi * 16 + (lane & 15);
-                if (rg / ROWS != pass) continue;                // wave-uniform
-                float v[4];
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int rg = wm * 64 + mi * 16 + (lane & 15);
+                    if (rg / ROWS != pass) continue;                // wave-uniform
+                    float vv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[mi][ni][r] + bz[ni][r];
-                    if (relu && !has_res) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) {
+                        vv[r] = acc[mi][ni][r] + bz[ni][r];
+                        if (relu && !has_res) vv[r] = fmaxf(vv[r], 0.f);
+                    }
+                    store4((T *)(stg + (rg % ROWS) * RSO) + wn * 64 + ni * 16 + (lane >> 4) * 4, vv);
                 }
-                store4((T *)(stg + (rg % ROWS) * RSO) + wn * 64 + ni * 16 + (lane >> 4) * 4, v);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * NT, row = idx / CPR, ch = idx - row * CPR;
+                if (orow0 + row + pass * ROWS >= p.M) continue;
+                u32x4 val = *(const u32x4 *)(stg + row * RSO + ch * 16);
+                if (has_res) val = add_relu8(val, PREFETCH ? rv[pass][it] : *(const u32x4 *)((const T *)p.res + ooff[pass][it]), relu, T());
+                *(u32x4 *)((T *)p.Y + ooff[pass][it]) = val;
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
-            if (row0 + row + pass * ROWS >= p.M) continue;
-            u32x4 val = *(const u32x4 *)(stg + row * RSO + ch * 16);
-            if (has_res) val = add_relu8(val, rv[pass][it], relu, T());
-            *(u32x4 *)((T *)p.Y + ooff[pass][it]) = val;
-        }
+        if (!more) break;
+        v = vn;
+        if (!pre_issue) { __syncthreads(); issue(0); }
+        fetch_res();
     }
 }
 
@@ -228,12 +279,28 @@ static int launch_conv(int prec, int B, const void *X, int Cin, int Hi, const vo
     p.Cout = Cout; p.lgHo = lg2(Ho); p.lgWo = p.lgHo; p.stride = stride; p.taps = ksize * ksize; p.relu = relu;
     p.M = B * Ho * Ho; p.nct = Cout / 128; p.lgcpt = lg2(Cin / BK);
     p.tap0 = ksize == 3 ? 0 : (long long)(p.Wpi + 1) * Cin;
+    DA_REQUIRE((size_t)B * (Hi + 2) * (Hi + 2) * Cin * es < ((size_t)1 << 32) && (size_t)B * (Ho + 2) * (Ho + 2) * Cout * es < ((size_t)1 << 32),
+               "encoder conv: a chunk's feature map must stay below 4 GB (32-bit offsets): use a smaller chunk");
     DA_REQUIRE(Cin % BK == 0 && (1 << p.lgcpt) == Cin / BK && Cout % 128 == 0 && (1 << p.lgHo) == Ho && (ksize == 1 || ksize == 3),
                "encoder conv: unsupported geometry (Cin %d Cout %d H %d k %d)", Cin, Cout, Hi, ksize);
-    const int nrt = (p.M + 127) / 128;
-    const unsigned grid = (unsigned)(8 * ((nrt + 7) / 8) * p.nct);
-    if (prec == DA_PREC_BF16) k_conv_mfma<bf16_t><<<grid, 256, 0, st>>>(p);
-    else k_conv_mfma<float><<<grid, 256, 0, st>>>(p);
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("DA_ENCODER_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
+    static int big = -1;
+    if (big < 0) { const char *e = getenv("DA_ENCODER_WIDE_TILES"); big = (e && e[0] == '1') ? 1 : 0; }
+    // 256-pixel tiles (8 waves, DA_ENCODER_WIDE_TILES=1) measured SLOWER than two independent 128-pixel workgroups
+    // per CU (370 vs 346 us on the 32x32 layers): kept switchable for experiments, off by default
+    const bool wide = prec == DA_PREC_BF16 && big && (long long)((p.M + 255) / 256) * p.nct >= 256;
+    const int TMh = wide ? 256 : 128;
+    const int nrt = (p.M + TMh - 1) / TMh;
+    p.nvirt = 8 * ((nrt + 7) / 8) * p.nct;
+    static int per_cu = -1;
+    if (per_cu < 0) { const char *e = getenv("DA_ENCODER_WG_PER_CU"); per_cu = e ? atoi(e) : 2; if (per_cu < 1) per_cu = 1000000; }
+    // persistent: at most 256 CUs x 2 resident workgroups, a multiple of 8 * nct (see the kernel)
+    long long cap = (long long)256 * (wide ? (per_cu + 1) / 2 : per_cu) / (8 * p.nct) * (8 * p.nct);
+    if (cap < 8 * p.nct) cap = 8 * p.nct;
+    const unsigned grid = (unsigned)(p.nvirt < cap ? p.nvirt : cap);
+    if (wide) k_conv_mfma<bf16_t, 4><<<grid, 512, 0, st>>>(p);
+    else if (prec == DA_PREC_BF16) k_conv_mfma<bf16_t, 2><<<grid, 256, 0, st>>>(p);
+    else k_conv_mfma<float, 2><<<grid, 256, 0, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
 }
