@@ -55,22 +55,29 @@ __device__ __forceinline__ u32x4 add_relu8(u32x4 a, u32x4 b, bool relu, bf16_t) 
     return o;
 }
 
-// WM = waves along the pixel dimension: 2 -> 128-pixel tiles, 256 threads, two workgroups per CU (default);
-//      4 -> 256-pixel tiles, 512 threads, one workgroup per CU (same 2 waves per SIMD; experiment, slower).
-// What bounds it (ablation on the 32x32 layers, DA_ENCODER_DEBUG): DMA stream alone 325 us, MFMA + fragment
-// reads alone 241 us, everything 351 us, barriers + epilogue alone 102 us -- the K walk waits on the LATENCY
-// of the one DMA stage it has in flight (a stage is ~0.45 us of MFMA, an L2 round trip under load is longer),
-// not on the matrix pipe.  A third LDS slot does not fit twice per CU; see DESIGN.md 3d for what is next.
-template <typename T, int WM>
-__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void k_conv_mfma(ConvParams p) {
-    constexpr int TM = WM * 64, NT = WM * 128, SB = (TM + 128) * 128;       // tile rows, threads, bytes per stage
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SB];
+// Implicit-GEMM group convolution: 128 pixels x 128 channels per tile, 4 waves as 2 x 2 (64 x 64 each), K walked
+// tap-major in 128-byte stages.
+//
+// What bounds it (ablation on the 32x32 layers, DA_ENCODER_DEBUG, two-slot version): DMA stream alone 325 us,
+// MFMA + fragment reads alone 241 us, everything 351 us -- the K walk waits on the LATENCY of the single DMA
+// stage it has in flight (a stage is ~0.45 us of MFMA; a round trip through L2 / MALL / HBM under load is
+// longer), not on the matrix pipe.  Hence the asymmetric LDS ring: the activation tile (first touches come
+// from HBM) has THREE 16 KB slots and is fetched two stages ahead, the weight tile (always L2-hot) two slots,
+// one stage ahead: 80 KB per workgroup = exactly two workgroups per CU in the 160 KB LDS.  vmcnt retires in
+// order, so W(s+1) is issued BEFORE A(s+2) and the wait at the top of a stage is vmcnt(4): everything but
+// the four youngest DMA instructions (= A(s+2)) has landed.
+// Tried and dropped: 256 x 128 tiles with 128 x 64 wave tiles (3/4 of the LDS bytes per FLOP but one wave per
+// SIMD: 391 us), 8-wave 256-pixel tiles (370 us).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
+    constexpr int SA = 16384, OFFW = 3 * SA;                 // A ring: 3 x 16 KB, W ring: 2 x 16 KB behind it
+    __shared__ __attribute__((aligned(16))) unsigned char smem[5 * SA];
     const int tid = threadIdx.x, lane = tid & 63, wm = (tid >> 6) >> 1, wn = (tid >> 6) & 1;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int ES = (int)sizeof(T), EPC = 16 / ES, BK = 128 / ES;
-    constexpr int ROWS = ES == 4 ? 32 : 64, PASSES = TM / ROWS, CPR = 128 * ES / 16, NIT = ROWS * CPR / NT;
-    constexpr int WJ = 128 / (2 * WM) / 8;       // W-tile DMA instructions per wave per stage (8 rows each)
+    constexpr int ROWS = ES == 4 ? 32 : 64, PASSES = 128 / ROWS, CPR = 128 * ES / 16, NIT = ROWS * CPR / 256;
     constexpr int RSO = 128 * ES + 16;
+    static_assert(ROWS * RSO <= 2 * SA, "epilogue staging lives in A slots 1-2");
     constexpr bool PREFETCH = ES == 2;           // fp32 (parity mode): 64 more registers would spill; fetched in the epilogue
     const int Ho = 1 << p.lgHo, Wo = 1 << p.lgWo;
     const int K = p.taps * p.Cin;
@@ -78,24 +85,22 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void k_conv_mfma(ConvPar
     const bool relu = p.relu != 0, has_res = p.res != nullptr;
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
 
-    // PERSISTENT workgroups: 2 per CU, each walks virtual tiles v, v + grid, ...  A tile's first K stage is put
-    // in flight BEFORE the previous tile's epilogue and its stores drain under the next tile's K walk; with one
-    // tile per workgroup all co-resident workgroups ran their (HBM-bound) prologue and epilogue phases in
-    // lock step and memory time simply added to MFMA time.
+    // PERSISTENT workgroups: 2 per CU, each walks virtual tiles v, v + grid, ...  A tile's first stage is put in
+    // flight BEFORE the previous tile's epilogue and its stores drain under the next tile's K walk.
     // Virtual tile -> (pixel tile, channel tile), XCD-aware: the channel tiles of one pixel tile re-read the same
     // im2col rows, so they sit on the same XCD (workgroups are dispatched round-robin over the 8 XCDs and the
     // grid is a multiple of 8 * nct, so a workgroup's XCD and channel tile never change).
     const int V = p.nvirt;
-    auto valid = [&](int v) { const int sq = v >> 3; return ((v & 7) + 8 * (sq / p.nct)) * TM < p.M; };
+    auto valid = [&](int v) { const int sq = v >> 3; return ((v & 7) + 8 * (sq / p.nct)) * 128 < p.M; };
     int v = blockIdx.x;
     while (v < V && !valid(v)) v += gridDim.x;
     if (v >= V) return;
     const int col0 = ((v >> 3) % p.nct) * 128;
 
-    unsigned ap[4], wp[WJ];                   // byte offsets from p.X / p.W (a chunk's maps stay below 4 GB, see launch_conv)
+    unsigned ap[4], wp[4];                   // byte offsets from p.X / p.W (a chunk's maps stay below 4 GB, see launch_conv)
     int row0 = 0;
     auto setup = [&](int vv) {
-        row0 = ((vv & 7) + 8 * ((vv >> 3) / p.nct)) * TM;
+        row0 = ((vv & 7) + 8 * ((vv >> 3) / p.nct)) * 128;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = min(row0 + 32 * wid + 8 * j + lr, p.M - 1);
@@ -105,21 +110,26 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void k_conv_mfma(ConvPar
         }
     };
 #pragma unroll
-    for (int j = 0; j < WJ; ++j)
-        wp[j] = (unsigned)((size_t)min(col0 + 8 * WJ * wid + 8 * j + lr, p.Cout - 1) * K * ES + lc * 16);
-    auto issue = [&](int s) {
+    for (int j = 0; j < 4; ++j)
+        wp[j] = (unsigned)((size_t)min(col0 + 32 * wid + 8 * j + lr, p.Cout - 1) * K * ES + lc * 16);
+    // LDS-DMA: wave w fills rows [32w, 32w+32) of a tile, 8 rows (1 KB) per instruction; the destination is
+    // lane-linear, so the XOR swizzle (16-byte chunk ^ (row & 7)) is applied to the per-lane SOURCE address
+    auto issueA = [&](int s) {
         const int tap = s >> p.lgcpt, cb = s - (tap << p.lgcpt);
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;              // tap / 3 for tap < 9
         const char *xa = (const char *)p.X + ((size_t)(ky * p.Wpi + kx) * p.Cin + (size_t)cb * BK) * ES;
-        const char *xw = (const char *)p.W + (size_t)s * 128;
-        unsigned char *sa = smem + (s & 1) * SB + (32 * wid) * 128, *sw = smem + (s & 1) * SB + TM * 128 + (8 * WJ * wid) * 128;
+        unsigned char *sa = smem + (s % 3) * SA + (32 * wid) * 128;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (!(p.debug & 1))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xa + ap[j]),
                                              (__attribute__((address_space(3))) void *)(sa + j * 1024), 16, 0, 0);
+    };
+    auto issueW = [&](int s) {
+        const char *xw = (const char *)p.W + (size_t)s * 128;
+        unsigned char *sw = smem + OFFW + (s & 1) * SA + (32 * wid) * 128;
 #pragma unroll
-        for (int j = 0; j < WJ; ++j)
+        for (int j = 0; j < 4; ++j)
             if (!(p.debug & 2))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xw + wp[j]),
                                              (__attribute__((address_space(3))) void *)(sw + j * 1024), 16, 0, 0);
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void k_conv_mfma(ConvPar
         for (int pass = 0; pass < PASSES; ++pass)
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * NT, row = idx / CPR, ch = idx - row * CPR;
+                const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
                 const int m = min(row0 + row + pass * ROWS, p.M - 1), col = col0 + ch * EPC;
                 const int b = m >> (p.lgHo + p.lgWo), y = (m >> p.lgWo) & (Ho - 1), x = m & (Wo - 1);
                 ooff[pass][it] = (unsigned)((((size_t)b * (Ho + 2) + (y + 1)) * (Wo + 2) + (x + 1)) * p.Cout + col);
@@ -149,12 +159,15 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void k_conv_mfma(ConvPar
         const f32x4 b4 = *(const f32x4 *)(p.bias + col0 + wn * 64 + ni * 16 + (lane >> 4) * 4);
         bz[ni][0] = b4[0]; bz[ni][1] = b4[1]; bz[ni][2] = b4[2]; bz[ni][3] = b4[3];
     }
+    constexpr int NRES = PASSES * NIT;
 
     setup(v);
-    issue(0);
-    fetch_res();
-    const bool pre_issue = (nk & 1) == 0;        // stage 0 of the next tile lands in slot 0, the staging area is slot (nk - 1) & 1
+    issueW(0);
+    issueA(0);
     for (;;) {
+        // VMEM order at this point: W(0), A(0) [, epilogue stores of the previous tile]; now A(1), residual
+        if (nk > 1) issueA(1);
+        fetch_res();
         f32x4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -162,35 +175,39 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void k_conv_mfma(ConvPar
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         for (int s = 0; s < nk; ++s) {
-            // own DMA landed + everyone done with the other slot.  vmcnt retires in order and the residual loads
-            // were issued AFTER the stage-0 DMA: the first wait may leave exactly those in flight (they are
-            // covered by the wait of stage 1, a whole MFMA stage later).
-            if (PREFETCH && s == 0 && has_res) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PASSES * NIT) : "memory");
-                __syncthreads();
+            // A(s), W(s) landed; the youngest DMA group -- A(s+1), four instructions -- may stay in flight, and at
+            // s == 0 so may the residual loads issued behind it
+            if (s == 0 && PREFETCH && has_res) {
+                if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES + 4) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");
+            } else if (s + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
-                dma_barrier();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (s + 1 < nk) issue(s + 1);
-            const unsigned char *sA = smem + (s & 1) * SB;
-            if (!(p.debug & 4)) mma_block<T>(sA, sA + TM * 128, wm, wn, lane, acc);
+            __syncthreads();                         // + everyone is done with stage s - 1 (its slots are refilled now)
+            if (s + 1 < nk) issueW(s + 1);
+            if (s + 2 < nk) issueA(s + 2);
+            if (!(p.debug & 4)) mma_block<T>(smem + (s % 3) * SA, smem + OFFW + (s & 1) * SA, wm, wn, lane, acc);
         }
 
         int vn = v + gridDim.x;
         while (vn < V && !valid(vn)) vn += gridDim.x;
         const bool more = vn < V;
+        __syncthreads();                             // every slot is free
         if (more) {
-            setup(vn);                                   // every DMA of this tile has been issued: ap[] is free
-            if (pre_issue) { __syncthreads(); issue(0); }   // slot 0: everyone is past its last read (stage nk - 2)
+            setup(vn);                               // every DMA of this tile has been issued: ap[] is free
+            issueW(0);
+            issueA(0);                               // A slot 0, W slot 0; the staging area below is A slots 1-2
         }
 
         // epilogue: (+ folded BatchNorm bias) -> LDS -> coalesced 16-byte stores of whole pixel rows, the
-        // residual is added (and the ReLU applied) on the coalesced side.  Plain barriers: the only DMA in
-        // flight is the next tile's stage 0, which must NOT be waited for here.
-        unsigned char *stg = smem + ((nk - 1) & 1) * SB;
+        // residual is added (and the ReLU applied) on the coalesced side.  Plain barriers: the DMA in flight is
+        // the next tile's stage 0, which must NOT be waited for here.
+        unsigned char *stg = smem + SA;
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
-            __syncthreads();
+            if (pass > 0) __syncthreads();
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void k_conv_mfma(ConvPar
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * NT, row = idx / CPR, ch = idx - row * CPR;
+                const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
                 if (orow0 + row + pass * ROWS >= p.M) continue;
                 u32x4 val = *(const u32x4 *)(stg + row * RSO + ch * 16);
                 if (has_res) val = add_relu8(val, PREFETCH ? rv[pass][it] : *(const u32x4 *)((const T *)p.res + ooff[pass][it]), relu, T());
@@ -218,8 +235,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void k_conv_mfma(ConvPar
         }
         if (!more) break;
         v = vn;
-        if (!pre_issue) { __syncthreads(); issue(0); }
-        fetch_res();
+        __syncthreads();                             // staging area (A slots 1-2) read out before A(1) lands in it
     }
 }
 
@@ -284,23 +300,16 @@ static int launch_conv(int prec, int B, const void *X, int Cin, int Hi, const vo
     DA_REQUIRE(Cin % BK == 0 && (1 << p.lgcpt) == Cin / BK && Cout % 128 == 0 && (1 << p.lgHo) == Ho && (ksize == 1 || ksize == 3),
                "encoder conv: unsupported geometry (Cin %d Cout %d H %d k %d)", Cin, Cout, Hi, ksize);
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("DA_ENCODER_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
-    static int big = -1;
-    if (big < 0) { const char *e = getenv("DA_ENCODER_WIDE_TILES"); big = (e && e[0] == '1') ? 1 : 0; }
-    // 256-pixel tiles (8 waves, DA_ENCODER_WIDE_TILES=1) measured SLOWER than two independent 128-pixel workgroups
-    // per CU (370 vs 346 us on the 32x32 layers): kept switchable for experiments, off by default
-    const bool wide = prec == DA_PREC_BF16 && big && (long long)((p.M + 255) / 256) * p.nct >= 256;
-    const int TMh = wide ? 256 : 128;
-    const int nrt = (p.M + TMh - 1) / TMh;
+    const int nrt = (p.M + 127) / 128;
     p.nvirt = 8 * ((nrt + 7) / 8) * p.nct;
     static int per_cu = -1;
     if (per_cu < 0) { const char *e = getenv("DA_ENCODER_WG_PER_CU"); per_cu = e ? atoi(e) : 2; if (per_cu < 1) per_cu = 1000000; }
     // persistent: at most 256 CUs x 2 resident workgroups, a multiple of 8 * nct (see the kernel)
-    long long cap = (long long)256 * (wide ? (per_cu + 1) / 2 : per_cu) / (8 * p.nct) * (8 * p.nct);
+    long long cap = (long long)256 * per_cu / (8 * p.nct) * (8 * p.nct);
     if (cap < 8 * p.nct) cap = 8 * p.nct;
     const unsigned grid = (unsigned)(p.nvirt < cap ? p.nvirt : cap);
-    if (wide) k_conv_mfma<bf16_t, 4><<<grid, 512, 0, st>>>(p);
-    else if (prec == DA_PREC_BF16) k_conv_mfma<bf16_t, 2><<<grid, 256, 0, st>>>(p);
-    else k_conv_mfma<float, 2><<<grid, 256, 0, st>>>(p);
+    if (prec == DA_PREC_BF16) k_conv_mfma<bf16_t><<<grid, 256, 0, st>>>(p);
+    else k_conv_mfma<float><<<grid, 256, 0, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
 }
