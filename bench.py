@@ -199,7 +199,7 @@ def encode_bench(args, world, rank, dev):
         if not args.no_cpu_baseline and world == 1:
             from oracle import encoder as OE
             sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-            threads = os.cpu_count() or 1
+            threads = min(64, os.cpu_count() or 1)       # more threads are slower on these small convolutions
             torch.set_num_threads(threads)
             xs = x[:96].cpu()
             OE.visual_features(sd, xs[:32])
