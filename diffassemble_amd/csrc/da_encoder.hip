@@ -67,7 +67,10 @@ __device__ __forceinline__ u32x4 add_relu8(u32x4 a, u32x4 b, bool relu, bf16_t) 
 // order, so W(s+1) is issued BEFORE A(s+2) and the wait at the top of a stage is vmcnt(4): everything but
 // the four youngest DMA instructions (= A(s+2)) has landed.
 // Tried and dropped: 256 x 128 tiles with 128 x 64 wave tiles (3/4 of the LDS bytes per FLOP but one wave per
-// SIMD: 391 us), 8-wave 256-pixel tiles (370 us).
+// SIMD: 391 us), 8-wave 256-pixel tiles (370 us), a "row slab" variant for the stride-1 layers that fetches the
+// input rows of one filter row once, three stages ahead, and reads the three kx operands from it at a
+// one-pixel offset (1/3 of the activation DMA: 329 vs 331 us -- what is left is the weight tile, one stage
+// ahead; a third weight slot does not fit twice per CU), starting half of the workgroups out of phase (+-0).
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
     constexpr int SA = 16384, OFFW = 3 * SA;                 // A ring: 3 x 16 KB, W ring: 2 x 16 KB behind it

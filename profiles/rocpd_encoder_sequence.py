@@ -7,7 +7,7 @@ import sys
 con = sqlite3.connect(sys.argv[1])
 B = int(sys.argv[2])
 rows = con.execute("select name, start, end, grid_x from kernels order by start").fetchall()
-rows = [r for r in rows if "k_conv_mfma" in r[0] or "k_enc_stem" in r[0]]
+rows = [r for r in rows if "k_conv" in r[0] or "k_enc_stem" in r[0]]
 per = 20
 LAYERS = [("stem 3->128 @32", 32 * 32 * 128 * 27 * 2)]
 cin, h = 128, 32
