@@ -31,7 +31,7 @@ struct ConvParams {
     int M;                                  // B * Ho * Wo output pixels
     int nct, lgcpt;                         // column tiles; log2(K stages per tap)
     int nvirt;                              // virtual tiles: 8 * ceil(pixel tiles / 8) * nct
-    int debug;                              // DA_ENCODER_DEBUG bits (timing experiments only): 1 = no A DMA, 2 = no W DMA, 4 = no MFMA
+    int debug;                              // DA_ENCODER_DEBUG bits (builds with -DDA_ENCODER_PROBE only; timing experiments): 1 = no A DMA, 2 = no W DMA, 4 = no MFMA
     long long tap0;                         // element offset of tap 0 from the pixel's base: 0 (3x3, pad 1) | (Wpi + 1) * Cin (1x1, pad 0)
 };
 
@@ -124,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
         unsigned char *sa = smem + (s % 3) * SA + (32 * wid) * 128;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
+#ifdef DA_ENCODER_PROBE
             if (!(p.debug & 1))
+#endif
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xa + ap[j]),
                                              (__attribute__((address_space(3))) void *)(sa + j * 1024), 16, 0, 0);
     };
@@ -133,7 +135,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
         unsigned char *sw = smem + OFFW + (s & 1) * SA + (32 * wid) * 128;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
+#ifdef DA_ENCODER_PROBE
             if (!(p.debug & 2))
+#endif
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xw + wp[j]),
                                              (__attribute__((address_space(3))) void *)(sw + j * 1024), 16, 0, 0);
     };
@@ -191,7 +195,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
             __syncthreads();                         // + everyone is done with stage s - 1 (its slots are refilled now)
             if (s + 1 < nk) issueW(s + 1);
             if (s + 2 < nk) issueA(s + 2);
-            if (!(p.debug & 4)) mma_block<T>(smem + (s % 3) * SA, smem + OFFW + (s & 1) * SA, wm, wn, lane, acc);
+#ifdef DA_ENCODER_PROBE
+            if (!(p.debug & 4))
+#endif
+            mma_block<T>(smem + (s % 3) * SA, smem + OFFW + (s & 1) * SA, wm, wn, lane, acc);
         }
 
         int vn = v + gridDim.x;
