@@ -227,6 +227,73 @@ def encode_bench(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def e2e_bench(args, world, rank, dev):
+    """Pixels -> poses: what one validation / test batch costs end to end.  One "step" = p_sample_loop on a Batch
+    of `--puzzles` 900-piece puzzles given their 32x32 crops and the collated edge_index: piece encoder
+    (model='resnet18equiv') + graph plan from edge_index + the 100-step hipGraph DDIM loop."""
+    import torch.distributed as dist
+    from diffassemble_amd import sharding as S
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    G, K, Wm = args.puzzles, args.steps, args.warmup
+    n = G * N_PIECES
+    torch.manual_seed(0)
+    m = GNN_Diffusion(steps=T_STEPS, sampling="DDIM", inference_ratio=1, rotation=True, noise_weight=1.0,
+                      model_mean_type=ModelMeanType.START_X, visual_pretrained=False, backbone="resnet18equiv")
+    m = m.to(dev).eval()
+    m.model.precision = args.precision
+    x = torch.rand((n, 3, 32, 32), generator=torch.Generator(device=dev).manual_seed(5 + rank), device=dev)
+    ei, batch = dense_batch(G, N_PIECES, dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = [0.0, 0.0, 0.0]
+
+    def step(timed=False):
+        m.model._plan_key = None                      # a new Batch every step: the plan is rebuilt from edge_index
+        if timed: ev[0].record()
+        feats = m.visual_features(x)
+        if timed: ev[1].record()
+        eng = m.model.engine(dev)
+        m.model._plan_for(eng, ei, batch)
+        if timed: ev[2].record()
+        imgs, _ = m.p_sample_loop((n, 4), None, ei, batch, patch_feats=feats)
+        if timed:
+            ev[3].record()
+            torch.cuda.synchronize()
+            for k in range(3):
+                acc[k] += ev[k].elapsed_time(ev[k + 1])
+        return imgs[-1]
+
+    for _ in range(max(Wm, 1)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = S.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(out).all()
+    kp = min(K, 5)
+    for _ in range(kp):
+        step(True)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "puzzles solved per second, pixels -> poses (900-piece dense, T=100, resnet18equiv encoder)",
+            "value": world * G * K / dt, "unit": "puzzles/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "p_sample_loop from 32x32 crops + collated edge_index, 30x30 dense puzzles, DDIM T=100",
+                       "puzzles_per_gpu": G, "parallelism": f"puzzle-sharded x{world}"},
+            "phases_ms": {"encoder": acc[0] / kp, "graph_plan": acc[1] / kp, "sampling_loop": acc[2] / kp},
+            "roofline": None, "cpu_baseline": None,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,9 +302,9 @@ def main():
     ap.add_argument("--puzzles", type=int, default=int(os.environ.get("BENCH_PUZZLES", 32)),
                     help="independent 900-piece puzzles per GPU (the batch of one step)")
     ap.add_argument("--precision", default=os.environ.get("BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"])
-    ap.add_argument("--mode", default=os.environ.get("BENCH_MODE", "sample"), choices=["sample", "train", "encode"],
+    ap.add_argument("--mode", default=os.environ.get("BENCH_MODE", "sample"), choices=["sample", "train", "encode", "e2e"],
                     help="sample = the headline metric (default); train = BASELINE config 5 (one optimizer step); "
-                         "encode = the piece encoder (SURVEY 8f rank 2)")
+                         "encode = the piece encoder (SURVEY 8f rank 2); e2e = pixels -> poses (encoder + plan + loop)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("BENCH_ENCODER_CHUNK", 0)),
                     help="--mode encode: pieces per encoder chunk (0 = engine default)")
     ap.add_argument("--train-puzzles", type=int, default=int(os.environ.get("BENCH_TRAIN_PUZZLES", 64)),
@@ -261,6 +328,8 @@ def main():
         return train_bench(args, world, rank, dev)
     if args.mode == "encode":
         return encode_bench(args, world, rank, dev)
+    if args.mode == "e2e":
+        return e2e_bench(args, world, rank, dev)
 
     from diffassemble_amd import _lib
     from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType

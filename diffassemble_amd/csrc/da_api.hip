@@ -63,6 +63,7 @@ struct da_denoiser {
     // the GELU): softmax(QK^T)(V Wf_h^T) == (softmax(QK^T) V) Wf_h^T per head, so the last attention runs with
     // 32-wide value heads and the [N, 1152] tensor z is never formed either (dense path only)
     bool lastfold = false;
+    bool dense_only = false;     // every layer can take the block-diagonal MFMA attention: complete graphs never touch the CSR arrays
     void *convLf_w = nullptr;         // [2*HC + H*32, 256] act dtype: Wq | Wk | (Wf_h Wv_h)_h
     float *convLf_b = nullptr;        // [2*HC + H*32]
     void *skipc_w = nullptr;          // [32, 256] act dtype = Wf0 . Ws_last
@@ -166,7 +167,9 @@ static bool dense_ok(const da_graph *g, int heads, int C) {
 
 static int check_graph(const da_denoiser *d, const da_graph *g) {
     DA_REQUIRE(g && g->n_real > 0 && g->n_nodes >= g->n_real, "da_graph: bad node counts");
-    DA_REQUIRE(g->row_ptr && (g->col_src || g->n_edges == 0), "da_graph: CSR arrays missing");
+    // complete graphs (dense != 0) on a denoiser whose every layer has an MFMA attention kernel never walk the
+    // edge list; the host may then leave the CSR arrays out (da_denoiser_flags bit 2) unless alpha is wanted
+    if (!(g->dense && d->dense_only)) DA_REQUIRE(g->row_ptr && (g->col_src || g->n_edges == 0), "da_graph: CSR arrays missing");
     DA_REQUIRE(d->V == 0 || g->n_nodes == g->n_real + d->V * g->n_graphs,
                "da_graph: exophormer expects n_nodes = n_real + V*G (%d vs %d + %d*%d)", g->n_nodes, g->n_real,
                d->V, g->n_graphs);
@@ -329,6 +332,8 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                  return linear(prec, nproj, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, w.qkvs, 4 * c.hc, st); }))) return rc;
         if (virt0 && (rc = launch_scatter_virtual(prec, n - nr, d->V, d->heads, c.C, d->virt_qkvs, nr, nullptr, 0, nullptr, nullptr,
                                                   nullptr, nullptr, w.qkvs, st))) return rc;
+        DA_REQUIRE(g->row_ptr && (g->col_src || g->n_edges == 0), "da_graph: this call walks the edge list (alpha requested or no "
+                   "MFMA attention for this layer) but the CSR arrays are missing");
         if ((rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
                  return launch_attn_csr(prec, n, g->row_ptr, g->col_src, g->edge_id, d->heads, c.C, w.qkvs,
                                         resid, act, dst, al, nullptr, st); }))) return rc;
@@ -509,11 +514,15 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
         }
     }
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("da_denoiser_create: sync failed"); return fail(2); }
+    d->dense_only = d->heads == 8 && !dense_disabled() && !mfma_disabled();
+    for (int l = 0; l < d->n_layers; ++l) d->dense_only = d->dense_only && (d->conv[l].C == 32 || d->conv[l].C == 144);
     *out = d;
     return 0;
 }
 
-int da_denoiser_flags(const da_denoiser *d) { return d ? (d->fused_mlp2 ? 1 : 0) | (d->lastfold ? 2 : 0) : 0; }
+int da_denoiser_flags(const da_denoiser *d) {
+    return d ? (d->fused_mlp2 ? 1 : 0) | (d->lastfold ? 2 : 0) | (d->dense_only ? 4 : 0) : 0;
+}
 
 void da_denoiser_destroy(da_denoiser *d) {
     if (!d) return;

@@ -97,6 +97,8 @@ class DenoiserEngine:
             _lib.check(self.lib.da_denoiser_create(C.byref(w), self.prec, _lib.stream_ptr(self.device),
                                                    C.byref(handle)))
         self.handle = handle
+        self.flags = int(self.lib.da_denoiser_flags(handle))
+        self.dense_only = bool(self.flags & 4)     # complete graphs never need the CSR arrays (unless alpha is wanted)
         del keep                      # create() synchronised: the fp32 staging copies may go
         self._ws = {}
         self._loop_bufs = {}
@@ -114,8 +116,10 @@ class DenoiserEngine:
     def plan(self, edge_index, batch):
         return build_plan(edge_index.to(self.device), batch.to(self.device), self.virt_nodes)
 
-    def _workspace(self, plan: GraphPlan):
-        g = plan.c_struct()
+    def _workspace(self, plan: GraphPlan, need_csr=None):
+        if need_csr is None:       # complete graphs on an all-MFMA denoiser never walk the edge list
+            need_csr = not (plan.dense and self.dense_only)
+        g = plan.c_struct(need_csr)
         need = int(self.lib.da_denoiser_workspace_bytes(self.handle, C.byref(g)))
         key = (plan.n_nodes, plan.n_real)
         ws = self._ws.get(key)
@@ -136,6 +140,8 @@ class DenoiserEngine:
     def forward(self, plan, x, t, feats=None, return_alpha=False, return_pre_head=False, alpha_all_layers=False):
         """Eff_GAT(.._3d).forward_with_feats.  ``feats=None`` reuses the features already staged
         for this plan (sampling loop).  t: int64 [N] tensor or python int."""
+        if return_alpha:
+            plan.ensure_csr()              # alpha[E, H] is produced by the edge-list kernels
         if feats is not None:
             g, ws = self.set_features(plan, feats)
         else:

@@ -49,9 +49,9 @@ class GraphPlan:
     dense: int
     n_edges: int
     max_graph_nodes: int
-    row_ptr: torch.Tensor      # int32 [n_nodes + 1]
-    col_src: torch.Tensor      # int32 [E]
-    edge_id: torch.Tensor      # int32 [E]
+    row_ptr: torch.Tensor      # int32 [n_nodes + 1]   (None until ensure_csr() for complete graphs: the dense
+    col_src: torch.Tensor      # int32 [E]              kernels never walk the edge list, so the sort is skipped
+    edge_id: torch.Tensor      # int32 [E]              unless somebody needs it)
     graph_ptr: torch.Tensor    # int32 [G + 1]
     n_pad: int                 # dense mode: rows of the head-major Q / K / V buffers
     pad_ptr: torch.Tensor      # int32 [G + 1] (64-aligned slot of each graph)
@@ -68,6 +68,12 @@ class GraphPlan:
     irr_row_ptr: torch.Tensor = None   # int32 [n_nodes + 1]
     irr_col_src: torch.Tensor = None   # int32 [E_irregular]
 
+    def ensure_csr(self):
+        """CSR by destination of ``edge_index`` (stable: keeps the caller's order inside a segment)."""
+        if self.row_ptr is None:
+            self.row_ptr, self.col_src, self.edge_id = _csr_by_destination(self.edge_index, self.n_nodes)
+        return self
+
     def with_source_csr(self):
         """Add the by-source orientation of the same edge list (da_graph.out_ptr / out_dst), which
         the attention backward walks to form dK / dV without atomics."""
@@ -80,13 +86,18 @@ class GraphPlan:
             self.out_dst = dst[perm].to(torch.int32).contiguous()
         return self
 
-    def c_struct(self):
+    def c_struct(self, need_csr=True):
+        """``need_csr=False``: leave the CSR arrays out if they have not been built (only valid for complete
+        graphs on a denoiser that reports da_denoiser_flags bit 2, without alpha)."""
         g = _lib.DaGraph()
         g.n_nodes, g.n_real, g.n_graphs, g.dense = self.n_nodes, self.n_real, self.n_graphs, self.dense
         g.n_edges = self.n_edges
-        g.row_ptr = self.row_ptr.data_ptr()
-        g.col_src = self.col_src.data_ptr()
-        g.edge_id = self.edge_id.data_ptr()
+        if need_csr:
+            self.ensure_csr()
+        if self.row_ptr is not None:
+            g.row_ptr = self.row_ptr.data_ptr()
+            g.col_src = self.col_src.data_ptr()
+            g.edge_id = self.edge_id.data_ptr()
         g.graph_ptr = self.graph_ptr.data_ptr()
         g.max_graph_nodes = self.max_graph_nodes
         g.n_pad = self.n_pad
@@ -104,6 +115,14 @@ class GraphPlan:
 def _hybrid_mode():
     import os
     return os.environ.get("DA_HYBRID", "auto")
+
+
+def _csr_by_destination(edge_index, n_nodes):
+    src, dst = edge_index[0], edge_index[1]
+    perm = torch.argsort(dst, stable=True)          # keeps the caller's order inside a segment
+    row_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dst.device)
+    row_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_nodes), 0)
+    return row_ptr.to(torch.int32), src[perm].to(torch.int32).contiguous(), perm.to(torch.int32).contiguous()
 
 
 def build_plan(edge_index, batch, virt_nodes=0, detect_dense=True, hybrid=None):
@@ -128,9 +147,9 @@ def build_plan(edge_index, batch, virt_nodes=0, detect_dense=True, hybrid=None):
     E = edge_index.shape[1]
     assert n_nodes < 2 ** 31 and E < 2 ** 31
     src, dst = edge_index[0], edge_index[1]
-    perm = torch.argsort(dst, stable=True)          # keeps the caller's order inside a segment
-    row_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
-    row_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_nodes), 0)
+    # complete graphs: the CSR is built on demand (GraphPlan.ensure_csr) -- sorting 26 M edges of 32 900-piece
+    # puzzles is most of the plan time and the dense kernels never read it
+    row_ptr, col_src, edge_id = (None, None, None) if dense else _csr_by_destination(edge_index, n_nodes)
     # padded slots: the rows of graph g (its real nodes, then its virtual nodes) own a 64-aligned block
     padded = (counts + virt_nodes + 63) // 64 * 64
     pad_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
@@ -148,8 +167,7 @@ def build_plan(edge_index, batch, virt_nodes=0, detect_dense=True, hybrid=None):
         n_pad=int(pad_ptr[-1]), pad_ptr=pad_ptr.to(torch.int32), row_map=row_map.to(torch.int32).contiguous(),
         n_nodes=n_nodes, n_real=N, n_graphs=G, dense=dense, n_edges=E,
         max_graph_nodes=int(counts.max()) if G else 0,
-        row_ptr=row_ptr.to(torch.int32), col_src=src[perm].to(torch.int32).contiguous(),
-        edge_id=perm.to(torch.int32).contiguous(), graph_ptr=graph_ptr.to(torch.int32),
+        row_ptr=row_ptr, col_src=col_src, edge_id=edge_id, graph_ptr=graph_ptr.to(torch.int32),
         edge_index=edge_index, **hyb)
 
 
@@ -200,9 +218,18 @@ def _detect_dense(edge_index, batch, counts):
     full = int((counts * counts).sum())
     if E != full and E != full - N:
         return 0
-    if not bool((batch[src] == batch[dst]).all()):
+    gs = batch[src]
+    if not bool((gs == batch[dst]).all()):
         return 0
-    if torch.unique(src * N + dst).numel() != E:
+    # all E pairs distinct <=> they hit E different cells of the per-graph n_g x n_g tables (one scatter, no sort)
+    gptr = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=src.device)
+    gptr[1:] = torch.cumsum(counts, 0)
+    pbase = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=src.device)
+    pbase[1:] = torch.cumsum(counts * counts, 0)
+    cell = pbase[gs] + (dst - gptr[gs]) * counts[gs] + (src - gptr[gs])
+    seen = torch.zeros(full, dtype=torch.bool, device=src.device)
+    seen[cell] = True
+    if int(seen.sum()) != E:
         return 0
     loops = int((src == dst).sum())
     if E == full and loops == N:

@@ -133,7 +133,9 @@ void da_denoiser_destroy(da_denoiser *d);
 
 /* Which algebraic folds the packed denoiser uses (2D transformer arch): bit 0 = mlp.2 composed into the
  * conv-0 projection and final_mlp.0; bit 1 = last conv's value / skip projections composed with final_mlp.0
- * (32-wide value heads in the last attention).  For reporting executed vs algorithmic FLOPs.            */
+ * (32-wide value heads in the last attention).  For reporting executed vs algorithmic FLOPs.
+ * bit 2 = every layer has a block-diagonal MFMA attention kernel: for complete graphs (da_graph.dense != 0)
+ * row_ptr / col_src / edge_id may be NULL unless alpha is requested (the host can skip sorting the edge list). */
 int da_denoiser_flags(const da_denoiser *d);
 
 /* Bytes of caller-provided workspace needed for a graph of this size.                      */

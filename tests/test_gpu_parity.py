@@ -600,7 +600,28 @@ def test_fold_flags_reported(dev):
     spec = C.by_name("rot144_g1")
     case = C.build_case(spec)
     eng = make_engine(case, spec, "bf16", dev)
-    assert int(eng.lib.da_denoiser_flags(eng.handle)) == 3            # 2D transformer arch: both folds
+    assert int(eng.lib.da_denoiser_flags(eng.handle)) == 7            # 2D transformer arch: both folds + all-MFMA attention
+    assert eng.dense_only
     spec = C.by_name("exo144_v4_g1")
     eng = make_engine(C.build_case(spec), spec, "bf16", dev)
-    assert int(eng.lib.da_denoiser_flags(eng.handle)) == 3            # exophormer: same folds (the last one on hybrid graphs)
+    assert int(eng.lib.da_denoiser_flags(eng.handle)) == 7            # exophormer: same folds (the last one on hybrid graphs)
+    spec3 = C.FWD3D[0]
+    eng3 = make_engine(C.build_case(spec3, "3d"), spec3, "bf16", dev, variant="3d")
+    assert not eng3.dense_only                                          # 3D: the C = 104 layer walks the edge list
+
+
+def test_dense_plan_without_csr_and_alpha_on_demand(dev):
+    """Complete graphs skip the edge-list sort; asking for alpha afterwards builds the CSR and still matches."""
+    spec = C.by_name("rot144_g2_sharp")
+    case = C.build_case(spec)
+    eng = make_engine(case, spec, "fp32", dev)
+    plan = eng.plan(case["edge_index"], case["batch"])
+    assert plan.dense == 1 and plan.row_ptr is None
+    out = eng.forward(plan, case["x"].to(dev), case["t"].to(dev), case["feats"].to(dev))
+    assert plan.row_ptr is None                                        # the forward never needed it
+    ref, att = OD.eff_gat_forward_with_feats(case["sd"], case["x"], case["t"], case["edge_index"], case["feats"],
+                                             case["batch"], arch=spec["arch"], virt_nodes=spec["V"])
+    assert rel(out, ref) < RTOL32
+    out2, alpha = eng.forward(plan, case["x"].to(dev), case["t"].to(dev), case["feats"].to(dev), return_alpha=True)
+    assert plan.row_ptr is not None
+    assert rel(out2, ref) < RTOL32 and rel(alpha, att[-1][1]) < RTOL32

@@ -111,6 +111,11 @@ def test_dense_detection():
         ei, batch = W.collate([W.dense_edge_index(n, loops) for n in (6, 9)], (6, 9))
         p = build_plan(ei, batch)
         assert p.dense == flag and p.max_graph_nodes == 9 and p.graph_ptr.tolist() == [0, 6, 15]
+        # complete graphs: the edge-list sort is deferred until somebody needs the CSR (alpha, CSR kernels)
+        assert p.row_ptr is None and p.col_src is None
+        p.ensure_csr()
+        assert p.row_ptr.tolist()[-1] == ei.shape[1] and p.col_src.numel() == ei.shape[1]
+        assert torch.equal(ei[0][p.edge_id.long()], p.col_src.long())
     ei, batch = W.collate([W.dense_edge_index(6, True)], (6,))
     assert build_plan(ei[:, :-1], batch).dense == 0                      # one edge missing
     dup = torch.cat([ei[:, :-1], ei[:, :1]], 1)
