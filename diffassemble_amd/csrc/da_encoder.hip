@@ -70,7 +70,11 @@ __device__ __forceinline__ u32x4 add_relu8(u32x4 a, u32x4 b, bool relu, bf16_t) 
 // SIMD: 391 us), 8-wave 256-pixel tiles (370 us), a "row slab" variant for the stride-1 layers that fetches the
 // input rows of one filter row once, three stages ahead, and reads the three kx operands from it at a
 // one-pixel offset (1/3 of the activation DMA: 329 vs 331 us -- what is left is the weight tile, one stage
-// ahead; a third weight slot does not fit twice per CU), starting half of the workgroups out of phase (+-0).
+// ahead; a third weight slot does not fit twice per CU), starting half of the workgroups out of phase (+-0),
+// 256 x 128 tiles with 128 x 64 wave tiles on 64-byte stages in a three-slot ring at two workgroups per CU (3/4
+// of the LDS and DMA bytes per FLOP, both operands two stages ahead: 352 vs 340 us).  With the DMA compiled out
+// the kernel runs at 1 280 - 1 400 TFLOP/s, which is also what hipBLASLt reaches on this box (1 239): that, not
+// 2.5 PFLOP/s, is the practical ceiling of the matrix pipe here; the DMA stream costs the remaining 25 - 30 %.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
     constexpr int SA = 16384, OFFW = 3 * SA;                 // A ring: 3 x 16 KB, W ring: 2 x 16 KB behind it
