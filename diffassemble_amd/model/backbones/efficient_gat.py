@@ -73,9 +73,13 @@ class Eff_GAT(DenoiserBase):
                 "no piece encoder available (timm / equivariant ResNet are outside the hot path): "
                 "pass precomputed patch_feats [N, 1088]")
         if self.model == "resnet18equiv":
-            if self.all_equivariant:
-                raise NotImplementedError("all_equivariant=True (4 rotated crops per piece) is not built")
             self.visual_backbone.precision = getattr(self, "precision", None) or default_precision()
+            if self.all_equivariant:
+                # efficient_gat.py:156-158: patch_rgb [N, 4, 3, 32, 32] holds the four quarter-turn views of a piece;
+                # the encoder runs on each and the outputs are averaged -- one batched call over 4 N crops here
+                n = patch_rgb.shape[0]
+                views = patch_rgb.transpose(0, 1).reshape(4 * n, *patch_rgb.shape[2:])
+                return self.visual_backbone.patch_features(views).float().view(4, n, -1).mean(0)
             feats = self.visual_backbone.patch_features(patch_rgb)    # normalise + encoder + cat, all in HIP
             return feats.float()
         patch_rgb = (patch_rgb - self.mean) / self.std

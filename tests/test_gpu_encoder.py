@@ -126,3 +126,19 @@ def test_sampling_loop_from_pixels(dev):
     ref, _ = ODF.p_sample_loop(dsd, ODF.make_schedule(T), x0, ei, feats, batch, T, inference_ratio=ratio)
     assert len(imgs) == len(ref) == 10
     assert rel(torch.stack(imgs), torch.stack(ref)) < 5e-4
+
+
+def test_all_equivariant_averages_the_four_views(dev):
+    """Eff_GAT(all_equivariant=True): patch_rgb [N, 4, 3, 32, 32] -> mean over the four views of the encoder
+    output (efficient_gat.py:156-158)."""
+    from diffassemble_amd.model.backbones import Eff_GAT
+    m = Eff_GAT(steps=10, input_channels=4, output_channels=4, model="resnet18equiv", visual_pretrained=False,
+                all_equivariant=True)
+    esd = W.make_encoder_state(5)
+    m.visual_backbone.load_state_dict(esd)
+    m = m.to(dev).eval()
+    m.precision = "fp32"
+    x = W.make_patches(4 * 6, 9).view(6, 4, 3, 32, 32)
+    out = m.visual_features(x.to(dev))
+    ref = torch.stack([OE.visual_features(esd, x[:, i]) for i in range(4)]).mean(0)
+    assert out.shape == (6, 1088) and rel(out, ref) < RTOL32
