@@ -68,6 +68,11 @@ class ResNet(nn.Module):
         self.linear2 = nn.Linear(128 * 4 * 4 * 4, 544)
         self._engine = None
         self._engine_key = None
+        # The reference's "frozen" encoder (freeze_backbone=True) still runs BatchNorm on BATCH statistics while
+        # the LightningModule is in train mode.  That mode is not built; set this to True to train the denoiser
+        # on features of the encoder's RUNNING statistics instead (what a frozen encoder usually means) -- a
+        # documented deviation from the reference, off by default.
+        self.frozen_eval_stats = False
 
     def engine(self):
         """Packed weights, rebuilt when a parameter / buffer was replaced or modified in place."""
@@ -82,9 +87,10 @@ class ResNet(nn.Module):
     def patch_features(self, patch_rgb):
         """[N, 3, 32, 32] in [0, 1], NOT normalised (the kernel normalises) -> [N, 1088] =
         cat(linear1(out3), linear2(out4)), the two maps Eff_GAT.visual_features keeps."""
-        if self.training:
+        if self.training and not self.frozen_eval_stats:
             raise NotImplementedError(
-                "the HIP piece encoder implements eval-mode BatchNorm only; call .eval() (sampling / validation) "
+                "the HIP piece encoder implements eval-mode BatchNorm only; call .eval() (sampling / validation), "
+                "set visual_backbone.frozen_eval_stats = True (frozen encoder on its running statistics) "
                 "or pass precomputed patch_feats when training")
         return self.engine().forward(patch_rgb)
 

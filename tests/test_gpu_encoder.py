@@ -142,3 +142,36 @@ def test_all_equivariant_averages_the_four_views(dev):
     out = m.visual_features(x.to(dev))
     ref = torch.stack([OE.visual_features(esd, x[:, i]) for i in range(4)]).mean(0)
     assert out.shape == (6, 1088) and rel(out, ref) < RTOL32
+
+
+def test_training_step_from_pixels_with_frozen_encoder(dev):
+    """p_losses(cond = crops): HIP encoder on its running statistics (frozen_eval_stats) feeding the HIP training
+    forward / backward of the denoiser; loss and a gradient against oracle encoder + oracle p_losses."""
+    from oracle import diffusion as ODF
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    T, n = 100, 36
+    m = GNN_Diffusion(steps=T, sampling="DDIM", rotation=True, model_mean_type=ModelMeanType.EPSILON,
+                      visual_pretrained=False, backbone="resnet18equiv")
+    dsd, esd = W.make_denoiser_state(T, 4, 4, seed=31), W.make_encoder_state(31)
+    m.model.load_state_dict({**dsd, **{"visual_backbone." + k: v for k, v in esd.items()}}, strict=False)
+    m = m.to(dev).train()
+    with pytest.raises(NotImplementedError):
+        m.model.visual_features(W.make_patches(2, 0).to(dev))
+    m.model.visual_backbone.frozen_eval_stats = True
+    m.model.precision = "fp32"
+    rng = np.random.default_rng(4)
+    x0 = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32))
+    noise = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32))
+    t = torch.full((n,), 37, dtype=torch.int64)
+    patches = W.make_patches(n, 6)
+    ei, batch = W.dense_edge_index(n, True), torch.zeros(n, dtype=torch.int64)
+    loss = m.p_losses(x0.to(dev), t.to(dev), noise=noise.to(dev), loss_type="huber", cond=patches.to(dev),
+                      edge_index=ei.to(dev), batch=batch.to(dev))
+    loss.backward()
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    feats = OE.visual_features(esd, patches)
+    ref = ODF.p_losses(sd_ref, ODF.make_schedule(T), x0, t, noise, ei, feats, batch, mean_type="EPSILON")
+    ref.backward()
+    assert rel(loss, ref) < 1e-4
+    g = dict(m.model.named_parameters())["final_mlp.0.weight"].grad
+    assert rel(g, sd_ref["final_mlp.0.weight"].grad) < 1e-3
