@@ -374,20 +374,25 @@ def test_dense_path_is_deterministic_under_load(dev):
     assert torch.equal(alone, ref[g * n:(g + 1) * n])
 
 
-def test_900_piece_expander_vs_oracle_single_layer(dev):
-    """Config 3 graph (30x30, random 90-regular + V=8 virtual nodes): the full fp32 forward on
-    the GPU against the CPU oracle (one forward: ~seconds on the host)."""
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_900_piece_expander_vs_oracle_single_layer(dev, prec):
+    """Config 3 graph (30x30, random 90-regular + V=8 virtual nodes): the full forward on the GPU (hybrid
+    masked-MFMA hidden layers, edge-list last layer because alpha is requested) against the CPU oracle (one
+    forward: ~seconds on the host)."""
     spec = dict(name="exp900", sizes=[900], c=4, graph="regular90", arch="exophormer", V=8, steps=100, seed=31,
                 qk_gain=3.0)
     case = C.build_case(spec)
     ref, att = OD.eff_gat_forward_with_feats(case["sd"], case["x"], case["t"], case["edge_index"],
                                              case["feats"], case["batch"], "exophormer", 8)
-    eng = make_engine(case, spec, "fp32", dev)
+    eng = make_engine(case, spec, prec, dev)
     plan = eng.plan(case["edge_index"], case["batch"])
     assert plan.n_edges == 900 * 90 + 900 + 8 * 908 == 89164        # SURVEY 8d config 3
+    tol = RTOL32 if prec == "fp32" else RTOLBF
     out, alpha = eng.forward(plan, case["x"].to(dev), case["t"].to(dev), case["feats"].to(dev), return_alpha=True)
-    assert rel(out, ref) < RTOL32
-    assert rel(alpha, att[-1][1]) < RTOL32
+    assert rel(out, ref) < tol
+    assert rel(alpha, att[-1][1]) < tol
+    out2 = eng.forward(plan, case["x"].to(dev), case["t"].to(dev), case["feats"].to(dev))   # folded masked last layer too
+    assert rel(out2, ref) < tol
 
 
 # ---------------------------------------------------------------------------- hybrid path (sparse-but-heavy graphs)
