@@ -175,3 +175,24 @@ def test_training_step_from_pixels_with_frozen_encoder(dev):
     assert rel(loss, ref) < 1e-4
     g = dict(m.model.named_parameters())["final_mlp.0.weight"].grad
     assert rel(g, sd_ref["final_mlp.0.weight"].grad) < 1e-3
+
+
+def test_full_size_properties(dev):
+    """BASELINE-size batch (the 28 800 crops of 32 900-piece puzzles) through size-independent properties: a
+    piece's features depend on nothing but the piece -- permuting the batch permutes the rows bit for bit, a
+    different chunking changes nothing, and a prefix of the batch gives the prefix of the result."""
+    from diffassemble_amd.encoder import EncoderEngine
+    sd = W.make_encoder_state(6)
+    n = 32 * 900
+    x = torch.rand((n, 3, 32, 32), generator=torch.Generator(device=dev).manual_seed(3), device=dev)
+    eng = EncoderEngine(sd, precision="bf16", device=dev)
+    a = eng.forward(x).clone()
+    assert torch.isfinite(a.float()).all()
+    perm = torch.randperm(n, generator=torch.Generator(device=dev).manual_seed(4), device=dev)
+    assert torch.equal(eng.forward(x[perm].contiguous()), a[perm])
+    assert torch.equal(EncoderEngine(sd, precision="bf16", device=dev, chunk=640).forward(x), a)
+    assert torch.equal(eng.forward(x[:1000].contiguous()), a[:1000])
+    # and the oracle on a sample of the rows
+    idx = torch.arange(0, n, 1901, device=dev)
+    ref = OE.visual_features(sd, x[idx].cpu())
+    assert rel(a[idx].float(), ref) < RTOLBF
