@@ -181,3 +181,63 @@ def test_greedy_assignment_matches_reference_semantics():
         mask[i, :] = 0
         mask[:, j] = 0
     assert got.tolist() == [list(e) for e in exp]
+
+
+# ---------------------------------------------------------------------------- piece-encoder host logic (packing)
+def test_encoder_filter_bank_matches_reference_indices():
+    """diffassemble_amd.encoder.p4_filter_bank (product, closed form) against the reference's own index arrays
+    (fixture from make_gconv_indices.py) applied the way groupy's trans_filter does."""
+    import numpy as np
+    from diffassemble_amd import encoder as PE
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "encoder_v1.npz"))
+    for stab, tag in ((1, "z2"), (4, "p4")):
+        for k in (1, 3):
+            inds = gold[f"inds/c4_{tag}_k{k}"].astype(np.int64).reshape(-1, 3)
+            w = torch.arange(4 * 3 * stab * k * k, dtype=torch.float32).reshape(4, 3, stab, k, k)
+            ref = w[:, :, inds[:, 0], inds[:, 1], inds[:, 2]].reshape(4, 3, 4, stab, k, k).permute(0, 2, 1, 3, 4, 5)
+            assert torch.equal(PE.p4_filter_bank(w), ref.reshape(16, 3 * stab, k, k))
+
+
+def test_encoder_packing_folds_batchnorm_and_relayouts_linears():
+    """The packed weights the HIP kernels consume reproduce conv -> eval BatchNorm (oracle) as ONE biased conv,
+    and the halo-indexed linear equals the reference's NCHW flatten + nn.Linear."""
+    from diffassemble_amd import encoder as PE
+    from oracle import encoder as OE
+    sd = W.make_encoder_state(0)
+    assert [c for c, _ in PE.conv_keys()] == [s["conv"] for s in W.encoder_conv_specs()[1:]] and len(PE.conv_keys()) == 19
+    for ck, bk in PE.conv_keys()[:2] + [("layer2.0.conv1", "layer2.0.bn1"), ("layer3.0.shortcut.0", "layer3.0.shortcut.1")]:
+        bank, bias = PE._fold_bn(sd, bk, PE.p4_filter_bank(sd[ck + ".weight"]))
+        k = bank.shape[-1]
+        stride = 2 if ck in ("layer2.0.conv1", "layer3.0.shortcut.0") else 1
+        x = torch.randn(2, bank.shape[1] // 4, 4, 8, 8, generator=torch.Generator().manual_seed(1))
+        ref = OE.bn_eval(sd, bk, OE.gconv(sd, ck, x, stride, k // 2))
+        y = torch.nn.functional.conv2d(x.reshape(2, -1, 8, 8).double(), bank, bias, stride=stride, padding=k // 2)
+        assert float((y.reshape(ref.shape) - ref).abs().max()) < 1e-5, ck
+        # K ordered tap-major / channel-minor, as the NHWC implicit GEMM walks it
+        packed = bank.permute(0, 2, 3, 1).reshape(bank.shape[0], -1)
+        assert torch.equal(packed[:, :bank.shape[1]], bank[:, :, 0, 0])
+    lw = PE._halo_linear(sd["linear1.weight"], 256, 8)
+    x = torch.randn(3, 256, 8, 8, generator=torch.Generator().manual_seed(2))
+    xp = torch.zeros(3, 10, 10, 256)
+    xp[:, 1:9, 1:9, :] = x.permute(0, 2, 3, 1)
+    assert float((xp.reshape(3, -1) @ lw.T - x.reshape(3, -1) @ sd["linear1.weight"].T).abs().max()) < 1e-4
+    assert float(lw.reshape(544, 10, 10, 256)[:, 0].abs().max()) == 0.0          # halo columns are zero
+
+
+def test_encoder_module_has_the_reference_state_dict_layout():
+    """ResNet18() keys / shapes = what the reference's resnet_equivariant.ResNet18().state_dict() holds (dumped in
+    the survey probe), and the encoder refuses to run without a ROCm device or in train mode."""
+    from diffassemble_amd.model.backbones.resnet_equivariant import ResNet18
+    net = ResNet18()
+    sd = net.state_dict()
+    ref = W.make_encoder_state(0)
+    assert set(sd) == set(ref)
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    net.load_state_dict(ref)
+    with pytest.raises(NotImplementedError):
+        net.patch_features(torch.zeros(1, 3, 32, 32))                   # train mode
+    net.eval()
+    with pytest.raises(Exception) as ei:
+        net.patch_features(torch.zeros(1, 3, 32, 32))                   # CPU tensor / no GPU: loud failure
+    assert "ROCm" in str(ei.value) or "hip" in str(ei.value).lower()
