@@ -31,6 +31,7 @@ struct ConvParams {
     int M;                                  // B * Ho * Wo output pixels
     int nct, lgcpt;                         // column tiles; log2(K stages per tap)
     int nvirt;                              // virtual tiles: 8 * ceil(pixel tiles / 8) * nct
+    int nrt8;                               // pixel tiles per XCD: ceil(pixel tiles / 8)
     int debug;                              // DA_ENCODER_DEBUG bits (builds with -DDA_ENCODER_PROBE only; timing experiments): 1 = no A DMA, 2 = no W DMA, 4 = no MFMA
     long long tap0;                         // element offset of tap 0 from the pixel's base: 0 (3x3, pad 1) | (Wpi + 1) * Cin (1x1, pad 0)
 };
@@ -94,11 +95,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
 
     // PERSISTENT workgroups: 2 per CU, each walks virtual tiles v, v + grid, ...  A tile's first stage is put in
     // flight BEFORE the previous tile's epilogue and its stores drain under the next tile's K walk.
-    // Virtual tile -> (pixel tile, channel tile), XCD-aware: the channel tiles of one pixel tile re-read the same
-    // im2col rows, so they sit on the same XCD (workgroups are dispatched round-robin over the 8 XCDs and the
-    // grid is a multiple of 8 * nct, so a workgroup's XCD and channel tile never change).
+    // Virtual tile -> (pixel tile, channel tile), XCD-aware (workgroups are dispatched round-robin over the 8 XCDs and
+    // the grid is a multiple of 8 * nct, so a workgroup's XCD and channel tile never change): the channel tiles of
+    // one pixel tile sit on the same XCD, and every XCD owns a CONTIGUOUS range of pixel tiles, so the 64 tiles
+    // its workgroups hold at any time are neighbours -- adjacent row bands of the same pieces share their halo
+    // rows in that XCD's L2 (with tiles dealt round-robin FETCH_SIZE was 1.8x the compulsory input bytes: every
+    // band's two halo rows were fetched from HBM once per XCD).
     const int V = p.nvirt;
-    auto valid = [&](int v) { const int sq = v >> 3; return ((v & 7) + 8 * (sq / p.nct)) * 128 < p.M; };
+    auto tile_of = [&](int v) { return (v & 7) * p.nrt8 + (v >> 3) / p.nct; };      // XCD v & 7 owns a CONTIGUOUS range of pixel tiles
+    auto valid = [&](int v) { return tile_of(v) * 128 < p.M; };
     int v = blockIdx.x;
     while (v < V && !valid(v)) v += gridDim.x;
     if (v >= V) return;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
     unsigned ap[4], wp[4];                   // byte offsets from p.X / p.W (a chunk's maps stay below 4 GB, see launch_conv)
     int row0 = 0;
     auto setup = [&](int vv) {
-        row0 = ((vv & 7) + 8 * ((vv >> 3) / p.nct)) * 128;
+        row0 = tile_of(vv) * 128;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = min(row0 + 32 * wid + 8 * j + lr, p.M - 1);
@@ -315,7 +320,8 @@ static int launch_conv(int prec, int B, const void *X, int Cin, int Hi, const vo
                "encoder conv: unsupported geometry (Cin %d Cout %d H %d k %d)", Cin, Cout, Hi, ksize);
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("DA_ENCODER_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
     const int nrt = (p.M + 127) / 128;
-    p.nvirt = 8 * ((nrt + 7) / 8) * p.nct;
+    p.nrt8 = (nrt + 7) / 8;
+    p.nvirt = 8 * p.nrt8 * p.nct;
     static int per_cu = -1;
     if (per_cu < 0) { const char *e = getenv("DA_ENCODER_WG_PER_CU"); per_cu = e ? atoi(e) : 2; if (per_cu < 1) per_cu = 1000000; }
     // persistent: at most 256 CUs x 2 resident workgroups, a multiple of 8 * nct (see the kernel)
