@@ -79,6 +79,12 @@ struct da_denoiser {
     std::vector<LoopEntry> loops;
     hipStream_t cap_stream = nullptr;     // private stream used only to RECORD graphs (the caller's
                                           // stream may be the legacy null stream, which cannot capture)
+    // hybrid graphs: the virtual rows of a hidden layer (one 16-wave workgroup per row, latency-bound, 256 rows
+    // for 32 puzzles) run on this side stream UNDER the masked MFMA attention of the real rows -- the two
+    // kernels read the same Q / K / V and write disjoint rows.  Fork / join with events, so the pattern is
+    // captured into the sampling-loop hipGraph as two parallel branches.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace da {
@@ -311,6 +317,21 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                     DenseMask mk;
                     mk.mask = g->mask; mk.mask_ptr = g->mask_ptr; mk.irr_row_ptr = g->irr_row_ptr;
                     mk.irr_col_src = g->irr_col_src; mk.row_map = g->row_map;
+                    if (d->side_stream && !d->prof_on && n > nr) {
+                        // fork: virtual rows on the side stream, real rows here, join before the next projection
+                        DA_CHECK_HIP(hipEventRecord(d->ev_fork, st));
+                        DA_CHECK_HIP(hipStreamWaitEvent(d->side_stream, d->ev_fork, 0));
+                        rc = launch_attn_csr_cont(prec, n, nr, g->irr_row_ptr, g->irr_col_src, g->row_map, d->heads, c.C,
+                                                  g->n_pad, L, resid, act, dst, d->side_stream);
+                        if (rc) return rc < 0 ? 1 : rc;
+                        DA_CHECK_HIP(hipEventRecord(d->ev_join, d->side_stream));
+                        rc = launch_attn_dense(prec, L, d->heads, c.C, g->n_graphs, g->max_graph_nodes, g->graph_ptr,
+                                               g->pad_ptr, 0, resid, act, dst, st, &mk);
+                        if (rc) return rc < 0 ? 1 : rc;
+                        DA_CHECK_HIP(hipStreamWaitEvent(st, d->ev_join, 0));
+                        xin = dst; ldx = c.hc;
+                        continue;
+                    }
                     rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
                         int r2 = launch_attn_dense(prec, L, d->heads, c.C, g->n_graphs, g->max_graph_nodes, g->graph_ptr,
                                                    g->pad_ptr, 0, resid, act, dst, st, &mk);
@@ -514,6 +535,17 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
         }
     }
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("da_denoiser_create: sync failed"); return fail(2); }
+    {   // side stream of the hybrid path (see the struct); DA_DISABLE_HYBRID_OVERLAP=1 keeps everything on one stream
+        const char *e = getenv("DA_DISABLE_HYBRID_OVERLAP");
+        if (d->V > 0 && !(e && e[0] == '1')) {
+            if (hipStreamCreateWithFlags(&d->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming) != hipSuccess) {
+                set_error("da_denoiser_create: side stream / events");
+                return fail(2);
+            }
+        }
+    }
     d->dense_only = d->heads == 8 && !dense_disabled() && !mfma_disabled();
     for (int l = 0; l < d->n_layers; ++l) d->dense_only = d->dense_only && (d->conv[l].C == 32 || d->conv[l].C == 144);
     *out = d;
@@ -529,6 +561,9 @@ void da_denoiser_destroy(da_denoiser *d) {
     for (hipEvent_t e : d->prof_ev) (void)hipEventDestroy(e);
     for (auto &e : d->loops) (void)hipGraphExecDestroy(e.exec);
     if (d->cap_stream) (void)hipStreamDestroy(d->cap_stream);
+    if (d->side_stream) (void)hipStreamDestroy(d->side_stream);
+    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+    if (d->ev_join) (void)hipEventDestroy(d->ev_join);
     for (void *p : d->owned) (void)hipFree(p);
     delete d;
 }
