@@ -217,7 +217,7 @@ static int timed(da_denoiser *d, int cls, hipStream_t st, F &&launch) {
 
 static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const int64_t *t, int64_t t_scalar,
                         float *out, float *alpha, int alpha_all, float *pre_head, const Workspace &w,
-                        hipStream_t st) {
+                        hipStream_t st, DdimFuse *ddim = nullptr) {
     const int prec = d->prec, nr = g->n_real, n = g->n_nodes, D = d->D;
     int rc;
     // (a-3) embedding: pose MLP + learned timestep lookup into the concat buffer, then mlp
@@ -292,8 +292,10 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                              return linear(prec, nr, d->hidden, 32, w.h, d->hidden, d->headc_w, d->headc_b, DA_ACT_NONE, nullptr, w.head_pre, 32, st); }))) return rc;
                     if ((rc = timed(d, DA_PROF_HEAD, st, [&] {
                              return linear(prec, nr, c.din, 32, xin, ldx, d->skipc_w, d->skipc_b, DA_ACT_NONE, w.head_pre, w.head_pre, 32, st); }))) return rc;
+                    if (ddim && d->c_out == d->c_in) ddim->done = 1;        // the head kernel applies the DDIM update itself
                     return timed(d, DA_PROF_HEAD, st, [&] {
-                        return launch_head_fold(prec, nr, d->heads, d->c_out, w.pz, w.head_pre, d->head_w1, d->head_b1, out, st); });
+                        return launch_head_fold(prec, nr, d->heads, d->c_out, w.pz, w.head_pre, d->head_w1, d->head_b1, out, st,
+                                                (ddim && ddim->done) ? ddim : nullptr); });
                 }
             }
         }
@@ -641,9 +643,16 @@ static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s,
     int it = 0, rc;
     const int first = ((s->steps - 1) / ratio) * ratio;            // reversed(range(0, steps, ratio))[0]
     for (int i = first; i >= 0 && it < n_iters; i -= ratio, ++it) {
-        if ((rc = forward_impl(d, g, cur, nullptr, i, w.model_out, nullptr, 0, nullptr, w, st))) return rc;
         float *nxt = traj ? traj + (size_t)it * nr * c : ((it & 1) ? w.xbuf1 : w.xbuf0);
         const int nonneg = (i - ratio) >= 0;
+        DdimFuse df;
+        df.s = ds; df.mean_type = mean_type; df.ratio = ratio; df.prev_all_nonneg = nonneg; df.t = i; df.x = cur; df.x_prev = nxt;
+        df.done = 0;
+        static int fuse_off = -1;
+        if (fuse_off < 0) { const char *e = getenv("DA_DISABLE_DDIM_FUSION"); fuse_off = (e && e[0] == '1') ? 1 : 0; }
+        const bool try_fuse = !fuse_off && d->variant == DA_VARIANT_2D && !d->prof_on;
+        if ((rc = forward_impl(d, g, cur, nullptr, i, w.model_out, nullptr, 0, nullptr, w, st, try_fuse ? &df : nullptr))) return rc;
+        if (df.done) { cur = nxt; continue; }
         rc = timed(d, DA_PROF_UPDATE, st, [&] {
             if (d->variant == DA_VARIANT_3D)
                 return launch_ddim3d(ds, mean_type, nr, cur, w.model_out, nullptr, i, ratio, nonneg, nxt, st);

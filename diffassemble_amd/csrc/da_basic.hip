@@ -149,20 +149,8 @@ __global__ __launch_bounds__(256) void k_ddim2d(DeviceSchedule s, int mean_type,
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * c) return;
     const int r = idx / c;
-    int64_t ti = t ? t[r] : t_scalar;
-    ti = ti < 0 ? 0 : (ti >= s.steps ? s.steps - 1 : ti);
-    int64_t tp = ti - ratio;
-    const float ap = s.alphas_cumprod[ti];
-    const float ap_prev = (prev_all_nonneg && tp >= 0) ? s.alphas_cumprod[tp] : 1.0f;
-    const float beta = 1.0f - ap;
-    const float xv = x[idx], m = mo[idx];
-    const float x0 = mean_type == DA_MEAN_START_X ? m : (xv - sqrtf(beta) * m) / sqrtf(ap);
-    const float eps = (s.sqrt_recip_alphas_cumprod[ti] * xv - x0) / s.sqrt_recipm1_alphas_cumprod[ti];
-    const float var = ((1.0f - ap_prev) / (1.0f - ap)) * (1.0f - ap / ap_prev);
-    const float std_eta = eta * sqrtf(var);
-    float prev = sqrtf(ap_prev) * x0 + sqrtf(1.0f - ap_prev - std_eta * std_eta) * eps;
-    if (eta > 0.f && noise) prev += std_eta * noise[idx];
-    x_prev[idx] = prev;
+    const int64_t ti = t ? t[r] : t_scalar;
+    x_prev[idx] = ddim2d_value(s, mean_type, ti, ratio, prev_all_nonneg, eta, x[idx], mo[idx], (eta > 0.f && noise) ? noise[idx] : 0.f);
 }
 
 // DDPM update, p_sample_ddpm spatial_diffusion.py:485-510.
@@ -305,7 +293,7 @@ int launch_mm_nn_f32(int M, int N, int K, const float *A, int lda, const float *
 template <typename T>
 __global__ __launch_bounds__(256) void k_head_fold(int n, int H, int c_out, const float *__restrict__ pz, const T *__restrict__ pre,
                                                    const float *__restrict__ w2, const float *__restrict__ b2,
-                                                   float *__restrict__ out) {
+                                                   float *__restrict__ out, DdimFuse df) {
     __shared__ float f[8][33];
     const int j = threadIdx.x & 31, ln = threadIdx.x >> 5;
     const int r = blockIdx.x * 8 + ln;
@@ -320,14 +308,20 @@ __global__ __launch_bounds__(256) void k_head_fold(int n, int H, int c_out, cons
 #pragma unroll
         for (int k = 0; k < 32; ++k) a = fmaf(w2[j * 32 + k], f[ln][k], a);
         out[(size_t)r * c_out + j] = a;
+        // sampling loop: the DDIM update of this element right here (x_prev never aliases x: the loop ping-pongs)
+        if (df.x_prev)
+            df.x_prev[(size_t)r * c_out + j] = ddim2d_value(df.s, df.mean_type, df.t, df.ratio, df.prev_all_nonneg, 0.f,
+                                                            df.x[(size_t)r * c_out + j], a, 0.f);
     }
 }
 
 int launch_head_fold(int prec, int n, int H, int c_out, const float *pz, const void *pre, const float *w2, const float *b2,
-                     float *out, hipStream_t st) {
+                     float *out, hipStream_t st, const DdimFuse *dfp) {
     if (n <= 0) return 0;
-    if (prec == DA_PREC_BF16) k_head_fold<bf16_t><<<(n + 7) / 8, 256, 0, st>>>(n, H, c_out, pz, (const bf16_t *)pre, w2, b2, out);
-    else k_head_fold<float><<<(n + 7) / 8, 256, 0, st>>>(n, H, c_out, pz, (const float *)pre, w2, b2, out);
+    DdimFuse df;
+    if (dfp) df = *dfp; else { df = DdimFuse(); df.x = nullptr; df.x_prev = nullptr; }
+    if (prec == DA_PREC_BF16) k_head_fold<bf16_t><<<(n + 7) / 8, 256, 0, st>>>(n, H, c_out, pz, (const bf16_t *)pre, w2, b2, out, df);
+    else k_head_fold<float><<<(n + 7) / 8, 256, 0, st>>>(n, H, c_out, pz, (const float *)pre, w2, b2, out, df);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -10,6 +10,35 @@ struct DeviceSchedule {
         *sqrt_recipm1_alphas_cumprod, *sqrt_one_minus_alphas_cumprod, *posterior_variance;
 };
 
+// DDIM update of one element, p_sample_ddim spatial_diffusion.py:555-566,603-627 (fp32, op order kept); shared by
+// k_ddim2d and the fused tail of the folded head (k_head_fold), so both produce the same bits.
+__device__ __forceinline__ float ddim2d_value(const DeviceSchedule &s, int mean_type, long long ti, int ratio,
+                                              int prev_all_nonneg, float eta, float xv, float m, float noise) {
+    ti = ti < 0 ? 0 : (ti >= s.steps ? s.steps - 1 : ti);
+    const long long tp = ti - ratio;
+    const float ap = s.alphas_cumprod[ti];
+    const float ap_prev = (prev_all_nonneg && tp >= 0) ? s.alphas_cumprod[tp] : 1.0f;
+    const float beta = 1.0f - ap;
+    const float x0 = mean_type == DA_MEAN_START_X ? m : (xv - sqrtf(beta) * m) / sqrtf(ap);
+    const float eps = (s.sqrt_recip_alphas_cumprod[ti] * xv - x0) / s.sqrt_recipm1_alphas_cumprod[ti];
+    const float var = ((1.0f - ap_prev) / (1.0f - ap)) * (1.0f - ap / ap_prev);
+    const float std_eta = eta * sqrtf(var);
+    float prev = sqrtf(ap_prev) * x0 + sqrtf(1.0f - ap_prev - std_eta * std_eta) * eps;
+    if (eta > 0.f) prev += std_eta * noise;
+    return prev;
+}
+
+// Sampling loop: the deterministic DDIM update (eta = 0, scalar timestep) applied by the head kernel itself --
+// one launch less per step.  `done` is set by forward_impl when the folded head took it.
+struct DdimFuse {
+    DeviceSchedule s;
+    int mean_type, ratio, prev_all_nonneg;
+    long long t;
+    const float *x;            // [n, c] current sample (c == c_out)
+    float *x_prev;             // [n, c]
+    int done;
+};
+
 // da_basic.hip
 int launch_set_feats(int prec, int n, int F, int D, const float *feats, void *comb_in, hipStream_t st);
 int launch_set_virtual_rows(int prec, int rows, int V, int D, const void *emb, void *dst, hipStream_t st);
@@ -31,7 +60,7 @@ int launch_mm_nn_f32(int M, int N, int K, const float *A, int lda, const float *
 int launch_scatter_virtual(int prec, int rows, int V, int H, int C, const void *src, int n_real, const int32_t *row_map,
                            int n_pad, void *Q, void *K, void *Vt, void *S, void *qkvs, hipStream_t st);
 int launch_head_fold(int prec, int n, int H, int c_out, const float *pz, const void *pre, const float *w2, const float *b2,
-                     float *out, hipStream_t st);
+                     float *out, hipStream_t st, const DdimFuse *df = nullptr);
 
 // da_attn_csr.hip
 int launch_attn_csr(int prec, int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id,
