@@ -15,7 +15,11 @@ namespace da {
 
 __device__ __forceinline__ float dist2(const float *a, const float *b) {
     const float dx = a[0] - b[0], dy = a[1] - b[1];
-    return sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    // a diverged sample (NaN / Inf poses) must still be assignable: +inf is the "retired" marker of rmin and a NaN
+    // never wins a comparison, so non-finite distances rank as the largest finite value (the reference returns
+    // some wrong assignment in that case; here the row simply goes last, and nothing indexes out of LDS)
+    return d <= 3.402823466e38f ? d : 3.402823466e38f;
 }
 
 // lexicographic (value, index) minimum
@@ -73,7 +77,12 @@ __global__ __launch_bounds__(1024) void k_greedy_assign(const float *__restrict_
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < nw; ++w) lexmin(v, i, redv[w], redi[w]);
-            const int j = rarg[i];
+            if (i >= n) {                                        // cannot happen with finite rmin; never index past LDS
+                i = 0;
+                while (i < n - 1 && !(rmin[i] < INFINITY)) ++i;
+            }
+            int j = rarg[i];
+            j = j < 0 ? 0 : (j >= m ? m - 1 : j);
             bcast[0] = i; bcast[1] = j;
             out[((size_t)r0 + k) * 3] = i;
             out[((size_t)r0 + k) * 3 + 1] = j;

@@ -14,6 +14,31 @@ def default_precision():
     return os.environ.get("DIFFASSEMBLE_PRECISION", "bf16")
 
 
+class _Held:
+    """Cache key over caller tensors that cannot go stale: it keeps a strong reference to every keyed
+    tensor, so the caching allocator cannot hand their addresses to a different same-shaped tensor while
+    the entry lives, and then compares (address, shape, stride, dtype, ``_version``) -- ``_version`` is
+    shared by all views of a storage, so in-place edits through any alias miss.  (A key on ``data_ptr``
+    alone hit for the NEXT Batch of a Lightning loop: batch i is freed before batch i+1 is moved to the
+    device and gets the same addresses with ``_version == 0`` -- a fresh random expander per sample,
+    puzzle_dataset.py:194-212, silently ran on the previous sample's plan.)"""
+
+    __slots__ = ("tensors", "sig", "extra")
+
+    def __init__(self, tensors, extra=()):
+        self.tensors = tuple(tensors)
+        self.sig = tuple(self._sig(t) for t in self.tensors)
+        self.extra = tuple(extra)
+
+    @staticmethod
+    def _sig(t):
+        return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version)
+
+    def matches(self, tensors, extra=()):
+        return (len(tensors) == len(self.tensors) and tuple(extra) == self.extra
+                and all(self._sig(t) == s for t, s in zip(tensors, self.sig)))
+
+
 class DenoiserBase(nn.Module):
     variant = "2d"
 
@@ -22,7 +47,10 @@ class DenoiserBase(nn.Module):
         return {k: v for k, v in self.state_dict().items() if not k.startswith(skip)}
 
     def _param_version(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # the fused optimizer updates the flat parameter buffer through a raw pointer (no ``_version``
+        # bump): its step counter is part of the key, so packed inference weights never outlive a step
+        te = getattr(self, "_train_engine", None)
+        return (tuple((p.data_ptr(), p._version) for p in self.parameters()), te.version if te is not None else 0)
 
     def engine(self, device=None, precision=None) -> DenoiserEngine:
         """The packed HIP denoiser for the module's CURRENT parameters (rebuilt when a
@@ -40,19 +68,18 @@ class DenoiserBase(nn.Module):
         return self._engine
 
     def _plan_for(self, eng, edge_index, batch):
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
-               batch.data_ptr(), batch.numel(), batch._version, id(eng))
-        if getattr(self, "_plan_key", None) != key:
+        key = getattr(self, "_plan_key", None)
+        if key is None or not key.matches((edge_index, batch), (id(eng),)):
             self._plan = eng.plan(edge_index, batch)
-            self._plan_key = key
+            self._plan_key = _Held((edge_index, batch), (id(eng),))
             self._feat_key = None
         return self._plan
 
     def _stage_features(self, eng, plan, feats):
-        key = (feats.data_ptr(), tuple(feats.shape), feats._version, id(plan))
-        if getattr(self, "_feat_key", None) != key:
+        key = getattr(self, "_feat_key", None)
+        if key is None or not key.matches((feats,), (id(plan),)):
             eng.set_features(plan, feats)
-            self._feat_key = key
+            self._feat_key = _Held((feats,), (id(plan),))
 
     def train_engine(self, device=None) -> TrainEngine:
         """Flat-buffer training engine (diffassemble_amd/train.py); rebinds the live parameters as views
@@ -72,12 +99,11 @@ class DenoiserBase(nn.Module):
         """forward_with_feats under autograd: da_train_forward now, da_train_backward when the loss is
         back-propagated (attention weights are not returned on this path, as p_losses asks)."""
         te = self.train_engine(xy_pos.device)
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
-               batch.data_ptr(), batch.numel(), batch._version, "train")
-        if getattr(self, "_tplan_key", None) != key:
+        key = getattr(self, "_tplan_key", None)
+        if key is None or not key.matches((edge_index, batch), (id(te),)):
             from ...graph_plan import build_plan
             self._tplan = build_plan(edge_index.to(te.device), batch.to(te.device), te.virt_nodes).with_source_csr()
-            self._tplan_key = key
+            self._tplan_key = _Held((edge_index, batch), (id(te),))
         out = DenoiserTrainFn.apply(te, self._tplan, xy_pos, time, feats, *te.params)
         return out, None
 

@@ -310,6 +310,24 @@ class GNN_Diffusion(LightningModule):
         from transformers.optimization import Adafactor
         return Adafactor(self.parameters())
 
+    def sync_gradients(self):
+        """Data-parallel gradient exchange of the denoiser: one fused all-reduce of the training
+        engine's flat gradient buffer over RCCL/xGMI.  Lightning calls it through ``on_before_optimizer_step``
+        (once per optimizer step, after gradient accumulation); hand-written loops call it between
+        ``loss.backward()`` and ``optimizer.step()`` (``FusedAdafactor.step`` does it by itself)."""
+        te = getattr(self.model, "_train_engine", None)
+        if te is not None:
+            te.sync_gradients()
+
+    def on_before_optimizer_step(self, optimizer=None, *args, **kwargs):
+        """The reference relies on ``pl.Trainer(strategy="ddp")`` (train_script.py:215-218) to average
+        gradients.  The HIP backward writes ``param.grad`` directly (DenoiserTrainFn returns no autograd
+        gradients), so a DDP wrapper's reducer hooks never fire for these parameters: with one process per
+        GPU and ``torch.distributed`` initialised (Lightning's DDP strategy does both; its wrapper leaves
+        parameters it saw no gradient for untouched under ``find_unused_parameters=True``, the "ddp" default
+        of the Lightning versions the reference pins) the exchange happens HERE, as one all-reduce."""
+        self.sync_gradients()
+
     def training_step(self, batch, batch_idx):
         """spatial_diffusion.py:707-766 (image dumps omitted)."""
         batch_size = batch.batch.max().item() + 1
@@ -383,8 +401,12 @@ class GNN_Diffusion(LightningModule):
         return self._eval_step(batch, batch_idx)
 
     def validation_epoch_end(self, outputs) -> None:
+        """spatial_diffusion.py:903 logs the Metric objects, which Lightning computes AND resets at epoch
+        end; logging plain values, the reset is done here so every epoch reports its own accuracy."""
         if hasattr(self, "metrics"):
             self.log_dict({k: m.compute() for k, m in self.metrics.items()})
+            for m in self.metrics.values():
+                m.reset()
 
     def test_epoch_end(self, outputs) -> None:
         return self.validation_epoch_end(outputs)

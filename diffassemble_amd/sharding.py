@@ -63,7 +63,13 @@ def allreduce_gradients(flat_grad, average=True):
     gradients is the global-batch gradient (spatial_diffusion.py:707-721 under DDP)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return flat_grad
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    if flat_grad.is_cuda and dist.get_backend() == "gloo":
+        # test configuration only (several ranks sharing one GPU cannot use RCCL): stage through the host
+        host = flat_grad.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat_grad.copy_(host)
+    else:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     if average:
         flat_grad.div_(dist.get_world_size())
     return flat_grad

@@ -85,6 +85,17 @@ class TrainEngine:
         self.gw = self._weights_struct(dict(zip(names, self.grad_views)))
         self._ws = None
         self._ws_key = None
+        self.version = 0              # bumped by every raw-pointer update of ``flat`` (FusedAdafactor.step)
+        self.grads_synced = False     # True between sync_gradients() and the next backward
+
+    def sync_gradients(self, average=True):
+        """Data-parallel exchange (the reference gets it from Lightning's ``strategy="ddp"``,
+        train_script.py:215-218): ONE all-reduce of ``flat_grad`` over the default process group, at most once
+        per set of accumulated backward passes.  No-op without an initialised multi-rank group."""
+        from .sharding import allreduce_gradients
+        if not self.grads_synced:
+            allreduce_gradients(self.flat_grad, average=average)
+            self.grads_synced = True
 
     def _weights_struct(self, by):
         w = _lib.DaWeights()
@@ -147,6 +158,7 @@ class TrainEngine:
                        for p, gv in zip(self.params, self.grad_views))
         if not attached:
             self.flat_grad.zero_()
+        self.grads_synced = False
         x = x.detach().to(self.device, torch.float32).contiguous()
         t = t.detach().to(self.device, torch.int64).contiguous()
         d_out = d_out.detach().to(self.device, torch.float32).contiguous()
@@ -267,6 +279,8 @@ class FusedAdafactor(torch.optim.Optimizer):
             return loss                                   # nothing back-propagated yet
         g = self.defaults
         self.step_count += 1
+        eng.sync_gradients()          # no-op on one rank / when GNN_Diffusion.on_before_optimizer_step already did it
+        eng.version += 1              # invalidates packed inference weights (DenoiserBase._param_version)
         with torch.cuda.device(eng.device):
             _lib.check(self.lib.da_adafactor_step(
                 self.n_params, _lib.ptr(self.ptab), self.n_blocks, _lib.ptr(self.btab), _lib.ptr(eng.flat),

@@ -41,8 +41,49 @@ LOOPS3D = [
 TRAIN2D = [
     dict(name="train_rot144_g2", base="rot144_g2_sharp", mean="EPSILON", seed=11),
 ]
+# golden_v2.npz (make_golden_v2.py): the BENCHED sizes -- 900-piece dense (headline) and the scripted
+# Exphander degree d = 539 ("60 %", train_celeba_rot.sh:12) -- and the reference's own greedy_cost_assignment
+FWD2D_BIG = [
+    dict(name="rot900_g1",       sizes=[900], c=4, graph="dense",      arch="transformer", V=0, steps=100, seed=21, qk_gain=3.0),
+    dict(name="exo900_d539_v8",  sizes=[900], c=4, graph="regular539", arch="exophormer",  V=8, steps=300, seed=22, qk_gain=3.0),
+]
+LOOPS2D_BIG = [
+    dict(name="ddim_rot900_x0", base="rot900_g1", T=100, ratio=1, mean="START_X", noise_weight=1.0, sampling="DDIM", max_iters=3),
+]
+# greedy_cost_assignment (spatial_diffusion.py:179-216): pos1 = predicted positions, pos2 = grid cells
+GREEDY = [
+    dict(name="greedy_6x6_noisy",   rows=6,  cols=6,  noise=0.30, seed=31, kind="noisy"),
+    dict(name="greedy_12x12_noisy", rows=12, cols=12, noise=0.10, seed=32, kind="noisy"),
+    dict(name="greedy_30x30_noisy", rows=30, cols=30, noise=0.05, seed=33, kind="noisy"),
+    dict(name="greedy_12x12_exact", rows=12, cols=12, noise=0.0,  seed=34, kind="exact"),     # all-zero-distance ties
+    dict(name="greedy_rect_20v30",  rows=5,  cols=6,  noise=0.20, seed=35, kind="fewer_rows", n1=20),
+    dict(name="greedy_dups",        rows=4,  cols=4,  noise=0.0,  seed=36, kind="dups"),      # ties at non-zero distances
+]
 # fmt: on
 SCHEDULE_T = [50, 100, 300]
+GOLDEN2_FILE = os.path.join(os.path.dirname(__file__), "golden_v2.npz")
+
+
+def greedy_inputs(spec):
+    """(pos1 [n, 2], pos2 [m, 2]) fp32 of a GREEDY case, regenerated from its seed.  pos2 is the grid the
+    eval step builds (spatial_diffusion.py:925-930: linspace(-1, 1) meshgrid, 'xy' indexing)."""
+    rng = np.random.default_rng(spec["seed"])
+    y = torch.linspace(-1, 1, spec["rows"])
+    x = torch.linspace(-1, 1, spec["cols"])
+    grid = torch.stack(torch.meshgrid(x, y, indexing="xy"), -1).reshape(-1, 2)
+    m = grid.shape[0]
+    perm = torch.from_numpy(rng.permutation(m))
+    noise = torch.from_numpy(rng.standard_normal((m, 2)).astype(np.float32)) * spec["noise"]
+    if spec["kind"] in ("noisy", "exact"):
+        pos1 = grid[perm] + noise
+    elif spec["kind"] == "fewer_rows":
+        pos1 = (grid[perm] + noise)[: spec["n1"]]
+    elif spec["kind"] == "dups":
+        pos1 = grid[perm].clone()
+        pos1[: m // 2] = torch.tensor([0.1234, -0.4321])          # half of the pieces on one point
+    else:
+        raise ValueError(spec["kind"])
+    return pos1.contiguous(), grid.contiguous()
 
 
 def _graph(kind, n, rng):
@@ -81,7 +122,7 @@ def build_case(spec, variant="2d"):
 
 
 def by_name(name):
-    for lst in (FWD2D, FWD3D):
+    for lst in (FWD2D, FWD3D, FWD2D_BIG):
         for s in lst:
             if s["name"] == name:
                 return s
@@ -90,3 +131,7 @@ def by_name(name):
 
 def load_golden():
     return np.load(GOLDEN_FILE)
+
+
+def load_golden2():
+    return np.load(GOLDEN2_FILE)

@@ -249,3 +249,66 @@ def test_csr_training_path_on_complete_graphs_subprocess():
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "3 passed" in r.stdout
+
+
+# ---------------------------------------------------------------------------- data parallelism through the module surface
+def _dp_train_worker(rank, world, port, ret):
+    """One data-parallel rank (both ranks share cuda:0, so the group is gloo; on the 8-GPU node it is nccl = RCCL):
+    the reference-shaped module, its own shard of the puzzles, three optimizer steps the way a hand-written loop /
+    Lightning drives them.  No explicit gradient exchange here: ``on_before_optimizer_step`` (Lightning's hook) is
+    called on even steps and left to ``FusedAdafactor.step`` on odd ones -- both routes must all-reduce exactly once."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DIFFASSEMBLE_FUSED_OPTIMIZER="1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import cases as CC
+    from diffassemble_amd import sharding as S
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    dev = torch.device("cuda:0")
+    spec = CC.by_name("rot144_g2_sharp")
+    case = CC.build_case(spec)
+    m = GNN_Diffusion(steps=spec["steps"], sampling="DDIM", rotation=True, visual_pretrained=False,
+                      model_mean_type=ModelMeanType.EPSILON)
+    m.model.load_state_dict(case["sd"], strict=False)
+    m = m.to(dev).train()
+    opt = m.configure_optimizers()
+    assert type(opt).__name__ == "FusedAdafactor"
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(case["x"].shape, generator=g)
+    x, feats, ei, batch, lo, hi = S.shard_batch(case["x"], case["feats"], case["edge_index"], case["batch"], rank, world)
+    for step in range(3):
+        opt.zero_grad()
+        loss = m.p_losses(x.to(dev), case["t"][lo:hi].to(dev), noise=noise[lo:hi].to(dev), loss_type="huber", cond=None,
+                          edge_index=ei.to(dev), batch=batch.to(dev), patch_feats=feats.to(dev))
+        loss.backward()
+        if step % 2 == 0:
+            m.on_before_optimizer_step(opt)
+        opt.step()
+    torch.cuda.synchronize()
+    te = m.model.train_engine()
+    ret[f"flat{world}_{rank}"] = te.flat.detach().cpu()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_training_two_ranks_equals_full_batch(dev):
+    """train_script.py:215-218 (strategy="ddp") on this build: two ranks, one puzzle each, three fused-Adafactor steps
+    == one process on both puzzles (the mean of the two shard losses' gradients is the full-batch gradient), and both
+    ranks hold bit-identical parameters afterwards (the optimizer's reductions are deterministic)."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_train_worker, args=(2, 29561, ret), nprocs=2, join=True)
+    mp.spawn(_dp_train_worker, args=(1, 29563, ret), nprocs=1, join=True)
+    a, b, full = ret["flat2_0"], ret["flat2_1"], ret["flat1_0"]
+    assert torch.equal(a, b), "data-parallel replicas diverged"
+    case = C.build_case(C.by_name("rot144_g2_sharp"))
+    moved = float((full - a).abs().max())
+    assert rel(a, full) < 1e-4, rel(a, full)
+    assert float((full.abs().max())) > 0 and moved < 1e-3

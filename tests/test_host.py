@@ -241,3 +241,36 @@ def test_encoder_module_has_the_reference_state_dict_layout():
     with pytest.raises(Exception) as ei:
         net.patch_features(torch.zeros(1, 3, 32, 32))                   # CPU tensor / no GPU: loud failure
     assert "ROCm" in str(ei.value) or "hip" in str(ei.value).lower()
+
+
+@pytest.mark.parametrize("g", C.GREEDY, ids=lambda s: s["name"])
+def test_host_greedy_assignment_vs_reference_torchscript(g):
+    """The host glue version (stable sort of all pairs) against OUTPUTS of the reference's own TorchScript
+    greedy_cost_assignment (golden_v2.npz): index-exact, in assignment order."""
+    from diffassemble_amd.model.spatial_diffusion import greedy_cost_assignment
+    pos1, pos2 = C.greedy_inputs(g)
+    exp = torch.from_numpy(C.load_golden2()[f"{g['name']}/assignment"])
+    assert torch.equal(greedy_cost_assignment(pos1, pos2), exp)
+
+
+def test_cache_key_holds_its_tensors_and_sees_in_place_edits():
+    """_Held (DenoiserBase plan / feature caches): a key built from a tensor cannot match a DIFFERENT tensor that the
+    allocator placed at the same address (it keeps the first one alive), matches new views of the same memory, and
+    misses after an in-place edit through any alias."""
+    import gc
+    import weakref
+    from diffassemble_amd.model.backbones._denoiser_base import _Held
+    a = torch.arange(12).reshape(2, 6)
+    key = _Held((a,), ("plan",))
+    assert key.matches((a,), ("plan",)) and key.matches((a.view(2, 6),), ("plan",))
+    assert not key.matches((a,), ("other",)) and not key.matches((a.clone(),), ("plan",))
+    assert not key.matches((a[:, :3],), ("plan",)) and not key.matches((a.t(),), ("plan",))
+    w = weakref.ref(a)
+    del a
+    gc.collect()
+    assert w() is not None                                    # the key keeps the storage alive: its address cannot be reused
+    b = w()
+    b[0, 0] = 99                                              # in-place edit bumps the shared version counter
+    assert not key.matches((b,), ("plan",))
+    src = open(os.path.join(ROOT, "diffassemble_amd", "model", "backbones", "_denoiser_base.py")).read()
+    assert "data_ptr(), tuple(edge_index.shape)" not in src  # the address-only keys are gone

@@ -207,3 +207,20 @@ def test_p_losses_and_gradients_match_reference(golden, tr):
             assert rel_err(stats(p.grad), golden[f"{tr['name']}/grad_stats/{k}"]) < 1e-3, k
             n += 1
     assert n >= 28
+
+
+# ------------------------------------------------------------------ benched sizes (golden_v2.npz, make_golden_v2.py)
+@pytest.mark.parametrize("spec", C.FWD2D_BIG, ids=lambda s: s["name"])
+def test_oracle_at_the_benched_sizes_vs_reference_fixture(spec):
+    """The oracle on the headline 900-piece dense puzzle and on the scripted Exphander degree d = 539 against
+    the reference's own forward (about 20 s each on the host)."""
+    g2 = C.load_golden2()
+    case = C.build_case(spec)
+    out, att = D.eff_gat_forward_with_feats(case["sd"], case["x"], case["t"], case["edge_index"], case["feats"],
+                                            case["batch"], spec["arch"], spec["V"])
+    n = spec["name"]
+    assert rel_err(out, g2[f"{n}/out"]) < RTOL
+    assert tuple(att[-1][0].shape) == tuple(g2[f"{n}/ei_last_shape"])
+    assert rel_err(att[-1][1][:256], g2[f"{n}/alpha_last_head"]) < RTOL
+    assert rel_err(att[-1][1][-256:], g2[f"{n}/alpha_last_tail"]) < RTOL
+    assert rel_err(stats(att[-1][1]), g2[f"{n}/alpha_last_stats"]) < RTOL
