@@ -1,28 +1,41 @@
 #!/usr/bin/env python
-"""Headline benchmark: denoising steps/sec on 900-piece dense puzzles, T = 100 (BASELINE.json).
+"""Benchmarks of the hot path.  Default = the headline metric of BASELINE.json:
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-One "step" = one p_sample_ddim call of the reference (spatial_diffusion.py:548-627): one denoiser
-forward over the whole batch + the DDIM pose update.  Every rank holds its own batch of
-``--puzzles`` independent 30x30 puzzles (N = 900 pieces, E = 810 000 edges each, dense with self
-loops: BASELINE config 3'); puzzles shard across GPUs with NO data-path collective (weak scaling,
-SURVEY 8e).  Inputs (piece features, x_T; weights = the module's seeded default init) are synthetic and resident in HBM
-before the timed region.  The K timed steps are consecutive iterations of the T = 100 DDIM loop,
-replayed as hipGraph launches; timing is barrier + synchronize on both sides, MAX over ranks.
+  denoising steps/sec on 900-piece dense puzzles, T = 100 (BASELINE config 3').
 
-value = puzzle-level denoising steps per second over the whole job
-      = n_gpus * puzzles_per_gpu * K / seconds          (also reported: batch steps/s, ms/step).
+One "step" = one p_sample_ddim call of the reference (spatial_diffusion.py:548-627): one denoiser forward over the
+whole batch + the DDIM pose update.  Every rank holds its own batch of ``--puzzles`` independent puzzles; puzzles shard
+across GPUs with NO data-path collective (weak scaling).  Inputs (piece features, x_T; weights = the
+module's seeded default init) are synthetic and resident in HBM before the timed region; the per-Batch staging
+(``da_denoiser_set_features``: feature copy + the loop-invariant share of mlp.0) happens once per sampling
+loop, OUTSIDE the timed region, and is reported as ``set_features_ms``.  The K timed steps are consecutive iterations
+of the DDIM loop, replayed as hipGraph launches; timing is barrier + synchronize on both sides, MAX over ranks.
+``replay`` additionally reports the median / min / max over >= 30 further replays of the same graph (one K-step
+replay is a ~10 ms sample).
 
-roofline: per-kernel-class time is measured live with HIP events on the launch stream
-(da_profile_*), in a separate eager pass over the same steps; the dominant kernel is the
-last-layer graph attention (C = 144, 60 % of the attention FLOPs).
-cpu_baseline: the CPU oracle (pure-torch fp32 restatement of the reference, oracle/) timed on
-this box's host cores on ONE puzzle for ONE step (~15-30 s of CPU work) -- baseline only.
+Every BASELINE configuration is driver-runnable with the same JSON schema:
+
+  --config 1    6x6 translation-only, T=50, EPSILON, fp32, G=1      (the reference's CPU-runnable case)
+  --config 2    12x12 rot+trans dense, T=100, bf16, G=512
+  --config 3    30x30 Exphander (--degree 539 | 90 ...), exophormer arch V=8, T=100, bf16, G=32
+  --config 3p   30x30 dense -- the headline, default
+  --config 4    3D fragments: P=20, D=832, SE(3) head, T=300 / ratio 10, bf16, G=256
+  --config 5    training: 12x12 rot dense, 64 puzzles per GPU, Huber, Adafactor, one optimizer step per "step"
+
+roofline: per-kernel-class time is measured live with HIP events on the launch stream (da_profile_*), in a separate
+eager pass over the same steps.  ``roofline.kernel`` is the class with the LARGEST share of the step's kernel time;
+every class is listed under ``roofline.classes`` with its algorithmic FLOP (the reference's formulation) and
+the FLOP / bytes the kernels really execute after the algebraic folds of DESIGN 3c; ``attention_total`` is the
+north-star figure (MFMA utilisation of the dense attention, all four layers).
+cpu_baseline: the CPU oracle (pure-torch fp32 restatement of the reference, oracle/) timed on this box's host cores on
+ONE puzzle: thread count chosen by a sweep, 1 warm-up + 3 repeats, median -- baseline only.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -35,30 +48,235 @@ N_PIECES, T_STEPS = int(os.environ.get("BENCH_N_EXPERIMENT", 900)), 100   # the 
 F_NODE = 6_432_128          # FLOP per piece per step (SURVEY 8d / BASELINE.md)
 F_EDGE = 7_680              # FLOP per edge per step, all 4 layers
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0                            # MI355X_MICROARCH.md (HBM3E spec; ~6300 achievable)
+PROFILE_ROUND = "r02"
+
+CONFIGS = {
+    "1": dict(name="6x6 translation-only (N=36, K36 without self loops, E=1260), DDIM T=50, EPSILON, c=2, transformer arch",
+              variant="2d", arch="transformer", V=0, n=36, graph="dense_noloop", rotation=False, T=50, ratio=1,
+              mean="EPSILON", G=1, prec="fp32"),
+    "2": dict(name="12x12 rot+trans dense puzzle (N=144, E=20736 incl. self loops), DDIM T=100, START_X, c=4, transformer arch",
+              variant="2d", arch="transformer", V=0, n=144, graph="dense", rotation=True, T=100, ratio=1,
+              mean="START_X", G=512, prec="bf16"),
+    "3": dict(name="30x30 Exphander puzzle (N=900, random d-regular expander, exophormer arch, 8 virtual nodes), DDIM T=100, START_X, c=4",
+              variant="2d", arch="exophormer", V=8, n=900, graph="regular", rotation=True, T=100, ratio=1,
+              mean="START_X", G=32, prec="bf16"),
+    "3p": dict(name="30x30 dense puzzle (N=900, E=810000 incl. self loops), DDIM eta=0, T=100, START_X, rot+trans c=4, transformer arch",
+               variant="2d", arch="transformer", V=0, n=N_PIECES, graph="dense", rotation=True, T=T_STEPS, ratio=1,
+               mean="START_X", G=32, prec="bf16"),
+    "4": dict(name="3D fragments (P=20 per object, D=832, complete graph E=400, SE(3) pose head), DDIM T=300 ratio 10, START_X",
+              variant="3d", arch="transformer", V=0, n=20, graph="dense", rotation=True, T=300, ratio=10,
+              mean="START_X", G=256, prec="bf16"),
+}
 
 
-def dense_batch(G, n, device):
-    """edge_index / batch of G complete graphs with self loops, built on the device."""
+def dense_batch(G, n, device, loops=True):
+    """edge_index / batch of G complete graphs (with or without self loops), built on the device."""
     r = torch.arange(n, device=device).repeat_interleave(n)
     c = torch.arange(n, device=device).repeat(n)
+    if not loops:
+        keep = r != c
+        r, c = r[keep], c[keep]
     one = torch.stack([r, c])
     ei = torch.cat([one + g * n for g in range(G)], 1)
     batch = torch.arange(G, device=device).repeat_interleave(n)
     return ei, batch
 
 
-def cpu_baseline(sd, seed, threads):
+def make_graphs(cfg, G, degree, device, seed):
+    if cfg["graph"] == "regular":
+        import numpy as np
+        from diffassemble_amd import expander
+        perms = expander.draw_permutations(cfg["n"], G, np.random.default_rng(seed))
+        return expander.regular_edge_index(perms, degree, device)
+    return dense_batch(G, cfg["n"], device, loops=cfg["graph"] == "dense")
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# work models: algorithmic (the reference's formulation, SURVEY 8d) and executed (after the folds of DESIGN 3c)
+def work_model(cfg, G, E, n_nodes_ext, flags, prec, hybrid, fused_hidden=False):
+    """-> {class: dict(alg_flop, exec_flop, bytes)} PER STEP for the whole batch.  ``bytes`` = compulsory HBM traffic
+    of the class's kernels (each operand read once, each result written once, activation dtype s)."""
+    threed = cfg["variant"] == "3d"
+    D, Hd = (832, 256) if threed else (1152, 128)
+    c = 7 if threed else (4 if cfg["rotation"] else 2)
+    N = G * cfg["n"]
+    Nx = n_nodes_ext                     # + virtual rows (exophormer)
+    s = 2 if prec == "bf16" else 4
+    mlp2_fused, last_fold = bool(flags & 1), bool(flags & 2)
+    W = {}
+    W["embed"] = dict(alg=N * 2 * (c * 16 + 16 * 32), exe=N * 2 * (c * 16 + 16 * 32), bytes=N * (c * 4 + 8 + 64 * s))
+    # mlp: Linear(D -> Hd) act Linear(Hd -> D); executed: the feature columns of mlp.0 are hoisted (K = 64 per step),
+    # mlp.2 is composed into its consumers when the fold is on
+    exe_mlp = N * 2 * 64 * Hd + (0 if mlp2_fused else N * 2 * Hd * D)
+    W["linear_mlp"] = dict(alg=N * 2 * (D * Hd + Hd * D), exe=exe_mlp,
+                           bytes=N * (64 * s + Hd * s + Hd * s) + (0 if mlp2_fused else N * (Hd + D) * s))
+    k0 = Hd if mlp2_fused else D
+    n3 = (2 * D + 256) if last_fold else 4 * D
+    exe_q = Nx * 2 * (k0 * 1024 + 256 * 1024 * 2 + 256 * n3)
+    W["linear_qkvs"] = dict(alg=Nx * 2 * (D * 1024 + 256 * 1024 * 2 + 256 * 4 * D), exe=exe_q,
+                            bytes=Nx * s * ((k0 + 1024) + 2 * (256 + 1024) + (256 + n3)))
+    cv = 32 if last_fold else D // 8
+    if hybrid or E == G * cfg["n"] ** 2 or E == G * cfg["n"] * (cfg["n"] - 1):
+        pairs = G * cfg["n"] ** 2        # the matrix-core kernels multiply every (query, key) pair of a graph
+        W["attn_hidden"] = dict(alg=E * 3 * 4 * 256, exe=pairs * 3 * 4 * 256, bytes=3 * Nx * s * 5 * 256)
+        W["attn_last"] = dict(alg=E * 4 * D, exe=pairs * 2 * 8 * (D // 8 + cv),
+                              bytes=Nx * s * (2 * D + 8 * cv) + N * (8 * cv * 4 if last_fold else 2 * D * s))
+    else:                                # edge-list kernels: one K row + one V row gathered per edge
+        W["attn_hidden"] = dict(alg=E * 3 * 4 * 256, exe=E * 3 * 4 * 256, bytes=3 * (E * (2 * 256 * s + 4) + Nx * 2 * 256 * s))
+        W["attn_last"] = dict(alg=E * 4 * D, exe=E * 4 * D, bytes=E * (2 * D * s + 4) + Nx * 2 * D * s)
+    if threed:
+        hf = N * 2 * 2 * (D * 256 + 256 * 3)
+        W["head"] = dict(alg=hf, exe=hf, bytes=N * (D * s + 2 * 256 * s + 7 * 4))
+    else:
+        hf = N * 2 * (D * 32 + 32 * c)
+        he = N * 2 * ((Hd + 256) * 32 + 32 * c) if last_fold else hf
+        W["head"] = dict(alg=hf, exe=he, bytes=N * ((Hd + 256 + 8 * 32 * 2) * s if last_fold else D * s) + N * c * 4)
+    W["update"] = dict(alg=N * c * 12, exe=N * c * 12, bytes=N * c * 4 * 3)
+    if fused_hidden:
+        # hidden convs run as ONE kernel each (da_conv_fused.hip): their projections move from linear_qkvs into
+        # conv_fused together with the C = 32 attention; Q / K / V / skip never reach HBM
+        pa, pe = Nx * 2 * (D * 1024 + 256 * 1024 * 2), Nx * 2 * (k0 * 1024 + 256 * 1024 * 2)
+        ah = W.pop("attn_hidden")
+        W["conv_fused"] = dict(alg=pa + ah["alg"], exe=pe + ah["exe"], bytes=Nx * s * ((k0 + 256) + 2 * (256 + 256)),
+                               alg_attention=ah["alg"], exe_attention=ah["exe"])
+        W["linear_qkvs"] = dict(alg=W["linear_qkvs"]["alg"] - pa, exe=W["linear_qkvs"]["exe"] - pe, bytes=Nx * s * (256 + n3))
+    return W
+
+
+def roofline_report(prof, kp, work, prec, traffic_file, cfg_key, G):
+    """Per-class roofline entries + the dominant class (largest share of the step's kernel time)."""
+    peak = PEAK_TFLOPS[prec]
+    total_ms = sum(ms for ms, _ in prof.values())
+    pmc = {}
+    try:    # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside this process): profiles/<round>/pmc_traffic.json
+        pmc = json.load(open(traffic_file)).get(cfg_key, {}).get(prec, {}).get(str(G), {})
+    except (OSError, ValueError):
+        pass
+    classes = {}
+    for k, (ms, n) in prof.items():
+        if not n or k not in work:
+            continue
+        w = work[k]
+        per_step_s = ms / kp * 1e-3
+        launches = n / kp
+        ent = {"time_share": ms / total_ms, "us_per_step": ms / kp * 1e3, "launches_per_step": launches,
+               "avg_launch_us": ms / n * 1e3,
+               "alg_flop_per_launch": w["alg"] / launches, "exec_flop_per_launch": w["exe"] / launches,
+               "alg_tflops": w["alg"] / per_step_s / 1e12, "exec_tflops": w["exe"] / per_step_s / 1e12,
+               "frac_mfma_peak_alg": w["alg"] / per_step_s / 1e12 / peak,
+               "frac_mfma_peak_exec": w["exe"] / per_step_s / 1e12 / peak,
+               "compulsory_bytes_per_launch": w["bytes"] / launches,
+               "compulsory_GBps": w["bytes"] / per_step_s / 1e9,
+               "frac_hbm_peak": w["bytes"] / per_step_s / 1e9 / HBM_PEAK_GBPS}
+        if k in pmc:      # measured: FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, bytes per launch
+            t = (2.0 * pmc[k]["fetch_kib"] + pmc[k]["write_kib"]) * 1024.0
+            ent["pmc_traffic_bytes_per_launch"] = t
+            ent["pmc_traffic_GBps"] = t / (ms / n * 1e-3) / 1e9
+        classes[k] = ent
+    dom = max(classes, key=lambda k: classes[k]["time_share"])
+    d = classes[dom]
+    gather = d["frac_hbm_peak"] > d["frac_mfma_peak_alg"]
+    if gather:
+        roof = {"bound": "hbm", "kernel": dom, "achieved": d["compulsory_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": d["frac_hbm_peak"], "traffic": d.get("pmc_traffic_bytes_per_launch")}
+    else:
+        roof = {"bound": "mfma", "kernel": dom, "achieved": d["alg_tflops"], "peak": peak, "unit": "TFLOP/s",
+                "frac": d["frac_mfma_peak_alg"], "traffic": d.get("pmc_traffic_bytes_per_launch"),
+                "executed_tflops": d["exec_tflops"], "executed_frac_of_peak": d["frac_mfma_peak_exec"]}
+    roof["kernel_time_share"] = d["time_share"]
+    roof["avg_launch_us"] = d["avg_launch_us"]
+    roof["traffic_source"] = (f"profiles/{PROFILE_ROUND}/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                              if roof["traffic"] is not None else None)
+    akeys = [k for k in ("attn_hidden", "attn_last", "conv_fused") if k in classes]
+    if akeys:
+        att = [classes[k] for k in akeys]
+        t = sum(a["us_per_step"] for a in att) * 1e-6
+        alg = sum(work[k]["alg"] for k in akeys)
+        exe = sum(work[k]["exe"] for k in akeys)
+        roof["attention_total"] = {"classes": akeys, "us_per_step": t * 1e6, "alg_tflops": alg / t / 1e12,
+                                   "frac_mfma_peak_alg": alg / t / 1e12 / peak,
+                                   "exec_tflops": exe / t / 1e12, "frac_mfma_peak_exec": exe / t / 1e12 / peak,
+                                   "time_share": sum(a["time_share"] for a in att)}
+        if "conv_fused" in akeys:
+            # the fused kernels' time includes their Q|K|V|skip projections; the attention-only FLOP over that time is a
+            # LOWER bound of the attention's MFMA utilisation
+            aa = sum(work[k].get("alg_attention", work[k]["alg"]) for k in akeys)
+            roof["attention_total"]["note"] = "conv_fused time includes the layers' projections (counted in alg/exec above)"
+            roof["attention_total"]["frac_mfma_peak_attention_flop_only_lower_bound"] = aa / t / 1e12 / peak
+    roof["classes"] = classes
+    roof["kernel_ms_per_step"] = total_ms / kp
+    return roof
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(cfg, sd, degree, full=False):
+    """The oracle (oracle/: pure-torch fp32 edge-list restatement of the reference) on the host cores, ONE puzzle of the
+    configuration.  Thread count: 1 warm-up + 1 step at each of {1, 16, 64, all} on a bounded sample, best wins; then
+    1 warm-up + 3 repeats at that count on the real puzzle size, median."""
+    import numpy as np
     from oracle import diffusion as ODF
     from oracle import weights as W
-    torch.set_num_threads(threads)
-    x, feats = W.make_inputs(N_PIECES, 4, 1088, seed)
-    ei, batch = W.collate([W.dense_edge_index(N_PIECES, True)], [N_PIECES])
-    sch = ODF.make_schedule(T_STEPS)
-    t0 = time.perf_counter()
-    ODF.p_sample_loop(sd, sch, x, ei, feats, batch, T_STEPS, 1, "START_X", max_iters=1)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "puzzle-steps/s", "cores": threads, "kind": "port",
-            "sample": f"1 DDIM step of 1 puzzle (N=900, E=810000), oracle/ torch fp32, {dt:.1f} s"}
+    threed = cfg["variant"] == "3d"
+    n = cfg["n"]
+    c = 7 if threed else (4 if cfg["rotation"] else 2)
+
+    def sample(n_, seed=7):
+        rng = np.random.default_rng(seed)
+        if cfg["graph"] == "regular":
+            d_ = min(degree, n_ - 1) - ((min(degree, n_ - 1) * n_) % 2)
+            ei1 = W.random_regular_edge_index(n_, d_, rng)
+        else:
+            ei1 = W.dense_edge_index(n_, cfg["graph"] == "dense")
+        ei, batch = W.collate([ei1], [n_])
+        x, feats = W.make_inputs(n_, c, 768 if threed else 1088, seed)
+        if threed:
+            x[:, :4] = torch.nn.functional.normalize(x[:, :4], dim=-1)
+        return x, feats, ei, batch
+
+    sch = ODF.make_schedule(cfg["T"])
+
+    def steps(inp, k):
+        x, feats, ei, batch = inp
+        t0 = time.perf_counter()
+        if threed:
+            ODF.p_sample_loop_3d(sd, sch, x, ei, feats, batch, cfg["T"], cfg["ratio"], cfg["mean"], max_iters=k)
+        else:
+            ODF.p_sample_loop(sd, sch, x, ei, feats, batch, cfg["T"], cfg["ratio"], cfg["mean"], cfg["arch"], cfg["V"], max_iters=k)
+        return (time.perf_counter() - t0) / k
+
+    allc = os.cpu_count() or 1
+    cand = sorted({1, min(16, allc), min(64, allc), allc})
+    n_sweep = min(n, 300)                       # bounded: a 300-piece puzzle of the same kind costs ~1/9 of the real one
+    sw = sample(n_sweep)
+    k_sweep = 3 if n_sweep >= 200 else 10
+    sweep = {}
+    for th in cand:
+        torch.set_num_threads(th)
+        steps(sw, 1)
+        sweep[th] = 1.0 / steps(sw, k_sweep)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    real = sample(n)
+    k_real = 1 if n >= 900 else (5 if n >= 144 else 20)
+    steps(real, 1)                              # warm-up
+    reps = [steps(real, k_real) for _ in range(3)]
+    med = statistics.median(reps)
+    out = {"value": 1.0 / med, "unit": "puzzle-steps/s", "cores": best, "kind": "port",
+           "sample": f"1 puzzle (N={n}), {k_real} DDIM step(s) per repeat, 1 warm-up + 3 repeats, median {med:.2f} s/step "
+                     f"(repeats {', '.join(f'{r:.2f}' for r in reps)}), oracle/ torch fp32, {best} threads",
+           "thread_sweep": {"sample": f"N={n_sweep} puzzle of the same kind, {k_sweep} steps after 1 warm-up",
+                            "puzzle_steps_per_s": {str(k): v for k, v in sweep.items()}},
+           "host_cores": allc}
+    if full or n < 900:
+        torch.set_num_threads(1)
+        steps(real, 1)
+        out["value_1_thread"] = 1.0 / steps(real, k_real)
+    else:
+        out["value_1_thread"] = None
+        out["value_1_thread_note"] = "k=1 at N=900 takes minutes: see thread_sweep['1'] (N=300) or run --cpu-baseline-full"
+    torch.set_num_threads(allc)
+    return out
 
 
 def train_bench(args, world, rank, dev):
@@ -90,7 +308,7 @@ def train_bench(args, world, rank, dev):
         loss = m.p_losses(x0, t, loss_type="huber", cond=None, edge_index=ei, batch=batch, patch_feats=feats)
         loss.backward()
         if timed: ev[1].record()
-        S.allreduce_gradients(te.flat_grad)
+        te.sync_gradients()                       # ONE fused all-reduce (FusedAdafactor.step would do it otherwise)
         if timed: ev[2].record()
         opt.step()
         if timed:
@@ -294,24 +512,194 @@ def e2e_bench(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def build_module(cfg, dev, prec):
+    """The reference-shaped module with seeded default-initialised weights (no checkpoints here), exactly what
+    viz_script.py / train_3d.py would build."""
+    from diffassemble_amd.model.spatial_diffusion import ModelMeanType
+    torch.manual_seed(0)
+    mean = getattr(ModelMeanType, cfg["mean"])
+    if cfg["variant"] == "3d":
+        from diffassemble_amd.model.spatial_diffusion_3d_test_double_diffusion import GNN_Diffusion as G3
+        m = G3(steps=cfg["T"], sampling="DDIM", inference_ratio=cfg["ratio"], noise_weight=1.0, model_mean_type=mean,
+               backbone="vn_dgcnn", architecture=cfg["arch"])
+    else:
+        from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion
+        m = GNN_Diffusion(steps=cfg["T"], sampling="DDIM", inference_ratio=cfg["ratio"], rotation=cfg["rotation"],
+                          noise_weight=1.0, model_mean_type=mean, visual_pretrained=False, architecture=cfg["arch"],
+                          virt_nodes=cfg["V"] or 4)
+    m = m.to(dev).eval()
+    m.model.precision = prec
+    return m
+
+
+def sample_bench(args, world, rank, dev):
+    from diffassemble_amd import _lib
+    from diffassemble_amd.graph_plan import build_plan
+    cfg = CONFIGS[args.config]
+    G = args.puzzles or cfg["G"]
+    prec = args.precision or cfg["prec"]
+    K, Wm = args.steps, args.warmup
+    n = cfg["n"]
+    threed = cfg["variant"] == "3d"
+    model = build_module(cfg, dev, prec)
+    eng = model.model.engine(dev)
+    sd = {k: v.detach().cpu() for k, v in model.model._denoiser_state().items()}        # for the CPU baseline leg
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    N = G * n
+    feats = torch.randn((N, 768 if threed else 1088), generator=gen, device=dev)
+    c = 7 if threed else (4 if cfg["rotation"] else 2)
+    x_T = torch.randn((N, c), generator=gen, device=dev)
+    if threed:                                   # identity rotations + random translations (...double_diffusion.py:697-710)
+        x_T[:, :4] = 0.0
+        x_T[:, 0] = 1.0
+    ei, batch = make_graphs(cfg, G, args.degree, dev, 3 + rank)
+    plan = eng.plan(ei, batch)
+    E = int(plan.n_edges)
+    sch = model._schedule()
+    mt = _lib.MEAN_START_X if cfg["mean"] == "START_X" else _lib.MEAN_EPSILON
+    its = (cfg["T"] + cfg["ratio"] - 1) // cfg["ratio"]
+
+    def run(n_iters, graph, p=None):
+        return eng.sample_loop(p or plan, sch, x_T, feats, ratio=cfg["ratio"], mean_type=mt, max_iters=n_iters,
+                               keep_trajectory=False, use_graph=graph, restage=False)
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    eng.set_features(plan, feats)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        eng.set_features(plan, feats)
+    e1.record()
+    torch.cuda.synchronize()
+    set_features_ms = e0.elapsed_time(e1) / 3
+    chunks = [its] * (K // its) + ([K % its] if K % its else [])
+    if Wm > 0:
+        run(min(Wm, its), False)                           # W untimed eager steps
+    for ck in sorted(set(chunks)):
+        run(ck, True)                                      # capture + instantiate (+ one untimed replay)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for ck in chunks:
+        _, x_final = run(ck, True)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    assert torch.isfinite(x_final).all(), "non-finite poses"
+
+    # the same graph replayed >= 30 more times, each replay timed on its own (rank-local; extra information only)
+    reps = []
+    for _ in range(args.replays):
+        torch.cuda.synchronize()
+        tr = time.perf_counter()
+        run(chunks[0], True)
+        torch.cuda.synchronize()
+        reps.append((time.perf_counter() - tr) / chunks[0] * 1e3)
+    replay = {"replays": len(reps), "steps_per_replay": chunks[0], "ms_per_step_median": statistics.median(reps),
+              "ms_per_step_min": min(reps), "ms_per_step_max": max(reps)} if reps else None
+
+    roof = sparse = None
+    flags = int(eng.flags)
+    if not args.no_roofline:
+        kp = min(K, 20, its)
+        eng.profile(True)
+        run(kp, False)
+        prof = eng.profile_read()
+        eng.profile(False)
+        work = work_model(cfg, G, E, plan.n_nodes, flags, prec, bool(plan.hybrid), prof.get("conv_fused", (0, 0))[1] > 0)
+        tf = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic.json")
+        roof = roofline_report(prof, kp, work, prec, tf, args.config, G)
+        roof["whole_step_tflops_in_kernels"] = sum(w["alg"] for w in work.values()) / (roof["kernel_ms_per_step"] * 1e-3) / 1e12
+        roof["folds"] = {"mlp2_composed": bool(flags & 1), "value_heads_folded": bool(flags & 2)}
+        try:        # measured ceilings of the box (tools/measure_peaks.py)
+            mp = json.load(open(os.path.join(ROOT, "profiles", "r01", "measured_peaks.json")))
+            roof["measured_library_gemm_tflops_context"] = mp.get("hipblaslt_bf16_gemm_8192_tflops")
+        except (OSError, ValueError):
+            pass
+        if cfg["graph"] == "regular" and plan.hybrid:
+            # the pure edge-list (gather) kernels on the same Batch: the HBM-bound sparse path of the north star
+            kp2 = min(kp, 5)
+            plan_csr = build_plan(ei, batch, eng.virt_nodes, hybrid="off")
+            eng.set_features(plan_csr, feats)
+            run(2, False, plan_csr)
+            eng.profile(True)
+            run(kp2, False, plan_csr)
+            prof2 = eng.profile_read()
+            eng.profile(False)
+            work2 = work_model(cfg, G, E, plan.n_nodes, flags, prec, False)
+            sparse = roofline_report(prof2, kp2, work2, prec, tf, args.config + "_csr", G)
+            sparse["note"] = ("same Batch through the edge-list kernels only (hybrid split off): algorithmic gather bytes / kernel "
+                              "time; K/V rows of a Batch that fits the 256 MB Infinity Cache are not HBM bytes -- compare with "
+                              "pmc_traffic where present")
+            eng.set_features(plan, feats)
+    del ei
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(cfg, sd, args.degree, args.cpu_baseline_full)
+        value = world * G * K / dt
+        f_node = 6_164_704 if threed else F_NODE
+        f_edge = 4 * (3 * 256 + (832 if threed else 1152))
+        head = args.config == "3p"
+        wl = cfg["name"] + (f", d={args.degree} (E={E // G} per puzzle incl. virtual-node edges)" if cfg["graph"] == "regular" else "")
+        line = {
+            "metric": "denoising steps/sec (900-piece dense graph, T=100)" if head else f"denoising steps/sec (BASELINE config {args.config})",
+            "value": value, "unit": "puzzle-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": prec, "data": "synthetic",
+            "config": {"workload": wl, "baseline_config": args.config, "puzzles_per_gpu": G, "global_puzzles": world * G,
+                       "parallelism": f"puzzle-sharded x{world}", "loop": "hipGraph replay",
+                       "attention_path": "dense MFMA" if plan.dense else ("hybrid: adjacency-masked MFMA + CSR remainder" if plan.hybrid else "edge list (CSR gather)")},
+            "batch_steps_per_s": world * K / dt,
+            "algorithmic_tflops": world * (N * f_node + E * f_edge) * K / dt / 1e12,
+            "timed_region": {"seconds": dt, "graph_replays": len(chunks),
+                             "excluded": "per-Batch staging (set_features_ms, once per sampling loop), graph capture, warm-up"},
+            "set_features_ms": set_features_ms, "replay": replay,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if sparse is not None:
+            line["sparse_path"] = sparse
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--puzzles", type=int, default=int(os.environ.get("BENCH_PUZZLES", 32)),
-                    help="independent 900-piece puzzles per GPU (the batch of one step)")
-    ap.add_argument("--precision", default=os.environ.get("BENCH_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--config", default=os.environ.get("BENCH_CONFIG", "3p"), choices=["1", "2", "3", "3p", "4", "5"],
+                    help="BASELINE configuration (default 3p = the headline metric; 5 = --mode train)")
+    ap.add_argument("--puzzles", type=int, default=int(os.environ.get("BENCH_PUZZLES", 0)),
+                    help="independent puzzles per GPU (the batch of one step); 0 = the configuration's default")
+    ap.add_argument("--degree", type=int, default=int(os.environ.get("BENCH_DEGREE", 539)),
+                    help="--config 3: Exphander degree (539 = the scripted 60 %%, 90 = 10 %%)")
+    ap.add_argument("--precision", default=os.environ.get("BENCH_PRECISION", ""), choices=["", "bf16", "fp32"])
     ap.add_argument("--mode", default=os.environ.get("BENCH_MODE", "sample"), choices=["sample", "train", "encode", "e2e"],
-                    help="sample = the headline metric (default); train = BASELINE config 5 (one optimizer step); "
+                    help="sample = a sampling-loop configuration (default); train = BASELINE config 5 (one optimizer step); "
                          "encode = the piece encoder (SURVEY 8f rank 2); e2e = pixels -> poses (encoder + plan + loop)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("BENCH_ENCODER_CHUNK", 0)),
                     help="--mode encode: pieces per encoder chunk (0 = engine default)")
     ap.add_argument("--train-puzzles", type=int, default=int(os.environ.get("BENCH_TRAIN_PUZZLES", 64)),
                     help="--mode train: 12x12 puzzles per GPU")
+    ap.add_argument("--replays", type=int, default=30, help="extra individually timed graph replays for the median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle with ONE thread at full size")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.config == "5":
+        args.mode = "train"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -327,124 +715,14 @@ def main():
     if args.mode == "train":
         return train_bench(args, world, rank, dev)
     if args.mode == "encode":
+        args.precision = args.precision or "bf16"
+        args.puzzles = args.puzzles or 32
         return encode_bench(args, world, rank, dev)
     if args.mode == "e2e":
+        args.precision = args.precision or "bf16"
+        args.puzzles = args.puzzles or 32
         return e2e_bench(args, world, rank, dev)
-
-    from diffassemble_amd import _lib
-    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
-
-    G, K, Wm = args.puzzles, args.steps, args.warmup
-    # the reference-shaped module with seeded default-initialised weights (no checkpoints here), exactly what
-    # viz_script.py would build: rotation=True -> c = 4, transformer arch, START_X, DDIM
-    torch.manual_seed(0)
-    model = GNN_Diffusion(steps=T_STEPS, sampling="DDIM", inference_ratio=1, rotation=True, noise_weight=1.0,
-                          model_mean_type=ModelMeanType.START_X, visual_pretrained=False).to(dev).eval()
-    model.model.precision = args.precision
-    eng = model.model.engine(dev)
-    sd = {k: v.detach().cpu() for k, v in model.model._denoiser_state().items()}        # for the CPU baseline leg
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    feats = torch.randn((G * N_PIECES, 1088), generator=gen, device=dev)
-    x_T = torch.randn((G * N_PIECES, 4), generator=gen, device=dev)
-    ei, batch = dense_batch(G, N_PIECES, dev)
-    plan = eng.plan(ei, batch)
-    del ei
-    sch = model._schedule()
-    mt = _lib.MEAN_START_X
-
-    def run(n_iters, graph):
-        return eng.sample_loop(plan, sch, x_T, feats, ratio=1, mean_type=mt, max_iters=n_iters,
-                               keep_trajectory=False, use_graph=graph, restage=False)
-
-    eng.set_features(plan, feats)
-    chunks = [T_STEPS] * (K // T_STEPS) + ([K % T_STEPS] if K % T_STEPS else [])
-    if Wm > 0:
-        run(min(Wm, T_STEPS), False)                       # W untimed eager steps
-    for c in sorted(set(chunks)):
-        run(c, True)                                       # capture + instantiate (+ one untimed replay)
-    torch.cuda.synchronize()
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for c in chunks:
-        _, x_final = run(c, True)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt)
-    assert torch.isfinite(x_final).all(), "non-finite poses"
-
-    roof = None
-    kernels = None
-    if not args.no_roofline:
-        eng.profile(True)
-        kp = min(K, 20)
-        run(kp, False)
-        prof = eng.profile_read()
-        eng.profile(False)
-        kernels = {k: {"ms_per_launch": (ms / n if n else 0.0), "launches_per_step": n / kp} for k, (ms, n) in prof.items()}
-        ms_last, n_last = prof["attn_last"]
-        flop_last = G * N_PIECES * N_PIECES * 4 * 1152             # QK^T + PV, mul+add, C*H = 1152
-        ach = flop_last / (ms_last / n_last * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.precision]
-        traffic, tsrc = None, None
-        try:        # PMC traffic is collected offline (rocprofv3 --pmc cannot run inside this process)
-            ent = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))[args.precision][str(G)]
-            traffic = (2.0 * ent["fetch_kib"] + ent["write_kib"]) * 1024.0
-            tsrc = "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
-        except (OSError, KeyError, ValueError):
-            pass
-        flags = int(eng.lib.da_denoiser_flags(eng.handle))
-        cv = 32 if flags & 2 else 144                            # value-head width the kernel actually multiplies
-        flop_exec = G * N_PIECES * N_PIECES * 2 * 8 * (144 + cv)
-        roof = {"bound": "mfma", "kernel": "attn_last (graph attention, conv 3, C=144)", "achieved": ach,
-                "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
-                "flop_per_launch": flop_last, "avg_launch_ms": ms_last / n_last,
-                # `achieved` counts the reference's formulation (E * 4 * H * C).  With the value heads
-                # folded into final_mlp.0 the kernel multiplies fewer FLOPs for the same result:
-                "executed_flop_per_launch": flop_exec,
-                "executed_tflops": flop_exec / (ms_last / n_last * 1e-3) / 1e12,
-                "executed_frac_of_peak": flop_exec / (ms_last / n_last * 1e-3) / 1e12 / peak,
-                "value_heads_folded": bool(flags & 2)}
-        try:        # measured ceiling of the box (tools/measure_peaks.py): hipBLASLt bf16 GEMM at 8192^3
-            mp = json.load(open(os.path.join(ROOT, "profiles", "r01", "measured_peaks.json")))
-            if args.precision == "bf16":
-                roof["peak_measured_library_gemm"] = mp["hipblaslt_bf16_gemm_8192_tflops"]
-                roof["frac_of_measured_library_gemm"] = ach / mp["hipblaslt_bf16_gemm_8192_tflops"]
-        except (OSError, KeyError, ValueError):
-            pass
-        ms_all = sum(ms for ms, _ in prof.values()) / kp
-        flop_step = G * (N_PIECES * F_NODE + N_PIECES * N_PIECES * F_EDGE)
-        roof["whole_step_tflops_in_kernels"] = flop_step / (ms_all * 1e-3) / 1e12
-
-    if rank == 0:
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(sd, 1234, os.cpu_count() or 1)
-        value = world * G * K / dt
-        line = {
-            "metric": "denoising steps/sec (900-piece dense graph, T=100)",
-            "value": value, "unit": "puzzle-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "30x30 dense puzzle (N=900, E=810000 incl. self loops), DDIM eta=0, T=100, "
-                                   "START_X, rot+trans c=4, transformer arch",
-                       "puzzles_per_gpu": G, "global_puzzles": world * G, "parallelism": f"puzzle-sharded x{world}",
-                       "loop": "hipGraph replay"},
-            "batch_steps_per_s": world * K / dt,
-            "algorithmic_tflops": world * G * (N_PIECES * F_NODE + N_PIECES ** 2 * F_EDGE) * K / dt / 1e12,
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
-        }
-        print(json.dumps(line))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    return sample_bench(args, world, rank, dev)
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
 MEAN_EPSILON, MEAN_START_X = 0, 1
 ACT_NONE, ACT_GELU, ACT_LEAKY02 = 0, 1, 2
-PROF_CLASSES = ("embed", "linear_mlp", "linear_qkvs", "attn_hidden", "attn_last", "head", "update")
+PROF_CLASSES = ("embed", "linear_mlp", "linear_qkvs", "attn_hidden", "attn_last", "head", "update", "conv_fused")
 
 _fp = C.c_void_p        # device pointers travel as integers
 _FPL = _fp * DA_MAX_LAYERS

@@ -299,6 +299,16 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                 }
             }
         }
+        if (!al && !last && g->dense && !g->hybrid && n == nr && !resid && dense_ok(g, d->heads, c.C) &&
+            conv_fused_applicable(prec, d->heads, c.C, c.din, g->max_graph_nodes, c.hc)) {
+            // hidden conv on complete graphs: projection + attention of a (graph, head) in ONE kernel, K / V in LDS
+            rc = timed(d, DA_PROF_CONV_FUSED, st, [&] {
+                return launch_conv_fused(prec, d->heads, c.C, c.din, g->n_graphs, g->max_graph_nodes, g->graph_ptr,
+                                         g->dense == 2, xin, ldx, c.w, c.b, act, dst, c.hc, st); });
+            if (rc) return rc < 0 ? 1 : rc;
+            xin = dst; ldx = c.hc;
+            continue;
+        }
         if (!al && w.dq && dense_ok(g, d->heads, c.C)) {
             // complete graphs: projection scattered into head-major Q / K / V, block-diagonal MFMA attention
             QkvScatter qs;
@@ -722,6 +732,12 @@ int da_conv_dense(int prec, const da_graph *g, int heads, int C, int Din, const 
     DA_REQUIRE(dense_ok(g, heads, C), "da_conv_dense: graph is not dense or head width %d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
     const size_t s = esize(prec), hc = (size_t)heads * C;
+    if (!residual && !g->hybrid && conv_fused_applicable(prec, heads, C, Din, g->max_graph_nodes, (int)hc)) {
+        int rf = launch_conv_fused(prec, heads, C, Din, g->n_graphs, g->max_graph_nodes, g->graph_ptr, g->dense == 2, x, Din, w,
+                                   b, act, out, (int)hc, st);
+        DA_REQUIRE(rf == 0, "da_conv_dense: fused conv launch failed (%d)", rf);
+        return 0;
+    }
     const size_t hb = align_up(((size_t)g->n_pad + 64) * hc * s, 256);
     char *base = (char *)scratch;
     QkvScatter qs;

@@ -1,0 +1,309 @@
+// One hidden TransformerConv layer (Transformer_GNN.py:32,38 -> PyG TransformerConv, C = 32 channels per head)
+// on COMPLETE graphs as ONE kernel: the fused Q | K | V | skip projection of a (graph, head) AND its
+// attention, with nothing but the layer's input x and its output touching HBM.
+//
+//   out[i, 32h:32h+32] = act( softmax_j(q_i . k_j / sqrt(32)) v_j + skip_i ),   [q|k|v|skip]_i = W_h x_i + b_h
+//
+// Why (rocprof, 32 puzzles of 900 pieces, bf16): the two-kernel form spends 35 us per layer in the projection
+// GEMM (M = 28 800, K = 256, N = 1024: 59 MB of head-major Q / K / V / skip written and read back) and 61 us in
+// the attention, whose 128-query workgroups re-stream K_h / V_h eight times.  Here one workgroup owns one
+// (graph, head): K_h and V_h^T of all n <= 992 keys are projected ONCE into LDS (n x 64 B + 32 x 2n B, ~120 KB at
+// n = 900) and stay there; every wave then walks 32-query slabs: Q^T and skip^T of the slab straight out of the
+// matrix cores into the operand / accumulator registers the attention needs, 29 blocks of 32 keys against the
+// resident K / V^T, epilogue in registers.  HBM traffic per layer: x (read through L2 by the 8 heads of a graph,
+// which share an XCD) and out.
+//
+// Register-level layouts (v_mfma_f32_32x32x16_bf16: A lane l = row l&31, 8 k-values 8(l>>5)..; B lane l = column
+// l&31, same k-values; D lane l = column l&31, register r = row (r&3) + 8(r>>2) + 4(l>>5)):
+//   K^T = W_k x^T      A = W_k rows (channel), B = x rows (node)  -> lane (node, half) holds channels
+//                      ch(r) = (r&3) + 8(r>>2) + 4 half.  Registers 8t..8t+7 are written as ONE 16-byte chunk
+//                      (2t + half) of K's LDS row: the channel order inside a row is whatever the S^T MFMA of the
+//                      attention consumes, because
+//   Q^T = W_q x^T      comes out in the same layout, and its registers 8t..8t+7 (as bf16) ARE the B operand of
+//                      k-step t of S^T = K Q^T (the dot product only needs K and Q to agree on the order).
+//   V   = x W_v^T      A = x rows (node), B = W_v rows (channel) -> lane (channel, half) holds 4-node runs, written
+//                      as 8-byte pieces of row `channel` of V^T [32][n]: the PV operand is then a plain 16-byte read.
+//   skip^T = W_s x^T   same layout as O^T = V^T P^T: added in registers.
+// x fragments are loaded from global memory in operand shape (16 B per lane per k-step; x_g is L2 resident), the four
+// 32 x KIN weight blocks of the head sit in LDS in fragment order (W_k, W_v during the projection phase, W_q, W_s
+// during the attention phase: same 2 x 16 KB region).  Softmax as in da_attn_dense.hip: MFMA row rho is fed key
+// pi(rho) so that a lane holds 16 consecutive keys of one query, lane-local running max / sum, rescale only when
+// the max moves by more than 2^8, exp2 with the scale folded in.
+//
+// bf16 only (fp32 K / V do not fit in LDS: the fp32 parity mode keeps the two-kernel path), H = 8, C = 32,
+// KIN in {128, 256}.
+#include <stdlib.h>
+
+#include "da_common.h"
+#include "da_internal.h"
+
+namespace da {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+struct ConvFusedParams {
+    const bf16_t *x;            // [N][ldx]
+    int ldx;
+    const bf16_t *W;            // [4 * 256][KIN]: rows Q | K | V | skip, feature f = 32 h + c inside a block
+    const float *bias;          // [4 * 256]
+    bf16_t *out;                // [N][256]
+    const int32_t *graph_ptr;
+    int n_graphs, act, nodiag;
+    float sc;                   // log2(e) / sqrt(32)
+};
+
+__device__ __forceinline__ f32x16 mfma(const u32x4 &a, const u32x4 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ u32x4 pack8(const f32x16 &v, int r0) {
+    bf16x8 b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b[e] = (__bf16)v[r0 + e];
+    return __builtin_bit_cast(u32x4, b);
+}
+
+// LDS regions: K [n32][64 B] (16-byte chunks XOR-swizzled by (key >> 2) & 3), V^T [32][VS] (VS = 2 n32 + 16: an odd
+// number of 16-byte slots), W fragments [2][KS][64 lanes][16 B]
+template <int KIN>
+__global__ __launch_bounds__(512, 2) void k_conv_fused(ConvFusedParams p) {
+    constexpr int KS = KIN / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // all 8 heads of a graph on ONE XCD (workgroup b runs on XCD b % 8): they share x_g in its L2
+    const int nblk = gridDim.x;
+    const int bid = (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8);
+    const int g = bid >> 3, h = bid & 7;
+    const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0;
+    if (n_g <= 0) return;
+    const int nslab = (n_g + 31) >> 5, n32 = nslab * 32;
+    const int VS = 2 * n32 + 16;
+    unsigned char *sK = smem;
+    unsigned char *sV = smem + (size_t)n32 * 64;
+    unsigned char *sW = sV + (size_t)32 * VS;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), NW = blockDim.x >> 6;
+
+    // ---- weight blocks of this head into LDS in fragment order: piece (m, s, lane') = W_m[ch = lane' & 31][16 s + 8 (lane' >> 5) ..+8]
+    auto stage_w = [&](int blk0, int blk1) {
+        for (int it = tid; it < 2 * KS * 64; it += blockDim.x) {
+            const int m = it / (KS * 64), r = it - m * (KS * 64), s = r >> 6, l2 = r & 63;
+            const int blk = m ? blk1 : blk0;
+            const bf16_t *src = p.W + ((size_t)blk * 256 + 32 * h + (l2 & 31)) * KIN + 16 * s + 8 * (l2 >> 5);
+            *(u32x4 *)(sW + (size_t)it * 16) = *(const u32x4 *)src;
+        }
+    };
+    // x fragments of one 32-node slab: lane (node, half), k-step s -> x[node][16 s + 8 half ..+8]
+    auto load_x = [&](int slab, u32x4 (&xf)[KS]) {
+        const int node = min(32 * slab + i, n_g - 1);
+        const bf16_t *row = p.x + (size_t)(node0 + node) * p.ldx + 8 * half;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[s] = *(const u32x4 *)(row + 16 * s);
+    };
+    // bias of the 16 channels a lane holds in the transposed (channel x node) layouts
+    auto load_bias16 = [&](int blk, float (&b)[16]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = *(const f32x4 *)(p.bias + blk * 256 + 32 * h + 8 * j + 4 * half);
+            b[4 * j] = v[0]; b[4 * j + 1] = v[1]; b[4 * j + 2] = v[2]; b[4 * j + 3] = v[3];
+        }
+    };
+
+    // =========================== phase 1: K_h and V_h^T of the whole graph into LDS ===========================
+    stage_w(1, 2);
+    __syncthreads();
+    {
+        float bk[16];
+        load_bias16(1, bk);
+        const float bv = p.bias[2 * 256 + 32 * h + i];
+        for (int slab = wid; slab < nslab; slab += NW) {
+            u32x4 xf[KS];
+            load_x(slab, xf);
+            f32x16 aK, aV;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { aK[r] = 0.f; aV[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const u32x4 wk = *(const u32x4 *)(sW + (size_t)(s * 64 + lane) * 16);
+                const u32x4 wv = *(const u32x4 *)(sW + (size_t)((KS + s) * 64 + lane) * 16);
+                aK = mfma(wk, xf[s], aK);          // K^T[ch][node]
+                aV = mfma(xf[s], wv, aV);          // V[node][ch]
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the W fragment reads from piling up in registers
+            }
+            // K: this lane = node 32 slab + i; rows beyond the graph are zero (their scores are masked anyway)
+            const int key = 32 * slab + i;
+            const bool kin = key < n_g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aK[r] = kin ? aK[r] + bk[r] : 0.f;
+            const int sw = (key >> 2) & 3;
+            *(u32x4 *)(sK + (size_t)key * 64 + (((0 + half) ^ sw) << 4)) = pack8(aK, 0);
+            *(u32x4 *)(sK + (size_t)key * 64 + (((2 + half) ^ sw) << 4)) = pack8(aK, 8);
+            // V^T: this lane = channel i; register r = node 32 slab + (r&3) + 8 (r>>2) + 4 half; zero beyond the graph
+            // (a masked probability is exactly 0, and 0 x garbage must stay 0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nd = 32 * slab + 8 * j + 4 * half;
+                bf16x4 b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = (__bf16)((nd + e < n_g) ? aV[4 * j + e] + bv : 0.f);
+                *(u32x2 *)(sV + (size_t)i * VS + (size_t)nd * 2) = __builtin_bit_cast(u32x2, b);
+            }
+        }
+    }
+    __syncthreads();
+    stage_w(0, 3);
+    __syncthreads();
+
+    // =========================== phase 2: attention of this wave's query slabs ===========================
+    float bq[16], bs[16];
+    load_bias16(0, bq);
+    load_bias16(3, bs);
+    const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);       // key fed to MFMA row i
+    for (int slab = wid; slab < nslab; slab += NW) {
+        // ---- Q^T (-> B operand of S^T) and skip^T (-> added to O^T at the end) of the slab
+        u32x4 qf[2];
+        f32x16 aS;
+        {
+            u32x4 xf[KS];
+            load_x(slab, xf);
+            f32x16 aQ;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { aQ[r] = 0.f; aS[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const u32x4 wq = *(const u32x4 *)(sW + (size_t)(s * 64 + lane) * 16);
+                const u32x4 ws = *(const u32x4 *)(sW + (size_t)((KS + s) * 64 + lane) * 16);
+                aQ = mfma(wq, xf[s], aQ);
+                aS = mfma(ws, xf[s], aS);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { aQ[r] += bq[r]; aS[r] += bs[r]; }
+            qf[0] = pack8(aQ, 0);
+            qf[1] = pack8(aQ, 8);
+        }
+        const int qidx = 32 * slab + i;                   // this lane's query (index inside the graph)
+        f32x16 O;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] = 0.f;
+        float m = -INFINITY, l = 0.f;
+        // LDS addresses of this lane's fragments inside a 32-key block
+        const int krow = pi_i;                            // key (inside the block) this lane feeds
+        const unsigned char *vrow = sV + (size_t)i * VS + (size_t)(16 * half) * 2;
+        auto qk = [&](int kb) {
+            const int key = 32 * kb + krow, sw = (key >> 2) & 3;
+            const u32x4 k0 = *(const u32x4 *)(sK + (size_t)key * 64 + (((0 + half) ^ sw) << 4));
+            const u32x4 k1 = *(const u32x4 *)(sK + (size_t)key * 64 + (((2 + half) ^ sw) << 4));
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            s = mfma(k0, qf[0], s);
+            s = mfma(k1, qf[1], s);
+            return s;
+        };
+        f32x16 s = qk(0);
+        for (int kb = 0; kb < nslab; ++kb) {
+            // V^T fragments of this block and S^T of the NEXT block are in flight under the softmax
+            const u32x4 v0 = *(const u32x4 *)(vrow + (size_t)(32 * kb) * 2);
+            const u32x4 v1 = *(const u32x4 *)(vrow + (size_t)(32 * kb + 8) * 2);
+            f32x16 sn;
+            if (kb + 1 < nslab) sn = qk(kb + 1);
+            // this lane holds keys 32 kb + 16 half + r, r = 0..15, of query qidx
+            const int kbase = 32 * kb + 16 * half;
+            const bool tail = 32 * kb + 32 > n_g;
+            const bool diag = p.nodiag && kb == slab;
+            if (tail || diag) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
+            }
+            const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
+            const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
+            const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+            const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
+            const bool grow = !(m > -INFINITY) || (mloc - m) * p.sc > 8.0f;
+            if (__any(grow)) {
+                float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));
+                if (mnew == -INFINITY) mnew = 0.f;               // nothing but masked keys so far
+                const float corr = __builtin_amdgcn_exp2f((m - mnew) * p.sc);
+                m = mnew;
+                l *= corr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[r] *= corr;
+            }
+            const float ms = m * p.sc;
+            float pr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms));
+            l += ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])) +
+                 (((pr[8] + pr[9]) + (pr[10] + pr[11])) + ((pr[12] + pr[13]) + (pr[14] + pr[15])));
+            bf16x8 pf0, pf1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pf0[e] = (__bf16)pr[e]; pf1[e] = (__bf16)pr[8 + e]; }
+            O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O, 0, 0, 0);
+            O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
+            if (kb + 1 < nslab) s = sn;
+        }
+        // ---- epilogue in registers: normalise (PyG: sum + 1e-16), + skip, activation, 8-byte stores
+        const float lt = l + __shfl_xor(l, 32);
+        const float inv = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+        if (qidx < n_g) {
+            bf16_t *dst = p.out + (size_t)(node0 + qidx) * 256 + 32 * h + 4 * half;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x4 b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = (__bf16)apply_act(fmaf(O[4 * j + e], inv, aS[4 * j + e]), p.act);
+                *(u32x2 *)(dst + 8 * j) = __builtin_bit_cast(u32x2, b);
+            }
+        }
+    }
+}
+
+static bool conv_fused_disabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_DISABLE_CONV_FUSED"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+size_t conv_fused_lds_bytes(int max_graph_nodes, int kin) {
+    const size_t n32 = (size_t)((max_graph_nodes + 31) / 32) * 32;
+    return n32 * 64 + 32 * (2 * n32 + 16) + (size_t)2 * (kin / 16) * 1024;
+}
+
+bool conv_fused_applicable(int prec, int heads, int C, int kin, int max_graph_nodes, int ldo) {
+    return !conv_fused_disabled() && prec == DA_PREC_BF16 && heads == 8 && C == 32 && (kin == 128 || kin == 256) && ldo == 256 &&
+           max_graph_nodes > 0 && conv_fused_lds_bytes(max_graph_nodes, kin) <= 160 * 1024;
+}
+
+// returns 0 = launched, -1 = configuration not supported (caller takes the two-kernel path)
+int launch_conv_fused(int prec, int heads, int C, int kin, int n_graphs, int max_graph_nodes, const int32_t *graph_ptr,
+                      int nodiag, const void *x, int ldx, const void *W, const float *bias, int act, void *out, int ldo,
+                      hipStream_t st) {
+    if (!conv_fused_applicable(prec, heads, C, kin, max_graph_nodes, ldo) || n_graphs <= 0) return -1;
+    const size_t lds = conv_fused_lds_bytes(max_graph_nodes, kin);
+    ConvFusedParams p;
+    p.x = (const bf16_t *)x; p.ldx = ldx; p.W = (const bf16_t *)W; p.bias = bias; p.out = (bf16_t *)out;
+    p.graph_ptr = graph_ptr; p.n_graphs = n_graphs; p.act = act; p.nodiag = nodiag;
+    p.sc = 1.4426950408889634f / sqrtf(32.0f);
+    const int nblk = n_graphs * 8;
+    // 8 waves per workgroup when a graph has enough 32-query slabs to feed them, else 4
+    const int threads = max_graph_nodes > 128 ? 512 : 256;
+    if (kin == 256) {
+        static bool attr = false;
+        if (!attr) { DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        k_conv_fused<256><<<nblk, threads, lds, st>>>(p);
+    } else {
+        static bool attr = false;
+        if (!attr) { DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        k_conv_fused<128><<<nblk, threads, lds, st>>>(p);
+    }
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace da

@@ -105,6 +105,12 @@ int launch_attn_csr_cont(int prec, int n_nodes, int n_real, const int32_t *irr_r
                          const int32_t *row_map, int heads, int C, int n_pad, const DenseLayout &L,
                          const void *residual, int act, void *out, hipStream_t st);
 
+// da_conv_fused.hip: one hidden conv (projection + attention of a (graph, head)) as ONE kernel, K / V resident in LDS
+bool conv_fused_applicable(int prec, int heads, int C, int kin, int max_graph_nodes, int ldo);
+int launch_conv_fused(int prec, int heads, int C, int kin, int n_graphs, int max_graph_nodes, const int32_t *graph_ptr,
+                      int nodiag, const void *x, int ldx, const void *W, const float *bias, int act, void *out, int ldo,
+                      hipStream_t st);
+
 // generic linear dispatch (MFMA when the shape allows, else simple)
 int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, int act,
            const void *res, void *out, int ldo, hipStream_t st);

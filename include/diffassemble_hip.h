@@ -217,7 +217,8 @@ enum {
     DA_PROF_ATTN_LAST = 4,    /* attention of the last conv (C = D/8)                        */
     DA_PROF_HEAD = 5,         /* pose head                                                   */
     DA_PROF_UPDATE = 6,       /* DDIM / DDPM update                                          */
-    DA_PROF_NCLASS = 7
+    DA_PROF_CONV_FUSED = 7,   /* hidden conv as ONE kernel: projection + attention (C = 32)  */
+    DA_PROF_NCLASS = 8
 };
 int da_profile_enable(da_denoiser *d, int on);
 int da_profile_read(da_denoiser *d, float *ms /* [DA_PROF_NCLASS] host */,

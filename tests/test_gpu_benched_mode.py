@@ -166,7 +166,10 @@ def test_bf16_full_loop_drift_vs_fp32(dev, n, G):
     assert float(per_step[-1]) < 2e-2
 
 
-def _train_solver(dev, sizes_train, steps=400, seed=0):
+FEAT_NOISE = 0.1          # std of the non-pose feature columns (probe: tests/tools/train_solver_probe.py)
+
+
+def _train_solver(dev, sizes_train, steps=400, seed=0, lr=2e-3, G=8):
     """Train the 2D denoiser with the HIP training path (da_train_forward/backward, START_X objective, Huber, as
     training_step does) on synthetic puzzles whose piece features carry the piece's true pose: a few hundred
     steps make it a solver, so that the sampling loop's end metric means something."""
@@ -175,21 +178,23 @@ def _train_solver(dev, sizes_train, steps=400, seed=0):
     m = GNN_Diffusion(steps=100, sampling="DDIM", inference_ratio=1, noise_weight=1.0, rotation=True,
                       model_mean_type=ModelMeanType.START_X, visual_pretrained=False, architecture="transformer")
     m = m.to(dev).train()
-    opt = torch.optim.Adam([p for p in m.model.parameters()], lr=2e-3)
+    opt = torch.optim.Adam([p for p in m.model.parameters()], lr=lr)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps)
     gen = torch.Generator().manual_seed(seed)
     for it in range(steps):
         side = sizes_train[it % len(sizes_train)]
-        x0, feats, ei, batch = _puzzle_batch(side, 4, gen)
-        t = torch.randint(0, 100, (4,), generator=gen)[batch]
+        x0, feats, ei, batch = _puzzle_batch(side, G, gen, FEAT_NOISE)
+        t = torch.randint(0, 100, (G,), generator=gen)[batch]
         loss = m.p_losses(x0.to(dev), t.to(dev), loss_type="huber", cond=None, edge_index=ei.to(dev),
                           batch=batch.to(dev), patch_feats=feats.to(dev))
         opt.zero_grad(set_to_none=False)
         loss.backward()
         opt.step()
-    return m.eval(), float(loss)
+        sched.step()
+    return m.eval(), float(loss.detach())
 
 
-def _puzzle_batch(side, G, gen):
+def _puzzle_batch(side, G, gen, feat_noise=1.0):
     """G puzzles of side x side pieces: ground-truth poses (grid xy in [-1, 1] + a random quarter-turn as (cos, sin)),
     features = N(0, 1) with the pose written (scaled) into the first four columns."""
     n = side * side
@@ -200,7 +205,7 @@ def _puzzle_batch(side, G, gen):
         perm = torch.randperm(n, generator=gen)
         k = torch.randint(0, 4, (n,), generator=gen).float() * (np.pi / 2)
         pose = torch.cat([grid[perm], torch.stack([torch.cos(k), torch.sin(k)], 1).round()], 1)
-        f = torch.randn(n, 1088, generator=gen)
+        f = torch.randn(n, 1088, generator=gen) * feat_noise
         f[:, :4] = pose * 4.0
         xs.append(pose)
         fs.append(f)
@@ -215,11 +220,11 @@ def test_end_metric_bf16_equals_fp32_on_a_trained_solver(dev):
     fp32 accuracy must be high enough for the comparison to mean something."""
     import math
     from diffassemble_amd.engine import greedy_assign
-    m, last_loss = _train_solver(dev, [6, 12, 30], steps=450)
+    m, last_loss = _train_solver(dev, [6, 12, 12, 16], steps=2500)      # ~15 s of HIP training steps
     gen = torch.Generator().manual_seed(1234)
     for side, G in ((12, 4), (30, 2)):
         n = side * side
-        x_gt, feats, ei, batch = _puzzle_batch(side, G, gen)
+        x_gt, feats, ei, batch = _puzzle_batch(side, G, gen, FEAT_NOISE)
         y = torch.linspace(-1, 1, side)
         grid = torch.stack(torch.meshgrid(y, y, indexing="xy"), -1).reshape(-1, 2).repeat(G, 1).to(dev)
         ptr = torch.arange(0, (G + 1) * n, n, dtype=torch.int32, device=dev)

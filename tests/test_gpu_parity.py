@@ -112,6 +112,38 @@ def test_da_conv_dense_matches_pyg_semantics(dev, C_head, Din, prec, loops):
     assert rel(out.float(), ref) < (2e-5 if prec == "fp32" else 2e-2)
 
 
+@pytest.mark.parametrize("Din", [128, 256])
+@pytest.mark.parametrize("loops", [True, False])
+@pytest.mark.parametrize("sizes", [[900], [992, 3, 33], [32, 64, 31, 65, 1], [144] * 5], ids=["900", "992_3_33", "slab_edges", "5x144"])
+def test_conv_fused_one_kernel_hidden_layer(dev, Din, loops, sizes):
+    """k_conv_fused (da_conv_fused.hip: projection + attention of a (graph, head) in ONE kernel, K / V^T resident in
+    LDS) through da_conv_dense in bf16 -- which dispatches to it for C = 32, Din in {128, 256}, graphs of <= 992
+    pieces -- against the edge-list oracle on the same bf16-rounded inputs, and against the exact-fp32 two-kernel
+    path of the library.  Sizes cover the 900-piece headline, the LDS limit (992), slabs that end exactly on / one
+    past a 32-query boundary, 1-piece graphs (no edge at all without self loops: PyG gives act(0 + skip))."""
+    from diffassemble_amd import engine as E
+    from diffassemble_amd.graph_plan import build_plan
+    H, Ch = 8, 32
+    N = sum(sizes)
+    g = torch.Generator().manual_seed(Din + len(sizes))
+    ei, batch = W.collate([W.dense_edge_index(n, loops) for n in sizes], sizes)
+    x = torch.randn(N, Din, generator=g).bfloat16().float()
+    HC = H * Ch
+    ws = [(torch.randn(HC, Din, generator=g) / Din ** 0.5 * (3.0 if k < 2 else 1.0)).bfloat16().float() for k in range(4)]
+    bs = [torch.randn(HC, generator=g) * 0.1 for _ in range(4)]
+    plan = build_plan(ei.to(dev), batch.to(dev), 0)
+    assert plan.dense == (1 if loops else 2)
+    out = E.conv_dense(plan, x.to(dev), torch.cat(ws).to(dev), torch.cat(bs).to(dev), H, Ch, None, 1, "bf16")
+    assert torch.isfinite(out.float()).all()
+    exact = E.conv_dense(plan, x.to(dev), torch.cat(ws).to(dev), torch.cat(bs).to(dev), H, Ch, None, 1, "fp32")
+    assert rel(out.float(), exact) < 2e-2
+    if N <= 1100:                                     # the edge-list oracle on the host
+        ref, _ = R.transformer_conv(x, ei, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], ws[3], bs[3], H)
+        ref = torch.nn.functional.gelu(ref)
+        assert rel(exact, ref) < 2e-5
+        assert rel(out.float(), ref) < 2e-2
+
+
 # ---------------------------------------------------------------------------- 2D forward
 @pytest.mark.parametrize("spec", C.FWD2D, ids=lambda s: s["name"])
 def test_forward_2d_fp32_vs_oracle_and_golden(dev, golden, spec):
