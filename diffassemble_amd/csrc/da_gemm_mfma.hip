@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
 static bool aligned16(const void *p) { return (((size_t)p) & 15) == 0; }
 
 int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st);   // da_gemm_astat.hip
+int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st);    // da_gemm_wreg.hip
 
 // returns 0 = launched, -1 = shape not supported by this kernel (caller falls back), >0 error
 int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
@@ -254,6 +255,11 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     {   // short reductions: A-stationary kernel (da_gemm_astat.hip)
         static int off = -1;
         if (off < 0) { const char *e = getenv("DA_DISABLE_ASTAT"); off = (e && e[0] == '1') ? 1 : 0; }
+        if (K * es <= 512) {
+            // tall inputs: W in registers, A tiles streamed by a producer wave (da_gemm_wreg.hip)
+            const int rw = launch_gemm_wreg(prec, p, qs, act, st);
+            if (rw >= 0) return rw;
+        }
         if (!off && K * es <= 512) {
             const int rc = launch_gemm_astat(prec, p, qs, act, st);
             if (rc >= 0) return rc;

@@ -1,0 +1,226 @@
+// W-in-registers MFMA linear kernel for SHORT reductions and TALL inputs (bf16, K in {128, 256}, M >> Nout):
+// the fused Q | K | V (| skip) projections, e.g. conv 3 of the 2D denoiser: M = 28 800 nodes, K = 256, Nout = 2560.
+//
+// The A-stationary kernel (da_gemm_astat.hip) keeps a 128-row panel of A in LDS and streams W tiles through a
+// barrier every 8 MFMAs per wave; measured 435-484 TFLOP/s on these shapes, far from every roof.
+// Here the roles are swapped and the barrier count drops 4x while the LDS bytes per FLOP drop 2x:
+//   * every consumer wave keeps ITS 32 output columns of W -- 32 x K bf16 = 64 VGPRs at K = 256 -- in registers for
+//     the whole kernel, as the A operand of v_mfma_f32_32x32x16_bf16 (D^T[col][node] = W . x^T);
+//   * the workgroup (8 consumer waves = 256 columns) walks its share of the 32-row tiles of A: a tile (32 x K,
+//     16 KB) arrives by LDS-DMA into a 4-slot ring, every consumer multiplies the SAME tile against its own columns
+//     (one 16-byte LDS read per MFMA, conflict-free through an XOR swizzle applied on the DMA source address);
+//   * a ninth wave is the PRODUCER: it issues all DMA of a tile (17 instructions: 16 KB of A + the padded-row slots
+//     of the 32 nodes), waits for them with COUNTED vmcnt and joins the one barrier per tile.  Consumers therefore
+//     never wait on vmcnt: their only vector-memory operations inside the loop are the output stores, which stay in
+//     flight for as long as HBM needs (gfx950's vmcnt counts loads and stores together and the two return out of
+//     order with respect to each other, so a wave that mixes both can only ever wait for "everything");
+//   * epilogue per wave: the 32 x 32 accumulator goes through a wave-private fp32 LDS strip (no workgroup barrier)
+//     and leaves as 16-byte stores, bias / activation applied on the row-major side in fp32 (one rounding).
+// QKV scatter mode writes Q / K / V head-major at the padded row slots and skip row-major, like the other kernels.
+#include <stdlib.h>
+
+#include "da_gemm_common.h"
+
+namespace da {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16w;
+
+template <int N> __device__ __forceinline__ void wreg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int KIN, bool QKV, int ACT>
+__global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_wg) {
+    constexpr int KS = KIN / 16;                 // k-steps of 16
+    constexpr int ROWB = KIN * 2;                // bytes of one A row
+    constexpr int TILEB = 32 * ROWB;             // one 32-row tile
+    constexpr int NDMA = TILEB / 1024;           // 1 KB DMA instructions per tile
+    constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (32 / 16)
+    constexpr int NSTG = 4;
+    constexpr int SROW = 144;                    // strip row: 32 fp32 + 16 B pad
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *ring = smem;                                  // [NSTG][TILEB]
+    unsigned char *slots = smem + NSTG * TILEB;                  // [NSTG][256 B]: padded-row slot of the tile's 32 nodes
+    unsigned char *strips = slots + NSTG * 256;                  // [8][32][SROW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nrt = (p.M + 31) >> 5;
+    const int t0 = blockIdx.y * tiles_per_wg, t1 = min(t0 + tiles_per_wg, nrt);
+    const int ntile = t1 - t0;
+    if (ntile <= 0) return;
+
+    if (wid == 8) {
+        // ------------------------------------------------ producer wave
+        const int rsub = lane / CPR, pc = lane % CPR;             // row inside a DMA instruction, physical chunk
+        auto issue = [&](int ti) {
+            const int row0 = (t0 + ti) * 32;
+            unsigned char *buf = ring + (ti % NSTG) * TILEB;
+#pragma unroll
+            for (int q = 0; q < NDMA; ++q) {
+                const int row = q * (64 / CPR) + rsub;            // row inside the tile
+                const int lc = pc ^ (row & 15);                   // logical chunk this LDS slot holds
+                const char *src = (const char *)p.A + (size_t)min(row0 + row, p.M - 1) * (size_t)p.lda * 2 + lc * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(buf + q * 1024), 16, 0, 0);
+            }
+            // padded-row slots of the tile's nodes (QKV scatter); one 4-byte piece per lane, lanes >= 32 re-load row 31
+            const int32_t *rm = QKV ? p.row_map + min(row0 + min(lane, 31), p.M - 1) : (const int32_t *)p.A;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rm,
+                                             (__attribute__((address_space(3))) void *)(slots + (ti % NSTG) * 256), 4, 0, 0);
+        };
+        constexpr int PER = NDMA + 1;
+        const int pre = min(NSTG - 1, ntile);
+        for (int ti = 0; ti < pre; ++ti) issue(ti);
+        for (int i = 0; i < ntile; ++i) {
+            const int issued = min(ntile, i + NSTG - 1);          // tiles 0 .. issued-1 are in flight or landed
+            const int younger = issued - 1 - i;                   // tiles after i that may stay in flight: 0, 1 or 2
+            if (younger >= 2) wreg_wait_vmcnt<2 * PER>();
+            else if (younger == 1) wreg_wait_vmcnt<PER>();
+            else wreg_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                         // tile i is readable; everyone is done with tile i - 1
+            if (i + NSTG - 1 < ntile) issue(i + NSTG - 1);        // into the slot of tile i - 1
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- consumer waves
+    const int i32 = lane & 31, half = lane >> 5;
+    const int col0 = blockIdx.x * 256 + wid * 32;
+    const bool active = col0 < p.Nout;
+    // this wave's 32 columns of W as A-operand fragments: lane (col, half), k-step s -> W[col][16 s + 8 half ..+8]
+    u32x4 wf[KS];
+    {
+        const char *wrow = (const char *)p.W + (size_t)min(col0 + i32, p.Nout - 1) * (size_t)p.ldw * 2 + half * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wf[s] = *(const u32x4 *)(wrow + s * 32);
+    }
+    // row-major side of the epilogue: this lane stores the 16-byte chunk `ch` (8 columns) of rows rr and rr + 16
+    const int ch = lane & 3, rr = lane >> 2;
+    const int colc = col0 + 8 * ch;
+    float bz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bz[e] = (p.bias && active) ? p.bias[min(colc + e, p.Nout - 1)] : 0.f;
+    bf16_t *dbase;
+    size_t rstride;
+    bool use_slot = false;
+    if (!QKV) {
+        dbase = (bf16_t *)p.out + colc;
+        rstride = (size_t)p.ldo;
+    } else {
+        const int which = min(colc / p.HC, 3), f = colc - which * p.HC;
+        if (which == 2 && p.Cv > 0) {
+            const int h = f / p.Cv, c = f - h * p.Cv;
+            dbase = (bf16_t *)p.Vt + (size_t)h * p.n_pad * p.Cv + c;
+            rstride = (size_t)p.Cv;
+            use_slot = true;
+        } else if (which == 3) {
+            dbase = (bf16_t *)p.S + f;
+            rstride = (size_t)p.HC;
+        } else {
+            const int h = f / p.C, c = f - h * p.C;
+            dbase = (bf16_t *)(which == 0 ? p.Q : (which == 1 ? p.Kb : p.Vt)) + (size_t)h * p.n_pad * p.C + c;
+            rstride = (size_t)p.C;
+            use_slot = true;
+        }
+    }
+    unsigned char *strip = strips + wid * (32 * SROW);
+    // wait for the W / bias loads here, once: inside the loop this wave only ever issues stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = 0; i < ntile; ++i) {
+        __builtin_amdgcn_s_barrier();                             // producer: tile i has landed
+        if (!active) continue;
+        const unsigned char *buf = ring + (i % NSTG) * TILEB + i32 * ROWB;
+        f32x16w acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // x fragments one group of four k-steps ahead of their MFMAs (a dependent 16-byte LDS read in front of every
+        // MFMA leaves the matrix pipe idle for the read latency); sched_barrier keeps hipcc from sinking the reads again
+        constexpr int PF = 4, NG = KS / PF;
+        u32x4 xa[2][PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) xa[0][s] = *(const u32x4 *)(buf + (((2 * s + half) ^ (i32 & 15)) << 4));
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) {
+#pragma unroll
+                for (int s = 0; s < PF; ++s)
+                    xa[(gq + 1) & 1][s] = *(const u32x4 *)(buf + (((2 * ((gq + 1) * PF + s) + half) ^ (i32 & 15)) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < PF; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[gq * PF + s]),
+                                                              __builtin_bit_cast(bf16x8, xa[gq & 1][s]), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // D^T[col][node]: lane (node = i32, half) holds columns 8 j + 4 half + (0..3) -> strip[node][col] fp32
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *(f32x4 *)(strip + i32 * SROW + (8 * j + 4 * half) * 4) = (f32x4){acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+        const int row0 = (t0 + i) * 32;
+        const int32_t *sl = (const int32_t *)(slots + (i % NSTG) * 256);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = rr + 16 * k;
+            const f32x4 a = *(const f32x4 *)(strip + row * SROW + ch * 32);
+            const f32x4 b = *(const f32x4 *)(strip + row * SROW + ch * 32 + 16);
+            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)apply_act(v[e] + bz[e], ACT);
+            const int m = row0 + row;
+            if (m < p.M) {
+                const size_t ridx = use_slot ? (size_t)sl[row] : (size_t)m;
+                *(u32x4 *)(dbase + ridx * rstride) = __builtin_bit_cast(u32x4, o);
+            }
+        }
+    }
+}
+
+static bool wreg_disabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_DISABLE_WREG"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+// returns 0 = launched, -1 = not applicable (caller falls back to the A-stationary / generic kernels)
+int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st) {
+    if (wreg_disabled() || prec != DA_PREC_BF16) return -1;
+    GemmParams p = p0;
+    if ((p.K != 128 && p.K != 256) || p.pre || p.res || p.M < 4096 || (p.Nout & 31) || p.Nout < 256) return -1;
+    if (qs) {
+        // a wave's 16-byte output chunk (8 columns) must not straddle a column block or a head
+        if ((qs->HC & 31) || (qs->C & 7) || (qs->Cv & 7) || act != DA_ACT_NONE) return -1;
+    } else if ((p.ldo & 7) || (((size_t)p.out) & 15)) {
+        return -1;
+    }
+    const int nrt = (p.M + 31) / 32;
+    const int ncg = (p.Nout + 255) / 256;
+    int nchunk = 256 / ncg;
+    nchunk = nchunk < 1 ? 1 : (nchunk > nrt ? nrt : nchunk);
+    const int tiles = (nrt + nchunk - 1) / nchunk;
+    nchunk = (nrt + tiles - 1) / tiles;
+    const dim3 grid((unsigned)ncg, (unsigned)nchunk);
+#define DA_WREG(KK, QQ, AA)                                                                                              \
+    do {                                                                                                                  \
+        constexpr int lds = 4 * 32 * KK * 2 + 4 * 256 + 8 * 32 * 144;                                                     \
+        static bool attr = false;                                                                                         \
+        if (!attr) {                                                                                                      \
+            DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_wreg<KK, QQ, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            attr = true;                                                                                                  \
+        }                                                                                                                 \
+        k_gemm_wreg<KK, QQ, AA><<<grid, 576, lds, st>>>(p, tiles);                                                        \
+    } while (0)
+    if (qs) {
+        if (p.K == 256) DA_WREG(256, true, DA_ACT_NONE); else DA_WREG(128, true, DA_ACT_NONE);
+    } else if (act == DA_ACT_GELU) {
+        if (p.K == 256) DA_WREG(256, false, DA_ACT_GELU); else DA_WREG(128, false, DA_ACT_GELU);
+    } else if (act == DA_ACT_NONE) {
+        if (p.K == 256) DA_WREG(256, false, DA_ACT_NONE); else DA_WREG(128, false, DA_ACT_NONE);
+    } else {
+        return -1;
+    }
+#undef DA_WREG
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace da

@@ -14,7 +14,8 @@ from torch import Tensor
 
 from .. import _lib
 from ..engine import Schedule
-from ._lightning_compat import LightningModule
+from .. import metrics3d
+from ._lightning_compat import LightningModule, MeanMetric
 from .backbones import Eff_GAT_3d
 from .spatial_diffusion import (ModelMeanType, ModelScheduler, cosine_beta_schedule,  # noqa: F401
                                 cosine_discrete_beta_schedule, extract, linear_beta_schedule)
@@ -158,6 +159,74 @@ class GNN_Diffusion(LightningModule):
 
     def p_losses(self, *args, **kwargs):
         raise NotImplementedError("3D training losses (pytorch3d kNN / chamfer) are out of scope: SURVEY.md 2 #2")
+
+    # ------------------------------------------------------------------ Lightning hooks (inference callers)
+    def initialize_torchmetrics(self, categories):
+        """...double_diffusion.py:347-364: four MeanMetrics per category + their averages."""
+        import torch.nn as nn
+        metrics = {}
+        for i in categories:
+            for k in ("rmse_t", "rmse_r", "gd_r", "part_acc"):
+                metrics[f"{k}_{i}"] = MeanMetric()
+        self.metrics = nn.ModuleDict(metrics)
+        self.avg_metrics = nn.ModuleDict({f"{k}_AVG": MeanMetric() for k in ("rmse_t", "rmse_r", "gd_r", "part_acc")})
+
+    @torch.no_grad()
+    def _eval_step(self, batch, batch_idx):
+        """validation_step / test_step (:895-960, :1036-1080): one sampling loop for the whole Batch, then per object
+        the four pose metrics against the ground-truth poses in ``batch.x`` (wandb / mesh dumps omitted).  Returns the
+        final poses [P, 7]."""
+        sampled_pos, _ = self.p_sample_loop(batch.x.shape, batch.pcds, batch.edge_index, batch=batch.batch,
+                                            pcd_feats=getattr(batch, "pcd_feats", None))
+        final_pos = sampled_pos[-1]
+        G = int(batch.batch.max()) + 1
+        for i in range(G):
+            idx = torch.where(batch.batch == i)[0]
+            gt_pos, pred_pos = batch.x[idx], final_pos[idx]
+            pred_r, pred_t, gt_r, gt_t = pred_pos[:, :4], pred_pos[:, 4:7], gt_pos[:, :4], gt_pos[:, 4:]
+            vals = {"rmse_t": metrics3d.trans_metrics(pred_t, gt_t),
+                    "rmse_r": metrics3d.rot_metrics(pred_r, gt_r, "rmse"),
+                    "gd_r": metrics3d.rot_metrics(pred_r, gt_r, "geodesic")}
+            if getattr(batch, "pcds", None) is not None:
+                vals["part_acc"] = metrics3d.calc_part_acc(batch.pcds[idx], pred_t, gt_t, pred_r, gt_r)
+            if hasattr(self, "metrics"):
+                cat = batch.category[i]
+                for k, v in vals.items():
+                    if f"{k}_{cat}" in self.metrics:
+                        self.metrics[f"{k}_{cat}"].update(v)
+        if hasattr(self, "metrics"):
+            self.log_dict({k: m.compute() for k, m in self.metrics.items()})
+        return final_pos
+
+    def validation_step(self, batch, batch_idx):
+        return self._eval_step(batch, batch_idx)
+
+    def test_step(self, batch, batch_idx):
+        return self._eval_step(batch, batch_idx)
+
+    @torch.no_grad()
+    def prediction_step(self, batch, batch_idx):
+        return self.p_sample_loop(batch.x.shape, batch.pcds, batch.edge_index, batch=batch.batch,
+                                  pcd_feats=getattr(batch, "pcd_feats", None))
+
+    def predict_step(self, batch, batch_idx, dataloader_idx=0):
+        return self.prediction_step(batch, batch_idx)
+
+    def validation_epoch_end(self, outputs) -> None:
+        """:1015-1031: every per-category metric feeds the matching *_AVG metric; the per-category metrics are reset
+        (Lightning does that for logged Metric objects at epoch end)."""
+        if not hasattr(self, "metrics"):
+            return
+        for k in ("rmse_t", "rmse_r", "gd_r", "part_acc"):
+            for name, m in self.metrics.items():
+                if name.startswith(k + "_") and getattr(m, "count", 1):
+                    self.avg_metrics[f"{k}_AVG"].update(float(m.compute()))
+        self.log_dict({k: m.compute() for k, m in self.avg_metrics.items()})
+        for m in list(self.metrics.values()) + list(self.avg_metrics.values()):
+            m.reset()
+
+    def test_epoch_end(self, outputs) -> None:
+        return self.validation_epoch_end(outputs)
 
     def configure_optimizers(self):
         from transformers.optimization import Adafactor

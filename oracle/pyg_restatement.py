@@ -131,3 +131,25 @@ def quaternion_to_matrix(quaternions):
         two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
         two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
     return o.reshape(quaternions.shape[:-1] + (3, 3))
+
+
+def quaternion_apply(quaternion, point):
+    """pytorch3d.transforms.quaternion_apply: rotate points by unit quaternions (real part first), as the
+    product q (0, p) q^-1 restricted to its vector part (restated from the published algorithm)."""
+    w, u = quaternion[..., :1], quaternion[..., 1:]
+    t = 2.0 * torch.cross(u, point, dim=-1)
+    return point + w * t + torch.cross(u, t, dim=-1)
+
+
+class _KNN:
+    def __init__(self, dists, idx):
+        self.dists, self.idx, self.knn = dists, idx, None
+
+
+def knn_points(p1, p2, lengths1=None, lengths2=None, K=1, **kwargs):
+    """pytorch3d.ops.knn_points for K = 1 on equal-length clouds: SQUARED euclidean distance to, and index of, the
+    nearest point of p2 for every point of p1 (brute force)."""
+    assert K == 1
+    d = ((p1[:, :, None, :] - p2[:, None, :, :]) ** 2).sum(-1)
+    dist, idx = d.min(-1)
+    return _KNN(dist[..., None], idx[..., None])

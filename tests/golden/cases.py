@@ -59,6 +59,13 @@ GREEDY = [
     dict(name="greedy_rect_20v30",  rows=5,  cols=6,  noise=0.20, seed=35, kind="fewer_rows", n1=20),
     dict(name="greedy_dups",        rows=4,  cols=4,  noise=0.0,  seed=36, kind="dups"),      # ties at non-zero distances
 ]
+# 3D evaluation metrics (utils_3d.py trans_metrics / rot_metrics / calc_part_acc): P parts of N points, prediction = ground
+# truth perturbed by `noise` (the first part exactly right, the last one far off)
+METRICS3D = [
+    dict(name="metrics3d_p7", P=7, N=200, noise=0.05, seed=51),
+    dict(name="metrics3d_p20", P=20, N=1000, noise=0.02, seed=52),
+    dict(name="metrics3d_p2_far", P=2, N=64, noise=1.0, seed=53),
+]
 # fmt: on
 SCHEDULE_T = [50, 100, 300]
 GOLDEN2_FILE = os.path.join(os.path.dirname(__file__), "golden_v2.npz")
@@ -119,6 +126,20 @@ def build_case(spec, variant="2d"):
     tg = torch.from_numpy(rng.integers(0, spec["steps"], size=len(sizes)))
     t = tg[batch]
     return dict(sd=sd, x=x, t=t, feats=feats, edge_index=edge_index, batch=batch)
+
+
+def metrics3d_inputs(spec):
+    """(pcds [P, N, 3], pred [P, 7], gt [P, 7]) fp32: poses are (unit quaternion wxyz | translation) rows."""
+    rng = np.random.default_rng(spec["seed"])
+    P, N = spec["P"], spec["N"]
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32))  # noqa: E731
+    pcds = f(P, N, 3) * 0.3
+    gt = torch.cat([torch.nn.functional.normalize(f(P, 4), dim=-1), f(P, 3) * 0.5], 1)
+    pred = gt + spec["noise"] * f(P, 7)
+    pred[0] = gt[0]
+    pred[-1, 4:] += 2.0
+    pred[:, :4] = torch.nn.functional.normalize(pred[:, :4], dim=-1)
+    return pcds.contiguous(), pred.contiguous(), gt.contiguous()
 
 
 def by_name(name):

@@ -9,7 +9,9 @@ like make_golden.py; golden_v1.npz stays as it is).  Stores the reference's OUTP
 * ``exo900_d539_v8``: 900 pieces on a random 539-regular Exphander graph, exophormer arch with 8 virtual
   nodes (the scripted configuration, singularity/gianscarpe/train_celeba_rot.sh:4-15): forward out [900, 4];
 * the reference's TorchScript ``greedy_cost_assignment`` (spatial_diffusion.py:179-216) on six position sets
-  (6x6 / 12x12 / 30x30 noisy, exact grids = all-zero-distance ties, fewer pieces than cells, duplicated points).
+  (6x6 / 12x12 / 30x30 noisy, exact grids = all-zero-distance ties, fewer pieces than cells, duplicated points);
+* the reference's 3D evaluation metrics (model/utils_3d.py ``trans_metrics``, ``rot_metrics`` rmse / geodesic,
+  ``calc_part_acc``) on three seeded pose sets.
 
 Inputs and weights are regenerated from seeds by cases.py.   Run:  python tests/golden/make_golden_v2.py
 (about two minutes on 8 cores).
@@ -101,6 +103,16 @@ for g in C.GREEDY:
     ass = sd2.greedy_cost_assignment(pos1, pos2)              # the reference's TorchScript function itself
     put(g["name"], "assignment", ass)
     print("greedy", g["name"], tuple(ass.shape), flush=True)
+
+import importlib  # noqa: E402
+ut3d = importlib.import_module("model.utils_3d")            # the reference's own metric functions
+for ms in C.METRICS3D:
+    pcds, pred, gt = C.metrics3d_inputs(ms)
+    put(ms["name"], "rmse_t", ut3d.trans_metrics(pred[:, 4:], gt[:, 4:]))
+    put(ms["name"], "rmse_r", ut3d.rot_metrics(pred[:, :4], gt[:, :4], metric="rmse"))
+    put(ms["name"], "gd_r", ut3d.rot_metrics(pred[:, :4], gt[:, :4], metric="geodesic"))
+    put(ms["name"], "part_acc", ut3d.calc_part_acc(pcds, pred[:, 4:], gt[:, 4:], pred[:, :4], gt[:, :4], None))
+    print("metrics3d", ms["name"], [float(OUT[f"{ms['name']}/{k}"]) for k in ("rmse_t", "rmse_r", "gd_r", "part_acc")], flush=True)
 
 np.savez_compressed(C.GOLDEN2_FILE, **OUT)
 print("wrote", C.GOLDEN2_FILE, os.path.getsize(C.GOLDEN2_FILE), "bytes,", len(OUT), "arrays")

@@ -6,9 +6,10 @@ copied: the reference files are imported from where they lie.
 
 Missing third-party packages (torch_geometric, pytorch_lightning, timm, kornia, wandb,
 torchmetrics, torchvision, pytorch3d, trimesh, torch_scatter) are replaced by inert
-stubs, except the two that carry arithmetic on the path, which are bound to the
-oracle's restatement (oracle/pyg_restatement.py): ``torch_geometric.nn.TransformerConv``
-and ``pytorch3d.transforms.{matrix_to_quaternion, quaternion_to_matrix}``.
+stubs, except the ones that carry arithmetic on the path, which are bound to the
+oracle's restatement (oracle/pyg_restatement.py): ``torch_geometric.nn.TransformerConv``,
+``pytorch3d.transforms.{matrix_to_quaternion, quaternion_to_matrix, quaternion_apply}`` and
+``pytorch3d.ops.knn.knn_points`` (K = 1; only the 3D evaluation metrics call the last two).
 """
 import importlib
 import os
@@ -101,14 +102,14 @@ def install_stubs():
     _mod("pytorch3d.transforms", matrix_to_quaternion=R.matrix_to_quaternion,
          quaternion_to_matrix=R.quaternion_to_matrix, matrix_to_euler_angles=_Anything(),
          rotation_6d_to_matrix=_Anything(), matrix_to_rotation_6d=_Anything(),
-         quaternion_apply=_Anything(), quaternion_multiply=_Anything(),
+         quaternion_apply=R.quaternion_apply, quaternion_multiply=_Anything(),
          quaternion_invert=_Anything(), euler_angles_to_matrix=_Anything(),
          axis_angle_to_matrix=_Anything(), matrix_to_axis_angle=_Anything(),
          random_quaternions=_Anything(), random_rotations=_Anything(),
          so3_exp_map=_Anything(), so3_log_map=_Anything(), Transform3d=_Anything,
          axis_angle_to_quaternion=_Anything(), quaternion_to_axis_angle=_Anything())
     _mod("pytorch3d.ops")
-    _mod("pytorch3d.ops.knn", knn_gather=_Anything(), knn_points=_Anything())
+    _mod("pytorch3d.ops.knn", knn_gather=_Anything(), knn_points=R.knn_points)
     _mod("pytorch3d.structures")
     _mod("pytorch3d.structures.pointclouds", Pointclouds=_Anything)
     # backbones/__init__.py:1 imports a file that is not in the tree

@@ -57,6 +57,48 @@ def test_da_linear(dev, M, K, N, act, prec):
     assert rel(out.float(), ref) < (1e-5 if prec == "fp32" else 1e-2)
 
 
+@pytest.mark.parametrize("M,K,N,act", [(5000, 256, 1024, 0), (4101, 128, 256, 1), (9000, 256, 2560, 0), (4096, 256, 288, 1)])
+def test_da_linear_tall_inputs_w_in_registers(dev, M, K, N, act):
+    """k_gemm_wreg (da_gemm_wreg.hip: W columns in registers, A tiles streamed by a producer wave) takes bf16 linears
+    with K in {128, 256} and M >= 4096; M not a multiple of the 32-row tile, Nout not a multiple of the 256-column
+    workgroup, GELU epilogue."""
+    from diffassemble_amd import engine as E
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).bfloat16().float()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
+    b = torch.randn(N, generator=g)
+    ref = torch.nn.functional.linear(x, w, b)
+    ref = torch.nn.functional.gelu(ref) if act else ref
+    out = E.linear(x.to(dev), w.to(dev), b.to(dev), act, None, "bf16")
+    assert rel(out.float(), ref) < 1e-2
+    # against the exact-fp32 kernels of the library (different code path): bf16 output rounding only
+    ex = E.linear(x.to(dev), w.to(dev), b.to(dev), act, None, "fp32")
+    assert rel(out.float(), ex) < 6e-3
+
+
+@pytest.mark.parametrize("C_head,loops", [(144, True), (32, False)])
+def test_da_conv_dense_tall_batch_through_w_in_registers_projection(dev, monkeypatch, C_head, loops):
+    """Five 900-piece puzzles (4500 nodes >= 4096): the fused Q|K|V|skip projection goes through k_gemm_wreg's QKV
+    scatter (head-major rows at padded slots, 144-wide heads that straddle its 32-column wave tiles); C = 32 with the
+    one-kernel conv switched off so that the two-kernel path is the one exercised."""
+    from diffassemble_amd import engine as E
+    from diffassemble_amd.graph_plan import build_plan
+    H, Din, sizes = 8, 256, [900, 899, 901, 900, 900]
+    N = sum(sizes)
+    g = torch.Generator().manual_seed(C_head)
+    ei, batch = W.collate([W.dense_edge_index(n, loops) for n in sizes], sizes)
+    x = torch.randn(N, Din, generator=g).bfloat16().float()
+    HC = H * C_head
+    ws = [(torch.randn(HC, Din, generator=g) / Din ** 0.5 * (3.0 if k < 2 else 1.0)).bfloat16().float() for k in range(4)]
+    bs = [torch.randn(HC, generator=g) * 0.1 for _ in range(4)]
+    plan = build_plan(ei.to(dev), batch.to(dev), 0)
+    del ei
+    args = (plan, x.to(dev), torch.cat(ws).to(dev), torch.cat(bs).to(dev), H, C_head, None, 1)
+    exact = E.conv_dense(*args, "fp32")
+    out = E.conv_dense(*args, "bf16")
+    assert rel(out.float(), exact) < 2e-2
+
+
 @pytest.mark.parametrize("C_head", [32, 144, 104])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_da_attn_csr_matches_pyg_semantics(dev, C_head, prec):
