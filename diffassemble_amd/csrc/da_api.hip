@@ -175,7 +175,8 @@ static int check_graph(const da_denoiser *d, const da_graph *g) {
     DA_REQUIRE(g && g->n_real > 0 && g->n_nodes >= g->n_real, "da_graph: bad node counts");
     // complete graphs (dense != 0) on a denoiser whose every layer has an MFMA attention kernel never walk the
     // edge list; the host may then leave the CSR arrays out (da_denoiser_flags bit 2) unless alpha is wanted
-    if (!(g->dense && d->dense_only)) DA_REQUIRE(g->row_ptr && (g->col_src || g->n_edges == 0), "da_graph: CSR arrays missing");
+    const bool hyb = g->hybrid && g->mask && g->mask_ptr && g->irr_row_ptr;
+    if (!((g->dense || hyb) && d->dense_only)) DA_REQUIRE(g->row_ptr && (g->col_src || g->n_edges == 0), "da_graph: CSR arrays missing");
     DA_REQUIRE(d->V == 0 || g->n_nodes == g->n_real + d->V * g->n_graphs,
                "da_graph: exophormer expects n_nodes = n_real + V*G (%d vs %d + %d*%d)", g->n_nodes, g->n_real,
                d->V, g->n_graphs);

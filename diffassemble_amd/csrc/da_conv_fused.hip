@@ -55,7 +55,15 @@ struct ConvFusedParams {
     const int32_t *graph_ptr;
     int n_graphs, act, nodiag;
     float sc;                   // log2(e) / sqrt(32)
+    int debug;                  // DA_FUSED_PROBE builds (tools/fused_probe.py): 1 no phase 2, 2 no softmax, 4 no PV, 8 no QK,
+                                // 16 no x loads in phase 2, 32 one key block, 64 no phase 1
 };
+
+#ifdef DA_FUSED_PROBE
+#define DA_FDBG(...) __VA_ARGS__
+#else
+#define DA_FDBG(...)
+#endif
 
 __device__ __forceinline__ f32x16 mfma(const u32x4 &a, const u32x4 &b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -69,10 +77,14 @@ __device__ __forceinline__ u32x4 pack8(const f32x16 &v, int r0) {
 }
 
 // LDS regions: K [n32][64 B] (16-byte chunks XOR-swizzled by (key >> 2) & 3), V^T [32][VS] (VS = 2 n32 + 16: an odd
-// number of 16-byte slots), W fragments [2][KS][64 lanes][16 B]
+// number of 16-byte slots), W fragments [2][KS][64 lanes][16 B].
+// Occupancy: ONE workgroup per CU (the K / V^T images of a 900-piece graph are 120 KB), so the waves per SIMD come from
+// the workgroup itself: 16 waves (4 per SIMD) at <= 128 VGPRs -- the attention loop is bound by VALU issue and
+// dependency latency (ablation, tools/fused_probe.py), which is what more resident waves hide.  A wave owns at most
+// MAXS = 2 query slabs (launch_conv_fused picks the wave count so that this holds).
 template <int KIN>
-__global__ __launch_bounds__(512, 2) void k_conv_fused(ConvFusedParams p) {
-    constexpr int KS = KIN / 16;
+__global__ __launch_bounds__(1024, 4) void k_conv_fused(ConvFusedParams p) {
+    constexpr int KS = KIN / 16, MAXS = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // all 8 heads of a graph on ONE XCD (workgroup b runs on XCD b % 8): they share x_g in its L2
     const int nblk = gridDim.x;
@@ -97,48 +109,63 @@ __global__ __launch_bounds__(512, 2) void k_conv_fused(ConvFusedParams p) {
             *(u32x4 *)(sW + (size_t)it * 16) = *(const u32x4 *)src;
         }
     };
-    // x fragments of one 32-node slab: lane (node, half), k-step s -> x[node][16 s + 8 half ..+8]
-    auto load_x = [&](int slab, u32x4 (&xf)[KS]) {
-        const int node = min(32 * slab + i, n_g - 1);
-        const bf16_t *row = p.x + (size_t)(node0 + node) * p.ldx + 8 * half;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) xf[s] = *(const u32x4 *)(row + 16 * s);
-    };
-    // bias of the 16 channels a lane holds in the transposed (channel x node) layouts
-    auto load_bias16 = [&](int blk, float (&b)[16]) {
+    // bias of the 16 channels a lane holds in the transposed (channel x node) layouts, as an accumulator initialiser
+    auto bias16 = [&](int blk) {
+        f32x16 b;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 v = *(const f32x4 *)(p.bias + blk * 256 + 32 * h + 8 * j + 4 * half);
             b[4 * j] = v[0]; b[4 * j + 1] = v[1]; b[4 * j + 2] = v[2]; b[4 * j + 3] = v[3];
+        }
+        return b;
+    };
+    // Two projections of one 32-node slab against the two weight blocks currently in LDS, accumulated onto a0 / a1:
+    //   a0 += W_0 . x^T (channel x node);  a1 += second_node_major ? x . W_1^T (node x channel) : W_1 . x^T.
+    // x fragments come straight from global memory in operand shape -- lane (node, half), k-step s -> x[node][16 s + 8 half
+    // ..+8] -- eight k-steps (32 VGPRs) at a time.
+    auto project = [&](int slab, f32x16 &a0, f32x16 &a1, bool second_node_major) {
+        const int node = min(32 * slab + i, n_g - 1);
+        const bf16_t *row = p.x + (size_t)(node0 + node) * p.ldx + 8 * half;
+        // the weight fragments are the same for every slab: without this the compiler hoists all 2 x KS reads (128 VGPRs)
+        // out of the slab loop and spills
+        unsigned lo = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(lo));
+#pragma unroll 1
+        for (int hk = 0; hk < KS; hk += 8) {
+            // (the address is laundered so that the second half's loads are not hoisted above the first half's MFMAs:
+            // 64 VGPRs of x fragments at once do not fit beside the accumulators at 4 waves per SIMD)
+            const bf16_t *rowh = row + 16 * hk;
+            asm volatile("" : "+v"(rowh));
+            u32x4 xf[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) xf[s] = *(const u32x4 *)(rowh + 16 * s);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const u32x4 w0 = *(const u32x4 *)(sW + (size_t)(hk + s) * 1024 + lo);
+                const u32x4 w1 = *(const u32x4 *)(sW + (size_t)(KS + hk + s) * 1024 + lo);
+                a0 = mfma(w0, xf[s], a0);
+                a1 = second_node_major ? mfma(xf[s], w1, a1) : mfma(w1, xf[s], a1);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the W fragment reads from piling up in registers
+            }
         }
     };
 
     // =========================== phase 1: K_h and V_h^T of the whole graph into LDS ===========================
     stage_w(1, 2);
     __syncthreads();
+    DA_FDBG(if (!(p.debug & 64)))
     {
-        float bk[16];
-        load_bias16(1, bk);
         const float bv = p.bias[2 * 256 + 32 * h + i];
         for (int slab = wid; slab < nslab; slab += NW) {
-            u32x4 xf[KS];
-            load_x(slab, xf);
-            f32x16 aK, aV;
+            f32x16 aK = bias16(1), aV;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { aK[r] = 0.f; aV[r] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const u32x4 wk = *(const u32x4 *)(sW + (size_t)(s * 64 + lane) * 16);
-                const u32x4 wv = *(const u32x4 *)(sW + (size_t)((KS + s) * 64 + lane) * 16);
-                aK = mfma(wk, xf[s], aK);          // K^T[ch][node]
-                aV = mfma(xf[s], wv, aV);          // V[node][ch]
-                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the W fragment reads from piling up in registers
-            }
+            for (int r = 0; r < 16; ++r) aV[r] = bv;
+            project(slab, aK, aV, true);           // K^T[ch][node], V[node][ch]
             // K: this lane = node 32 slab + i; rows beyond the graph are zero (their scores are masked anyway)
             const int key = 32 * slab + i;
             const bool kin = key < n_g;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) aK[r] = kin ? aK[r] + bk[r] : 0.f;
+            for (int r = 0; r < 16; ++r) aK[r] = kin ? aK[r] : 0.f;
             const int sw = (key >> 2) & 3;
             *(u32x4 *)(sK + (size_t)key * 64 + (((0 + half) ^ sw) << 4)) = pack8(aK, 0);
             *(u32x4 *)(sK + (size_t)key * 64 + (((2 + half) ^ sw) << 4)) = pack8(aK, 8);
@@ -149,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_fused(ConvFusedParams p) {
                 const int nd = 32 * slab + 8 * j + 4 * half;
                 bf16x4 b;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b[e] = (__bf16)((nd + e < n_g) ? aV[4 * j + e] + bv : 0.f);
+                for (int e = 0; e < 4; ++e) b[e] = (__bf16)((nd + e < n_g) ? aV[4 * j + e] : 0.f);
                 *(u32x2 *)(sV + (size_t)i * VS + (size_t)nd * 2) = __builtin_bit_cast(u32x2, b);
             }
         }
@@ -158,107 +185,114 @@ __global__ __launch_bounds__(512, 2) void k_conv_fused(ConvFusedParams p) {
     stage_w(0, 3);
     __syncthreads();
 
-    // =========================== phase 2: attention of this wave's query slabs ===========================
-    float bq[16], bs[16];
-    load_bias16(0, bq);
-    load_bias16(3, bs);
-    const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);       // key fed to MFMA row i
-    for (int slab = wid; slab < nslab; slab += NW) {
-        // ---- Q^T (-> B operand of S^T) and skip^T (-> added to O^T at the end) of the slab
-        u32x4 qf[2];
-        f32x16 aS;
-        {
-            u32x4 xf[KS];
-            load_x(slab, xf);
-            f32x16 aQ;
+    // ====== phase 1b: Q^T (-> B operand of S^T, kept in registers) and skip^T of this wave's slabs.  skip goes to the
+    // OUTPUT rows as bf16 right away (the two-kernel path rounds it to bf16 too) and is read back by the same lanes in the
+    // epilogue: 16 registers per slab that the attention loop does not have to carry.
+    u32x4 qf[MAXS][2];                           // bf16: registers 8t..8t+7 of the (channel x node) accumulator
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { aQ[r] = 0.f; aS[r] = 0.f; }
+    for (int j = 0; j < MAXS; ++j) {
+        const int slab = wid + j * NW;
+        if (slab < nslab) {
+            f32x16 aQ = bias16(0), aS = bias16(3);
+            project(slab, aQ, aS, false);
+            qf[j][0] = pack8(aQ, 0); qf[j][1] = pack8(aQ, 8);
+            const int qidx = 32 * slab + i;
+            if (qidx < n_g) {
+                bf16_t *dst = p.out + (size_t)(node0 + qidx) * 256 + 32 * h + 4 * half;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const u32x4 wq = *(const u32x4 *)(sW + (size_t)(s * 64 + lane) * 16);
-                const u32x4 ws = *(const u32x4 *)(sW + (size_t)((KS + s) * 64 + lane) * 16);
-                aQ = mfma(wq, xf[s], aQ);
-                aS = mfma(ws, xf[s], aS);
-                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                for (int jj = 0; jj < 4; ++jj) {
+                    bf16x4 b;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = (__bf16)aS[4 * jj + e];
+                    *(u32x2 *)(dst + 8 * jj) = __builtin_bit_cast(u32x2, b);
+                }
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { aQ[r] += bq[r]; aS[r] += bs[r]; }
-            qf[0] = pack8(aQ, 0);
-            qf[1] = pack8(aQ, 8);
         }
+    }
+    DA_FDBG(if (p.debug & 1) return;)
+
+    // =========================== phase 2: attention of this wave's query slabs ===========================
+    const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);       // key fed to MFMA row i
+    // a 32-key block is 2 KB of K rows; (32 kb + pi_i) >> 2 == pi_i >> 2 (mod 4): the swizzle does not depend on kb
+    const unsigned char *kp0 = sK + (size_t)pi_i * 64 + (((0 + half) ^ ((pi_i >> 2) & 3)) << 4);
+    const unsigned char *kp1 = sK + (size_t)pi_i * 64 + (((2 + half) ^ ((pi_i >> 2) & 3)) << 4);
+    const unsigned char *vrow = sV + (size_t)i * VS + (size_t)(16 * half) * 2;
+    constexpr float THR = 16384.0f;              // block sums above this re-centre the running max (see below)
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+        const int slab = wid + j * NW;
+        if (slab >= nslab) break;
         const int qidx = 32 * slab + i;                   // this lane's query (index inside the graph)
         f32x16 O;
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[r] = 0.f;
-        float m = -INFINITY, l = 0.f;
-        // LDS addresses of this lane's fragments inside a 32-key block
-        const int krow = pi_i;                            // key (inside the block) this lane feeds
-        const unsigned char *vrow = sV + (size_t)i * VS + (size_t)(16 * half) * 2;
-        auto qk = [&](int kb) {
-            const int key = 32 * kb + krow, sw = (key >> 2) & 3;
-            const u32x4 k0 = *(const u32x4 *)(sK + (size_t)key * 64 + (((0 + half) ^ sw) << 4));
-            const u32x4 k1 = *(const u32x4 *)(sK + (size_t)key * 64 + (((2 + half) ^ sw) << 4));
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            s = mfma(k0, qf[0], s);
-            s = mfma(k1, qf[1], s);
-            return s;
-        };
-        f32x16 s = qk(0);
-        for (int kb = 0; kb < nslab; ++kb) {
-            // V^T fragments of this block and S^T of the NEXT block are in flight under the softmax
-            const u32x4 v0 = *(const u32x4 *)(vrow + (size_t)(32 * kb) * 2);
-            const u32x4 v1 = *(const u32x4 *)(vrow + (size_t)(32 * kb + 8) * 2);
-            f32x16 sn;
-            if (kb + 1 < nslab) sn = qk(kb + 1);
+        // Online softmax WITHOUT a per-block max: p = exp2((s - m) sc) is formed against the running reference m
+        // directly; only when a block's sum says the reference is stale (first block: m = -1e30 gives +inf; later: some
+        // score more than ~2^10 above m) is the block's true max taken and O / l rescaled.  Softmax is shift invariant,
+        // so any m works as long as nothing overflows: the max tree (8 v_max3 + compare per block) leaves the common path.
+        float m = -1e30f, l = 0.f;
+        int nkb = nslab;
+        DA_FDBG(if (p.debug & 32) nkb = 1;)
+        for (int kb = 0; kb < nkb; ++kb) {
+            const u32x4 k0 = *(const u32x4 *)(kp0 + (size_t)kb * 2048);
+            const u32x4 k1 = *(const u32x4 *)(kp1 + (size_t)kb * 2048);
+            const u32x4 v0 = *(const u32x4 *)(vrow + (size_t)kb * 64);
+            const u32x4 v1 = *(const u32x4 *)(vrow + (size_t)kb * 64 + 16);
+            f32x16 s = mfma(k0, qf[j][0], (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+            s = mfma(k1, qf[j][1], s);
             // this lane holds keys 32 kb + 16 half + r, r = 0..15, of query qidx
             const int kbase = 32 * kb + 16 * half;
-            const bool tail = 32 * kb + 32 > n_g;
-            const bool diag = p.nodiag && kb == slab;
-            if (tail || diag) {
+            if (32 * kb + 32 > n_g || (p.nodiag && kb == slab)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
             }
-            const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
-            const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
-            const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
-            const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
-            const bool grow = !(m > -INFINITY) || (mloc - m) * p.sc > 8.0f;
-            if (__any(grow)) {
-                float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));
-                if (mnew == -INFINITY) mnew = 0.f;               // nothing but masked keys so far
+            float ms = m * p.sc;
+            float pr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms));
+            float bsum = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])) +
+                         (((pr[8] + pr[9]) + (pr[10] + pr[11])) + ((pr[12] + pr[13]) + (pr[14] + pr[15])));
+            if (__any(!(bsum < THR))) {
+                // rare: re-centre on this block's max (both halves of a query agree through the cross-half exchange)
+                const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
+                const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
+                const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+                const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
+                const float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));     // >= -1e30: finite
                 const float corr = __builtin_amdgcn_exp2f((m - mnew) * p.sc);
                 m = mnew;
                 l *= corr;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) O[r] *= corr;
-            }
-            const float ms = m * p.sc;
-            float pr[16];
+                ms = m * p.sc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms));
-            l += ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])) +
-                 (((pr[8] + pr[9]) + (pr[10] + pr[11])) + ((pr[12] + pr[13]) + (pr[14] + pr[15])));
+                for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms));
+                bsum = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])) +
+                       (((pr[8] + pr[9]) + (pr[10] + pr[11])) + ((pr[12] + pr[13]) + (pr[14] + pr[15])));
+            }
+            l += bsum;
             bf16x8 pf0, pf1;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { pf0[e] = (__bf16)pr[e]; pf1[e] = (__bf16)pr[8 + e]; }
             O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O, 0, 0, 0);
             O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
-            if (kb + 1 < nslab) s = sn;
         }
         // ---- epilogue in registers: normalise (PyG: sum + 1e-16), + skip, activation, 8-byte stores
         const float lt = l + __shfl_xor(l, 32);
         const float inv = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
         if (qidx < n_g) {
             bf16_t *dst = p.out + (size_t)(node0 + qidx) * 256 + 32 * h + 4 * half;
+            u32x2 skv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int jj = 0; jj < 4; ++jj) skv[jj] = *(const u32x2 *)(dst + 8 * jj);     // skip^T, written in phase 1b by this lane
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const bf16x4 sv = __builtin_bit_cast(bf16x4, skv[jj]);
                 bf16x4 b;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b[e] = (__bf16)apply_act(fmaf(O[4 * j + e], inv, aS[4 * j + e]), p.act);
-                *(u32x2 *)(dst + 8 * j) = __builtin_bit_cast(u32x2, b);
+                for (int e = 0; e < 4; ++e) b[e] = (__bf16)apply_act(fmaf(O[4 * jj + e], inv, (float)sv[e]), p.act);
+                *(u32x2 *)(dst + 8 * jj) = __builtin_bit_cast(u32x2, b);
             }
         }
     }
@@ -290,9 +324,12 @@ int launch_conv_fused(int prec, int heads, int C, int kin, int n_graphs, int max
     p.x = (const bf16_t *)x; p.ldx = ldx; p.W = (const bf16_t *)W; p.bias = bias; p.out = (bf16_t *)out;
     p.graph_ptr = graph_ptr; p.n_graphs = n_graphs; p.act = act; p.nodiag = nodiag;
     p.sc = 1.4426950408889634f / sqrtf(32.0f);
+    { const char *e = getenv("DA_FUSED_DEBUG"); p.debug = e ? atoi(e) : 0; }
     const int nblk = n_graphs * 8;
-    // 8 waves per workgroup when a graph has enough 32-query slabs to feed them, else 4
-    const int threads = max_graph_nodes > 128 ? 512 : 256;
+    // waves per workgroup: enough that no wave owns more than two 32-query slabs (the kernel keeps a slab's Q^T / skip^T
+    // fragments in registers), 16 for the 900-piece graphs = 4 per SIMD
+    const int nslab_max = (max_graph_nodes + 31) / 32;
+    const int threads = nslab_max > 16 ? 1024 : (nslab_max > 8 ? 512 : 256);
     if (kin == 256) {
         static bool attr = false;
         if (!attr) { DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }

@@ -185,7 +185,9 @@ static bool wreg_disabled() {
 int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st) {
     if (wreg_disabled() || prec != DA_PREC_BF16) return -1;
     GemmParams p = p0;
-    if ((p.K != 128 && p.K != 256) || p.pre || p.res || p.M < 4096 || (p.Nout & 31) || p.Nout < 256) return -1;
+    // measured (28 800 rows): faster than the A-stationary kernel from ~1100 output columns up (K = 256: 3456 columns 77 vs 90 us,
+    // 4608: 97 vs 119; 1024: 39 vs 36 -- too few column groups to fill the chip), K = 128 x 1152: 23.5 vs 26 us
+    if ((p.K != 128 && p.K != 256) || p.pre || p.res || p.M < 4096 || (p.Nout & 31) || p.Nout < 1100) return -1;
     if (qs) {
         // a wave's 16-byte output chunk (8 columns) must not straddle a column block or a head
         if ((qs->HC & 31) || (qs->C & 7) || (qs->Cv & 7) || act != DA_ACT_NONE) return -1;

@@ -116,9 +116,14 @@ class DenoiserEngine:
     def plan(self, edge_index, batch):
         return build_plan(edge_index.to(self.device), batch.to(self.device), self.virt_nodes)
 
+    def plan_expander(self, perms, degree):
+        """Plan of a Batch of Exphander graphs straight from their permutations (no edge list, no sort)."""
+        from .graph_plan import expander_plan
+        return expander_plan(perms, degree, self.device, self.virt_nodes)
+
     def _workspace(self, plan: GraphPlan, need_csr=None):
-        if need_csr is None:       # complete graphs on an all-MFMA denoiser never walk the edge list
-            need_csr = not (plan.dense and self.dense_only)
+        if need_csr is None:       # complete / hybrid graphs on an all-MFMA denoiser never walk the edge list
+            need_csr = not ((plan.dense or plan.hybrid) and self.dense_only)
         g = plan.c_struct(need_csr)
         need = int(self.lib.da_denoiser_workspace_bytes(self.handle, C.byref(g)))
         key = (plan.n_nodes, plan.n_real)

@@ -56,7 +56,8 @@ class GraphPlan:
     n_pad: int                 # dense mode: rows of the head-major Q / K / V buffers
     pad_ptr: torch.Tensor      # int32 [G + 1] (64-aligned slot of each graph)
     row_map: torch.Tensor      # int32 [n_nodes] node -> padded row
-    edge_index: torch.Tensor   # int64 [2, E] (extended for exophormer) -- returned with alpha
+    _edge_index: torch.Tensor   # int64 [2, E] (extended for exophormer) -- returned with alpha; None until asked for
+                                # when the plan was built from expander permutations (see ``edge_index``)
     out_ptr: torch.Tensor = None   # int32 [n_nodes + 1] CSR by SOURCE (training backward), lazily built
     out_dst: torch.Tensor = None   # int32 [E]
     # hybrid mode (sparse-but-heavy graphs, e.g. Exphander + exophormer virtual nodes): the unique
@@ -67,6 +68,13 @@ class GraphPlan:
     mask_ptr: torch.Tensor = None  # int64 [G + 1] byte offsets
     irr_row_ptr: torch.Tensor = None   # int32 [n_nodes + 1]
     irr_col_src: torch.Tensor = None   # int32 [E_irregular]
+    edge_index_fn: object = None       # () -> the edge list, for plans built without one (expander_plan)
+
+    @property
+    def edge_index(self):
+        if self._edge_index is None and self.edge_index_fn is not None:
+            self._edge_index = self.edge_index_fn()
+        return self._edge_index
 
     def ensure_csr(self):
         """CSR by destination of ``edge_index`` (stable: keeps the caller's order inside a segment)."""
@@ -141,15 +149,14 @@ def build_plan(edge_index, batch, virt_nodes=0, detect_dense=True, hybrid=None):
     dense = 0
     if detect_dense and virt_nodes == 0 and edge_index.shape[1] > 0:
         dense = _detect_dense(edge_index, batch, counts)
+    real_ei, virt_ei = edge_index, None
     if virt_nodes > 0:
         edge_index = exophormer_edge_index(edge_index, batch, virt_nodes, G)
+        virt_ei = edge_index[:, real_ei.shape[1]:]
         n_nodes = N + virt_nodes * G
     E = edge_index.shape[1]
     assert n_nodes < 2 ** 31 and E < 2 ** 31
     src, dst = edge_index[0], edge_index[1]
-    # complete graphs: the CSR is built on demand (GraphPlan.ensure_csr) -- sorting 26 M edges of 32 900-piece
-    # puzzles is most of the plan time and the dense kernels never read it
-    row_ptr, col_src, edge_id = (None, None, None) if dense else _csr_by_destination(edge_index, n_nodes)
     # padded slots: the rows of graph g (its real nodes, then its virtual nodes) own a 64-aligned block
     padded = (counts + virt_nodes + 63) // 64 * 64
     pad_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
@@ -162,50 +169,156 @@ def build_plan(edge_index, batch, virt_nodes=0, detect_dense=True, hybrid=None):
     hyb = dict(hybrid=0)
     mode = hybrid if hybrid is not None else _hybrid_mode()
     if dense == 0 and mode != "off" and E > 0 and N > 0:
-        hyb = _hybrid_split(src, dst, batch, counts, graph_ptr, padded, n_nodes, N, mode == "force")
+        hyb = _hybrid_split(real_ei, virt_ei, batch, counts, graph_ptr, padded, n_nodes, N, mode == "force")
+    # complete and hybrid graphs: the CSR is built on demand (GraphPlan.ensure_csr) -- sorting the 15-26 M edges of 32
+    # 900-piece puzzles was most of the plan time and the matrix-core kernels never read it
+    row_ptr, col_src, edge_id = (None, None, None) if (dense or hyb["hybrid"]) else _csr_by_destination(edge_index, n_nodes)
     return GraphPlan(
         n_pad=int(pad_ptr[-1]), pad_ptr=pad_ptr.to(torch.int32), row_map=row_map.to(torch.int32).contiguous(),
         n_nodes=n_nodes, n_real=N, n_graphs=G, dense=dense, n_edges=E,
         max_graph_nodes=int(counts.max()) if G else 0,
         row_ptr=row_ptr, col_src=col_src, edge_id=edge_id, graph_ptr=graph_ptr.to(torch.int32),
-        edge_index=edge_index, **hyb)
+        _edge_index=edge_index, **hyb)
 
 
-def _hybrid_split(src, dst, batch, counts, graph_ptr, padded, n_nodes, N, force):
+def _pack_mask(counts, padded, graph_ptr, regular_cells=None, uniform_bool=None):
+    """Adjacency bit matrix in the layout the masked attention reads: rows of graph g start at mask_ptr[g], row stride
+    padded_g / 8 bytes, bit j of row i = edge j -> i.  Either from a [G, n, n] bool (all graphs the same size: pure
+    elementwise packing) or from (graph, target, source) triples."""
+    dev = counts.device
+    G = counts.numel()
+    stride = padded // 8
+    mask_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    mask_ptr[1:] = torch.cumsum(counts * stride, 0)
+    total = int(mask_ptr[-1]) + 64
+    if uniform_bool is not None:
+        n, npad = uniform_bool.shape[1], int(padded[0])
+        m = torch.zeros((G, n, npad), dtype=torch.uint8, device=dev)
+        m[:, :, :n] = uniform_bool
+        w = (1 << torch.arange(8, device=dev, dtype=torch.int32)).to(torch.uint8)
+        packed = (m.view(G, n, npad // 8, 8) * w).sum(-1, dtype=torch.uint8)
+        out = torch.zeros(total, dtype=torch.uint8, device=dev)
+        out[: G * n * (npad // 8)] = packed.reshape(-1)
+        return out, mask_ptr
+    g, i, j = regular_cells
+    byte = mask_ptr[g] + i * stride[g] + (j >> 3)
+    acc = torch.zeros(total, dtype=torch.int32, device=dev)
+    acc.index_add_(0, byte, (1 << (j & 7)).to(torch.int32))           # bits of a byte are distinct pairs: sum == or
+    return acc.to(torch.uint8), mask_ptr
+
+
+def _irregular_csr(isrc, idst, n_nodes):
+    order = torch.argsort(idst, stable=True)
+    irr_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=idst.device)
+    irr_ptr[1:] = torch.cumsum(torch.bincount(idst, minlength=n_nodes), 0)
+    return irr_ptr.to(torch.int32), isrc[order].to(torch.int32).contiguous()
+
+
+def _hybrid_split(real_ei, virt_ei, batch, counts, graph_ptr, padded, n_nodes, N, force):
     """Split the edge list into (a) "regular" edges -- both ends real, same graph, the pair occurs once --
     stored as one adjacency bit per (target, source) pair, and (b) everything else as CSR by destination
     (PyG's multi-edge semantics live there).  Worth it when the regular part is most of the edges and the
     graphs are big and dense enough that streaming whole K/V tiles beats gathering rows (measured on
-    MI355X: 900-node Exphander graphs are 7-19x faster through the matrix cores)."""
-    dev = src.device
-    E = src.numel()
-    real = (src < N) & (dst < N)
-    same = torch.zeros(E, dtype=torch.bool, device=dev)
-    same[real] = batch[src[real]] == batch[dst[real]]
-    key = dst * n_nodes + src
-    uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
-    regular = same & (cnt[inv] == 1)
+    MI355X: 900-node Exphander graphs are 7-19x faster through the matrix cores).
+
+    No sort over the edge list: multiplicities come from ONE scatter-add into the per-graph n_g x n_g cell tables
+    (26 M cells for 32 puzzles of 900 pieces; the torch.unique this replaces sorted 15 M keys), the exophormer's virtual
+    edges -- all irregular, and a few hundred thousand at most -- are the only thing that is sorted."""
+    dev = batch.device
+    src, dst = real_ei[0], real_ei[1]
+    E0 = src.numel()
+    G = counts.numel()
+    gs = batch[src]
+    same = gs == batch[dst]
+    pbase = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    pbase[1:] = torch.cumsum(counts * counts, 0)
+    li, lj = dst - graph_ptr[gs], src - graph_ptr[gs]
+    cell = pbase[gs] + li * counts[gs] + lj                      # (only meaningful where `same`)
+    cell = torch.where(same, cell, torch.zeros_like(cell))
+    cnt = torch.zeros(int(pbase[-1]) + 1, dtype=torch.int32, device=dev)
+    cnt.index_add_(0, cell, same.to(torch.int32))
+    once = cnt == 1
+    regular = same & once[cell]
     n_reg = int(regular.sum())
-    pairs = int((counts * counts).sum())
+    E = E0 + (virt_ei.shape[1] if virt_ei is not None else 0)
+    pairs = int(pbase[-1])
     if not force and not (int(counts.max()) >= 256 and n_reg >= 0.5 * E and n_reg >= 0.03 * pairs):
         return dict(hybrid=0)
-    G = counts.numel()
-    stride = padded // 8                                              # bytes per mask row of graph g
-    mask_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
-    mask_ptr[1:] = torch.cumsum(counts * stride, 0)
-    rs, rd = src[regular], dst[regular]
-    g = batch[rd]
-    i, j = rd - graph_ptr[g], rs - graph_ptr[g]
-    byte = mask_ptr[g] + i * stride[g] + (j >> 3)
-    acc = torch.zeros(int(mask_ptr[-1]) + 64, dtype=torch.int32, device=dev)
-    acc.index_add_(0, byte, (1 << (j & 7)).to(torch.int32))           # bits of a byte are distinct pairs: sum == or
-    irr = ~regular
+    n0 = int(counts[0])
+    if bool((counts == n0).all()):
+        mask, mask_ptr = _pack_mask(counts, padded, graph_ptr, uniform_bool=once[:-1].view(G, n0, n0))
+    else:
+        cells = once[:-1].nonzero().flatten()
+        g = torch.searchsorted(pbase, cells, right=True) - 1
+        loc = cells - pbase[g]
+        mask, mask_ptr = _pack_mask(counts, padded, graph_ptr, regular_cells=(g, loc // counts[g], loc % counts[g]))
+    irr = (~regular).nonzero().flatten()                           # duplicates / cross-graph pairs: usually none
     isrc, idst = src[irr], dst[irr]
-    order = torch.argsort(idst, stable=True)
-    irr_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
-    irr_ptr[1:] = torch.cumsum(torch.bincount(idst, minlength=n_nodes), 0)
-    return dict(hybrid=1, mask=acc.to(torch.uint8), mask_ptr=mask_ptr, irr_row_ptr=irr_ptr.to(torch.int32),
-                irr_col_src=isrc[order].to(torch.int32).contiguous())
+    if virt_ei is not None:
+        isrc, idst = torch.cat([isrc, virt_ei[0]]), torch.cat([idst, virt_ei[1]])
+    irr_ptr, irr_src = _irregular_csr(isrc, idst, n_nodes)
+    return dict(hybrid=1, mask=mask, mask_ptr=mask_ptr, irr_row_ptr=irr_ptr, irr_col_src=irr_src)
+
+
+def expander_plan(perms, degree, batch_device=None, virt_nodes=0):
+    """GraphPlan of a Batch of Exphander graphs (puzzle_dataset.py:115-152) straight from their permutations
+    (``diffassemble_amd.expander``): in position space the graph is a circulant band, so the adjacency bit of a pair is
+    a closed form of the two positions -- no edge list, no sort, no multiplicity table.  The exophormer's virtual-node
+    edges (exophormer_gnn.py:183-200) depend only on the Batch shape and are planned as in ``build_plan``.  The edge
+    list itself (``plan.edge_index``, needed when attention weights are returned) is materialised on demand.
+    perms: int64 [G, n]; all graphs have n nodes."""
+    from . import expander
+    perms = torch.as_tensor(perms)
+    dev = torch.device(batch_device) if batch_device is not None else perms.device
+    perms = perms.to(dev)
+    G, n = perms.shape
+    d = int(degree)
+    reps = d // 2
+    if (n * d) % 2 != 0:
+        raise TypeError("nodes * degree must be even")
+    N = G * n
+    batch = torch.arange(G, device=dev).repeat_interleave(n)
+    counts = torch.full((G,), n, dtype=torch.int64, device=dev)
+    graph_ptr = torch.arange(G + 1, device=dev, dtype=torch.int64) * n
+    V = int(virt_nodes)
+    n_nodes = N + V * G
+    padded = (counts + V + 63) // 64 * 64
+    pad_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    pad_ptr[1:] = torch.cumsum(padded, 0)
+    row_map = torch.arange(N, device=dev) - graph_ptr[batch] + pad_ptr[batch]
+    if V > 0:
+        vg = torch.arange(V * G, device=dev) // V
+        row_map = torch.cat([row_map, pad_ptr[vg] + n + torch.arange(V * G, device=dev) % V])
+
+    def edge_list():
+        ei, b = expander.regular_edge_index(perms, d)
+        return exophormer_edge_index(ei, b, V, G) if V > 0 else ei
+
+    dup_free = 2 * reps < n and not (d % 2 == 1 and reps >= n // 2)       # rolls k and n - k never coincide
+    mode = _hybrid_mode()
+    n_virt_edges = (N + G * V * (n + V)) if V > 0 else 0
+    E = N * d + n_virt_edges
+    if not dup_free or mode == "off" or not (n >= 256 and d * n >= 0.03 * n * n or mode == "force"):
+        return build_plan(edge_list(), batch, V)                          # generic route (multi-edges, tiny graphs, ...)
+    pos = torch.empty_like(perms)
+    pos.scatter_(1, perms, torch.arange(n, device=dev).expand(G, n))      # pos[g, node] = its position in the permutation
+    dist = (pos[:, :, None] - pos[:, None, :]) % n                        # [G, target, source]
+    cd = torch.minimum(dist, n - dist)
+    adj = (cd >= 1) & (cd <= reps)
+    if d % 2 == 1:
+        adj |= cd * 2 == n
+    mask, mask_ptr = _pack_mask(counts, padded, graph_ptr, uniform_bool=adj)
+    if V > 0:
+        ve = exophormer_edge_index(torch.zeros((2, 0), dtype=torch.int64, device=dev), batch, V, G)
+        irr_ptr, irr_src = _irregular_csr(ve[0], ve[1], n_nodes)
+    else:
+        e = torch.zeros(0, dtype=torch.int64, device=dev)
+        irr_ptr, irr_src = _irregular_csr(e, e, n_nodes)
+    return GraphPlan(
+        n_pad=int(pad_ptr[-1]), pad_ptr=pad_ptr.to(torch.int32), row_map=row_map.to(torch.int32).contiguous(),
+        n_nodes=n_nodes, n_real=N, n_graphs=G, dense=0, n_edges=E, max_graph_nodes=n,
+        row_ptr=None, col_src=None, edge_id=None, graph_ptr=graph_ptr.to(torch.int32), _edge_index=None,
+        edge_index_fn=edge_list, hybrid=1, mask=mask, mask_ptr=mask_ptr, irr_row_ptr=irr_ptr, irr_col_src=irr_src)
 
 
 def _detect_dense(edge_index, batch, counts):

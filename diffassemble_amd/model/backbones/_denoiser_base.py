@@ -67,8 +67,17 @@ class DenoiserBase(nn.Module):
             self._plan_key = self._feat_key = None
         return self._engine
 
-    def _plan_for(self, eng, edge_index, batch):
+    def _plan_for(self, eng, edge_index, batch, expander=None):
+        """``expander=(perms [G, n], degree)``: the Batch's graphs are Exphander graphs described by their permutations
+        (diffassemble_amd.expander); the plan is then built in closed form and ``edge_index`` may be None."""
         key = getattr(self, "_plan_key", None)
+        if expander is not None:
+            perms, degree = expander
+            if key is None or not key.matches((perms,), (id(eng), "expander", int(degree))):
+                self._plan = eng.plan_expander(perms, degree)
+                self._plan_key = _Held((perms,), (id(eng), "expander", int(degree)))
+                self._feat_key = None
+            return self._plan
         if key is None or not key.matches((edge_index, batch), (id(eng),)):
             self._plan = eng.plan(edge_index, batch)
             self._plan_key = _Held((edge_index, batch), (id(eng),))

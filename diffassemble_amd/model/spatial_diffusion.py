@@ -259,8 +259,10 @@ class GNN_Diffusion(LightningModule):
         return prev, attentions
 
     @torch.no_grad()
-    def p_sample_loop(self, shape, cond, edge_index, batch, patch_feats=None):
-        """spatial_diffusion.py:635-676.  ``patch_feats`` may be passed to bypass the encoder."""
+    def p_sample_loop(self, shape, cond, edge_index, batch, patch_feats=None, expander=None):
+        """spatial_diffusion.py:635-676.  ``patch_feats`` may be passed to bypass the encoder; ``expander=(perms, degree)``
+        (extension): the graphs are Exphander graphs given by their permutations -- planned in closed form on
+        the device, ``edge_index`` may then be None on the hipGraph fast path."""
         device = self.device
         img = torch.randn(shape, device=device) * self.noise_weight
         if patch_feats is None:
@@ -270,7 +272,7 @@ class GNN_Diffusion(LightningModule):
                 and not self.classifier_free_prob > 0.0)
         if fast:
             eng = self.model.engine(device)
-            plan = self.model._plan_for(eng, edge_index, batch)
+            plan = self.model._plan_for(eng, edge_index, batch, expander)
             self.model._feat_key = None
             traj, _ = eng.sample_loop(plan, self._schedule(), img, patch_feats, ratio=self.inference_ratio,
                                       mean_type=self._mean_type(), keep_trajectory=True,
@@ -340,7 +342,20 @@ class GNN_Diffusion(LightningModule):
 
     @torch.no_grad()
     def prediction_step(self, batch, batch_idx):
-        return self.p_sample_loop(batch.x.shape, batch.patches, batch.edge_index, batch=batch.batch)
+        return self.p_sample_loop(batch.x.shape, batch.patches, batch.edge_index, batch=batch.batch,
+                                  expander=self._expander_of(batch))
+
+    @staticmethod
+    def _expander_of(batch):
+        """(perms [G, n], degree) when the dataset attached the Exphander permutations to the Batch
+        (``expander_perm`` [G * n] as PyG collates a per-sample [n] attribute, ``expander_degree``), else None."""
+        perm = getattr(batch, "expander_perm", None)
+        if perm is None:
+            return None
+        G = int(batch.batch.max()) + 1
+        deg = getattr(batch, "expander_degree")
+        deg = int(deg[0]) if torch.is_tensor(deg) else int(deg)
+        return perm.view(G, -1), deg
 
     def predict_step(self, batch, batch_idx, dataloader_idx=0):
         return self.prediction_step(batch, batch_idx)
@@ -350,7 +365,7 @@ class GNN_Diffusion(LightningModule):
         """validation_step / test_step, spatial_diffusion.py:775-903,915-: sampling loop, greedy
         assignment of predicted positions to the grid, puzzle / piece accuracy."""
         imgs, _ = self.p_sample_loop(batch.x.shape, batch.patches, batch.edge_index, batch=batch.batch,
-                                     patch_feats=getattr(batch, "patch_feats", None))
+                                     patch_feats=getattr(batch, "patch_feats", None), expander=self._expander_of(batch))
         img = imgs[-1]
         G = int(batch.batch.max()) + 1
         dims = batch.patches_dim.tolist()

@@ -66,6 +66,13 @@ METRICS3D = [
     dict(name="metrics3d_p20", P=20, N=1000, noise=0.02, seed=52),
     dict(name="metrics3d_p2_far", P=2, N=64, noise=1.0, seed=53),
 ]
+# Exphander graphs: generate_random_regular_graph(n, d, default_rng(seed)) (puzzle_dataset.py:115-152)
+EXPANDER = [
+    dict(name="expander_n64_d6", n=64, d=6, seed=61, full=True),
+    dict(name="expander_n36_d7", n=36, d=7, seed=62, full=True),        # odd degree: + the perfect matching
+    dict(name="expander_n900_d90", n=900, d=90, seed=63, full=False),
+    dict(name="expander_n900_d539", n=900, d=539, seed=64, full=False),  # the scripted "60 %"
+]
 # fmt: on
 SCHEDULE_T = [50, 100, 300]
 GOLDEN2_FILE = os.path.join(os.path.dirname(__file__), "golden_v2.npz")
@@ -126,6 +133,14 @@ def build_case(spec, variant="2d"):
     tg = torch.from_numpy(rng.integers(0, spec["steps"], size=len(sizes)))
     t = tg[batch]
     return dict(sd=sd, x=x, t=t, feats=feats, edge_index=edge_index, batch=batch)
+
+
+def edge_checksum(s, r):
+    """Order-dependent and order-independent digests of an edge list (int64 arrays / tensors)."""
+    s, r = np.asarray(s, dtype=np.int64), np.asarray(r, dtype=np.int64)
+    k = np.arange(1, s.size + 1, dtype=np.int64)
+    return np.array([s.size, int(s.sum()), int(r.sum()), int(((s * 7 + r * 13) % 1000003).sum()),
+                     int(((s * 31 + r * 17 + 5) * (k % 8191 + 1) % 1000003).sum())], dtype=np.int64)
 
 
 def metrics3d_inputs(spec):

@@ -11,7 +11,9 @@ like make_golden.py; golden_v1.npz stays as it is).  Stores the reference's OUTP
 * the reference's TorchScript ``greedy_cost_assignment`` (spatial_diffusion.py:179-216) on six position sets
   (6x6 / 12x12 / 30x30 noisy, exact grids = all-zero-distance ties, fewer pieces than cells, duplicated points);
 * the reference's 3D evaluation metrics (model/utils_3d.py ``trans_metrics``, ``rot_metrics`` rmse / geodesic,
-  ``calc_part_acc``) on three seeded pose sets.
+  ``calc_part_acc``) on three seeded pose sets;
+* the reference's ``generate_random_regular_graph`` (dataset/puzzle_dataset.py:115-152) for four (n, d, seed):
+  full edge lists of the small graphs, digests + head / tail of the 900-node ones.
 
 Inputs and weights are regenerated from seeds by cases.py.   Run:  python tests/golden/make_golden_v2.py
 (about two minutes on 8 cores).
@@ -113,6 +115,17 @@ for ms in C.METRICS3D:
     put(ms["name"], "gd_r", ut3d.rot_metrics(pred[:, :4], gt[:, :4], metric="geodesic"))
     put(ms["name"], "part_acc", ut3d.calc_part_acc(pcds, pred[:, 4:], gt[:, 4:], pred[:, :4], gt[:, :4], None))
     print("metrics3d", ms["name"], [float(OUT[f"{ms['name']}/{k}"]) for k in ("rmse_t", "rmse_r", "gd_r", "part_acc")], flush=True)
+
+from ref_import import import_reference_dataset  # noqa: E402
+ds = import_reference_dataset()
+for ex in C.EXPANDER:
+    snd, rcv = ds.generate_random_regular_graph(ex["n"], ex["d"], np.random.default_rng(ex["seed"]))
+    put(ex["name"], "checksum", C.edge_checksum(snd, rcv))
+    put(ex["name"], "head", np.stack([snd[:512], rcv[:512]]))
+    put(ex["name"], "tail", np.stack([snd[-512:], rcv[-512:]]))
+    if ex["full"]:
+        put(ex["name"], "edges", np.stack([snd, rcv]))
+    print("expander", ex["name"], snd.size, flush=True)
 
 np.savez_compressed(C.GOLDEN2_FILE, **OUT)
 print("wrote", C.GOLDEN2_FILE, os.path.getsize(C.GOLDEN2_FILE), "bytes,", len(OUT), "arrays")

@@ -126,6 +126,31 @@ def import_reference():
     return sd2, sd3
 
 
+def import_reference_dataset():
+    """The reference's dataset/puzzle_dataset.py (graph generators: generate_random_regular_graph :115-152) loaded from
+    where it lies, with inert stand-ins for the PyG data / torchvision transform classes it subclasses."""
+    install_stubs()
+
+    class _Cls:
+        def __init__(self, *a, **k):
+            pass
+
+    _mod("torch_geometric.data", Data=_Cls, Dataset=_Cls, Batch=_Cls)
+    _mod("torch_geometric.data.datapipes", functional_transform=lambda *a, **k: (lambda c: c))
+    _mod("torch_geometric.loader", DataLoader=_Cls)
+    _mod("torch_geometric.transforms", BaseTransform=_Cls)
+    _mod("torch_geometric.utils", get_laplacian=_Anything(), to_scipy_sparse_matrix=_Anything(), dense_to_sparse=_Anything())
+    tvt = sys.modules["torchvision.transforms"]
+    tvt.InterpolationMode = _Anything()
+    tvt.RandomResizedCrop = _Cls
+    tvt.RandomHorizontalFlip = _Cls
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_puzzle_dataset", os.path.join(REF, "dataset", "puzzle_dataset.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
 if __name__ == "__main__":
     a, b = import_reference()
     print("imported", a.__file__, b.__file__)

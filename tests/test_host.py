@@ -274,3 +274,60 @@ def test_cache_key_holds_its_tensors_and_sees_in_place_edits():
     assert not key.matches((b,), ("plan",))
     src = open(os.path.join(ROOT, "diffassemble_amd", "model", "backbones", "_denoiser_base.py")).read()
     assert "data_ptr(), tuple(edge_index.shape)" not in src  # the address-only keys are gone
+
+
+@pytest.mark.parametrize("ex", C.EXPANDER, ids=lambda s: s["name"])
+def test_expander_edge_index_matches_reference_generator(ex):
+    """diffassemble_amd.expander.regular_edge_index (closed form from the permutation, torch index arithmetic) emits
+    exactly the edge list of the reference's generate_random_regular_graph for the same numpy generator: same edges in
+    the same order (golden_v2.npz holds the reference's output: everything for the small graphs, digests + head / tail
+    for the 900-node ones)."""
+    from diffassemble_amd import expander
+    g2 = C.load_golden2()
+    perms = expander.draw_permutations(ex["n"], 1, np.random.default_rng(ex["seed"]))
+    ei, batch = expander.regular_edge_index(perms, ex["d"])
+    n = ex["name"]
+    assert ei.shape == (2, ex["n"] * ex["d"]) and batch.shape == (ex["n"],)
+    assert np.array_equal(C.edge_checksum(ei[0].numpy(), ei[1].numpy()), g2[f"{n}/checksum"])
+    assert np.array_equal(ei[:, :512].numpy(), g2[f"{n}/head"]) and np.array_equal(ei[:, -512:].numpy(), g2[f"{n}/tail"])
+    if ex["full"]:
+        assert np.array_equal(ei.numpy(), g2[f"{n}/edges"])
+    # two graphs in one Batch: PyG-collated offsets
+    perms2 = expander.draw_permutations(ex["n"], 2, np.random.default_rng(ex["seed"]))
+    ei2, b2 = expander.regular_edge_index(perms2, ex["d"])
+    assert torch.equal(ei2[:, : ei.shape[1]], ei) and int(ei2[:, ei.shape[1]:].min()) == ex["n"] and b2.tolist() == [0] * ex["n"] + [1] * ex["n"]
+
+
+def test_expander_plan_closed_form_equals_plan_from_edge_list(monkeypatch):
+    """graph_plan.expander_plan (adjacency bits as a closed form of the permutation positions, no edge list) ==
+    build_plan on the reference-ordered edge list of the same graphs: mask, remainder CSR (exophormer virtual edges),
+    padded rows, edge count and -- on demand -- the extended edge list itself; and the sort-free multiplicity split of
+    build_plan keeps duplicated / cross-graph edges on the CSR side."""
+    from diffassemble_amd import expander, graph_plan as GP
+    monkeypatch.setenv("DA_HYBRID", "force")
+    rng = np.random.default_rng(5)
+    perms = expander.draw_permutations(70, 3, rng)
+    for d, V in ((10, 4), (7, 0), (20, 8)):
+        ei, b = expander.regular_edge_index(perms, d)
+        p1 = GP.build_plan(ei, b, V)
+        p2 = GP.expander_plan(perms, d, virt_nodes=V)
+        assert p1.hybrid == 1 and p2.hybrid == 1 and p2._edge_index is None and p1.row_ptr is None
+        for f in ("mask", "mask_ptr", "irr_row_ptr", "irr_col_src", "row_map", "pad_ptr", "graph_ptr"):
+            assert torch.equal(getattr(p1, f), getattr(p2, f)), (d, V, f)
+        assert (p1.n_edges, p1.n_nodes, p1.n_pad) == (p2.n_edges, p2.n_nodes, p2.n_pad)
+        assert torch.equal(p1.edge_index, p2.edge_index)
+        # every regular edge has its bit, and nothing else does
+        stride = int(p1.pad_ptr[1] - p1.pad_ptr[0]) // 8
+        bits = np.unpackbits(p1.mask[: 3 * 70 * stride].numpy().reshape(3, 70, stride), axis=-1, bitorder="little")[:, :, :70]
+        adj = np.zeros((3, 70, 70), dtype=np.uint8)
+        g = (ei[1] // 70).numpy()
+        adj[g, (ei[1] % 70).numpy(), (ei[0] % 70).numpy()] = 1
+        assert np.array_equal(bits, adj)
+    sizes = [70, 130, 45]
+    ei, b = W.collate([W.random_regular_edge_index(n, 10, rng) for n in sizes], sizes)
+    dup = ei[:, :50]
+    cross = torch.tensor([[0, 75], [80, 3]])
+    p = GP.build_plan(torch.cat([ei, dup, cross], 1), b, 0)
+    assert p.hybrid == 1
+    assert p.irr_col_src.numel() == 100 + 2                      # both copies of a duplicated pair + the cross-graph edges
+    assert int(np.unpackbits(p.mask.numpy()).sum()) == ei.shape[1] - 50

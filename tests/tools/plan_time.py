@@ -34,6 +34,20 @@ for G in (1, 32):
     e1 = W.random_regular_edge_index(n, 539 if (n * 539) % 2 == 0 else 540, rng)
     ei = torch.cat([e1 + g * n for g in range(G)], 1)
     timed(f"expander d=540 exophormer V=8 G={G}", ei, batch, 8)
+# Exphander graphs straight from their permutations (no edge list): graph_plan.expander_plan
+from diffassemble_amd import expander  # noqa: E402
+from diffassemble_amd.graph_plan import expander_plan  # noqa: E402
+for G in (1, 32):
+    for d in (90, 539 + 1):
+        perms = expander.draw_permutations(900, G, np.random.default_rng(1)).to(dev)
+        for _ in range(2):
+            expander_plan(perms, d, dev, 8)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(5):
+            p = expander_plan(perms, d, dev, 8)
+        torch.cuda.synchronize()
+        print(f"{'expander_plan d=%d V=8 G=%d' % (d, G):40s} E={p.n_edges:9d} plan {1e3 * (time.perf_counter() - t) / 5:8.2f} ms  hybrid={p.hybrid}")
 n = 144
 e1 = W.dense_edge_index(n, True)
 ei = torch.cat([e1 + g * n for g in range(512)], 1)
