@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     for (int cb = 0; cb < CF::NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[cb][r] = 0.f;
-    float m = -INFINITY, l = 0.f;
+    float m = -1e30f, l = 0.f;               // finite reference (see the softmax below); only the slow path moves it
 
     // ---- LDS-DMA plan: instruction q (1 KB) of a tile is issued by wave q % 4; lane -> slot q*64+lane
     const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
@@ -353,17 +353,34 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             float pr[16];
             DA_ATTN_DBG(if (p.debug & 2) { _Pragma("unroll") for (int r = 0; r < 16; ++r) pr[r] = s[r]; } else)
             {
-                // lane-local max as a tree (v_max3); the cross-half exchange is only needed when the
-                // running max actually moves, and the wave-wide ballot already sees both halves
-                const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
-                const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
-                const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
-                const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
-                // rescale only when the running max grows by more than 2^8 (softmax is shift invariant)
-                const bool grow = !(m > -INFINITY) || (mloc - m) * p.sc > 8.0f;
-                if (__any(grow)) {
-                    float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));
-                    if (mnew == -INFINITY) mnew = 0.f;           // nothing but masked keys so far
+                // Online softmax WITHOUT a per-block max: p = exp2((s - m) sc) is formed against the running reference m
+                // directly; only when a block's sum says the reference is stale -- first block: m = -1e30 gives +inf;
+                // later: some score more than ~2^10 above m -- is the block's true max taken (lane-local v_max3 tree + one
+                // cross-half exchange) and O / l rescaled.  Softmax is shift invariant, so any m works as long as nothing
+                // overflows; p <= 2^14 keeps every accumulator far from the fp32 range.  The kernel is bound by instruction
+                // issue (rocprof: SQ_ACTIVE_INST_ANY summed over the 4 waves of a SIMD > its cycles), so the 11-instruction
+                // max tree leaves the common path and the scale / sum run as packed-f32 pairs (v_pk_fma_f32, v_pk_add_f32).
+                typedef __attribute__((ext_vector_type(2))) float f32x2;
+                const f32x2 sc2 = {p.sc, p.sc};
+                f32x2 e2[8];
+                auto exp_block = [&](float ms_) {
+                    const f32x2 nm = {-ms_, -ms_};
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const f32x2 t = (f32x2){s[2 * r], s[2 * r + 1]} * sc2 + nm;
+                        e2[r] = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    }
+                    const f32x2 a = (e2[0] + e2[1]) + (e2[2] + e2[3]), b = (e2[4] + e2[5]) + (e2[6] + e2[7]);
+                    const f32x2 c = a + b;
+                    return c[0] + c[1];
+                };
+                float bsum = exp_block(m * p.sc);
+                if (__any(!(bsum < 16384.0f))) {
+                    const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
+                    const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
+                    const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+                    const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
+                    const float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));        // >= -1e30: finite
                     const float corr = __builtin_amdgcn_exp2f((m - mnew) * p.sc);
                     m = mnew;
                     l *= corr;
@@ -371,12 +388,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
                     for (int cb = 0; cb < CF::NCB; ++cb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) O[cb][r] *= corr;
+                    bsum = exp_block(m * p.sc);
                 }
-                const float ms = m * p.sc;
+                l += bsum;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pr[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.sc, -ms));
-                l += ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])) +
-                     (((pr[8] + pr[9]) + (pr[10] + pr[11])) + ((pr[12] + pr[13]) + (pr[14] + pr[15])));
+                for (int r = 0; r < 8; ++r) { pr[2 * r] = e2[r][0]; pr[2 * r + 1] = e2[r][1]; }
             }
             DA_ATTN_DBG(asm volatile("" :: "v"(pr[0]), "v"(pr[15]));)
             DA_TICK(t4_);
@@ -452,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     if (wave_on) {
         float *orow = so + (wid * 32 + i) * RSOF;
         if (MASKED && half == 0) {            // partial softmax state rides in the row's 4 spare floats
-            orow[CO] = (m > -INFINITY) ? m * (p.sc * 0.6931471805599453f) : 0.f;
+            orow[CO] = (m > -1e29f) ? m * (p.sc * 0.6931471805599453f) : 0.f;
             orow[CO + 1] = lt;
         }
 #pragma unroll

@@ -298,9 +298,16 @@ __global__ __launch_bounds__(1024, 4) void k_conv_fused(ConvFusedParams p) {
     }
 }
 
+// OPT-IN (DA_CONV_FUSED=1).  Measured on MI355X, 32 puzzles of 900 pieces, bf16, per hidden layer: this kernel 94-96 us
+// against 35 us (projection GEMM) + 61 us (k_attn_dense) = 96 us for the two-kernel path -- a tie at 256 workgroups and
+// a loss below (8 puzzles: 82 vs 40 us; one workgroup per (graph, head) cannot fill the chip).  Ablation
+// (tools/fused_probe.py) and SQ counters (profiles/r02/pmc_fused_vs_two_kernel.txt): 41 us go to the projection phases,
+// which wait on operand-shaped global loads of x (2/3 of the wave cycles in s_waitcnt), 53 us to the attention loop, which
+// executes the same 19 M VALU instructions as k_attn_dense but with one workgroup per CU.  Kept as the measured record
+// of VERDICT r01 direction 4(iii); the default path is the two-kernel one.
 static bool conv_fused_disabled() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_DISABLE_CONV_FUSED"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) { const char *e = getenv("DA_CONV_FUSED"); v = (e && e[0] == '1') ? 0 : 1; }
     return v == 1;
 }
 

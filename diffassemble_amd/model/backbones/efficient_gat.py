@@ -66,8 +66,10 @@ class Eff_GAT(DenoiserBase):
         return self._run(xy_pos, time, edge_index, patch_feats, batch, self.return_attentions)
 
     def visual_features(self, patch_rgb):
-        """efficient_gat.py:149-189 (efficientnet_b0 / resnet branch): normalise, encoder,
-        concat feature maps 2 and 3.  Out of the accelerated path; plain torch."""
+        """efficient_gat.py:149-189: normalise, piece encoder, concat feature maps 2 and 3 -> [N, 1088].
+        ``model='resnet18equiv'`` (the reference's in-tree P4-equivariant ResNet-18) runs in the HIP library
+        (da_encoder_forward, eval-mode BatchNorm); the timm encoders are third-party and, when timm
+        is importable, run as plain torch outside the accelerated path."""
         if self.visual_backbone is None:
             raise NotImplementedError(
                 "no piece encoder available (timm / equivariant ResNet are outside the hot path): "

@@ -307,7 +307,8 @@ def test_two_same_shaped_batches_back_to_back_do_not_share_plan_or_features(dev)
         assert rel(pred, ref) < RTOL32, f"Batch {trial}: training forward used a stale plan"
         outs.append(out.clone())
         del ei, batch, x, feats, out, prev, att, pred                  # Batch i dies before Batch i+1 is moved
-    assert ptrs[0] == ptrs[1], "the allocator did not reuse the addresses: the regression is not exercised"
+    # (with the fix the caches HOLD the keyed tensors, so the allocator can no longer hand Batch 1 the addresses of Batch 0;
+    # tests/test_host.py::test_cache_key_holds_its_tensors_and_sees_in_place_edits pins that property)
     assert rel(outs[0], outs[1]) > 1e-2                                # the two Batches really differ
 
 
@@ -328,7 +329,6 @@ def test_new_patch_feats_same_address_are_restaged_in_the_step_by_step_path(dev)
         out, _ = m.forward_with_feats(x_cpu.to(dev), t.to(dev), None, ei, feats, batch, return_attentions=True)
         assert rel(out, ref) < RTOL32, trial
         del feats
-    assert ptrs[0] == ptrs[1]
     # in-place edit of a live tensor bumps _version: also restaged
     feats = W.make_inputs(144, 4, 1088, 300)[1].to(dev)
     a = m.forward_with_feats(case["x"].to(dev), t.to(dev), None, ei, feats, batch)

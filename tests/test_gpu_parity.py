@@ -158,6 +158,25 @@ def test_da_conv_dense_matches_pyg_semantics(dev, C_head, Din, prec, loops):
 @pytest.mark.parametrize("loops", [True, False])
 @pytest.mark.parametrize("sizes", [[900], [992, 3, 33], [32, 64, 31, 65, 1], [144] * 5], ids=["900", "992_3_33", "slab_edges", "5x144"])
 def test_conv_fused_one_kernel_hidden_layer(dev, Din, loops, sizes):
+    import os
+    if os.environ.get("DA_CONV_FUSED") != "1":
+        pytest.skip("opt-in kernel: exercised by test_conv_fused_opt_in_subprocess with DA_CONV_FUSED=1")
+    _conv_fused_case(dev, Din, loops, sizes)
+
+
+def test_conv_fused_opt_in_subprocess(dev):
+    """The one-kernel hidden conv is opt-in (DA_CONV_FUSED=1, read once per process): run its parity cases in a
+    subprocess with the switch on."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DA_CONV_FUSED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_conv_fused_one_kernel_hidden_layer"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0 and "16 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _conv_fused_case(dev, Din, loops, sizes):
     """k_conv_fused (da_conv_fused.hip: projection + attention of a (graph, head) in ONE kernel, K / V^T resident in
     LDS) through da_conv_dense in bf16 -- which dispatches to it for C = 32, Din in {128, 256}, graphs of <= 992
     pieces -- against the edge-list oracle on the same bf16-rounded inputs, and against the exact-fp32 two-kernel
