@@ -63,7 +63,7 @@ CONFIGS = {
               mean="START_X", G=32, prec="bf16"),
     "3p": dict(name="30x30 dense puzzle (N=900, E=810000 incl. self loops), DDIM eta=0, T=100, START_X, rot+trans c=4, transformer arch",
                variant="2d", arch="transformer", V=0, n=N_PIECES, graph="dense", rotation=True, T=T_STEPS, ratio=1,
-               mean="START_X", G=32, prec="bf16"),
+               mean="START_X", G=64, prec="bf16"),      # 64 puzzles per GPU: +4 % puzzle-steps/s over 32 (measured 24 .. 96)
     "4": dict(name="3D fragments (P=20 per object, D=832, complete graph E=400, SE(3) pose head), DDIM T=300 ratio 10, START_X",
               variant="3d", arch="transformer", V=0, n=20, graph="dense", rotation=True, T=300, ratio=10,
               mean="START_X", G=256, prec="bf16"),

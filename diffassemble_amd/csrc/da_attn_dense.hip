@@ -169,10 +169,14 @@ __device__ __forceinline__ void stc(bf16_t *d, const float (&v)[8]) {
     *(u32x4 *)d = __builtin_bit_cast(u32x4, b);
 }
 
-template <typename T, int C, bool MASKED, int CV>
+// NST = stages of the K / V ring.  An LDS-DMA takes ~2 us from issue to landing under load (measured), longer than a
+// wave spends on one 64-key tile of the C = 32 layers: with two stages (one tile in flight) every tile waited for its own
+// DMA and the kernel ran at the DMA latency (15 tiles x ~2 us per workgroup, 8 workgroups per CU in two rounds = the
+// measured 55-61 us).  NST - 1 tiles are kept in flight instead, waited for with a COUNTED vmcnt.
+template <typename T, int C, bool MASKED, int CV, int NST>
 __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     using CF = Cfg<T, C, CV>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 stages x (K | V)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // NST stages x (K | V)
 
     // XCD-aware remap: hardware places workgroup b on XCD b % 8; give XCD x head x of every graph and
     // walk the query tiles of one (graph, head) consecutively.
@@ -274,16 +278,32 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     }
     DA_ATTN_DBG(unsigned long long c_bar = 0, c_iss = 0, c_qk = 0, c_sm = 0, c_pv = 0;)
     DA_TICK(t_start);
-    issue(0, 0);
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nkt) issue(st, st);
     for (int kt = 0; kt < nkt; ++kt) {
         DA_TICK(t0_);
-        dma_barrier();                         // own DMA landed (vmcnt(0)) + everyone left the other stage
+        // tile kt must have landed; the younger tiles already issued (at most NST - 2 of them) may stay in flight.  Loads
+        // retire in order, so "at most k * nmine of my VMEM operations outstanding" implies tile kt is in LDS; anything
+        // else this wave has pending (MASKED: adjacency words) only makes the wait conservative.
+        {
+            // every wave issues NI / 4 or NI / 4 + 1 DMA instructions per tile: counting NI / 4 per younger tile is exact
+            // for most waves and at worst waits for `younger` instructions more than necessary
+            constexpr int PERW = CF::NI / 4;
+            const int younger = min(nkt - 1 - kt, NST - 2);
+            if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PERW) : "memory");
+            else if (NST >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // raw barrier: __syncthreads() would drain the DMA still in flight (its fence carries vmcnt(0))
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // everyone's share landed + everyone left the slot refilled below
+        }
         DA_TICK(t1_);
-        if (kt + 1 < nkt DA_ATTN_DBG(&& !(p.debug & 1))) issue(kt + 1, (kt + 1) & 1);
+        if (kt + NST - 1 < nkt DA_ATTN_DBG(&& !(p.debug & 1))) issue(kt + NST - 1, (kt + NST - 1) % NST);
         DA_TICK(t2_);
         DA_ATTN_DBG(c_bar += t1_ - t0_; c_iss += t2_ - t1_;)
         if (!wave_on) continue;
-        const unsigned char *stg = smem + (kt & 1) * CF::STAGE;
+        const unsigned char *stg = smem + (kt % NST) * CF::STAGE;
         // MASKED: adjacency words of THIS tile were requested during the previous one; request the next tile's now
         unsigned mw_cur[CF::KB];
         if (MASKED) {
@@ -320,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             DA_TICK(t3_);
             // V fragments of the first channel blocks: issued behind the QK^T chain, they land under the softmax
             u32x2 vlo[CF::ES == 2 ? CF::NCB : 1][2], vhi[CF::ES == 2 ? CF::NCB : 1][2];
-            const unsigned vb = lds0 + (unsigned)((kt & 1) * CF::STAGE + vbase + kb * 32 * CF::RSV);
+            const unsigned vb = lds0 + (unsigned)((kt % NST) * CF::STAGE + vbase + kb * 32 * CF::RSV);
             if (CF::ES == 2) {
                 // only the first two channel blocks now; the rest are fetched two blocks ahead inside the PV
                 // loop: a wave may have 15 LDS operations in flight (lgkmcnt is 4 bits) and the 9 K reads +
@@ -461,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     }
     constexpr int CO = CV;                                        // width of the staged rows (= C unless the value heads are folded)
     constexpr int RSOF = CO + 4;                                  // floats per staged row (16-B aligned, odd # of 16-B slots)
-    static_assert(128 * RSOF * 4 <= 2 * CF::STAGE, "O staging must fit in the K/V ring");
+    static_assert(128 * RSOF * 4 <= NST * CF::STAGE, "O staging must fit in the K/V ring");
     float *so = (float *)smem;
     dma_barrier();                                              // ring no longer read by anyone
     DA_ATTN_DBG(if (p.debug & 16) return;)
@@ -646,18 +666,37 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     DA_ATTN_DBG(if (p.prof && tid == 0) { DA_TICK(t_end_); unsigned long long *o = p.prof + 8 * blockIdx.x; o[0] = t_end_ - t_start; o[1] = c_bar; o[2] = c_iss; o[3] = c_qk; o[4] = c_sm; o[5] = c_pv; o[6] = t_end_ - t_loop_end; o[7] = 1; })
 }
 
-template <typename T, int C, bool MASKED, int CV>
-static int launch_tcm(const AttnDenseParams &p, int nblocks, hipStream_t st) {
+template <typename T, int C, bool MASKED, int CV, int NST>
+static int launch_tcmn(const AttnDenseParams &p, int nblocks, hipStream_t st) {
     using CF = Cfg<T, C, CV>;
-    const int lds = 2 * CF::STAGE;
+    const int lds = NST * CF::STAGE;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C, MASKED, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C, MASKED, CV, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    k_attn_dense<T, C, MASKED, CV><<<nblocks, 256, lds, st>>>(p);
+    k_attn_dense<T, C, MASKED, CV, NST><<<nblocks, 256, lds, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
+}
+// ring depth per instance: the C = 32 layers (9 KB stages, 4 workgroups per CU) take four stages; the C = 144 layer's
+// stages are 23 - 47 KB, where a third stage costs a resident workgroup: two by default, DA_ATTN_STAGES=3 for A/B runs of
+// the folded bf16 instance
+static int attn_stages_env() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_ATTN_STAGES"); v = e ? atoi(e) : 0; }
+    return v;
+}
+template <typename T, int C, bool MASKED, int CV>
+static int launch_tcm(const AttnDenseParams &p, int nblocks, hipStream_t st) {
+    if constexpr (C == 32) {
+        return launch_tcmn<T, C, MASKED, CV, 4>(p, nblocks, st);
+    } else if constexpr (sizeof(T) == 2 && CV == 32 && !MASKED) {
+        if (attn_stages_env() == 3) return launch_tcmn<T, C, MASKED, CV, 3>(p, nblocks, st);
+        return launch_tcmn<T, C, MASKED, CV, 2>(p, nblocks, st);
+    } else {
+        return launch_tcmn<T, C, MASKED, CV, 2>(p, nblocks, st);
+    }
 }
 template <typename T, int C>
 static int launch_tc(const AttnDenseParams &p, int nblocks, hipStream_t st) {
