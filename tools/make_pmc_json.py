@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""profiles/r02/r02_pmc_traffic_<tag>.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, summarised per kernel by
+profiles/rocpd_pmc.py) -> profiles/r02/pmc_traffic.json, the per-kernel-CLASS bytes-per-launch table bench.py attaches to
+its roofline entries.  Values stay in the counters' KiB; bench.py applies the gfx950 correction (FETCH_SIZE x 2,
+MI355X_MICROARCH.md) when it converts."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+CLASS = [  # (regex on the kernel name, class)
+    (r"k_attn_dense<unsigned short, 32,", "attn_hidden"), (r"k_attn_dense<unsigned short, 144,", "attn_last"),
+    (r"k_attn_csr<unsigned short, 4>", "attn_hidden"), (r"k_attn_csr<unsigned short, 18>", "attn_last"),
+    (r"k_attn_csr_cont", "attn_hidden"),
+    (r"k_gemm_astat_rs<unsigned short, true", "linear_qkvs"), (r"k_gemm_wreg<256, true", "linear_qkvs"),
+    (r"k_gemm_wreg<256, false", "linear_qkvs"), (r"k_embed_pos_time", "embed"), (r"k_head_fold", "head"),
+]
+# tag -> (bench config key, puzzles per GPU, launches of the class per denoising step)
+RUNS = {"headline": ("3p", 64, None), "config3_d539": ("3", 32, False), "config3_d90": ("3_d90", 32, False),
+        "config3_d539_csr_only": ("3_csr", 32, True)}
+
+
+def parse(path, want_csr):
+    """want_csr: keep ONLY (True) / drop (False) the pure edge-list kernels k_attn_csr<T, EPL> -- in a hybrid run they
+    belong to bench.py's `sparse_path` comparison leg, not to the timed loop."""
+    per = {}
+    for line in open(path):
+        m = re.match(r"(.{56}) (FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)", line)
+        if not m:
+            continue
+        name, ctr, n, avg = m.group(1), m.group(2), int(m.group(3)), float(m.group(4))
+        is_csr = bool(re.search(r"k_attn_csr<unsigned short, \d+>", name))
+        if want_csr is not None and is_csr != want_csr and ("k_attn" in name):
+            continue
+        for rx, cls in CLASS:
+            if re.search(rx, name):
+                d = per.setdefault(cls, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+                d[ctr][0] += avg * n
+                d[ctr][1] += n
+                break
+    return {c: {"fetch_kib": v["FETCH_SIZE"][0] / max(v["FETCH_SIZE"][1], 1), "write_kib": v["WRITE_SIZE"][0] / max(v["WRITE_SIZE"][1], 1),
+                "launches": v["FETCH_SIZE"][1]} for c, v in per.items()}
+
+
+out = {"_comment": "KiB per launch, averaged over the launches of a kernel class in `python bench.py --steps 20 --warmup 2` "
+                   "(tools/collect_profiles.sh); FETCH_SIZE is NOT yet doubled here"}
+for tag, (key, G, want_csr) in RUNS.items():
+    p = os.path.join(ROOT, "profiles", "r02", f"r02_pmc_traffic_{tag}.txt")
+    if os.path.exists(p):
+        out.setdefault(key, {}).setdefault("bf16", {})[str(G)] = parse(p, want_csr)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
