@@ -178,6 +178,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     using CF = Cfg<T, C, CV>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // NST stages x (K | V)
 
+    // MASKED: the adjacency bits enter as the INITIAL VALUE of the S^T accumulator -- 0 for an edge, -inf for no edge -- so
+    // masking costs no VALU pass over the scores (the bit test + select pair per score doubled the softmax's instruction
+    // count: 128 vs 54 us per C = 32 layer).  The 16 floats a lane needs for a 32-key block come from a 16-entry table in
+    // LDS, one 16-byte read per nibble of its 16-bit mask word: entry i = {bit0 ? 0 : -inf, ..., bit3 ? 0 : -inf}.
+    float *mlut = (float *)(smem + NST * CF::STAGE);
+    if (MASKED && threadIdx.x < 64) {
+        const int e = threadIdx.x >> 2, b = threadIdx.x & 3;
+        mlut[threadIdx.x] = ((e >> b) & 1) ? 0.f : -INFINITY;
+    }
+    // (visible to every wave after the first barrier of the tile loop)
+
     // XCD-aware remap: hardware places workgroup b on XCD b % 8; give XCD x head x of every graph and
     // walk the query tiles of one (graph, head) consecutively.
     const int bid = blockIdx.x;
@@ -329,8 +340,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + koff + kb * 32 * CF::RS + ch * 32);
             __builtin_amdgcn_sched_barrier(0);       // keep the K read batch ahead of the MFMA chain
             f32x16 s;
+            if (MASKED) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 b4 = *(const f32x4 *)((const unsigned char *)mlut + (((mw >> (4 * j)) & 15u) << 4));
+                    s[4 * j] = b4[0]; s[4 * j + 1] = b4[1]; s[4 * j + 2] = b4[2]; s[4 * j + 3] = b4[3];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            }
             DA_ATTN_DBG(if (!(p.debug & 8)))
             {
 #pragma unroll
@@ -357,10 +376,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             // this lane now holds keys key0 + 16*half + r, r = 0..15, of query qidx.
             // mask padded keys (last tile) and the diagonal (graphs without self loops)
             const int kbase = key0 + 16 * half;
-            if (MASKED) {                       // only the edges of the graph (bits beyond n_g are 0)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (!((mw >> r) & 1u)) s[r] = -INFINITY;
+            if (MASKED) {                       // non-edges already sit at -inf (accumulator initial value; bits beyond n_g are 0)
             } else {
                 const bool tail = key0 + 32 > n_g;
                 const bool diag = p.nodiag && key0 < q0 + 32 && key0 + 32 > q0;
@@ -669,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
 template <typename T, int C, bool MASKED, int CV, int NST>
 static int launch_tcmn(const AttnDenseParams &p, int nblocks, hipStream_t st) {
     using CF = Cfg<T, C, CV>;
-    const int lds = NST * CF::STAGE;
+    const int lds = NST * CF::STAGE + (MASKED ? 256 : 0);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C, MASKED, CV, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

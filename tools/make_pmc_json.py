@@ -17,8 +17,8 @@ CLASS = [  # (regex on the kernel name, class)
     (r"k_gemm_wreg<256, false", "linear_qkvs"), (r"k_embed_pos_time", "embed"), (r"k_head_fold", "head"),
 ]
 # tag -> (bench config key, puzzles per GPU, launches of the class per denoising step)
-RUNS = {"headline": ("3p", 64, None), "config3_d539": ("3", 32, False), "config3_d90": ("3_d90", 32, False),
-        "config3_d539_csr_only": ("3_csr", 32, True)}
+RUNS = {"headline": ("3p", 64, None), "config3_d539": ("3_d539", 32, False), "config3_d90": ("3_d90", 32, False),
+        "config3_d539_csr_only": ("3_d539_csr", 32, True), "config3_d90_csr_only": ("3_d90_csr", 32, True)}
 
 
 def parse(path, want_csr):
