@@ -600,7 +600,7 @@ def sample_bench(args, world, rank, dev):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
     assert torch.isfinite(x_final).all(), "non-finite poses"
@@ -718,11 +718,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         assert world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    # BENCH_DIST_BACKEND=gloo lets several ranks share one GPU (a 1-GPU box can then exercise the N > 1 code path; the
+    # numbers of such a run mean nothing).  Default: one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.mode == "train":
         return train_bench(args, world, rank, dev)

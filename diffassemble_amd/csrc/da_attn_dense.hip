@@ -706,6 +706,8 @@ static int attn_stages_env() {
 template <typename T, int C, bool MASKED, int CV>
 static int launch_tcm(const AttnDenseParams &p, int nblocks, hipStream_t st) {
     if constexpr (C == 32) {
+        // (tried: three stages under a 96-VGPR budget = five workgroups per CU instead of four: 25 spilled registers, 184 vs
+        // 167 us for the three hidden layers)
         return launch_tcmn<T, C, MASKED, CV, 4>(p, nblocks, st);
     } else if constexpr (sizeof(T) == 2 && CV == 32 && !MASKED) {
         if (attn_stages_env() == 3) return launch_tcmn<T, C, MASKED, CV, 3>(p, nblocks, st);

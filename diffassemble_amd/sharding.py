@@ -50,6 +50,8 @@ def max_over_ranks(seconds, device=None):
     """Job time = slowest rank (bench contract)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(seconds)
+    if dist.get_backend() != "nccl":
+        device = "cpu"                 # gloo (tests, several ranks on one GPU): reduce on the host
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t)
