@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -75,6 +75,17 @@ class DaEncoderWeights(C.Structure):
     ]
 
 
+PCD_STAGES, PCD_K = 3, 20
+
+
+class DaPcdEncoderWeights(C.Structure):
+    _fields_ = [
+        ("feat_dim", C.c_int32), ("reserved0", C.c_int32),
+        ("premap", _fp * PCD_STAGES), ("bn_a", _fp * PCD_STAGES), ("conv_b", _fp * PCD_STAGES),
+        ("conv6", _fp), ("linear0", _fp),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/diffassemble_hip.h declares
 PROTOTYPES = {
     "da_abi_version": (C.c_int, []),
@@ -107,6 +118,11 @@ PROTOTYPES = {
     "da_encoder_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "da_encoder_forward": (C.c_int, [C.c_int, C.POINTER(DaEncoderWeights), C.c_int, _fp, _fp, C.c_int, _fp, C.c_size_t,
                                      C.c_int, C.c_int, _fp]),
+    "da_pcd_encoder_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "da_pcd_encoder_forward": (C.c_int, [C.POINTER(DaPcdEncoderWeights), C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp,
+                                         C.c_size_t, C.c_int, _fp]),
+    "da_knn": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp]),
+    "da_nearest_sq": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     "da_train_backward": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp,
                                     _fp, C.c_size_t, _fp]),
 }

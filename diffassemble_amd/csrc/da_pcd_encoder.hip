@@ -1,0 +1,460 @@
+// 3D piece encoder: the reference's vector-neuron DGCNN over fragment point clouds, inference
+// (eval-mode BatchNorm), plus the nearest-neighbour distances of the part-accuracy metric.
+//
+// Replaces (paths under /root/reference/puzzle_diff/model/):
+//   backbones/vnn/vn_dgcnn.py:34-74     VN_DGCNN.forward: 3 x (kNN graph feature -> VNLinearLeakyReLU [x2] -> mean over
+//                                       the 20 neighbours), cat -> conv6 -> mean over points -> [P, 768] (or linear0, inv)
+//   backbones/vnn/vn_dgcnn.py:84-120    get_graph_feature / knn: a dense [N, N] pairwise matrix + topk(20) per cloud,
+//                                       then a [P, 2C, 3, N, 20] gather (device hard-coded to 'cuda', :94)
+//   backbones/vnn/vn_layers.py:50-91    VNLinearLeakyReLU (map_to_feat, VNBatchNorm :133-154, map_to_dir, projection)
+//   chamfer_distance.py:148-149         pytorch3d knn_points(K = 1) both ways (utils_3d.py:1089-1129 calc_part_acc)
+// The reference materialises the [P, N, N] distance matrix, the [P, 2C, 3, N, 20] edge tensor and ~10 elementwise
+// temporaries of that size per layer (fp32; 20 x 42 x 3 floats per point and layer).  Here:
+//   * k_pcd_knn keeps a 32-query x N slab of the distance matrix in LDS and selects the 20 nearest per query by 20
+//     wave-wide arg-max rounds: the matrix never reaches HBM, only the int32 neighbour lists do;
+//   * the first layer of a stage is linear in cat(x_j - x_i, x_i), so it is evaluated PER POINT once
+//     (k_pcd_premap: A = W[:, :C] x, U = (W[:, C:] - W[:, :C]) x, for the feature and the direction maps) and an edge
+//     costs two vector adds: p = A_j + U_i.  20x fewer multiplies than the reference's per-edge matmul;
+//   * k_pcd_edge (one thread per point) walks the 20 neighbours, applies BatchNorm-of-the-norm + the vector leaky
+//     projection, the stage's second VN layer (weights through scalar loads) and the mean over neighbours in registers;
+//   * k_pcd_conv6 fuses the concat, conv6, its activation and the mean over points (wave reduction -> per-block
+//     partials, summed in a fixed order: deterministic).
+// All arithmetic is fp32 on the vector ALU: the neighbour selection is discrete, and the whole encoder runs once per
+// sampling loop (spatial_diffusion_3d_test_double_diffusion.py:700), not per step.
+#include <float.h>
+
+#include "da_internal.h"
+
+namespace da {
+
+constexpr int KNN = DA_PCD_K, VC = DA_PCD_C, VROW = DA_PCD_ROW, V3 = VC * 3;   // 20 neighbours, 21 channels, 64-float rows
+constexpr float VN_EPS = 1e-6f;                                               // vn_layers.py:11
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// -------------------------------------------------------------------------------------------------------------
+// Wave-wide maximum through DPP (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast15 / row_bcast31): no LDS
+// round trips.  Every lane returns the maximum of the 64 inputs.
+__device__ __forceinline__ float wave_max(float v) {
+#define DA_DPP_MAX(ctrl, rmask)                                                                                          \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false)))
+    DA_DPP_MAX(0x111, 0xf);
+    DA_DPP_MAX(0x112, 0xf);
+    DA_DPP_MAX(0x114, 0xf);
+    DA_DPP_MAX(0x118, 0xf);
+    DA_DPP_MAX(0x142, 0xa);
+    DA_DPP_MAX(0x143, 0xc);
+#undef DA_DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// The k largest scores of one LDS row (Npad = 64 NR entries at most), k <= 64, by k rounds of a wave-wide arg-max over
+// register-resident scores (lane l holds entries l, l + 64, ...).  Ties go to the lower index.  Lane t returns the
+// index of rank t.
+template <int NR>
+__device__ __forceinline__ int select_topk(const float *row, int Npad, int k, int lane) {
+    float v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = r * 64 < Npad ? row[r * 64 + lane] : -INFINITY;
+    int res = 0;
+    for (int t = 0; t < k; ++t) {
+        float best = v[0];
+#pragma unroll
+        for (int r = 1; r < NR; ++r) best = fmaxf(best, v[r]);
+        const float wmax = wave_max(best);
+        unsigned long long tied = __ballot(best == wmax);
+        int wl = __builtin_ctzll(tied);
+        if (tied & (tied - 1)) {                       // several lanes hold the maximum: the lowest INDEX wins
+            int br = 0;
+#pragma unroll
+            for (int r = NR - 1; r >= 0; --r) br = v[r] == wmax ? r : br;
+            const int bj = br * 64 + lane;
+            int wbj = __builtin_amdgcn_readlane(bj, wl);
+            for (tied &= tied - 1; tied; tied &= tied - 1) {
+                const int l2 = __builtin_ctzll(tied), b2 = __builtin_amdgcn_readlane(bj, l2);
+                if (b2 < wbj) { wbj = b2; wl = l2; }
+            }
+        }
+        bool done = lane != wl;
+        int wr = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bool hit = !done && v[r] == wmax;
+            wr = hit ? r : wr;
+            v[r] = hit ? -INFINITY : v[r];
+            done = done || hit;
+        }
+        const int wj = __builtin_amdgcn_readlane(wr, wl) * 64 + wl;
+        res = lane == t ? wj : res;
+    }
+    return res;
+}
+
+// Same selection for rows that do not fit the registers: the scores stay in LDS, the winner is overwritten.
+__device__ __forceinline__ int select_topk_lds(volatile float *row, int Npad, int k, int lane) {
+    int res = 0;
+    for (int t = 0; t < k; ++t) {
+        float best = -INFINITY;
+        int bj = lane;
+        for (int j = lane; j < Npad; j += 64) {
+            const float x = row[j];
+            if (x > best) { best = x; bj = j; }
+        }
+        const float wmax = wave_max(best);
+        unsigned long long tied = __ballot(best == wmax);
+        int wl = __builtin_ctzll(tied), wbj = __builtin_amdgcn_readlane(bj, wl);
+        for (tied &= tied - 1; tied; tied &= tied - 1) {
+            const int l2 = __builtin_ctzll(tied), b2 = __builtin_amdgcn_readlane(bj, l2);
+            if (b2 < wbj) { wbj = b2; wl = l2; }
+        }
+        if (lane == wl) row[wbj] = -INFINITY;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        res = lane == t ? wbj : res;
+    }
+    return res;
+}
+
+// k nearest neighbours (self included) in an F-dimensional feature space, per cloud.
+// grid (ceil(N / QB), clouds), 256 threads.  LDS: the QB squared query norms and QB x Npad scores.
+// score(i, j) = -|xi|^2 + 2 xi.xj - |xj|^2, the reference's formula (vn_dgcnn.py:115-117); the k LARGEST are kept,
+// in decreasing order (topk), ties broken towards the lower index.  Non-finite scores rank last.
+template <int F>
+__global__ __launch_bounds__(256) void k_pcd_knn(const float *__restrict__ X, int ldx, int N, int QB, int Npad, int k,
+                                                 int32_t *__restrict__ idx) {
+    extern __shared__ float smem[];
+    float *qxx = smem, *score = qxx + ((QB + 3) & ~3);
+    const int cloud = blockIdx.y, q0 = blockIdx.x * QB, tid = threadIdx.x;
+    const float *Xc = X + (size_t)cloud * N * ldx;
+    if (tid < QB) {
+        const float *qr = Xc + (size_t)min(q0 + tid, N - 1) * ldx;
+        float s = 0.f;
+        for (int f = 0; f < (F == 3 ? 3 : F); ++f) s += qr[f] * qr[f];
+        qxx[tid] = s;
+    }
+    __syncthreads();
+    // Scores of this thread's candidates against the block's queries.  A query row is wave-uniform: it comes through
+    // the scalar cache into SGPRs (no LDS traffic), the candidate row sits in VGPRs, the dot product is packed fp32 FMAs.
+    for (int j = tid; j < Npad; j += 256) {
+        if (j < N) {
+            if constexpr (F == 64) {
+                f32x2 c[32];
+#pragma unroll
+                for (int f = 0; f < 32; f += 2) {
+                    const float4 v = *(const float4 *)(Xc + (size_t)j * ldx + 2 * f);
+                    c[f] = f32x2{v.x, v.y}; c[f + 1] = f32x2{v.z, v.w};
+                }
+                f32x2 xx2 = {0.f, 0.f};
+#pragma unroll
+                for (int f = 0; f < 32; ++f) xx2 = __builtin_elementwise_fma(c[f], c[f], xx2);
+                const float xxj = xx2.x + xx2.y;
+#pragma unroll 2
+                for (int q = 0; q < QB; ++q) {
+                    const f32x2 *qr = (const f32x2 *)(Xc + (size_t)min(q0 + q, N - 1) * ldx);
+                    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+                    for (int f = 0; f < 32; f += 2) {
+                        a0 = __builtin_elementwise_fma(qr[f], c[f], a0);
+                        a1 = __builtin_elementwise_fma(qr[f + 1], c[f + 1], a1);
+                    }
+                    const float dot = (a0.x + a0.y) + (a1.x + a1.y);
+                    const float sc = (-qxx[q] - (-2.f * dot)) - xxj;
+                    score[q * Npad + j] = fabsf(sc) <= FLT_MAX ? sc : -FLT_MAX;  // NaN / inf rank after every finite score
+                }
+            } else {
+                const float c0 = Xc[(size_t)j * ldx], c1 = Xc[(size_t)j * ldx + 1], c2 = Xc[(size_t)j * ldx + 2];
+                const float xxj = c0 * c0 + c1 * c1 + c2 * c2;
+                for (int q = 0; q < QB; ++q) {
+                    const float *qr = Xc + (size_t)min(q0 + q, N - 1) * ldx;
+                    const float dot = qr[0] * c0 + qr[1] * c1 + qr[2] * c2;
+                    const float sc = (-qxx[q] - (-2.f * dot)) - xxj;
+                    score[q * Npad + j] = fabsf(sc) <= FLT_MAX ? sc : -FLT_MAX;
+                }
+            }
+        } else {
+            for (int q = 0; q < QB; ++q) score[q * Npad + j] = -INFINITY;          // padding: never before a real point
+        }
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int q = wave; q < QB && q0 + q < N; q += 4) {
+        float *row = score + q * Npad;
+        int r;
+        if (Npad <= 256) r = select_topk<4>(row, Npad, k, lane);
+        else if (Npad <= 512) r = select_topk<8>(row, Npad, k, lane);
+        else if (Npad <= 1024) r = select_topk<16>(row, Npad, k, lane);
+        else r = select_topk_lds(row, Npad, k, lane);
+        if (lane < k) idx[((size_t)cloud * N + q0 + q) * k + lane] = min(r, N - 1);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Per-point maps of a stage's first VN layer.  X row: C channels x 3 (ldx floats per point).  T row (256 floats):
+// [A | Ad | U | Ud], 64-float segments of 21 x 3 values: A = Wf[:, :C] x, Ad = Wd[:, :C] x, U = (Wf[:, C:] - Wf[:, :C]) x,
+// Ud likewise.  Wm = [4][21][C] holds the four maps (host-packed).  One thread per point.
+template <int C>
+__global__ __launch_bounds__(256) void k_pcd_premap(const float *__restrict__ X, int ldx, const float *__restrict__ Wm,
+                                                    long long total, float *__restrict__ T) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    float x[C * 3];
+#pragma unroll
+    for (int e = 0; e < C * 3; ++e) x[e] = X[p * ldx + e];
+    float *t = T + p * 4 * VROW;
+    for (int m = 0; m < 4; ++m) {
+        for (int o = 0; o < VC; ++o) {
+            const float *w = Wm + (m * VC + o) * C;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float wv = w[c];
+                a0 += wv * x[c * 3]; a1 += wv * x[c * 3 + 1]; a2 += wv * x[c * 3 + 2];
+            }
+            t[m * VROW + o * 3] = a0; t[m * VROW + o * 3 + 1] = a1; t[m * VROW + o * 3 + 2] = a2;
+        }
+        t[m * VROW + V3] = 0.f;
+    }
+}
+
+// VNBatchNorm on the norm (eval: norm * scale + shift) + the vector leaky projection, vn_layers.py:80-91.
+__device__ __forceinline__ void vn_act(float &p0, float &p1, float &p2, float d0, float d1, float d2, float scale, float shift) {
+    const float norm = sqrtf(p0 * p0 + p1 * p1 + p2 * p2) + VN_EPS;
+    const float f = (norm * scale + shift) / norm;
+    p0 *= f; p1 *= f; p2 *= f;
+    const float dot = p0 * d0 + p1 * d1 + p2 * d2;
+    float q0 = p0, q1 = p1, q2 = p2;
+    if (dot < 0.f) {
+        const float c = dot / (d0 * d0 + d1 * d1 + d2 * d2 + VN_EPS);
+        q0 -= c * d0; q1 -= c * d1; q2 -= c * d2;
+    }
+    p0 = 0.2f * p0 + 0.8f * q0; p1 = 0.2f * p1 + 0.8f * q1; p2 = 0.2f * p2 + 0.8f * q2;
+}
+
+// One stage's edge work: for point i and each neighbour j: h = act(A_j + U_i; Ad_j + Ud_i); optionally the second
+// VN layer (21 -> 21); mean over the k neighbours -> Xout row (64 floats, 63 used, pad = 0).  One thread per point.
+// wb = [2][21][21] (feature, direction maps) then [2][21] (scale, shift) of the second layer.
+template <bool HAS_B>
+__global__ __launch_bounds__(128) void k_pcd_edge(const float *__restrict__ T, const int32_t *__restrict__ idx,
+                                                  const float *__restrict__ bn_a, const float *__restrict__ wb, int N,
+                                                  long long total, float *__restrict__ Xout) {
+    const long long p = (long long)blockIdx.x * 128 + threadIdx.x;
+    if (p >= total) return;
+    const long long base = p / N * N;
+    float u[V3], ud[V3], acc[V3];
+#pragma unroll
+    for (int e = 0; e < V3; ++e) { u[e] = T[p * 4 * VROW + 2 * VROW + e]; ud[e] = T[p * 4 * VROW + 3 * VROW + e]; acc[e] = 0.f; }
+#pragma unroll 1
+    for (int r = 0; r < KNN; ++r) {
+        const int j = idx[p * KNN + r];
+        const float *tj = T + (base + j) * 4 * VROW;
+        float h[V3];
+#pragma unroll
+        for (int c = 0; c < VC; ++c) {
+            float p0 = tj[c * 3] + u[c * 3], p1 = tj[c * 3 + 1] + u[c * 3 + 1], p2 = tj[c * 3 + 2] + u[c * 3 + 2];
+            const float d0 = tj[VROW + c * 3] + ud[c * 3], d1 = tj[VROW + c * 3 + 1] + ud[c * 3 + 1], d2 = tj[VROW + c * 3 + 2] + ud[c * 3 + 2];
+            vn_act(p0, p1, p2, d0, d1, d2, bn_a[c], bn_a[VC + c]);
+            h[c * 3] = p0; h[c * 3 + 1] = p1; h[c * 3 + 2] = p2;
+        }
+        if constexpr (HAS_B) {
+#pragma unroll
+            for (int o = 0; o < VC; ++o) {
+                float p0 = 0.f, p1 = 0.f, p2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < VC; ++c) {
+                    const float wf = wb[o * VC + c], wd = wb[VC * VC + o * VC + c];
+                    p0 += wf * h[c * 3]; p1 += wf * h[c * 3 + 1]; p2 += wf * h[c * 3 + 2];
+                    d0 += wd * h[c * 3]; d1 += wd * h[c * 3 + 1]; d2 += wd * h[c * 3 + 2];
+                }
+                vn_act(p0, p1, p2, d0, d1, d2, wb[2 * VC * VC + o], wb[2 * VC * VC + VC + o]);
+                acc[o * 3] += p0; acc[o * 3 + 1] += p1; acc[o * 3 + 2] += p2;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V3; ++e) acc[e] += h[e];
+        }
+    }
+    float *xo = Xout + p * VROW;
+#pragma unroll
+    for (int e = 0; e < V3; ++e) xo[e] = acc[e] / (float)KNN;
+    xo[V3] = 0.f;
+}
+
+// conv6 (63 -> feat channels, ONE shared direction) over cat(x1, x2, x3), its activation, and the sum over the
+// block's points.  w6 = [feat][63] feature map, [63] direction map, [2][feat] scale / shift.
+// grid (ceil(N / 256), clouds); partial[cloud][block][feat * 3].
+__global__ __launch_bounds__(256) void k_pcd_conv6(const float *__restrict__ X1, const float *__restrict__ X2,
+                                                   const float *__restrict__ X3, const float *__restrict__ w6, int feat,
+                                                   int N, float *__restrict__ partial) {
+    __shared__ float red[4][3 * 256];
+    const int cloud = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = blockIdx.x * 256 + tid;
+    const bool on = i < N;
+    const long long p = (long long)cloud * N + min(i, N - 1);
+    float f[3 * V3];
+#pragma unroll
+    for (int e = 0; e < V3; ++e) { f[e] = X1[p * VROW + e]; f[V3 + e] = X2[p * VROW + e]; f[2 * V3 + e] = X3[p * VROW + e]; }
+    const float *wd = w6 + (size_t)feat * V3, *sc = wd + V3, *sh = sc + feat;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < V3; ++c) { const float w = wd[c]; d0 += w * f[c * 3]; d1 += w * f[c * 3 + 1]; d2 += w * f[c * 3 + 2]; }
+#pragma unroll 1
+    for (int o = 0; o < feat; ++o) {
+        const float *w = w6 + (size_t)o * V3;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < V3; ++c) { const float wv = w[c]; p0 += wv * f[c * 3]; p1 += wv * f[c * 3 + 1]; p2 += wv * f[c * 3 + 2]; }
+        vn_act(p0, p1, p2, d0, d1, d2, sc[o], sh[o]);
+        if (!on) p0 = p1 = p2 = 0.f;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) { p0 += __shfl_xor(p0, off); p1 += __shfl_xor(p1, off); p2 += __shfl_xor(p2, off); }
+        if (lane == 0) { red[wave][o * 3] = p0; red[wave][o * 3 + 1] = p1; red[wave][o * 3 + 2] = p2; }
+    }
+    __syncthreads();
+    float *dst = partial + ((size_t)cloud * gridDim.x + blockIdx.x) * feat * 3;
+    for (int e = tid; e < feat * 3; e += 256) dst[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// Mean over points (fixed-order sum of the block partials), then vn_dgcnn.py:62-74: cat(x, mean(x)) pooled over the
+// points is the pooled map twice -> out[cloud][(c, k)] for c < 2 feat;  inv: mean over the 2 feat channels of
+// linear0(x[c, :]) = linear0(mean_c x[c, :]) -> out[cloud][2 feat].
+__global__ __launch_bounds__(256) void k_pcd_final(const float *__restrict__ partial, int nblk, int feat, int N,
+                                                   const float *__restrict__ lin0, int inv, float *__restrict__ out, int ldo) {
+    __shared__ float m[3 * 256];
+    __shared__ float m3[3];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < feat * 3; e += 256) {
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += partial[((size_t)cloud * nblk + b) * feat * 3 + e];
+        m[e] = s / (float)N;
+    }
+    __syncthreads();
+    float *o = out + (size_t)cloud * ldo;
+    if (!inv) {
+        for (int e = tid; e < feat * 3; e += 256) { o[e] = m[e]; o[feat * 3 + e] = m[e]; }
+        return;
+    }
+    if (tid < 3) {
+        float s = 0.f;
+        for (int c = 0; c < feat; ++c) s += m[c * 3 + tid];
+        m3[tid] = (s + s) / (float)(2 * feat);
+    }
+    __syncthreads();
+    const float *b0 = lin0 + (size_t)2 * feat * 3;
+    for (int e = tid; e < 2 * feat; e += 256) o[e] = lin0[e * 3] * m3[0] + lin0[e * 3 + 1] * m3[1] + lin0[e * 3 + 2] * m3[2] + b0[e];
+}
+
+// For every point of a: the squared distance to its nearest point of b (same cloud index).  grid (ceil(N/256), clouds).
+__global__ __launch_bounds__(256) void k_nearest_sq(const float *__restrict__ a, const float *__restrict__ b, int N, int M,
+                                                    float *__restrict__ out) {
+    __shared__ float tile[3 * 1024];
+    const int cloud = blockIdx.y, tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    const float *ap = a + ((size_t)cloud * N + min(i, N - 1)) * 3;
+    const float ax = ap[0], ay = ap[1], az = ap[2];
+    float best = FLT_MAX;
+    for (int m0 = 0; m0 < M; m0 += 1024) {
+        const int cnt = min(1024, M - m0);
+        __syncthreads();
+        for (int e = tid; e < cnt * 3; e += 256) tile[e] = b[((size_t)cloud * M + m0) * 3 + e];
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const float dx = ax - tile[j * 3], dy = ay - tile[j * 3 + 1], dz = az - tile[j * 3 + 2];
+            best = fminf(best, dx * dx + dy * dy + dz * dz);
+        }
+    }
+    if (i < N) out[(size_t)cloud * N + i] = best;
+}
+
+static int knn_launch(int clouds, int N, int dim, const float *x, int ldx, int k, int32_t *idx, hipStream_t st) {
+    const int F = dim <= 3 ? 3 : 64;
+    const int Npad = (N + 63) & ~63;
+    int QB = 32;
+    auto bytes = [&](int qb) { return (size_t)(((qb + 3) & ~3) + (size_t)qb * Npad) * sizeof(float); };
+    while (QB > 1 && bytes(QB) > 64 * 1024) QB >>= 1;          // two blocks per CU
+    DA_REQUIRE(bytes(QB) <= 160 * 1024 - 512, "kNN: %d points per cloud do not fit the LDS slab", N);
+    const dim3 grid((N + QB - 1) / QB, clouds);
+    if (F == 3) {
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(QB)));
+        k_pcd_knn<3><<<grid, 256, bytes(QB), st>>>(x, ldx, N, QB, Npad, k, idx);
+    } else {
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(QB)));
+        k_pcd_knn<64><<<grid, 256, bytes(QB), st>>>(x, ldx, N, QB, Npad, k, idx);
+    }
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace da
+
+using namespace da;
+
+extern "C" {
+
+int da_knn(int n_clouds, int n_points, int dim, const float *x, int ldx, int k, int32_t *idx, void *stream) {
+    DA_REQUIRE(x && idx, "da_knn: null argument");
+    DA_REQUIRE(n_clouds > 0 && n_points >= k && k > 0 && k <= 64, "da_knn: need n_points >= k, 0 < k <= 64 (got %d, %d)", n_points, k);
+    DA_REQUIRE(dim == 3 ? ldx >= 3 : (dim > 3 && dim <= 64 && ldx == 64), "da_knn: dim 3 (ldx >= 3) or 4..64 with zero-padded 64-float rows");
+    return knn_launch(n_clouds, n_points, dim, x, ldx, k, idx, (hipStream_t)stream);
+}
+
+int da_nearest_sq(int n_clouds, int n, int m, const float *a, const float *b, float *d_ab, float *d_ba, void *stream) {
+    DA_REQUIRE(a && b && (d_ab || d_ba), "da_nearest_sq: null argument");
+    DA_REQUIRE(n_clouds > 0 && n > 0 && m > 0, "da_nearest_sq: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    if (d_ab) { k_nearest_sq<<<dim3((n + 255) / 256, n_clouds), 256, 0, st>>>(a, b, n, m, d_ab); DA_LAUNCH_CHECK(); }
+    if (d_ba) { k_nearest_sq<<<dim3((m + 255) / 256, n_clouds), 256, 0, st>>>(b, a, m, n, d_ba); DA_LAUNCH_CHECK(); }
+    return 0;
+}
+
+size_t da_pcd_encoder_workspace_bytes(int n_points, int chunk, int feat_dim) {
+    const size_t pts = (size_t)chunk * n_points, nblk = (n_points + 255) / 256;
+    return align_up(pts * VROW * 4, 256) * 3 + align_up(pts * 4 * VROW * 4, 256) + align_up(pts * KNN * 4, 256) +
+           align_up((size_t)chunk * nblk * feat_dim * 3 * 4, 256);
+}
+
+int da_pcd_encoder_forward(const da_pcd_encoder_weights *w, int n_parts, int n_points, const float *points, int inv,
+                           float *out, int ld_out, void *workspace, size_t workspace_bytes, int chunk, void *stream) {
+    DA_REQUIRE(w && points && out && workspace, "da_pcd_encoder_forward: null argument");
+    DA_REQUIRE(n_parts > 0 && chunk > 0 && n_points >= KNN, "da_pcd_encoder_forward: need >= %d points per fragment", KNN);
+    const int feat = w->feat_dim;
+    DA_REQUIRE(feat > 0 && feat <= 256, "da_pcd_encoder_forward: feat_dim %d outside 1..256", feat);
+    DA_REQUIRE(!inv || w->linear0, "da_pcd_encoder_forward: the invariant output needs linear0");
+    DA_REQUIRE(ld_out >= (inv ? 2 * feat : 6 * feat), "da_pcd_encoder_forward: ld_out too small");
+    for (int s = 0; s < DA_PCD_STAGES; ++s)
+        DA_REQUIRE(w->premap[s] && w->bn_a[s] && (s == 2 || w->conv_b[s]), "da_pcd_encoder_forward: stage %d weights missing", s);
+    DA_REQUIRE(w->conv6, "da_pcd_encoder_forward: conv6 weights missing");
+    DA_REQUIRE(workspace_bytes >= da_pcd_encoder_workspace_bytes(n_points, chunk, feat), "da_pcd_encoder_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cp = (size_t)chunk * n_points;
+    char *base = (char *)workspace;
+    float *X[3];
+    for (int s = 0; s < 3; ++s) X[s] = (float *)(base + s * align_up(cp * VROW * 4, 256));
+    float *T = (float *)(base + 3 * align_up(cp * VROW * 4, 256));
+    int32_t *idx = (int32_t *)((char *)T + align_up(cp * 4 * VROW * 4, 256));
+    float *partial = (float *)((char *)idx + align_up(cp * KNN * 4, 256));
+    const int nblk = (n_points + 255) / 256;
+    for (int p0 = 0; p0 < n_parts; p0 += chunk) {
+        const int B = n_parts - p0 < chunk ? n_parts - p0 : chunk;
+        const long long total = (long long)B * n_points;
+        const float *pts = points + (size_t)p0 * n_points * 3;
+        for (int s = 0; s < 3; ++s) {
+            const float *xin = s == 0 ? pts : X[s - 1];
+            const int ldx = s == 0 ? 3 : VROW;
+            int rc = knn_launch(B, n_points, s == 0 ? 3 : V3, xin, ldx, KNN, idx, st);
+            if (rc) return rc;
+            const int nb = (int)((total + 255) / 256);
+            if (s == 0) k_pcd_premap<1><<<nb, 256, 0, st>>>(xin, ldx, w->premap[s], total, T);
+            else k_pcd_premap<VC><<<nb, 256, 0, st>>>(xin, ldx, w->premap[s], total, T);
+            DA_LAUNCH_CHECK();
+            const int ne = (int)((total + 127) / 128);
+            if (w->conv_b[s]) k_pcd_edge<true><<<ne, 128, 0, st>>>(T, idx, w->bn_a[s], w->conv_b[s], n_points, total, X[s]);
+            else k_pcd_edge<false><<<ne, 128, 0, st>>>(T, idx, w->bn_a[s], nullptr, n_points, total, X[s]);
+            DA_LAUNCH_CHECK();
+        }
+        k_pcd_conv6<<<dim3(nblk, B), 256, 0, st>>>(X[0], X[1], X[2], w->conv6, feat, n_points, partial);
+        DA_LAUNCH_CHECK();
+        k_pcd_final<<<B, 256, 0, st>>>(partial, nblk, feat, n_points, w->linear0, inv, out + (size_t)p0 * ld_out, ld_out);
+        DA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // extern "C"

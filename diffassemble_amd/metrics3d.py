@@ -3,8 +3,9 @@ sampled poses live on; runs once per Batch AFTER the sampling loop, not on the p
 
 Counterparts of puzzle_diff/model/utils_3d.py ``trans_metrics`` (:362-383), ``rot_metrics`` (:415-450, 'rmse' and
 'geodesic'), ``geodesic_distance`` (:916-945) and ``calc_part_acc`` (:1089-1129).  The reference routes the last one
-through pytorch3d's CUDA ``knn_points`` (model/chamfer_distance.py:148-149), which does not exist on ROCm; fragments are
-1000 points, so the K = 1 search is a [P, 1000, 1000] distance tensor here.  Poses are (unit quaternion wxyz |
+through pytorch3d's CUDA ``knn_points`` (model/chamfer_distance.py:148-149), which does not exist on ROCm: on the device
+the K = 1 search both ways is ``da_nearest_sq`` (diffassemble_amd/csrc/da_pcd_encoder.hip; b tiles staged in LDS, the
+[P, N, N] distance tensor is never formed).  Host tensors take the cdist route below.  Poses are (unit quaternion wxyz |
 translation) rows, [P, 7]; fragments [P, N, 3]."""
 import math
 
@@ -54,6 +55,11 @@ def calc_part_acc(pts, t1, t2, q1, q2, thr=0.01):
     fragment is below ``thr``, as a fraction of the parts."""
     a = _rotate(q1, pts) + t1[:, None, :]
     b = _rotate(q2, pts) + t2[:, None, :]
-    d = torch.cdist(a, b, compute_mode="donot_use_mm_for_euclid_dist").pow(2)       # exact differences: the threshold sits near 0
-    loss = d.min(2)[0].mean(1) + d.min(1)[0].mean(1)
+    if a.device.type == "cuda":
+        from .pcd_encoder import nearest_sq
+        d_ab, d_ba = nearest_sq(a, b)
+        loss = d_ab.mean(1) + d_ba.mean(1)
+    else:                                       # poses already moved to the host by the caller
+        d = torch.cdist(a, b, compute_mode="donot_use_mm_for_euclid_dist").pow(2)   # exact differences: the threshold sits near 0
+        loss = d.min(2)[0].mean(1) + d.min(1)[0].mean(1)
     return (loss < thr).sum() / loss.numel()

@@ -23,7 +23,13 @@ class Eff_GAT_3d(DenoiserBase):
         if backbone not in _FEAT_DIM:
             raise Exception(f"Backbone not implemented {backbone}")
         self.use_vn_dgcnn_equiv_inv_mp = False
-        self.pcd_backbone = None        # point-cloud encoders: out of the per-timestep path
+        # point-cloud encoders (efficient_gat_3d.py:73-97): once per sampling loop, not per step.  The
+        # vector-neuron DGCNN the 3D configuration trains with (train_3d.py: backbone="vn_dgcnn") runs in the HIP library
+        # (da_pcd_encoder_forward, eval mode); the PointNet variants are not built: pass pcd_feats.
+        self.pcd_backbone = None
+        if backbone in ("vn_dgcnn", "vn_dgcnn_inv"):
+            from .vnn.vn_dgcnn import VN_DGCNN
+            self.pcd_backbone = VN_DGCNN(feat_dim=128, inv=(backbone == "vn_dgcnn_inv"))
         feat_dim = _FEAT_DIM[backbone]
         self.combined_features_dim = feat_dim + 32 + 32
         self.gnn_feat_dim = self.combined_features_dim
@@ -54,7 +60,8 @@ class Eff_GAT_3d(DenoiserBase):
         return self._run(xy_pos, time, edge_index, pcd_feats, batch, self.return_attentions)
 
     def pcd_features(self, pcd):
+        """efficient_gat_3d.py:230-236: pcd [P, N, 3] -> pcd_feats [P, feat_dim]."""
         if self.pcd_backbone is None:
             raise NotImplementedError(
-                "point-cloud encoders (VN-DGCNN / PointNet) are outside the hot path: pass pcd_feats")
+                "only the VN-DGCNN point-cloud encoders are built (backbone='vn_dgcnn' / 'vn_dgcnn_inv'): pass pcd_feats")
         return self.pcd_backbone(pcd)

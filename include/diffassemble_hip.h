@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 7
+#define DA_ABI_VERSION 8
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -339,6 +339,53 @@ size_t da_encoder_workspace_bytes(int precision, int n_patches, int chunk);
 int da_encoder_forward(int precision, const da_encoder_weights *w, int n_patches, const float *patches,
                        void *feats, int ld_feats, void *workspace, size_t workspace_bytes, int chunk,
                        int zero_workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * 3D piece encoder: the reference's vector-neuron DGCNN, eval-mode BatchNorm.
+ * Replaces Eff_GAT_3d.pcd_features -> VN_DGCNN.forward (backbones/vnn/vn_dgcnn.py:34-74) with
+ * get_graph_feature / knn (:84-120) and VNLinearLeakyReLU / VNBatchNorm (backbones/vnn/vn_layers.py:50-91,
+ * 133-154); all fp32.  A stage = kNN(20) in the current feature space -> first VN layer on cat(x_j - x_i, x_i)
+ * -> [second VN layer] -> mean over the neighbours; three stages, then conv6 + mean over the points.
+ *
+ * da_pcd_encoder_weights holds PACKED fp32 device pointers (host: diffassemble_amd/pcd_encoder.py, from the
+ * reference's state-dict tensors; Cin = 1, 21, 21 for the three stages, W = map_to_feat / map_to_dir of the
+ * stage's first layer, columns [:Cin] act on x_j - x_i and [Cin:] on x_i):
+ *   premap[s] [4][21][Cin]    Wf[:, :Cin], Wd[:, :Cin], Wf[:, Cin:] - Wf[:, :Cin], Wd[:, Cin:] - Wd[:, :Cin]
+ *   bn_a[s]   [2][21]         eval BatchNorm of the norm as  norm * scale + shift
+ *   conv_b[s] [2][21][21] + [2][21]   second layer of the stage (feature map, direction map, scale, shift);
+ *                             NULL for stage 3 (conv5 stands alone)
+ *   conv6     [feat_dim][63] + [63] + [2][feat_dim]   feature map, the ONE shared direction map, scale, shift
+ *   linear0   [2 feat_dim][3] + [2 feat_dim]          only read for the invariant output (may be NULL otherwise)
+ * ------------------------------------------------------------------------------------- */
+enum { DA_PCD_K = 20, DA_PCD_C = 21, DA_PCD_ROW = 64, DA_PCD_STAGES = 3 };
+typedef struct da_pcd_encoder_weights {
+    int32_t feat_dim;                        /* conv6 output channels (128 in the reference)  */
+    int32_t reserved0;
+    const float *premap[DA_PCD_STAGES];
+    const float *bn_a[DA_PCD_STAGES];
+    const float *conv_b[DA_PCD_STAGES];
+    const float *conv6;
+    const float *linear0;
+} da_pcd_encoder_weights;
+
+/* Workspace for fragments of n_points points processed `chunk` at a time. */
+size_t da_pcd_encoder_workspace_bytes(int n_points, int chunk, int feat_dim);
+
+/* points [n_parts, n_points, 3] fp32 -> out [n_parts, 6 feat_dim] (inv == 0: the pooled equivariant map twice,
+ * vn_dgcnn.py:62-73) or [n_parts, 2 feat_dim] (inv != 0: linear0 path, :68-69); row stride ld_out floats.
+ * n_points >= 20.  Stream-capturable. */
+int da_pcd_encoder_forward(const da_pcd_encoder_weights *w, int n_parts, int n_points, const float *points, int inv,
+                           float *out, int ld_out, void *workspace, size_t workspace_bytes, int chunk, void *stream);
+
+/* The encoder's neighbour search on its own (vn_dgcnn.py:114-120): for every point of every cloud the k nearest
+ * points of the same cloud (itself included), nearest first, ties towards the lower index -> idx [n_clouds,
+ * n_points, k] (cloud-local).  x rows: dim == 3 with stride ldx >= 3, or 4 <= dim <= 64 as zero-padded 64-float rows. */
+int da_knn(int n_clouds, int n_points, int dim, const float *x, int ldx, int k, int32_t *idx, void *stream);
+
+/* Nearest-neighbour squared distances both ways (chamfer_distance.py:148-149 = pytorch3d knn_points K = 1, used by
+ * utils_3d.py:1089-1129 calc_part_acc): a [n_clouds, n, 3], b [n_clouds, m, 3] -> d_ab [n_clouds, n],
+ * d_ba [n_clouds, m]; either output may be NULL. */
+int da_nearest_sq(int n_clouds, int n, int m, const float *a, const float *b, float *d_ab, float *d_ba, void *stream);
 
 #ifdef __cplusplus
 }

@@ -163,3 +163,43 @@ def make_patches(n, seed=0):
     """[n, 3, 32, 32] fp32 in [0, 1] (puzzle_dataset.py:290-299 hands the model 32x32 RGB crops)."""
     rng = np.random.default_rng(seed)
     return torch.from_numpy(rng.uniform(0.0, 1.0, size=(n, 3, 32, 32)).astype(np.float32))
+
+
+def vn_dgcnn_layer_specs(feat_dim=128):
+    """(name, in_channels, out_channels, shared_direction) of the VNLinearLeakyReLU layers of the reference's
+    ``VN_DGCNN`` (vnn/vn_dgcnn.py:13-31), then the dead ``VnInv`` stack (vn_layers.py:193-206)."""
+    c = 64 // 3
+    live = [("conv1", 2, c, False), ("conv2", c, c, False), ("conv3", 2 * c, c, False), ("conv4", c, c, False),
+            ("conv5", 2 * c, c, False), ("conv6", 3 * c, feat_dim, True)]
+    dead = [("VnInv.vn1", 2 * feat_dim, feat_dim, False), ("VnInv.vn2", feat_dim, feat_dim // 2, False)]
+    return live, dead
+
+
+def make_vn_dgcnn_state(feat_dim=128, seed=0):
+    """State dict with the key layout of the reference's ``VN_DGCNN(feat_dim)``.  Linear maps at torch's default scale
+    U(+-1/sqrt(fan_in)); BatchNorm affine AND running statistics randomised (the running mean sits near the typical
+    vector norm so that the normalised norms take both signs)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    live, dead = vn_dgcnn_layer_specs(feat_dim)
+    for name, cin, cout, shared in live + dead:
+        b = 1.0 / math.sqrt(cin)
+        sd[f"{name}.map_to_feat.weight"] = _uniform(rng, (cout, cin), b)
+        sd[f"{name}.map_to_dir.weight"] = _uniform(rng, (1 if shared else cout, cin), b)
+        sd[f"{name}.batchnorm.bn.weight"] = torch.from_numpy(rng.uniform(0.6, 1.4, size=cout).astype(np.float32))
+        sd[f"{name}.batchnorm.bn.bias"] = torch.from_numpy((0.5 + 0.2 * rng.standard_normal(cout)).astype(np.float32))
+        sd[f"{name}.batchnorm.bn.running_mean"] = torch.from_numpy(rng.uniform(0.05, 0.4, size=cout).astype(np.float32))
+        sd[f"{name}.batchnorm.bn.running_var"] = torch.from_numpy(rng.uniform(0.02, 0.2, size=cout).astype(np.float32))
+        sd[f"{name}.batchnorm.bn.num_batches_tracked"] = torch.tensor(100, dtype=torch.int64)
+    sd["VnInv.vn_lin.weight"] = _uniform(rng, (3, feat_dim // 2), 1.0 / math.sqrt(feat_dim // 2))
+    _linear(rng, sd, "linear0", 3, 2 * feat_dim)
+    return sd
+
+
+def make_point_clouds(P, N, seed=0):
+    """[P, N, 3] fp32: each fragment is an anisotropic blob with its own offset and scale, like the centred,
+    unit-scaled fragments the reference's dataset hands over (1000 points each in the Breaking Bad configuration)."""
+    rng = np.random.default_rng(seed)
+    pts = rng.standard_normal((P, N, 3)) * rng.uniform(0.05, 0.4, size=(P, 1, 3))
+    pts += 0.3 * rng.standard_normal((P, 1, 3))
+    return torch.from_numpy(pts.astype(np.float32))

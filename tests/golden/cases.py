@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..",
 from oracle import weights as W  # noqa: E402
 
 GOLDEN_FILE = os.path.join(os.path.dirname(__file__), "golden_v1.npz")
+GOLDEN3_FILE = os.path.join(os.path.dirname(__file__), "golden_v3.npz")
 
 # fmt: off
 FWD2D = [
@@ -74,6 +75,13 @@ EXPANDER = [
     dict(name="expander_n900_d539", n=900, d=539, seed=64, full=False),  # the scripted "60 %"
 ]
 # fmt: on
+# 3D piece encoder (vnn/vn_dgcnn.py): fragments x points, eval mode; inputs/weights from oracle/weights.py seeds
+PCD_ENC = [
+    dict(name="vn_p3_n256", P=3, N=256, seed=5, wseed=3, inv=False),
+    dict(name="vn_p3_n256_inv", P=3, N=256, seed=6, wseed=4, inv=True),
+    dict(name="vn_p2_n1000", P=2, N=1000, seed=7, wseed=3, inv=False),      # the Breaking Bad point count
+    dict(name="vn_p5_n37", P=5, N=37, seed=8, wseed=9, inv=False),          # ragged: N not a multiple of anything
+]
 SCHEDULE_T = [50, 100, 300]
 GOLDEN2_FILE = os.path.join(os.path.dirname(__file__), "golden_v2.npz")
 
@@ -171,3 +179,12 @@ def load_golden():
 
 def load_golden2():
     return np.load(GOLDEN2_FILE)
+
+
+def load_golden3():
+    return np.load(GOLDEN3_FILE)
+
+
+def pcd_encoder_case(spec):
+    """(state dict, clouds [P, N, 3]) of a PCD_ENC entry."""
+    return W.make_vn_dgcnn_state(128, spec["wseed"]), W.make_point_clouds(spec["P"], spec["N"], spec["seed"])
