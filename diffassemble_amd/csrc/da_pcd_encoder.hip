@@ -49,7 +49,9 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // The k largest scores of one LDS row (Npad = 64 NR entries at most), k <= 64, by k rounds of a wave-wide arg-max over
 // register-resident scores (lane l holds entries l, l + 64, ...).  Ties go to the lower index.  Lane t returns the
-// index of rank t.
+// index of rank t.  (VALU-issue bound, ~7 NR instructions per round.  Reading the winning lane's registers into SGPRs
+// and patching one slot under a uniform branch has fewer vector instructions but ran 25 % slower: v_readlane -> SALU
+// compare chains stall.)
 template <int NR>
 __device__ __forceinline__ int select_topk(const float *row, int Npad, int k, int lane) {
     float v[NR];
@@ -89,6 +91,51 @@ __device__ __forceinline__ int select_topk(const float *row, int Npad, int k, in
     return res;
 }
 
+// The same k entries as an UNORDERED set (what the encoder needs: it pools over the neighbours), 3x fewer vector
+// instructions: the scores become order-preserving 32-bit keys, the k-th largest key tau is built bit by bit (32 rounds
+// of "how many keys >= candidate": one v_cmp per register, the counting is s_bcnt1 on the ballot masks), then the keys
+// > tau and the first k - count(> tau) keys == tau (lowest indices first, the ordered variant's tie rule) are compacted
+// into dst[0..k) through mbcnt prefix counts.
+template <int NR>
+__device__ __forceinline__ void select_set(const float *row, int Npad, int N, int k, int lane, int32_t *dst) {
+    unsigned u[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const unsigned b = __builtin_bit_cast(unsigned, r * 64 < Npad ? row[r * 64 + lane] : -INFINITY);
+        u[r] = b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+    }
+    unsigned tau = 0;
+    bool exact = false;                                 // exactly k keys >= tau: the set is known, stop refining
+    for (int bit = 31; bit >= 0 && !exact; --bit) {
+        const unsigned cand = tau | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) c += __builtin_popcountll(__ballot(u[r] >= cand));
+        tau = c >= k ? cand : tau;
+        exact = c == k;
+    }
+    int g = k;
+    if (!exact) {                                       // tau is the k-th largest key and it repeats
+        g = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) g += __builtin_popcountll(__ballot(u[r] > tau));
+    }
+    const int need = k - g;
+    int og = 0, oe = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool gt = exact ? u[r] >= tau : u[r] > tau, eq = !exact && u[r] == tau;
+        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+        const int pg = og + __builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, 0));
+        const int pe = oe + __builtin_amdgcn_mbcnt_hi((unsigned)(me >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)me, 0));
+        const int j = min(r * 64 + lane, N - 1);
+        if (gt) dst[pg] = j;
+        else if (eq && pe < need) dst[g + pe] = j;
+        og += __builtin_popcountll(mg);
+        oe += __builtin_popcountll(me);
+    }
+}
+
 // Same selection for rows that do not fit the registers: the scores stay in LDS, the winner is overwritten.
 __device__ __forceinline__ int select_topk_lds(volatile float *row, int Npad, int k, int lane) {
     int res = 0;
@@ -120,7 +167,7 @@ __device__ __forceinline__ int select_topk_lds(volatile float *row, int Npad, in
 // in decreasing order (topk), ties broken towards the lower index.  Non-finite scores rank last.
 template <int F>
 __global__ __launch_bounds__(256) void k_pcd_knn(const float *__restrict__ X, int ldx, int N, int QB, int Npad, int k,
-                                                 int32_t *__restrict__ idx) {
+                                                 int ordered, int32_t *__restrict__ idx) {
     extern __shared__ float smem[];
     float *qxx = smem, *score = qxx + ((QB + 3) & ~3);
     const int cloud = blockIdx.y, q0 = blockIdx.x * QB, tid = threadIdx.x;
@@ -158,7 +205,7 @@ __global__ __launch_bounds__(256) void k_pcd_knn(const float *__restrict__ X, in
                     }
                     const float dot = (a0.x + a0.y) + (a1.x + a1.y);
                     const float sc = (-qxx[q] - (-2.f * dot)) - xxj;
-                    score[q * Npad + j] = fabsf(sc) <= FLT_MAX ? sc : -FLT_MAX;  // NaN / inf rank after every finite score
+                    score[q * Npad + j] = fabsf(sc) <= FLT_MAX ? sc + 0.f : -FLT_MAX;  // NaN / inf rank last; -0 -> +0 (bit compares)
                 }
             } else {
                 const float c0 = Xc[(size_t)j * ldx], c1 = Xc[(size_t)j * ldx + 1], c2 = Xc[(size_t)j * ldx + 2];
@@ -167,7 +214,7 @@ __global__ __launch_bounds__(256) void k_pcd_knn(const float *__restrict__ X, in
                     const float *qr = Xc + (size_t)min(q0 + q, N - 1) * ldx;
                     const float dot = qr[0] * c0 + qr[1] * c1 + qr[2] * c2;
                     const float sc = (-qxx[q] - (-2.f * dot)) - xxj;
-                    score[q * Npad + j] = fabsf(sc) <= FLT_MAX ? sc : -FLT_MAX;
+                    score[q * Npad + j] = fabsf(sc) <= FLT_MAX ? sc + 0.f : -FLT_MAX;
                 }
             }
         } else {
@@ -178,12 +225,19 @@ __global__ __launch_bounds__(256) void k_pcd_knn(const float *__restrict__ X, in
     const int wave = tid >> 6, lane = tid & 63;
     for (int q = wave; q < QB && q0 + q < N; q += 4) {
         float *row = score + q * Npad;
+        int32_t *dst = idx + ((size_t)cloud * N + q0 + q) * k;
+        if (!ordered && Npad <= 1024) {
+            if (Npad <= 256) select_set<4>(row, Npad, N, k, lane, dst);
+            else if (Npad <= 512) select_set<8>(row, Npad, N, k, lane, dst);
+            else select_set<16>(row, Npad, N, k, lane, dst);
+            continue;
+        }
         int r;
         if (Npad <= 256) r = select_topk<4>(row, Npad, k, lane);
         else if (Npad <= 512) r = select_topk<8>(row, Npad, k, lane);
         else if (Npad <= 1024) r = select_topk<16>(row, Npad, k, lane);
         else r = select_topk_lds(row, Npad, k, lane);
-        if (lane < k) idx[((size_t)cloud * N + q0 + q) * k + lane] = min(r, N - 1);
+        if (lane < k) dst[lane] = min(r, N - 1);
     }
 }
 
@@ -215,61 +269,99 @@ __global__ __launch_bounds__(256) void k_pcd_premap(const float *__restrict__ X,
     }
 }
 
-// VNBatchNorm on the norm (eval: norm * scale + shift) + the vector leaky projection, vn_layers.py:80-91.
+// VNBatchNorm on the norm (eval: norm * scale + shift) + the vector leaky projection, vn_layers.py:80-91.  Branch-free;
+// v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the IEEE sequences: ~1e-7 relative, far inside the parity tolerance.
 __device__ __forceinline__ void vn_act(float &p0, float &p1, float &p2, float d0, float d1, float d2, float scale, float shift) {
-    const float norm = sqrtf(p0 * p0 + p1 * p1 + p2 * p2) + VN_EPS;
-    const float f = (norm * scale + shift) / norm;
+    const float norm = __builtin_amdgcn_sqrtf(p0 * p0 + p1 * p1 + p2 * p2) + VN_EPS;
+    const float f = (norm * scale + shift) * __builtin_amdgcn_rcpf(norm);
     p0 *= f; p1 *= f; p2 *= f;
     const float dot = p0 * d0 + p1 * d1 + p2 * d2;
-    float q0 = p0, q1 = p1, q2 = p2;
-    if (dot < 0.f) {
-        const float c = dot / (d0 * d0 + d1 * d1 + d2 * d2 + VN_EPS);
-        q0 -= c * d0; q1 -= c * d1; q2 -= c * d2;
-    }
-    p0 = 0.2f * p0 + 0.8f * q0; p1 = 0.2f * p1 + 0.8f * q1; p2 = 0.2f * p2 + 0.8f * q2;
+    // 0.2 p + 0.8 (p - [dot < 0] dot / (|d|^2 + eps) d)
+    const float c = dot < 0.f ? 0.8f * dot * __builtin_amdgcn_rcpf(d0 * d0 + d1 * d1 + d2 * d2 + VN_EPS) : 0.f;
+    p0 -= c * d0; p1 -= c * d1; p2 -= c * d2;
 }
 
 // One stage's edge work: for point i and each neighbour j: h = act(A_j + U_i; Ad_j + Ud_i); optionally the second
 // VN layer (21 -> 21); mean over the k neighbours -> Xout row (64 floats, 63 used, pad = 0).  One thread per point.
-// wb = [2][21][21] (feature, direction maps) then [2][21] (scale, shift) of the second layer.
+// wb = [2][21 o][22] (feature map, direction map; rows zero-padded to 11 pairs) then [2][21] (scale, shift) of the
+// second layer.  The second layer is packed fp32 over channel pairs: (even, odd partial sums) += (w[o][c], w[o][c + 1]) *
+// (h[c][k], h[c + 1][k]); a weight pair is one 64-bit scalar operand and streams through SGPRs.
 template <bool HAS_B>
-__global__ __launch_bounds__(128) void k_pcd_edge(const float *__restrict__ T, const int32_t *__restrict__ idx,
-                                                  const float *__restrict__ bn_a, const float *__restrict__ wb, int N,
-                                                  long long total, float *__restrict__ Xout) {
+__global__ __launch_bounds__(128, 1) void k_pcd_edge(const float *__restrict__ T, const int32_t *__restrict__ idx,
+                                                     const float *__restrict__ bn_a, const float *__restrict__ wb, int N,
+                                                     long long total, float *__restrict__ Xout) {
+    // The point's own U / Ud rows stay in 126 registers (re-reading them per neighbour doubled the divergent 16-byte
+    // loads the kernel is bound by: 5.4 ms vs 2.3 ms per 640 000 points); one wave per SIMD, overflow into AGPRs.
+    constexpr bool PIN_U = true;
     const long long p = (long long)blockIdx.x * 128 + threadIdx.x;
     if (p >= total) return;
     const long long base = p / N * N;
-    float u[V3], ud[V3], acc[V3];
+    float acc[V3];
 #pragma unroll
-    for (int e = 0; e < V3; ++e) { u[e] = T[p * 4 * VROW + 2 * VROW + e]; ud[e] = T[p * 4 * VROW + 3 * VROW + e]; acc[e] = 0.f; }
+    for (int e = 0; e < V3; ++e) acc[e] = 0.f;
+    float4 uu[PIN_U ? 16 : 1], ud[PIN_U ? 16 : 1];
+    if constexpr (PIN_U) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            uu[e] = *(const float4 *)(T + p * 4 * VROW + 2 * VROW + 4 * e);
+            ud[e] = *(const float4 *)(T + p * 4 * VROW + 3 * VROW + 4 * e);
+        }
+    }
 #pragma unroll 1
     for (int r = 0; r < KNN; ++r) {
         const int j = idx[p * KNN + r];
         const float *tj = T + (base + j) * 4 * VROW;
-        float h[V3];
+        int toff = 0, woff = 0;                           // opaque zeros: keep the U / Ud loads and the weight loads
+        asm volatile("" : "+v"(toff));                    // inside the loop (not hoisted into ~1000 live registers)
+        asm volatile("" : "+s"(woff));
+        const float *ti = T + p * 4 * VROW + 2 * VROW + toff;
+        const float *wl = wb + woff;
+        // h[k][c / 2] holds the channel pair (c, c + 1) of component k: the operand layout of the packed second layer
+        f32x2 h[3][VC / 2 + 1];
+        h[0][VC / 2] = h[1][VC / 2] = h[2][VC / 2] = f32x2{0.f, 0.f};
+        // first layer, four channels (12 floats = three 16-byte loads per operand) at a time; channel 20 + the pad last
 #pragma unroll
-        for (int c = 0; c < VC; ++c) {
-            float p0 = tj[c * 3] + u[c * 3], p1 = tj[c * 3 + 1] + u[c * 3 + 1], p2 = tj[c * 3 + 2] + u[c * 3 + 2];
-            const float d0 = tj[VROW + c * 3] + ud[c * 3], d1 = tj[VROW + c * 3 + 1] + ud[c * 3 + 1], d2 = tj[VROW + c * 3 + 2] + ud[c * 3 + 2];
-            vn_act(p0, p1, p2, d0, d1, d2, bn_a[c], bn_a[VC + c]);
-            h[c * 3] = p0; h[c * 3 + 1] = p1; h[c * 3 + 2] = p2;
+        for (int e0 = 0; e0 < VROW; e0 += 12) {
+            float a[12], ad[12];
+#pragma unroll
+            for (int e = 0; e < 12 && e0 + e < VROW; e += 4) {
+                const float4 x = *(const float4 *)(tj + e0 + e), xd = *(const float4 *)(tj + VROW + e0 + e);
+                float4 y, yd;
+                if constexpr (PIN_U) { y = uu[(e0 + e) / 4]; yd = ud[(e0 + e) / 4]; }
+                else { y = *(const float4 *)(ti + e0 + e); yd = *(const float4 *)(ti + VROW + e0 + e); }
+                a[e] = x.x + y.x; a[e + 1] = x.y + y.y; a[e + 2] = x.z + y.z; a[e + 3] = x.w + y.w;
+                ad[e] = xd.x + yd.x; ad[e + 1] = xd.y + yd.y; ad[e + 2] = xd.z + yd.z; ad[e + 3] = xd.w + yd.w;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4 && e0 / 3 + cc < VC; ++cc) {
+                const int c = e0 / 3 + cc;
+                float p0 = a[cc * 3], p1 = a[cc * 3 + 1], p2 = a[cc * 3 + 2];
+                vn_act(p0, p1, p2, ad[cc * 3], ad[cc * 3 + 1], ad[cc * 3 + 2], bn_a[c], bn_a[VC + c]);
+                if constexpr (!HAS_B) { acc[c * 3] += p0; acc[c * 3 + 1] += p1; acc[c * 3 + 2] += p2; }
+                else if (c & 1) { h[0][c / 2].y = p0; h[1][c / 2].y = p1; h[2][c / 2].y = p2; }
+                else { h[0][c / 2].x = p0; h[1][c / 2].x = p1; h[2][c / 2].x = p2; }
+            }
+            __builtin_amdgcn_sched_barrier(0);            // do not hoist every chunk's loads to the top (VGPR budget)
         }
         if constexpr (HAS_B) {
+            constexpr int WR = VC / 2 + 1;                 // 11 weight pairs per (zero-padded) row of 22
+            const f32x2 *wf = (const f32x2 *)wl, *wd = wf + VC * WR;
+            const float *bn = wl + 4 * VC * WR;
 #pragma unroll
             for (int o = 0; o < VC; ++o) {
-                float p0 = 0.f, p1 = 0.f, p2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+                f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f}, t0 = {0.f, 0.f}, t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < VC; ++c) {
-                    const float wf = wb[o * VC + c], wd = wb[VC * VC + o * VC + c];
-                    p0 += wf * h[c * 3]; p1 += wf * h[c * 3 + 1]; p2 += wf * h[c * 3 + 2];
-                    d0 += wd * h[c * 3]; d1 += wd * h[c * 3 + 1]; d2 += wd * h[c * 3 + 2];
+                for (int c = 0; c < WR; ++c) {
+                    const f32x2 a = wf[o * WR + c], b = wd[o * WR + c];
+                    s0 = __builtin_elementwise_fma(a, h[0][c], s0); s1 = __builtin_elementwise_fma(a, h[1][c], s1);
+                    s2 = __builtin_elementwise_fma(a, h[2][c], s2);
+                    t0 = __builtin_elementwise_fma(b, h[0][c], t0); t1 = __builtin_elementwise_fma(b, h[1][c], t1);
+                    t2 = __builtin_elementwise_fma(b, h[2][c], t2);
                 }
-                vn_act(p0, p1, p2, d0, d1, d2, wb[2 * VC * VC + o], wb[2 * VC * VC + VC + o]);
+                float p0 = s0.x + s0.y, p1 = s1.x + s1.y, p2 = s2.x + s2.y;
+                vn_act(p0, p1, p2, t0.x + t0.y, t1.x + t1.y, t2.x + t2.y, bn[o], bn[VC + o]);
                 acc[o * 3] += p0; acc[o * 3 + 1] += p1; acc[o * 3 + 2] += p2;
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < V3; ++e) acc[e] += h[e];
         }
     }
     float *xo = Xout + p * VROW;
@@ -363,7 +455,7 @@ __global__ __launch_bounds__(256) void k_nearest_sq(const float *__restrict__ a,
     if (i < N) out[(size_t)cloud * N + i] = best;
 }
 
-static int knn_launch(int clouds, int N, int dim, const float *x, int ldx, int k, int32_t *idx, hipStream_t st) {
+static int knn_launch(int clouds, int N, int dim, const float *x, int ldx, int k, int ordered, int32_t *idx, hipStream_t st) {
     const int F = dim <= 3 ? 3 : 64;
     const int Npad = (N + 63) & ~63;
     int QB = 32;
@@ -373,10 +465,10 @@ static int knn_launch(int clouds, int N, int dim, const float *x, int ldx, int k
     const dim3 grid((N + QB - 1) / QB, clouds);
     if (F == 3) {
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(QB)));
-        k_pcd_knn<3><<<grid, 256, bytes(QB), st>>>(x, ldx, N, QB, Npad, k, idx);
+        k_pcd_knn<3><<<grid, 256, bytes(QB), st>>>(x, ldx, N, QB, Npad, k, ordered, idx);
     } else {
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(QB)));
-        k_pcd_knn<64><<<grid, 256, bytes(QB), st>>>(x, ldx, N, QB, Npad, k, idx);
+        k_pcd_knn<64><<<grid, 256, bytes(QB), st>>>(x, ldx, N, QB, Npad, k, ordered, idx);
     }
     DA_LAUNCH_CHECK();
     return 0;
@@ -392,7 +484,7 @@ int da_knn(int n_clouds, int n_points, int dim, const float *x, int ldx, int k, 
     DA_REQUIRE(x && idx, "da_knn: null argument");
     DA_REQUIRE(n_clouds > 0 && n_points >= k && k > 0 && k <= 64, "da_knn: need n_points >= k, 0 < k <= 64 (got %d, %d)", n_points, k);
     DA_REQUIRE(dim == 3 ? ldx >= 3 : (dim > 3 && dim <= 64 && ldx == 64), "da_knn: dim 3 (ldx >= 3) or 4..64 with zero-padded 64-float rows");
-    return knn_launch(n_clouds, n_points, dim, x, ldx, k, idx, (hipStream_t)stream);
+    return knn_launch(n_clouds, n_points, dim, x, ldx, k, 1, idx, (hipStream_t)stream);
 }
 
 int da_nearest_sq(int n_clouds, int n, int m, const float *a, const float *b, float *d_ab, float *d_ba, void *stream) {
@@ -438,7 +530,7 @@ int da_pcd_encoder_forward(const da_pcd_encoder_weights *w, int n_parts, int n_p
         for (int s = 0; s < 3; ++s) {
             const float *xin = s == 0 ? pts : X[s - 1];
             const int ldx = s == 0 ? 3 : VROW;
-            int rc = knn_launch(B, n_points, s == 0 ? 3 : V3, xin, ldx, KNN, idx, st);
+            int rc = knn_launch(B, n_points, s == 0 ? 3 : V3, xin, ldx, KNN, 0, idx, st);      // the pooling is order-free
             if (rc) return rc;
             const int nb = (int)((total + 255) / 256);
             if (s == 0) k_pcd_premap<1><<<nb, 256, 0, st>>>(xin, ldx, w->premap[s], total, T);

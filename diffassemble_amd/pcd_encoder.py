@@ -44,7 +44,10 @@ class PcdEncoderEngine:
             w.premap[s] = keep(wf[:, :cin], wd[:, :cin], wf[:, cin:] - wf[:, :cin], wd[:, cin:] - wd[:, :cin])
             w.bn_a[s] = keep(_bn_affine(sd, a))
             if b is not None:
-                w.conv_b[s] = keep(sd[f"{b}.map_to_feat.weight"], sd[f"{b}.map_to_dir.weight"], _bn_affine(sd, b))
+                # rows zero-padded to 22: a (c, c + 1) weight pair is one 64-bit scalar operand of a packed fp32 FMA
+                pad = torch.nn.functional.pad
+                w.conv_b[s] = keep(pad(sd[f"{b}.map_to_feat.weight"], (0, 1)), pad(sd[f"{b}.map_to_dir.weight"], (0, 1)),
+                                   _bn_affine(sd, b))
         w6, d6 = sd["conv6.map_to_feat.weight"], sd["conv6.map_to_dir.weight"]
         self.feat_dim = int(w6.shape[0])
         assert w6.shape[1] == 63 and tuple(d6.shape) == (1, 63), (tuple(w6.shape), tuple(d6.shape))

@@ -352,8 +352,8 @@ int da_encoder_forward(int precision, const da_encoder_weights *w, int n_patches
  * stage's first layer, columns [:Cin] act on x_j - x_i and [Cin:] on x_i):
  *   premap[s] [4][21][Cin]    Wf[:, :Cin], Wd[:, :Cin], Wf[:, Cin:] - Wf[:, :Cin], Wd[:, Cin:] - Wd[:, :Cin]
  *   bn_a[s]   [2][21]         eval BatchNorm of the norm as  norm * scale + shift
- *   conv_b[s] [2][21][21] + [2][21]   second layer of the stage (feature map, direction map, scale, shift);
- *                             NULL for stage 3 (conv5 stands alone)
+ *   conv_b[s] [2][21][22] + [2][21]   second layer of the stage: feature map, direction map (rows zero-padded to
+ *                             22), then scale, shift; NULL for stage 3 (conv5 stands alone)
  *   conv6     [feat_dim][63] + [63] + [2][feat_dim]   feature map, the ONE shared direction map, scale, shift
  *   linear0   [2 feat_dim][3] + [2 feat_dim]          only read for the invariant output (may be NULL otherwise)
  * ------------------------------------------------------------------------------------- */

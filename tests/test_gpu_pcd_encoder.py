@@ -142,3 +142,32 @@ def test_3d_model_encodes_point_clouds(dev):
     with pytest.raises(NotImplementedError):
         m.train()
         m.pcd_features(pts)
+
+
+def test_3d_module_samples_from_raw_fragments(dev):
+    """spatial_diffusion_3d_test_double_diffusion.GNN_Diffusion.p_sample_loop(shape, cond = fragments, ...) with no
+    precomputed features (the reference's call, ...double_diffusion.py:689-700): the encoder runs once, the loop is the
+    same as the one fed with pcd_features(cond), and validation_step scores the part accuracy through da_nearest_sq."""
+    from types import SimpleNamespace
+    from diffassemble_amd.model.spatial_diffusion_3d_test_double_diffusion import GNN_Diffusion, ModelMeanType
+    torch.manual_seed(1)
+    m = GNN_Diffusion(steps=20, sampling="DDIM", inference_ratio=2, model_mean_type=ModelMeanType.START_X,
+                      backbone="vn_dgcnn").to(dev).eval()
+    m.model.pcd_backbone.load_state_dict(W.make_vn_dgcnn_state(128, 2))
+    sizes = [6, 9]
+    P = sum(sizes)
+    pts = W.make_point_clouds(P, 128, 4).to(dev)
+    ei, batch = W.collate([W.dense_edge_index(k, True) for k in sizes], sizes)
+    ei, batch = ei.to(dev), batch.to(dev)
+    torch.manual_seed(5)
+    a, _ = m.p_sample_loop((P, 7), pts, ei, batch)
+    torch.manual_seed(5)
+    b, _ = m.p_sample_loop((P, 7), None, ei, batch, pcd_feats=m.pcd_features(pts))
+    assert len(a) == 10 and all(torch.equal(x, y) for x, y in zip(a, b)) and torch.isfinite(a[-1]).all()
+    gt = torch.cat([torch.nn.functional.normalize(torch.randn(P, 4), dim=-1), 0.3 * torch.randn(P, 3)], 1).to(dev)
+    bt = SimpleNamespace(x=gt, pcds=pts, edge_index=ei, batch=batch, category=["everyday", "everyday"])
+    m.initialize_torchmetrics(["everyday"])
+    final = m.validation_step(bt, 0)
+    assert final.shape == (P, 7)
+    acc = float(m.metrics["part_acc_everyday"].compute())
+    assert 0.0 <= acc <= 1.0
