@@ -442,6 +442,74 @@ def encode_bench(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def pcd_encode_bench(args, world, rank, dev):
+    """the vector-neuron DGCNN fragment encoder (backbone='vn_dgcnn'), eval mode: one "step" = the
+    1000-point clouds of `--puzzles` 20-fragment objects -> pcd_feats [P, 768].  Runs once per sampling loop in the
+    reference (spatial_diffusion_3d_test_double_diffusion.py:700).  With --e2e-3d also plan + the config-4 DDIM loop."""
+    import torch.distributed as dist
+    from diffassemble_amd import sharding as S
+    from diffassemble_amd.model.backbones.vnn.vn_dgcnn import VN_DGCNN
+    from oracle import weights as W
+    G, K, Wm = args.puzzles, args.steps, args.warmup
+    P, N = G * 20, 1000
+    net = VN_DGCNN(128).to(dev).eval()
+    net.load_state_dict(W.make_vn_dgcnn_state(128, 1))
+    eng = net.engine()
+    pts = W.make_point_clouds(P, N, 2 + rank).to(dev)
+    out = torch.empty((P, 768), dtype=torch.float32, device=dev)
+    for _ in range(max(Wm, 1)):
+        eng.forward(pts, out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(K):
+        eng.forward(pts, out)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = S.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(out).all()
+    if rank == 0:
+        ms_dev = e0.elapsed_time(e1) / K
+        # algorithmic flops per fragment: three score matrices N^2 x 2F (F = 3, 63, 63), the per-edge second VN layers
+        # (2 x 21 x 21 x 3 MACs, two stages), the per-point first layers (4 maps) and conv6
+        fl = N * N * 2 * (3 + 63 + 63) + 2 * (N * 20) * 2 * (2 * 21 * 21 * 3) + N * 2 * (4 * 21 * 3 * (1 + 21 + 21)) + N * 2 * 129 * 63 * 3
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import vn_dgcnn as OV
+            sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+            xs = pts[:6].cpu().numpy()
+            OV.forward(sd, xs[:1])
+            tc = time.perf_counter()
+            OV.forward(sd, xs)
+            dc = time.perf_counter() - tc
+            cpu = {"value": 6 / dc, "unit": "fragments/s", "cores": min(os.cpu_count() or 1, torch.get_num_threads()), "kind": "port",
+                   "sample": f"6 fragments x 1000 points through oracle/vn_dgcnn.py (numpy fp32), {dc:.1f} s"}
+        print(json.dumps({
+            "metric": "fragment encoder throughput (VN-DGCNN, 1000-point clouds, eval)",
+            "value": world * P * K / dt, "unit": "fragments/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "1000-point fragments of 20-fragment objects -> pcd_feats [P, 768], backbone='vn_dgcnn'",
+                       "objects_per_gpu": G, "fragments_per_gpu": P, "chunk": eng._ws_key[1],
+                       "parallelism": f"object-sharded x{world}"},
+            "gflop_per_fragment": fl / 1e9,
+            "roofline": {"bound": "valu", "achieved": P * fl / (ms_dev * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": P * fl / (ms_dev * 1e-3) / 1e12 / 157.3, "traffic": None,
+                         "kernel": "whole encoder pass (3 x k_pcd_knn + 3 x k_pcd_edge dominate); fp32 vector ALU, "
+                                   "peak = packed-fp32 FMA rate",
+                         "ms_device": ms_dev},
+            "cpu_baseline": cpu,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def e2e_bench(args, world, rank, dev):
     """Pixels -> poses: what one validation / test batch costs end to end.  One "step" = p_sample_loop on a Batch
     of `--puzzles` 900-piece puzzles given their 32x32 crops and the collated edge_index: piece encoder
@@ -700,7 +768,8 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("BENCH_PRECISION", ""), choices=["", "bf16", "fp32"])
     ap.add_argument("--mode", default=os.environ.get("BENCH_MODE", "sample"), choices=["sample", "train", "encode", "e2e"],
                     help="sample = a sampling-loop configuration (default); train = BASELINE config 5 (one optimizer step); "
-                         "encode = the piece encoder (SURVEY 8f rank 2); e2e = pixels -> poses (encoder + plan + loop)")
+                         "encode = the piece encoder (SURVEY 8f rank 2; with --config 4: the 3D fragment encoder, 8f rank 4); "
+                         "e2e = pixels -> poses (encoder + plan + loop)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("BENCH_ENCODER_CHUNK", 0)),
                     help="--mode encode: pieces per encoder chunk (0 = engine default)")
     ap.add_argument("--train-puzzles", type=int, default=int(os.environ.get("BENCH_TRAIN_PUZZLES", 64)),
@@ -734,6 +803,9 @@ def main():
 
     if args.mode == "train":
         return train_bench(args, world, rank, dev)
+    if args.mode == "encode" and args.config == "4":
+        args.puzzles = args.puzzles or 32
+        return pcd_encode_bench(args, world, rank, dev)
     if args.mode == "encode":
         args.precision = args.precision or "bf16"
         args.puzzles = args.puzzles or 32
