@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvParams p) {
 // every store instruction writes two whole pixels (2 x 256 / 512 B contiguous).
 template <typename T>
 __global__ __launch_bounds__(256) void k_enc_stem(const float *__restrict__ patches, const float *__restrict__ w,
-                                                  const float *__restrict__ bias, T *__restrict__ Y) {
+                                                  const float *__restrict__ bias, T *__restrict__ Y, int relu) {
     __shared__ float win[3 * 34 * 34];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float mean[3] = {0.4850f, 0.4560f, 0.4060f}, sd[3] = {0.2290f, 0.2240f, 0.2250f};
@@ -298,14 +298,14 @@ __global__ __launch_bounds__(256) void k_enc_stem(const float *__restrict__ patc
                     for (int q = 0; q < 4; ++q) acc[q] = fmaf(v, wr[q][c * 9 + ky * 3 + kx], acc[q]);
                 }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = fmaxf(acc[q], 0.f);
+        for (int q = 0; q < 4; ++q) acc[q] = relu ? fmaxf(acc[q], 0.f) : acc[q];
         store4(Y + (((size_t)b * 34 + (y + 1)) * 34 + (x + 1)) * 128 + 4 * l32, acc);
     }
 }
 
 static int lg2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-static int launch_conv(int prec, int B, const void *X, int Cin, int Hi, const void *W, const float *bias, const void *res,
+int launch_conv(int prec, int B, const void *X, int Cin, int Hi, const void *W, const float *bias, const void *res,
                        void *Y, int Cout, int ksize, int stride, int relu, hipStream_t st) {
     const int es = (int)esize(prec), BK = 128 / es;
     ConvParams p;
@@ -330,6 +330,12 @@ static int launch_conv(int prec, int B, const void *X, int Cin, int Hi, const vo
     const unsigned grid = (unsigned)(p.nvirt < cap ? p.nvirt : cap);
     if (prec == DA_PREC_BF16) k_conv_mfma<bf16_t><<<grid, 256, 0, st>>>(p);
     else k_conv_mfma<float><<<grid, 256, 0, st>>>(p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_enc_stem_f32(int B, const float *patches, const float *w, const float *bias, float *Y, int relu, hipStream_t st) {
+    k_enc_stem<float><<<B, 256, 0, st>>>(patches, w, bias, Y, relu);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -375,8 +381,8 @@ int da_encoder_forward(int precision, const da_encoder_weights *w, int n_patches
     for (int p0 = 0; p0 < n_patches; p0 += chunk) {
         const int B = n_patches - p0 < chunk ? n_patches - p0 : chunk;
         const float *px = patches + (size_t)p0 * 3 * 32 * 32;
-        if (precision == DA_PREC_BF16) k_enc_stem<bf16_t><<<B, 256, 0, st>>>(px, w->stem_w, w->stem_b, (bf16_t *)a32);
-        else k_enc_stem<float><<<B, 256, 0, st>>>(px, w->stem_w, w->stem_b, (float *)a32);
+        if (precision == DA_PREC_BF16) k_enc_stem<bf16_t><<<B, 256, 0, st>>>(px, w->stem_w, w->stem_b, (bf16_t *)a32, 1);
+        else k_enc_stem<float><<<B, 256, 0, st>>>(px, w->stem_w, w->stem_b, (float *)a32, 1);
         DA_LAUNCH_CHECK();
         char *o3 = out3 + (size_t)p0 * P8 * es, *o4 = out4 + (size_t)p0 * P4 * es;
         // layer1 (32 planes, 32x32); packed order = state-dict order: conv1, conv2 (, shortcut) per block

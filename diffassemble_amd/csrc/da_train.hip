@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_reduce_partial(int splits, int N, int K
 
 constexpr size_t PART_CAP = (size_t)16 << 20;        // floats of split-reduction scratch (64 MB)
 
-static int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                           float *partial, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int tn = (N + 63) / 64, tk = (K + 63) / 64;
@@ -489,7 +489,7 @@ int launch_transpose_f32(int rows, int cols, const float *src, float *dst, hipSt
     DA_LAUNCH_CHECK();
     return 0;
 }
-static int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch, hipStream_t st) {
+int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch, hipStream_t st) {
     const int rows_per = 128, chunks = (M + rows_per - 1) / rows_per;      // chunks * N floats of scratch
     k_colsum_partial<<<dim3((N + 63) / 64, chunks), 256, 0, st>>>(M, N, A, lda, rows_per, scratch);
     k_colsum_finish<<<(N + 255) / 256, 256, 0, st>>>(chunks, N, scratch, out);

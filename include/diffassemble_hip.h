@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 8
+#define DA_ABI_VERSION 9
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -386,6 +386,48 @@ int da_knn(int n_clouds, int n_points, int dim, const float *x, int ldx, int k, 
  * utils_3d.py:1089-1129 calc_part_acc): a [n_clouds, n, 3], b [n_clouds, m, 3] -> d_ab [n_clouds, n],
  * d_ba [n_clouds, m]; either output may be NULL. */
 int da_nearest_sq(int n_clouds, int n, int m, const float *a, const float *b, float *d_ab, float *d_ba, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Training path of the 2D piece encoder (the encoder runs in EVERY training step,
+ * model/spatial_diffusion.py:450): fp32 primitives over the zero-haloed NHWC maps [B][H+2][H+2][C4]
+ * (C4 = planes * 4, channel = plane * 4 + rotation; the halo must be zero and is never written).  Together
+ * they replace ResNet.forward in train() mode (backbones/resnet_equivariant.py:14-38,93-112: BatchNorm3d on
+ * batch statistics) and torch autograd through it, including SplitGConv2D's conv2d / trans_filter
+ * (backbones/groupy/gconv/pytorch_gconv/splitgconv2d.py:15-22,70-92).  The network walk is host logic
+ * (diffassemble_amd/encoder_train.py).  `scratch`: da_enc_train_scratch_bytes(n_patches) bytes.
+ * ------------------------------------------------------------------------------------- */
+size_t da_enc_train_scratch_bytes(int n_patches);
+
+/* Y = conv(X, W) + bias [+ res] [ReLU]: the inference kernel unfused.  X [B][Hi+2][Hi+2][Cin], W [Cout][k*k*Cin]
+ * (tap-major, channel-minor), Y [B][Hi/stride+2][..][Cout]; k in {1, 3}.  Also the DGRAD of a stride-1
+ * convolution when W holds the flipped / transposed bank; `res` (may alias Y) accumulates other paths. */
+int da_enc_conv(int precision, int B, const void *X, int Cin, int Hi, const void *W, const float *bias, const void *res,
+                void *Y, int Cout, int ksize, int stride, int relu, void *stream);
+/* stem: normalise + P4ConvZ2(3 -> 128 channels, 3x3) + bias [ReLU], patches [B,3,32,32] -> Y [B][34][34][128] */
+int da_enc_stem(int B, const float *patches, const float *w, const float *bias, float *Y, int relu, void *stream);
+/* the stem's input as GEMM rows for its weight gradient: cols [B][34][34][32] (27 taps + zero pad; zero halo) */
+int da_enc_stem_im2col(int B, const float *patches, float *cols, void *stream);
+/* nn.BatchNorm3d batch statistics: mean / biased variance per plane over (B, 4, H, W) */
+int da_enc_bn_stats(int B, int H, int C4, const float *Y, float *mean, float *var, void *scratch, void *stream);
+/* Z = (Y - mean) * (rsqrt(var + 1e-5) * gamma) + beta [+ res] [ReLU] */
+int da_enc_bn_apply(int B, int H, int C4, const float *Y, const float *mean, const float *var, const float *gamma,
+                    const float *beta, const float *res, int relu, float *Z, void *stream);
+/* backward of that unit: g = dZ [masked by Z > 0]; dgamma += sum g xhat; dbeta += sum g;
+ * dY = gamma rstd (g - mean(g) - xhat mean(g xhat)); dRes = g when non-NULL (gradient of the added tensor) */
+int da_enc_bn_backward(int B, int H, int C4, const float *dZ, const float *Z, const float *Y, const float *mean,
+                       const float *var, const float *gamma, int relu, float *dgamma, float *dbeta, float *dY,
+                       float *dRes, void *scratch, void *stream);
+/* zero-stuffing of a gradient map to twice the resolution (stride-2 layers are differentiated as stride 1) */
+int da_enc_upsample2(int B, int H, int C4, const float *S, float *Up, void *stream);
+/* C += A^T B over rows: A [M, N] (lda), B [M, K] (ldb), C [N, K] (ldc); fp32 MFMA, deterministic split over rows.
+ * One call per filter tap is a convolution's weight gradient (dY's zero halo makes the haloed maps plain
+ * GEMM operands).  scratch: 64 MB. */
+int da_gemm_tn_f32(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                   void *scratch, void *stream);
+/* out[c] += sum_m A[m][c]; scratch: ceil(M / 128) * N floats */
+int da_colsum_f32(int M, int N, const float *A, int lda, float *out, void *scratch, void *stream);
+/* dW[i] += sum_{r<4} dBank[table[4 i + r]]: backward of the filter-bank gather (trans_filter) */
+int da_enc_bank_grad(int n, const int32_t *table, const float *dbank, float *dW, void *stream);
 
 #ifdef __cplusplus
 }

@@ -44,31 +44,39 @@ def gconv(sd, key, x, stride, padding):
     return y.reshape(B, tw.shape[0] // 4, 4, y.shape[-2], y.shape[-1])
 
 
-def bn_eval(sd, key, x):
-    """nn.BatchNorm3d in eval mode over [B, C, 4, H, W]: per plane C, shared by the 4 rotations."""
+def bn_eval(sd, key, x, stats=None):
+    """nn.BatchNorm3d over [B, C, 4, H, W]: per plane C, shared by the 4 rotations.  Eval mode (running statistics);
+    with ``stats`` (a dict) TRAINING mode: batch statistics over (B, 4, H, W), biased variance for the normalisation,
+    and the running-statistics update torch applies (momentum 0.1, unbiased variance) recorded into ``stats``."""
     sh = (1, -1, 1, 1, 1)
+    if stats is not None:
+        mu, var = x.mean((0, 2, 3, 4)), x.var((0, 2, 3, 4), unbiased=False)
+        n = x.numel() // x.shape[1]
+        stats[key + ".running_mean"] = (0.9 * sd[key + ".running_mean"] + 0.1 * mu).detach()
+        stats[key + ".running_var"] = (0.9 * sd[key + ".running_var"] + 0.1 * var * n / (n - 1)).detach()
+        return (x - mu.view(sh)) * (torch.rsqrt(var + BN_EPS) * sd[key + ".weight"]).view(sh) + sd[key + ".bias"].view(sh)
     inv = torch.rsqrt(sd[key + ".running_var"] + BN_EPS) * sd[key + ".weight"]
     return (x - sd[key + ".running_mean"].view(sh)) * inv.view(sh) + sd[key + ".bias"].view(sh)
 
 
-def basic_block(sd, p, x, stride, has_shortcut):
+def basic_block(sd, p, x, stride, has_shortcut, stats=None):
     """resnet_equivariant.py:33-38."""
-    out = F.relu(bn_eval(sd, p + "bn1", gconv(sd, p + "conv1", x, stride, 1)))
-    out = bn_eval(sd, p + "bn2", gconv(sd, p + "conv2", out, 1, 1))
-    sc = bn_eval(sd, p + "shortcut.1", gconv(sd, p + "shortcut.0", x, stride, 0)) if has_shortcut else x
+    out = F.relu(bn_eval(sd, p + "bn1", gconv(sd, p + "conv1", x, stride, 1), stats))
+    out = bn_eval(sd, p + "bn2", gconv(sd, p + "conv2", out, 1, 1), stats)
+    sc = bn_eval(sd, p + "shortcut.1", gconv(sd, p + "shortcut.0", x, stride, 0), stats) if has_shortcut else x
     return F.relu(out + sc)
 
 
-def resnet18_p4(sd, x, collect=None):
-    """resnet_equivariant.py:93-112 -> [out1, out2, linear1(out3), linear2(out4)]."""
+def resnet18_p4(sd, x, collect=None, stats=None):
+    """resnet_equivariant.py:93-112 -> [out1, out2, linear1(out3), linear2(out4)].  ``stats``: see bn_eval."""
     B = x.shape[0]
-    out = F.relu(bn_eval(sd, "bn1", gconv(sd, "conv1", x, 1, 1)))
+    out = F.relu(bn_eval(sd, "bn1", gconv(sd, "conv1", x, 1, 1), stats))
     outs = []
     for li in range(1, 5):
         for bi in range(2):
             p = f"layer{li}.{bi}."
             stride = 2 if (li > 1 and bi == 0) else 1
-            out = basic_block(sd, p, out, stride, (p + "shortcut.0.weight") in sd)
+            out = basic_block(sd, p, out, stride, (p + "shortcut.0.weight") in sd, stats)
         outs.append(out)
         if collect is not None:
             collect.append(out)
@@ -81,10 +89,12 @@ MEAN = torch.tensor([0.4850, 0.4560, 0.4060])[None, :, None, None]     # efficie
 STD = torch.tensor([0.2290, 0.2240, 0.2250])[None, :, None, None]
 
 
-def visual_features(sd, patch_rgb, collect=None):
+def visual_features(sd, patch_rgb, collect=None, stats=None):
     """Eff_GAT.visual_features for model='resnet18equiv', all_equivariant=False
-    (efficient_gat.py:149-189): [N, 3, 32, 32] -> patch_feats [N, 1088]."""
-    feats = resnet18_p4(sd, (patch_rgb - MEAN) / STD, collect)
+    (efficient_gat.py:149-189): [N, 3, 32, 32] -> patch_feats [N, 1088].  With ``stats`` (a dict) the BatchNorms run in
+    TRAINING mode, as they do inside ``training_step`` (spatial_diffusion.py:450); torch autograd through this function
+    is the gradient oracle of the encoder's backward."""
+    feats = resnet18_p4(sd, (patch_rgb - MEAN) / STD, collect, stats)
     n = patch_rgb.shape[0]
     return torch.cat([feats[2].reshape(n, -1), feats[3].reshape(n, -1)], -1)
 
