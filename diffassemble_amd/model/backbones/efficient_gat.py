@@ -67,9 +67,11 @@ class Eff_GAT(DenoiserBase):
 
     def visual_features(self, patch_rgb):
         """efficient_gat.py:149-189: normalise, piece encoder, concat feature maps 2 and 3 -> [N, 1088].
-        ``model='resnet18equiv'`` (the reference's in-tree P4-equivariant ResNet-18) runs in the HIP library
-        (da_encoder_forward, eval-mode BatchNorm); the timm encoders are third-party and, when timm
-        is importable, run as plain torch outside the accelerated path."""
+        ``model='resnet18equiv'`` (the reference's in-tree P4-equivariant ResNet-18) runs in the HIP library: eval mode
+        through da_encoder_forward (BatchNorm folded), train() mode -- batch statistics, trainable unless
+        ``freeze_backbone`` -- through the da_enc_* training primitives with the backward joined to autograd
+        (SURVEY 8f-2); the timm encoders are third-party and, when timm is importable, run as plain torch outside the
+        accelerated path."""
         if self.visual_backbone is None:
             raise NotImplementedError(
                 "no piece encoder available (timm / equivariant ResNet are outside the hot path): "
@@ -82,7 +84,11 @@ class Eff_GAT(DenoiserBase):
                 n = patch_rgb.shape[0]
                 views = patch_rgb.transpose(0, 1).reshape(4 * n, *patch_rgb.shape[2:])
                 return self.visual_backbone.patch_features(views).float().view(4, n, -1).mean(0)
-            feats = self.visual_backbone.patch_features(patch_rgb)    # normalise + encoder + cat, all in HIP
+            if self.freeze_backbone:                                   # efficient_gat.py:152-154
+                with torch.no_grad():
+                    feats = self.visual_backbone.patch_features(patch_rgb)
+            else:
+                feats = self.visual_backbone.patch_features(patch_rgb)    # normalise + encoder + cat, all in HIP
             return feats.float()
         patch_rgb = (patch_rgb - self.mean) / self.std
         if self.freeze_backbone:

@@ -4,10 +4,12 @@ state-dict keys (``conv1.weight [32,3,1,3,3]``, ``layerL.B.conv{1,2}.weight [O,I
 ``layerL.0.shortcut.{0,1}.*``, BatchNorm3d ``weight/bias/running_mean/running_var/num_batches_tracked``,
 ``linear1 [544,16384]``, ``linear2 [544,8192]``), so checkpoints load unchanged.
 
-The modules only HOLD parameters; the arithmetic of an eval-mode forward runs in
-libdiffassemble_hip.so through ``diffassemble_amd.encoder.EncoderEngine`` (no torch fallback).
-Training-mode BatchNorm (batch statistics + backward through the encoder) is not built: calling the
-encoder in training mode raises.
+The modules only HOLD parameters.  The arithmetic of an eval-mode forward runs in libdiffassemble_hip.so through
+``diffassemble_amd.encoder.EncoderEngine`` (BatchNorm folded, bf16 or fp32); in train() mode -- BatchNorm3d on batch
+statistics, the reference's behaviour inside ``training_step`` -- forward AND backward run through
+``diffassemble_amd.encoder_train.EncoderTrainEngine`` (fp32 HIP primitives), joined to torch autograd by
+``_EncoderTrainFunction``: gradients land in ``param.grad``, running statistics are updated like torch does.  No torch
+fallback in either mode.
 """
 import math
 
@@ -15,6 +17,22 @@ import torch
 import torch.nn as nn
 
 from ...encoder import EncoderEngine
+
+
+class _EncoderTrainFunction(torch.autograd.Function):
+    """patch_feats = encoder(patches) in train() mode.  The parameters are passed so that the output joins the autograd
+    graph; their gradients are ADDED into ``param.grad`` by the engine, so ``None`` is returned for them (and for the
+    pixels).  One forward must be followed by its backward before the next forward (the engine owns the activations)."""
+
+    @staticmethod
+    def forward(ctx, eng, patches, *params):
+        ctx.eng, ctx.n_params = eng, len(params)
+        return eng.forward(patches).clone()
+
+    @staticmethod
+    def backward(ctx, d_feats):
+        ctx.eng.backward(d_feats)
+        return (None, None) + (None,) * ctx.n_params
 
 
 class _GConv(nn.Module):
@@ -68,10 +86,11 @@ class ResNet(nn.Module):
         self.linear2 = nn.Linear(128 * 4 * 4 * 4, 544)
         self._engine = None
         self._engine_key = None
-        # The reference's "frozen" encoder (freeze_backbone=True) still runs BatchNorm on BATCH statistics while
-        # the LightningModule is in train mode.  That mode is not built; set this to True to train the denoiser
-        # on features of the encoder's RUNNING statistics instead (what a frozen encoder usually means) -- a
-        # documented deviation from the reference, off by default.
+        self._train_engine = None
+        # Set to True to run a FROZEN encoder on its RUNNING statistics while the LightningModule is in train mode (what
+        # "frozen" usually means).  The reference's freeze_backbone=True still normalises with batch statistics
+        # (efficient_gat.py:152-154 under model.train()), which is what happens here by default: train() mode = batch
+        # statistics, with or without gradients.
         self.frozen_eval_stats = False
 
     def engine(self):
@@ -88,10 +107,12 @@ class ResNet(nn.Module):
         """[N, 3, 32, 32] in [0, 1], NOT normalised (the kernel normalises) -> [N, 1088] =
         cat(linear1(out3), linear2(out4)), the two maps Eff_GAT.visual_features keeps."""
         if self.training and not self.frozen_eval_stats:
-            raise NotImplementedError(
-                "the HIP piece encoder implements eval-mode BatchNorm only; call .eval() (sampling / validation), "
-                "set visual_backbone.frozen_eval_stats = True (frozen encoder on its running statistics) "
-                "or pass precomputed patch_feats when training")
+            if self._train_engine is None or self._train_engine.device != patch_rgb.device:
+                from ...encoder_train import EncoderTrainEngine
+                self._train_engine = EncoderTrainEngine(self, patch_rgb.device)
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                return _EncoderTrainFunction.apply(self._train_engine, patch_rgb, *self.parameters())
+            return self._train_engine.forward(patch_rgb).clone()           # frozen (no_grad) encoder in train mode
         return self.engine().forward(patch_rgb)
 
     def forward(self, x):

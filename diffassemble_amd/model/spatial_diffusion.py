@@ -320,6 +320,19 @@ class GNN_Diffusion(LightningModule):
         te = getattr(self.model, "_train_engine", None)
         if te is not None:
             te.sync_gradients()
+        enc = getattr(self.model, "visual_backbone", None)
+        if enc is not None and getattr(enc, "_train_engine", None) is not None:
+            # the encoder's HIP backward also writes param.grad directly: one more flat all-reduce (11 M values)
+            from ..sharding import allreduce_gradients
+            import torch.distributed as dist
+            grads = [p.grad for p in enc.parameters() if p.grad is not None]
+            if grads and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                allreduce_gradients(flat, average=True)
+                off = 0
+                for g in grads:
+                    g.copy_(flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
 
     def on_before_optimizer_step(self, optimizer=None, *args, **kwargs):
         """The reference relies on ``pl.Trainer(strategy="ddp")`` (train_script.py:215-218) to average

@@ -93,9 +93,9 @@ def test_eff_gat_forward_from_pixels(dev):
         feats = OE.visual_features(esd, patches)
         ref, _ = OD.eff_gat_forward_with_feats(dsd, xy, t, ei, feats, batch, arch="transformer")
         assert rel(out, ref) < 2e-4
-        m.train()
-        with pytest.raises(NotImplementedError):
-            m.visual_features(patches.to(dev))
+        m.train()                                   # BatchNorm on batch statistics (tests/test_gpu_encoder_train.py)
+        ft = m.visual_features(patches.to(dev))
+        assert rel(ft, OE.visual_features(esd, patches, stats={})) < 1e-4 and ft.requires_grad
     finally:
         _os.environ.pop("DIFFASSEMBLE_PRECISION", None)
 
@@ -155,8 +155,6 @@ def test_training_step_from_pixels_with_frozen_encoder(dev):
     dsd, esd = W.make_denoiser_state(T, 4, 4, seed=31), W.make_encoder_state(31)
     m.model.load_state_dict({**dsd, **{"visual_backbone." + k: v for k, v in esd.items()}}, strict=False)
     m = m.to(dev).train()
-    with pytest.raises(NotImplementedError):
-        m.model.visual_features(W.make_patches(2, 0).to(dev))
     m.model.visual_backbone.frozen_eval_stats = True
     m.model.precision = "fp32"
     rng = np.random.default_rng(4)
@@ -175,6 +173,50 @@ def test_training_step_from_pixels_with_frozen_encoder(dev):
     assert rel(loss, ref) < 1e-4
     g = dict(m.model.named_parameters())["final_mlp.0.weight"].grad
     assert rel(g, sd_ref["final_mlp.0.weight"].grad) < 1e-3
+
+
+def test_training_step_from_pixels_trains_the_encoder(dev):
+    """The scripted configuration (--backbone resnet18equiv, freeze_backbone False): p_losses(cond = crops) in train()
+    mode runs the encoder on BATCH statistics, and loss.backward() reaches the encoder's parameters through the denoiser's
+    d_feats.  Loss, a denoiser gradient and encoder gradients (last block: tight; stem: the chaotic-backward tolerance of
+    tests/test_gpu_encoder_train.py) against torch autograd through oracle encoder (training mode) + oracle p_losses."""
+    from oracle import diffusion as ODF
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    T, n = 100, 36
+    m = GNN_Diffusion(steps=T, sampling="DDIM", rotation=True, model_mean_type=ModelMeanType.EPSILON,
+                      visual_pretrained=False, backbone="resnet18equiv", freeze_backbone=False)
+    dsd, esd = W.make_denoiser_state(T, 4, 4, seed=32), W.make_encoder_state(32)
+    m.model.load_state_dict({**dsd, **{"visual_backbone." + k: v for k, v in esd.items()}}, strict=False)
+    m = m.to(dev).train()
+    m.model.precision = "fp32"
+    rng = np.random.default_rng(5)
+    x0 = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32))
+    noise = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32))
+    t = torch.full((n,), 41, dtype=torch.int64)
+    patches = W.make_patches(n, 7)
+    ei, batch = W.dense_edge_index(n, True), torch.zeros(n, dtype=torch.int64)
+    loss = m.p_losses(x0.to(dev), t.to(dev), noise=noise.to(dev), loss_type="huber", cond=patches.to(dev),
+                      edge_index=ei.to(dev), batch=batch.to(dev))
+    loss.backward()
+    sd_ref = {k: v.double().clone().requires_grad_(True) for k, v in dsd.items()}
+    e_ref = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v))
+             for k, v in esd.items()}
+    OE.MEAN, OE.STD = OE.MEAN.double(), OE.STD.double()
+    try:
+        feats = OE.visual_features(e_ref, patches.double(), stats={})
+    finally:
+        OE.MEAN, OE.STD = OE.MEAN.float(), OE.STD.float()
+    ref = ODF.p_losses(sd_ref, ODF.make_schedule(T), x0.double(), t, noise.double(), ei, feats, batch, mean_type="EPSILON")
+    ref.backward()
+    assert rel(loss, ref) < 1e-4
+    P = dict(m.model.named_parameters())
+    assert rel(P["final_mlp.0.weight"].grad, sd_ref["final_mlp.0.weight"].grad) < 1e-3
+    assert rel(P["visual_backbone.linear2.weight"].grad, e_ref["linear2.weight"].grad) < 1e-3
+    assert rel(P["visual_backbone.layer4.1.bn2.weight"].grad, e_ref["layer4.1.bn2.weight"].grad) < 2e-2
+    for k in ("conv1.weight", "layer1.0.conv1.weight", "layer2.0.shortcut.0.weight"):
+        g, r = P["visual_backbone." + k].grad, e_ref[k].grad
+        assert abs(float(g.abs().sum()) - float(r.abs().sum())) <= 5e-3 * float(r.abs().sum()) and rel(g, r) < 5e-2, k
+    assert int(m.model.visual_backbone.bn1.num_batches_tracked) == 101
 
 
 def test_full_size_properties(dev):
