@@ -301,14 +301,18 @@ class GNN_Diffusion(LightningModule):
 
     # ------------------------------------------------------------------ Lightning hooks (callers)
     def configure_optimizers(self):
-        """spatial_diffusion.py:701-705: Adafactor with transformers' defaults.  On a ROCm device, when only
-        the denoiser trains (no piece encoder attached), the same update runs as one library call over the
-        training engine's flat buffers (``FusedAdafactor`` -> da_adafactor_step); set
-        DIFFASSEMBLE_FUSED_OPTIMIZER=0 for transformers' own implementation."""
+        """spatial_diffusion.py:701-705: Adafactor with transformers' defaults.  On a ROCm device the denoiser's update
+        runs as one library call over the training engine's flat buffers (``FusedAdafactor`` -> da_adafactor_step); with
+        a piece encoder attached its parameters keep transformers' implementation (``HybridAdafactor``).  Set
+        DIFFASSEMBLE_FUSED_OPTIMIZER=0 for transformers' own implementation throughout."""
         fused = os.environ.get("DIFFASSEMBLE_FUSED_OPTIMIZER", "1") != "0"
         if fused and self.device.type == "cuda" and getattr(self.model, "visual_backbone", None) is None:
             from ..train import FusedAdafactor
             return FusedAdafactor(self.parameters(), self.model.train_engine(self.device))
+        if fused and self.device.type == "cuda":
+            # trainable piece encoder attached: fused update for the denoiser, transformers' Adafactor (same rule) for the rest
+            from ..train import HybridAdafactor
+            return HybridAdafactor(self.parameters(), self.model.train_engine(self.device))
         from transformers.optimization import Adafactor
         return Adafactor(self.parameters())
 

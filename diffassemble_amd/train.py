@@ -288,3 +288,33 @@ class FusedAdafactor(torch.optim.Optimizer):
                 self.step_count, g["eps"][0], g["eps"][1], g["clip_threshold"], g["decay_rate"],
                 _lib.stream_ptr(eng.device)))
         return loss
+
+
+class HybridAdafactor(torch.optim.Optimizer):
+    """The reference's single ``Adafactor(self.parameters())`` (spatial_diffusion.py:701-705) when a trainable piece
+    encoder is attached: the denoiser's parameters go through ``FusedAdafactor`` (one library call over the flat buffers),
+    every other parameter with a gradient (the encoder's 5-D group-convolution weights, BatchNorm affines, the two wide
+    linears -- shapes the fused kernel's row / column tables do not cover) through transformers' own Adafactor with the
+    same defaults, so the update rule is the reference's for all of them.  Presents itself as ONE optimizer (Lightning's
+    automatic optimisation wants exactly one)."""
+
+    def __init__(self, params, engine: TrainEngine):
+        from transformers.optimization import Adafactor
+        params = list(params)
+        mine = {id(p) for p in engine.params}
+        rest = [p for p in params if id(p) not in mine and p.requires_grad]
+        super().__init__(params, {})
+        self.fused = FusedAdafactor([p for p in params if id(p) in mine], engine)
+        self.rest = Adafactor(rest) if rest else None
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.fused.zero_grad(set_to_none)
+        if self.rest is not None:
+            self.rest.zero_grad(set_to_none)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = self.fused.step(closure)
+        if self.rest is not None and any(p.grad is not None for g in self.rest.param_groups for p in g["params"]):
+            self.rest.step()
+        return loss

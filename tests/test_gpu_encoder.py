@@ -219,6 +219,69 @@ def test_training_step_from_pixels_trains_the_encoder(dev):
     assert int(m.model.visual_backbone.bn1.num_batches_tracked) == 101
 
 
+def test_optimizer_steps_from_pixels_update_encoder_and_denoiser(dev):
+    """configure_optimizers() with a trainable encoder = HybridAdafactor (fused denoiser update + transformers' Adafactor for
+    the encoder): after one step from pixels every trained tensor matches the reference's optimizer applied to the oracle's
+    autograd gradients; a few more steps on the same Batch reduce the loss; eval() afterwards runs on the updated weights
+    and running statistics (packed inference weights are rebuilt)."""
+    from oracle import diffusion as ODF
+    from transformers.optimization import Adafactor
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    T, n = 100, 36
+    m = GNN_Diffusion(steps=T, sampling="DDIM", rotation=True, model_mean_type=ModelMeanType.EPSILON,
+                      visual_pretrained=False, backbone="resnet18equiv", freeze_backbone=False)
+    dsd, esd = W.make_denoiser_state(T, 4, 4, seed=33), W.make_encoder_state(33)
+    m.model.load_state_dict({**dsd, **{"visual_backbone." + k: v for k, v in esd.items()}}, strict=False)
+    m = m.to(dev).train()
+    m.model.precision = "fp32"
+    opt = m.configure_optimizers()
+    assert type(opt).__name__ == "HybridAdafactor"
+    rng = np.random.default_rng(6)
+    x0 = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32))
+    noise = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32))
+    t = torch.full((n,), 23, dtype=torch.int64)
+    patches = W.make_patches(n, 8)
+    ei, batch = W.dense_edge_index(n, True), torch.zeros(n, dtype=torch.int64)
+
+    def step():
+        opt.zero_grad()
+        loss = m.p_losses(x0.to(dev), t.to(dev), noise=noise.to(dev), loss_type="huber", cond=patches.to(dev),
+                          edge_index=ei.to(dev), batch=batch.to(dev))
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    l0 = step()
+    # reference: oracle forward (training-mode encoder) + autograd + transformers' Adafactor on all live tensors
+    ref = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    eref = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in esd.items()}
+    live = [v for v in list(ref.values()) + list(eref.values()) if torch.is_tensor(v) and v.requires_grad]
+    ropt = Adafactor(live)
+    lr = ODF.p_losses(ref, ODF.make_schedule(T), x0, t, noise, ei, OE.visual_features(eref, patches, stats={}), batch, mean_type="EPSILON")
+    lr.backward()
+    ropt.step()
+    assert abs(l0 - float(lr)) < 1e-4 * abs(float(lr))
+    P = dict(m.model.named_parameters())
+    for k in ("mlp.0.weight", "final_mlp.2.bias", "gnn_backbone.module_list.3.lin_value.weight"):
+        assert rel(P[k], ref[k]) < 1e-4, k
+    for k in ("linear2.weight", "linear2.bias", "linear1.weight"):
+        assert rel(P["visual_backbone." + k], eref[k]) < 1e-4, k
+    # Adafactor normalises every [3, 3] filter slice of a 5-D weight by that slice's OWN second moments, so slices whose
+    # gradient is all noise (the chaotic part of the backward, tests/test_gpu_encoder_train.py) get O(1) normalised updates
+    # made of that noise: compare the STEP as a whole (cosine against the reference's step), not entry by entry
+    for k in ("layer4.1.conv2.weight", "layer4.1.bn2.bias", "layer2.0.shortcut.0.weight", "conv1.weight", "bn1.weight"):
+        d_got = (P["visual_backbone." + k].detach().cpu() - esd[k]).double().flatten()
+        d_ref = (eref[k].detach() - esd[k]).double().flatten()
+        cos = float((d_got @ d_ref) / (d_got.norm() * d_ref.norm() + 1e-30))
+        assert float(d_got.norm()) > 0 and cos > 0.98, (k, cos)
+    losses = [l0] + [step() for _ in range(4)]
+    assert losses[-1] < losses[0]
+    m.eval()
+    f_eval = m.model.visual_features(patches[:5].to(dev))
+    sd_now = {k: v.detach().cpu() for k, v in m.model.visual_backbone.state_dict().items()}
+    assert rel(f_eval, OE.visual_features(sd_now, patches[:5])) < 1e-4
+
+
 def test_full_size_properties(dev):
     """BASELINE-size batch (the 28 800 crops of 32 900-piece puzzles) through size-independent properties: a
     piece's features depend on nothing but the piece -- permuting the batch permutes the rows bit for bit, a
