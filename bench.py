@@ -286,12 +286,14 @@ def train_bench(args, world, rank, dev):
     from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
     n, G, K, Wm = 144, args.train_puzzles, args.steps, args.warmup
     torch.manual_seed(0)
+    pixels = bool(args.pixels)               # --pixels: the scripted configuration, encoder trained from the 32x32 crops
     m = GNN_Diffusion(steps=T_STEPS, sampling="DDIM", rotation=True, visual_pretrained=False,
-                      model_mean_type=ModelMeanType.EPSILON)
+                      model_mean_type=ModelMeanType.EPSILON, **({"backbone": "resnet18equiv", "freeze_backbone": False} if pixels else {}))
     m = m.to(dev).train()
     opt = m.configure_optimizers()
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
-    feats = torch.randn((G * n, 1088), generator=gen, device=dev)
+    feats = None if pixels else torch.randn((G * n, 1088), generator=gen, device=dev)
+    crops = torch.rand((G * n, 3, 32, 32), generator=gen, device=dev) if pixels else None
     x0 = torch.randn((G * n, 4), generator=gen, device=dev)
     ei, batch = dense_batch(G, n, dev)
     te = m.model.train_engine(dev)
@@ -302,10 +304,10 @@ def train_bench(args, world, rank, dev):
         t = torch.randint(0, T_STEPS, (G,), generator=gen, device=dev)[batch]
         opt.zero_grad()
         if timed: ev[0].record()
-        loss = m.p_losses(x0, t, loss_type="huber", cond=None, edge_index=ei, batch=batch, patch_feats=feats)
+        loss = m.p_losses(x0, t, loss_type="huber", cond=crops, edge_index=ei, batch=batch, patch_feats=feats)
         loss.backward()
         if timed: ev[1].record()
-        te.sync_gradients()                       # ONE fused all-reduce (FusedAdafactor.step would do it otherwise)
+        m.sync_gradients()                        # ONE fused all-reduce (+ the encoder's flat one with --pixels)
         if timed: ev[2].record()
         opt.step()
         if timed:
@@ -340,7 +342,9 @@ def train_bench(args, world, rank, dev):
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32", "data": "synthetic",
             "config": {"workload": "BASELINE config 5: 12x12 rot dense (N=144, E=20736), G per GPU below, huber, "
-                                   "EPSILON, one Adafactor step; denoiser only (piece features synthetic)",
+                                   "EPSILON, one Adafactor step; " +
+                                   ("encoder (P4 ResNet-18, batch-statistics BatchNorm) + denoiser trained from 32x32 crops"
+                                    if pixels else "denoiser only (piece features synthetic)"),
                        "puzzles_per_gpu": G, "global_puzzles": world * G,
                        "parallelism": f"data parallel x{world}, one fused gradient all-reduce"},
             "optimizer_steps_per_s": K / dt,
@@ -774,6 +778,8 @@ def main():
                     help="--mode encode: pieces per encoder chunk (0 = engine default)")
     ap.add_argument("--train-puzzles", type=int, default=int(os.environ.get("BENCH_TRAIN_PUZZLES", 64)),
                     help="--mode train: 12x12 puzzles per GPU")
+    ap.add_argument("--pixels", action="store_true",
+                    help="--mode train: train the piece encoder too, from 32x32 crops (the scripted --backbone resnet18equiv)")
     ap.add_argument("--replays", type=int, default=30, help="extra individually timed graph replays for the median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle with ONE thread at full size")

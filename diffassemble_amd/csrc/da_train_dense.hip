@@ -149,8 +149,10 @@ __global__ __launch_bounds__(256) void k_pair_rows(int mode, int n_nodes, int H,
                                                    const int32_t *__restrict__ node_graph, const long long *__restrict__ poff,
                                                    float *P, float *dP) {
     const int lane = threadIdx.x & 63;
-    const long long wv = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wv >= (long long)n_nodes * H) return;
+    // grid-stride over the (node, head) rows: the launch caps the grid (gridsz), a Batch has more rows than that cap
+    // covers from 4 097 nodes on (the first version returned for them and left raw scores in P)
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long wv = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < (long long)n_nodes * H; wv += n_waves) {
     const int node = (int)(wv / H), h = (int)(wv - (long long)node * H);
     const int g = node_graph[node], n_g = gp[g + 1] - gp[g], i = node - gp[g];
     const int ldp = (n_g + 3) & ~3;
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) void k_pair_rows(int mode, int n_nodes, int H,
         for (int j = lane; j < n_g; j += 64) D = fmaf(row[j], drow[j], D);
         for (int o = 32; o > 0; o >>= 1) D += __shfl_xor(D, o);
         for (int j = lane; j < n_g; j += 64) drow[j] = row[j] * (drow[j] - D);
+    }
     }
 }
 

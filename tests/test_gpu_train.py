@@ -93,6 +93,32 @@ def test_backward_matches_oracle_autograd(dev, name):
     assert all(lo <= params[k].grad.data_ptr() < hi for k in g_ref)
 
 
+def test_large_batch_dense_training_rows_beyond_the_grid_cap(dev):
+    """30 puzzles of 12x12 = 4 320 nodes x 8 heads = 34 560 attention rows: more than the 32 768 rows the capped launch of
+    the dense training softmax covers in one pass (the rows beyond it used to keep raw scores instead of probabilities --
+    invisible at the near-uniform attention of a fresh model, catastrophic once the scores grow).  Sharp attention
+    (qk_gain) makes the difference decisive; forward, loss and gradients against the oracle."""
+    spec = dict(name="rot144_g30_sharp", sizes=[144] * 30, arch="transformer", V=0, graph="dense", c=4, steps=100, seed=77,
+                qk_gain=6.0)
+    case = C.build_case(spec)
+    rng = np.random.default_rng(18)
+    target = torch.from_numpy(rng.standard_normal(tuple(case["x"].shape)).astype(np.float32))
+    pred_ref, loss_ref, g_ref, gf_ref = oracle_grads(spec, case, case["x"], target)
+    m = make_module(spec, case, dev)
+    feats = case["feats"].to(dev).requires_grad_(True)
+    out, _ = m.forward_with_feats(case["x"].to(dev), case["t"].to(dev), None, case["edge_index"].to(dev), feats, case["batch"].to(dev))
+    assert rel(out, pred_ref) < 1e-4
+    assert rel(out[-144:], pred_ref[-144:]) < 1e-4            # the last puzzle: rows far beyond the cap
+    loss = F.smooth_l1_loss(target.to(dev), out)
+    loss.backward()
+    assert rel(loss, loss_ref) < 1e-5
+    params = dict(m.named_parameters())
+    for k in ("gnn_backbone.module_list.0.lin_query.weight", "gnn_backbone.module_list.3.lin_value.weight", "mlp.0.weight",
+              "final_mlp.2.weight"):
+        assert rel(params[k].grad, g_ref[k]) < GTOL, k
+    assert rel(feats.grad, gf_ref) < GTOL and rel(feats.grad[-144:], gf_ref[-144:]) < 10 * GTOL
+
+
 def test_gradient_accumulation_and_zeroing(dev):
     """Two backward passes accumulate like autograd; zero_grad(set_to_none=True) restarts from zero."""
     spec = C.by_name("k36_loop_sharp")
