@@ -226,7 +226,7 @@ def test_encoder_packing_folds_batchnorm_and_relayouts_linears():
 
 def test_encoder_module_has_the_reference_state_dict_layout():
     """ResNet18() keys / shapes = what the reference's resnet_equivariant.ResNet18().state_dict() holds (dumped in
-    the survey probe), and the encoder refuses to run without a ROCm device or in train mode."""
+    the survey probe), and the encoder refuses to run without a ROCm device, in train() and in eval() mode alike."""
     from diffassemble_amd.model.backbones.resnet_equivariant import ResNet18
     net = ResNet18()
     sd = net.state_dict()
@@ -235,8 +235,9 @@ def test_encoder_module_has_the_reference_state_dict_layout():
     for k in ref:
         assert tuple(sd[k].shape) == tuple(ref[k].shape), k
     net.load_state_dict(ref)
-    with pytest.raises(NotImplementedError):
-        net.patch_features(torch.zeros(1, 3, 32, 32))                   # train mode
+    with pytest.raises(Exception) as ei:
+        net.patch_features(torch.zeros(1, 3, 32, 32))                   # train mode (batch statistics): no CPU path either
+    assert "ROCm" in str(ei.value)
     net.eval()
     with pytest.raises(Exception) as ei:
         net.patch_features(torch.zeros(1, 3, 32, 32))                   # CPU tensor / no GPU: loud failure
