@@ -95,7 +95,9 @@ __device__ __forceinline__ int select_topk(const float *row, int Npad, int k, in
 // instructions: the scores become order-preserving 32-bit keys, the k-th largest key tau is built bit by bit (32 rounds
 // of "how many keys >= candidate": one v_cmp per register, the counting is s_bcnt1 on the ballot masks), then the keys
 // > tau and the first k - count(> tau) keys == tau (lowest indices first, the ordered variant's tie rule) are compacted
-// into dst[0..k) through mbcnt prefix counts.
+// into dst[0..k) through mbcnt prefix counts.  The rounds are bound by the SCALAR unit (s_bcnt1 + s_add per register, one
+// scalar instruction per cycle per CU): bracketing tau between the k-th largest lane maximum and the maximum (fewer
+// 16-register rounds, 32 one-register rounds more) and searching two queries of a wave jointly both measured SLOWER (+13 %).
 template <int NR>
 __device__ __forceinline__ void select_set(const float *row, int Npad, int N, int k, int lane, int32_t *dst) {
     unsigned u[NR];
@@ -254,18 +256,32 @@ __global__ __launch_bounds__(256) void k_pcd_premap(const float *__restrict__ X,
 #pragma unroll
     for (int e = 0; e < C * 3; ++e) x[e] = X[p * ldx + e];
     float *t = T + p * 4 * VROW;
+    // four output channels (12 floats = three 16-byte stores) at a time: a thread owns a whole 1 KB row of T, so every
+    // store instruction touches 64 different lines -- 4-byte stores made this kernel store-bound (0.67 -> 0.34 ms)
     for (int m = 0; m < 4; ++m) {
-        for (int o = 0; o < VC; ++o) {
-            const float *w = Wm + (m * VC + o) * C;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 1
+        for (int o0 = 0; o0 < 24; o0 += 4) {
+            float a[12];
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float wv = w[c];
-                a0 += wv * x[c * 3]; a1 += wv * x[c * 3 + 1]; a2 += wv * x[c * 3 + 2];
+            for (int q = 0; q < 4; ++q) {
+                const int o = o0 + q < VC ? o0 + q : VC - 1;          // rows 21..23 of the padded segment: recomputed, masked below
+                const float *w = Wm + (m * VC + o) * C;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float wv = w[c];
+                    a0 += wv * x[c * 3]; a1 += wv * x[c * 3 + 1]; a2 += wv * x[c * 3 + 2];
+                }
+                const bool on = o0 + q < VC;
+                a[q * 3] = on ? a0 : 0.f; a[q * 3 + 1] = on ? a1 : 0.f; a[q * 3 + 2] = on ? a2 : 0.f;
             }
-            t[m * VROW + o * 3] = a0; t[m * VROW + o * 3 + 1] = a1; t[m * VROW + o * 3 + 2] = a2;
+            if (o0 < 20) {
+#pragma unroll
+                for (int e = 0; e < 12; e += 4) *(float4 *)(t + m * VROW + o0 * 3 + e) = float4{a[e], a[e + 1], a[e + 2], a[e + 3]};
+            } else {                                                   // channel 20 + the pad: floats 60..63
+                *(float4 *)(t + m * VROW + 60) = float4{a[0], a[1], a[2], 0.f};
+            }
         }
-        t[m * VROW + V3] = 0.f;
     }
 }
 
