@@ -252,6 +252,54 @@ class FusedAdafactor(torch.optim.Optimizer):
         self.scratch = torch.empty(2 * self.n_blocks + 4 * self.n_params + c_off + 64, dtype=torch.float32, device=dev)
         self.step_count = 0
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def _slots(self):
+        """(index in the optimizer's parameter list, parameter, view, (rows, cols, factored, row_off, col_off))"""
+        order = {id(p): i for i, p in enumerate(q for g in self.param_groups for q in g["params"])}
+        tab = self.ptab.cpu().numpy().view("int32").reshape(self.n_params, 14)
+        for pid, (p, v) in enumerate(zip(self.engine.params, self.engine.views)):
+            r = tab[pid]
+            row_off = int(r[6:8].view("int64")[0])
+            col_off = int(r[8:10].view("int64")[0])
+            yield order[id(p)], p, v, (int(r[2]), int(r[3]), bool(r[4]), row_off, col_off)
+
+    def state_dict(self):
+        """The second-moment statistics in transformers' per-parameter layout (``step``, ``exp_avg_sq_row`` [shape[:-1]],
+        ``exp_avg_sq_col`` [shape[:-2] + shape[-1:]] for matrices, ``exp_avg_sq`` for vectors), keyed by the parameter's index
+        in this optimizer: what ``Adafactor(...).state_dict()`` holds, so Lightning's checkpoint / resume keeps them (the
+        base class would save an empty state: the statistics live in one flat device buffer)."""
+        sd = super().state_dict()
+        state = {}
+        for idx, p, v, (rows, cols, fact, ro, co) in self._slots():
+            st = {"step": self.step_count}
+            if fact:
+                st["exp_avg_sq_row"] = self.state_buf[ro:ro + rows].clone().view(v.shape[:-1])
+                st["exp_avg_sq_col"] = self.state_buf[co:co + cols].clone().view(v.shape[:-2] + v.shape[-1:])
+            else:
+                st["exp_avg_sq"] = self.state_buf[ro:ro + cols].clone().view(v.shape)
+            state[idx] = st
+        sd["state"] = state
+        return sd
+
+    def load_state_dict(self, sd):
+        state = sd.get("state", {})
+        steps = set()
+        with torch.no_grad():
+            for idx, p, v, (rows, cols, fact, ro, co) in self._slots():
+                st = state.get(idx, state.get(str(idx)))
+                if st is None:
+                    continue
+                steps.add(int(st["step"]))
+                if fact:
+                    self.state_buf[ro:ro + rows].copy_(st["exp_avg_sq_row"].reshape(-1))
+                    self.state_buf[co:co + cols].copy_(st["exp_avg_sq_col"].reshape(-1))
+                else:
+                    self.state_buf[ro:ro + cols].copy_(st["exp_avg_sq"].reshape(-1))
+        if len(steps) > 1:
+            raise _lib.DaError(f"FusedAdafactor.load_state_dict: parameters at different steps {sorted(steps)}")
+        if steps:
+            self.step_count = steps.pop()
+
     def zero_grad(self, set_to_none: bool = True):
         """One fill of the flat gradient buffer (the views stay attached as ``.grad``) instead of one
         launch per parameter; parameters outside the engine are handled the usual way."""
@@ -311,6 +359,15 @@ class HybridAdafactor(torch.optim.Optimizer):
         self.fused.zero_grad(set_to_none)
         if self.rest is not None:
             self.rest.zero_grad(set_to_none)
+
+    def state_dict(self):
+        return {"fused": self.fused.state_dict(), "rest": self.rest.state_dict() if self.rest is not None else None,
+                "param_groups": super().state_dict()["param_groups"], "state": {}}
+
+    def load_state_dict(self, sd):
+        self.fused.load_state_dict(sd["fused"])
+        if self.rest is not None and sd.get("rest") is not None:
+            self.rest.load_state_dict(sd["rest"])
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -258,6 +258,38 @@ def test_fused_adafactor_matches_transformers(dev):
         torch.cuda.synchronize()
         for n, p, rp in zip(te.names, te.params, ref_params):
             assert rel(p, rp) < 2e-6, (step, n, rel(p, rp))
+    # checkpoint / resume: the statistics come out in transformers' own per-parameter layout ...
+    sd = opt.state_dict()
+    order = {id(p): i for i, p in enumerate(q for gr in opt.param_groups for q in gr["params"])}
+    for n, p, rp in zip(te.names, te.params, ref_params):
+        mine, theirs = sd["state"][order[id(p)]], ref.state[rp]
+        assert mine["step"] == theirs["step"] == 3
+        for k in ("exp_avg_sq_row", "exp_avg_sq_col", "exp_avg_sq"):
+            assert (k in mine) == (k in theirs), (n, k)
+            if k in mine:
+                assert mine[k].shape == theirs[k].shape and rel(mine[k], theirs[k]) < 1e-5, (n, k)
+    # ... and a fresh optimizer that loads them continues bit for bit like the one that kept running
+    import io
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    snap = te.flat.clone()
+    grads = [torch.randn(p.shape, generator=g, device=dev) for p in te.params]
+
+    def one_step(o):
+        for p, gv, gr in zip(te.params, te.grad_views, grads):
+            gv.copy_(gr)
+            p.grad = gv
+        o.step()
+        return te.flat.clone()
+
+    after_a = one_step(opt)
+    te.flat.copy_(snap)
+    opt2 = FusedAdafactor(m.parameters(), te)
+    opt2.load_state_dict(torch.load(buf, map_location=dev))
+    assert opt2.step_count == 3
+    after_b = one_step(opt2)
+    assert torch.equal(after_a, after_b)
     # the step really moved the weights
     assert rel(te.params[5], case["sd"]["mlp.0.weight"]) > 1e-3
 
