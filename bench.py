@@ -290,6 +290,8 @@ def train_bench(args, world, rank, dev):
     m = GNN_Diffusion(steps=T_STEPS, sampling="DDIM", rotation=True, visual_pretrained=False,
                       model_mean_type=ModelMeanType.EPSILON, **({"backbone": "resnet18equiv", "freeze_backbone": False} if pixels else {}))
     m = m.to(dev).train()
+    if pixels and args.precision:
+        m.model.visual_backbone.train_precision = args.precision       # encoder maps in bf16 / fp32 (denoiser: fp32)
     opt = m.configure_optimizers()
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
     feats = None if pixels else torch.randn((G * n, 1088), generator=gen, device=dev)
@@ -340,7 +342,7 @@ def train_bench(args, world, rank, dev):
             "metric": "training steps/sec (12x12 rot dense, 64 puzzles/GPU, Huber, Adafactor)",
             "value": world * G * K / dt, "unit": "puzzle-train-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32", "data": "synthetic",
+            "dtype": "fp32" if not (pixels and args.precision == "bf16") else "bf16 encoder maps + fp32 denoiser", "data": "synthetic",
             "config": {"workload": "BASELINE config 5: 12x12 rot dense (N=144, E=20736), G per GPU below, huber, "
                                    "EPSILON, one Adafactor step; " +
                                    ("encoder (P4 ResNet-18, batch-statistics BatchNorm) + denoiser trained from 32x32 crops"

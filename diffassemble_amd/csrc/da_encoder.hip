@@ -334,8 +334,9 @@ int launch_conv(int prec, int B, const void *X, int Cin, int Hi, const void *W, 
     return 0;
 }
 
-int launch_enc_stem_f32(int B, const float *patches, const float *w, const float *bias, float *Y, int relu, hipStream_t st) {
-    k_enc_stem<float><<<B, 256, 0, st>>>(patches, w, bias, Y, relu);
+int launch_enc_stem(int prec, int B, const float *patches, const float *w, const float *bias, void *Y, int relu, hipStream_t st) {
+    if (prec == DA_PREC_BF16) k_enc_stem<bf16_t><<<B, 256, 0, st>>>(patches, w, bias, (bf16_t *)Y, relu);
+    else k_enc_stem<float><<<B, 256, 0, st>>>(patches, w, bias, (float *)Y, relu);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -27,7 +27,23 @@ namespace da {
 constexpr float ENC_BN_EPS = 1e-5f;           // nn.BatchNorm3d default (resnet_equivariant.py:22)
 constexpr int BN_PIX = 4096;                  // interior pixels per reduction block
 
-struct MapGeom { int B, H, C4; };            // haloed map [B][H + 2][H + 2][C4], interior H x H; plane = channel >> 2
+struct MapGeom { int B, H, C4; };
+
+// four consecutive channels of a map stored as fp32 or bf16 (the bf16 training mode keeps activations and activation
+// gradients in bf16; all arithmetic stays fp32)
+__device__ __forceinline__ float4 ld4(const float *p, size_t o) { return *(const float4 *)(p + o); }
+__device__ __forceinline__ float4 ld4(const bf16_t *p, size_t o) {
+    const uint2 v = *(const uint2 *)(p + o);
+    return float4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                  __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void st4(float *p, size_t o, const float4 &v) { *(float4 *)(p + o) = v; }
+__device__ __forceinline__ void st4(bf16_t *p, size_t o, const float4 &v) {
+    uint2 u;
+    u.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    u.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    *(uint2 *)(p + o) = u;
+}            // haloed map [B][H + 2][H + 2][C4], interior H x H; plane = channel >> 2
 
 __device__ __forceinline__ size_t pix_off(const MapGeom &g, long long ip) {      // ip: interior pixel index over (b, y, x)
     const int HH = g.H * g.H;
@@ -56,12 +72,14 @@ __device__ __forceinline__ void block_plane_reduce(const float (&v)[NV], int pla
 }
 
 // sum and sum of squares per plane over a block's interior pixels
-__global__ __launch_bounds__(256) void k_enc_bn_stats(MapGeom g, const float *__restrict__ Y, double *__restrict__ partial) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_enc_bn_stats(MapGeom g, const T *__restrict__ Y, double *__restrict__ partial) {
     const int planes = g.C4 >> 2, lanes = 256 / planes, tid = threadIdx.x, plane = tid % planes, lp = tid / planes;
     const long long total = (long long)g.B * g.H * g.H, p0 = (long long)blockIdx.x * BN_PIX, p1 = min(total, p0 + BN_PIX);
     float v[2] = {0.f, 0.f};
+#pragma unroll 4
     for (long long ip = p0 + lp; ip < p1; ip += lanes) {
-        const float4 y = *(const float4 *)(Y + pix_off(g, ip) + 4 * plane);
+        const float4 y = ld4(Y, pix_off(g, ip) + 4 * plane);
         v[0] += (y.x + y.y) + (y.z + y.w);
         v[1] += (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
     }
@@ -81,37 +99,40 @@ __global__ __launch_bounds__(128) void k_enc_bn_finish(int nblk, int planes, dou
 }
 
 // z = (y - mean) * (rsqrt(var + eps) * gamma) + beta [+ res] [ReLU], interior only (the halo of Z stays zero)
-__global__ __launch_bounds__(256) void k_enc_bn_apply(MapGeom g, const float *__restrict__ Y, const float *__restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void k_enc_bn_apply(MapGeom g, const T *__restrict__ Y, const float *__restrict__ mean,
                                                       const float *__restrict__ var, const float *__restrict__ gamma,
-                                                      const float *__restrict__ beta, const float *res, int relu, float *Z) {
+                                                      const float *__restrict__ beta, const T *res, int relu, T *Z) {
     const int planes = g.C4 >> 2;
     const long long total = (long long)g.B * g.H * g.H * planes;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int plane = (int)(i % planes);
         const size_t o = pix_off(g, i / planes) + 4 * plane;
         const float mu = mean[plane], sc = rsqrtf(var[plane] + ENC_BN_EPS) * gamma[plane], sh = beta[plane];
-        float4 y = *(const float4 *)(Y + o);
+        float4 y = ld4(Y, o);
         y.x = (y.x - mu) * sc + sh; y.y = (y.y - mu) * sc + sh; y.z = (y.z - mu) * sc + sh; y.w = (y.w - mu) * sc + sh;
-        if (res) { const float4 r = *(const float4 *)(res + o); y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w; }
+        if (res) { const float4 r = ld4(res, o); y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w; }
         if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-        *(float4 *)(Z + o) = y;
+        st4(Z, o, y);
     }
 }
 
 // backward reductions per plane: s1 = sum g, s2 = sum g * xhat, with g = dZ masked by the unit's ReLU (Z > 0)
-__global__ __launch_bounds__(256) void k_enc_bn_bwd_reduce(MapGeom g, const float *__restrict__ dZ, const float *__restrict__ Z,
-                                                           const float *__restrict__ Y, const float *__restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void k_enc_bn_bwd_reduce(MapGeom g, const T *__restrict__ dZ, const T *__restrict__ Z,
+                                                           const T *__restrict__ Y, const float *__restrict__ mean,
                                                            const float *__restrict__ var, int relu, double *__restrict__ partial) {
     const int planes = g.C4 >> 2, lanes = 256 / planes, tid = threadIdx.x, plane = tid % planes, lp = tid / planes;
     const long long total = (long long)g.B * g.H * g.H, p0 = (long long)blockIdx.x * BN_PIX, p1 = min(total, p0 + BN_PIX);
     const float mu = mean[plane], rstd = rsqrtf(var[plane] + ENC_BN_EPS);
     float v[2] = {0.f, 0.f};
+#pragma unroll 4
     for (long long ip = p0 + lp; ip < p1; ip += lanes) {
         const size_t o = pix_off(g, ip) + 4 * plane;
-        float4 d = *(const float4 *)(dZ + o);
-        const float4 y = *(const float4 *)(Y + o);
+        float4 d = ld4(dZ, o);
+        const float4 y = ld4(Y, o);
         if (relu) {
-            const float4 z = *(const float4 *)(Z + o);
+            const float4 z = ld4(Z, o);
             d.x = z.x > 0.f ? d.x : 0.f; d.y = z.y > 0.f ? d.y : 0.f; d.z = z.z > 0.f ? d.z : 0.f; d.w = z.w > 0.f ? d.w : 0.f;
         }
         v[0] += (d.x + d.y) + (d.z + d.w);
@@ -132,11 +153,12 @@ __global__ __launch_bounds__(128) void k_enc_bn_bwd_finish(int nblk, int planes,
 }
 
 // dY = gamma * rstd * (g - s1 / n - xhat * s2 / n);  dRes = g (the gradient of the tensor added before the ReLU), optional
-__global__ __launch_bounds__(256) void k_enc_bn_bwd_apply(MapGeom g, const float *dZ, const float *__restrict__ Z,
-                                                          const float *__restrict__ Y, const float *__restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void k_enc_bn_bwd_apply(MapGeom g, const T *dZ, const T *__restrict__ Z,
+                                                          const T *__restrict__ Y, const float *__restrict__ mean,
                                                           const float *__restrict__ var, const float *__restrict__ gamma,
-                                                          const float *__restrict__ s12, float inv_n, int relu, float *dY,
-                                                          float *dRes) {
+                                                          const float *__restrict__ s12, float inv_n, int relu, T *dY,
+                                                          T *dRes) {
     const int planes = g.C4 >> 2;
     const long long total = (long long)g.B * g.H * g.H * planes;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -144,22 +166,23 @@ __global__ __launch_bounds__(256) void k_enc_bn_bwd_apply(MapGeom g, const float
         const size_t o = pix_off(g, i / planes) + 4 * plane;
         const float mu = mean[plane], rstd = rsqrtf(var[plane] + ENC_BN_EPS), k = gamma[plane] * rstd;
         const float m1 = s12[plane] * inv_n, m2 = s12[planes + plane] * inv_n;
-        float4 d = *(const float4 *)(dZ + o);
-        const float4 y = *(const float4 *)(Y + o);
+        float4 d = ld4(dZ, o);
+        const float4 y = ld4(Y, o);
         if (relu) {
-            const float4 z = *(const float4 *)(Z + o);
+            const float4 z = ld4(Z, o);
             d.x = z.x > 0.f ? d.x : 0.f; d.y = z.y > 0.f ? d.y : 0.f; d.z = z.z > 0.f ? d.z : 0.f; d.w = z.w > 0.f ? d.w : 0.f;
         }
-        if (dRes) *(float4 *)(dRes + o) = d;
+        if (dRes) st4(dRes, o, d);
         float4 r;
         r.x = k * (d.x - m1 - (y.x - mu) * rstd * m2); r.y = k * (d.y - m1 - (y.y - mu) * rstd * m2);
         r.z = k * (d.z - m1 - (y.z - mu) * rstd * m2); r.w = k * (d.w - m1 - (y.w - mu) * rstd * m2);
-        *(float4 *)(dY + o) = r;
+        st4(dY, o, r);
     }
 }
 
 // zero-stuffing: Up (interior 2H x 2H) gets S(i, j) at interior (2i, 2j) and zeros elsewhere (halo untouched = zero)
-__global__ __launch_bounds__(256) void k_enc_upsample2(MapGeom g /* of the SMALL map */, const float *__restrict__ S, float *__restrict__ Up) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_enc_upsample2(MapGeom g /* of the SMALL map */, const T *__restrict__ S, T *__restrict__ Up) {
     const int q4 = g.C4 >> 2, H2 = 2 * g.H;
     const long long total = (long long)g.B * H2 * H2 * q4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -169,14 +192,15 @@ __global__ __launch_bounds__(256) void k_enc_upsample2(MapGeom g /* of the SMALL
         const int r = (int)(ip - b * H2 * H2), y = r / H2, x = r - y * H2;
         float4 v = {0.f, 0.f, 0.f, 0.f};
         if (!(y & 1) && !(x & 1))
-            v = *(const float4 *)(S + (((size_t)b * (g.H + 2) + (y / 2 + 1)) * (g.H + 2) + (x / 2 + 1)) * g.C4 + 4 * c);
-        *(float4 *)(Up + (((size_t)b * (H2 + 2) + (y + 1)) * (H2 + 2) + (x + 1)) * g.C4 + 4 * c) = v;
+            v = ld4(S, (((size_t)b * (g.H + 2) + (y / 2 + 1)) * (g.H + 2) + (x / 2 + 1)) * g.C4 + 4 * c);
+        st4(Up, (((size_t)b * (H2 + 2) + (y + 1)) * (H2 + 2) + (x + 1)) * g.C4 + 4 * c, v);
     }
 }
 
 // im2col of the NORMALISED 3-channel crop for the stem's wgrad: cols [B][34][34][32], taps c*9 + ky*3 + kx in 0..26 at
 // interior pixels, zero elsewhere (the conv pads the normalised image with zeros, efficient_gat.py:150)
-__global__ __launch_bounds__(256) void k_enc_stem_im2col(int B, const float *__restrict__ patches, float *__restrict__ cols) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_enc_stem_im2col(int B, const float *__restrict__ patches, T *__restrict__ cols) {
     const float mean[3] = {0.4850f, 0.4560f, 0.4060f}, sd[3] = {0.2290f, 0.2240f, 0.2250f};
     const long long total = (long long)B * 34 * 34 * 32;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -189,7 +213,7 @@ __global__ __launch_bounds__(256) void k_enc_stem_im2col(int B, const float *__r
             const int y = yh - 1 + ky - 1, x = xh - 1 + kx - 1;
             if (y >= 0 && y < 32 && x >= 0 && x < 32) v = (patches[(((size_t)b * 3 + c) * 32 + y) * 32 + x] - mean[c]) / sd[c];
         }
-        cols[i] = v;
+        stf(cols + i, v);
     }
 }
 
@@ -221,44 +245,50 @@ int da_enc_conv(int precision, int B, const void *X, int Cin, int Hi, const void
     return launch_conv(precision, B, X, Cin, Hi, W, bias, res, Y, Cout, ksize, stride, relu, (hipStream_t)stream);
 }
 
-int da_enc_stem(int B, const float *patches, const float *w, const float *bias, float *Y, int relu, void *stream) {
+int da_enc_stem(int precision, int B, const float *patches, const float *w, const float *bias, void *Y, int relu, void *stream) {
     DA_REQUIRE(patches && w && bias && Y && B > 0, "da_enc_stem: null argument");
-    return launch_enc_stem_f32(B, patches, w, bias, Y, relu, (hipStream_t)stream);
+    return launch_enc_stem(precision, B, patches, w, bias, Y, relu, (hipStream_t)stream);
 }
 
-int da_enc_stem_im2col(int B, const float *patches, float *cols, void *stream) {
+int da_enc_stem_im2col(int precision, int B, const float *patches, void *cols, void *stream) {
     DA_REQUIRE(patches && cols && B > 0, "da_enc_stem_im2col: null argument");
-    k_enc_stem_im2col<<<grid_for((long long)B * 1156 * 32), 256, 0, (hipStream_t)stream>>>(B, patches, cols);
+    if (precision == DA_PREC_BF16) k_enc_stem_im2col<bf16_t><<<grid_for((long long)B * 1156 * 32), 256, 0, (hipStream_t)stream>>>(B, patches, (bf16_t *)cols);
+    else k_enc_stem_im2col<float><<<grid_for((long long)B * 1156 * 32), 256, 0, (hipStream_t)stream>>>(B, patches, (float *)cols);
     DA_LAUNCH_CHECK();
     return 0;
 }
 
 static int geom_ok(int B, int H, int C4) { return B > 0 && H > 0 && C4 >= 128 && C4 <= 512 && C4 % 128 == 0; }
 
-int da_enc_bn_stats(int B, int H, int C4, const float *Y, float *mean, float *var, void *scratch, void *stream) {
+int da_enc_bn_stats(int precision, int B, int H, int C4, const void *Y, float *mean, float *var, void *scratch, void *stream) {
     DA_REQUIRE(Y && mean && var && scratch && geom_ok(B, H, C4), "da_enc_bn_stats: bad argument");
     const MapGeom g{B, H, C4};
     const long long total = (long long)B * H * H;
     const int nblk = (int)((total + BN_PIX - 1) / BN_PIX);
     hipStream_t st = (hipStream_t)stream;
-    k_enc_bn_stats<<<nblk, 256, 0, st>>>(g, Y, (double *)scratch);
+    if (precision == DA_PREC_BF16) k_enc_bn_stats<bf16_t><<<nblk, 256, 0, st>>>(g, (const bf16_t *)Y, (double *)scratch);
+    else k_enc_bn_stats<float><<<nblk, 256, 0, st>>>(g, (const float *)Y, (double *)scratch);
     k_enc_bn_finish<<<1, 128, 0, st>>>(nblk, C4 / 4, (double)total * 4.0, (const double *)scratch, mean, var);
     DA_LAUNCH_CHECK();
     return 0;
 }
 
-int da_enc_bn_apply(int B, int H, int C4, const float *Y, const float *mean, const float *var, const float *gamma,
-                    const float *beta, const float *res, int relu, float *Z, void *stream) {
+int da_enc_bn_apply(int precision, int B, int H, int C4, const void *Y, const float *mean, const float *var, const float *gamma,
+                    const float *beta, const void *res, int relu, void *Z, void *stream) {
     DA_REQUIRE(Y && mean && var && gamma && beta && Z && geom_ok(B, H, C4), "da_enc_bn_apply: bad argument");
     const MapGeom g{B, H, C4};
-    k_enc_bn_apply<<<grid_for((long long)B * H * H * (C4 / 4)), 256, 0, (hipStream_t)stream>>>(g, Y, mean, var, gamma, beta, res, relu, Z);
+    const unsigned grid = grid_for((long long)B * H * H * (C4 / 4));
+    if (precision == DA_PREC_BF16)
+        k_enc_bn_apply<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)Y, mean, var, gamma, beta, (const bf16_t *)res, relu, (bf16_t *)Z);
+    else
+        k_enc_bn_apply<float><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const float *)Y, mean, var, gamma, beta, (const float *)res, relu, (float *)Z);
     DA_LAUNCH_CHECK();
     return 0;
 }
 
-int da_enc_bn_backward(int B, int H, int C4, const float *dZ, const float *Z, const float *Y, const float *mean, const float *var,
-                       const float *gamma, int relu, float *dgamma, float *dbeta, float *dY, float *dRes, void *scratch,
-                       void *stream) {
+int da_enc_bn_backward(int precision, int B, int H, int C4, const void *dZ, const void *Z, const void *Y, const float *mean,
+                       const float *var, const float *gamma, int relu, float *dgamma, float *dbeta, void *dY, void *dRes,
+                       void *scratch, void *stream) {
     DA_REQUIRE(dZ && Y && mean && var && gamma && dgamma && dbeta && dY && scratch && (Z || !relu) && geom_ok(B, H, C4),
                "da_enc_bn_backward: bad argument");
     const MapGeom g{B, H, C4};
@@ -267,18 +297,30 @@ int da_enc_bn_backward(int B, int H, int C4, const float *dZ, const float *Z, co
     hipStream_t st = (hipStream_t)stream;
     double *partial = (double *)scratch;
     float *s12 = (float *)((char *)scratch + align_up((size_t)nblk * 128 * 2 * sizeof(double), 256));
-    k_enc_bn_bwd_reduce<<<nblk, 256, 0, st>>>(g, dZ, Z, Y, mean, var, relu, partial);
-    k_enc_bn_bwd_finish<<<1, 128, 0, st>>>(nblk, planes, partial, s12, dgamma, dbeta);
-    k_enc_bn_bwd_apply<<<grid_for(total * planes), 256, 0, st>>>(g, dZ, Z, Y, mean, var, gamma, s12, (float)(1.0 / ((double)total * 4.0)),
-                                                                relu, dY, dRes);
+    const float inv_n = (float)(1.0 / ((double)total * 4.0));
+    if (precision == DA_PREC_BF16) {
+        typedef const bf16_t *P;
+        k_enc_bn_bwd_reduce<bf16_t><<<nblk, 256, 0, st>>>(g, (P)dZ, (P)Z, (P)Y, mean, var, relu, partial);
+        k_enc_bn_bwd_finish<<<1, 128, 0, st>>>(nblk, planes, partial, s12, dgamma, dbeta);
+        k_enc_bn_bwd_apply<bf16_t><<<grid_for(total * planes), 256, 0, st>>>(g, (P)dZ, (P)Z, (P)Y, mean, var, gamma, s12, inv_n, relu,
+                                                                            (bf16_t *)dY, (bf16_t *)dRes);
+    } else {
+        typedef const float *P;
+        k_enc_bn_bwd_reduce<float><<<nblk, 256, 0, st>>>(g, (P)dZ, (P)Z, (P)Y, mean, var, relu, partial);
+        k_enc_bn_bwd_finish<<<1, 128, 0, st>>>(nblk, planes, partial, s12, dgamma, dbeta);
+        k_enc_bn_bwd_apply<float><<<grid_for(total * planes), 256, 0, st>>>(g, (P)dZ, (P)Z, (P)Y, mean, var, gamma, s12, inv_n, relu,
+                                                                           (float *)dY, (float *)dRes);
+    }
     DA_LAUNCH_CHECK();
     return 0;
 }
 
-int da_enc_upsample2(int B, int H, int C4, const float *S, float *Up, void *stream) {
+int da_enc_upsample2(int precision, int B, int H, int C4, const void *S, void *Up, void *stream) {
     DA_REQUIRE(S && Up && geom_ok(B, H, C4), "da_enc_upsample2: bad argument");
     const MapGeom g{B, H, C4};
-    k_enc_upsample2<<<grid_for((long long)B * 4 * H * H * (C4 / 4)), 256, 0, (hipStream_t)stream>>>(g, S, Up);
+    const unsigned grid = grid_for((long long)B * 4 * H * H * (C4 / 4));
+    if (precision == DA_PREC_BF16) k_enc_upsample2<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const bf16_t *)S, (bf16_t *)Up);
+    else k_enc_upsample2<float><<<grid, 256, 0, (hipStream_t)stream>>>(g, (const float *)S, (float *)Up);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -287,6 +329,13 @@ int da_gemm_tn_f32(int M, int N, int K, const float *A, int lda, const float *B,
                    void *stream) {
     DA_REQUIRE(A && B && C && scratch && M > 0 && N > 0 && K > 0, "da_gemm_tn_f32: bad argument");
     return launch_gemm_tn(M, N, K, A, lda, B, ldb, C, ldc, (float *)scratch, (hipStream_t)stream);
+}
+
+int da_gemm_tn_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, float *C, int ldc, void *scratch,
+                    void *stream) {
+    DA_REQUIRE(A && B && C && scratch && M > 0 && N > 0 && K > 0, "da_gemm_tn_bf16: bad argument");
+    DA_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0, "da_gemm_tn_bf16: operands must be 16-byte aligned with row strides that are multiples of 8");
+    return launch_gemm_tn_bf16(M, N, K, (const bf16_t *)A, lda, (const bf16_t *)B, ldb, C, ldc, (float *)scratch, (hipStream_t)stream);
 }
 
 int da_colsum_f32(int M, int N, const float *A, int lda, float *out, void *scratch, void *stream) {

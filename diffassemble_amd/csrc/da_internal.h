@@ -58,11 +58,13 @@ int launch_transpose_f32(int rows, int cols, const float *src, float *dst, hipSt
 // C (+)= A^T B over rows (A [M, N], B [M, K] row-major; split-row partials through `partial`, >= 16 M floats)
 int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, float *partial,
                    hipStream_t st);
+int launch_gemm_tn_bf16(int M, int N, int K, const bf16_t *A, int lda, const bf16_t *B, int ldb, float *C, int ldc, float *partial,
+                        hipStream_t st);
 int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch, hipStream_t st);   // out[c] += sum_m A[m][c]
 // da_encoder.hip: implicit-GEMM convolution over zero-haloed NHWC maps; the fp32 stem
 int launch_conv(int prec, int B, const void *X, int Cin, int Hi, const void *W, const float *bias, const void *res, void *Y,
                 int Cout, int ksize, int stride, int relu, hipStream_t st);
-int launch_enc_stem_f32(int B, const float *patches, const float *w, const float *bias, float *Y, int relu, hipStream_t st);
+int launch_enc_stem(int prec, int B, const float *patches, const float *w, const float *bias, void *Y, int relu, hipStream_t st);
 int launch_mm_nn_f32(int M, int N, int K, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
                      int ldc, hipStream_t st);
 int launch_scatter_virtual(int prec, int rows, int V, int H, int C, const void *src, int n_real, const int32_t *row_map,

@@ -157,8 +157,18 @@ __global__ __launch_bounds__(256) void k_reduce_partial(int splits, int N, int K
                                                         float *C, int ldc) {
     const size_t NK = (size_t)N * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < NK; i += (size_t)gridDim.x * blockDim.x) {
+        // fixed summation order (deterministic), eight independent loads in flight: the split count reaches several
+        // hundred for the encoder's weight gradients and one dependent load per iteration was latency-bound
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[(size_t)k * NK + i];
+        int k = 0;
+        for (; k + 8 <= splits; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(k + u) * NK + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < splits; ++k) s += partial[(size_t)k * NK + i];
         const size_t n = i / K, kk = i - n * K;
         C[n * ldc + kk] += s;
     }
@@ -182,6 +192,124 @@ int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B,
         k_gemm_tn<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, nullptr, Mc);
     } else {
         k_gemm_tn<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, partial, Mc);
+        const size_t NK = (size_t)N * K;
+        k_reduce_partial<<<(unsigned)((NK + 255) / 256 > 4096 ? 4096 : (NK + 255) / 256), 256, 0, st>>>((int)splits, N, K, partial, C, ldc);
+    }
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 variant of the dW kernel (the encoder's bf16 training mode): C[n][k] (+)= sum_m A[m][n] B[m][k], A / B bf16
+// row-major, fp32 accumulation and output.  v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE reduction indices per lane,
+// and the reduction index m is the slow one in memory, so the tiles are transposed on their way into LDS: a thread loads
+// 16 bytes (8 columns of one row) and writes them as eight 2-byte stores into the [column][m] image (row pitch 72 bytes:
+// the two 8-byte fragment reads of a lane are conflict-free across the 32-lane groups, the 2-byte writes of the two
+// column groups of a wave land on disjoint banks).  Tile 128 (n) x 128 (k), 32 rows of m per stage, 4 waves as 2 x 2.
+// Arbitrary N, K (zero-filled loads, masked stores); lda / ldb multiples of 8, 16-byte aligned bases.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__global__ __launch_bounds__(256) void k_gemm_tn_bf16(int M, int N, int K, const bf16_t *__restrict__ A, int lda,
+                                                      const bf16_t *__restrict__ B, int ldb, float *C, int ldc,
+                                                      float *partial, int Mc) {
+    constexpr int PITCH = 72;
+    __shared__ __attribute__((aligned(16))) unsigned char As[128 * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[128 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
+    const int m_beg = blockIdx.z * Mc, m_end = min(M, m_beg + Mc);
+    const int srow = tid & 31, sch = tid >> 5;                   // staging role: row of the stage, 8-column chunk (and + 8)
+    auto ldchunk = [&](const bf16_t *P, int ld, int m, int col, int cols) -> u32x4 {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (m >= m_end || col >= cols) return v;
+        const bf16_t *q = P + (size_t)m * ld + col;
+        if (col + 8 <= cols) return *(const u32x4 *)q;
+        unsigned short e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 8 && col + i < cols; ++i) e[i] = q[i];
+        v[0] = e[0] | ((unsigned)e[1] << 16); v[1] = e[2] | ((unsigned)e[3] << 16);
+        v[2] = e[4] | ((unsigned)e[5] << 16); v[3] = e[6] | ((unsigned)e[7] << 16);
+        return v;
+    };
+    auto put = [&](unsigned char *S, int chunk, const u32x4 &v) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            *(unsigned short *)(S + (8 * chunk + e) * PITCH + srow * 2) = (unsigned short)(v[e >> 1] >> ((e & 1) * 16));
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    u32x4 ra[2], rb[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        ra[p] = ldchunk(A, lda, m_beg + srow, n0 + 8 * (sch + 8 * p), N);
+        rb[p] = ldchunk(B, ldb, m_beg + srow, k0 + 8 * (sch + 8 * p), K);
+    }
+    for (int m0 = m_beg; m0 < m_end; m0 += 32) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { put(As, sch + 8 * p, ra[p]); put(Bs, sch + 8 * p, rb[p]); }
+        __syncthreads();
+        if (m0 + 32 < m_end) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                ra[p] = ldchunk(A, lda, m0 + 32 + srow, n0 + 8 * (sch + 8 * p), N);
+                rb[p] = ldchunk(B, ldb, m0 + 32 + srow, k0 + 8 * (sch + 8 * p), K);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned char *pa = As + (wr * 64 + i * 32 + (lane & 31)) * PITCH + ks * 32 + (lane >> 5) * 16;
+                const unsigned char *pb = Bs + (wc * 64 + i * 32 + (lane & 31)) * PITCH + ks * 32 + (lane >> 5) * 16;
+                const uint2 a0 = *(const uint2 *)pa, a1 = *(const uint2 *)(pa + 8), b0 = *(const uint2 *)pb, b1 = *(const uint2 *)(pb + 8);
+                a[i] = (u32x4){a0.x, a0.y, a1.x, a1.y};
+                b[i] = (u32x4){b0.x, b0.y, b1.x, b1.y};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                       acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float *dst = partial ? partial + (size_t)blockIdx.z * N * K : C;
+    const int ldd = partial ? K : ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), k = k0 + wc * 64 + j * 32 + (lane & 31);
+                if (n < N && k < K) {
+                    if (partial) dst[(size_t)n * ldd + k] = acc[i][j][r];
+                    else dst[(size_t)n * ldd + k] += acc[i][j][r];
+                }
+            }
+}
+
+int launch_gemm_tn_bf16(int M, int N, int K, const bf16_t *A, int lda, const bf16_t *B, int ldb, float *C, int ldc,
+                        float *partial, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int tn = (N + 127) / 128, tk = (K + 127) / 128;
+    long splits = 2048 / ((long)tn * tk);
+    const long by_rows = (M + 511) / 512, by_cap = (long)(PART_CAP / ((size_t)N * K));
+    splits = splits > by_rows ? by_rows : splits;
+    splits = splits > by_cap ? by_cap : splits;
+    if (splits < 1) splits = 1;
+    int Mc = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
+    splits = (M + Mc - 1) / Mc;
+    const dim3 grid((unsigned)tk, (unsigned)tn, (unsigned)splits);
+    if (splits == 1) {
+        k_gemm_tn_bf16<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, nullptr, Mc);
+    } else {
+        k_gemm_tn_bf16<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, partial, Mc);
         const size_t NK = (size_t)N * K;
         k_reduce_partial<<<(unsigned)((NK + 255) / 256 > 4096 ? 4096 : (NK + 255) / 256), 256, 0, st>>>((int)splits, N, K, partial, C, ldc);
     }

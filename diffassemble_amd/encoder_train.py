@@ -45,7 +45,13 @@ class EncoderTrainEngine:
     ``forward(patches)`` -> patch_feats [n, 1088] fp32 and updates the BatchNorm running statistics like torch does;
     ``backward(d_feats)`` ADDS the parameter gradients into ``param.grad`` (allocated on first use)."""
 
-    def __init__(self, module, device=None):
+    def __init__(self, module, device=None, precision="fp32"):
+        """``precision``: "fp32" (the parity mode) or "bf16" -- activations and activation gradients stored in bf16, the
+        convolutions on the bf16 matrix cores, BatchNorm arithmetic, master weights and every parameter gradient in fp32."""
+        assert precision in ("fp32", "bf16"), precision
+        self.precision = precision
+        self.prec = _lib.PREC_BF16 if precision == "bf16" else _lib.PREC_F32
+        self.act = torch.bfloat16 if precision == "bf16" else torch.float32
         self.module = module
         self.params = dict(module.named_parameters())
         self.buffers = dict(module.named_buffers())
@@ -84,27 +90,33 @@ class EncoderTrainEngine:
             self.wf, self.wt = {}, {}
             for conv, _, cin, *_ in self.units:
                 bank = p4_filter_bank(self.params[conv + ".weight"].detach().float())
-                self.wf[conv] = bank.reshape(128, 27).contiguous() if cin is None else self._pack_fwd(bank)
+                self.wf[conv] = bank.reshape(128, 27).contiguous() if cin is None else self._pack_fwd(bank).to(self.act)
                 if cin is not None:
-                    self.wt[conv] = self._pack_dgrad(bank)
+                    self.wt[conv] = self._pack_dgrad(bank).to(self.act)
             self.lin = {}
             for name, C, H in (("linear1", 256, 8), ("linear2", 512, 4)):
-                wh = _halo_linear(self.params[name + ".weight"].detach().float(), C, H).contiguous()
-                self.lin[name] = (wh, wh.t().contiguous(), self.params[name + ".bias"].detach().float().contiguous())
+                wh = _halo_linear(self.params[name + ".weight"].detach().float(), C, H).to(self.act).contiguous()
+                # transposed copy for dA = dF W; its K (= 544) is zero-padded to 576 so that the bf16 matrix kernel's
+                # 64-element K steps divide it
+                wht = torch.zeros(wh.shape[1], 576, dtype=self.act, device=wh.device)
+                wht[:, :544] = wh.t()
+                self.lin[name] = (wh, wht, self.params[name + ".bias"].detach().float().contiguous())
         self._pack_key = key
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, n):
         if self._n == n:
             return
-        dev, z = self.device, lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)  # noqa: E731
+        dev = self.device
+        z = lambda *s: torch.zeros(*s, dtype=self.act, device=self.device)  # noqa: E731
+        zf = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)  # noqa: E731
         self.Y, self.Z, self.mean, self.var = [], [], [], []
         for _, _, _, planes, _, stride, H in self.units:
             Ho = H // stride
             self.Y.append(z(n, Ho + 2, Ho + 2, planes * 4))
             self.Z.append(z(n, Ho + 2, Ho + 2, planes * 4))
-            self.mean.append(z(planes))
-            self.var.append(z(planes))
+            self.mean.append(zf(planes))
+            self.var.append(zf(planes))
         # gradient pool: five maps per resolution (dOut, dY, gRes, dZ of the inner unit, spare) + zero-stuffed maps
         self.pool = {}
         for H, C4 in ((32, 128), (16, 256), (8, 256), (4, 512)):
@@ -113,7 +125,7 @@ class EncoderTrainEngine:
         self.cols = z(n, 34, 34, 32)
         self.bn_scratch = torch.empty(self.lib.da_enc_train_scratch_bytes(n), dtype=torch.uint8, device=dev)
         self.colsum_scratch = torch.empty(((n + 127) // 128) * 544 + 64, dtype=torch.float32, device=dev)
-        self.feats = torch.empty(n, 1088, dtype=torch.float32, device=dev)
+        self.feats = torch.empty(n, 1088, dtype=self.act, device=dev)
         self._n = n
 
     # ------------------------------------------------------------------ primitives
@@ -123,20 +135,20 @@ class EncoderTrainEngine:
     def _conv(self, X, cin4, Hi, W, Y, cout4, k, stride, res=None):
         """Y = conv(X, W) [+ res]; pieces are independent, so the batch goes through in slices whose maps stay below the
         kernel's 4 GB (32-bit offset) limit."""
-        per = 4 * max(X[0].numel(), Y[0].numel())
+        per = X.element_size() * max(X[0].numel(), Y[0].numel())
         step = max(1, ((1 << 32) - 1) // per)
         for i in range(0, X.shape[0], step):
             j = min(X.shape[0], i + step)
-            _lib.check(self.lib.da_enc_conv(_lib.PREC_F32, j - i, _lib.ptr(X[i:j]), cin4, Hi, _lib.ptr(W), _lib.ptr(self.zero_bias),
+            _lib.check(self.lib.da_enc_conv(self.prec, j - i, _lib.ptr(X[i:j]), cin4, Hi, _lib.ptr(W), _lib.ptr(self.zero_bias),
                                             _lib.ptr(None if res is None else res[i:j]), _lib.ptr(Y[i:j]), cout4, k, stride, 0,
                                             self._st()))
 
     def _bn_forward(self, u, res, relu):
         _, bn, _, planes, _, stride, H = self.units[u]
         Ho, n = H // stride, self._n
-        _lib.check(self.lib.da_enc_bn_stats(n, Ho, planes * 4, _lib.ptr(self.Y[u]), _lib.ptr(self.mean[u]), _lib.ptr(self.var[u]),
+        _lib.check(self.lib.da_enc_bn_stats(self.prec, n, Ho, planes * 4, _lib.ptr(self.Y[u]), _lib.ptr(self.mean[u]), _lib.ptr(self.var[u]),
                                             _lib.ptr(self.bn_scratch), self._st()))
-        _lib.check(self.lib.da_enc_bn_apply(n, Ho, planes * 4, _lib.ptr(self.Y[u]), _lib.ptr(self.mean[u]), _lib.ptr(self.var[u]),
+        _lib.check(self.lib.da_enc_bn_apply(self.prec, n, Ho, planes * 4, _lib.ptr(self.Y[u]), _lib.ptr(self.mean[u]), _lib.ptr(self.var[u]),
                                             _lib.ptr(self.params[bn + ".weight"]), _lib.ptr(self.params[bn + ".bias"]),
                                             _lib.ptr(res), int(relu), _lib.ptr(self.Z[u]), self._st()))
         with torch.no_grad():                                     # running statistics, as torch updates them
@@ -153,10 +165,14 @@ class EncoderTrainEngine:
 
     def _bn_backward(self, u, dZ, relu, dY, dRes=None):
         _, bn, _, planes, _, stride, H = self.units[u]
-        _lib.check(self.lib.da_enc_bn_backward(self._n, H // stride, planes * 4, _lib.ptr(dZ), _lib.ptr(self.Z[u]), _lib.ptr(self.Y[u]),
+        _lib.check(self.lib.da_enc_bn_backward(self.prec, self._n, H // stride, planes * 4, _lib.ptr(dZ), _lib.ptr(self.Z[u]), _lib.ptr(self.Y[u]),
                                                _lib.ptr(self.mean[u]), _lib.ptr(self.var[u]), _lib.ptr(self.params[bn + ".weight"]),
                                                int(relu), _lib.ptr(self._grad(bn + ".weight")), _lib.ptr(self._grad(bn + ".bias")),
                                                _lib.ptr(dY), _lib.ptr(dRes), _lib.ptr(self.bn_scratch), self._st()))
+
+    def _gemm_tn(self, M, N, K, A, lda, B, ldb, C, ldc):
+        fn = self.lib.da_gemm_tn_bf16 if self.precision == "bf16" else self.lib.da_gemm_tn_f32
+        _lib.check(fn(M, N, K, _lib.ptr(A), lda, _lib.ptr(B), ldb, _lib.ptr(C), ldc, _lib.ptr(self.gemm_scratch), self._st()))
 
     def _wgrad(self, conv, dY, X, cin4, cout4, k, H):
         """dBank[o][tap][c] += sum_q dY[q][o] X[q + offset(tap)][c] over the haloed positions (dY's halo is zero), then the
@@ -169,9 +185,7 @@ class EncoderTrainEngine:
             ky, kx = (tap // 3, tap % 3) if k == 3 else (1, 1)
             off = (Wp + 1) + (ky - 1) * Wp + (kx - 1)
             b = X.view(-1)[off * cin4:]
-            _lib.check(self.lib.da_gemm_tn_f32(rows, cout4, cin4, _lib.ptr(a), cout4, _lib.ptr(b), cin4,
-                                               _lib.ptr(dbank.view(-1)[tap * cin4:]), k * k * cin4, _lib.ptr(self.gemm_scratch),
-                                               self._st()))
+            self._gemm_tn(rows, cout4, cin4, a, cout4, b, cin4, dbank.view(-1)[tap * cin4:], k * k * cin4)
         w = self.params[conv + ".weight"]
         _lib.check(self.lib.da_enc_bank_grad(w.numel(), _lib.ptr(self._tables[conv]), _lib.ptr(dbank), _lib.ptr(self._grad(conv + ".weight")),
                                              self._st()))
@@ -186,7 +200,7 @@ class EncoderTrainEngine:
         self._alloc(n)
         self._pack()
         self.x = x
-        _lib.check(self.lib.da_enc_stem(n, _lib.ptr(x), _lib.ptr(self.wf["conv1"]), _lib.ptr(self.zero_bias), _lib.ptr(self.Y[0]), 0,
+        _lib.check(self.lib.da_enc_stem(self.prec, n, _lib.ptr(x), _lib.ptr(self.wf["conv1"]), _lib.ptr(self.zero_bias), _lib.ptr(self.Y[0]), 0,
                                         self._st()))
         self._bn_forward(0, None, True)
         cur, u = 0, 1                                    # cur: unit whose Z is the running activation
@@ -211,9 +225,9 @@ class EncoderTrainEngine:
         for name, src, col in (("linear1", self.out3, 0), ("linear2", self.out4, 544)):
             wh, _, bias = self.lin[name]
             A = self.Z[src].view(n, -1)
-            _lib.check(self.lib.da_linear(_lib.PREC_F32, n, A.shape[1], 544, _lib.ptr(A), A.shape[1], _lib.ptr(wh), _lib.ptr(bias),
+            _lib.check(self.lib.da_linear(self.prec, n, A.shape[1], 544, _lib.ptr(A), A.shape[1], _lib.ptr(wh), _lib.ptr(bias),
                                           _lib.ACT_NONE, None, _lib.ptr(self.feats[:, col:]), 1088, self._st()))
-        return self.feats
+        return self.feats.float() if self.precision == "bf16" else self.feats
 
     # ------------------------------------------------------------------ backward
     @torch.no_grad()
@@ -221,6 +235,9 @@ class EncoderTrainEngine:
         n = self._n
         d = d_feats.detach().to(torch.float32).contiguous()
         assert d.shape == (n, 1088)
+        da = torch.zeros(n, 2 * 576, dtype=self.act, device=self.device)   # operand copy of dF, each head padded to 576 columns
+        da[:, :544] = d[:, :544]
+        da[:, 576:576 + 544] = d[:, 544:]
         st = self._st
         # linear heads: dA = dF W (halo columns of the packed weight are zero -> the halo of dA is zero), dW += dF^T A
         heads = {}
@@ -228,13 +245,12 @@ class EncoderTrainEngine:
             wh, wht, _ = self.lin[name]
             A = self.Z[src].view(n, -1)
             dA = self.pool[H][0]
-            dF = d[:, col:col + 544]
-            _lib.check(self.lib.da_linear(_lib.PREC_F32, n, 544, A.shape[1], _lib.ptr(dF), 1088, _lib.ptr(wht),
+            dF, dFa = d[:, col:col + 544], da[:, (576 if col else 0):]
+            _lib.check(self.lib.da_linear(self.prec, n, 576, A.shape[1], _lib.ptr(dFa), 1152, _lib.ptr(wht),
                                           _lib.ptr(torch.zeros(A.shape[1], dtype=torch.float32, device=self.device)),
                                           _lib.ACT_NONE, None, _lib.ptr(dA), A.shape[1], st()))
-            dwh = torch.zeros_like(wh)
-            _lib.check(self.lib.da_gemm_tn_f32(n, 544, A.shape[1], _lib.ptr(dF), 1088, _lib.ptr(A), A.shape[1], _lib.ptr(dwh), A.shape[1],
-                                               _lib.ptr(self.gemm_scratch), st()))
+            dwh = torch.zeros(wh.shape, dtype=torch.float32, device=self.device)
+            self._gemm_tn(n, 544, A.shape[1], dFa, 1152, A, A.shape[1], dwh, A.shape[1])
             # back from the haloed NHWC columns to the reference's NCHW flatten (inverse of encoder._halo_linear)
             self._grad(name + ".weight").add_(dwh.view(544, H + 2, H + 2, C)[:, 1:H + 1, 1:H + 1, :].permute(0, 3, 1, 2).reshape(544, -1))
             _lib.check(self.lib.da_colsum_f32(n, 544, _lib.ptr(dF), 1088, _lib.ptr(self._grad(name + ".bias")), _lib.ptr(self.colsum_scratch), st()))
@@ -257,19 +273,18 @@ class EncoderTrainEngine:
             else:
                 up, dIn = self.up[Hin], self.pool[Hin][0]
                 prior = dIn if cur == self.out3 else None            # layer3's output also feeds linear1: accumulate
-                _lib.check(self.lib.da_enc_upsample2(n, H, C4, _lib.ptr(dY), _lib.ptr(up), st()))
+                _lib.check(self.lib.da_enc_upsample2(self.prec, n, H, C4, _lib.ptr(dY), _lib.ptr(up), st()))
                 self._wgrad(conv_a, up, self.Z[cur], cin * 4, C4, 3, Hin)
                 self._conv(up, C4, Hin, self.wt[conv_a], dIn, cin * 4, 3, 1, res=prior)
                 self._bn_backward(s, gRes, False, dY)
-                _lib.check(self.lib.da_enc_upsample2(n, H, C4, _lib.ptr(dY), _lib.ptr(up), st()))
+                _lib.check(self.lib.da_enc_upsample2(self.prec, n, H, C4, _lib.ptr(dY), _lib.ptr(up), st()))
                 self._wgrad(self.units[s][0], up, self.Z[cur], cin * 4, C4, 1, Hin)
                 self._conv(up, C4, Hin, self.wt[self.units[s][0]], dIn, cin * 4, 1, 1, res=dIn)
         # stem: BatchNorm backward, then the weight gradient as one TN GEMM against the im2col of the normalised crops
         dOut, dY = self.pool[32][0], self.pool[32][1]
         self._bn_backward(0, dOut, True, dY)
-        _lib.check(self.lib.da_enc_stem_im2col(n, _lib.ptr(self.x), _lib.ptr(self.cols), st()))
+        _lib.check(self.lib.da_enc_stem_im2col(self.prec, n, _lib.ptr(self.x), _lib.ptr(self.cols), st()))
         dbank = torch.zeros(128, 27, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.da_gemm_tn_f32(n * 34 * 34, 128, 27, _lib.ptr(dY), 128, _lib.ptr(self.cols), 32, _lib.ptr(dbank), 27,
-                                           _lib.ptr(self.gemm_scratch), st()))
+        self._gemm_tn(n * 34 * 34, 128, 27, dY, 128, self.cols, 32, dbank, 27)
         w = self.params["conv1.weight"]
         _lib.check(self.lib.da_enc_bank_grad(w.numel(), _lib.ptr(self._tables["conv1"]), _lib.ptr(dbank), _lib.ptr(self._grad("conv1.weight")), st()))

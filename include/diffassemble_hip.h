@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 9
+#define DA_ABI_VERSION 10
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -403,27 +403,33 @@ size_t da_enc_train_scratch_bytes(int n_patches);
  * convolution when W holds the flipped / transposed bank; `res` (may alias Y) accumulates other paths. */
 int da_enc_conv(int precision, int B, const void *X, int Cin, int Hi, const void *W, const float *bias, const void *res,
                 void *Y, int Cout, int ksize, int stride, int relu, void *stream);
-/* stem: normalise + P4ConvZ2(3 -> 128 channels, 3x3) + bias [ReLU], patches [B,3,32,32] -> Y [B][34][34][128] */
-int da_enc_stem(int B, const float *patches, const float *w, const float *bias, float *Y, int relu, void *stream);
+/* The map-shaped primitives below take `precision` = the STORAGE type of the maps (DA_PREC_F32: the parity mode;
+ * DA_PREC_BF16: activations and activation gradients in bf16, all arithmetic and every parameter gradient in fp32). */
+/* stem: normalise + P4ConvZ2(3 -> 128 channels, 3x3) + bias [ReLU], patches [B,3,32,32] fp32 -> Y [B][34][34][128] */
+int da_enc_stem(int precision, int B, const float *patches, const float *w, const float *bias, void *Y, int relu, void *stream);
 /* the stem's input as GEMM rows for its weight gradient: cols [B][34][34][32] (27 taps + zero pad; zero halo) */
-int da_enc_stem_im2col(int B, const float *patches, float *cols, void *stream);
+int da_enc_stem_im2col(int precision, int B, const float *patches, void *cols, void *stream);
 /* nn.BatchNorm3d batch statistics: mean / biased variance per plane over (B, 4, H, W) */
-int da_enc_bn_stats(int B, int H, int C4, const float *Y, float *mean, float *var, void *scratch, void *stream);
+int da_enc_bn_stats(int precision, int B, int H, int C4, const void *Y, float *mean, float *var, void *scratch, void *stream);
 /* Z = (Y - mean) * (rsqrt(var + 1e-5) * gamma) + beta [+ res] [ReLU] */
-int da_enc_bn_apply(int B, int H, int C4, const float *Y, const float *mean, const float *var, const float *gamma,
-                    const float *beta, const float *res, int relu, float *Z, void *stream);
+int da_enc_bn_apply(int precision, int B, int H, int C4, const void *Y, const float *mean, const float *var, const float *gamma,
+                    const float *beta, const void *res, int relu, void *Z, void *stream);
 /* backward of that unit: g = dZ [masked by Z > 0]; dgamma += sum g xhat; dbeta += sum g;
  * dY = gamma rstd (g - mean(g) - xhat mean(g xhat)); dRes = g when non-NULL (gradient of the added tensor) */
-int da_enc_bn_backward(int B, int H, int C4, const float *dZ, const float *Z, const float *Y, const float *mean,
-                       const float *var, const float *gamma, int relu, float *dgamma, float *dbeta, float *dY,
-                       float *dRes, void *scratch, void *stream);
+int da_enc_bn_backward(int precision, int B, int H, int C4, const void *dZ, const void *Z, const void *Y, const float *mean,
+                       const float *var, const float *gamma, int relu, float *dgamma, float *dbeta, void *dY,
+                       void *dRes, void *scratch, void *stream);
 /* zero-stuffing of a gradient map to twice the resolution (stride-2 layers are differentiated as stride 1) */
-int da_enc_upsample2(int B, int H, int C4, const float *S, float *Up, void *stream);
+int da_enc_upsample2(int precision, int B, int H, int C4, const void *S, void *Up, void *stream);
 /* C += A^T B over rows: A [M, N] (lda), B [M, K] (ldb), C [N, K] (ldc); fp32 MFMA, deterministic split over rows.
  * One call per filter tap is a convolution's weight gradient (dY's zero halo makes the haloed maps plain
  * GEMM operands).  scratch: 64 MB. */
 int da_gemm_tn_f32(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                    void *scratch, void *stream);
+/* the same with bf16 operands (fp32 accumulation and output): v_mfma_f32_32x32x16_bf16, tiles transposed on their way
+ * into LDS.  lda / ldb multiples of 8, 16-byte aligned bases. */
+int da_gemm_tn_bf16(int M, int N, int K, const void *A, int lda, const void *B, int ldb, float *C, int ldc,
+                    void *scratch, void *stream);
 /* out[c] += sum_m A[m][c]; scratch: ceil(M / 128) * N floats */
 int da_colsum_f32(int M, int N, const float *A, int lda, float *out, void *scratch, void *stream);
 /* dW[i] += sum_{r<4} dBank[table[4 i + r]]: backward of the filter-bank gather (trans_filter) */
