@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -135,6 +135,7 @@ PROTOTYPES = {
     "da_gemm_tn_bf16": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp]),
     "da_colsum_f32": (C.c_int, [C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp]),
     "da_enc_bank_grad": (C.c_int, [C.c_int, _fp, _fp, _fp, _fp]),
+    "da_expander_mask": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp]),
     "da_train_backward": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp,
                                     _fp, C.c_size_t, _fp]),
 }

@@ -277,18 +277,8 @@ def expander_plan(perms, degree, batch_device=None, virt_nodes=0):
     if (n * d) % 2 != 0:
         raise TypeError("nodes * degree must be even")
     N = G * n
-    batch = torch.arange(G, device=dev).repeat_interleave(n)
-    counts = torch.full((G,), n, dtype=torch.int64, device=dev)
-    graph_ptr = torch.arange(G + 1, device=dev, dtype=torch.int64) * n
     V = int(virt_nodes)
     n_nodes = N + V * G
-    padded = (counts + V + 63) // 64 * 64
-    pad_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
-    pad_ptr[1:] = torch.cumsum(padded, 0)
-    row_map = torch.arange(N, device=dev) - graph_ptr[batch] + pad_ptr[batch]
-    if V > 0:
-        vg = torch.arange(V * G, device=dev) // V
-        row_map = torch.cat([row_map, pad_ptr[vg] + n + torch.arange(V * G, device=dev) % V])
 
     def edge_list():
         ei, b = expander.regular_edge_index(perms, d)
@@ -299,26 +289,60 @@ def expander_plan(perms, degree, batch_device=None, virt_nodes=0):
     n_virt_edges = (N + G * V * (n + V)) if V > 0 else 0
     E = N * d + n_virt_edges
     if not dup_free or mode == "off" or not (n >= 256 and d * n >= 0.03 * n * n or mode == "force"):
+        batch = torch.arange(G, device=dev).repeat_interleave(n)
         return build_plan(edge_list(), batch, V)                          # generic route (multi-edges, tiny graphs, ...)
-    pos = torch.empty_like(perms)
-    pos.scatter_(1, perms, torch.arange(n, device=dev).expand(G, n))      # pos[g, node] = its position in the permutation
-    dist = (pos[:, :, None] - pos[:, None, :]) % n                        # [G, target, source]
-    cd = torch.minimum(dist, n - dist)
-    adj = (cd >= 1) & (cd <= reps)
-    if d % 2 == 1:
-        adj |= cd * 2 == n
-    mask, mask_ptr = _pack_mask(counts, padded, graph_ptr, uniform_bool=adj)
-    if V > 0:
-        ve = exophormer_edge_index(torch.zeros((2, 0), dtype=torch.int64, device=dev), batch, V, G)
-        irr_ptr, irr_src = _irregular_csr(ve[0], ve[1], n_nodes)
-    else:
-        e = torch.zeros(0, dtype=torch.int64, device=dev)
-        irr_ptr, irr_src = _irregular_csr(e, e, n_nodes)
+    # everything but the adjacency bits depends on the Batch SHAPE only: built once per (G, n, V, device)
+    key = (G, n, V, str(dev))
+    sh = _EXPANDER_SHAPES.get(key)
+    if sh is None:
+        batch = torch.arange(G, device=dev).repeat_interleave(n)
+        counts = torch.full((G,), n, dtype=torch.int64, device=dev)
+        graph_ptr = torch.arange(G + 1, device=dev, dtype=torch.int64) * n
+        padded = (counts + V + 63) // 64 * 64
+        pad_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+        pad_ptr[1:] = torch.cumsum(padded, 0)
+        row_map = torch.arange(N, device=dev) - graph_ptr[batch] + pad_ptr[batch]
+        if V > 0:
+            vg = torch.arange(V * G, device=dev) // V
+            row_map = torch.cat([row_map, pad_ptr[vg] + n + torch.arange(V * G, device=dev) % V])
+            ve = exophormer_edge_index(torch.zeros((2, 0), dtype=torch.int64, device=dev), batch, V, G)
+            irr_ptr, irr_src = _irregular_csr(ve[0], ve[1], n_nodes)
+        else:
+            e = torch.zeros(0, dtype=torch.int64, device=dev)
+            irr_ptr, irr_src = _irregular_csr(e, e, n_nodes)
+        stride = int(padded[0]) // 8
+        mask_ptr = torch.arange(G + 1, device=dev, dtype=torch.int64) * (n * stride)
+        sh = dict(counts=counts, padded=padded, graph_ptr=graph_ptr, stride=stride, mask_ptr=mask_ptr,
+                  n_pad=int(pad_ptr[-1]), pad_ptr=pad_ptr.to(torch.int32), row_map=row_map.to(torch.int32).contiguous(),
+                  graph_ptr32=graph_ptr.to(torch.int32), irr_ptr=irr_ptr, irr_src=irr_src)
+        if len(_EXPANDER_SHAPES) > 16:
+            _EXPANDER_SHAPES.clear()
+        _EXPANDER_SHAPES[key] = sh
+    if dev.type == "cuda":
+        # two launches: inverse permutations, then the bit rows (csrc/da_graph.hip)
+        from . import _lib
+        perms64 = perms.to(torch.int64).contiguous()
+        mask = torch.zeros(G * n * sh["stride"] + 64, dtype=torch.uint8, device=dev)
+        pos32 = torch.empty(G * n, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().da_expander_mask(G, n, d, _lib.ptr(perms64), _lib.ptr(pos32), sh["stride"], _lib.ptr(mask),
+                                               _lib.stream_ptr(dev)))
+    else:                                                                 # host tensors (CPU tests of the host logic)
+        pos = torch.empty_like(perms)
+        pos.scatter_(1, perms, torch.arange(n, device=dev).expand(G, n))  # pos[g, node] = its position in the permutation
+        dist = (pos[:, :, None] - pos[:, None, :]) % n                    # [G, target, source]
+        cd = torch.minimum(dist, n - dist)
+        adj = (cd >= 1) & (cd <= reps)
+        if d % 2 == 1:
+            adj |= cd * 2 == n
+        mask, _ = _pack_mask(sh["counts"], sh["padded"], sh["graph_ptr"], uniform_bool=adj)
     return GraphPlan(
-        n_pad=int(pad_ptr[-1]), pad_ptr=pad_ptr.to(torch.int32), row_map=row_map.to(torch.int32).contiguous(),
+        n_pad=sh["n_pad"], pad_ptr=sh["pad_ptr"], row_map=sh["row_map"],
         n_nodes=n_nodes, n_real=N, n_graphs=G, dense=0, n_edges=E, max_graph_nodes=n,
-        row_ptr=None, col_src=None, edge_id=None, graph_ptr=graph_ptr.to(torch.int32), _edge_index=None,
-        edge_index_fn=edge_list, hybrid=1, mask=mask, mask_ptr=mask_ptr, irr_row_ptr=irr_ptr, irr_col_src=irr_src)
+        row_ptr=None, col_src=None, edge_id=None, graph_ptr=sh["graph_ptr32"], _edge_index=None,
+        edge_index_fn=edge_list, hybrid=1, mask=mask, mask_ptr=sh["mask_ptr"], irr_row_ptr=sh["irr_ptr"], irr_col_src=sh["irr_src"])
+
+
+_EXPANDER_SHAPES = {}
 
 
 def _detect_dense(edge_index, batch, counts):

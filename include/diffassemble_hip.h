@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 10
+#define DA_ABI_VERSION 11
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -434,6 +434,14 @@ int da_gemm_tn_bf16(int M, int N, int K, const void *A, int lda, const void *B, 
 int da_colsum_f32(int M, int N, const float *A, int lda, float *out, void *scratch, void *stream);
 /* dW[i] += sum_{r<4} dBank[table[4 i + r]]: backward of the filter-bank gather (trans_filter) */
 int da_enc_bank_grad(int n, const int32_t *table, const float *dbank, float *dW, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Exphander graphs (dataset/puzzle_dataset.py:115-152 generate_random_regular_graph): the adjacency
+ * bit rows of da_graph.mask for n_graphs graphs of n nodes and degree d, from the permutations the generator draws
+ * (perms int64 [n_graphs, n]): bit j of row i of graph g = edge j -> i, rows of row_bytes bytes, graph g at
+ * g * n * row_bytes.  pos: int32 scratch [n_graphs * n] (receives the inverse permutations).  Two launches. */
+int da_expander_mask(int n_graphs, int n, int degree, const int64_t *perms, int32_t *pos, int row_bytes,
+                     unsigned char *mask, void *stream);
 
 #ifdef __cplusplus
 }

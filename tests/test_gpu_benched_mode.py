@@ -455,3 +455,20 @@ def test_3d_module_p_sample_loop_and_eval_hooks(dev):
     m.validation_epoch_end([])
     out = m.predict_step(batch, 0)
     assert len(out[0]) == 30
+
+
+@pytest.mark.parametrize("n,d,V,G", [(900, 539, 8, 3), (900, 90, 8, 2), (320, 81, 4, 2), (256, 200, 0, 4)])
+def test_expander_mask_kernel_equals_host_closed_form(dev, n, d, V, G, monkeypatch):
+    """graph_plan.expander_plan on the device (da_expander_mask: inverse permutations + bit rows, two launches; the
+    shape-only parts cached) against the same function on host tensors (torch closed form, itself checked against the plan
+    built from the reference generator's edge list in tests/test_host.py): every plan array bit for bit, odd degrees and
+    a second Batch of the same shape included."""
+    monkeypatch.setenv("DIFFASSEMBLE_HYBRID", "force")
+    from diffassemble_amd import expander, graph_plan as GP
+    for seed in (0, 1):
+        perms = expander.draw_permutations(n, G, np.random.default_rng(seed))
+        a = GP.expander_plan(perms.to(dev), d, virt_nodes=V)
+        b = GP.expander_plan(perms, d, virt_nodes=V)
+        assert a.hybrid == b.hybrid == 1 and a.n_edges == b.n_edges and a.n_pad == b.n_pad
+        for f in ("mask", "mask_ptr", "row_map", "pad_ptr", "graph_ptr", "irr_row_ptr", "irr_col_src"):
+            assert torch.equal(getattr(a, f).cpu(), getattr(b, f)), (f, seed)
