@@ -380,3 +380,64 @@ def test_data_parallel_training_two_ranks_equals_full_batch(dev):
     assert float((g2 - g1).abs().max() / g1.abs().max()) < 1e-5          # averaged shard gradients == full-batch gradient
     assert rel(a[keep], full[keep]) < 2e-4, rel(a[keep], full[keep])      # ... and so are three optimizer steps
 
+
+
+def _dp_pixels_worker(rank, world, port, ret):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import weights as WW
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    dev = torch.device("cuda:0")
+    T, n = 100, 36
+    m = GNN_Diffusion(steps=T, sampling="DDIM", rotation=True, model_mean_type=ModelMeanType.EPSILON, visual_pretrained=False,
+                      backbone="resnet18equiv", freeze_backbone=False)
+    m.model.load_state_dict({**WW.make_denoiser_state(T, 4, 4, seed=41),
+                             **{"visual_backbone." + k: v for k, v in WW.make_encoder_state(41).items()}}, strict=False)
+    m = m.to(dev).train()
+    opt = m.configure_optimizers()
+    g = torch.Generator().manual_seed(100 + rank)                      # every rank its own puzzle
+    x0, noise = torch.randn(n, 4, generator=g), torch.randn(n, 4, generator=g)
+    crops = torch.rand(n, 3, 32, 32, generator=g)
+    t = torch.full((n,), 30 + rank, dtype=torch.int64)
+    ei, batch = WW.dense_edge_index(n, True), torch.zeros(n, dtype=torch.int64)
+    enc = m.model.visual_backbone
+    for step in range(2):
+        opt.zero_grad()
+        loss = m.p_losses(x0.to(dev), t.to(dev), noise=noise.to(dev), loss_type="huber", cond=crops.to(dev), edge_index=ei.to(dev),
+                          batch=batch.to(dev))
+        loss.backward()
+        if step == 0:
+            ret[f"local_{rank}"] = torch.cat([p.grad.reshape(-1) for p in enc.parameters()]).cpu()
+        m.on_before_optimizer_step(opt)
+        if step == 0:
+            ret[f"synced_{rank}"] = torch.cat([p.grad.reshape(-1) for p in enc.parameters()]).cpu()
+        opt.step()
+    torch.cuda.synchronize()
+    ret[f"enc_{rank}"] = torch.cat([p.detach().reshape(-1) for p in enc.parameters()]).cpu()
+    ret[f"den_{rank}"] = m.model.train_engine().flat.detach().cpu()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_from_pixels_averages_encoder_gradients(dev):
+    """Two ranks training encoder + denoiser from their own crops (per-rank BatchNorm statistics, as under the reference's
+    DDP): on_before_optimizer_step leaves on every rank the MEAN of the two ranks' encoder gradients (the encoder's HIP
+    backward writes param.grad directly, so a DDP reducer would never see them), and after two HybridAdafactor steps the
+    replicas hold bit-identical encoder and denoiser parameters."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_pixels_worker, args=(2, 29571, ret), nprocs=2, join=True)
+    mean = 0.5 * (ret["local_0"] + ret["local_1"])
+    assert torch.equal(ret["synced_0"], ret["synced_1"])
+    assert float((ret["synced_0"] - mean).abs().max()) <= 1e-6 * float(mean.abs().max())
+    assert not torch.equal(ret["local_0"], ret["local_1"])
+    assert torch.equal(ret["enc_0"], ret["enc_1"]) and torch.equal(ret["den_0"], ret["den_1"])
