@@ -25,6 +25,9 @@ namespace da {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16w;
 
+#ifndef DA_WREG_NSTG
+#define DA_WREG_NSTG 4
+#endif
 template <int N> __device__ __forceinline__ void wreg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int KIN, bool QKV, int ACT>
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_w
     constexpr int TILEB = 32 * ROWB;             // one 32-row tile
     constexpr int NDMA = TILEB / 1024;           // 1 KB DMA instructions per tile
     constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (32 / 16)
-    constexpr int NSTG = 4;
+    constexpr int NSTG = DA_WREG_NSTG;
     constexpr int SROW = 144;                    // strip row: 32 fp32 + 16 B pad
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *ring = smem;                                  // [NSTG][TILEB]
@@ -51,6 +54,7 @@ __global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_w
         // ------------------------------------------------ producer wave
         const int rsub = lane / CPR, pc = lane % CPR;             // row inside a DMA instruction, physical chunk
         auto issue = [&](int ti) {
+            if (p.debug & 1024) return;
             const int row0 = (t0 + ti) * 32;
             unsigned char *buf = ring + (ti % NSTG) * TILEB;
 #pragma unroll
@@ -71,8 +75,10 @@ __global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_w
         for (int ti = 0; ti < pre; ++ti) issue(ti);
         for (int i = 0; i < ntile; ++i) {
             const int issued = min(ntile, i + NSTG - 1);          // tiles 0 .. issued-1 are in flight or landed
-            const int younger = issued - 1 - i;                   // tiles after i that may stay in flight: 0, 1 or 2
-            if (younger >= 2) wreg_wait_vmcnt<2 * PER>();
+            const int younger = issued - 1 - i;                   // tiles after i that may stay in flight: 0 .. NSTG - 2
+            static_assert((NSTG - 2) * PER <= 63, "vmcnt is a 6-bit counter");
+            if (NSTG >= 5 && younger >= 3) wreg_wait_vmcnt<(NSTG >= 5 ? 3 : 0) * PER>();
+            else if (younger >= 2) wreg_wait_vmcnt<2 * PER>();
             else if (younger == 1) wreg_wait_vmcnt<PER>();
             else wreg_wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                         // tile i is readable; everyone is done with tile i - 1
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_w
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < PF; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[gq * PF + s]),
+                if (!(p.debug & 512)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[gq * PF + s]),
                                                               __builtin_bit_cast(bf16x8, xa[gq & 1][s]), acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -167,12 +173,185 @@ __global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_w
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)apply_act(v[e] + bz[e], ACT);
             const int m = row0 + row;
-            if (m < p.M) {
+            if (m < p.M && !(p.debug & 256)) {
                 const size_t ridx = use_slot ? (size_t)sl[row] : (size_t)m;
                 *(u32x4 *)(dbase + ridx * rstride) = __builtin_bit_cast(u32x4, o);
             }
         }
     }
+}
+
+template <int KIN, bool QKV, int ACT>
+__global__ __launch_bounds__(320) void k_gemm_wreg2(GemmParams p, int tiles_per_wg) {
+    constexpr int KS = KIN / 16;                 // k-steps of 16
+    constexpr int ROWB = KIN * 2;                // bytes of one A row
+    constexpr int TILEB = 32 * ROWB;             // one 32-row tile
+    constexpr int NDMA = TILEB / 1024;           // 1 KB DMA instructions per tile
+    constexpr int CPR = ROWB / 16;               // 16-byte chunks per row (32 / 16)
+    constexpr int NSTG = DA_WREG_NSTG;
+    constexpr int SROW = 272;                    // strip row: 64 fp32 + 16 B pad
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *ring = smem;                                  // [NSTG][TILEB]
+    unsigned char *slots = smem + NSTG * TILEB;                  // [NSTG][256 B]: padded-row slot of the tile's 32 nodes
+    unsigned char *strips = slots + NSTG * 256;                  // [4][32][SROW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nrt = (p.M + 31) >> 5;
+    const int t0 = blockIdx.y * tiles_per_wg, t1 = min(t0 + tiles_per_wg, nrt);
+    const int ntile = t1 - t0;
+    if (ntile <= 0) return;
+
+    if (wid == 4) {
+        // ------------------------------------------------ producer wave
+        const int rsub = lane / CPR, pc = lane % CPR;             // row inside a DMA instruction, physical chunk
+        auto issue = [&](int ti) {
+            if (p.debug & 1024) return;
+            const int row0 = (t0 + ti) * 32;
+            unsigned char *buf = ring + (ti % NSTG) * TILEB;
+#pragma unroll
+            for (int q = 0; q < NDMA; ++q) {
+                const int row = q * (64 / CPR) + rsub;            // row inside the tile
+                const int lc = pc ^ (row & 15);                   // logical chunk this LDS slot holds
+                const char *src = (const char *)p.A + (size_t)min(row0 + row, p.M - 1) * (size_t)p.lda * 2 + lc * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(buf + q * 1024), 16, 0, 0);
+            }
+            // padded-row slots of the tile's nodes (QKV scatter); one 4-byte piece per lane, lanes >= 32 re-load row 31
+            const int32_t *rm = QKV ? p.row_map + min(row0 + min(lane, 31), p.M - 1) : (const int32_t *)p.A;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rm,
+                                             (__attribute__((address_space(3))) void *)(slots + (ti % NSTG) * 256), 4, 0, 0);
+        };
+        constexpr int PER = NDMA + 1;
+        const int pre = min(NSTG - 1, ntile);
+        for (int ti = 0; ti < pre; ++ti) issue(ti);
+        for (int i = 0; i < ntile; ++i) {
+            const int issued = min(ntile, i + NSTG - 1);          // tiles 0 .. issued-1 are in flight or landed
+            const int younger = issued - 1 - i;                   // tiles after i that may stay in flight: 0 .. NSTG - 2
+            static_assert((NSTG - 2) * PER <= 63, "vmcnt is a 6-bit counter");
+            if (NSTG >= 5 && younger >= 3) wreg_wait_vmcnt<(NSTG >= 5 ? 3 : 0) * PER>();
+            else if (younger >= 2) wreg_wait_vmcnt<2 * PER>();
+            else if (younger == 1) wreg_wait_vmcnt<PER>();
+            else wreg_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                         // tile i is readable; everyone is done with tile i - 1
+            if (i + NSTG - 1 < ntile) issue(i + NSTG - 1);        // into the slot of tile i - 1
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- consumer waves
+    const int i32 = lane & 31, half = lane >> 5;
+    const int col0 = blockIdx.x * 256 + wid * 64;
+    const bool active = col0 < p.Nout;
+    // this wave's 32 columns of W as A-operand fragments: lane (col, half), k-step s -> W[col][16 s + 8 half ..+8]
+    u32x4 wf[2][KS];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const char *wrow = (const char *)p.W + (size_t)min(col0 + cb * 32 + i32, p.Nout - 1) * (size_t)p.ldw * 2 + half * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wf[cb][s] = *(const u32x4 *)(wrow + s * 32);
+    }
+    // row-major side of the epilogue: this lane stores the 16-byte chunk `ch` (8 columns) of rows rr and rr + 16
+    const int ch = lane & 7, rr = lane >> 3;
+    const int colc = col0 + 8 * ch;
+    float bz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bz[e] = (p.bias && active) ? p.bias[min(colc + e, p.Nout - 1)] : 0.f;
+    bf16_t *dbase;
+    size_t rstride;
+    bool use_slot = false;
+    if (!QKV) {
+        dbase = (bf16_t *)p.out + colc;
+        rstride = (size_t)p.ldo;
+    } else {
+        const int which = min(colc / p.HC, 3), f = colc - which * p.HC;
+        if (which == 2 && p.Cv > 0) {
+            const int h = f / p.Cv, c = f - h * p.Cv;
+            dbase = (bf16_t *)p.Vt + (size_t)h * p.n_pad * p.Cv + c;
+            rstride = (size_t)p.Cv;
+            use_slot = true;
+        } else if (which == 3) {
+            dbase = (bf16_t *)p.S + f;
+            rstride = (size_t)p.HC;
+        } else {
+            const int h = f / p.C, c = f - h * p.C;
+            dbase = (bf16_t *)(which == 0 ? p.Q : (which == 1 ? p.Kb : p.Vt)) + (size_t)h * p.n_pad * p.C + c;
+            rstride = (size_t)p.C;
+            use_slot = true;
+        }
+    }
+    unsigned char *strip = strips + wid * (32 * SROW);
+    // wait for the W / bias loads here, once: inside the loop this wave only ever issues stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Software pipeline (one consumer wave per SIMD: nobody else hides this wave's epilogue): the MFMAs of tile i are issued
+    // first and run on the matrix pipe while the wave converts and stores tile i - 1 out of its LDS strip; only then are
+    // the accumulators of tile i written to the strip.  The padded-row slots of a tile are copied to registers when it
+    // lands (the producer refills that ring entry one barrier later).
+    int slot_prev[4] = {0, 0, 0, 0}, slot_cur[4] = {0, 0, 0, 0};
+    auto drain = [&](int it) {                                    // strip (tile `it`) -> bf16 -> global
+        const int row0 = (t0 + it) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = rr + 8 * k;
+            const f32x4 a = *(const f32x4 *)(strip + row * SROW + ch * 32);
+            const f32x4 b = *(const f32x4 *)(strip + row * SROW + ch * 32 + 16);
+            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)apply_act(v[e] + bz[e], ACT);
+            const int m = row0 + row;
+            if (m < p.M && !(p.debug & 256)) {
+                const size_t ridx = use_slot ? (size_t)slot_prev[k] : (size_t)m;
+                *(u32x4 *)(dbase + ridx * rstride) = __builtin_bit_cast(u32x4, o);
+            }
+        }
+    };
+    for (int i = 0; i < ntile; ++i) {
+        __builtin_amdgcn_s_barrier();                             // producer: tile i has landed
+        if (!active) continue;
+        const unsigned char *buf = ring + (i % NSTG) * TILEB + i32 * ROWB;
+        if (QKV) {
+            const int32_t *sl = (const int32_t *)(slots + (i % NSTG) * 256);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) slot_cur[k] = sl[rr + 8 * k];
+        }
+        f32x16w acc, acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+        // x fragments one group of four k-steps ahead of their MFMAs (a dependent 16-byte LDS read in front of every
+        // MFMA leaves the matrix pipe idle for the read latency); sched_barrier keeps hipcc from sinking the reads again
+        constexpr int PF = 4, NG = KS / PF;
+        u32x4 xa[2][PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) xa[0][s] = *(const u32x4 *)(buf + (((2 * s + half) ^ (i32 & 15)) << 4));
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) {
+#pragma unroll
+                for (int s = 0; s < PF; ++s)
+                    xa[(gq + 1) & 1][s] = *(const u32x4 *)(buf + (((2 * ((gq + 1) * PF + s) + half) ^ (i32 & 15)) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < PF; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[0][gq * PF + s]),
+                                                              __builtin_bit_cast(bf16x8, xa[gq & 1][s]), acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[1][gq * PF + s]),
+                                                               __builtin_bit_cast(bf16x8, xa[gq & 1][s]), acc2, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i > 0) drain(i - 1);                                  // under the matrix pipe's work on tile i
+        __builtin_amdgcn_sched_barrier(0);
+        // D^T[col][node]: lane (node = i32, half) holds columns 8 j + 4 half + (0..3) -> strip[node][col] fp32
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(f32x4 *)(strip + i32 * SROW + (8 * j + 4 * half) * 4) = (f32x4){acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+            *(f32x4 *)(strip + i32 * SROW + 128 + (8 * j + 4 * half) * 4) = (f32x4){acc2[4 * j], acc2[4 * j + 1], acc2[4 * j + 2], acc2[4 * j + 3]};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) slot_prev[k] = slot_cur[k];
+    }
+    if (active && ntile > 0) drain(ntile - 1);
 }
 
 static bool wreg_disabled() {
@@ -187,7 +366,15 @@ int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int a
     GemmParams p = p0;
     // measured (28 800 rows): faster than the A-stationary kernel from ~1100 output columns up (K = 256: 3456 columns 77 vs 90 us,
     // 4608: 97 vs 119; 1024: 39 vs 36 -- too few column groups to fill the chip), K = 128 x 1152: 23.5 vs 26 us
-    if ((p.K != 128 && p.K != 256) || p.pre || p.res || p.M < 4096 || (p.Nout & 31) || p.Nout < 1100) return -1;
+    // Two variants.  k_gemm_wreg: 8 consumer waves x 32 columns (two waves per SIMD cover each other's epilogues): the wide
+    // projections (Nout >= 1100: conv 3, 110 vs 115 us).  k_gemm_wreg2: 4 consumer waves x 64 columns -- every x fragment
+    // read from LDS feeds two MFMAs, half the LDS reads and barriers per FLOP -- for 512 <= Nout < 1100, where it replaces
+    // the A-stationary kernel (57 600 rows: K = 256 x 1024 columns 70.5 -> 48.9 us, K = 128 x 1024 53.6 -> 38.6 us; the
+    // A-stationary kernel re-streams all of W through LDS for every 128-row panel).  DA_WREG2=0 / =1 force one of them.
+    static int v2mode = -2;
+    if (v2mode == -2) { const char *e = getenv("DA_WREG2"); v2mode = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    const bool v2 = v2mode == 1 || (v2mode == -1 && p.Nout < 1100);
+    if ((p.K != 128 && p.K != 256) || p.pre || p.res || p.M < 4096 || (p.Nout & (v2 ? 63 : 31)) || p.Nout < (v2 ? 512 : 1100)) return -1;
     if (qs) {
         // a wave's 16-byte output chunk (8 columns) must not straddle a column block or a head
         if ((qs->HC & 31) || (qs->C & 7) || (qs->Cv & 7) || act != DA_ACT_NONE) return -1;
@@ -203,7 +390,17 @@ int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int a
     const dim3 grid((unsigned)ncg, (unsigned)nchunk);
 #define DA_WREG(KK, QQ, AA)                                                                                              \
     do {                                                                                                                  \
-        constexpr int lds = 4 * 32 * KK * 2 + 4 * 256 + 8 * 32 * 144;                                                     \
+        if (v2) {                                                                                                         \
+            constexpr int lds2 = DA_WREG_NSTG * 32 * KK * 2 + DA_WREG_NSTG * 256 + 4 * 32 * 272;                          \
+            static bool attr2 = false;                                                                                    \
+            if (!attr2) {                                                                                                 \
+                DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_wreg2<KK, QQ, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2)); \
+                attr2 = true;                                                                                             \
+            }                                                                                                             \
+            k_gemm_wreg2<KK, QQ, AA><<<grid, 320, lds2, st>>>(p, tiles);                                                  \
+            break;                                                                                                        \
+        }                                                                                                                 \
+        constexpr int lds = DA_WREG_NSTG * 32 * KK * 2 + DA_WREG_NSTG * 256 + 8 * 32 * 144;                                                     \
         static bool attr = false;                                                                                         \
         if (!attr) {                                                                                                      \
             DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_wreg<KK, QQ, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
