@@ -14,6 +14,7 @@ CLASS = [  # (regex on the kernel name, class)
     (r"k_attn_csr<unsigned short, 4>", "attn_hidden"), (r"k_attn_csr<unsigned short, 18>", "attn_last"),
     (r"k_attn_csr_cont", "attn_hidden"),
     (r"k_gemm_astat_rs<unsigned short, true", "linear_qkvs"), (r"k_gemm_wreg<256, true", "linear_qkvs"),
+    (r"k_gemm_wreg2<", "linear_qkvs"),
     (r"k_gemm_wreg<256, false", "linear_qkvs"), (r"k_embed_pos_time", "embed"), (r"k_head_fold", "head"),
 ]
 # tag -> (bench config key, puzzles per GPU, launches of the class per denoising step)
