@@ -171,3 +171,19 @@ def test_3d_module_samples_from_raw_fragments(dev):
     assert final.shape == (P, 7)
     acc = float(m.metrics["part_acc_everyday"].compute())
     assert 0.0 <= acc <= 1.0
+
+
+def test_large_clouds_and_other_k(dev):
+    """Clouds beyond the register-resident selection (N > 1024: the scores stay in LDS, da_knn's ordered path) through
+    the whole encoder, and da_knn for k other than 20 (nearest first, against torch's sort of the same scores)."""
+    from diffassemble_amd.pcd_encoder import PcdEncoderEngine, knn
+    sd, pts = W.make_vn_dgcnn_state(128, 31), W.make_point_clouds(2, 1500, 32)
+    assert_clouds_close(PcdEncoderEngine(sd, device=dev).forward(pts.to(dev)), OV.forward(sd, pts.numpy()), 1500)
+    x = W.make_point_clouds(3, 700, 33)
+    d = torch.cdist(x, x).pow(2)
+    for k in (1, 5, 33, 64):
+        idx = knn(x.to(dev), k=k).cpu().long()
+        got = torch.gather(d, 2, idx)
+        want = d.sort(2)[0][:, :, :k]
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-7), k
+        assert (got[:, :, 1:] >= got[:, :, :-1] * (1 - 1e-4) - 1e-7).all()        # cdist's own rounding: not exactly monotone
