@@ -479,11 +479,14 @@ static int knn_launch(int clouds, int N, int dim, const float *x, int ldx, int k
     while (QB > 1 && bytes(QB) > 64 * 1024) QB >>= 1;          // two blocks per CU
     DA_REQUIRE(bytes(QB) <= 160 * 1024 - 512, "kNN: %d points per cloud do not fit the LDS slab", N);
     const dim3 grid((N + QB - 1) / QB, clouds);
+    // the dynamic-LDS ceiling is raised ONCE per kernel (not per launch: the launches must stay stream-capturable)
+    static bool attr3 = false, attr64 = false;
+    constexpr int LDS_MAX = 160 * 1024 - 512;
     if (F == 3) {
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(QB)));
+        if (!attr3) { DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX)); attr3 = true; }
         k_pcd_knn<3><<<grid, 256, bytes(QB), st>>>(x, ldx, N, QB, Npad, k, ordered, idx);
     } else {
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes(QB)));
+        if (!attr64) { DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX)); attr64 = true; }
         k_pcd_knn<64><<<grid, 256, bytes(QB), st>>>(x, ldx, N, QB, Npad, k, ordered, idx);
     }
     DA_LAUNCH_CHECK();

@@ -187,3 +187,26 @@ def test_large_clouds_and_other_k(dev):
         want = d.sort(2)[0][:, :, :k]
         assert torch.allclose(got, want, rtol=1e-4, atol=1e-7), k
         assert (got[:, :, 1:] >= got[:, :, :-1] * (1 - 1e-4) - 1e-7).all()        # cdist's own rounding: not exactly monotone
+
+
+def test_pcd_encoder_is_stream_capturable(dev):
+    """da_pcd_encoder_forward inside a hipGraph (as its header promises): capture once, replay on new clouds written into
+    the captured input buffer, same bits as the eager call."""
+    from diffassemble_amd.pcd_encoder import PcdEncoderEngine
+    sd = W.make_vn_dgcnn_state(128, 51)
+    eng = PcdEncoderEngine(sd, device=dev)
+    buf = W.make_point_clouds(6, 300, 52).to(dev)
+    out = torch.empty(6, 768, device=dev)
+    eng.forward(buf, out)                                   # warm-up: workspace allocation, one-time attributes
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            eng.forward(buf, out)
+    new = W.make_point_clouds(6, 300, 53).to(dev)
+    buf.copy_(new)
+    g.replay()
+    torch.cuda.synchronize()
+    got = out.clone()
+    assert torch.equal(got, eng.forward(new.clone()))
