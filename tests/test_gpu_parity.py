@@ -57,11 +57,13 @@ def test_da_linear(dev, M, K, N, act, prec):
     assert rel(out.float(), ref) < (1e-5 if prec == "fp32" else 1e-2)
 
 
-@pytest.mark.parametrize("M,K,N,act", [(5000, 256, 1152, 0), (4101, 128, 1120, 1), (9000, 256, 2560, 0), (4096, 256, 1312, 1)])
+@pytest.mark.parametrize("M,K,N,act", [(5000, 256, 1152, 0), (4101, 128, 1120, 1), (9000, 256, 2560, 0), (4096, 256, 1312, 1),
+                                        (4500, 256, 1024, 0), (4099, 128, 1024, 1), (7001, 256, 576, 1), (4096, 128, 512, 0), (4610, 256, 1088, 0)])
 def test_da_linear_tall_inputs_w_in_registers(dev, M, K, N, act):
-    """k_gemm_wreg (da_gemm_wreg.hip: W columns in registers, A tiles streamed by a producer wave) takes bf16 linears
-    with K in {128, 256} and M >= 4096; M not a multiple of the 32-row tile, Nout not a multiple of the 256-column
-    workgroup, GELU epilogue."""
+    """k_gemm_wreg / k_gemm_wreg2 (da_gemm_wreg.hip: W columns in registers, A tiles streamed by a producer wave) take bf16
+    linears with K in {128, 256} and M >= 4096 (Nout >= 1100: 8 waves x 32 columns; 512 <= Nout < 1100, multiple of 64:
+    4 waves x 64 columns); M not a multiple of the 32-row tile, Nout not a multiple of the 256-column workgroup (the last
+    one has idle waves), GELU epilogue."""
     from diffassemble_amd import engine as E
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(M, K, generator=g).bfloat16().float()
@@ -76,11 +78,11 @@ def test_da_linear_tall_inputs_w_in_registers(dev, M, K, N, act):
     assert rel(out.float(), ex) < 6e-3
 
 
-@pytest.mark.parametrize("C_head,loops", [(144, True), (144, False)])
+@pytest.mark.parametrize("C_head,loops", [(144, True), (144, False), (32, True), (32, False)])
 def test_da_conv_dense_tall_batch_through_w_in_registers_projection(dev, monkeypatch, C_head, loops):
-    """Five 900-piece puzzles (4500 nodes >= 4096): the fused Q|K|V|skip projection (4608 columns) goes through
-    k_gemm_wreg's QKV scatter (head-major rows at padded slots, 144-wide heads that straddle its 32-column wave
-    tiles)."""
+    """Five 900-piece puzzles (4500 nodes >= 4096): the fused Q|K|V|skip projection goes through the W-in-registers
+    kernels' QKV scatter (head-major rows at padded slots): 4608 columns of 144-wide heads that straddle k_gemm_wreg's
+    32-column wave tiles, and the 1024 columns of the 32-wide hidden layers through k_gemm_wreg2 (two heads per wave)."""
     from diffassemble_amd import engine as E
     from diffassemble_amd.graph_plan import build_plan
     H, Din, sizes = 8, 256, [900, 899, 901, 900, 900]
