@@ -249,7 +249,7 @@ def test_optimizer_steps_from_pixels_update_encoder_and_denoiser(dev):
                           edge_index=ei.to(dev), batch=batch.to(dev))
         loss.backward()
         opt.step()
-        return float(loss)
+        return float(loss.detach())
 
     l0 = step()
     # reference: oracle forward (training-mode encoder) + autograd + transformers' Adafactor on all live tensors
