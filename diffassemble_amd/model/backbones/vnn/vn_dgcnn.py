@@ -6,7 +6,6 @@ vn_layers.py): ``VN_DGCNN(feat_dim, inv)`` with the same state-dict keys (``conv
 The modules only HOLD parameters; an eval-mode forward runs in libdiffassemble_hip.so through
 ``diffassemble_amd.pcd_encoder.PcdEncoderEngine`` (kNN, vector-neuron layers and pooling as HIP kernels; no torch
 fallback).  Training-mode BatchNorm (batch statistics) and the backward through the encoder are not built."""
-import torch
 import torch.nn as nn
 
 from ....pcd_encoder import PcdEncoderEngine
