@@ -15,7 +15,6 @@ position by position), but vectorised: no per-graph Python loop, no ``batch.uniq
 Index plumbing only (torch sort/bincount on whatever device the inputs live on); the plan
 is built once per Batch and reused for all T sampling steps.
 """
-import ctypes as C
 from dataclasses import dataclass
 
 import torch
