@@ -472,3 +472,18 @@ def test_expander_mask_kernel_equals_host_closed_form(dev, n, d, V, G, monkeypat
         assert a.hybrid == b.hybrid == 1 and a.n_edges == b.n_edges and a.n_pad == b.n_pad
         for f in ("mask", "mask_ptr", "row_map", "pad_ptr", "graph_ptr", "irr_row_ptr", "irr_col_src"):
             assert torch.equal(getattr(a, f).cpu(), getattr(b, f)), (f, seed)
+
+
+@pytest.mark.parametrize("n,d,G", [(257, 100, 3), (320, 319, 2), (1000, 31, 1)])
+def test_expander_mask_kernel_odd_sizes(dev, n, d, G, monkeypatch):
+    """Node counts that are not multiples of 8 / 64 (ragged last mask byte), the densest degree (n - 1), odd degrees (the
+    antipodal matching needs an even n) and a sparse one under the forced hybrid mode: device plan == host closed form."""
+    monkeypatch.setenv("DIFFASSEMBLE_HYBRID", "force")
+    from diffassemble_amd import expander, graph_plan as GP
+    perms = expander.draw_permutations(n, G, np.random.default_rng(n + d))
+    a, b = GP.expander_plan(perms.to(dev), d, virt_nodes=4), GP.expander_plan(perms, d, virt_nodes=4)
+    assert a.hybrid == b.hybrid
+    if a.hybrid:
+        assert torch.equal(a.mask.cpu(), b.mask) and torch.equal(a.mask_ptr.cpu(), b.mask_ptr)
+    else:
+        assert torch.equal(a.row_ptr.cpu(), b.row_ptr) and torch.equal(a.col_src.cpu(), b.col_src)

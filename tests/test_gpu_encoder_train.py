@@ -226,3 +226,31 @@ def test_encoder_training_step_bf16(dev, seed, n):
     assert min(r[1] for r in heads) > 0.999 and min(r[1] for r in last) > 0.96 and min(r[1] for r in report) > 0.9, report
     assert all(abs(r[2] - 1) < 0.15 for r in report), report
     assert rel(net.bn1.running_mean, st["bn1.running_mean"]) < 1e-2
+
+
+@pytest.mark.parametrize("n", [1, 5])
+def test_encoder_training_tiny_batches(dev, n):
+    """One piece (BatchNorm statistics over a single piece's 4 x H x W values) and an odd batch: features and the last
+    block's gradients against the fp64 oracle."""
+    from diffassemble_amd.encoder_train import EncoderTrainEngine
+    from diffassemble_amd.model.backbones.resnet_equivariant import ResNet18
+    seed = 7
+    net = ResNet18(precision="fp32")
+    net.load_state_dict(W.make_encoder_state(seed))
+    net = net.to(dev).train()
+    eng = EncoderTrainEngine(net, dev)
+    x, G = W.make_patches(n, seed + 100), W.randn((n, 1088), seed + 200)
+    feats = eng.forward(x.to(dev))
+    eng.backward(G.to(dev))
+    sd = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else (v.double() if v.is_floating_point() else v))
+          for k, v in W.make_encoder_state(seed).items()}
+    OE.MEAN, OE.STD = OE.MEAN.double(), OE.STD.double()
+    try:
+        fo = OE.visual_features(sd, x.double(), stats={})
+        (fo * G.double()).sum().backward()
+    finally:
+        OE.MEAN, OE.STD = OE.MEAN.float(), OE.STD.float()
+    assert rel(feats, fo) < 2e-5
+    P = dict(net.named_parameters())
+    for k in ("linear1.weight", "linear2.bias", "layer4.1.bn2.weight", "layer4.1.conv2.weight"):
+        assert rel(P[k].grad, sd[k].grad) < (1e-5 if k.startswith("linear") else 2e-2), k

@@ -210,3 +210,19 @@ def test_pcd_encoder_is_stream_capturable(dev):
     torch.cuda.synchronize()
     got = out.clone()
     assert torch.equal(got, eng.forward(new.clone()))
+
+
+def test_smallest_cloud_and_single_fragment(dev):
+    """N = 20 (every point neighbours every point: the encoder's lower limit), one fragment; nearest_sq on 1-point clouds."""
+    from diffassemble_amd import _lib
+    from diffassemble_amd.pcd_encoder import PcdEncoderEngine, knn, nearest_sq
+    sd, pts = W.make_vn_dgcnn_state(128, 61), W.make_point_clouds(1, 20, 62)
+    eng = PcdEncoderEngine(sd, device=dev)
+    assert_clouds_close(eng.forward(pts.to(dev)), OV.forward(sd, pts.numpy()), 20)
+    idx = knn(pts.to(dev)).cpu()
+    assert all(sorted(r.tolist()) == list(range(20)) for r in idx[0])
+    with pytest.raises(_lib.DaError):
+        eng.forward(W.make_point_clouds(1, 19, 63).to(dev))             # fewer points than neighbours: loud, like topk
+    a, b = torch.tensor([[[0.0, 0.0, 0.0]]]), torch.tensor([[[1.0, 2.0, 2.0], [0.5, 0.0, 0.0]]])
+    d_ab, d_ba = nearest_sq(a.to(dev), b.to(dev))
+    assert torch.allclose(d_ab.cpu(), torch.tensor([[0.25]])) and torch.allclose(d_ba.cpu(), torch.tensor([[9.0, 0.25]]))
