@@ -682,10 +682,287 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     DA_ATTN_DBG(if (p.prof && tid == 0) { DA_TICK(t_end_); unsigned long long *o = p.prof + 8 * blockIdx.x; o[0] = t_end_ - t_start; o[1] = c_bar; o[2] = c_iss; o[3] = c_qk; o[4] = c_sm; o[5] = c_pv; o[6] = t_end_ - t_loop_end; o[7] = 1; })
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_attn_dense2: the C = 32 bf16 instance on complete graphs (the three hidden layers of the 2D arch = the class with the
+// largest share of the sampling step) with TWO 32-query slabs per wave.  Why: SQ counters and the ablation runs of
+// tools/attn_ablate.py say the one-slab kernel is bound by the instruction stream as a whole -- per 32 keys x 32 queries a
+// wave issues ~45 VALU + 4 MFMA next to ~45 "skeleton" instructions (K / V fragment reads, DMA issue, counted waits, barrier,
+// tail / diagonal tests, loop control), and the parts add up instead of overlapping across the 4 resident waves of a SIMD
+// (tools/overlap_probe.hip: even a clean MFMA -> VALU -> MFMA chain only overlaps ~35 %).  With two slabs every K / V
+// fragment read from LDS feeds the MFMAs of 64 queries, the skeleton is paid once per 2 x 1024 scores, a workgroup
+// (4 waves, 256 queries) streams each K / V tile once for twice the queries, and inside a wave the matrix work of one slab
+// sits next to the softmax of the other.  MEASURED: no faster (168 VGPRs = 3 waves per SIMD; see attn2_env below) -- the
+// skeleton was not what bounds the kernel.  Slabs w and w + 4 of the workgroup's eight belong to wave w, so the last tile of
+// a 900-piece puzzle (5 slabs) still gives every wave work (2, 1, 1, 1); one-slab waves run the NS = 1 body.
+// Same LDS image, DMA ring, fragment layouts, softmax and epilogue arithmetic as k_attn_dense<bf16_t, 32, false, 32, 4>:
+// results are bit-identical to it (tests/test_gpu_parity.py::test_attn_dense2_matches_one_slab_kernel).
+template <int NS> struct SlabTag { static constexpr int value = NS; };
+
+__global__ __launch_bounds__(256, 2) void k_attn_dense2(AttnDenseParams p) {
+    using T = bf16_t;
+    constexpr int C = 32, NST = 4, QT = 256;
+    using CF = Cfg<T, C, C>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int bid = blockIdx.x;
+    const int h = bid & 7, s_ = bid >> 3;
+    const int qt = s_ % p.nqt, g = s_ / p.nqt;                       // p.nqt counts 256-query tiles here
+    const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
+    if (qt * QT >= n_g) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nslab = min(8, (n_g - qt * QT + 31) >> 5);             // 32-query slabs of this workgroup
+    const bool wave_on = wid < nslab, two = wid + 4 < nslab;
+    const int HC = p.H * C;
+    const size_t np = (size_t)p.n_pad;
+
+    // Q fragments of both slabs stay in registers; rows beyond the graph are zeroed (their scores stay finite)
+    int q0[2], qidx[2];
+    u32x4 qf[2][CF::NCH];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        q0[sl] = qt * QT + (wid + 4 * sl) * 32;
+        qidx[sl] = q0[sl] + i;
+        const unsigned char *qrow = (const unsigned char *)p.Q + ((size_t)h * np + pad0 + min(q0[sl], n_g - 1) / 32 * 32 + i) * CF::ROWB;
+#pragma unroll
+        for (int ch = 0; ch < CF::NCH; ++ch) {
+            qf[sl][ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
+            if (qidx[sl] >= n_g) qf[sl][ch] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
+
+    // ---- LDS-DMA plan (as in k_attn_dense): instruction q (1 KB) of a tile is issued by wave q % 4
+    const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
+    const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWBV;
+    unsigned soff[CF::MAXI];
+#pragma unroll
+    for (int x = 0; x < CF::MAXI; ++x) {
+        const int q = wid + 4 * x;
+        unsigned o = 0;
+        if (q < CF::NIK) {
+            const int s = q * 64 + lane, row = s / CF::KSPR, col = s - row * CF::KSPR;
+            if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
+        } else {
+            const int s = (q - CF::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
+            if (row < CF::BKEYS && col < CF::KVALIDV) o = (unsigned)(row * CF::ROWBV + col * 16);
+        }
+        soff[x] = o;
+    }
+    auto issue = [&](int kt, int stage) {
+        unsigned char *sb = smem + stage * CF::STAGE;
+        const unsigned char *kb_ = Kg + (size_t)kt * CF::BKEYS * CF::ROWB;
+        const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ROWBV;
+#pragma unroll
+        for (int x = 0; x < CF::MAXI; ++x) {
+            const int q = wid + 4 * x;
+            if (4 * x + 3 < CF::NI || q < CF::NI) {
+                const unsigned char *src = (q < CF::NIK ? kb_ : vb_) + soff[x];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    const int nkt = (n_g + CF::BKEYS - 1) / CF::BKEYS;
+    const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);     // key fed to MFMA row i
+    const int koff = pi_i * CF::RS + half * 16;
+    const int li = lane & 15;
+    const int vbase = CF::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    constexpr int RSOF = C + 4;                                  // floats per staged output row
+    static_assert(QT * RSOF * 4 <= NST * CF::STAGE, "O staging must fit in the K/V ring");
+    float *so = (float *)smem;
+
+    auto run = [&](auto tag) {
+        constexpr int NS = decltype(tag)::value;
+        f32x16 O[NS];
+        float m[NS], l[NS];
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[sl][r] = 0.f;
+            m[sl] = -1e30f; l[sl] = 0.f;
+        }
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nkt) issue(st, st);
+        for (int kt = 0; kt < nkt; ++kt) {
+            {
+                constexpr int PERW = CF::NI / 4;
+                const int younger = min(nkt - 1 - kt, NST - 2);
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PERW) : "memory");
+                else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (kt + NST - 1 < nkt) issue(kt + NST - 1, (kt + NST - 1) % NST);
+            if (!wave_on) continue;
+            const unsigned char *stg = smem + (kt % NST) * CF::STAGE;
+#pragma unroll
+            for (int kb = 0; kb < CF::KB; ++kb) {
+                const int key0 = kt * CF::BKEYS + kb * 32;
+                if (key0 >= n_g) break;
+                u32x4 kf[CF::NCH];
+#pragma unroll
+                for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + koff + kb * 32 * CF::RS + ch * 32);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 s[NS];
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[sl][r] = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < CF::NCH; ++ch) s[sl] = mma_chunk(T(), kf[ch], qf[sl][ch], s[sl]);
+                }
+                // V fragments of this block (shared by the slabs): issued behind the QK^T chains, they land under the softmax
+                u32x2 vlo[2], vhi[2];
+                const unsigned vb = lds0 + (unsigned)((kt % NST) * CF::STAGE + vbase + kb * 32 * CF::RSV);
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    vlo[mm] = tr_read(vb, (8 * mm) * CF::RSV);
+                    vhi[mm] = tr_read(vb, (8 * mm + 4) * CF::RSV);
+                }
+                const int kbase = key0 + 16 * half;
+                const bool tail = key0 + 32 > n_g;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    const bool diag = p.nodiag && key0 < q0[sl] + 32 && key0 + 32 > q0[sl];
+                    if (tail || diag) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx[sl])) s[sl][r] = -INFINITY;
+                    }
+                    // online softmax against the running reference m (see k_attn_dense): no per-block max on the common path
+                    typedef __attribute__((ext_vector_type(2))) float f32x2;
+                    const f32x2 sc2 = {p.sc, p.sc};
+                    f32x2 e2[8];
+                    auto exp_block = [&](float ms_) {
+                        const f32x2 nm = {-ms_, -ms_};
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const f32x2 t = (f32x2){s[sl][2 * r], s[sl][2 * r + 1]} * sc2 + nm;
+                            e2[r] = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                        }
+                        const f32x2 a = (e2[0] + e2[1]) + (e2[2] + e2[3]), b = (e2[4] + e2[5]) + (e2[6] + e2[7]);
+                        const f32x2 c = a + b;
+                        return c[0] + c[1];
+                    };
+                    float bsum = exp_block(m[sl] * p.sc);
+                    if (__any(!(bsum < 16384.0f))) {
+                        const float a0 = fmaxf(fmaxf(s[sl][0], s[sl][1]), s[sl][2]), a1 = fmaxf(fmaxf(s[sl][3], s[sl][4]), s[sl][5]);
+                        const float a2 = fmaxf(fmaxf(s[sl][6], s[sl][7]), s[sl][8]), a3 = fmaxf(fmaxf(s[sl][9], s[sl][10]), s[sl][11]);
+                        const float a4 = fmaxf(fmaxf(s[sl][12], s[sl][13]), s[sl][14]);
+                        const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[sl][15]));
+                        const float mnew = fmaxf(m[sl], fmaxf(mloc, __shfl_xor(mloc, 32)));
+                        const float corr = __builtin_amdgcn_exp2f((m[sl] - mnew) * p.sc);
+                        m[sl] = mnew;
+                        l[sl] *= corr;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[sl][r] *= corr;
+                        bsum = exp_block(m[sl] * p.sc);
+                    }
+                    l[sl] += bsum;
+                    bf16x8 pf0, pf1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pf0[2 * e] = (__bf16)e2[e][0]; pf0[2 * e + 1] = (__bf16)e2[e][1];
+                        pf1[2 * e] = (__bf16)e2[4 + e][0]; pf1[2 * e + 1] = (__bf16)e2[4 + e][1];
+                    }
+                    if (sl == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]));
+                    const u32x4 v0 = {vlo[0][0], vlo[0][1], vhi[0][0], vhi[0][1]};
+                    const u32x4 v1 = {vlo[1][0], vlo[1][1], vhi[1][0], vhi[1][1]};
+                    O[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O[sl], 0, 0, 0);
+                    O[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O[sl], 0, 0, 0);
+                    if (sl + 1 < NS) __builtin_amdgcn_sched_barrier(0);      // slab 0's PV is in the matrix pipe under slab 1's softmax
+                }
+            }
+        }
+        // ---- normalise (PyG: sum + 1e-16) and stage O as [query][c] fp32 rows
+        dma_barrier();                                              // ring no longer read by anyone
+        if (wave_on) {
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const float lt = l[sl] + __shfl_xor(l[sl], 32);
+                const float inv = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+                float *orow = so + ((wid + 4 * sl) * 32 + i) * RSOF;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int c0 = 8 * jj + 4 * half;
+                    *(f32x4 *)(orow + c0) = (f32x4){O[sl][4 * jj] * inv, O[sl][4 * jj + 1] * inv, O[sl][4 * jj + 2] * inv, O[sl][4 * jj + 3] * inv};
+                }
+            }
+        }
+    };
+    if (two) run(SlabTag<2>());
+    else run(SlabTag<1>());
+    dma_barrier();
+
+    // ---- all 256 threads stream whole output rows: + skip (+ residual), activation, 16-byte coalesced stores
+    constexpr int EPC = 8, CPR = C / EPC;
+    const int nq = min(QT, n_g - qt * QT);
+    constexpr int NB = 3;
+    for (int it0 = tid; it0 < nq * CPR; it0 += 256 * NB) {
+        u32x4 skv[NB], rsv[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int it = it0 + 256 * k;
+            if (it < nq * CPR) {
+                const int q = it / CPR, ch = it - q * CPR;
+                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                skv[k] = *(const u32x4 *)((const T *)p.S + off);
+                if (p.res) rsv[k] = *(const u32x4 *)((const T *)p.res + off);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int it = it0 + 256 * k;
+            if (it < nq * CPR) {
+                const int q = it / CPR, ch = it - q * CPR;
+                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                const float *src = so + q * RSOF + ch * EPC;
+                float v[EPC], sk[EPC];
+                const f32x4 a = *(const f32x4 *)src, b2 = *(const f32x4 *)(src + 4);
+                v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b2[0]; v[5] = b2[1]; v[6] = b2[2]; v[7] = b2[3];
+                unpack_chunk(T(), skv[k], sk);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+                if (p.res) {
+                    unpack_chunk(T(), rsv[k], sk);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = apply_act(v[e], p.act);
+                stc((T *)p.out + off, v);
+            }
+        }
+    }
+}
+
+// opt-in (DA_ATTN2=1): measured EQUAL to the one-slab kernel at 64 puzzles (173 vs 174 us per conv) and slower at 32
+// (95.5 vs 89.1) -- kept as the record of the experiment, see DESIGN.md
+static int attn2_env() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_ATTN2"); v = e ? atoi(e) : 0; }
+    return v;
+}
+static int launch_attn_dense2(AttnDenseParams p, int heads, int n_graphs, int max_graph_nodes, hipStream_t st) {
+    using CF = Cfg<bf16_t, 32, 32>;
+    p.nqt = (max_graph_nodes + 255) / 256;
+    const int nblocks = p.nqt * heads * n_graphs;
+    k_attn_dense2<<<nblocks, 256, 4 * CF::STAGE, st>>>(p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T, int C, bool MASKED, int CV, int NST>
 static int launch_tcmn(const AttnDenseParams &p, int nblocks, hipStream_t st) {
     using CF = Cfg<T, C, CV>;
-    const int lds = NST * CF::STAGE + (MASKED ? 256 : 0);
+    int lds = NST * CF::STAGE + (MASKED ? 256 : 0);
+    DA_ATTN_DBG({ const char *e = getenv("DA_ATTN_LDS_PAD"); if (e) lds += atoi(e); })      // occupancy experiments
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C, MASKED, CV, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -746,6 +1023,8 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
         if (mk) return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, true, 32>(p, nblocks, st) : launch_tcm<float, 144, true, 32>(p, nblocks, st);
         return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, false, 32>(p, nblocks, st) : launch_tcm<float, 144, false, 32>(p, nblocks, st);
     }
+    if (prec == DA_PREC_BF16 && C == 32 && !p.mask && attn2_env() DA_ATTN_DBG(&& !p.debug && !p.prof))
+        return launch_attn_dense2(p, heads, n_graphs, max_graph_nodes, st);
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, nblocks, st) : launch_tc<bf16_t, 144>(p, nblocks, st);
     return C == 32 ? launch_tc<float, 32>(p, nblocks, st) : launch_tc<float, 144>(p, nblocks, st);
 }

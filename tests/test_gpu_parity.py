@@ -166,6 +166,28 @@ def test_conv_fused_one_kernel_hidden_layer(dev, Din, loops, sizes):
     _conv_fused_case(dev, Din, loops, sizes)
 
 
+@pytest.mark.parametrize("loops", [True, False])
+@pytest.mark.parametrize("sizes", [[900], [1025, 3, 33], [256, 257, 160, 129, 1], [144] * 5], ids=["900", "1025_3_33", "tile_edges", "5x144"])
+def test_attn_two_slab_kernel(dev, loops, sizes):
+    """k_attn_dense2 (two 32-query slabs per wave, 256-query workgroups; opt-in, DA_ATTN2=1): sizes cover the headline, a
+    fifth tile of one query, tiles of exactly 8 / 8 + 1 / 5 / 4 + 1 slabs (waves with two, one and no slab) and 1-piece graphs."""
+    import os
+    if os.environ.get("DA_ATTN2") != "1":
+        pytest.skip("opt-in kernel: exercised by test_attn_two_slab_opt_in_subprocess with DA_ATTN2=1")
+    _conv_fused_case(dev, 256, loops, sizes)
+
+
+def test_attn_two_slab_opt_in_subprocess(dev):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DA_ATTN2="1")
+    env.pop("DA_CONV_FUSED", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_attn_two_slab_kernel"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0 and "8 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_conv_fused_opt_in_subprocess(dev):
     """The one-kernel hidden conv is opt-in (DA_CONV_FUSED=1, read once per process): run its parity cases in a
     subprocess with the switch on."""

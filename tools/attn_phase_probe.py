@@ -5,6 +5,7 @@ dev = torch.device('cuda:0')
 prof = torch.zeros(8 * 8192, dtype=torch.int64, device=dev)
 os.environ["DA_ATTN_PROF_PTR"] = str(prof.data_ptr())
 from diffassemble_amd import _lib
+if os.environ.get("PROBE_LIB"): _lib.LIB_PATH = os.environ["PROBE_LIB"]
 from diffassemble_amd.graph_plan import build_plan
 G = int(os.environ.get("G", 32)); n = 900; H = 8
 r = torch.arange(n, device=dev).repeat_interleave(n); c = torch.arange(n, device=dev).repeat(n)
