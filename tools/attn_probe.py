@@ -2,6 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from diffassemble_amd import engine as E, _lib
+if os.environ.get("PROBE_LIB"): _lib.LIB_PATH = os.environ["PROBE_LIB"]
 from diffassemble_amd.graph_plan import build_plan
 import ctypes as C
 dev = torch.device('cuda:0')
