@@ -55,7 +55,8 @@ struct AttnDenseParams {
     const void *res;                // [N][H*C] or null
     void *out;                      // [N][H*C]
     const int32_t *graph_ptr, *pad_ptr;
-    int n_pad, H, n_graphs, nqt, act, nodiag;
+    int n_pad, H, n_graphs, nqt, act, nodiag;       // nqt = query tiles per graph (set by the launcher: depends on the waves per workgroup)
+    int max_nodes;                                  // largest graph of the batch
     float sc;                       // log2(e) / sqrt(C)
     unsigned long long *prof;       // DA_ATTN_PROBE: per-workgroup cycle breakdown of wave 0
     int debug;                      // DA_ATTN_DEBUG bits (timing experiments): 1 no DMA, 2 no softmax, 4 no PV, 8 no QK
@@ -173,9 +174,23 @@ __device__ __forceinline__ void stc(bf16_t *d, const float (&v)[8]) {
 // wave spends on one 64-key tile of the C = 32 layers: with two stages (one tile in flight) every tile waited for its own
 // DMA and the kernel ran at the DMA latency (15 tiles x ~2 us per workgroup, 8 workgroups per CU in two rounds = the
 // measured 55-61 us).  NST - 1 tiles are kept in flight instead, waited for with a COUNTED vmcnt.
-template <typename T, int C, bool MASKED, int CV, int NST>
-__global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define DA_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        DA_VMCNT_CASE(1) DA_VMCNT_CASE(2) DA_VMCNT_CASE(3) DA_VMCNT_CASE(4) DA_VMCNT_CASE(5) DA_VMCNT_CASE(6) DA_VMCNT_CASE(7) DA_VMCNT_CASE(8)
+        DA_VMCNT_CASE(9) DA_VMCNT_CASE(10) DA_VMCNT_CASE(11) DA_VMCNT_CASE(12) DA_VMCNT_CASE(13) DA_VMCNT_CASE(14) DA_VMCNT_CASE(15) DA_VMCNT_CASE(16)
+        DA_VMCNT_CASE(17) DA_VMCNT_CASE(18) DA_VMCNT_CASE(19) DA_VMCNT_CASE(20) DA_VMCNT_CASE(21) DA_VMCNT_CASE(22) DA_VMCNT_CASE(23) DA_VMCNT_CASE(24)
+#undef DA_VMCNT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // 0, or more than the cases cover: wait for everything
+    }
+}
+
+template <typename T, int C, bool MASKED, int CV, int NST, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
     using CF = Cfg<T, C, CV>;
+    // NW waves of 32 queries per workgroup: 4 in production; 5 and 8 exist for the A/B record (see attn_nw)
+    constexpr int QT = 32 * NW, NT = 64 * NW, MAXI = (CF::NI + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // NST stages x (K | V)
 
     // MASKED: the adjacency bits enter as the INITIAL VALUE of the S^T accumulator -- 0 for an edge, -inf for no edge -- so
@@ -195,11 +210,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     const int h = bid & 7, s_ = bid >> 3;
     const int qt = s_ % p.nqt, g = s_ / p.nqt;
     const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
-    if (qt * 128 >= n_g) return;
+    if (qt * QT >= n_g) return;
 
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q0 = qt * 128 + wid * 32;
+    const int q0 = qt * QT + wid * 32;
     const bool wave_on = q0 < n_g;
     const int HC = p.H * C;
     const size_t np = (size_t)p.n_pad;
@@ -219,13 +234,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
         for (int r = 0; r < 16; ++r) O[cb][r] = 0.f;
     float m = -1e30f, l = 0.f;               // finite reference (see the softmax below); only the slow path moves it
 
-    // ---- LDS-DMA plan: instruction q (1 KB) of a tile is issued by wave q % 4; lane -> slot q*64+lane
+    // ---- LDS-DMA plan: instruction q (1 KB) of a tile is issued by wave q % NW; lane -> slot q*64+lane
     const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
     const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWBV;
-    unsigned soff[CF::MAXI];
+    unsigned soff[MAXI];
 #pragma unroll
-    for (int x = 0; x < CF::MAXI; ++x) {
-        const int q = wid + 4 * x;
+    for (int x = 0; x < MAXI; ++x) {
+        const int q = wid + NW * x;
         unsigned o = 0;
         if (q < CF::NIK) {
             const int s = q * 64 + lane, row = s / CF::KSPR, col = s - row * CF::KSPR;
@@ -241,9 +256,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
         const unsigned char *kb_ = Kg + (size_t)kt * CF::BKEYS * CF::ROWB;
         const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ROWBV;
 #pragma unroll
-        for (int x = 0; x < CF::MAXI; ++x) {
-            const int q = wid + 4 * x;
-            if (4 * x + 3 < CF::NI || q < CF::NI) {            // compile-time true except for a partial last round
+        for (int x = 0; x < MAXI; ++x) {
+            const int q = wid + NW * x;
+            if (NW * x + NW - 1 < CF::NI || q < CF::NI) {            // compile-time true except for a partial last round
                 const unsigned char *src = (q < CF::NIK ? kb_ : vb_) + soff[x];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
@@ -251,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
         }
     };
 
+    const int myn = (CF::NI - wid + NW - 1) / NW;             // q = wid, wid + NW, ... < NI
     int nkt = (n_g + CF::BKEYS - 1) / CF::BKEYS;
     DA_ATTN_DBG(if (p.debug & 32) nkt = 1;)
     const int qidx = q0 + i;                     // this lane's query (index inside the graph)
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     if (MASKED && wave_on) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int qg = qt * 128 + wid * 32 + (lane >> 3) + 8 * r;
+            const int qg = qt * QT + wid * 32 + (lane >> 3) + 8 * r;
             if (qg < n_g) {
                 rm_beg[r] = p.irr_row_ptr[node0 + qg];
                 rm_end[r] = p.irr_row_ptr[node0 + qg + 1];
@@ -298,13 +314,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
         // retire in order, so "at most k * nmine of my VMEM operations outstanding" implies tile kt is in LDS; anything
         // else this wave has pending (MASKED: adjacency words) only makes the wait conservative.
         {
-            // every wave issues NI / 4 or NI / 4 + 1 DMA instructions per tile: counting NI / 4 per younger tile is exact
-            // for most waves and at worst waits for `younger` instructions more than necessary
-            constexpr int PERW = CF::NI / 4;
-            const int younger = min(nkt - 1 - kt, NST - 2);
-            if (NST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PERW) : "memory");
-            else if (NST >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // wave `wid` issues `myn` DMA instructions per tile, so younger * myn outstanding operations is exact
+            wait_vmcnt(min(nkt - 1 - kt, NST - 2) * myn);
             // raw barrier: __syncthreads() would drain the DMA still in flight (its fence carries vmcnt(0))
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();      // everyone's share landed + everyone left the slot refilled below
@@ -497,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     }
     constexpr int CO = CV;                                        // width of the staged rows (= C unless the value heads are folded)
     constexpr int RSOF = CO + 4;                                  // floats per staged row (16-B aligned, odd # of 16-B slots)
-    static_assert(128 * RSOF * 4 <= NST * CF::STAGE, "O staging must fit in the K/V ring");
+    static_assert(QT * RSOF * 4 <= NST * CF::STAGE, "O staging must fit in the K/V ring");
     float *so = (float *)smem;
     dma_barrier();                                              // ring no longer read by anyone
     DA_ATTN_DBG(if (p.debug & 16) return;)
@@ -520,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     }
     dma_barrier();
     constexpr int EPC = 16 / CF::ES, CPR = C / EPC;              // elements per 16-B chunk, chunks per row
-    const int nq = min(128, n_g - qt * 128);                      // valid queries of this tile
+    const int nq = min(QT, n_g - qt * QT);                      // valid queries of this tile
     if (MASKED) {
         // Remainder edges of this tile's queries (hybrid mode): the rows staged above hold the UN-normalised
         // sum of the masked attention with (max, sum) in their spare floats; each query's few remaining
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
             u32x4 qr[4][MAXT], kr[4][MAXT], vr[4][MAXTV];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qg = min(qt * 128 + wid * 32 + (lane >> 3) + 8 * r, n_g - 1);
+                const int qg = min(qt * QT + wid * 32 + (lane >> 3) + 8 * r, n_g - 1);
                 load_row(p.Q, (size_t)h * np + pad0 + qg, qr[r]);
                 load_row(p.K, (size_t)h * np + rm_slot[r], kr[r]);
                 load_vrow((size_t)h * np + rm_slot[r], vr[r]);
@@ -622,36 +633,36 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense(AttnDenseParams p) {
     }
     if (CV != C) {                // MASKED + folded value heads: normalised per-head rows for the tail kernel
         constexpr int CQ = CV / 4;
-        for (int it = tid; it < nq * CQ; it += 256) {
+        for (int it = tid; it < nq * CQ; it += NT) {
             const int q = it / CQ, ch = it - q * CQ;
             const float lr = so[q * RSOF + CO + 1];
             const float ir = lr > 0.f ? 1.0f / (lr + 1e-16f) : 0.f;
             const f32x4 a = *(const f32x4 *)(so + q * RSOF + ch * 4);
-            *(f32x4 *)(p.fold_out + ((size_t)h * p.n_rows + node0 + qt * 128 + q) * CV + ch * 4) = (f32x4){a[0] * ir, a[1] * ir, a[2] * ir, a[3] * ir};
+            *(f32x4 *)(p.fold_out + ((size_t)h * p.n_rows + node0 + qt * QT + q) * CV + ch * 4) = (f32x4){a[0] * ir, a[1] * ir, a[2] * ir, a[3] * ir};
         }
         return;
     }
     // batches of NB chunks per thread: all skip / residual loads of a batch are in flight before the
     // first one is consumed (a rolled load -> add -> store loop pays one L2/HBM latency per chunk)
     constexpr int NB = 3;
-    for (int it0 = tid; it0 < nq * CPR; it0 += 256 * NB) {
+    for (int it0 = tid; it0 < nq * CPR; it0 += NT * NB) {
         u32x4 skv[NB], rsv[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int it = it0 + 256 * k;
+            const int it = it0 + NT * k;
             if (it < nq * CPR) {
                 const int q = it / CPR, ch = it - q * CPR;
-                const size_t off = ((size_t)node0 + qt * 128 + q) * HC + (size_t)h * C + ch * EPC;
+                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
                 skv[k] = *(const u32x4 *)((const T *)p.S + off);
                 if (p.res) rsv[k] = *(const u32x4 *)((const T *)p.res + off);
             }
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int it = it0 + 256 * k;
+            const int it = it0 + NT * k;
             if (it < nq * CPR) {
                 const int q = it / CPR, ch = it - q * CPR;
-                const size_t off = ((size_t)node0 + qt * 128 + q) * HC + (size_t)h * C + ch * EPC;
+                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
                 const float *src = so + q * RSOF + ch * EPC;
                 float v[EPC], sk[EPC];
                 {
@@ -958,19 +969,29 @@ static int launch_attn_dense2(AttnDenseParams p, int heads, int n_graphs, int ma
     return 0;
 }
 
-template <typename T, int C, bool MASKED, int CV, int NST>
-static int launch_tcmn(const AttnDenseParams &p, int nblocks, hipStream_t st) {
+template <typename T, int C, bool MASKED, int CV, int NST, int NW>
+static int launch_tcmn(AttnDenseParams p, hipStream_t st) {
     using CF = Cfg<T, C, CV>;
     int lds = NST * CF::STAGE + (MASKED ? 256 : 0);
     DA_ATTN_DBG({ const char *e = getenv("DA_ATTN_LDS_PAD"); if (e) lds += atoi(e); })      // occupancy experiments
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C, MASKED, CV, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C, MASKED, CV, NST, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    k_attn_dense<T, C, MASKED, CV, NST><<<nblocks, 256, lds, st>>>(p);
+    p.nqt = (p.max_nodes + 32 * NW - 1) / (32 * NW);
+    k_attn_dense<T, C, MASKED, CV, NST, NW><<<p.nqt * p.H * p.n_graphs, 64 * NW, lds, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
+}
+// waves per workgroup of the C = 32 instances.  Four.  DA_ATTN_NW=5 / 8 select the other shapes for A/B runs; measured at 64
+// puzzles of 900 pieces (sustained, us per conv = projection + attention): 4 waves 143.3 - 145.3; 5 waves (29 slabs =
+// 6 x 5 - 1 instead of 8 x 4 - 3 idle wave slots, each K / V tile streamed for 160 queries) 190.5 -- the odd wave of every
+// workgroup lands on a SIMD that already holds one of its waves; 8 waves (256 queries, two workgroups per CU) 148.4 - 148.8.
+static int attn_nw(int) {
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("DA_ATTN_NW"); env = e ? atoi(e) : 0; }
+    return (env == 5 || env == 8) ? env : 4;
 }
 // ring depth per instance: the C = 32 layers (9 KB stages, 4 workgroups per CU) take four stages; the C = 144 layer's
 // stages are 23 - 47 KB, where a third stage costs a resident workgroup: two by default, DA_ATTN_STAGES=3 for A/B runs of
@@ -981,21 +1002,23 @@ static int attn_stages_env() {
     return v;
 }
 template <typename T, int C, bool MASKED, int CV>
-static int launch_tcm(const AttnDenseParams &p, int nblocks, hipStream_t st) {
+static int launch_tcm(const AttnDenseParams &p, hipStream_t st) {
     if constexpr (C == 32) {
         // (tried: three stages under a 96-VGPR budget = five workgroups per CU instead of four: 25 spilled registers, 184 vs
         // 167 us for the three hidden layers)
-        return launch_tcmn<T, C, MASKED, CV, 4>(p, nblocks, st);
+        if (attn_nw(p.max_nodes) == 5) return launch_tcmn<T, C, MASKED, CV, 4, 5>(p, st);
+        if (attn_nw(p.max_nodes) == 8) return launch_tcmn<T, C, MASKED, CV, 4, 8>(p, st);
+        return launch_tcmn<T, C, MASKED, CV, 4, 4>(p, st);
     } else if constexpr (sizeof(T) == 2 && CV == 32 && !MASKED) {
-        if (attn_stages_env() == 3) return launch_tcmn<T, C, MASKED, CV, 3>(p, nblocks, st);
-        return launch_tcmn<T, C, MASKED, CV, 2>(p, nblocks, st);
+        if (attn_stages_env() == 3) return launch_tcmn<T, C, MASKED, CV, 3, 4>(p, st);
+        return launch_tcmn<T, C, MASKED, CV, 2, 4>(p, st);
     } else {
-        return launch_tcmn<T, C, MASKED, CV, 2>(p, nblocks, st);
+        return launch_tcmn<T, C, MASKED, CV, 2, 4>(p, st);
     }
 }
 template <typename T, int C>
-static int launch_tc(const AttnDenseParams &p, int nblocks, hipStream_t st) {
-    return p.mask ? launch_tcm<T, C, true, C>(p, nblocks, st) : launch_tcm<T, C, false, C>(p, nblocks, st);
+static int launch_tc(const AttnDenseParams &p, hipStream_t st) {
+    return p.mask ? launch_tcm<T, C, true, C>(p, st) : launch_tcm<T, C, false, C>(p, st);
 }
 
 // returns 0 = launched, -1 = configuration not supported (caller uses the CSR kernel)
@@ -1007,26 +1030,25 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     AttnDenseParams p;
     p.Q = L.Q; p.K = L.K; p.Vt = L.Vt; p.S = L.S; p.res = res; p.out = out;
     p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.n_graphs = n_graphs;
-    p.nqt = (max_graph_nodes + 127) / 128; p.act = act; p.nodiag = nodiag;
+    p.nqt = 0; p.max_nodes = max_graph_nodes; p.act = act; p.nodiag = nodiag;
     p.sc = 1.4426950408889634f / sqrtf((float)C);
     p.mask = mk ? mk->mask : nullptr; p.mask_ptr = mk ? (const long long *)mk->mask_ptr : nullptr;
     p.irr_row_ptr = mk ? mk->irr_row_ptr : nullptr; p.irr_col_src = mk ? mk->irr_col_src : nullptr;
     p.row_map = mk ? mk->row_map : nullptr;
     { const char *e = getenv("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
     { const char *e = getenv("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
-    const int nblocks = p.nqt * heads * n_graphs;
-    if (nblocks <= 0) return 0;
+    if (n_graphs <= 0 || max_graph_nodes <= 0) return 0;
     p.fold_out = nullptr; p.n_rows = 0;
     if (fold) {           // value heads folded to 32 channels (last layer of the 2D transformer arch)
         if (C != 144 || fold->cv != 32) return -1;
         p.fold_out = fold->out; p.n_rows = fold->n_rows;
-        if (mk) return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, true, 32>(p, nblocks, st) : launch_tcm<float, 144, true, 32>(p, nblocks, st);
-        return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, false, 32>(p, nblocks, st) : launch_tcm<float, 144, false, 32>(p, nblocks, st);
+        if (mk) return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, true, 32>(p, st) : launch_tcm<float, 144, true, 32>(p, st);
+        return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, false, 32>(p, st) : launch_tcm<float, 144, false, 32>(p, st);
     }
     if (prec == DA_PREC_BF16 && C == 32 && !p.mask && attn2_env() DA_ATTN_DBG(&& !p.debug && !p.prof))
         return launch_attn_dense2(p, heads, n_graphs, max_graph_nodes, st);
-    if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, nblocks, st) : launch_tc<bf16_t, 144>(p, nblocks, st);
-    return C == 32 ? launch_tc<float, 32>(p, nblocks, st) : launch_tc<float, 144>(p, nblocks, st);
+    if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, st) : launch_tc<bf16_t, 144>(p, st);
+    return C == 32 ? launch_tc<float, 32>(p, st) : launch_tc<float, 144>(p, st);
 }
 
 }  // namespace da

@@ -6,7 +6,7 @@ if os.environ.get("PROBE_LIB"): _lib.LIB_PATH = os.environ["PROBE_LIB"]
 from diffassemble_amd.graph_plan import build_plan
 import ctypes as C
 dev = torch.device('cuda:0')
-G = int(os.environ.get("G", 32)); n = 900; H = 8
+G = int(os.environ.get("G", 32)); n = int(os.environ.get("N", 900)); H = 8
 iters = int(os.environ.get("ITERS", 10))
 prec = os.environ.get("PREC", "bf16")
 r = torch.arange(n, device=dev).repeat_interleave(n); c = torch.arange(n, device=dev).repeat(n)
@@ -29,4 +29,4 @@ for Ch in [int(x) for x in os.environ.get("CS", "144,32").split(",")]:
     s.record()
     for _ in range(iters): run()
     e.record(); torch.cuda.synchronize()
-    print(f"C={Ch} G={G} {prec}: conv (gemm+attn) {s.elapsed_time(e)/iters*1e3:.1f} us; attn flops {G*n*n*4*HC/1e9:.1f} GF")
+    print(f"C={Ch} G={G} n={n} {prec}: conv (gemm+attn) {s.elapsed_time(e)/iters*1e3:.1f} us; attn flops {G*n*n*4*HC/1e9:.1f} GF")
