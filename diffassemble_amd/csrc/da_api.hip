@@ -85,6 +85,11 @@ struct da_denoiser {
     // captured into the sampling-loop hipGraph as two parallel branches.
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // da_sample_loop_pair: the second branch of the two-branch loop graph
+    hipStream_t pair_stream = nullptr;
+    hipEvent_t ev_pair_fork = nullptr, ev_pair_join = nullptr;
+    struct PairEntry { LoopKey a, b; hipGraphExec_t exec; };
+    std::vector<PairEntry> pair_loops;
 };
 
 namespace da {
@@ -577,6 +582,10 @@ void da_denoiser_destroy(da_denoiser *d) {
     if (d->side_stream) (void)hipStreamDestroy(d->side_stream);
     if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
     if (d->ev_join) (void)hipEventDestroy(d->ev_join);
+    for (auto &e : d->pair_loops) (void)hipGraphExecDestroy(e.exec);
+    if (d->pair_stream) (void)hipStreamDestroy(d->pair_stream);
+    if (d->ev_pair_fork) (void)hipEventDestroy(d->ev_pair_fork);
+    if (d->ev_pair_join) (void)hipEventDestroy(d->ev_pair_join);
     for (void *p : d->owned) (void)hipFree(p);
     delete d;
 }
@@ -718,6 +727,81 @@ int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int 
         d->loops.push_back({key, exec});
     }
     DA_CHECK_HIP(hipGraphLaunch(exec, st));
+    return 0;
+}
+
+// Two independent halves of one Batch as two parallel branches of ONE hipGraph: each branch is the complete loop of
+// da_sample_loop over its own graphs, poses and workspace; the branches share nothing but the weights, so the runtime
+// overlaps one half's projections / tail kernels with the other half's attention.
+int da_sample_loop_pair(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio, int max_iters,
+                        const da_graph *g_a, const float *x_init_a, float *x_final_a, void *workspace_a, size_t workspace_a_bytes,
+                        const da_graph *g_b, const float *x_init_b, float *x_final_b, void *workspace_b, size_t workspace_b_bytes,
+                        void *stream) {
+    DA_REQUIRE(d && s && g_a && g_b && x_init_a && x_init_b && x_final_a && x_final_b && workspace_a && workspace_b,
+               "da_sample_loop_pair: null argument");
+    DA_REQUIRE(inference_ratio >= 1 && s->steps >= 1, "da_sample_loop_pair: bad ratio/steps");
+    DA_REQUIRE(d->variant == DA_VARIANT_3D || d->c_in == d->c_out, "da_sample_loop_pair: c_in != c_out");
+    DA_REQUIRE(!g_a->hybrid && !g_b->hybrid, "da_sample_loop_pair: hybrid graphs fork a side stream of their own");
+    DA_REQUIRE(!d->prof_on, "da_sample_loop_pair: not available while profiling (event bracketing is not capturable)");
+    int rc = check_graph(d, g_a);
+    if (rc) return rc;
+    if ((rc = check_graph(d, g_b))) return rc;
+    const Workspace wa = carve(d, g_a, workspace_a), wb = carve(d, g_b, workspace_b);
+    DA_REQUIRE(workspace_a_bytes >= wa.total && workspace_b_bytes >= wb.total, "da_sample_loop_pair: workspace too small");
+    {
+        const char *a0 = (const char *)workspace_a, *b0 = (const char *)workspace_b;
+        DA_REQUIRE(a0 + wa.total <= b0 || b0 + wb.total <= a0, "da_sample_loop_pair: the two workspaces overlap");
+    }
+    const int total = (s->steps + inference_ratio - 1) / inference_ratio;
+    const int n_iters = (max_iters > 0 && max_iters < total) ? max_iters : total;
+    auto make_key = [&](const da_graph *g, const float *xi, float *xf, void *ws, size_t wsb) {
+        LoopKey k;
+        memset(&k, 0, sizeof(k));
+        k.g = *g; k.s = *s; k.mean_type = mean_type; k.ratio = inference_ratio; k.max_iters = n_iters;
+        k.x_init = xi; k.traj = nullptr; k.x_final = xf; k.ws = ws; k.ws_bytes = wsb;
+        return k;
+    };
+    const LoopKey ka = make_key(g_a, x_init_a, x_final_a, workspace_a, workspace_a_bytes);
+    const LoopKey kb = make_key(g_b, x_init_b, x_final_b, workspace_b, workspace_b_bytes);
+    hipGraphExec_t exec = nullptr;
+    for (auto &e : d->pair_loops)
+        if (memcmp(&ka, &e.a, sizeof(ka)) == 0 && memcmp(&kb, &e.b, sizeof(kb)) == 0) exec = e.exec;
+    if (!exec) {
+        if (d->pair_loops.size() >= 4) {
+            (void)hipGraphExecDestroy(d->pair_loops.front().exec);
+            d->pair_loops.erase(d->pair_loops.begin());
+        }
+        if (!d->cap_stream) DA_CHECK_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
+        if (!d->pair_stream) {
+            DA_CHECK_HIP(hipStreamCreateWithFlags(&d->pair_stream, hipStreamNonBlocking));
+            DA_CHECK_HIP(hipEventCreateWithFlags(&d->ev_pair_fork, hipEventDisableTiming));
+            DA_CHECK_HIP(hipEventCreateWithFlags(&d->ev_pair_join, hipEventDisableTiming));
+        }
+        hipStream_t cs = d->cap_stream, ps = d->pair_stream;
+        hipGraph_t graph = nullptr;
+        DA_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+        hipError_t e = hipEventRecord(d->ev_pair_fork, cs);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ps, d->ev_pair_fork, 0);                 // ps joins the capture
+        int rca = 0, rcb = 0;
+        if (e == hipSuccess) {
+            rca = enqueue_loop(d, g_a, s, mean_type, inference_ratio, n_iters, x_init_a, nullptr, x_final_a, wa, cs);
+            rcb = enqueue_loop(d, g_b, s, mean_type, inference_ratio, n_iters, x_init_b, nullptr, x_final_b, wb, ps);
+            e = hipEventRecord(d->ev_pair_join, ps);
+            if (e == hipSuccess) e = hipStreamWaitEvent(cs, d->ev_pair_join, 0);
+        }
+        const hipError_t e2 = hipStreamEndCapture(cs, &graph);
+        if (rca || rcb) { if (graph) (void)hipGraphDestroy(graph); return rca ? rca : rcb; }
+        if (e != hipSuccess || e2 != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            set_error("da_sample_loop_pair: capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+            return 2;
+        }
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return 2; }
+        d->pair_loops.push_back({ka, kb, exec});
+    }
+    DA_CHECK_HIP(hipGraphLaunch(exec, (hipStream_t)stream));
     return 0;
 }
 

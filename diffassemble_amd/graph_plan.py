@@ -119,6 +119,30 @@ class GraphPlan:
         return g
 
 
+def split_complete(plan: GraphPlan, g_split: int):
+    """Two plans over the graphs [0, g_split) and [g_split, G) of a complete-graph plan without virtual nodes (the
+    puzzles of a Batch never interact), plus the node index where the second one starts -- for the two-branch
+    sampling loop (da_sample_loop_pair).  Cached on the plan."""
+    cached = getattr(plan, "_halves", None)
+    if cached is not None and cached[0] == g_split:
+        return cached[1]
+    assert plan.dense and not plan.hybrid and plan.n_nodes == plan.n_real and 0 < g_split < plan.n_graphs
+    gph, pph = plan.graph_ptr.cpu().tolist(), plan.pad_ptr.cpu().tolist()
+    halves = []
+    for g0, g1 in ((0, g_split), (g_split, plan.n_graphs)):
+        n0, n1, p0, p1 = gph[g0], gph[g1], pph[g0], pph[g1]
+        sizes = [gph[i + 1] - gph[i] for i in range(g0, g1)]
+        halves.append(GraphPlan(
+            n_nodes=n1 - n0, n_real=n1 - n0, n_graphs=g1 - g0, dense=plan.dense,
+            n_edges=sum(k * k if plan.dense == 1 else k * (k - 1) for k in sizes), max_graph_nodes=max(sizes),
+            row_ptr=None, col_src=None, edge_id=None, graph_ptr=(plan.graph_ptr[g0:g1 + 1] - n0).contiguous(),
+            n_pad=p1 - p0, pad_ptr=(plan.pad_ptr[g0:g1 + 1] - p0).contiguous(),
+            row_map=(plan.row_map[n0:n1] - p0).contiguous(), _edge_index=None))
+    out = (halves[0], halves[1], gph[g_split])
+    plan._halves = (g_split, out)
+    return out
+
+
 def _hybrid_mode():
     import os
     return os.environ.get("DA_HYBRID", "auto")

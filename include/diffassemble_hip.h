@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 11
+#define DA_ABI_VERSION 12
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -201,6 +201,19 @@ int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int 
                    int inference_ratio, int max_iters, const float *x_init, float *traj,
                    float *x_final, void *workspace, size_t workspace_bytes, int use_graph,
                    void *stream);
+
+/* The same loop over TWO disjoint sets of puzzles of one Batch (the puzzles of a Batch never
+ * interact: spatial_diffusion.py:635-676 runs them through one block-diagonal graph), recorded
+ * as two parallel branches of one hipGraph -- each with its own da_graph, poses and workspace
+ * (features staged into each with da_denoiser_set_features) -- and replayed with one launch:
+ * one half's projections overlap the other half's attention.  Complete graphs only (hybrid
+ * graphs already fork a side stream inside the forward); no trajectory; always a hipGraph.   */
+int da_sample_loop_pair(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio,
+                        int max_iters,
+                        const da_graph *g_a, const float *x_init_a, float *x_final_a,
+                        void *workspace_a, size_t workspace_a_bytes,
+                        const da_graph *g_b, const float *x_init_b, float *x_final_b,
+                        void *workspace_b, size_t workspace_b_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart: the reference has no profiler hooks).

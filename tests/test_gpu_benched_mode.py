@@ -487,3 +487,46 @@ def test_expander_mask_kernel_odd_sizes(dev, n, d, G, monkeypatch):
         assert torch.equal(a.mask.cpu(), b.mask) and torch.equal(a.mask_ptr.cpu(), b.mask_ptr)
     else:
         assert torch.equal(a.row_ptr.cpu(), b.row_ptr) and torch.equal(a.col_src.cpu(), b.col_src)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("sizes,loops", [([144] * 4, True), ([36, 144, 100, 64, 9], False), ([900, 900], True)],
+                         ids=["4x144", "ragged5_noloops", "2x900"])
+def test_two_branch_loop_equals_one_branch(dev, monkeypatch, prec, sizes, loops):
+    """da_sample_loop_pair (two half Batches as parallel branches of one hipGraph; the default from 64 puzzles up): the
+    final poses of every puzzle are BIT-identical to the one-branch loop over the whole Batch -- same kernels, same
+    reduction orders, the halves only share the weights -- for even and odd splits, ragged sizes, graphs without
+    self loops, restaged and re-used features, and on replay of the cached graph."""
+    from diffassemble_amd import DenoiserEngine, Schedule, _lib
+    N = sum(sizes)
+    sd = W.make_denoiser_state(100, 4, 4, seed=43, qk_gain=3.0)
+    x, feats = W.make_inputs(N, 4, 1088, 43)
+    ei, batch = W.collate([W.dense_edge_index(n, loops) for n in sizes], sizes)
+    sch = Schedule(ODF.make_schedule(100), dev)
+    eng = DenoiserEngine(sd, precision=prec, device=dev)
+    plan = eng.plan(ei, batch)
+    xd, fd = x.to(dev), feats.to(dev)
+    kw = dict(ratio=10, mean_type=_lib.MEAN_START_X, keep_trajectory=False, use_graph=True)
+    monkeypatch.setenv("DA_TWO_BRANCH", "0")
+    _, one = eng.sample_loop(plan, sch, xd, fd, **kw)
+    one = one.clone()
+    monkeypatch.setenv("DA_TWO_BRANCH", "1")
+    monkeypatch.setenv("DA_TWO_BRANCH_MIN_GRAPHS", "2")
+    assert eng._two_branch(plan, False, True)
+    _, two = eng.sample_loop(plan, sch, xd, fd, **kw)
+    assert torch.equal(two, one)
+    two.zero_()
+    _, again = eng.sample_loop(plan, sch, xd, fd, restage=False, **kw)          # cached graph, staged features
+    assert torch.equal(again, one)
+    # new features at the same address are restaged even with restage=False (the version counter moved)
+    fd.mul_(0.5)
+    _, half = eng.sample_loop(plan, sch, xd, fd, restage=False, **kw)
+    half = half.clone()
+    monkeypatch.setenv("DA_TWO_BRANCH", "0")
+    _, ref = eng.sample_loop(plan, sch, xd, fd, **kw)
+    assert torch.equal(half, ref) and not torch.equal(half, one)
+    # trajectories, eager loops and small Batches keep the one-branch path
+    monkeypatch.setenv("DA_TWO_BRANCH", "1")
+    assert not eng._two_branch(plan, True, True) and not eng._two_branch(plan, False, False)
+    monkeypatch.setenv("DA_TWO_BRANCH_MIN_GRAPHS", "64")
+    assert not eng._two_branch(plan, False, True)
