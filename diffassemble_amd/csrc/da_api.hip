@@ -522,7 +522,7 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
             const int L = d->n_layers - 1, hcL = d->conv[L].hc, CL = d->conv[L].C, dinL = d->conv[L].din;
             static int off2 = -1;
             if (off2 < 0) { const char *e = getenv("DA_DISABLE_LAST_FOLD"); off2 = (e && e[0] == '1') ? 1 : 0; }
-            if (!off2 && CL == 144 && hcL == D && dinL % 32 == 0) {
+            if (!off2 && CL == 144 && hcL == D && dinL % 32 == 0 && d->c_out <= 8) {        // (k_head_fold: 8 outputs per row at most)
                 const int nf = 2 * hcL + H * 32;
                 float *lw = (float *)alloc((size_t)nf * dinL * 4);
                 float *sw = (float *)alloc((size_t)32 * dinL * 4);

@@ -290,28 +290,49 @@ int launch_mm_nn_f32(int M, int N, int K, const float *A, int lda, const float *
 
 // Tail of the folded last layer (2D): f = GELU(sum_h Pz[h][n][:] + pre[n][:]) ; out[n] = W2 f + b2
 // (final_mlp: efficient_gat.py:144-146 with the value heads and the residual already projected to 32 wide).
+// 32 rows per workgroup, 8 lanes per row with four channels each: every load is 16 bytes (the per-head partial outputs are
+// the 59 MB this kernel exists to read at 64 puzzles; one float per thread left it latency-bound at 2.2 TB/s).  The sums run
+// in the same order as before (pre, then heads 0 .. H-1; k ascending), so the outputs are bit-identical.
+__device__ __forceinline__ void ld4f(const float *p, float (&v)[4]) {
+    const float4 f = *(const float4 *)p;
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+}
+__device__ __forceinline__ void ld4f(const bf16_t *p, float (&v)[4]) {
+    const uint2 u = *(const uint2 *)p;
+    v[0] = bf2f((bf16_t)(u.x & 0xffff)); v[1] = bf2f((bf16_t)(u.x >> 16));
+    v[2] = bf2f((bf16_t)(u.y & 0xffff)); v[3] = bf2f((bf16_t)(u.y >> 16));
+}
 template <typename T>
 __global__ __launch_bounds__(256) void k_head_fold(int n, int H, int c_out, const float *__restrict__ pz, const T *__restrict__ pre,
                                                    const float *__restrict__ w2, const float *__restrict__ b2,
                                                    float *__restrict__ out, DdimFuse df) {
-    __shared__ float f[8][33];
-    const int j = threadIdx.x & 31, ln = threadIdx.x >> 5;
-    const int r = blockIdx.x * 8 + ln;
+    __shared__ float f[32][33];
+    const int q = threadIdx.x & 7, lr = threadIdx.x >> 3;
+    const int r = blockIdx.x * 32 + lr;
     if (r < n) {
-        float a = ldf(pre + (size_t)r * 32 + j);
-        for (int h = 0; h < H; ++h) a += pz[((size_t)h * n + r) * 32 + j];
-        f[ln][j] = gelu_erf(a);
+        float a[4], v[4];
+        ld4f(pre + (size_t)r * 32 + 4 * q, a);
+        for (int h = 0; h < H; ++h) {
+            ld4f(pz + ((size_t)h * n + r) * 32 + 4 * q, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[lr][4 * q + e] = gelu_erf(a[e]);
     }
     __syncthreads();
-    if (r < n && j < c_out) {
+    // second linear: thread -> (row, output channel), c_out <= 8
+    const int lr2 = threadIdx.x / c_out, j = threadIdx.x - lr2 * c_out;
+    const int r2 = blockIdx.x * 32 + lr2;
+    if (lr2 < 32 && r2 < n) {
         float a = b2[j];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) a = fmaf(w2[j * 32 + k], f[ln][k], a);
-        out[(size_t)r * c_out + j] = a;
+        for (int k = 0; k < 32; ++k) a = fmaf(w2[j * 32 + k], f[lr2][k], a);
+        out[(size_t)r2 * c_out + j] = a;
         // sampling loop: the DDIM update of this element right here (x_prev never aliases x: the loop ping-pongs)
         if (df.x_prev)
-            df.x_prev[(size_t)r * c_out + j] = ddim2d_value(df.s, df.mean_type, df.t, df.ratio, df.prev_all_nonneg, 0.f,
-                                                            df.x[(size_t)r * c_out + j], a, 0.f);
+            df.x_prev[(size_t)r2 * c_out + j] = ddim2d_value(df.s, df.mean_type, df.t, df.ratio, df.prev_all_nonneg, 0.f,
+                                                             df.x[(size_t)r2 * c_out + j], a, 0.f);
     }
 }
 
@@ -320,8 +341,9 @@ int launch_head_fold(int prec, int n, int H, int c_out, const float *pz, const v
     if (n <= 0) return 0;
     DdimFuse df;
     if (dfp) df = *dfp; else { df = DdimFuse(); df.x = nullptr; df.x_prev = nullptr; }
-    if (prec == DA_PREC_BF16) k_head_fold<bf16_t><<<(n + 7) / 8, 256, 0, st>>>(n, H, c_out, pz, (const bf16_t *)pre, w2, b2, out, df);
-    else k_head_fold<float><<<(n + 7) / 8, 256, 0, st>>>(n, H, c_out, pz, (const float *)pre, w2, b2, out, df);
+    if (c_out > 8) { set_error("launch_head_fold: c_out %d > 8", c_out); return 2; }
+    if (prec == DA_PREC_BF16) k_head_fold<bf16_t><<<(n + 31) / 32, 256, 0, st>>>(n, H, c_out, pz, (const bf16_t *)pre, w2, b2, out, df);
+    else k_head_fold<float><<<(n + 31) / 32, 256, 0, st>>>(n, H, c_out, pz, (const float *)pre, w2, b2, out, df);
     DA_LAUNCH_CHECK();
     return 0;
 }
