@@ -118,7 +118,7 @@ def work_model(cfg, G, E, n_nodes_ext, flags, prec, hybrid, fused_hidden=False):
         pairs = G * cfg["n"] ** 2        # the matrix-core kernels multiply every (query, key) pair of a graph
         W["attn_hidden"] = dict(alg=E * 3 * 4 * 256, exe=pairs * 3 * 4 * 256, bytes=3 * Nx * s * 5 * 256)
         W["attn_last"] = dict(alg=E * 4 * D, exe=pairs * 2 * 8 * (D // 8 + cv),
-                              bytes=Nx * s * (2 * D + 8 * cv) + N * (8 * cv * 4 if last_fold else 2 * D * s))
+                              bytes=Nx * s * (2 * D + 8 * cv) + N * (8 * cv * s if last_fold else 2 * D * s))
     else:                                # edge-list kernels: one K row + one V row gathered per edge
         W["attn_hidden"] = dict(alg=E * 3 * 4 * 256, exe=E * 3 * 4 * 256, bytes=3 * (E * (2 * 256 * s + 4) + Nx * 2 * 256 * s))
         W["attn_last"] = dict(alg=E * 4 * D, exe=E * 4 * D, bytes=E * (2 * D * s + 4) + Nx * 2 * D * s)
@@ -128,7 +128,7 @@ def work_model(cfg, G, E, n_nodes_ext, flags, prec, hybrid, fused_hidden=False):
     else:
         hf = N * 2 * (D * 32 + 32 * c)
         he = N * 2 * ((Hd + 256) * 32 + 32 * c) if last_fold else hf
-        W["head"] = dict(alg=hf, exe=he, bytes=N * ((Hd + 256 + 8 * 32 * 2) * s if last_fold else D * s) + N * c * 4)
+        W["head"] = dict(alg=hf, exe=he, bytes=N * ((Hd + 256 + 8 * 32) * s if last_fold else D * s) + N * c * 4)
     W["update"] = dict(alg=N * c * 12, exe=N * c * 12, bytes=N * c * 4 * 3)
     if fused_hidden:
         # hidden convs run as ONE kernel each (da_conv_fused.hip): their projections move from linear_qkvs into

@@ -96,7 +96,7 @@ namespace da {
 
 struct Workspace {
     char *comb_in, *h, *combined, *qkvs, *xa, *xb, *z, *hh;
-    float *pz;                        // [H, n_real, 32] fp32 per-head outputs of the folded last attention
+    void *pz;                         // [H, n_real, 32] act dtype: per-head outputs of the folded last attention
     char *head_pre;                   // [n_real, 32] act dtype: residual share of final_mlp.0 (fused_mlp2)
     char *feat_proj;                  // [n_real, hidden] act dtype: mlp.0 over the piece-feature columns (+ bias), once per Batch
     char *dq, *dk, *dvt, *dskip;      // dense path: head-major Q, K, V ([H][n_pad][C] each), row-major skip
@@ -123,7 +123,7 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     w.h = take(nrp * d->hidden * s);
     w.feat_proj = take(nrp * d->hidden * s);
     w.head_pre = take(nrp * 32 * s);
-    w.pz = (float *)take(nrp * 32 * (size_t)d->heads * sizeof(float));
+    w.pz = take(nrp * 32 * (size_t)d->heads * sizeof(float));
     w.combined = take(np * d->D * s);
     w.qkvs = take(np * 4 * (size_t)hcmax * s);
     w.xa = take(np * 256 * s);

@@ -66,7 +66,7 @@ struct AttnDenseParams {
     const int32_t *irr_row_ptr;     // remainder edges (virtual nodes, duplicates, cross-graph pairs): CSR by destination
     const int32_t *irr_col_src;
     const int32_t *row_map;         // node -> padded slot (for the sources of remainder edges)
-    float *fold_out;                // CV != C: [H][n_rows][CV] fp32 normalised per-head outputs (no skip / activation here)
+    void *fold_out;                 // CV != C: [H][n_rows][CV] normalised per-head outputs in the activation dtype (no skip / activation here)
     int n_rows;
 };
 
@@ -496,12 +496,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
         static_assert(CV == C || CF::NCB == 1, "folded value heads are one 32-channel block");
         if (wave_on && qidx < n_g) {
             const float invf = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
-            float *dst = p.fold_out + ((size_t)h * p.n_rows + node0 + qidx) * CV;
+            T *dst = (T *)p.fold_out + ((size_t)h * p.n_rows + node0 + qidx) * CV;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int c0 = 8 * jj + 4 * half;
-                if (c0 < CV)
-                    *(f32x4 *)(dst + c0) = (f32x4){O[0][4 * jj] * invf, O[0][4 * jj + 1] * invf, O[0][4 * jj + 2] * invf, O[0][4 * jj + 3] * invf};
+                if (c0 < CV) {
+                    const float v4[4] = {O[0][4 * jj] * invf, O[0][4 * jj + 1] * invf, O[0][4 * jj + 2] * invf, O[0][4 * jj + 3] * invf};
+                    st4(dst + c0, v4);
+                }
             }
         }
         return;
@@ -638,7 +640,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
             const float lr = so[q * RSOF + CO + 1];
             const float ir = lr > 0.f ? 1.0f / (lr + 1e-16f) : 0.f;
             const f32x4 a = *(const f32x4 *)(so + q * RSOF + ch * 4);
-            *(f32x4 *)(p.fold_out + ((size_t)h * p.n_rows + node0 + qt * QT + q) * CV + ch * 4) = (f32x4){a[0] * ir, a[1] * ir, a[2] * ir, a[3] * ir};
+            const float v4[4] = {a[0] * ir, a[1] * ir, a[2] * ir, a[3] * ir};
+            st4((T *)p.fold_out + ((size_t)h * p.n_rows + node0 + qt * QT + q) * CV + ch * 4, v4);
         }
         return;
     }

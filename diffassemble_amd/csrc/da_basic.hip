@@ -291,7 +291,8 @@ int launch_mm_nn_f32(int M, int N, int K, const float *A, int lda, const float *
 // Tail of the folded last layer (2D): f = GELU(sum_h Pz[h][n][:] + pre[n][:]) ; out[n] = W2 f + b2
 // (final_mlp: efficient_gat.py:144-146 with the value heads and the residual already projected to 32 wide).
 // 32 rows per workgroup, 8 lanes per row with four channels each: every load is 16 bytes (the per-head partial outputs are
-// the 59 MB this kernel exists to read at 64 puzzles; one float per thread left it latency-bound at 2.2 TB/s).  The sums run
+// what this kernel exists to read -- 59 MB at 64 puzzles while they were fp32; they are kept in the activation dtype now,
+// like the attention output they replace -- and one float per thread left it latency-bound at 2.2 TB/s).  The sums run
 // in the same order as before (pre, then heads 0 .. H-1; k ascending), so the outputs are bit-identical.
 __device__ __forceinline__ void ld4f(const float *p, float (&v)[4]) {
     const float4 f = *(const float4 *)p;
@@ -303,7 +304,7 @@ __device__ __forceinline__ void ld4f(const bf16_t *p, float (&v)[4]) {
     v[2] = bf2f((bf16_t)(u.y & 0xffff)); v[3] = bf2f((bf16_t)(u.y >> 16));
 }
 template <typename T>
-__global__ __launch_bounds__(256) void k_head_fold(int n, int H, int c_out, const float *__restrict__ pz, const T *__restrict__ pre,
+__global__ __launch_bounds__(256) void k_head_fold(int n, int H, int c_out, const T *__restrict__ pz, const T *__restrict__ pre,
                                                    const float *__restrict__ w2, const float *__restrict__ b2,
                                                    float *__restrict__ out, DdimFuse df) {
     __shared__ float f[32][33];
@@ -336,14 +337,14 @@ __global__ __launch_bounds__(256) void k_head_fold(int n, int H, int c_out, cons
     }
 }
 
-int launch_head_fold(int prec, int n, int H, int c_out, const float *pz, const void *pre, const float *w2, const float *b2,
+int launch_head_fold(int prec, int n, int H, int c_out, const void *pz, const void *pre, const float *w2, const float *b2,
                      float *out, hipStream_t st, const DdimFuse *dfp) {
     if (n <= 0) return 0;
     DdimFuse df;
     if (dfp) df = *dfp; else { df = DdimFuse(); df.x = nullptr; df.x_prev = nullptr; }
     if (c_out > 8) { set_error("launch_head_fold: c_out %d > 8", c_out); return 2; }
-    if (prec == DA_PREC_BF16) k_head_fold<bf16_t><<<(n + 31) / 32, 256, 0, st>>>(n, H, c_out, pz, (const bf16_t *)pre, w2, b2, out, df);
-    else k_head_fold<float><<<(n + 31) / 32, 256, 0, st>>>(n, H, c_out, pz, (const float *)pre, w2, b2, out, df);
+    if (prec == DA_PREC_BF16) k_head_fold<bf16_t><<<(n + 31) / 32, 256, 0, st>>>(n, H, c_out, (const bf16_t *)pz, (const bf16_t *)pre, w2, b2, out, df);
+    else k_head_fold<float><<<(n + 31) / 32, 256, 0, st>>>(n, H, c_out, (const float *)pz, (const float *)pre, w2, b2, out, df);
     DA_LAUNCH_CHECK();
     return 0;
 }

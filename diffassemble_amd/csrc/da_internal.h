@@ -69,7 +69,7 @@ int launch_mm_nn_f32(int M, int N, int K, const float *A, int lda, const float *
                      int ldc, hipStream_t st);
 int launch_scatter_virtual(int prec, int rows, int V, int H, int C, const void *src, int n_real, const int32_t *row_map,
                            int n_pad, void *Q, void *K, void *Vt, void *S, void *qkvs, hipStream_t st);
-int launch_head_fold(int prec, int n, int H, int c_out, const float *pz, const void *pre, const float *w2, const float *b2,
+int launch_head_fold(int prec, int n, int H, int c_out, const void *pz, const void *pre, const float *w2, const float *b2,
                      float *out, hipStream_t st, const DdimFuse *df = nullptr);
 
 // da_attn_csr.hip
@@ -104,7 +104,7 @@ struct DenseMask {             // hybrid mode: adjacency bits of the regular edg
 };
 struct DenseFold {             // value heads folded with the next linear layer: V is [H][n_pad][cv], output per head
     int cv;
-    float *out;                // [H][n_rows][cv] fp32, normalised
+    void *out;                 // [H][n_rows][cv] in the activation dtype, normalised
     int n_rows;
 };
 int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes,
