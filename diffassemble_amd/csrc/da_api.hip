@@ -293,7 +293,17 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                                              g->hybrid ? &mk : nullptr, &fo); });
                 if (rc > 0) return rc;
                 if (rc == 0) {
-                    // pre-activation of final_mlp.0 from the hidden layer (mlp.2 share) and from this conv's input (skip share)
+                    // the whole tail in one kernel where it is covered (bf16, hidden 128, conv input 256) ...
+                    {
+                        const bool fuse_ddim = ddim && d->c_out == d->c_in;
+                        int rt = -1;
+                        if ((rc = timed(d, DA_PROF_HEAD, st, [&] {
+                                 rt = launch_tail_fused(prec, nr, d->heads, d->c_out, d->hidden, c.din, w.h, xin, ldx, d->headc_w, d->headc_b,
+                                                        d->skipc_w, d->skipc_b, w.pz, d->head_w1, d->head_b1, out, st, fuse_ddim ? ddim : nullptr);
+                                 return rt > 0 ? rt : 0; }))) return rc;
+                        if (rt == 0) { if (fuse_ddim) ddim->done = 1; return 0; }
+                    }
+                    // ... else: pre-activation of final_mlp.0 from the hidden layer (mlp.2 share) and from this conv's input (skip share)
                     if ((rc = timed(d, DA_PROF_HEAD, st, [&] {
                              return linear(prec, nr, d->hidden, 32, w.h, d->hidden, d->headc_w, d->headc_b, DA_ACT_NONE, nullptr, w.head_pre, 32, st); }))) return rc;
                     if ((rc = timed(d, DA_PROF_HEAD, st, [&] {

@@ -337,6 +337,107 @@ __global__ __launch_bounds__(256) void k_head_fold(int n, int H, int c_out, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The whole folded tail of the 2D transformer arch as ONE kernel (bf16 mode, hidden 128, conv input 256, 8 heads):
+//   pre[n]  = Wh . h[n] + bh  +  Ws . xin[n] + bs          (mlp.2 share and skip share of final_mlp.0, 32 wide)
+//   f[n]    = GELU(pre[n] + sum_h Pz[h][n])                (Pz: per-head outputs of the folded last attention)
+//   out[n]  = W2 f[n] + b2   (+ the DDIM update of the sampling loop)
+// It used to be two skinny GEMMs (N = 32: 15.4 + 9.9 us at 64 puzzles, 1.9 TB/s) + k_head_fold (14 us); the tail only
+// has to read h (14.7 MB), xin (29.5 MB) and Pz (14.7 MB).  One wave per 32 rows, transposed product D^T = W . X^T on
+// v_mfma_f32_32x32x16_bf16: A = the 32 x 384 weight block, held in 96 registers for the wave's lifetime (K chunk c: lane
+// (m, g) holds W[m][16 c + 8 g .. + 7]); B = the rows themselves, one 16-byte global load per lane and chunk (lane (n, g):
+// row n, the same 8 columns) -- all 24 loads of a slab are in flight before the first MFMA.  The accumulator leaves
+// lane (n, g) with channels (r & 3) + 8 (r >> 2) + 4 g, r = 0..15, of row n: the GELU is lane-local, the 32 -> c_out
+// product is two half sums joined by one cross-half exchange.
+typedef __attribute__((ext_vector_type(8))) __bf16 tl_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float tl_f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int tl_u32x4;
+__global__ __launch_bounds__(64) void k_tail_fused(int n, int H, int c_out, const bf16_t *__restrict__ h, const bf16_t *__restrict__ xin,
+                                                   int ldx, const bf16_t *__restrict__ wh, const float *__restrict__ bh,
+                                                   const bf16_t *__restrict__ wsk, const float *__restrict__ bsk,
+                                                   const bf16_t *__restrict__ pz, const float *__restrict__ w2,
+                                                   const float *__restrict__ b2, float *__restrict__ out, DdimFuse df, int slabs_per_wave) {
+    constexpr int KH = 128, KX = 256, NCH = (KH + KX) / 16;
+    const int lane = threadIdx.x, m = lane & 31, g = lane >> 5;
+    tl_u32x4 wf[NCH];
+#pragma unroll
+    for (int c = 0; c < KH / 16; ++c) wf[c] = *(const tl_u32x4 *)(wh + (size_t)m * KH + 16 * c + 8 * g);
+#pragma unroll
+    for (int c = 0; c < KX / 16; ++c) wf[KH / 16 + c] = *(const tl_u32x4 *)(wsk + (size_t)m * KX + 16 * c + 8 * g);
+    float bias[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int ch = (r & 3) + 8 * (r >> 2) + 4 * g; bias[r] = bh[ch] + bsk[ch]; }
+    for (int sl = 0; sl < slabs_per_wave; ++sl) {
+        const int row0 = (blockIdx.x * slabs_per_wave + sl) * 32;
+        if (row0 >= n) break;
+        const int row = min(row0 + m, n - 1);                        // rows beyond n: computed, not stored
+        tl_u32x4 xf[NCH];
+#pragma unroll
+        for (int c = 0; c < KH / 16; ++c) xf[c] = *(const tl_u32x4 *)(h + (size_t)row * KH + 16 * c + 8 * g);
+#pragma unroll
+        for (int c = 0; c < KX / 16; ++c) xf[KH / 16 + c] = *(const tl_u32x4 *)(xin + (size_t)row * ldx + 16 * c + 8 * g);
+        // per-head partial outputs of this lane's 16 channels: 4 pieces of 4 consecutive channels per head
+        uint2 pzv[8][4];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                pzv[hh][q] = hh < H ? *(const uint2 *)(pz + ((size_t)hh * n + row) * 32 + 8 * q + 4 * g) : make_uint2(0u, 0u);
+        tl_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias[r];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tl_bf16x8, wf[c]), __builtin_bit_cast(tl_bf16x8, xf[c]), acc, 0, 0, 0);
+        float f[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+#pragma unroll
+            for (int hh = 0; hh < 8; ++hh) {
+                const uint2 u = pzv[hh][q];
+                a[0] += bf2f((bf16_t)(u.x & 0xffff)); a[1] += bf2f((bf16_t)(u.x >> 16));
+                a[2] += bf2f((bf16_t)(u.y & 0xffff)); a[3] += bf2f((bf16_t)(u.y >> 16));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[4 * q + e] = gelu_erf(a[e]);
+        }
+        // second linear: this lane's 16 channels, then the other half's
+        for (int j = 0; j < c_out; ++j) {
+            float part = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k0 = (r & 3) + 8 * (r >> 2);
+                const float wlo = w2[j * 32 + k0], whi = w2[j * 32 + k0 + 4];        // uniform: scalar loads
+                part = fmaf(g ? whi : wlo, f[r], part);
+            }
+            const float a = b2[j] + part + __shfl_xor(part, 32);
+            if (g == 0 && row0 + m < n) {
+                const size_t o = (size_t)(row0 + m) * c_out + j;
+                out[o] = a;
+                if (df.x_prev) df.x_prev[o] = ddim2d_value(df.s, df.mean_type, df.t, df.ratio, df.prev_all_nonneg, 0.f, df.x[o], a, 0.f);
+            }
+        }
+    }
+}
+
+// returns 0 = launched, -1 = shape / precision not covered (the caller runs the three-kernel tail)
+int launch_tail_fused(int prec, int n, int H, int c_out, int hidden, int din, const void *h, const void *xin, int ldx, const void *wh,
+                      const float *bh, const void *wsk, const float *bsk, const void *pz, const float *w2, const float *b2, float *out,
+                      hipStream_t st, const DdimFuse *dfp) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("DA_TAIL_FUSED"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off || prec != DA_PREC_BF16 || hidden != 128 || din != 256 || H > 8 || c_out > 8 || (ldx & 7)) return -1;
+    if (n <= 0) return 0;
+    DdimFuse df;
+    if (dfp) df = *dfp; else { df = DdimFuse(); df.x = nullptr; df.x_prev = nullptr; }
+    const int slabs = (n + 31) / 32, spw = slabs > 2048 ? 2 : 1;
+    k_tail_fused<<<(slabs + spw - 1) / spw, 64, 0, st>>>(n, H, c_out, (const bf16_t *)h, (const bf16_t *)xin, ldx, (const bf16_t *)wh, bh,
+                                                         (const bf16_t *)wsk, bsk, (const bf16_t *)pz, w2, b2, out, df, spw);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_head_fold(int prec, int n, int H, int c_out, const void *pz, const void *pre, const float *w2, const float *b2,
                      float *out, hipStream_t st, const DdimFuse *dfp) {
     if (n <= 0) return 0;

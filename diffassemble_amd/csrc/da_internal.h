@@ -69,6 +69,9 @@ int launch_mm_nn_f32(int M, int N, int K, const float *A, int lda, const float *
                      int ldc, hipStream_t st);
 int launch_scatter_virtual(int prec, int rows, int V, int H, int C, const void *src, int n_real, const int32_t *row_map,
                            int n_pad, void *Q, void *K, void *Vt, void *S, void *qkvs, hipStream_t st);
+int launch_tail_fused(int prec, int n, int H, int c_out, int hidden, int din, const void *h, const void *xin, int ldx, const void *wh,
+                      const float *bh, const void *wsk, const float *bsk, const void *pz, const float *w2, const float *b2, float *out,
+                      hipStream_t st, const DdimFuse *dfp);
 int launch_head_fold(int prec, int n, int H, int c_out, const void *pz, const void *pre, const float *w2, const float *b2,
                      float *out, hipStream_t st, const DdimFuse *df = nullptr);
 
