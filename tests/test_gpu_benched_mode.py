@@ -530,3 +530,44 @@ def test_two_branch_loop_equals_one_branch(dev, monkeypatch, prec, sizes, loops)
     assert not eng._two_branch(plan, True, True) and not eng._two_branch(plan, False, False)
     monkeypatch.setenv("DA_TWO_BRANCH_MIN_GRAPHS", "64")
     assert not eng._two_branch(plan, False, True)
+
+
+_TAIL_SCRIPT = r"""
+import sys, os, torch
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests", "golden"))
+from oracle import weights as W, diffusion as ODF
+from diffassemble_amd import DenoiserEngine, Schedule, _lib
+dev = torch.device("cuda:0")
+sizes = [int(v) for v in sys.argv[3].split(",")]
+N = sum(sizes)
+sd = W.make_denoiser_state(100, 4, 4, seed=47, qk_gain=2.0)
+x, feats = W.make_inputs(N, 4, 1088, 47)
+ei, batch = W.collate([W.dense_edge_index(n, True) for n in sizes], sizes)
+eng = DenoiserEngine(sd, precision="bf16", device=dev)
+plan = eng.plan(ei, batch)
+out = eng.forward(plan, x.to(dev), torch.full((N,), 37, dtype=torch.int64, device=dev), feats.to(dev))
+sch = Schedule(ODF.make_schedule(100), dev)
+_, xf = eng.sample_loop(plan, sch, x.to(dev), feats.to(dev), ratio=10, mean_type=_lib.MEAN_START_X, keep_trajectory=False, use_graph=True)
+torch.save({"out": out.cpu(), "xf": xf.cpu()}, sys.argv[2])
+"""
+
+
+@pytest.mark.parametrize("sizes", ["900", "33,64,31,100,1"], ids=["900", "ragged"])
+def test_tail_fused_kernel_vs_three_kernel_tail(dev, tmp_path, sizes):
+    """k_tail_fused (the folded tail as one MFMA kernel, the bf16 default) against the three-kernel tail it replaces
+    (DA_TAIL_FUSED=0, read once per process -> two subprocesses): one forward and a 10-step DDIM loop whose update the
+    kernel applies itself; row counts that are not multiples of the 32-row slab.  The two paths differ only in where the
+    32-wide pre-activation is rounded to bf16 (the fused kernel keeps it in fp32), so they agree far inside the bf16
+    tolerance of the parity tests."""
+    root = os.path.dirname(os.path.dirname(__file__))
+    res = {}
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"tail_{flag}.pt")
+        env = dict(os.environ, DA_TAIL_FUSED=flag)
+        r = subprocess.run([sys.executable, "-c", _TAIL_SCRIPT, root, path, sizes], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[flag] = torch.load(path)
+    assert not torch.equal(res["1"]["out"], res["0"]["out"])          # the switch really selects another path
+    assert rel(res["1"]["out"], res["0"]["out"]) < 5e-3
+    assert rel(res["1"]["xf"], res["0"]["xf"]) < 5e-3
