@@ -15,7 +15,7 @@ CLASS = [  # (regex on the kernel name, class)
     (r"k_attn_csr_cont", "attn_hidden"),
     (r"k_gemm_astat_rs<unsigned short, true", "linear_qkvs"), (r"k_gemm_wreg<256, true", "linear_qkvs"),
     (r"k_gemm_wreg2<", "linear_qkvs"),
-    (r"k_gemm_wreg<256, false", "linear_qkvs"), (r"k_embed_pos_time", "embed"), (r"k_head_fold", "head"),
+    (r"k_gemm_wreg<256, false", "linear_qkvs"), (r"k_embed_pos_time", "embed"), (r"k_head_fold", "head"), (r"k_tail_fused", "head"),
 ]
 # tag -> (bench config key, puzzles per GPU, launches of the class per denoising step)
 RUNS = {"headline": ("3p", 64, None), "config3_d539": ("3_d539", 32, False), "config3_d90": ("3_d90", 32, False),
