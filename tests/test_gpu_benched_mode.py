@@ -553,11 +553,12 @@ torch.save({"out": out.cpu(), "xf": xf.cpu()}, sys.argv[2])
 """
 
 
-@pytest.mark.parametrize("sizes", ["900", "33,64,31,100,1"], ids=["900", "ragged"])
+@pytest.mark.parametrize("sizes", ["900", "33,64,31,100,1", ",".join(["144"] * 255 + ["150"])], ids=["900", "ragged", "36870_rows"])
 def test_tail_fused_kernel_vs_three_kernel_tail(dev, tmp_path, sizes):
     """k_tail_fused (the folded tail as one MFMA kernel, the bf16 default) against the three-kernel tail it replaces
     (DA_TAIL_FUSED=0, read once per process -> two subprocesses): one forward and a 10-step DDIM loop whose update the
-    kernel applies itself; row counts that are not multiples of the 32-row slab.  The two paths differ only in where the
+    kernel applies itself; row counts that are not multiples of the 32-row slab, and more than 32 768 rows (two slabs per
+    wave, the shape of the benched Batches).  The two paths differ only in where the
     32-wide pre-activation is rounded to bf16 (the fused kernel keeps it in fp32), so they agree far inside the bf16
     tolerance of the parity tests."""
     root = os.path.dirname(os.path.dirname(__file__))
