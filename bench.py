@@ -50,7 +50,7 @@ F_NODE = 6_432_128          # FLOP per piece per step (SURVEY 8d / BASELINE.md)
 F_EDGE = 7_680              # FLOP per edge per step, all 4 layers
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0                            # MI355X_MICROARCH.md (HBM3E spec; ~6300 achievable)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 CONFIGS = {
     "1": dict(name="6x6 translation-only (N=36, K36 without self loops, E=1260), DDIM T=50, EPSILON, c=2, transformer arch",
@@ -142,7 +142,7 @@ def work_model(cfg, G, E, n_nodes_ext, flags, prec, hybrid, fused_hidden=False):
     return W
 
 
-def roofline_report(prof, kp, work, prec, traffic_file, cfg_key, G):
+def roofline_report(prof, kp, work, prec, traffic_file, cfg_key, G, gather_path=False):
     """Per-class roofline entries + the dominant class (largest share of the step's kernel time)."""
     peak = PEAK_TFLOPS[prec]
     total_ms = sum(ms for ms, _ in prof.values())
@@ -174,10 +174,20 @@ def roofline_report(prof, kp, work, prec, traffic_file, cfg_key, G):
         classes[k] = ent
     dom = max(classes, key=lambda k: classes[k]["time_share"])
     d = classes[dom]
-    gather = d["frac_hbm_peak"] > d["frac_mfma_peak_alg"]
+    # HBM-bound = the edge-list (gather) attention kernels and the elementwise classes; every matrix-core class (dense /
+    # adjacency-masked attention, projections, tail) is priced against the MFMA peak
+    gather = (gather_path and dom in ("attn_hidden", "attn_last")) or dom in ("embed", "update")
     if gather:
-        roof = {"bound": "hbm", "kernel": dom, "achieved": d["compulsory_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": d["frac_hbm_peak"], "traffic": d.get("pmc_traffic_bytes_per_launch")}
+        t = d.get("pmc_traffic_bytes_per_launch")
+        if t is not None:      # measured bytes at the L2's memory side (Infinity-Cache hits included): the honest figure, never > 1
+            roof = {"bound": "hbm", "kernel": dom, "achieved": d["pmc_traffic_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": d["pmc_traffic_GBps"] / HBM_PEAK_GBPS, "traffic": t, "frac_is": "PMC bytes (incl. MALL hits) / time / 8 TB/s",
+                    "algorithmic_GBps": d["compulsory_GBps"]}
+        else:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": d["compulsory_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": min(d["frac_hbm_peak"], 1.0), "traffic": None,
+                    "frac_is": "algorithmic gather bytes / time / 8 TB/s, capped at 1 (rows served from the Infinity Cache are not HBM bytes; no PMC file for this run)",
+                    "algorithmic_frac_uncapped": d["frac_hbm_peak"]}
     else:
         roof = {"bound": "mfma", "kernel": dom, "achieved": d["alg_tflops"], "peak": peak, "unit": "TFLOP/s",
                 "frac": d["frac_mfma_peak_alg"], "traffic": d.get("pmc_traffic_bytes_per_launch"),
@@ -339,6 +349,42 @@ def train_bench(args, world, rank, dev):
         step(True)
     if rank == 0:
         flop_fwd = G * (n * F_NODE + n * n * F_EDGE)
+        # roofline of the step's dominant phase (forward + backward of the denoiser, fp32 MFMA kernels): algorithmic FLOP =
+        # 3 x the forward's (backward = dX and dW products of every forward product) over the HIP-event time of
+        # that phase; the encoder (--pixels) is outside this count
+        fb_s = acc[0] / kp * 1e-3
+        roof = {"bound": "mfma", "kernel": "forward + backward (fp32 MFMA linears, grouped attention GEMMs, dW GEMMs)",
+                "achieved": 3 * flop_fwd / fb_s / 1e12, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
+                "frac": 3 * flop_fwd / fb_s / 1e12 / PEAK_TFLOPS["fp32"], "traffic": None,
+                "phase_share": {"forward+backward": acc[0] / sum(acc), "gradient_allreduce": acc[1] / sum(acc), "optimizer": acc[2] / sum(acc)},
+                "note": "denoiser FLOP only" + (" (the encoder's convolutions run in the same phase and are not counted)" if pixels else "")}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1 and not pixels:
+            # the oracle's p_losses + torch autograd on the host cores: 2 puzzles of 12x12, 1 warm-up + 3 repeats, median
+            from oracle import diffusion as ODF
+            sdc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.model._denoiser_state().items()}
+            schc = ODF.make_schedule(T_STEPS)
+            gc_ = torch.Generator().manual_seed(3)
+            Gc = 2
+            eic, bc = dense_batch(Gc, n, "cpu")
+            xc, nc_ = torch.randn((Gc * n, 4), generator=gc_), torch.randn((Gc * n, 4), generator=gc_)
+            fc = torch.randn((Gc * n, 1088), generator=gc_)
+            tc = torch.randint(0, T_STEPS, (Gc,), generator=gc_)[bc]
+            threads = min(16, os.cpu_count() or 1)
+            torch.set_num_threads(threads)
+
+            def cpu_step():
+                t0 = time.perf_counter()
+                loss_c = ODF.p_losses(sdc, schc, xc, tc, nc_, eic, fc, bc, "EPSILON")
+                loss_c.backward()
+                for v in sdc.values():
+                    v.grad = None
+                return time.perf_counter() - t0
+            cpu_step()
+            reps = sorted(cpu_step() for _ in range(3))
+            cpu = {"value": Gc / reps[1], "unit": "puzzle-train-steps/s", "cores": threads, "kind": "port",
+                   "sample": f"{Gc} puzzles of 12x12: oracle p_losses (q_sample + denoiser forward, torch fp32) + autograd backward, no optimizer; "
+                             f"1 warm-up + 3 repeats, median {reps[1]:.2f} s"}
         print(json.dumps({
             "metric": "training steps/sec (12x12 rot dense, 64 puzzles/GPU, Huber, Adafactor)",
             "value": world * G * K / dt, "unit": "puzzle-train-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -353,7 +399,7 @@ def train_bench(args, world, rank, dev):
             "optimizer_steps_per_s": K / dt,
             "algorithmic_tflops": 3 * world * flop_fwd * K / dt / 1e12,
             "phases_ms": {"forward+backward": acc[0] / kp, "gradient_allreduce": acc[1] / kp, "optimizer": acc[2] / kp},
-            "distributed": dist_info(world), "roofline": None, "cpu_baseline": None,
+            "distributed": dist_info(world), "roofline": roof, "cpu_baseline": cpu,
         }))
     if world > 1:
         dist.destroy_process_group()
@@ -590,7 +636,17 @@ def e2e_bench(args, world, rank, dev):
             "config": {"workload": "p_sample_loop from 32x32 crops + collated edge_index, 30x30 dense puzzles, DDIM T=100",
                        "puzzles_per_gpu": G, "parallelism": f"puzzle-sharded x{world}"},
             "phases_ms": {"encoder": acc[0] / kp, "graph_plan": acc[1] / kp, "sampling_loop": acc[2] / kp},
-            "distributed": dist_info(world), "roofline": None, "cpu_baseline": None,
+            "distributed": dist_info(world),
+            "roofline": {"bound": "mfma", "kernel": "dominant phase: " + ("piece encoder (19 k_conv_mfma launches per chunk)" if acc[0] >= acc[2] else "100-step sampling loop"),
+                         "achieved": (n * encoder_flops_per_piece() / (acc[0] / kp * 1e-3) if acc[0] >= acc[2]
+                                      else T_STEPS * G * (N_PIECES * F_NODE + N_PIECES ** 2 * F_EDGE) / (acc[2] / kp * 1e-3)) / 1e12,
+                         "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                         "frac": (n * encoder_flops_per_piece() / (acc[0] / kp * 1e-3) if acc[0] >= acc[2]
+                                  else T_STEPS * G * (N_PIECES * F_NODE + N_PIECES ** 2 * F_EDGE) / (acc[2] / kp * 1e-3)) / 1e12 / PEAK_TFLOPS[args.precision],
+                         "traffic": None,
+                         "phases_tflops": {"encoder": n * encoder_flops_per_piece() / (acc[0] / kp * 1e-3) / 1e12,
+                                           "sampling_loop": T_STEPS * G * (N_PIECES * F_NODE + N_PIECES ** 2 * F_EDGE) / (acc[2] / kp * 1e-3) / 1e12}},
+            "cpu_baseline": None, "cpu_baseline_note": "see the --mode encode and default lines: encoder 89 pieces/s, loop 0.17 puzzle-steps/s on the host cores",
         }))
     if world > 1:
         dist.destroy_process_group()
@@ -737,7 +793,7 @@ def sample_bench(args, world, rank, dev):
         work = work_model(cfg, G, E, plan.n_nodes, flags, prec, bool(plan.hybrid), prof.get("conv_fused", (0, 0))[1] > 0)
         tf = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic.json")
         pmc_key = args.config + (f"_d{args.degree}" if cfg["graph"] == "regular" else "")
-        roof = roofline_report(prof, kp, work, prec, tf, pmc_key, G)
+        roof = roofline_report(prof, kp, work, prec, tf, pmc_key, G, gather_path=not (plan.dense or plan.hybrid))
         roof["whole_step_tflops_in_kernels"] = sum(w["alg"] for w in work.values()) / (roof["kernel_ms_per_step"] * 1e-3) / 1e12
         roof["folds"] = {"mlp2_composed": bool(flags & 1), "value_heads_folded": bool(flags & 2)}
         try:        # measured ceilings of the box (tools/measure_peaks.py)
@@ -758,12 +814,43 @@ def sample_bench(args, world, rank, dev):
             prof2 = eng.profile_read()
             eng.profile(False)
             work2 = work_model(cfg, G, E, plan.n_nodes, flags, prec, False)
-            sparse = roofline_report(prof2, kp2, work2, prec, tf, pmc_key + "_csr", G)
+            sparse = roofline_report(prof2, kp2, work2, prec, tf, pmc_key + "_csr", G, gather_path=True)
             sparse["note"] = ("same Batch through the edge-list kernels only (hybrid split off): algorithmic gather bytes / kernel "
                               "time; K/V rows of a Batch that fits the 256 MB Infinity Cache are not HBM bytes -- compare with "
                               "pmc_traffic where present")
             eng.set_features(plan, feats)
     del ei
+
+    parity = None
+    if prec == "bf16" and not args.no_parity_mode:
+        # the mode whose parity bound is north_star's 1e-4 (fp32 storage, exact-fp32 MFMA): same Batch, same loop, one
+        # captured replay of min(K, 20) steps after one untimed replay -- reported beside the benched bf16 figure
+        model.model.precision = "fp32"
+        eng32 = model.model.engine(dev)
+        plan32 = eng32.plan_expander(perms, args.degree) if cfg["graph"] == "regular" else eng32.plan(*dense_batch(G, n, dev, loops=cfg["graph"] == "dense"))
+        eng32.set_features(plan32, feats)
+        kq = min(K, 20, its)
+
+        def run32():
+            return eng32.sample_loop(plan32, sch, x_T, feats, ratio=cfg["ratio"], mean_type=mt, max_iters=kq, keep_trajectory=False,
+                                     use_graph=True, restage=False)
+        run32()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        _, xf32 = run32()
+        torch.cuda.synchronize()
+        barrier()
+        dt32 = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt32], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt32 = float(tt)
+        assert torch.isfinite(xf32).all()
+        parity = {"dtype": "fp32", "value": world * G * kq / dt32, "unit": "puzzle-steps/s", "ms_per_step": dt32 / kq * 1e3, "steps": kq,
+                  "note": "fp32 storage + exact-fp32 MFMA: the mode the 1e-4 parity tests run in (tests/test_gpu_parity.py)"}
+        del eng32, plan32
 
     if rank == 0:
         cpu = None
@@ -790,7 +877,7 @@ def sample_bench(args, world, rank, dev):
             "timed_region": {"seconds": dt, "graph_replays_per_pass": len(chunks),
                              "excluded": "per-Batch staging (set_features_ms, once per sampling loop), graph capture, warm-up"},
             "set_features_ms": set_features_ms, "graph_plan_ms": plan_ms, "fragment_encoder_ms": fragment_encoder_ms,
-            "replay": replay,
+            "replay": replay, "parity_mode": parity,
             "roofline": roof, "cpu_baseline": cpu,
         }
         if sparse is not None:
@@ -870,6 +957,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle with ONE thread at full size")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp32 (parity-mode) replay of the sampling configurations")
     args = ap.parse_args()
     if args.config == "5":
         args.mode = "train"

@@ -22,8 +22,32 @@ void set_error(const char *fmt, ...) {
 struct ConvW {
     void *w = nullptr;     // [4*HC, Din] act dtype, rows = Q | K | V | skip
     float *b = nullptr;    // [4*HC] fp32
+    // the same projection for the matrix-core attention kernels (da_attn_dense.hip / da_attn_dual.hip): the Q rows and
+    // biases are PRE-SCALED by log2(e) / sqrt(C), so that the kernels' scores arrive in log2 units and exp2 applies to them
+    // directly -- the softmax scale costs no instruction per score (scaled in fp32, before the rounding to the act dtype)
+    void *wd = nullptr;
+    float *bd = nullptr;
     int din = 0, hc = 0, C = 0;
 };
+
+// p[r][c] *= s for r < rows, c < cols (row pitch ld): scales the Q block of a packed projection in fp32
+__global__ void k_scale_block(float *p, int rows, int cols, int ld, float s) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)rows * cols) p[(i / cols) * ld + (i % cols)] *= s;
+}
+static int scale_block(float *p, int rows, int cols, int ld, float s, hipStream_t st) {
+    const size_t n = (size_t)rows * cols;
+    if (!n) return 0;
+    k_scale_block<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(p, rows, cols, ld, s);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+static bool q_prescale_on() {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("DA_DISABLE_Q_PRESCALE"); off = (e && e[0] == '1') ? 1 : 0; }
+    return !off;
+}
+static float q_scale_log2(int C) { return 1.4426950408889634f / sqrtf((float)C); }
 
 struct LoopKey {
     da_graph g;
@@ -59,6 +83,9 @@ struct da_denoiser {
     void *headc_w = nullptr;          // [32, hidden] act dtype = Wf0 . W2
     float *headc_b = nullptr;         // [32] = Wf0 . b2
     void *virt_qkvs = nullptr;        // exophormer: [V, 4*HC0] act dtype = virt_emb . Wcat0^T + bcat0 (constant per checkpoint)
+    void *conv0c_wd = nullptr, *virt_qkvs_d = nullptr;      // their dense-path variants (Q pre-scaled, see ConvW)
+    float *conv0c_bd = nullptr;
+    bool q_prescaled = false;
     // ... and the LAST conv's value / skip projections are folded with final_mlp.0 (its consumer, linear up to
     // the GELU): softmax(QK^T)(V Wf_h^T) == (softmax(QK^T) V) Wf_h^T per head, so the last attention runs with
     // 32-wide value heads and the [N, 1152] tensor z is never formed either (dense path only)
@@ -278,7 +305,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             if (rc > 0) return rc;
             if (rc == 0) {
                 DenseLayout L;
-                L.Q = w.dq; L.K = w.dk; L.Vt = w.dvt; L.S = nullptr; L.n_pad = g->n_pad;
+                L.Q = w.dq; L.K = w.dk; L.Vt = w.dvt; L.S = nullptr; L.n_pad = g->n_pad; L.q_prescaled = d->q_prescaled;
                 DenseFold fo;
                 fo.cv = 32; fo.out = w.pz; fo.n_rows = nr;
                 // hybrid graphs: adjacency-masked, remainder edges of the real rows folded in the epilogue; the
@@ -330,15 +357,17 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             QkvScatter qs;
             qs.HC = c.hc; qs.C = c.C; qs.n_pad = g->n_pad; qs.row_map = g->row_map;
             qs.Q = w.dq; qs.K = w.dk; qs.Vt = w.dvt; qs.S = w.dskip;
+            const void *wdense = (fused && l == 0) ? d->conv0c_wd : c.wd;
+            const float *bdense = (fused && l == 0) ? d->conv0c_bd : c.bd;
             rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
-                return launch_gemm_mfma(prec, nproj, c.din, 4 * c.hc, xin, ldx, c.w, c.b, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st); });
+                return launch_gemm_mfma(prec, nproj, c.din, 4 * c.hc, xin, ldx, wdense, bdense, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st); });
             if (rc > 0) return rc;
             if (rc == 0 && virt0 &&
-                (rc = launch_scatter_virtual(prec, n - nr, d->V, d->heads, c.C, d->virt_qkvs, nr, g->row_map, g->n_pad, w.dq, w.dk,
+                (rc = launch_scatter_virtual(prec, n - nr, d->V, d->heads, c.C, d->virt_qkvs_d, nr, g->row_map, g->n_pad, w.dq, w.dk,
                                              w.dvt, w.dskip, nullptr, st))) return rc;
             if (rc == 0) {
                 DenseLayout L;
-                L.Q = w.dq; L.K = w.dk; L.Vt = w.dvt; L.S = w.dskip; L.n_pad = g->n_pad;
+                L.Q = w.dq; L.K = w.dk; L.Vt = w.dvt; L.S = w.dskip; L.n_pad = g->n_pad; L.q_prescaled = d->q_prescaled;
                 if (g->hybrid) {
                     // sparse-but-heavy graphs: masked MFMA attention over the regular edges (partial softmax
                     // state), then the remaining edges + normalisation + skip / activation on the CSR side
@@ -421,6 +450,9 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
     DA_REQUIRE(precision == DA_PREC_F32 || precision == DA_PREC_BF16, "bad precision %d", precision);
     DA_REQUIRE(w->n_layers >= 2 && w->n_layers <= DA_MAX_LAYERS, "n_layers out of range");
     DA_REQUIRE(w->heads == 8, "heads must be 8");
+    // k_embed_pos_time keeps the pose-MLP weight rows in a fixed register array (da_basic.hip); fail here, not on the first
+    // forward or inside a hipGraph capture (the reference uses c_in = 2 / 4 in 2D and 7 in 3D)
+    DA_REQUIRE(w->c_in >= 1 && w->c_in <= 8, "da_denoiser_create: c_in = %d outside [1, 8]", w->c_in);
     hipStream_t st = (hipStream_t)stream;
     da_denoiser *d = new da_denoiser();
     d->prec = precision; d->variant = w->variant; d->arch = w->arch; d->steps = w->steps; d->c_in = w->c_in;
@@ -470,7 +502,22 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
             if (launch_convert(precision, blk, ws[k], wp + k * blk * s, st)) return fail(2);
             if (hipMemcpyAsync(c.b + (size_t)k * c.hc, bs[k], (size_t)c.hc * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
         }
+        c.wd = c.w; c.bd = c.b;
+        if (q_prescale_on()) {
+            char *wd = (char *)alloc(4 * blk * s + 4096);
+            float *tq = (float *)alloc(blk * 4);
+            c.bd = (float *)alloc(4 * (size_t)c.hc * 4);
+            if (!wd || !tq || !c.bd) return fail(2);
+            c.wd = wd;
+            if (hipMemcpyAsync(tq, ws[0], blk * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+            if (scale_block(tq, c.hc, c.din, c.din, q_scale_log2(c.C), st)) return fail(2);
+            if (launch_convert(precision, blk, tq, wd, st)) return fail(2);
+            if (hipMemcpyAsync(wd + blk * s, wp + blk * s, 3 * blk * s, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+            if (hipMemcpyAsync(c.bd, c.b, 4 * (size_t)c.hc * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+            if (scale_block(c.bd, 1, c.hc, c.hc, q_scale_log2(c.C), st)) return fail(2);
+        }
     }
+    d->q_prescaled = q_prescale_on();
     if (d->V > 0) {
         if (!w->virt_emb) { set_error("exophormer: virt_emb missing"); return fail(1); }
         d->virt_emb = pack(w->virt_emb, (size_t)d->V * D);
@@ -518,6 +565,15 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
             if (launch_gemm_simple(DA_PREC_F32, 1, D, 32, w->mlp_b1, D, w->head_w0, nullptr, DA_ACT_NONE, nullptr, d->headc_b, 32, st)) return fail(2);
             d->conv0c_w = pack(cw, (size_t)4 * hc0 * hid);
             d->headc_w = pack(hw, (size_t)32 * hid);
+            d->conv0c_wd = d->conv0c_w; d->conv0c_bd = d->conv0c_b;
+            if (d->q_prescaled) {          // dense-path variant: Q rows scaled in fp32, then packed (cw is not used afterwards)
+                d->conv0c_bd = (float *)alloc((size_t)4 * hc0 * 4);
+                if (!d->conv0c_bd) return fail(2);
+                if (hipMemcpyAsync(d->conv0c_bd, d->conv0c_b, (size_t)4 * hc0 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
+                if (scale_block(d->conv0c_bd, 1, hc0, hc0, q_scale_log2(d->conv[0].C), st)) return fail(2);
+                if (scale_block(cw, hc0, hid, hid, q_scale_log2(d->conv[0].C), st)) return fail(2);
+                d->conv0c_wd = pack(cw, (size_t)4 * hc0 * hid);
+            }
             if (d->V > 0) {            // exophormer: conv-0 projections of the virtual rows (they bypass mlp)
                 float *vq = (float *)alloc((size_t)d->V * 4 * hc0 * 4);
                 if (!vq) return fail(2);
@@ -525,6 +581,11 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
                     if (launch_gemm_simple(DA_PREC_F32, d->V, D, hc0, w->virt_emb, D, ws[k], bs[k], DA_ACT_NONE, nullptr,
                                            vq + (size_t)k * hc0, 4 * hc0, st)) return fail(2);
                 d->virt_qkvs = pack(vq, (size_t)d->V * 4 * hc0);
+                d->virt_qkvs_d = d->virt_qkvs;
+                if (d->q_prescaled) {
+                    if (scale_block(vq, d->V, hc0, 4 * hc0, q_scale_log2(d->conv[0].C), st)) return fail(2);
+                    d->virt_qkvs_d = pack(vq, (size_t)d->V * 4 * hc0);
+                }
             }
             if (rc) return fail(rc);
             d->fused_mlp2 = true;
@@ -555,6 +616,10 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
                 // skip: Wf [32, D] . Ws [D, din];  bias: Wf . bs + bf0
                 if (launch_mm_nn_f32(32, dinL, D, w->head_w0, D, w->conv_ws[L], dinL, nullptr, sw, dinL, st)) return fail(2);
                 if (launch_mm_nn_f32(32, 1, D, w->head_w0, D, w->conv_bs[L], 1, w->head_b0, d->skipc_b, 1, st)) return fail(2);
+                if (d->q_prescaled) {          // this projection only ever feeds the matrix-core attention
+                    if (scale_block(lw, hcL, dinL, dinL, q_scale_log2(CL), st)) return fail(2);
+                    if (scale_block(d->convLf_b, 1, hcL, hcL, q_scale_log2(CL), st)) return fail(2);
+                }
                 d->convLf_w = pack(lw, (size_t)nf * dinL);
                 d->skipc_w = pack(sw, (size_t)32 * dinL);
                 if (rc) return fail(rc);

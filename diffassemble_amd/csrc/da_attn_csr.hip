@@ -288,7 +288,7 @@ template <typename T>
 static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32_t *cs, const int32_t *row_map, int H, int C,
                          int n_pad, const DenseLayout &L, const T *residual, int act, T *out, hipStream_t st) {
     if (n_nodes <= n_real) return 0;
-    const float scale = 1.0f / sqrtf((float)C);
+    const float scale = L.q_prescaled ? 0.6931471805599453f : 1.0f / sqrtf((float)C);      // pre-scaled Q: q . k is in log2 units
     const int grid = (int)(((size_t)(n_nodes - n_real) * 64 + 255) / 256);
 #define DA_CONT_CASE(E)                                                                                          \
     case E:                                                                                                      \

@@ -59,6 +59,7 @@ struct AttnDenseParams {
     int max_nodes;                                  // largest graph of the batch
     float sc;                       // log2(e) / sqrt(C)
     unsigned long long *prof;       // DA_ATTN_PROBE: per-workgroup cycle breakdown of wave 0
+    int fast;                       // Q pre-scaled (sc == 1): start every wave in the shift-free softmax mode (see k_attn_dense)
     int debug;                      // DA_ATTN_DEBUG bits (timing experiments): 1 no DMA, 2 no softmax, 4 no PV, 8 no QK
     // hybrid (MASKED) mode: adjacency bits of the regular edges; the remainder edges are folded in by the epilogue
     const unsigned char *mask;      // rows of graph g at mask_ptr[g], row stride (pad_ptr[g+1] - pad_ptr[g]) / 8 bytes
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[cb][r] = 0.f;
     float m = -1e30f, l = 0.f;               // finite reference (see the softmax below); only the slow path moves it
+    bool fast = !MASKED && p.fast;          // shift-free mode (wave-uniform, one way out)
 
     // ---- LDS-DMA plan: instruction q (1 KB) of a tile is issued by wave q % NW; lane -> slot q*64+lane
     const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
@@ -421,8 +423,28 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
                     const f32x2 c = a + b;
                     return c[0] + c[1];
                 };
-                float bsum = exp_block(m * p.sc);
-                if (__any(!(bsum < 16384.0f))) {
+                // FAST mode (complete graphs, Q pre-scaled so that s is in log2 units): p = exp2(s) with NO reference at all.
+                // The shift only guards the exponent range, and fp32 / bf16 carry 8 exponent bits: while the running sum
+                // stays inside [2^-60, 2^60] nothing overflows or vanishes.  The block sum -- needed anyway -- is the test;
+                // the first block that leaves the range sends the wave to the referenced path below for good (its scores
+                // are still intact; what was accumulated so far is relative to the reference 0).
+                float bsum;
+                bool redo = !fast;
+                if (fast) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) e2[r] = (f32x2){__builtin_amdgcn_exp2f(s[2 * r]), __builtin_amdgcn_exp2f(s[2 * r + 1])};
+                    const f32x2 a = (e2[0] + e2[1]) + (e2[2] + e2[3]), b = (e2[4] + e2[5]) + (e2[6] + e2[7]);
+                    const f32x2 c = a + b;
+                    bsum = c[0] + c[1];
+                    if (__any(!(bsum < 1.152921504606847e18f) || !(l + bsum > 8.673617379884035e-19f))) {
+                        fast = false;
+                        redo = true;
+                        const float lq = l + __shfl_xor(l, 32);
+                        m = lq > 0.f ? 0.f : -1e30f;
+                    }
+                }
+                if (redo) bsum = exp_block(m * p.sc);
+                if (redo && __any(!(bsum < 16384.0f))) {
                     const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
                     const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
                     const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
@@ -1024,6 +1046,12 @@ static int launch_tc(const AttnDenseParams &p, hipStream_t st) {
     return p.mask ? launch_tcm<T, C, true, C>(p, st) : launch_tcm<T, C, false, C>(p, st);
 }
 
+// DA_ATTN_DUAL=0: the folded last layer on k_attn_dense instead of the two-slab kernel (da_attn_dual.hip), for A/B runs
+static int attn_dual_env() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_ATTN_DUAL"); v = e ? atoi(e) : 1; }
+    return v;
+}
 // returns 0 = launched, -1 = configuration not supported (caller uses the CSR kernel)
 int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes,
                       const int32_t *graph_ptr, const int32_t *pad_ptr, int nodiag, const void *res, int act,
@@ -1034,7 +1062,9 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.Q = L.Q; p.K = L.K; p.Vt = L.Vt; p.S = L.S; p.res = res; p.out = out;
     p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.n_graphs = n_graphs;
     p.nqt = 0; p.max_nodes = max_graph_nodes; p.act = act; p.nodiag = nodiag;
-    p.sc = 1.4426950408889634f / sqrtf((float)C);
+    p.fast = L.q_prescaled ? 1 : 0;
+    { static int off = -1; if (off < 0) { const char *e = getenv("DA_ATTN_NO_FAST"); off = (e && e[0] == '1') ? 1 : 0; } if (off) p.fast = 0; }
+    p.sc = L.q_prescaled ? 1.0f : 1.4426950408889634f / sqrtf((float)C);      // pre-scaled Q: the scores already are in log2 units
     p.mask = mk ? mk->mask : nullptr; p.mask_ptr = mk ? (const long long *)mk->mask_ptr : nullptr;
     p.irr_row_ptr = mk ? mk->irr_row_ptr : nullptr; p.irr_col_src = mk ? mk->irr_col_src : nullptr;
     p.row_map = mk ? mk->row_map : nullptr;
@@ -1045,6 +1075,10 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     if (fold) {           // value heads folded to 32 channels (last layer of the 2D transformer arch)
         if (C != 144 || fold->cv != 32) return -1;
         p.fold_out = fold->out; p.n_rows = fold->n_rows;
+        if (!mk && prec == DA_PREC_BF16 && L.q_prescaled && attn_dual_env() DA_ATTN_DBG(&& !p.debug && !p.prof)) {
+            const int r2 = launch_attn_dual(L, heads, C, n_graphs, max_graph_nodes, graph_ptr, pad_ptr, nodiag, act, out, fold, st);
+            if (r2 >= 0) return r2;
+        }
         if (mk) return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, true, 32>(p, st) : launch_tcm<float, 144, true, 32>(p, st);
         return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, false, 32>(p, st) : launch_tcm<float, 144, false, 32>(p, st);
     }

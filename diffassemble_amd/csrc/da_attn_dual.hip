@@ -1,0 +1,528 @@
+// Dense block-diagonal graph attention, bf16, TWO 32-query slabs per wave with the matrix work of one slab issued under
+// the softmax of the other (round 3).  Same arithmetic contract as k_attn_dense (da_attn_dense.hip: PyG TransformerConv on
+// complete graphs, Transformer_GNN.py:32,38; softmax denominators + 1e-16), same operand layouts:
+//
+//   S^T = K_blk . Q^T          32 keys x 32 queries per MFMA chain (v_mfma_f32_32x32x16_bf16), A = K rows from LDS, B = Q rows
+//                              in registers; MFMA row rho is fed key pi(rho) so that lane (q, half) ends up with the 16
+//                              consecutive keys 16 half .. 16 half + 15 of query q: the softmax is lane-local and P needs no
+//                              data movement to become the B operand of O^T += V^T . P^T.
+//
+// What is different, and why (measurements: DESIGN.md "Measured, round 3"):
+//   * a workgroup is 4 waves x 2 slabs = 256 queries: every K / V block streamed into LDS feeds twice the queries (half the
+//     LDS-DMA bytes per FLOP -- the 128-query kernel's C = 144 instance ran at the latency x bytes-in-flight limit of its
+//     two-stage ring) and every K fragment read from LDS feeds two MFMA chains;
+//   * the ring holds 32-key blocks (12 KB at C = 144), six of them: four blocks in flight per workgroup, one barrier per
+//     block, two workgroups per CU (144 KB of LDS);
+//   * software pipeline inside a wave: the chain S(b, slab 1) is issued interleaved with the exponentials of S(b, slab 0),
+//     the chain S(b + 1, slab 0) with those of S(b, slab 1); the K fragments of block b + 1 replace those of block b one
+//     by one, each behind the MFMA that consumed the old value;
+//   * the softmax shift costs no instruction: Q arrives PRE-SCALED by log2(e) / sqrt(C) (folded into the projection
+//     weights at pack time), and the running reference -m enters as the INITIAL VALUE of the S^T accumulator (a 16-register
+//     tuple per slab, rewritten only when the reference moves), so p = exp2(acc) directly;
+//   * the first block takes its true row max as the reference; afterwards the reference only moves when a block's sum says
+//     it is stale (> 2^14), as in k_attn_dense.
+#include <stdlib.h>
+
+#include "da_common.h"
+#include "da_internal.h"
+#include "da_attn_dual_asm.inc"
+
+namespace da {
+
+#ifdef DA_DUAL_PROBE
+#define DA_DUAL_DBG(...) __VA_ARGS__
+#define DA_DUAL_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define DA_DUAL_DBG(...)
+#define DA_DUAL_TICK(var)
+#endif
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct AttnDualParams {
+    const void *Q, *K, *V;          // [H][n_pad][C] (Q pre-scaled), [H][n_pad][C], [H][n_pad][CV]
+    const void *S;                  // skip [N][H*C] (not folded)
+    void *out;                      // folded: [H][n_rows][CV] normalised per-head rows; else [N][H*C] = act(attn + skip)
+    const int32_t *graph_ptr, *pad_ptr;
+    int n_pad, H, nqt, act, nodiag, n_rows;
+    int stagger, stagger_shift;     // experiment: delay half of the workgroups at start (cycles / which bit of the tile index)
+    unsigned long long *prof;       // DA_DUAL_PROBE builds: per-workgroup cycle breakdown of wave 0 (tools/attn_bench)
+};
+
+template <int C, int CV> struct DualCfg {
+    static constexpr int ROWB = C * 2, ROWBV = CV * 2;
+    static constexpr int NCH = ROWB / 32;                             // 16-element K-dim chunks (one MFMA each)
+    static constexpr int RS = ROWB + (((ROWB / 16) & 1) ? 0 : 16);    // K row pitch: odd number of 16-B slots
+    static constexpr int KSPR = RS / 16, KVALID = ROWB / 16;
+    static constexpr int RSV = (ROWBV - 64 + 255) / 256 * 256 + 64;   // V row pitch: 64 (mod 256) bytes (ds_read_b64_tr_b16 groups)
+    static constexpr int VSPR = RSV / 16, KVALIDV = ROWBV / 16;
+    static constexpr int BK = 32;                                     // keys per ring stage
+    static constexpr int NIK = (BK * KSPR + 63) / 64, NIV = (BK * VSPR + 63) / 64, NI = NIK + NIV;      // 1 KB DMA instructions
+    static constexpr int KBYTES = NIK * 1024, STAGE = (NIK + NIV) * 1024;
+    static constexpr int MAXI = (NI + 3) / 4;
+    static_assert(CV == 32, "one 32-channel value block");
+};
+
+__device__ __forceinline__ u32x2 tr_read_b64(unsigned lds_byte_addr, int imm) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(imm));
+    return r;
+}
+
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+#define DA_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        DA_VM(1) DA_VM(2) DA_VM(3) DA_VM(4) DA_VM(5) DA_VM(6) DA_VM(7) DA_VM(8) DA_VM(9) DA_VM(10) DA_VM(11) DA_VM(12) DA_VM(13) DA_VM(14) DA_VM(15) DA_VM(16)
+#undef DA_VM
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int V> struct SlabTag { static constexpr int value = V; };
+
+template <int C, int CV, int NST, bool FOLD>
+__global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
+    using CF = DualCfg<C, CV>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // XCD-aware remap (as k_attn_dense): hardware places workgroup b on XCD b % 8; XCD x takes head x of every graph and
+    // the query tiles of one (graph, head) run back to back on it, sharing its L2 copy of K / V
+    const int bid = blockIdx.x;
+    const int h = bid & 7, s_ = bid >> 3;
+    const int qt = s_ % p.nqt, g = s_ / p.nqt;
+    const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
+    const int nslab_g = (n_g + 31) >> 5;
+    const int s_lo = qt * nslab_g / p.nqt, s_hi = (qt + 1) * nslab_g / p.nqt;      // balanced split of the graph's slabs (<= 8 per tile)
+    if (s_lo >= s_hi) return;
+    if (p.stagger > 0 && ((s_ >> p.stagger_shift) & 1)) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(32);
+    }
+
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    DA_DUAL_DBG(unsigned long long c_sync = 0, c_r1 = 0, c_r2 = 0;)
+    DA_DUAL_TICK(t_start);
+    const bool wave_on = s_lo + wid < s_hi, two = s_lo + wid + 4 < s_hi;
+    const size_t np = (size_t)p.n_pad;
+
+    // ---- LDS-DMA plan: instruction q (1 KB) of a block is issued by wave q % 4; lane -> 16-byte slot q * 64 + lane
+    const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
+    const unsigned char *Vg = (const unsigned char *)p.V + ((size_t)h * np + pad0) * CF::ROWBV;
+    unsigned soff[CF::MAXI];
+#pragma unroll
+    for (int x = 0; x < CF::MAXI; ++x) {
+        const int q = wid + 4 * x;
+        unsigned o = 0;
+        if (q < CF::NIK) {
+            const int s = q * 64 + lane, row = s / CF::KSPR, col = s - row * CF::KSPR;
+            if (row < CF::BK && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
+        } else {
+            const int s = (q - CF::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
+            if (row < CF::BK && col < CF::KVALIDV) o = (unsigned)(row * CF::ROWBV + col * 16);
+        }
+        soff[x] = o;
+    }
+    auto issue = [&](int blk, int stage) {
+        unsigned char *sb = smem + stage * CF::STAGE;
+        const unsigned char *kb_ = Kg + (size_t)blk * CF::BK * CF::ROWB;
+        const unsigned char *vb_ = Vg + (size_t)blk * CF::BK * CF::ROWBV;
+#pragma unroll
+        for (int x = 0; x < CF::MAXI; ++x) {
+            const int q = wid + 4 * x;
+            if (4 * x + 3 < CF::NI || q < CF::NI) {
+                const unsigned char *src = (q < CF::NIK ? kb_ : vb_) + soff[x];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+    const int myn = (CF::NI - wid + 3) / 4;                  // DMA instructions of this wave per block
+    const int nb = (n_g + CF::BK - 1) / CF::BK;              // key blocks
+
+    const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);     // key fed to MFMA row i
+    const int koff = pi_i * CF::RS + half * 16;
+    const int li = lane & 15;
+    const int vbase = CF::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    // Q fragments of both slabs stay in registers (rows beyond the graph zeroed: their scores stay finite)
+    int q0[2], qidx[2];
+    u32x4 qf[2][CF::NCH];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int slab = min(s_lo + wid + 4 * sl, s_hi - 1);
+        q0[sl] = slab * 32;
+        qidx[sl] = q0[sl] + i;
+        const unsigned char *qrow = (const unsigned char *)p.Q + ((size_t)h * np + pad0 + qidx[sl]) * CF::ROWB;
+#pragma unroll
+        for (int ch = 0; ch < CF::NCH; ++ch) {
+            qf[sl][ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
+            if (qidx[sl] >= n_g) qf[sl][ch] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
+
+    // ---- block-level sync.  sync_block(blk) runs before the K fragments of block `blk` are read (for blk >= 1 that is the
+    // top of iteration blk - 1).  Block `blk` must have landed for every wave: loads retire in order and this wave has issued
+    // blocks up to `issued - 1`, so "at most (issued - 1 - blk) * myn of my DMA instructions outstanding" says my share is in
+    // LDS; the barrier says everybody's is.  The same barrier says every wave has finished iteration blk - 2 (K fragments of
+    // block blk - 2 consumed, its V fragments fenced before its PV products), so the stage of block blk - 2 is refilled right
+    // after it; blocks blk - 1 (V reads) and blk (K reads) are the two in use.  In flight behind them: NST - 2 blocks.
+    int issued = 0;
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nb) { issue(st, st); ++issued; }
+    auto sync_block = [&](int blk) {
+        if (CF::NI % 4 == 0 && issued - 1 - blk == NST - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * (CF::NI / 4)) : "memory");      // steady state
+        else wait_vm((issued - 1 - blk) * myn);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (blk > 0 && issued < nb) { issue(issued, issued % NST); ++issued; }      // block blk + NST - 2 -> stage of block blk - 2
+    };
+
+    // Softmax of one 32-key block of one slab.  s holds the scores in log2 units (Q is pre-scaled); p goes out packed as the
+    // B operand of the PV product.
+    //   FAST mode (the state every slab starts in): p = exp2(s) with NO shift at all.  Softmax is shift invariant, the only
+    //   reason to subtract a reference is the exponent range -- and fp32 / bf16 carry 8 exponent bits, so as long as the
+    //   running sum stays inside [2^-60, 2^60] nothing can overflow or vanish (O accumulates at most 900 x 2^60 x |v|).  The
+    //   block sum (needed for the denominator anyway) is the test; no max tree, no shift instruction, no reference registers.
+    //   GEN mode (entered per slab, one way, by the first block whose sum leaves that range; logits beyond +-41 before the
+    //   1/sqrt(C) -- not seen at a fresh model's near-uniform attention, possible in a trained one): the classic online
+    //   softmax with a running row max, recomputed from the still intact scores of the block that tripped the test.
+    auto rowmax = [&](const f32x16 &s) {
+        const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
+        const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
+        const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+        const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
+        return fmaxf(mloc, __shfl_xor(mloc, 32));
+    };
+    auto exp_block = [&](const f32x16 &s, float ref, bf16x8 &pf0, bf16x8 &pf1) {
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 x = {__builtin_amdgcn_exp2f(s[2 * e] - ref), __builtin_amdgcn_exp2f(s[2 * e + 1] - ref)};
+            const f32x2 y = {__builtin_amdgcn_exp2f(s[8 + 2 * e] - ref), __builtin_amdgcn_exp2f(s[8 + 2 * e + 1] - ref)};
+            acc += x;
+            acc += y;
+            pf0[2 * e] = (__bf16)x[0]; pf0[2 * e + 1] = (__bf16)x[1];
+            pf1[2 * e] = (__bf16)y[0]; pf1[2 * e + 1] = (__bf16)y[1];
+        }
+        return acc[0] + acc[1];
+    };
+    auto exp_block0 = [&](const f32x16 &s, bf16x8 &pf0, bf16x8 &pf1) {          // ref = 0: no subtraction emitted
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 x = {__builtin_amdgcn_exp2f(s[2 * e]), __builtin_amdgcn_exp2f(s[2 * e + 1])};
+            const f32x2 y = {__builtin_amdgcn_exp2f(s[8 + 2 * e]), __builtin_amdgcn_exp2f(s[8 + 2 * e + 1])};
+            acc += x;
+            acc += y;
+            pf0[2 * e] = (__bf16)x[0]; pf0[2 * e + 1] = (__bf16)x[1];
+            pf1[2 * e] = (__bf16)y[0]; pf1[2 * e + 1] = (__bf16)y[1];
+        }
+        return acc[0] + acc[1];
+    };
+
+    auto run = [&](auto tag) {
+        constexpr int NS = decltype(tag)::value;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 O[NS];
+        float m[NS], l[NS];
+        bool gen[NS];
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            O[sl] = zero16;
+            m[sl] = 0.f; l[sl] = 0.f; gen[sl] = false;
+        }
+        auto softmax = [&](f32x16 &s, int sl, int key0, bf16x8 &pf0, bf16x8 &pf1) {
+            const int kbase = key0 + 16 * half;
+            const bool tail = key0 + 32 > n_g;
+            const bool diag = p.nodiag && key0 < q0[sl] + 32 && key0 + 32 > q0[sl];
+            if (tail || diag) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = (kbase + r >= n_g || (p.nodiag && kbase + r == qidx[sl])) ? -INFINITY : s[r];
+            }
+            if (!gen[sl]) {
+                const float bsum = exp_block0(s, pf0, pf1);
+                const float tot = l[sl] + bsum;
+                if (!__any(!(bsum < 1.152921504606847e18f) || !(tot > 8.673617379884035e-19f))) {       // 2^60, 2^-60
+                    l[sl] = tot;
+                    return;
+                }
+                gen[sl] = true;
+            }
+            // GEN: online softmax with a running row max (per query: both halves agree on it)
+            const float lq = l[sl] + __shfl_xor(l[sl], 32);
+            const float mloc = rowmax(s);
+            const float mnew = (lq > 0.f) ? fmaxf(m[sl], mloc) : fmaxf(mloc, -1e30f);      // nothing accumulated yet: free choice
+            const float corr = (lq > 0.f) ? __builtin_amdgcn_exp2f(m[sl] - mnew) : 1.0f;
+            m[sl] = mnew;
+            l[sl] *= corr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[sl][r] *= corr;
+            l[sl] += exp_block(s, mnew, pf0, pf1);
+        };
+        auto pv = [&](int sl, const u32x4 &v0, const u32x4 &v1, const bf16x8 &pf0, const bf16x8 &pf1) {
+            O[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O[sl], 0, 0, 0);
+            O[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O[sl], 0, 0, 0);
+        };
+
+        // S^T chain of one slab over one key block: K fragments streamed from the block's ring stage (a ds_read_b128 per MFMA;
+        // at 256 B/clk the LDS carries both slabs' reads of a block with room to spare -- keeping the nine fragments of a
+        // C = 144 block in registers for the second slab cost 36 VGPRs and spilled)
+        auto chain = [&](int blk, int sl) {
+            const unsigned char *kp = smem + (blk % NST) * CF::STAGE + koff;
+            u32x4 kf[CF::NCH];
+#pragma unroll
+            for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(kp + ch * 32);
+            f32x16 s = zero16;
+#pragma unroll
+            for (int ch = 0; ch < CF::NCH; ++ch)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ch]), __builtin_bit_cast(bf16x8, qf[sl][ch]), s, 0, 0, 0);
+            return s;
+        };
+        f32x16 sA, sB;
+        // ---- prologue: block 0 landed -> S(0, slab 0)
+        sync_block(0);
+        sA = chain(0, 0);
+
+        // one key block, generic form (any mode, masks, last block): (NS = 2) S(b, slab 1), softmax of S(b, slab 0), its PV,
+        // S(b + 1, slab 0), softmax of S(b, slab 1), its PV; (NS = 1) S(b + 1), softmax of S(b), PV
+        auto block = [&](int b, auto next_tag) {
+            constexpr bool HAS_NEXT = decltype(next_tag)::value != 0;
+            if (HAS_NEXT) sync_block(b + 1);
+            const int key0 = b * CF::BK;
+            const unsigned vb = lds0 + (unsigned)((b % NST) * CF::STAGE + vbase);
+            u32x2 vlo[2], vhi[2];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                vlo[mm] = tr_read_b64(vb, (8 * mm) * CF::RSV);
+                vhi[mm] = tr_read_b64(vb, (8 * mm + 4) * CF::RSV);
+            }
+            bf16x8 pf0, pf1;
+            if (NS == 2) sB = chain(b, NS - 1);
+            else if (HAS_NEXT) sB = chain(b + 1, 0);
+            softmax(sA, 0, key0, pf0, pf1);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]));
+            const u32x4 v0 = {vlo[0][0], vlo[0][1], vhi[0][0], vhi[0][1]};
+            const u32x4 v1 = {vlo[1][0], vlo[1][1], vhi[1][0], vhi[1][1]};
+            pv(0, v0, v1, pf0, pf1);
+            if (NS == 2) {
+                if (HAS_NEXT) sA = chain(b + 1, 0);
+                softmax(sB, NS - 1, key0, pf0, pf1);
+                pv(NS - 1, v0, v1, pf0, pf1);
+            } else if (HAS_NEXT) {
+                sA = sB;
+            }
+        };
+        // The same key block in the common case -- both slabs in FAST mode, no diagonal to mask, not the last block -- as
+        // TWO straight-line regions, so that the scheduler can be told (sched_group_barrier) to put the exponentials of one
+        // slab between the MFMAs of the other slab's chain; left to itself hipcc issues each chain as one burst and the
+        // matrix pipe idles under the softmax of the same wave.  The range test sits at the end of each region; a slab that
+        // trips it is redone in GEN mode from its intact scores and every later block takes the generic path above.
+        auto gen_fix = [&](f32x16 &s, int sl, bf16x8 &pf0, bf16x8 &pf1) {
+            gen[sl] = true;
+            const float lq = l[sl] + __shfl_xor(l[sl], 32);
+            const float mloc = rowmax(s);
+            const float mnew = (lq > 0.f) ? fmaxf(m[sl], mloc) : fmaxf(mloc, -1e30f);
+            const float corr = (lq > 0.f) ? __builtin_amdgcn_exp2f(m[sl] - mnew) : 1.0f;
+            m[sl] = mnew;
+            l[sl] *= corr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[sl][r] *= corr;
+            l[sl] += exp_block(s, mnew, pf0, pf1);
+        };
+        auto mask_diag = [&](f32x16 &s, int sl, int key0) {                     // graphs without self loops: the block on the diagonal
+            if (p.nodiag && key0 < q0[sl] + 32 && key0 + 32 > q0[sl]) {
+                asm volatile("s_nop 7\n s_nop 3" ::: "memory");      // s may come straight out of an asm MFMA chain (12 wait states; the compiler cannot know)
+                const int kbase = key0 + 16 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = (kbase + r == qidx[sl]) ? -INFINITY : s[r];
+            }
+        };
+        int b = 0;
+        if constexpr (NS == 2) {
+            // ---- fast loop (two slabs, both in FAST mode): every key block is two generated inline-asm regions
+            // (da_attn_dual_asm.inc, tools/gen_attn_dual_asm.py) on pinned registers:
+            //   R1: V fragments + K fragments of block b; chain S(b, slab 1) -> sB  ||  exp / pack / row sum of sA -> pfA
+            //   R2: PV of slab 0 (O[0] += V . pfA); chain S(b + 1, slab 0) -> sA   ||  exp / pack / row sum of sB -> pfB
+            //   PV1: O[1] += V . pfB
+            // one MFMA per slot, its K fragment's replacement three chunks ahead, two exponentials + the pack and bf16 dot-sum
+            // of the previous pair behind it.  The range test runs on the row sums after each region; a slab that trips it is
+            // redone in GEN mode from its intact scores and the generic loop below finishes the puzzle.
+            f32x16 &Oa = O[0], &Ob = O[NS - 1];
+            u32x4 pfA0, pfA1, pfB0, pfB1, vf0, vf1;
+            float accv;
+            const unsigned ones = 0x3f803f80u;
+            auto fix = [&](f32x16 &s, int sl, u32x4 &p0, u32x4 &p1) {
+                asm volatile("s_nop 7\n s_nop 3" ::: "memory");                  // the scores came out of an asm MFMA: the compiler does not know
+                bf16x8 a, c;
+                gen_fix(s, sl, a, c);
+                p0 = __builtin_bit_cast(u32x4, a);
+                p1 = __builtin_bit_cast(u32x4, c);
+            };
+            for (; b + 1 < nb; ++b) {
+                if (gen[0] || gen[1]) break;
+                const int key0 = b * CF::BK;
+                DA_DUAL_TICK(t0_);
+                sync_block(b + 1);
+                DA_DUAL_TICK(t1_);
+                unsigned kaddr = lds0 + (unsigned)((b % NST) * CF::STAGE + koff);
+                const unsigned vaddr = lds0 + (unsigned)((b % NST) * CF::STAGE + vbase);
+                mask_diag(sA, 0, key0);
+                if constexpr (C == 144) DA_DUAL_R1_C144(); else DA_DUAL_R1_C32();
+                {
+                    const float tot = l[0] + accv;
+                    if (__any(!(accv < 1.152921504606847e18f) || !(tot > 8.673617379884035e-19f))) fix(sA, 0, pfA0, pfA1);
+                    else l[0] = tot;
+                }
+                DA_DUAL_TICK(t2_);
+                mask_diag(sB, 1, key0);
+                kaddr = lds0 + (unsigned)(((b + 1) % NST) * CF::STAGE + koff);
+                if constexpr (C == 144) DA_DUAL_R2_C144(); else DA_DUAL_R2_C32();
+                {
+                    const float tot = l[1] + accv;
+                    if (__any(!(accv < 1.152921504606847e18f) || !(tot > 8.673617379884035e-19f))) fix(sB, 1, pfB0, pfB1);
+                    else l[1] = tot;
+                }
+                if constexpr (C == 144) DA_DUAL_PV1_C144(); else DA_DUAL_PV1_C32();
+                DA_DUAL_TICK(t3_);
+                DA_DUAL_DBG(c_sync += t1_ - t0_; c_r1 += t2_ - t1_; c_r2 += t3_ - t2_;)
+            }
+            asm volatile("s_nop 7\n s_nop 3" ::: "memory");                      // sA / O: last written by asm MFMAs
+        }
+        for (; b + 1 < nb; ++b) block(b, SlabTag<1>());
+        block(nb - 1, SlabTag<0>());
+
+        // ---- epilogue
+        if (FOLD) {
+            // folded value heads (softmax(QK^T)(V W^T) == (softmax(QK^T) V) W^T): CV-wide normalised rows per head, summed
+            // over heads by the tail kernel -- no skip, no activation, straight from the accumulator layout
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const float lt = l[sl] + __shfl_xor(l[sl], 32);
+                const float invf = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+                if (qidx[sl] < n_g) {
+                    bf16_t *dst = (bf16_t *)p.out + ((size_t)h * p.n_rows + node0 + qidx[sl]) * CV;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int c0 = 8 * jj + 4 * half;
+                        const bf16x4 b4 = {(__bf16)(O[sl][4 * jj] * invf), (__bf16)(O[sl][4 * jj + 1] * invf), (__bf16)(O[sl][4 * jj + 2] * invf),
+                                           (__bf16)(O[sl][4 * jj + 3] * invf)};
+                        *(u32x2 *)(dst + c0) = __builtin_bit_cast(u32x2, b4);
+                    }
+                }
+            }
+        } else {
+            // hidden layer: normalised [query][c] fp32 rows staged through LDS (the ring is free once every wave is past its
+            // last block), streamed out by all 256 threads below
+            constexpr int RSOF = CV + 4;
+            float *so = (float *)smem;
+            dma_barrier();
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const float lt = l[sl] + __shfl_xor(l[sl], 32);
+                const float inv = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+                float *orow = so + ((wid + 4 * sl) * 32 + i) * RSOF;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int c0 = 8 * jj + 4 * half;
+                    *(f32x4 *)(orow + c0) = (f32x4){O[sl][4 * jj] * inv, O[sl][4 * jj + 1] * inv, O[sl][4 * jj + 2] * inv, O[sl][4 * jj + 3] * inv};
+                }
+            }
+        }
+    };
+
+    if (two) run(SlabTag<2>());
+    else if (wave_on) run(SlabTag<1>());
+    else {
+        // no slab (tile with fewer than four): this wave only streams its share of K / V and keeps the barriers
+        sync_block(0);
+        for (int b = 0; b + 1 < nb; ++b) sync_block(b + 1);
+        if (!FOLD) dma_barrier();
+    }
+    DA_DUAL_DBG(if (p.prof && tid == 0) { DA_DUAL_TICK(t_end); unsigned long long *o = p.prof + 4 * blockIdx.x; o[0] = t_end - t_start; o[1] = c_sync; o[2] = c_r1; o[3] = c_r2; })
+    if (FOLD) return;
+    {
+        // + skip, activation, 16-byte coalesced stores of whole output rows
+        constexpr int RSOF = CV + 4;
+        static_assert(256 * RSOF * 4 <= NST * CF::STAGE, "O staging must fit in the ring");
+        const float *so = (const float *)smem;
+        dma_barrier();
+        constexpr int CPR = C / 8;                                   // 16-byte chunks per output row of this head
+        const int HC = p.H * C;
+        const int qbase = s_lo * 32;                                 // staged row (w + 4 sl) * 32 + i = query qbase + that
+        const int nq = min((s_hi - s_lo) * 32, n_g - qbase);
+        constexpr int NB = 3;
+        for (int it0 = tid; it0 < nq * CPR; it0 += 256 * NB) {
+            u32x4 skv[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int it = it0 + 256 * k;
+                if (it < nq * CPR) {
+                    const int q = it / CPR, ch = it - q * CPR;
+                    skv[k] = *(const u32x4 *)((const bf16_t *)p.S + ((size_t)node0 + qbase + q) * HC + (size_t)h * C + ch * 8);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int it = it0 + 256 * k;
+                if (it < nq * CPR) {
+                    const int q = it / CPR, ch = it - q * CPR;
+                    const float *src = so + q * RSOF + ch * 8;
+                    const f32x4 a = *(const f32x4 *)src, b2 = *(const f32x4 *)(src + 4);
+                    float v[8] = {a[0], a[1], a[2], a[3], b2[0], b2[1], b2[2], b2[3]};
+                    bf16x8 ob;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += bf2f((bf16_t)(skv[k][e] & 0xffff));
+                        v[2 * e + 1] += bf2f((bf16_t)(skv[k][e] >> 16));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ob[e] = (__bf16)apply_act(v[e], p.act);
+                    *(u32x4 *)((bf16_t *)p.out + ((size_t)node0 + qbase + q) * HC + (size_t)h * C + ch * 8) = __builtin_bit_cast(u32x4, ob);
+                }
+            }
+        }
+    }
+}
+
+template <int C, int CV, int NST, bool FOLD>
+static int launch_dual_t(AttnDualParams p, int n_graphs, int max_nodes, hipStream_t st) {
+    using CF = DualCfg<C, CV>;
+    constexpr int lds = NST * CF::STAGE;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dual<C, CV, NST, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    const int nslab = (max_nodes + 31) / 32;
+    p.nqt = (nslab + 7) / 8;
+    k_attn_dual<C, CV, NST, FOLD><<<p.nqt * p.H * n_graphs, 256, lds, st>>>(p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// bf16, complete graphs, Q pre-scaled by log2(e) / sqrt(C).  Returns 0 = launched, -1 = shape not covered.
+int launch_attn_dual(const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes, const int32_t *graph_ptr,
+                     const int32_t *pad_ptr, int nodiag, int act, void *out, const DenseFold *fold, hipStream_t st) {
+    if (heads != 8) return -1;
+    AttnDualParams p;
+    p.Q = L.Q; p.K = L.K; p.V = L.Vt; p.S = L.S; p.out = fold ? fold->out : out;
+    p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.nqt = 0; p.act = act; p.nodiag = nodiag;
+    p.n_rows = fold ? fold->n_rows : 0;
+    { const char *e = getenv("DA_DUAL_STAGGER"); p.stagger = e ? atoi(e) : 0; e = getenv("DA_DUAL_STAGGER_SHIFT"); p.stagger_shift = e ? atoi(e) : 0; }
+    { const char *e = getenv("DA_DUAL_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
+    if (n_graphs <= 0 || max_graph_nodes <= 0) return 0;
+    if (fold && C == 144 && fold->cv == 32) return launch_dual_t<144, 32, 6, true>(p, n_graphs, max_graph_nodes, st);
+    if (!fold && C == 32) return launch_dual_t<32, 32, 8, false>(p, n_graphs, max_graph_nodes, st);
+    return -1;
+}
+
+}  // namespace da

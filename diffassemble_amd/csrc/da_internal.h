@@ -96,6 +96,7 @@ struct QkvScatter {            // where the fused projection scatters its four c
 struct DenseLayout {
     const void *Q, *K, *Vt, *S;
     int n_pad;
+    int q_prescaled = 0;       // Q rows already carry log2(e) / sqrt(C) (projection weights scaled at pack time, da_api.hip ConvW::wd)
 };
 int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
                      int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st, int ldw = 0,
@@ -113,6 +114,9 @@ struct DenseFold {             // value heads folded with the next linear layer:
 int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes,
                       const int32_t *graph_ptr, const int32_t *pad_ptr, int nodiag, const void *res, int act,
                       void *out, hipStream_t st, const DenseMask *mk = nullptr, const DenseFold *fold = nullptr);
+// da_attn_dual.hip: bf16, complete graphs, two query slabs per wave; Q must arrive pre-scaled by log2(e) / sqrt(C)
+int launch_attn_dual(const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes, const int32_t *graph_ptr,
+                     const int32_t *pad_ptr, int nodiag, int act, void *out, const DenseFold *fold, hipStream_t st);
 // hybrid mode: the rows the masked kernel does not own (virtual nodes) over their remainder edges
 int launch_attn_csr_cont(int prec, int n_nodes, int n_real, const int32_t *irr_row_ptr, const int32_t *irr_col_src,
                          const int32_t *row_map, int heads, int C, int n_pad, const DenseLayout &L,

@@ -237,6 +237,13 @@ def _irregular_csr(isrc, idst, n_nodes):
     return irr_ptr.to(torch.int32), isrc[order].to(torch.int32).contiguous()
 
 
+def _hybrid_worth_it(n_max, n_reg, n_edges, pairs):
+    """ONE predicate for both entry points (build_plan on an edge list, expander_plan in closed form): the masked matrix-core
+    attention pays when the graphs are big (>= 256 nodes), the regular edges (unique real -> real pairs inside a graph) are
+    at least half of all edges and at least 3 % of the (target, source) pairs."""
+    return n_max >= 256 and n_reg >= 0.5 * n_edges and n_reg >= 0.03 * pairs
+
+
 def _hybrid_split(real_ei, virt_ei, batch, counts, graph_ptr, padded, n_nodes, N, force):
     """Split the edge list into (a) "regular" edges -- both ends real, same graph, the pair occurs once --
     stored as one adjacency bit per (target, source) pair, and (b) everything else as CSR by destination
@@ -265,7 +272,7 @@ def _hybrid_split(real_ei, virt_ei, batch, counts, graph_ptr, padded, n_nodes, N
     n_reg = int(regular.sum())
     E = E0 + (virt_ei.shape[1] if virt_ei is not None else 0)
     pairs = int(pbase[-1])
-    if not force and not (int(counts.max()) >= 256 and n_reg >= 0.5 * E and n_reg >= 0.03 * pairs):
+    if not force and not _hybrid_worth_it(int(counts.max()), n_reg, E, pairs):
         return dict(hybrid=0)
     n0 = int(counts[0])
     if bool((counts == n0).all()):
@@ -311,7 +318,7 @@ def expander_plan(perms, degree, batch_device=None, virt_nodes=0):
     mode = _hybrid_mode()
     n_virt_edges = (N + G * V * (n + V)) if V > 0 else 0
     E = N * d + n_virt_edges
-    if not dup_free or mode == "off" or not (n >= 256 and d * n >= 0.03 * n * n or mode == "force"):
+    if not dup_free or mode == "off" or not (_hybrid_worth_it(n, N * d, E, G * n * n) or mode == "force"):
         batch = torch.arange(G, device=dev).repeat_interleave(n)
         return build_plan(edge_list(), batch, V)                          # generic route (multi-edges, tiny graphs, ...)
     # everything but the adjacency bits depends on the Batch SHAPE only: built once per (G, n, V, device)

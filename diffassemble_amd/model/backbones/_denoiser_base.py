@@ -113,7 +113,7 @@ class DenoiserBase(nn.Module):
             from ...graph_plan import build_plan
             self._tplan = build_plan(edge_index.to(te.device), batch.to(te.device), te.virt_nodes).with_source_csr()
             self._tplan_key = _Held((edge_index, batch), (id(te),))
-        out = DenoiserTrainFn.apply(te, self._tplan, xy_pos, time, feats, *te.params)
+        out = DenoiserTrainFn.apply(te, self._tplan, xy_pos, time, feats, te.anchor)
         return out, None
 
     @torch.no_grad()

@@ -20,19 +20,21 @@ from ...encoder import EncoderEngine
 
 
 class _EncoderTrainFunction(torch.autograd.Function):
-    """patch_feats = encoder(patches) in train() mode.  The parameters are passed so that the output joins the autograd
-    graph; their gradients are ADDED into ``param.grad`` by the engine, so ``None`` is returned for them (and for the
-    pixels).  One forward must be followed by its backward before the next forward (the engine owns the activations)."""
+    """patch_feats = encoder(patches) in train() mode.  Parameter gradients are ADDED into ``param.grad`` by the engine;
+    autograd only sees the ``anchor`` (one small parameter, zero gradient returned) so that the output joins the graph and
+    a DistributedDataParallel wrapper's reducer gets the one hook it needs to close its iteration (see
+    ``diffassemble_amd.train.DenoiserTrainFn``).  One forward must be followed by its backward before the next forward
+    (the engine owns the activations)."""
 
     @staticmethod
-    def forward(ctx, eng, patches, *params):
-        ctx.eng, ctx.n_params = eng, len(params)
+    def forward(ctx, eng, patches, anchor):
+        ctx.eng, ctx.anchor_shape = eng, anchor.shape
         return eng.forward(patches).clone()
 
     @staticmethod
     def backward(ctx, d_feats):
         ctx.eng.backward(d_feats)
-        return (None, None) + (None,) * ctx.n_params
+        return None, None, torch.zeros(ctx.anchor_shape, dtype=torch.float32, device=d_feats.device)
 
 
 class _GConv(nn.Module):
@@ -117,7 +119,8 @@ class ResNet(nn.Module):
                 from ...encoder_train import EncoderTrainEngine
                 self._train_engine = EncoderTrainEngine(self, patch_rgb.device, precision=self.train_precision)
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                return _EncoderTrainFunction.apply(self._train_engine, patch_rgb, *self.parameters())
+                anchor = min((p for p in self.parameters() if p.requires_grad), key=lambda p: p.numel())
+                return _EncoderTrainFunction.apply(self._train_engine, patch_rgb, anchor)
             return self._train_engine.forward(patch_rgb).clone()           # frozen (no_grad) encoder in train mode
         return self.engine().forward(patch_rgb)
 

@@ -26,6 +26,19 @@ def extract_rot(a, t, x_shape):
     return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
 
 
+def _metric_was_updated(m):
+    """True when a MeanMetric has seen at least one update since its last reset -- for torchmetrics' class
+    (``update_called`` / ``_update_count``) and for the stand-in of this package (``count``) alike."""
+    for attr in ("update_called", "_update_called"):
+        v = getattr(m, attr, None)
+        if isinstance(v, bool):
+            return v
+    v = getattr(m, "_update_count", None)
+    if v is not None:
+        return int(v) > 0
+    return float(getattr(m, "count", 0)) > 0
+
+
 class GNN_Diffusion(LightningModule):
     def __init__(self, steps=600, inference_ratio=1, sampling="DDPM", learning_rate=1e-4,
                  save_and_sample_every=1000, classifier_free_prob=0, classifier_free_w=0, noise_weight=0.0,
@@ -194,8 +207,9 @@ class GNN_Diffusion(LightningModule):
                 for k, v in vals.items():
                     if f"{k}_{cat}" in self.metrics:
                         self.metrics[f"{k}_{cat}"].update(v)
-        if hasattr(self, "metrics"):
-            self.log_dict({k: m.compute() for k, m in self.metrics.items()})
+        # (the step only UPDATES the per-category metrics; they are computed, logged and reset once per epoch in
+        # validation_epoch_end -- computing them here would log a batch-weighted mean of running means and, under DDP,
+        # trigger one metric sync per category per step)
         return final_pos
 
     def validation_step(self, batch, batch_idx):
@@ -217,11 +231,13 @@ class GNN_Diffusion(LightningModule):
         (Lightning does that for logged Metric objects at epoch end)."""
         if not hasattr(self, "metrics"):
             return
+        seen = {}
         for k in ("rmse_t", "rmse_r", "gd_r", "part_acc"):
             for name, m in self.metrics.items():
-                if name.startswith(k + "_") and getattr(m, "count", 1):
-                    self.avg_metrics[f"{k}_AVG"].update(float(m.compute()))
-        self.log_dict({k: m.compute() for k, m in self.avg_metrics.items()})
+                if name.startswith(k + "_") and _metric_was_updated(m):        # categories without a sample stay out of the averages
+                    seen[name] = m.compute()
+                    self.avg_metrics[f"{k}_AVG"].update(float(seen[name]))
+        self.log_dict({**seen, **{k: m.compute() for k, m in self.avg_metrics.items() if _metric_was_updated(m)}})
         for m in list(self.metrics.values()) + list(self.avg_metrics.values()):
             m.reset()
 

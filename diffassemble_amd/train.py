@@ -85,6 +85,8 @@ class TrainEngine:
         self.gw = self._weights_struct(dict(zip(names, self.grad_views)))
         self._ws = None
         self._ws_key = None
+        # the one parameter autograd sees (DenoiserTrainFn): the smallest trainable tensor
+        self.anchor = min((p for p in self.params if p.requires_grad), key=lambda p: p.numel(), default=self.params[0])
         self.version = 0              # bumped by every raw-pointer update of ``flat`` (FusedAdafactor.step)
         self.grads_synced = False     # True between sync_gradients() and the next backward
 
@@ -176,25 +178,34 @@ class TrainEngine:
 
 
 class DenoiserTrainFn(torch.autograd.Function):
-    """out = Eff_GAT.forward_with_feats(x, t, feats) with the backward in the HIP library.  The
-    parameters are passed so that ``out`` joins the autograd graph; their gradients are written
-    straight into ``TrainEngine.flat_grad`` (aliased by ``param.grad``), so ``None`` is returned for
-    them.  One forward must be followed by its backward before the next forward (shared workspace)."""
+    """out = Eff_GAT.forward_with_feats(x, t, feats) with the backward in the HIP library.  Parameter gradients are
+    written straight into ``TrainEngine.flat_grad`` (aliased by ``param.grad``), not returned to autograd.
+
+    ONE parameter -- the ``anchor`` (the engine's smallest tensor) -- is passed as an autograd input and receives a ZERO
+    gradient tensor (its real gradient went into its ``flat_grad`` slot like everybody else's, so ``grad += 0`` changes
+    nothing).  Reason: a ``torch.nn.parallel.DistributedDataParallel`` wrapper (what ``pl.Trainer(strategy="ddp")``
+    builds, train_script.py:215-218) only finishes an iteration when at least one of its autograd hooks fires.  With the
+    anchor the reducer sees one used parameter (whose bucket it averages -- harmless, the fused exchange averages the same
+    slot again) and, under ``find_unused_parameters=True``, classifies every other parameter as unused on all ranks and
+    leaves its ``.grad`` alone; ``GNN_Diffusion.on_before_optimizer_step`` then does the one fused all-reduce.  With
+    ``find_unused_parameters=False`` torch raises "Expected to have finished reduction in the prior iteration" on the
+    second iteration (tests/test_gpu_train.py::test_real_ddp_wrapper_*).
+    One forward must be followed by its backward before the next forward (shared workspace)."""
 
     @staticmethod
-    def forward(ctx, eng, plan, x, t, feats, *params):
+    def forward(ctx, eng, plan, x, t, feats, anchor):
         out = eng.forward(plan, x, t, feats)
         ctx.eng, ctx.plan = eng, plan
         ctx.want_dfeats = bool(feats.requires_grad)
         ctx.save_for_backward(x, t)
-        ctx.n_params = len(params)
+        ctx.anchor_shape = anchor.shape
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         x, t = ctx.saved_tensors
         d_feats = ctx.eng.backward(ctx.plan, x, t, d_out, ctx.want_dfeats)
-        return (None, None, None, None, d_feats) + (None,) * ctx.n_params
+        return None, None, None, None, d_feats, torch.zeros(ctx.anchor_shape, dtype=torch.float32, device=d_out.device)
 
 
 class FusedAdafactor(torch.optim.Optimizer):
@@ -365,9 +376,25 @@ class HybridAdafactor(torch.optim.Optimizer):
                 "param_groups": super().state_dict()["param_groups"], "state": {}}
 
     def load_state_dict(self, sd):
-        self.fused.load_state_dict(sd["fused"])
-        if self.rest is not None and sd.get("rest") is not None:
-            self.rest.load_state_dict(sd["rest"])
+        """Accepts its own layout ({"fused", "rest"}) and a PLAIN transformers-Adafactor state dict over the same parameter
+        list (a run started with DIFFASSEMBLE_FUSED_OPTIMIZER=0, or the reference's own checkpoint): the entries are routed
+        to the fused / remaining halves by the parameter's index in ``Adafactor(self.parameters())`` order."""
+        if "fused" in sd:
+            self.fused.load_state_dict(sd["fused"])
+            if self.rest is not None and sd.get("rest") is not None:
+                self.rest.load_state_dict(sd["rest"])
+            return
+        state = sd.get("state", {})
+        allp = [q for g in self.param_groups for q in g["params"]]
+        pos = {id(p): i for i, p in enumerate(allp)}
+        get = lambda i: state.get(i, state.get(str(i)))  # noqa: E731
+        f_idx = {id(p): i for i, p in enumerate(q for g in self.fused.param_groups for q in g["params"])}
+        self.fused.load_state_dict({"state": {f_idx[id(p)]: get(pos[id(p)]) for p in allp if id(p) in f_idx and get(pos[id(p)]) is not None}})
+        if self.rest is not None:
+            rest_params = [q for g in self.rest.param_groups for q in g["params"]]
+            rsd = self.rest.state_dict()
+            rsd["state"] = {i: get(pos[id(p)]) for i, p in enumerate(rest_params) if get(pos[id(p)]) is not None}
+            self.rest.load_state_dict(rsd)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -51,7 +51,7 @@ typedef struct da_weights {
     int32_t variant;      /* DA_VARIANT_*                                                  */
     int32_t arch;         /* DA_ARCH_*                                                     */
     int32_t steps;        /* rows of time_emb                                              */
-    int32_t c_in;         /* pose channels in: 2 | 4 (2D), 7 (3D)                          */
+    int32_t c_in;         /* pose channels in: 2 | 4 (2D), 7 (3D); 1 <= c_in <= 8, checked by da_denoiser_create */
     int32_t c_out;        /* pose channels out: 2 | 4 (2D); 3D heads are 3 + 3             */
     int32_t feat_dim;     /* piece-feature width F: 1088 (2D) / 768 (3D vn_dgcnn)          */
     int32_t hidden;       /* mlp hidden width: 128 (2D) / 256 (3D)                         */

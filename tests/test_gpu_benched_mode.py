@@ -29,7 +29,8 @@ from oracle import diffusion as ODF
 from oracle import weights as W
 
 pytestmark = pytest.mark.gpu
-RTOL32, ELEM32, TRAJ32, RTOLBF = 1e-4, 1e-3, 5e-4, 4e-2
+RTOL32, ELEM32, TRAJ32 = 1e-4, 1e-3, 5e-4
+RTOLBF = float(os.environ.get('DA_TEST_RTOLBF', 4e-2))
 
 
 def rel(a, b):
@@ -164,6 +165,71 @@ def test_bf16_full_loop_drift_vs_fp32(dev, n, G):
           f"last {float(per_step[-1]):.3e}, final max-abs drift {float((a[-1] - b[-1]).abs().max()):.3e}")
     assert float(per_step.max()) < RTOLBF
     assert float(per_step[-1]) < 2e-2
+
+
+def test_bf16_full_loop_drift_config3_exophormer_hybrid(dev):
+    """BASELINE config 3 in its benched mode: exophormer arch, V = 8 virtual nodes, two 900-piece
+    Exphander graphs of the scripted degree d = 539 (hybrid path: adjacency-masked matrix-core attention + CSR remainder),
+    T = 100 DDIM steps, bf16 against the fp32 HIP trajectory (which `test_exo900_d539_forward_vs_reference_fixture` ties to
+    the reference): per-step drift relative to the step's max-abs pose, and the decisions a solved puzzle is judged by --
+    greedy grid assignment and rotation quadrant -- compared piece by piece."""
+    import numpy as np
+    from diffassemble_amd import DenoiserEngine, Schedule, _lib, expander
+    n, G, d, V = 900, 2, 539, 8
+    sd = W.make_denoiser_state(100, 4, 4, arch="exophormer", virt_nodes=V, seed=43, qk_gain=3.0)
+    x, feats = W.make_inputs(G * n, 4, 1088, 43)
+    perms = expander.draw_permutations(n, G, np.random.default_rng(11)).to(dev)
+    sch = Schedule(ODF.make_schedule(100), dev)
+    trajs = {}
+    for prec in ("fp32", "bf16"):
+        eng = DenoiserEngine(sd, arch="exophormer", virt_nodes=V, precision=prec, device=dev)
+        plan = eng.plan_expander(perms, d)
+        assert plan.hybrid, "config 3 is benched on the hybrid path"
+        traj, _ = eng.sample_loop(plan, sch, x.to(dev), feats.to(dev), ratio=1, mean_type=_lib.MEAN_START_X, use_graph=True)
+        trajs[prec] = traj.clone()
+    a, b = trajs["bf16"].double(), trajs["fp32"].double()
+    assert torch.isfinite(a).all()
+    per_step = (a - b).abs().amax((1, 2)) / b.abs().amax((1, 2))
+    print(f"bf16 loop drift config 3 (exophormer d=539 V=8, hybrid): max over steps {float(per_step.max()):.3e}, first "
+          f"{float(per_step[0]):.3e}, last {float(per_step[-1]):.3e}, final max-abs drift {float((a[-1] - b[-1]).abs().max()):.3e}")
+    assert float(per_step.max()) < 1.2e-2          # measured 4e-3 (DESIGN 4): 3x head-room, not 10x
+    # rotation quadrant of every piece (cos, sin -> nearest of the four turns) identical
+    qa = torch.atan2(a[-1][:, 3], a[-1][:, 2]).div(np.pi / 2).round().remainder(4)
+    qb = torch.atan2(b[-1][:, 3], b[-1][:, 2]).div(np.pi / 2).round().remainder(4)
+    margin = (torch.atan2(b[-1][:, 3], b[-1][:, 2]).div(np.pi / 2) - qb).abs()         # distance to the quadrant centre, in quarter turns
+    decided = margin < 0.4                                                               # (an untrained model sits near boundaries)
+    assert bool((qa[decided] == qb[decided]).all())
+
+
+def test_bf16_full_loop_drift_config4_3d(dev):
+    """BASELINE config 4 in its benched mode: 3D fragments (P = 20 per object, D = 832, SE(3) head), T = 300 / ratio 10
+    = 30 DDIM steps, 16 objects, bf16 against the fp32 HIP trajectory (tied to the reference by test_ddim_3d_loop): the
+    translations by max-abs drift, the rotations by GEODESIC ANGLE between the two unit quaternions (q and -q are one
+    rotation) -- the quantity the quaternion / so3_scale algebra of k_ddim3d could amplify."""
+    from diffassemble_amd import DenoiserEngine, Schedule, _lib
+    P, G = 20, 16
+    sd = W.make_denoiser_state(300, 7, None, D=832, hidden=256, variant="3d", seed=44, qk_gain=2.0)
+    x, feats = W.make_inputs(G * P, 7, 768, 44)
+    x[:, :4] = 0.0
+    x[:, 0] = 1.0                                       # identity rotations + random translations (...double_diffusion.py:697-710)
+    ei, batch = W.collate([W.dense_edge_index(P, True)] * G, [P] * G)
+    sch = Schedule(ODF.make_schedule(300), dev)
+    trajs = {}
+    for prec in ("fp32", "bf16"):
+        eng = DenoiserEngine(sd, variant="3d", precision=prec, device=dev)
+        plan = eng.plan(ei, batch)
+        traj, _ = eng.sample_loop(plan, sch, x.to(dev), feats.to(dev), ratio=10, mean_type=_lib.MEAN_START_X, use_graph=True)
+        trajs[prec] = traj.clone()
+    a, b = trajs["bf16"].double(), trajs["fp32"].double()
+    assert torch.isfinite(a).all() and a.shape[0] == 30
+    dt = (a[..., 4:] - b[..., 4:]).abs().amax((1, 2)) / b[..., 4:].abs().amax((1, 2))
+    qa, qb = F.normalize(a[..., :4], dim=-1), F.normalize(b[..., :4], dim=-1)
+    ang = 2 * torch.acos((qa * qb).sum(-1).abs().clamp(max=1.0))                     # geodesic angle, radians, per step per fragment
+    print(f"bf16 loop drift config 4 (3D, T=300/10): translation max over steps {float(dt.max()):.3e} (last {float(dt[-1]):.3e}); "
+          f"rotation geodesic max {float(ang.max()):.3e} rad (last step max {float(ang[-1].max()):.3e}, mean {float(ang[-1].mean()):.3e})")
+    assert float(dt.max()) < 2e-2
+    assert float(ang.max()) < 5e-2                      # < 3 degrees at every step of every fragment
+    assert float((a[..., :4].norm(dim=-1) - 1).abs().max()) < 1e-3      # quaternions stay unit
 
 
 FEAT_NOISE = 0.1          # std of the non-pose feature columns (probe: tests/tools/train_solver_probe.py)

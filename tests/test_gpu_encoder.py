@@ -301,3 +301,56 @@ def test_full_size_properties(dev):
     idx = torch.arange(0, n, 1901, device=dev)
     ref = OE.visual_features(sd, x[idx].cpu())
     assert rel(a[idx].float(), ref) < RTOLBF
+
+
+def test_hybrid_adafactor_resumes_from_a_plain_adafactor_checkpoint(dev):
+    """a run started with DIFFASSEMBLE_FUSED_OPTIMIZER=0 (transformers' Adafactor over self.parameters(), what
+    the reference's checkpoints hold) must be resumable with the fused / hybrid optimizer: same parameter order, same
+    per-parameter state layout.  One step each from the same loaded statistics gives the same weights."""
+    import copy
+    from transformers.optimization import Adafactor
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    T, n = 100, 36
+    torch.manual_seed(0)
+
+    def build():
+        m = GNN_Diffusion(steps=T, sampling="DDIM", rotation=True, model_mean_type=ModelMeanType.EPSILON,
+                          visual_pretrained=False, backbone="resnet18equiv", freeze_backbone=False)
+        dsd, esd = W.make_denoiser_state(T, 4, 4, seed=35), W.make_encoder_state(35)
+        m.model.load_state_dict({**dsd, **{"visual_backbone." + k: v for k, v in esd.items()}}, strict=False)
+        m = m.to(dev).train()
+        m.model.precision = "fp32"
+        return m
+
+    rng = np.random.default_rng(9)
+    x0 = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32)).to(dev)
+    noise = torch.from_numpy(rng.standard_normal((n, 4)).astype(np.float32)).to(dev)
+    t = torch.full((n,), 31, dtype=torch.int64, device=dev)
+    patches = W.make_patches(n, 9).to(dev)
+    ei, batch = W.dense_edge_index(n, True).to(dev), torch.zeros(n, dtype=torch.int64, device=dev)
+
+    def step(m, opt):
+        opt.zero_grad()
+        m.p_losses(x0, t, noise=noise, loss_type="huber", cond=patches, edge_index=ei, batch=batch).backward()
+        opt.step()
+
+    ma = build()
+    plain = Adafactor(ma.parameters())
+    ma.model.train_engine(dev)                         # flat buffers bound before the first step (as configure_optimizers does)
+    step(ma, plain)
+    step(ma, plain)
+    sd = copy.deepcopy(plain.state_dict())
+    weights = {k: v.detach().clone() for k, v in ma.state_dict().items()}
+    step(ma, plain)                                    # the run that kept going
+    after_plain = {k: v.detach().clone() for k, v in ma.model.named_parameters()}
+
+    mb = build()
+    mb.load_state_dict(weights)
+    opt = mb.configure_optimizers()
+    assert type(opt).__name__ == "HybridAdafactor"
+    opt.load_state_dict(sd)                            # plain layout: no "fused" / "rest" keys
+    assert opt.fused.step_count == 2
+    step(mb, opt)
+    for k, v in mb.model.named_parameters():
+        if v.requires_grad and after_plain[k].abs().max() > 0:
+            assert rel(v, after_plain[k]) < 2e-5, k

@@ -17,7 +17,8 @@ from oracle import pyg_restatement as R
 from oracle import weights as W
 
 pytestmark = pytest.mark.gpu
-RTOL32, TRAJ32, RTOLBF = 1e-4, 5e-4, 4e-2
+RTOL32, TRAJ32 = 1e-4, 5e-4
+RTOLBF = float(__import__('os').environ.get('DA_TEST_RTOLBF', 4e-2))
 
 
 def rel(a, b):

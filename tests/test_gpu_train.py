@@ -441,3 +441,93 @@ def test_data_parallel_training_from_pixels_averages_encoder_gradients(dev):
     assert float((ret["synced_0"] - mean).abs().max()) <= 1e-6 * float(mean.abs().max())
     assert not torch.equal(ret["local_0"], ret["local_1"])
     assert torch.equal(ret["enc_0"], ret["enc_1"]) and torch.equal(ret["den_0"], ret["den_1"])
+
+
+# ---------------------------------------------------------------------------- a REAL DistributedDataParallel wrapper
+class _StepWrapper(torch.nn.Module):
+    """What Lightning's DDP strategy hands to DistributedDataParallel (train_script.py:215-218, strategy="ddp"): a thin
+    module whose forward() is the LightningModule's training_step / p_losses."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **k):
+        return self.module.p_losses(*a, **k)
+
+
+def _ddp_wrapper_worker(rank, world, port, find_unused, ret):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DIFFASSEMBLE_FUSED_OPTIMIZER="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import cases as CC
+    from diffassemble_amd import sharding as S
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    dev = torch.device("cuda:0")
+    spec = CC.by_name("rot144_g2_sharp")
+    case = CC.build_case(spec)
+    m = GNN_Diffusion(steps=spec["steps"], sampling="DDIM", rotation=True, visual_pretrained=False,
+                      model_mean_type=ModelMeanType.EPSILON)
+    m.model.load_state_dict(case["sd"], strict=False)
+    m = m.to(dev).train()
+    opt = m.configure_optimizers()
+    te = m.model.train_engine()
+    try:
+        ddp = torch.nn.parallel.DistributedDataParallel(_StepWrapper(m), device_ids=[0], find_unused_parameters=find_unused)
+        g = torch.Generator().manual_seed(5)
+        noise = torch.randn(case["x"].shape, generator=g)
+        x, feats, ei, batch, lo, hi = S.shard_batch(case["x"], case["feats"], case["edge_index"], case["batch"], rank, world)
+        for step in range(3):
+            opt.zero_grad()
+            loss = ddp(x.to(dev), case["t"][lo:hi].to(dev), noise=noise[lo:hi].to(dev), loss_type="huber", cond=None,
+                       edge_index=ei.to(dev), batch=batch.to(dev), patch_feats=feats.to(dev))
+            loss.backward()
+            m.on_before_optimizer_step(opt)              # Lightning's hook: the fused exchange (exactly once per step)
+            if step == 0:
+                ret[f"grad_{find_unused}_{rank}"] = te.flat_grad.detach().cpu()
+            opt.step()
+        torch.cuda.synchronize()
+        ret[f"flat_{find_unused}_{rank}"] = te.flat.detach().cpu()
+        ret[f"err_{find_unused}_{rank}"] = ""
+    except Exception as e:  # noqa: BLE001
+        ret[f"err_{find_unused}_{rank}"] = f"{type(e).__name__}: {e}"
+    dist.destroy_process_group()
+
+
+def test_real_ddp_wrapper_two_ranks(dev):
+    """torch's own DistributedDataParallel around the module (what pl.Trainer(strategy="ddp")
+    builds, train_script.py:215-218), two ranks, three optimizer steps.  The HIP backward hands autograd REAL gradient
+    tensors for the denoiser parameters only when a reducer is listening (see DenoiserTrainFn), so under the wrapper the
+    replicas must end bit-identical and equal to the single-process full-batch run -- with find_unused_parameters=True (the
+    dead linear1 / linear2 of the reference never receive a gradient) -- and the exchange must not happen twice."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ddp_wrapper_worker, args=(2, 29581, True, ret), nprocs=2, join=True)
+    assert ret["err_True_0"] == "" and ret["err_True_1"] == "", (ret["err_True_0"], ret["err_True_1"])
+    mp.spawn(_dp_train_worker, args=(1, 29583, ret), nprocs=1, join=True)                # the full batch in one process
+    a, b, full = ret["flat_True_0"], ret["flat_True_1"], ret["flat1_0"]
+    assert torch.equal(a, b), "replicas under the DDP wrapper diverged"
+    keep = torch.ones_like(full, dtype=torch.bool)
+    for off, n in ret["noise_slots"]:
+        keep[off:off + n] = False
+    g2, g1 = ret["grad_True_0"][keep], ret["grad1_0"][keep]
+    assert float((g2 - g1).abs().max() / g1.abs().max()) < 1e-5, "gradient under the wrapper != full-batch gradient (reduced twice?)"
+    assert rel(a[keep], full[keep]) < 2e-4
+
+
+def test_real_ddp_wrapper_without_find_unused_parameters_fails_loudly(dev):
+    """find_unused_parameters=False: the reference's dead parameters (efficient_gat.py:105-107) never get a gradient, so
+    torch's reducer raises on the second iteration -- the documented loud failure, not a silent hang."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ddp_wrapper_worker, args=(2, 29585, False, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert "Expected to have finished reduction" in ret[f"err_False_{r}"], ret[f"err_False_{r}"]

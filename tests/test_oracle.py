@@ -58,6 +58,69 @@ def test_segment_softmax_multi_edges_and_isolated_nodes():
     assert abs(float(a[3, 0]) - 1.0) < 1e-6
 
 
+@pytest.mark.parametrize("n,d,H,C", [(64, 6, 8, 32), (90, 17, 8, 144)])
+def test_transformer_conv_equals_masked_sdpa_on_a_random_expander(n, d, H, C):
+    """Independent check of the restated scatter arithmetic on a SPARSE simple graph: on a random
+    d-regular expander (the reference's generator: no multi-edges, no self loops) TransformerConv must equal dense
+    attention restricted by the adjacency matrix -- F.scaled_dot_product_attention(attn_mask = adj) shares no code with
+    segment_softmax / index_add.  Odd d exercises the perfect-matching edges of the generator."""
+    import numpy as np
+    torch.manual_seed(3)
+    Din = 48
+    x = torch.randn(n, Din)
+    ws = [torch.randn(H * C, Din) / math.sqrt(Din) for _ in range(4)]
+    bs = [torch.randn(H * C) * 0.1 for _ in range(4)]
+    ei = W.random_regular_edge_index(n, d, np.random.default_rng(5))
+    adj = torch.zeros(n, n, dtype=torch.bool)
+    adj[ei[1], ei[0]] = True                                   # row = target (query), column = source (key)
+    assert int(adj.sum()) == ei.shape[1] == n * d, "simple graph expected: every edge a distinct (target, source) pair"
+    out, alpha = R.transformer_conv(x, ei, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], ws[3], bs[3], H)
+    q = F.linear(x, ws[0], bs[0]).view(n, H, C).transpose(0, 1)
+    k = F.linear(x, ws[1], bs[1]).view(n, H, C).transpose(0, 1)
+    v = F.linear(x, ws[2], bs[2]).view(n, H, C).transpose(0, 1)
+    ref = F.scaled_dot_product_attention(q, k, v, attn_mask=adj[None]).transpose(0, 1).reshape(n, H * C) + F.linear(x, ws[3], bs[3])
+    assert rel_err(out, ref) < 1e-5
+    # the per-edge weights are the masked softmax's entries
+    p_full = torch.softmax((q @ k.transpose(1, 2) / math.sqrt(C)).masked_fill(~adj[None], float("-inf")), -1)     # [H, n, n]
+    assert torch.allclose(alpha, p_full[:, ei[1], ei[0]].t(), atol=1e-6)
+
+
+def test_transformer_conv_multi_edges_and_isolated_nodes_vs_fp64_loop():
+    """Multi-edges count once per occurrence, isolated targets get only their skip term, the 1e-16 sits in the
+    denominator: a plain fp64 per-node loop (no scatter, no segment ops) is the independent statement."""
+    torch.manual_seed(4)
+    n, H, C, Din = 7, 8, 32, 16
+    x = torch.randn(n, Din)
+    ws = [torch.randn(H * C, Din) / math.sqrt(Din) for _ in range(4)]
+    bs = [torch.randn(H * C) * 0.1 for _ in range(4)]
+    #            duplicated 1->0 three times, a self loop on 2, nodes 4 and 6 isolated as targets, 5 -> 3 twice
+    src = torch.tensor([1, 1, 1, 2, 3, 2, 0, 5, 5, 6, 4])
+    dst = torch.tensor([0, 0, 0, 0, 1, 2, 2, 3, 3, 5, 5])
+    ei = torch.stack([src, dst])
+    out, alpha = R.transformer_conv(x, ei, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], ws[3], bs[3], H)
+    xd = x.double()
+    q = F.linear(xd, ws[0].double(), bs[0].double()).view(n, H, C)
+    k = F.linear(xd, ws[1].double(), bs[1].double()).view(n, H, C)
+    v = F.linear(xd, ws[2].double(), bs[2].double()).view(n, H, C)
+    ref = F.linear(xd, ws[3].double(), bs[3].double()).view(n, H, C).clone()
+    aref = torch.zeros(ei.shape[1], H, dtype=torch.float64)
+    for i in range(n):
+        es = [e for e in range(ei.shape[1]) if int(dst[e]) == i]
+        if not es:
+            continue
+        for h in range(H):
+            sc = torch.stack([(q[i, h] * k[int(src[e]), h]).sum() / math.sqrt(C) for e in es])
+            w = torch.exp(sc - sc.max())
+            w = w / (w.sum() + 1e-16)
+            for e, we in zip(es, w):
+                ref[i, h] += we * v[int(src[e]), h]
+                aref[e, h] = we
+    assert rel_err(out, ref.reshape(n, H * C).float()) < 1e-5
+    assert torch.allclose(alpha.double(), aref, atol=1e-6)
+    for i in (4, 6):                                            # isolated targets: skip term only
+        assert torch.allclose(out[i], F.linear(x[i], ws[3], bs[3]), atol=1e-6)
+
+
 def test_quaternion_roundtrip():
     torch.manual_seed(1)
     q = F.normalize(torch.randn(64, 4), dim=-1)
