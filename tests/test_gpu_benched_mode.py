@@ -11,8 +11,8 @@
 * greedy assignment against the reference's TorchScript function.
 
 Tolerances:  RTOL32 = 1e-4 norm-wise (max-abs error / max-abs of the reference tensor) and ELEM32 = 1e-3 element-wise
-relative on every element whose magnitude is at least 5 % of the tensor's max-abs (fp32 parity mode); RTOLBF = 4e-2
-norm-wise for single bf16 forwards; loop drift bounds are stated in the tests.
+relative on every element whose magnitude is at least 5 % of the tensor's max-abs (fp32 parity mode); RTOLBF = 8e-3
+norm-wise for single bf16 forwards (2.6x the largest measured error, 3.1e-3); loop drift bounds are stated in the tests.
 """
 import os
 import subprocess
@@ -30,7 +30,7 @@ from oracle import weights as W
 
 pytestmark = pytest.mark.gpu
 RTOL32, ELEM32, TRAJ32 = 1e-4, 1e-3, 5e-4
-RTOLBF = float(os.environ.get('DA_TEST_RTOLBF', 4e-2))
+RTOLBF = float(os.environ.get('DA_TEST_RTOLBF', 8e-3))
 
 
 def rel(a, b):
@@ -144,7 +144,7 @@ def test_exo900_d539_forward_vs_reference_fixture(dev, golden2, monkeypatch, pre
 def test_bf16_full_loop_drift_vs_fp32(dev, n, G):
     """100 DDIM steps (T = 100, ratio 1, START_X, noise_weight 1) in the benched bf16 mode against the fp32 HIP
     trajectory (which the fixtures pin to the reference at 5e-4): the drift of EVERY step's poses, relative to that
-    step's max-abs pose, stays below 4e-2 and does not grow with the step count (the update is a contraction toward
+    step's max-abs pose, stays below RTOLBF = 8e-3 (measured 2.3 - 2.6e-3) and does not grow with the step count (the update is a contraction toward
     the predicted x0: rounding errors do not compound), and the final poses agree to 2 % of the final max-abs pose."""
     from diffassemble_amd import DenoiserEngine, Schedule, _lib
     side = int(round(n ** 0.5))
@@ -192,7 +192,7 @@ def test_bf16_full_loop_drift_config3_exophormer_hybrid(dev):
     per_step = (a - b).abs().amax((1, 2)) / b.abs().amax((1, 2))
     print(f"bf16 loop drift config 3 (exophormer d=539 V=8, hybrid): max over steps {float(per_step.max()):.3e}, first "
           f"{float(per_step[0]):.3e}, last {float(per_step[-1]):.3e}, final max-abs drift {float((a[-1] - b[-1]).abs().max()):.3e}")
-    assert float(per_step.max()) < 1.2e-2          # measured 4e-3: 3x head-room, not 10x
+    assert float(per_step.max()) < 8e-3            # measured 2.6e-3: 3x head-room, not 10x
     # rotation quadrant of every piece (cos, sin -> nearest of the four turns) identical
     qa = torch.atan2(a[-1][:, 3], a[-1][:, 2]).div(np.pi / 2).round().remainder(4)
     qb = torch.atan2(b[-1][:, 3], b[-1][:, 2]).div(np.pi / 2).round().remainder(4)
@@ -227,8 +227,8 @@ def test_bf16_full_loop_drift_config4_3d(dev):
     ang = 2 * torch.acos((qa * qb).sum(-1).abs().clamp(max=1.0))                     # geodesic angle, radians, per step per fragment
     print(f"bf16 loop drift config 4 (3D, T=300/10): translation max over steps {float(dt.max()):.3e} (last {float(dt[-1]):.3e}); "
           f"rotation geodesic max {float(ang.max()):.3e} rad (last step max {float(ang[-1].max()):.3e}, mean {float(ang[-1].mean()):.3e})")
-    assert float(dt.max()) < 2e-2
-    assert float(ang.max()) < 5e-2                      # < 3 degrees at every step of every fragment
+    assert float(dt.max()) < 1.5e-2                     # measured 4.8e-3
+    assert float(ang.max()) < 2e-3                      # measured 5.8e-4 rad = 0.03 degrees at every step of every fragment
     assert float((a[..., :4].norm(dim=-1) - 1).abs().max()) < 1e-3      # quaternions stay unit
 
 

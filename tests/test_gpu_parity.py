@@ -4,7 +4,9 @@ seeded inputs and against the committed fixtures produced from the reference's o
 Tolerances (north star: 1e-4 relative fp32):
   RTOL32 = 1e-4   fp32 parity mode, max-abs error relative to the max-abs of the reference tensor
   TRAJ32 = 5e-4   whole DDIM trajectories (rounding differences compound over T steps)
-  RTOLBF = 4e-2   bf16 perf mode (bf16 storage of activations/weights, fp32 accumulate)
+  RTOLBF = 8e-3   bf16 perf mode (bf16 storage of activations/weights, fp32 accumulate): 2.6x the largest error
+                  measured over every 2D case (1.5e-3 .. 3.1e-3, round 3; DA_TEST_RTOLBF=1e-9 prints them); RTOLBF3D = 1.5e-3
+                  for the 3D forwards (measured 1.5e-4 .. 4.6e-4)
 """
 import numpy as np
 import pytest
@@ -18,7 +20,8 @@ from oracle import weights as W
 
 pytestmark = pytest.mark.gpu
 RTOL32, TRAJ32 = 1e-4, 5e-4
-RTOLBF = float(__import__('os').environ.get('DA_TEST_RTOLBF', 4e-2))
+RTOLBF = float(__import__('os').environ.get('DA_TEST_RTOLBF', 8e-3))
+RTOLBF3D = float(__import__('os').environ.get('DA_TEST_RTOLBF', 1.5e-3))
 
 
 def rel(a, b):
@@ -398,7 +401,7 @@ def test_forward_3d(dev, golden, spec):
     engb = make_engine(case, spec, "bf16", dev, "3d")
     outb = engb.forward(engb.plan(case["edge_index"], case["batch"]), case["x"].to(dev), case["t"].to(dev),
                         case["feats"].to(dev))
-    assert rel(outb, ref) < RTOLBF
+    assert rel(outb, ref) < RTOLBF3D
 
 
 @pytest.mark.parametrize("lp", C.LOOPS3D, ids=lambda s: s["name"])
