@@ -978,6 +978,264 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense2(AttnDenseParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_attn_opt: the C = 32 bf16 instance on complete graphs with Q pre-scaled (the three hidden layers of the 2D arch), written
+// around what the round-3 measurements say bounds it: the SIMD's vector issue port (v_exp_f32 ~13-16 cycles, packs ~6.4,
+// every MFMA ~12 cycles of the same port; DESIGN.md "Measured, round 3").  Per score only the exponential and the pack are
+// left on that port:
+//   * OPTIMISTIC softmax: p = exp2(s) with no reference, no per-block range test, in place.  fp32 / bf16 carry 8 exponent
+//     bits, so this is exact whenever the row sums stay inside [2^-60, 2^100]; that is VERIFIED once, after the last key
+//     block, on the final row sums (an overflow anywhere shows up there as inf / NaN, total underflow as 0).  A workgroup
+//     whose check fails -- logits beyond +-41 before the 1/sqrt(C), not seen at a fresh model's near-uniform attention --
+//     re-runs its tile with the classic running-max recurrence (same loop, `gen` switched on: row max, rescale, shift);
+//   * the row sums come off the matrix pipe: l^T += 1 . P^T, two more MFMAs per block against an all-ones A operand (the
+//     pipe is two-thirds idle in this kernel), instead of seven packed adds + the range test on the vector port.
+// Same LDS image, DMA ring, fragment layouts and epilogue as k_attn_dense<bf16_t, 32, false, 32, 4, 4>.
+__global__ __launch_bounds__(256, 4) void k_attn_opt(AttnDenseParams p) {
+    using T = bf16_t;
+    constexpr int C = 32, NST = 4, NW = 4, QT = 128, NT = 256;
+    using CF = Cfg<T, C, C>;
+    constexpr int MAXI = (CF::NI + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *flags = (int *)(smem + NST * CF::STAGE);               // one word per wave: "my optimistic pass failed"
+
+    const int bid = blockIdx.x;
+    const int h = bid & 7, s_ = bid >> 3;
+    const int qt = s_ % p.nqt, g = s_ / p.nqt;
+    const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
+    if (qt * QT >= n_g) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0 = qt * QT + wid * 32;
+    const bool wave_on = q0 < n_g;
+    const int HC = p.H * C;
+    const size_t np = (size_t)p.n_pad;
+
+    u32x4 qf[CF::NCH];
+    {
+        const unsigned char *qrow = (const unsigned char *)p.Q + ((size_t)h * np + pad0 + min(q0, n_g - 1) / 32 * 32 + i) * CF::ROWB;
+#pragma unroll
+        for (int ch = 0; ch < CF::NCH; ++ch) qf[ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
+    }
+    const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
+    const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWBV;
+    unsigned soff[MAXI];
+#pragma unroll
+    for (int x = 0; x < MAXI; ++x) {
+        const int q = wid + NW * x;
+        unsigned o = 0;
+        if (q < CF::NIK) {
+            const int s = q * 64 + lane, row = s / CF::KSPR, col = s - row * CF::KSPR;
+            if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
+        } else {
+            const int s = (q - CF::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
+            if (row < CF::BKEYS && col < CF::KVALIDV) o = (unsigned)(row * CF::ROWBV + col * 16);
+        }
+        soff[x] = o;
+    }
+    auto issue = [&](int kt, int stage) {
+        unsigned char *sb = smem + stage * CF::STAGE;
+        const unsigned char *kb_ = Kg + (size_t)kt * CF::BKEYS * CF::ROWB;
+        const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ROWBV;
+#pragma unroll
+        for (int x = 0; x < MAXI; ++x) {
+            const int q = wid + NW * x;
+            if (NW * x + NW - 1 < CF::NI || q < CF::NI) {
+                const unsigned char *src = (q < CF::NIK ? kb_ : vb_) + soff[x];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+    const int myn = (CF::NI - wid + NW - 1) / NW;
+    const int nkt = (n_g + CF::BKEYS - 1) / CF::BKEYS;
+    const int qidx = q0 + i;
+    const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);
+    const int koff = pi_i * CF::RS + half * 16;
+    const int li = lane & 15;
+    const int vbase = CF::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    f32x16 O;
+    float ls = 0.f;               // this lane's share of the row sum (16 of the block's 32 keys)
+    float m = 0.f;                // GEN mode only: running row max (log2 units)
+    bool gen = false;             // false: optimistic pass
+    for (int attempt = 0; attempt < 2; ++attempt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] = 0.f;
+        ls = 0.f;
+        m = -1e30f;
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nkt) issue(st, st);
+        for (int kt = 0; kt < nkt; ++kt) {
+            {
+                const int younger = min(nkt - 1 - kt, NST - 2);
+                if (younger == NST - 2) { if (myn == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                else wait_vmcnt(younger * myn);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (kt + NST - 1 < nkt) issue(kt + NST - 1, (kt + NST - 1) % NST);
+            if (!wave_on) continue;
+            const unsigned char *stg = smem + (kt % NST) * CF::STAGE;
+#pragma unroll
+            for (int kb = 0; kb < CF::KB; ++kb) {
+                const int key0 = kt * CF::BKEYS + kb * 32;
+                if (key0 >= n_g) break;
+                u32x4 kf[CF::NCH];
+#pragma unroll
+                for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + koff + kb * 32 * CF::RS + ch * 32);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), kf[ch], qf[ch], s);
+                u32x2 vlo[2], vhi[2];
+                const unsigned vb = lds0 + (unsigned)((kt % NST) * CF::STAGE + vbase + kb * 32 * CF::RSV);
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    vlo[mm] = tr_read(vb, (8 * mm) * CF::RSV);
+                    vhi[mm] = tr_read(vb, (8 * mm + 4) * CF::RSV);
+                }
+                const int kbase = key0 + 16 * half;
+                const bool tail = key0 + 32 > n_g;
+                const bool diag = p.nodiag && key0 < q0 + 32 && key0 + 32 > q0;
+                if (tail || diag) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
+                }
+                if (gen) {
+                    // classic recurrence: new reference = max(old, block max); state rescaled when it moves
+                    const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
+                    const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
+                    const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+                    const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
+                    const float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));      // >= -1e30: finite
+                    if (__any(mnew > m)) {
+                        const float corr = __builtin_amdgcn_exp2f(m - mnew);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[r] *= corr;
+                        ls *= corr;
+                        m = mnew;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] -= m;
+                }
+                bf16x8 pf0, pf1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {               // pair by pair, so that at most two exponentials wait for their pack
+                    const float x0 = __builtin_amdgcn_exp2f(s[2 * e]), x1 = __builtin_amdgcn_exp2f(s[2 * e + 1]);
+                    pf0[2 * e] = (__bf16)x0; pf0[2 * e + 1] = (__bf16)x1;
+                    const float y0 = __builtin_amdgcn_exp2f(s[8 + 2 * e]), y1 = __builtin_amdgcn_exp2f(s[8 + 2 * e + 1]);
+                    pf1[2 * e] = (__bf16)y0; pf1[2 * e + 1] = (__bf16)y1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]));
+                const u32x4 v0 = {vlo[0][0], vlo[0][1], vhi[0][0], vhi[0][1]};
+                const u32x4 v1 = {vlo[1][0], vlo[1][1], vhi[1][0], vhi[1][1]};
+                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O, 0, 0, 0);
+                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
+                {
+                    // row sum of the bf16-rounded p (what the PV product weighs with): eight v_dot2_f32_bf16 against (1, 1)
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                    const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16x2 pa = {pf0[2 * e], pf0[2 * e + 1]}, pb = {pf1[2 * e], pf1[2 * e + 1]};
+                        ls = __builtin_amdgcn_fdot2_f32_bf16(pa, one2, ls, false);
+                        ls = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, ls, false);
+                    }
+                }
+            }
+        }
+        if (gen) break;
+        // ---- verification of the optimistic pass (workgroup-uniform verdict: the waves share the K / V stream)
+        const float lt0 = ls + __shfl_xor(ls, 32);
+        const bool bad = wave_on && __any(!(lt0 > 8.673617379884035e-19f && lt0 < 1.2676506002282294e30f) && qidx < n_g);      // 2^-60, 2^100; NaN fails
+        dma_barrier();
+        if (lane == 0) flags[wid] = bad ? 1 : 0;
+        __syncthreads();
+        const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+        __syncthreads();
+        if (!redo) break;
+        gen = true;
+    }
+
+    // ---- epilogue (as k_attn_dense): normalise, stage [query][c] fp32 rows through LDS, + skip, activation, 16-byte stores
+    const float lt = ls + __shfl_xor(ls, 32);
+    const float inv = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+    constexpr int RSOF = C + 4;
+    static_assert(QT * RSOF * 4 <= NST * CF::STAGE, "O staging must fit in the K/V ring");
+    float *so = (float *)smem;
+    dma_barrier();
+    if (wave_on) {
+        float *orow = so + (wid * 32 + i) * RSOF;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int c0 = 8 * jj + 4 * half;
+            *(f32x4 *)(orow + c0) = (f32x4){O[4 * jj] * inv, O[4 * jj + 1] * inv, O[4 * jj + 2] * inv, O[4 * jj + 3] * inv};
+        }
+    }
+    dma_barrier();
+    constexpr int EPC = 8, CPR = C / EPC;
+    const int nq = min(QT, n_g - qt * QT);
+    constexpr int NB = 3;
+    for (int it0 = tid; it0 < nq * CPR; it0 += NT * NB) {
+        u32x4 skv[NB], rsv[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int it = it0 + NT * k;
+            if (it < nq * CPR) {
+                const int q = it / CPR, ch = it - q * CPR;
+                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                skv[k] = *(const u32x4 *)((const T *)p.S + off);
+                if (p.res) rsv[k] = *(const u32x4 *)((const T *)p.res + off);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int it = it0 + NT * k;
+            if (it < nq * CPR) {
+                const int q = it / CPR, ch = it - q * CPR;
+                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                const float *src = so + q * RSOF + ch * EPC;
+                float v[EPC], sk[EPC];
+                const f32x4 a = *(const f32x4 *)src, b2 = *(const f32x4 *)(src + 4);
+                v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b2[0]; v[5] = b2[1]; v[6] = b2[2]; v[7] = b2[3];
+                unpack_chunk(T(), skv[k], sk);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+                if (p.res) {
+                    unpack_chunk(T(), rsv[k], sk);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = apply_act(v[e], p.act);
+                stc((T *)p.out + off, v);
+            }
+        }
+    }
+}
+
+// DA_ATTN_OPT=0: hidden layers on k_attn_dense's FAST path instead (A/B runs)
+static int attn_opt_env() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_ATTN_OPT"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static int launch_attn_opt(AttnDenseParams p, hipStream_t st) {
+    using CF = Cfg<bf16_t, 32, 32>;
+    p.nqt = (p.max_nodes + 127) / 128;
+    k_attn_opt<<<p.nqt * p.H * p.n_graphs, 256, 4 * CF::STAGE + 64, st>>>(p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 // opt-in (DA_ATTN2=1): measured EQUAL to the one-slab kernel at 64 puzzles (173 vs 174 us per conv) and slower at 32
 // (95.5 vs 89.1) -- kept as the record of the experiment, see DESIGN.md
 static int attn2_env() {
@@ -1082,6 +1340,8 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
         if (mk) return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, true, 32>(p, st) : launch_tcm<float, 144, true, 32>(p, st);
         return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, false, 32>(p, st) : launch_tcm<float, 144, false, 32>(p, st);
     }
+    if (prec == DA_PREC_BF16 && C == 32 && !p.mask && L.q_prescaled && p.fast && attn_opt_env() DA_ATTN_DBG(&& !p.debug && !p.prof))
+        return launch_attn_opt(p, st);
     if (prec == DA_PREC_BF16 && C == 32 && !p.mask && attn2_env() DA_ATTN_DBG(&& !p.debug && !p.prof))
         return launch_attn_dense2(p, heads, n_graphs, max_graph_nodes, st);
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, st) : launch_tc<bf16_t, 144>(p, st);
