@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
-ABI_VERSION = 12
+ABI_VERSION = 13
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -52,6 +52,11 @@ class DaGraph(C.Structure):
         ("hybrid", C.c_int32), ("reserved0", C.c_int32),
         ("mask", _fp), ("mask_ptr", _fp), ("irr_row_ptr", _fp), ("irr_col_src", _fp),
     ]
+
+
+class DaLoopOpts(C.Structure):
+    """da_loop_opts: sampler 0 = DDIM / 1 = DDPM, eta, classifier-free guidance switch + weight, per-iteration noise."""
+    _fields_ = [("sampler", C.c_int32), ("eta", C.c_float), ("cfg", C.c_int32), ("cfg_w", C.c_float), ("noise", C.c_void_p)]
 
 
 class DaSchedule(C.Structure):
@@ -102,6 +107,8 @@ PROTOTYPES = {
     "da_ddpm_step": (C.c_int, [C.POINTER(DaSchedule), C.c_int, C.c_int, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp]),
     "da_sample_loop": (C.c_int, [_fp, C.POINTER(DaGraph), C.POINTER(DaSchedule), C.c_int, C.c_int, C.c_int,
                                  _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
+    "da_sample_loop_ex": (C.c_int, [_fp, C.POINTER(DaGraph), C.POINTER(DaSchedule), C.c_int, C.c_int, C.c_int,
+                                    _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, C.POINTER(DaLoopOpts), _fp]),
     "da_sample_loop_pair": (C.c_int, [_fp, C.POINTER(DaSchedule), C.c_int, C.c_int, C.c_int,
                                       C.POINTER(DaGraph), _fp, _fp, _fp, C.c_size_t,
                                       C.POINTER(DaGraph), _fp, _fp, _fp, C.c_size_t, _fp]),

@@ -42,6 +42,18 @@ static int scale_block(float *p, int rows, int cols, int ld, float s, hipStream_
     DA_LAUNCH_CHECK();
     return 0;
 }
+// dst[r][c] = bias[c] in the activation dtype (the feature share of mlp.0 for zero features)
+__global__ void k_fill_bias_rows(int prec, int rows, int cols, const float *bias, void *dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    const float v = bias[i % cols];
+    if (prec == DA_PREC_BF16) ((bf16_t *)dst)[i] = f2bf(v); else ((float *)dst)[i] = v;
+}
+// classifier-free guidance, spatial_diffusion.py:585-589: out = (1 + w) cond - w unc, in place on `cond`
+__global__ void k_cfg_combine(size_t n, float wgt, float *cond, const float *unc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cond[i] = (1.0f + wgt) * cond[i] - wgt * unc[i];
+}
 static bool q_prescale_on() {
     static int off = -1;
     if (off < 0) { const char *e = getenv("DA_DISABLE_Q_PRESCALE"); off = (e && e[0] == '1') ? 1 : 0; }
@@ -57,6 +69,7 @@ struct LoopKey {
     float *traj, *x_final;
     void *ws;
     size_t ws_bytes;
+    da_loop_opts opts;        // zero for the plain DDIM loop
 };
 
 }  // namespace da
@@ -126,6 +139,8 @@ struct Workspace {
     void *pz;                         // [H, n_real, 32] act dtype: per-head outputs of the folded last attention
     char *head_pre;                   // [n_real, 32] act dtype: residual share of final_mlp.0 (fused_mlp2)
     char *feat_proj;                  // [n_real, hidden] act dtype: mlp.0 over the piece-feature columns (+ bias), once per Batch
+    char *feat_proj_unc;              // the same for ZERO features (= the bias, broadcast): the unconditional pass of classifier-free guidance
+    float *model_out_unc;
     char *dq, *dk, *dvt, *dskip;      // dense path: head-major Q, K, V ([H][n_pad][C] each), row-major skip
     size_t dense_off, dense_bytes;    // [dq, dq + dense_bytes) is zero-filled once per Batch
     float *model_out, *xbuf0, *xbuf1;
@@ -149,6 +164,7 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     w.comb_in = take(nrp * d->D * s);
     w.h = take(nrp * d->hidden * s);
     w.feat_proj = take(nrp * d->hidden * s);
+    w.feat_proj_unc = take(nrp * d->hidden * s);
     w.head_pre = take(nrp * 32 * s);
     w.pz = take(nrp * 32 * (size_t)d->heads * sizeof(float));
     w.combined = take(np * d->D * s);
@@ -170,6 +186,7 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     }
     const int cpose = d->variant == DA_VARIANT_3D ? 7 : d->c_out;
     w.model_out = (float *)take(nr * cpose * sizeof(float));
+    w.model_out_unc = (float *)take(nr * cpose * sizeof(float));
     w.xbuf0 = (float *)take(nr * 8 * sizeof(float));
     w.xbuf1 = (float *)take(nr * 8 * sizeof(float));
     w.total = off;
@@ -250,7 +267,7 @@ static int timed(da_denoiser *d, int cls, hipStream_t st, F &&launch) {
 
 static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const int64_t *t, int64_t t_scalar,
                         float *out, float *alpha, int alpha_all, float *pre_head, const Workspace &w,
-                        hipStream_t st, DdimFuse *ddim = nullptr) {
+                        hipStream_t st, DdimFuse *ddim = nullptr, bool uncond = false) {
     const int prec = d->prec, nr = g->n_real, n = g->n_nodes, D = d->D;
     int rc;
     // (a-3) embedding: pose MLP + learned timestep lookup into the concat buffer, then mlp
@@ -268,8 +285,9 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
              int r2 = mfma_disabled() ? -1
                                       : launch_gemm_mfma(prec, nr, D - d->F, d->hidden, w.comb_in + (size_t)d->F * es_, D,
                                                          (const char *)d->mlp_w0 + (size_t)d->F * es_, nullptr, act1, nullptr,
-                                                         w.h, d->hidden, nullptr, st, D, w.feat_proj);
+                                                         w.h, d->hidden, nullptr, st, D, uncond ? w.feat_proj_unc : w.feat_proj);
              if (r2 >= 0) return r2;
+             if (uncond) { set_error("unconditional pass: the hoisted mlp.0 path is not available for this shape"); return 1; }
              return linear(prec, nr, D, d->hidden, w.comb_in, D, d->mlp_w0, d->mlp_b0, act1, nullptr, w.h, d->hidden, st); }))) return rc;
     // mlp.2 (Linear(128 -> 1152), no activation in 2D) only feeds two linear consumers -- the conv-0 projection
     // and, through the residual, final_mlp.0 -- so for the transformer arch it is folded into their weights at
@@ -684,6 +702,9 @@ int da_denoiser_set_features(da_denoiser *d, const da_graph *g, const float *fea
                               w.feat_proj, d->hidden, nullptr, st, d->D, nullptr);
         if (rc > 0) return rc;
         DA_REQUIRE(rc == 0, "da_denoiser_set_features: feature projection shape not supported (F=%d)", d->F);
+        const size_t nb = (size_t)g->n_real * d->hidden;
+        k_fill_bias_rows<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(d->prec, g->n_real, d->hidden, d->mlp_b0, w.feat_proj_unc);
+        DA_LAUNCH_CHECK();
     }
     if (w.dense_bytes)      // padded rows / columns of the head-major buffers must be finite
         DA_CHECK_HIP(hipMemsetAsync((char *)workspace + w.dense_off, 0, w.dense_bytes, st));
@@ -729,7 +750,7 @@ int da_ddpm_step(const da_schedule *s, int n, int c, const float *x, const float
 
 static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int mean_type, int ratio,
                         int n_iters, const float *x_init, float *traj, float *x_final, const Workspace &w,
-                        hipStream_t st) {
+                        hipStream_t st, const da_loop_opts *o = nullptr) {
     const int nr = g->n_real;
     const int c = d->variant == DA_VARIANT_3D ? 7 : d->c_in;
     const size_t bytes = (size_t)nr * c * sizeof(float);
@@ -737,6 +758,13 @@ static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s,
     const float *cur = x_init;
     int it = 0, rc;
     const int first = ((s->steps - 1) / ratio) * ratio;            // reversed(range(0, steps, ratio))[0]
+    // the variants of the reference's samplers that need more than forward + deterministic update (all inside the same
+    // enqueue, so all inside the captured graph): classifier-free guidance = a second forward over zero features and a
+    // linear combination (spatial_diffusion.py:568-589); eta > 0 / DDPM = a noise term read from a caller-filled
+    // [n_iters, n_real, c] buffer (:485-510, :620-627 draw torch.randn_like per step; the host draws them in one call)
+    const bool cfg = o && o->cfg, ddpm = o && o->sampler == 1;
+    const float eta = o ? o->eta : 0.f;
+    const bool plain = !cfg && !ddpm && eta == 0.f;
     for (int i = first; i >= 0 && it < n_iters; i -= ratio, ++it) {
         float *nxt = traj ? traj + (size_t)it * nr * c : ((it & 1) ? w.xbuf1 : w.xbuf0);
         const int nonneg = (i - ratio) >= 0;
@@ -745,13 +773,22 @@ static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s,
         df.done = 0;
         static int fuse_off = -1;
         if (fuse_off < 0) { const char *e = getenv("DA_DISABLE_DDIM_FUSION"); fuse_off = (e && e[0] == '1') ? 1 : 0; }
-        const bool try_fuse = !fuse_off && d->variant == DA_VARIANT_2D && !d->prof_on;
+        const bool try_fuse = plain && !fuse_off && d->variant == DA_VARIANT_2D && !d->prof_on;
         if ((rc = forward_impl(d, g, cur, nullptr, i, w.model_out, nullptr, 0, nullptr, w, st, try_fuse ? &df : nullptr))) return rc;
         if (df.done) { cur = nxt; continue; }
+        if (cfg) {
+            if ((rc = forward_impl(d, g, cur, nullptr, i, w.model_out_unc, nullptr, 0, nullptr, w, st, nullptr, true))) return rc;
+            const size_t ne = (size_t)nr * c;
+            k_cfg_combine<<<(unsigned)((ne + 255) / 256), 256, 0, st>>>(ne, o->cfg_w, w.model_out, w.model_out_unc);
+            DA_LAUNCH_CHECK();
+        }
+        const float *nz = (o && o->noise) ? o->noise + (size_t)it * nr * c : nullptr;
         rc = timed(d, DA_PROF_UPDATE, st, [&] {
             if (d->variant == DA_VARIANT_3D)
                 return launch_ddim3d(ds, mean_type, nr, cur, w.model_out, nullptr, i, ratio, nonneg, nxt, st);
-            return launch_ddim2d(ds, mean_type, nr, c, cur, w.model_out, nullptr, i, ratio, nonneg, 0.f, nullptr, nxt, st);
+            if (ddpm)       // t_index == 0 adds no noise (spatial_diffusion.py:504-506)
+                return launch_ddpm2d(ds, nr, c, cur, w.model_out, nullptr, i, i == 0 ? nullptr : nz, nxt, st);
+            return launch_ddim2d(ds, mean_type, nr, c, cur, w.model_out, nullptr, i, ratio, nonneg, eta, eta > 0.f ? nz : nullptr, nxt, st);
         });
         if (rc) return rc;
         cur = nxt;
@@ -760,10 +797,16 @@ static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s,
     return 0;
 }
 
-int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int mean_type, int inference_ratio,
-                   int max_iters, const float *x_init, float *traj, float *x_final, void *workspace,
-                   size_t workspace_bytes, int use_graph, void *stream) {
+int da_sample_loop_ex(da_denoiser *d, const da_graph *g, const da_schedule *s, int mean_type, int inference_ratio,
+                      int max_iters, const float *x_init, float *traj, float *x_final, void *workspace,
+                      size_t workspace_bytes, int use_graph, const da_loop_opts *opts, void *stream) {
     DA_REQUIRE(d && g && s && x_init && workspace, "da_sample_loop: null argument");
+    da_loop_opts o;
+    memset(&o, 0, sizeof(o));
+    if (opts) { o.sampler = opts->sampler; o.eta = opts->eta; o.cfg = opts->cfg; o.cfg_w = opts->cfg_w; o.noise = opts->noise; }
+    DA_REQUIRE(o.sampler == 0 || o.sampler == 1, "da_sample_loop_ex: sampler must be 0 (DDIM) or 1 (DDPM)");
+    DA_REQUIRE(!(o.sampler == 1 || o.eta > 0.f) || o.noise, "da_sample_loop_ex: eta > 0 / DDPM need the noise buffer");
+    DA_REQUIRE(d->variant == DA_VARIANT_2D || (!o.cfg && o.sampler == 0 && o.eta == 0.f), "da_sample_loop_ex: the 3D loop has no guidance / stochastic variant");
     DA_REQUIRE(inference_ratio >= 1 && s->steps >= 1, "da_sample_loop: bad ratio/steps");
     DA_REQUIRE(d->variant == DA_VARIANT_3D || d->c_in == d->c_out, "da_sample_loop: c_in != c_out");
     int rc = check_graph(d, g);
@@ -774,12 +817,13 @@ int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int 
     int total = (s->steps + inference_ratio - 1) / inference_ratio;
     const int n_iters = (max_iters > 0 && max_iters < total) ? max_iters : total;
     if (d->prof_on) use_graph = 0;       // event bracketing is not capturable
-    if (!use_graph) return enqueue_loop(d, g, s, mean_type, inference_ratio, n_iters, x_init, traj, x_final, w, st);
+    if (!use_graph) return enqueue_loop(d, g, s, mean_type, inference_ratio, n_iters, x_init, traj, x_final, w, st, &o);
 
     LoopKey key;
     memset(&key, 0, sizeof(key));
     key.g = *g; key.s = *s; key.mean_type = mean_type; key.ratio = inference_ratio; key.max_iters = n_iters;
     key.x_init = x_init; key.traj = traj; key.x_final = x_final; key.ws = workspace; key.ws_bytes = workspace_bytes;
+    key.opts = o;
     hipGraphExec_t exec = nullptr;
     for (auto &e : d->loops)
         if (memcmp(&key, &e.key, sizeof(key)) == 0) exec = e.exec;
@@ -792,7 +836,7 @@ int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int 
         if (!d->cap_stream) DA_CHECK_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
         hipStream_t cs = d->cap_stream;
         DA_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
-        rc = enqueue_loop(d, g, s, mean_type, inference_ratio, n_iters, x_init, traj, x_final, w, cs);
+        rc = enqueue_loop(d, g, s, mean_type, inference_ratio, n_iters, x_init, traj, x_final, w, cs, &o);
         hipError_t e = hipStreamEndCapture(cs, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess || !graph) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return 2; }
@@ -803,6 +847,13 @@ int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int 
     }
     DA_CHECK_HIP(hipGraphLaunch(exec, st));
     return 0;
+}
+
+int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int mean_type, int inference_ratio,
+                   int max_iters, const float *x_init, float *traj, float *x_final, void *workspace,
+                   size_t workspace_bytes, int use_graph, void *stream) {
+    return da_sample_loop_ex(d, g, s, mean_type, inference_ratio, max_iters, x_init, traj, x_final, workspace, workspace_bytes,
+                             use_graph, nullptr, stream);
 }
 
 // Two independent halves of one Batch as two parallel branches of ONE hipGraph: each branch is the complete loop of

@@ -204,14 +204,22 @@ class DenoiserEngine:
         return out
 
     def sample_loop(self, plan, sched: Schedule, x_init, feats, *, ratio=1, mean_type=_lib.MEAN_START_X,
-                    max_iters=0, keep_trajectory=True, use_graph=True, restage=True):
-        """p_sample_loop: all DDIM iterations in one C call (one hipGraph launch when use_graph).
+                    max_iters=0, keep_trajectory=True, use_graph=True, restage=True, sampler="DDIM", eta=0.0,
+                    cfg_w=None, noise=None, generator=None):
+        """p_sample_loop: all iterations in one C call (one hipGraph launch when use_graph).
         Returns (traj [n_iters, N, c] or None, x_final [N, c]) -- engine-owned buffers that the next
         call with the same loop shape overwrites (clone to keep).  Note the cached graph also
-        borrows ``plan``'s arrays and the workspace."""
+        borrows ``plan``'s arrays and the workspace.
+
+        ``sampler="DDPM"``, ``eta > 0`` and ``cfg_w`` (classifier-free guidance weight; ``None`` = off) select the
+        reference's other samplers (spatial_diffusion.py:485-510, 568-589, 620-627) INSIDE the same captured loop
+        (da_sample_loop_ex).  The stochastic ones read one standard-normal draw per iteration from an engine-owned
+        [n_iters, N, c] buffer that is refilled before every launch: from ``noise`` when given (tests inject the
+        reference's saved draws), else by one ``torch.randn`` call (``generator`` optional)."""
         total = (sched.steps + ratio - 1) // ratio
         n_iters = min(max_iters, total) if max_iters and max_iters > 0 else total
-        if self._two_branch(plan, keep_trajectory, use_graph):
+        ex = sampler == "DDPM" or eta > 0 or cfg_w is not None
+        if not ex and self._two_branch(plan, keep_trajectory, use_graph):
             return None, self._sample_loop_pair(plan, sched, x_init, feats, ratio, mean_type, n_iters, restage)
         if restage:
             g, ws = self.set_features(plan, feats)
@@ -230,6 +238,25 @@ class DenoiserEngine:
         xi, traj, x_final = bufs
         xi.copy_(x_init)
         self._loop_keep = plan                                 # the cached hipGraph borrows its arrays
+        if ex:
+            o = _lib.DaLoopOpts()
+            o.sampler = 1 if sampler == "DDPM" else 0
+            o.eta = float(eta)
+            o.cfg, o.cfg_w = (0, 0.0) if cfg_w is None else (1, float(cfg_w))
+            if sampler == "DDPM" or eta > 0:
+                nb = self._loop_bufs.get(("noise",) + key)
+                if nb is None:
+                    nb = self._loop_bufs[("noise",) + key] = torch.empty((n_iters, plan.n_real, c), dtype=torch.float32, device=self.device)
+                if noise is not None:
+                    nb.copy_(noise)
+                else:
+                    nb.normal_(generator=generator)
+                o.noise = nb.data_ptr()
+            _lib.check(self.lib.da_sample_loop_ex(
+                self.handle, C.byref(g), C.byref(sched.c), int(mean_type), int(ratio), int(n_iters),
+                _lib.ptr(xi), _lib.ptr(traj), _lib.ptr(x_final), _lib.ptr(ws), ws.numel(),
+                int(bool(use_graph)), C.byref(o), _lib.stream_ptr(self.device)))
+            return traj, x_final
         _lib.check(self.lib.da_sample_loop(
             self.handle, C.byref(g), C.byref(sched.c), int(mean_type), int(ratio), int(n_iters),
             _lib.ptr(xi), _lib.ptr(traj), _lib.ptr(x_final), _lib.ptr(ws), ws.numel(),

@@ -268,15 +268,16 @@ class GNN_Diffusion(LightningModule):
         if patch_feats is None:
             patch_feats = self.visual_features(cond)
         its = list(reversed(range(0, self.steps, self.inference_ratio)))
-        fast = (self.sampling == "DDIM" and self.eta == 0 and not self.return_attentions
-                and not self.classifier_free_prob > 0.0)
-        if fast:
+        # one C call (a hipGraph replay) for every sampler of the reference: DDIM (eta >= 0), DDPM, with or without
+        # classifier-free guidance; only a request for the attention weights needs the per-step path below
+        if not self.return_attentions:
             eng = self.model.engine(device)
             plan = self.model._plan_for(eng, edge_index, batch, expander)
             self.model._feat_key = None
             traj, _ = eng.sample_loop(plan, self._schedule(), img, patch_feats, ratio=self.inference_ratio,
                                       mean_type=self._mean_type(), keep_trajectory=True,
-                                      use_graph=self.use_hip_graph)
+                                      use_graph=self.use_hip_graph, sampler=self.sampling, eta=float(self.eta),
+                                      cfg_w=(float(self.classifier_free_w) if self.classifier_free_prob > 0.0 and self.sampling == "DDIM" else None))
             return list(traj.clone().unbind(0)), [None] * len(its)
         imgs, attentions = [], []
         b = shape[0]

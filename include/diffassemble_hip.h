@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 12
+#define DA_ABI_VERSION 13
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -201,6 +201,24 @@ int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int 
                    int inference_ratio, int max_iters, const float *x_init, float *traj,
                    float *x_final, void *workspace, size_t workspace_bytes, int use_graph,
                    void *stream);
+
+/* The loop's other samplers, inside the same (capturable) enqueue -- spatial_diffusion.py:485-510 (p_sample_ddpm),
+ * :568-589 (classifier-free guidance: a second denoiser pass over ZERO piece features, out = (1 + w) cond - w unc) and
+ * :620-627 (eta > 0: + eta sqrt(var) noise).  `noise` [n_iters, n_real, c] fp32 holds one standard-normal draw per
+ * iteration (the reference calls torch.randn_like once per step; the caller fills the buffer once per loop); it is read
+ * by the update kernels of the replayed graph, so refill it in place before every launch.  2D only.  opts == NULL is
+ * da_sample_loop. */
+typedef struct da_loop_opts {
+    int32_t sampler;      /* 0 = DDIM (p_sample_ddim), 1 = DDPM (p_sample_ddpm)                       */
+    float eta;            /* DDIM only; 0 = deterministic                                             */
+    int32_t cfg;          /* != 0: classifier-free guidance                                           */
+    float cfg_w;          /* classifier_free_w                                                        */
+    const float *noise;   /* [n_iters, n_real, c] or NULL (required when sampler == 1 or eta > 0)     */
+} da_loop_opts;
+int da_sample_loop_ex(da_denoiser *d, const da_graph *g, const da_schedule *s, int mean_type,
+                      int inference_ratio, int max_iters, const float *x_init, float *traj,
+                      float *x_final, void *workspace, size_t workspace_bytes, int use_graph,
+                      const da_loop_opts *opts, void *stream);
 
 /* The same loop over TWO disjoint sets of puzzles of one Batch (the puzzles of a Batch never
  * interact: spatial_diffusion.py:635-676 runs them through one block-diagonal graph), recorded

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     for name in declared:
         assert getattr(h, name) is not None
-    assert h.da_abi_version() == _lib.ABI_VERSION == 12
+    assert h.da_abi_version() == _lib.ABI_VERSION == 13
 
 
 def test_single_hip_runtime_is_mapped():
@@ -43,7 +43,7 @@ def test_struct_layouts_match_the_c_header(tmp_path):
     import subprocess
     from diffassemble_amd import _lib
     structs = {"da_weights": _lib.DaWeights, "da_graph": _lib.DaGraph, "da_schedule": _lib.DaSchedule,
-               "da_encoder_weights": _lib.DaEncoderWeights}
+               "da_encoder_weights": _lib.DaEncoderWeights, "da_loop_opts": _lib.DaLoopOpts}
     lines = []
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
