@@ -295,11 +295,15 @@ def train_bench(args, world, rank, dev):
     import torch.distributed as dist
     from diffassemble_amd import sharding as S
     from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
-    n, G, K, Wm = 144, args.train_puzzles, args.steps, args.warmup
+    side = args.train_side
+    n, G, K, Wm = side * side, args.train_puzzles, args.steps, args.warmup
     torch.manual_seed(0)
     pixels = bool(args.pixels)               # --pixels: the scripted configuration, encoder trained from the 32x32 crops
+    exo = args.arch == "exophormer"          # --arch exophormer: the scripted ARCHITECTURE (train_celeba_rot.sh:4-15): Exphander
+    #                                          graphs of degree --degree (default: the scripted 60 %), 8 virtual nodes per puzzle
+    arch_kw = dict(architecture="exophormer", virt_nodes=8) if exo else {}
     m = GNN_Diffusion(steps=T_STEPS, sampling="DDIM", rotation=True, visual_pretrained=False,
-                      model_mean_type=ModelMeanType.EPSILON, **({"backbone": "resnet18equiv", "freeze_backbone": False} if pixels else {}))
+                      model_mean_type=ModelMeanType.EPSILON, **arch_kw, **({"backbone": "resnet18equiv", "freeze_backbone": False} if pixels else {}))
     m = m.to(dev).train()
     if pixels and args.precision:
         m.model.visual_backbone.train_precision = args.precision       # encoder maps in bf16 / fp32 (denoiser: fp32)
@@ -308,7 +312,16 @@ def train_bench(args, world, rank, dev):
     feats = None if pixels else torch.randn((G * n, 1088), generator=gen, device=dev)
     crops = torch.rand((G * n, 3, 32, 32), generator=gen, device=dev) if pixels else None
     x0 = torch.randn((G * n, 4), generator=gen, device=dev)
-    ei, batch = dense_batch(G, n, dev)
+    degree = 0
+    if exo:
+        import numpy as np
+        from diffassemble_amd import expander
+        degree = args.degree if 0 < args.degree < n and args.degree_given else round(0.6 * (n - 1))       # "60%" = round(60 (n - 1) / 100), puzzle_dataset.py:46-47
+        degree -= (degree * n) % 2
+        perms = expander.draw_permutations(n, G, np.random.default_rng(7 + rank))
+        ei, batch = expander.regular_edge_index(perms, degree, dev)
+    else:
+        ei, batch = dense_batch(G, n, dev)
     te = m.model.train_engine(dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     acc = [0.0, 0.0, 0.0]
@@ -348,7 +361,10 @@ def train_bench(args, world, rank, dev):
     for _ in range(kp):
         step(True)
     if rank == 0:
-        flop_fwd = G * (n * F_NODE + n * n * F_EDGE)
+        n_edges = (G * n * degree + G * n + G * 8 * (n + 8)) if exo else G * n * n       # exophormer: + the virtual-node edges (exophormer_gnn.py:183-200)
+        flop_fwd = (G * n + (G * 8 if exo else 0)) * F_NODE + n_edges * F_EDGE
+        from diffassemble_amd.graph_plan import build_plan
+        path = "dense (grouped GEMMs)" if not exo else ("hybrid: adjacency-masked grouped GEMMs + CSR remainder" if build_plan(ei, batch, 8).hybrid else "edge list (CSR)")
         # roofline of the step's dominant phase (forward + backward of the denoiser, fp32 MFMA kernels): algorithmic FLOP =
         # 3 x the forward's (backward = dX and dW products of every forward product) over the HIP-event time of
         # that phase; the encoder (--pixels) is outside this count
@@ -386,15 +402,18 @@ def train_bench(args, world, rank, dev):
                    "sample": f"{Gc} puzzles of 12x12: oracle p_losses (q_sample + denoiser forward, torch fp32) + autograd backward, no optimizer; "
                              f"1 warm-up + 3 repeats, median {reps[1]:.2f} s"}
         print(json.dumps({
-            "metric": "training steps/sec (12x12 rot dense, 64 puzzles/GPU, Huber, Adafactor)",
+            "metric": "training steps/sec (12x12 rot dense, 64 puzzles/GPU, Huber, Adafactor)" if (side == 12 and not exo) else
+                      f"training steps/sec ({side}x{side} rot, {'exophormer V=8, Exphander d=' + str(degree) if exo else 'dense'}, Huber, Adafactor)",
             "value": world * G * K / dt, "unit": "puzzle-train-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if not (pixels and args.precision == "bf16") else "bf16 encoder maps + fp32 denoiser", "data": "synthetic",
-            "config": {"workload": "BASELINE config 5: 12x12 rot dense (N=144, E=20736), G per GPU below, huber, "
-                                   "EPSILON, one Adafactor step; " +
+            "config": {"workload": ("BASELINE config 5: 12x12 rot dense (N=144, E=20736), G per GPU below, huber, EPSILON, one Adafactor step; "
+                                    if (side == 12 and not exo) else
+                                    f"training step, {side}x{side} rot puzzles (N={n}), " + (f"exophormer arch with 8 virtual nodes on Exphander graphs of degree {degree} "
+                                    f"(the scripted architecture, train_celeba_rot.sh:4-15; E={n_edges // G} per puzzle), " if exo else "dense, ") + "huber, EPSILON, one Adafactor step; ") +
                                    ("encoder (P4 ResNet-18, batch-statistics BatchNorm) + denoiser trained from 32x32 crops"
                                     if pixels else "denoiser only (piece features synthetic)"),
-                       "puzzles_per_gpu": G, "global_puzzles": world * G,
+                       "puzzles_per_gpu": G, "global_puzzles": world * G, "attention_path": path,
                        "parallelism": f"data parallel x{world}, one fused gradient all-reduce"},
             "optimizer_steps_per_s": K / dt,
             "algorithmic_tflops": 3 * world * flop_fwd * K / dt / 1e12,
@@ -951,6 +970,9 @@ def main():
                     help="--mode encode: pieces per encoder chunk (0 = engine default)")
     ap.add_argument("--train-puzzles", type=int, default=int(os.environ.get("BENCH_TRAIN_PUZZLES", 64)),
                     help="--mode train: 12x12 puzzles per GPU")
+    ap.add_argument("--arch", default="transformer", choices=["transformer", "exophormer"],
+                    help="--mode train: exophormer = the scripted training architecture (Exphander graphs + 8 virtual nodes)")
+    ap.add_argument("--train-side", type=int, default=12, help="--mode train: pieces per puzzle side (12 = BASELINE config 5)")
     ap.add_argument("--pixels", action="store_true",
                     help="--mode train: train the piece encoder too, from 32x32 crops (the scripted --backbone resnet18equiv)")
     ap.add_argument("--replays", type=int, default=30, help="extra individually timed graph replays for the median")
@@ -959,6 +981,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp32 (parity-mode) replay of the sampling configurations")
     args = ap.parse_args()
+    args.degree_given = any(a == "--degree" or a.startswith("--degree=") for a in sys.argv[1:]) or "BENCH_DEGREE" in os.environ
     if args.config == "5":
         args.mode = "train"
 

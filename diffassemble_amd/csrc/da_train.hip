@@ -486,6 +486,11 @@ int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, con
                          const long long *poff, const int32_t *node_graph, hipStream_t st);
 int dense_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
                          float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st);
+// hybrid graphs (adjacency-masked grouped GEMMs over the regular edges + CSR remainder, one softmax over both)
+int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P, float *stats,
+                          const long long *poff, const int32_t *node_graph, hipStream_t st);
+int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
+                          const float *stats, float *Dd, float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st);
 
 static bool train_dense_disabled() {
     static int v = -1;
@@ -512,6 +517,7 @@ struct Dims {
     int din[DA_MAX_LAYERS], C[DA_MAX_LAYERS], hc[DA_MAX_LAYERS];
     bool gelu_between;
     bool dense;                // complete graphs: grouped-GEMM attention (da_train_dense.hip)
+    bool hybrid;               // hybrid graphs: masked grouped GEMMs + CSR remainder (da_train_dense.hip)
     size_t pair_floats;
 };
 
@@ -529,10 +535,13 @@ static int dims_of(const da_weights *w, const da_graph *g, Dims &d) {
         d.C[l] = l == d.L - 1 ? d.D / d.H : 32;
         d.hc[l] = d.C[l] * d.H;
     }
-    DA_REQUIRE(g->n_real > 0 && g->n_nodes >= g->n_real && g->row_ptr, "training: bad graph");
+    DA_REQUIRE(g->n_real > 0 && g->n_nodes >= g->n_real, "training: bad graph");
     DA_REQUIRE(d.V == 0 || g->n_nodes == g->n_real + d.V * g->n_graphs, "training: exophormer expects n_nodes = n_real + V*G");
     d.dense = !train_dense_disabled() && g->dense != 0 && g->graph_ptr && d.V == 0 && g->max_graph_nodes > 0;
-    d.pair_floats = d.dense ? dense_pair_floats(g, d.H) : 0;
+    d.hybrid = !d.dense && !train_dense_disabled() && g->hybrid && g->mask && g->mask_ptr && g->irr_row_ptr && g->graph_ptr &&
+               g->pad_ptr && g->max_graph_nodes > 0;
+    DA_REQUIRE(d.dense || d.hybrid || g->row_ptr, "training: this graph walks the edge list but the CSR arrays are missing");
+    d.pair_floats = (d.dense || d.hybrid) ? dense_pair_floats(g, d.H) : 0;
     return 0;
 }
 
@@ -580,7 +589,7 @@ static TrainWs carve_train(const Dims &d, void *base) {
     w.dp1 = take(nr * 16);
     for (int l = 0; l < DA_MAX_LAYERS; ++l) w.P[l] = nullptr;
     w.dP = nullptr; w.poff = nullptr; w.node_graph = nullptr;
-    if (d.dense) {
+    if (d.dense || d.hybrid) {
         for (int l = 0; l < d.L; ++l) w.P[l] = take(d.pair_floats);
         w.dP = take(d.pair_floats);
         w.poff = (long long *)take(2 * ((size_t)d.G + 2));
@@ -681,6 +690,10 @@ int da_train_forward(const da_weights *w, const da_graph *g, const float *x, con
             if (l == 0 && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
             if ((rc = dense_train_attn_fwd(g, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr, ws.o[l], ws.P[l], ws.poff,
                                            ws.node_graph, st))) return rc;
+        } else if (d.hybrid) {
+            if (l == 0 && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
+            if ((rc = hybrid_train_attn_fwd(g, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr, ws.o[l], ws.P[l], ws.stats[l],
+                                            ws.poff, ws.node_graph, st))) return rc;
         } else if ((rc = launch_attn_csr(P, n, g->row_ptr, g->col_src, nullptr, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr,
                                          DA_ACT_NONE, ws.o[l], nullptr, ws.stats[l], st))) return rc;
         if (!last && d.gelu_between) {
@@ -704,7 +717,8 @@ int da_train_backward(const da_weights *w, const da_weights *grads, const da_gra
     int rc;
     if ((rc = dims_of(w, g, d))) return rc;
     DA_REQUIRE(grads && x && t && d_out && workspace, "da_train_backward: null argument");
-    DA_REQUIRE(d.dense || (g->out_ptr && g->out_dst), "da_train_backward: the graph needs the by-source CSR (out_ptr / out_dst)");
+    DA_REQUIRE(d.dense || (g->out_ptr && (g->out_dst || d.hybrid)), "da_train_backward: the graph needs the by-source CSR (out_ptr / "
+               "out_dst; of the remainder edges for hybrid graphs, where out_dst may be empty)");
     if ((rc = check_fused(w, d, "da_train_backward(weights)"))) return rc;
     if ((rc = check_fused(grads, d, "da_train_backward(grads)"))) return rc;
     TrainWs ws = carve_train(d, workspace);
@@ -730,6 +744,9 @@ int da_train_backward(const da_weights *w, const da_weights *grads, const da_gra
         const int hc = d.hc[l], din = d.din[l];
         if (d.dense) {
             if ((rc = dense_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.dY4, ws.poff, ws.node_graph, st))) return rc;
+        } else if (d.hybrid) {
+            if ((rc = hybrid_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.stats[l], ws.Dd, ws.dY4, ws.poff,
+                                            ws.node_graph, st))) return rc;
         } else if ((rc = launch_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.stats[l], ws.Dd, ws.dY4, st))) return rc;
         const float *xin = l == 0 ? ws.h0 : (d.gelu_between ? ws.hact[l - 1] : ws.o[l - 1]);
         float *dx = (l & 1) ? ws.dxa : ws.dxb;

@@ -283,4 +283,311 @@ int dense_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, con
     return 0;
 }
 
+
+// =====================================================================================================================
+// HYBRID graphs in training (Exphander edges + exophormer virtual nodes, the scripted training configuration,
+// singularity/gianscarpe/train_celeba_rot.sh:4-15): the unique real -> real in-graph edges ("regular", one adjacency bit per
+// (target, source) pair, da_graph.mask) run through the same grouped matrix-core GEMMs as complete graphs; every other edge
+// (virtual nodes, duplicated pairs, cross-graph pairs of the exophormer quirk, exophormer_gnn.py:183-200) stays a small CSR
+// by destination (irr_row_ptr / irr_col_src) + by source (out_ptr / out_dst of a hybrid training graph).  ONE softmax per
+// (target, head) spans both parts: statistics (max, 1 / (sum + 1e-16)) are computed over the masked dense row AND the row's
+// remainder edges, the dense part of P is kept, the remainder weights are recomputed from the statistics wherever needed --
+// exactly what the CSR kernels of da_train.hip do for whole graphs.
+// rows of the pair matrices + their remainder edges: one wave per (node, head); virtual rows (node >= n_real) have no dense part.
+//   mode 0: S (scaled scores) -> P in place (masked entries 0), stats[node, h] = (max, 1 / (sum + 1e-16)) over both parts
+//   mode 2: Dd[node, h] = sum_j P_ij dP_ij over the dense part (virtual rows: 0)
+//   mode 1: dS = P o (dP - Dd[node, h]) written over dP (Dd = the total over both parts by then)
+__global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int n_nodes, int n_real, int H, int C, const int32_t *__restrict__ gp,
+                                                          const int32_t *__restrict__ pad_ptr, const int32_t *__restrict__ node_graph,
+                                                          const long long *__restrict__ poff, const unsigned char *__restrict__ mask,
+                                                          const long long *__restrict__ mask_ptr, const int32_t *__restrict__ irr_ptr,
+                                                          const int32_t *__restrict__ irr_src, const float *__restrict__ qkvs,
+                                                          float *P, float *dP, float *__restrict__ stats, float *__restrict__ Dd) {
+    const int lane = threadIdx.x & 63;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int HC = H * C;
+    const float scale = 1.0f / sqrtf((float)C);
+    for (long long wv = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < (long long)n_nodes * H; wv += n_waves) {
+        const int node = (int)(wv / H), h = (int)(wv - (long long)node * H);
+        const bool real = node < n_real;
+        int n_g = 0, i = 0, ldp = 0;
+        float *row = nullptr;
+        const unsigned char *mrow = nullptr;
+        if (real) {
+            const int g = node_graph[node];
+            n_g = gp[g + 1] - gp[g]; i = node - gp[g]; ldp = (n_g + 3) & ~3;
+            row = P + poff[g] + ((size_t)h * n_g + i) * ldp;
+            mrow = mask + mask_ptr[g] + (size_t)i * (size_t)((pad_ptr[g + 1] - pad_ptr[g]) >> 3);
+        }
+        if (mode == 0) {
+            // online max / sum over the masked dense row ...
+            float m = -INFINITY, z = 0.f;
+            for (int j0 = 0; j0 < n_g; j0 += 64) {
+                const int j = j0 + lane;
+                const unsigned long long bits = *(const unsigned long long *)(mrow + (j0 >> 3));
+                const bool on = j < n_g && ((bits >> lane) & 1ull);
+                const float s = on ? row[j] : -INFINITY;
+                const float mn = fmaxf(m, s);
+                if (mn > -INFINITY) { z = z * expf(m - mn) + (on ? expf(s - mn) : 0.f); m = mn; }
+            }
+            // ... and this row's remainder edges (score on the fly: lanes over the head's channels)
+            const int eb = irr_ptr[node], ee = irr_ptr[node + 1];
+            const float *qp = qkvs + (size_t)node * 4 * HC + (size_t)h * C;
+            float mi = -INFINITY, zi = 0.f;
+            for (int e = eb; e < ee; ++e) {
+                const float *kp = qkvs + (size_t)irr_src[e] * 4 * HC + HC + (size_t)h * C;
+                float s = 0.f;
+                for (int c = lane; c < C; c += 64) s = fmaf(qp[c], kp[c], s);
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                s *= scale;
+                const float mn = fmaxf(mi, s);
+                zi = zi * expf(mi - mn) + expf(s - mn);
+                mi = mn;
+            }
+            // merge the lanes' partial (m, z) of the dense part, then the remainder's
+            for (int o = 32; o > 0; o >>= 1) {
+                const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
+                const float mn = fmaxf(m, m2);
+                if (mn > -INFINITY) { z = z * expf(m - mn) + z2 * expf(m2 - mn); m = mn; }
+            }
+            {
+                const float mn = fmaxf(m, mi);
+                if (mn > -INFINITY) { z = (m > -INFINITY ? z * expf(m - mn) : 0.f) + (mi > -INFINITY ? zi * expf(mi - mn) : 0.f); m = mn; }
+            }
+            const float inv = (m > -INFINITY) ? 1.0f / (z + 1e-16f) : 0.f;
+            const float mfin = (m > -INFINITY) ? m : 0.f;
+            for (int j0 = 0; j0 < n_g; j0 += 64) {
+                const int j = j0 + lane;
+                const unsigned long long bits = *(const unsigned long long *)(mrow + (j0 >> 3));
+                if (j < n_g) row[j] = ((bits >> lane) & 1ull) ? expf(row[j] - mfin) * inv : 0.f;
+            }
+            if (lane == 0) { stats[((size_t)node * H + h) * 2] = mfin; stats[((size_t)node * H + h) * 2 + 1] = inv; }
+        } else if (mode == 2) {
+            float D = 0.f;
+            if (real) {
+                const float *drow = dP + poff[node_graph[node]] + ((size_t)h * n_g + i) * ldp;
+                for (int j = lane; j < n_g; j += 64) D = fmaf(row[j], drow[j], D);
+                for (int o = 32; o > 0; o >>= 1) D += __shfl_xor(D, o);
+            }
+            if (lane == 0) Dd[(size_t)node * H + h] = D;
+        } else if (real) {
+            float *drow = dP + poff[node_graph[node]] + ((size_t)h * n_g + i) * ldp;
+            const float D = Dd[(size_t)node * H + h];
+            for (int j = lane; j < n_g; j += 64) drow[j] = row[j] * (drow[j] - D);
+        }
+    }
+}
+
+// o[i, :] += sum over i's remainder edges of p_e v_src, p_e = exp(s_e - m_i) inv_i from the combined statistics.  Wave per
+// destination, lane = EPL contiguous channels of the H*C-wide rows (8 lanes per head), as the CSR kernels of da_train.hip.
+template <int EPL>
+__global__ __launch_bounds__(256) void k_attn_irr_fwd(int n_nodes, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
+                                                      int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ stats,
+                                                      float *__restrict__ o, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (i >= n_nodes) return;
+    const int beg = irr_ptr[i], end = irr_ptr[i + 1];
+    if (beg == end) return;
+    const size_t ld = (size_t)4 * HC;
+    const int off = lane * EPL, head = lane >> 3;
+    float q[EPL], acc[EPL];
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) { q[x] = qkvs[(size_t)i * ld + off + x] * scale; acc[x] = 0.f; }
+    const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
+    for (int e = beg; e < end; ++e) {
+        const float *kp = qkvs + (size_t)irr_src[e] * ld + HC + off;
+        const float *vp = kp + HC;
+        float s = 0.f;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kp[x], s);
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        const float pe = expf(s - m) * inv;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vp[x], acc[x]);
+    }
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) o[(size_t)i * HC + off + x] += acc[x];
+}
+
+// backward over the remainder edges, destination side: D_i total = Dd[i] (dense part, on entry) + sum_e p_e dp_e; writes
+// D_i total back, dq_i of the remainder edges into dY4 (the dense dQ GEMM ACCUMULATES on top afterwards) and the skip gradient.
+template <int EPL>
+__global__ __launch_bounds__(256) void k_attn_irr_bwd_dst(int n_nodes, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
+                                                          int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ d_o,
+                                                          const float *__restrict__ stats, float *__restrict__ dY4, float *__restrict__ Dd,
+                                                          float scale) {
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (i >= n_nodes) return;
+    const size_t ld = (size_t)4 * HC;
+    const int off = lane * EPL, head = lane >> 3;
+    float q[EPL], g[EPL], a1[EPL], a2[EPL];
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        q[x] = qkvs[(size_t)i * ld + off + x] * scale;
+        g[x] = d_o[(size_t)i * HC + off + x];
+        a1[x] = a2[x] = 0.f;
+    }
+    const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
+    float D = 0.f;
+    const int beg = irr_ptr[i], end = irr_ptr[i + 1];
+    for (int e = beg; e < end; ++e) {
+        const float *kp = qkvs + (size_t)irr_src[e] * ld + HC + off;
+        const float *vp = kp + HC;
+        float kk[EPL], s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { kk[x] = kp[x]; s = fmaf(q[x], kk[x], s); dp = fmaf(g[x], vp[x], dp); }
+        s += __shfl_xor(s, 1); dp += __shfl_xor(dp, 1);
+        s += __shfl_xor(s, 2); dp += __shfl_xor(dp, 2);
+        s += __shfl_xor(s, 4); dp += __shfl_xor(dp, 4);
+        const float pe = expf(s - m) * inv, pd = pe * dp;
+        D += pd;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { a1[x] = fmaf(pd, kk[x], a1[x]); a2[x] = fmaf(pe, kk[x], a2[x]); }
+    }
+    const float Dt = D + Dd[(size_t)i * H + head];
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        dY4[(size_t)i * ld + off + x] = (a1[x] - Dt * a2[x]) * scale;
+        dY4[(size_t)i * ld + 3 * (size_t)HC + off + x] = g[x];
+    }
+    if ((lane & 7) == 0) Dd[(size_t)i * H + head] = Dt;          // (the head's eight lanes read it above, in lockstep)
+}
+
+// source side over the remainder edges (CSR by source): dk_j, dv_j ADDED to what the dense GEMMs wrote
+template <int EPL>
+__global__ __launch_bounds__(256) void k_attn_irr_bwd_src(int n_nodes, const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_dst,
+                                                          int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ d_o,
+                                                          const float *__restrict__ stats, const float *__restrict__ Dd,
+                                                          float *__restrict__ dY4, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int j = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (j >= n_nodes) return;
+    const int beg = out_ptr[j], end = out_ptr[j + 1];
+    if (beg == end) return;
+    const size_t ld = (size_t)4 * HC;
+    const int off = lane * EPL, head = lane >> 3;
+    float kk[EPL], vv[EPL], dk[EPL], dv[EPL];
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        kk[x] = qkvs[(size_t)j * ld + HC + off + x];
+        vv[x] = qkvs[(size_t)j * ld + 2 * (size_t)HC + off + x];
+        dk[x] = dv[x] = 0.f;
+    }
+    for (int e = beg; e < end; ++e) {
+        const int i = out_dst[e];
+        float q[EPL], g[EPL], s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) {
+            q[x] = qkvs[(size_t)i * ld + off + x] * scale; g[x] = d_o[(size_t)i * HC + off + x];
+            s = fmaf(q[x], kk[x], s); dp = fmaf(g[x], vv[x], dp);
+        }
+        const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
+        const float D = Dd[(size_t)i * H + head];
+        s += __shfl_xor(s, 1); dp += __shfl_xor(dp, 1);
+        s += __shfl_xor(s, 2); dp += __shfl_xor(dp, 2);
+        s += __shfl_xor(s, 4); dp += __shfl_xor(dp, 4);
+        const float pe = expf(s - m) * inv, ds = pe * (dp - D);
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { dk[x] = fmaf(ds, q[x], dk[x]); dv[x] = fmaf(pe, g[x], dv[x]); }
+    }
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        dY4[(size_t)j * ld + HC + off + x] += dk[x];
+        dY4[(size_t)j * ld + 2 * (size_t)HC + off + x] += dv[x];
+    }
+}
+
+// zero the dk | dv columns of rows [r0, r1) (virtual rows: only the remainder kernels write them)
+__global__ __launch_bounds__(256) void k_zero_kv_grad(int r0, int r1, int HC, float *__restrict__ dY4) {
+    const size_t total = (size_t)(r1 - r0) * 2 * HC;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / (2 * HC), c = idx - r * 2 * HC;
+        dY4[((size_t)r0 + r) * 4 * HC + HC + c] = 0.f;
+    }
+}
+
+#define DA_HYB_SWITCH(C, STMT4, STMT18)                                                     \
+    switch ((C) / 8) {                                                                      \
+        case 4: STMT4; break;                                                               \
+        case 18: STMT18; break;                                                             \
+        default: set_error("hybrid training attention: unsupported head width C=%d", (C)); return 1; \
+    }
+
+// forward: o = softmax over (regular edges U remainder edges) . v + skip (+ res); P (dense part) and stats kept
+int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P, float *stats,
+                          const long long *poff, const int32_t *node_graph, hipStream_t st) {
+    const int n = g->n_nodes, nr = g->n_real, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
+    GGemm s;
+    s.A = {(float *)qkvs, 0, 4 * HC, C};
+    s.B = {(float *)qkvs + HC, 0, 4 * HC, C};
+    s.C = {P, 1, 0, 0};
+    s.transA = 0; s.transB = 1; s.dimM = 0; s.dimN = 0; s.dimK = C; s.alpha = 1.0f / sqrtf((float)C); s.accumulate = 0;
+    s.H = H; s.gp = g->graph_ptr; s.poff = poff;
+    int rc;
+    if ((rc = ggemm(s, G, H, mx, st))) return rc;
+    k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(0, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
+                                                                    (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs, P,
+                                                                    nullptr, stats, nullptr);
+    k_init_out<<<gridsz((size_t)n * HC), 256, 0, st>>>(n, HC, qkvs, res, o);
+    DA_LAUNCH_CHECK();
+    GGemm pv;
+    pv.A = {P, 1, 0, 0};
+    pv.B = {(float *)qkvs + 2 * HC, 0, 4 * HC, C};
+    pv.C = {o, 0, HC, C};
+    pv.transA = 0; pv.transB = 0; pv.dimM = 0; pv.dimN = C; pv.dimK = 0; pv.alpha = 1.0f; pv.accumulate = 1;
+    pv.H = H; pv.gp = g->graph_ptr; pv.poff = poff;
+    if ((rc = ggemm(pv, G, H, mx, st))) return rc;
+    const float scale = 1.0f / sqrtf((float)C);
+    const int grid = (int)(((size_t)n * 64 + 255) / 256);
+    DA_HYB_SWITCH(C, (k_attn_irr_fwd<4><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)),
+                  (k_attn_irr_fwd<18><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)))
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward: dY4 = [dq | dk | dv | d_o]
+int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
+                          const float *stats, float *Dd, float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st) {
+    const int n = g->n_nodes, nr = g->n_real, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
+    const float scale = 1.0f / sqrtf((float)C);
+    const int grid = (int)(((size_t)n * 64 + 255) / 256);
+    int rc;
+    GGemm q;
+    q.H = H; q.gp = g->graph_ptr; q.poff = poff; q.accumulate = 0;
+    // dV (regular edges) = P^T dO ; virtual rows' dk | dv start from zero
+    q.A = {(float *)P, 1, 0, 0}; q.B = {(float *)d_o, 0, HC, C}; q.C = {dY4 + 2 * HC, 0, 4 * HC, C};
+    q.transA = 1; q.transB = 0; q.dimM = 0; q.dimN = C; q.dimK = 0; q.alpha = 1.0f;
+    if ((rc = ggemm(q, G, H, mx, st))) return rc;
+    if (n > nr) { k_zero_kv_grad<<<gridsz((size_t)(n - nr) * 2 * HC), 256, 0, st>>>(nr, n, HC, dY4); DA_LAUNCH_CHECK(); }
+    // dP = dO V^T ; D (dense part)
+    q.A = {(float *)d_o, 0, HC, C}; q.B = {(float *)qkvs + 2 * HC, 0, 4 * HC, C}; q.C = {dP, 1, 0, 0};
+    q.transA = 0; q.transB = 1; q.dimM = 0; q.dimN = 0; q.dimK = C; q.alpha = 1.0f;
+    if ((rc = ggemm(q, G, H, mx, st))) return rc;
+    k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(2, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
+                                                                    (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs,
+                                                                    (float *)P, dP, nullptr, Dd);
+    // remainder, destination side: D total, dq of the remainder edges, skip gradient
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)),
+                  (k_attn_irr_bwd_dst<18><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)))
+    // dS = P o (dP - D) over the regular edges
+    k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(1, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
+                                                                    (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs,
+                                                                    (float *)P, dP, nullptr, Dd);
+    DA_LAUNCH_CHECK();
+    // dQ += scale dS K (on top of the remainder's dq) ; dK = scale dS^T Q
+    q.A = {dP, 1, 0, 0}; q.B = {(float *)qkvs + HC, 0, 4 * HC, C}; q.C = {dY4, 0, 4 * HC, C};
+    q.transA = 0; q.transB = 0; q.dimM = 0; q.dimN = C; q.dimK = 0; q.alpha = scale; q.accumulate = 1;
+    if ((rc = ggemm(q, G, H, mx, st))) return rc;
+    q.A = {dP, 1, 0, 0}; q.B = {(float *)qkvs, 0, 4 * HC, C}; q.C = {dY4 + HC, 0, 4 * HC, C};
+    q.transA = 1; q.transB = 0; q.dimM = 0; q.dimN = C; q.dimK = 0; q.alpha = scale; q.accumulate = 0;
+    if ((rc = ggemm(q, G, H, mx, st))) return rc;
+    // remainder, source side: += dk, dv
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4><<<grid, 256, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
+                  (k_attn_irr_bwd_src<18><<<grid, 256, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace da

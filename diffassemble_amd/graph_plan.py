@@ -84,6 +84,22 @@ class GraphPlan:
     def with_source_csr(self):
         """Add the by-source orientation of the same edge list (da_graph.out_ptr / out_dst), which
         the attention backward walks to form dK / dV without atomics."""
+        import os
+        if self.dense and os.environ.get("DA_TRAIN_DISABLE_DENSE") != "1":
+            return self                        # complete graphs train on the grouped GEMMs: no edge list is walked
+        if self.out_ptr is None and self.hybrid:
+            # hybrid graphs: only the REMAINDER edges are walked (the regular ones run as adjacency-masked grouped GEMMs,
+            # da_train_dense.hip), so the by-source orientation is built from irr_row_ptr / irr_col_src alone -- the
+            # 15 M regular edges of a Batch of 60 % Exphander graphs are never sorted
+            dev = self.irr_col_src.device
+            cnt = (self.irr_row_ptr[1:] - self.irr_row_ptr[:-1]).to(torch.int64)
+            dst = torch.repeat_interleave(torch.arange(self.n_nodes, device=dev), cnt)
+            src = self.irr_col_src.to(torch.int64)
+            perm = torch.argsort(src, stable=True)
+            ptr = torch.zeros(self.n_nodes + 1, dtype=torch.int64, device=dev)
+            ptr[1:] = torch.cumsum(torch.bincount(src, minlength=self.n_nodes), 0)
+            self.out_ptr = ptr.to(torch.int32)
+            self.out_dst = dst[perm].to(torch.int32).contiguous()
         if self.out_ptr is None:
             src, dst = self.edge_index[0], self.edge_index[1]
             perm = torch.argsort(src, stable=True)

@@ -129,8 +129,17 @@ class TrainEngine:
         assign, ...): the caller rebuilds the engine."""
         return all(p.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
 
+    @staticmethod
+    def _cg(plan: GraphPlan):
+        """da_graph of a training plan: complete and hybrid graphs run on the grouped-GEMM attention (da_train_dense.hip) and
+        never walk the full edge list, so its CSR is not built for them (unless DA_TRAIN_DISABLE_DENSE=1 forces the edge-list
+        kernels); hybrid plans carry the by-source orientation of their REMAINDER edges in out_ptr / out_dst."""
+        import os
+        need_csr = not (plan.dense or plan.hybrid) or os.environ.get("DA_TRAIN_DISABLE_DENSE") == "1"
+        return plan.c_struct(need_csr)
+
     def _workspace(self, plan: GraphPlan):
-        g = plan.c_struct()
+        g = self._cg(plan)
         need = int(self.lib.da_train_workspace_bytes(C.byref(self.w), C.byref(g)))
         if need == 0:
             _lib.check(1)
@@ -146,7 +155,7 @@ class TrainEngine:
         assert x.shape == (plan.n_real, self.c_in) and feats.shape == (plan.n_real, self.F), (x.shape, feats.shape)
         out = torch.empty((plan.n_real, self.c_out), dtype=torch.float32, device=self.device)
         ws = self._workspace(plan)
-        g = plan.c_struct()
+        g = self._cg(plan)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.da_train_forward(C.byref(self.w), C.byref(g), _lib.ptr(x), _lib.ptr(t), _lib.ptr(feats),
                                                  _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self.device)))
@@ -166,7 +175,7 @@ class TrainEngine:
         d_out = d_out.detach().to(self.device, torch.float32).contiguous()
         d_feats = torch.empty((plan.n_real, self.F), dtype=torch.float32, device=self.device) if want_dfeats else None
         ws = self._workspace(plan)
-        g = plan.c_struct()
+        g = self._cg(plan)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.da_train_backward(C.byref(self.w), C.byref(self.gw), C.byref(g), _lib.ptr(x), _lib.ptr(t),
                                                   _lib.ptr(d_out), _lib.ptr(d_feats), _lib.ptr(ws), ws.numel(),

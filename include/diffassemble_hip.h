@@ -105,7 +105,10 @@ typedef struct da_graph {
     const int32_t *pad_ptr;   /* [n_graphs + 1] or NULL                                    */
     const int32_t *row_map;   /* [n_nodes] or NULL                                         */
     /* training only (da_train_backward): the same edges grouped by SOURCE node, i.e. the
-     * outgoing edges of node j are out_dst[out_ptr[j] .. out_ptr[j+1]); multi-edges kept.  */
+     * outgoing edges of node j are out_dst[out_ptr[j] .. out_ptr[j+1]); multi-edges kept.
+     * Hybrid graphs (below) train on adjacency-masked grouped GEMMs over their regular edges and
+     * walk only the REMAINDER edges: out_ptr / out_dst then hold the by-source orientation of
+     * irr_row_ptr / irr_col_src (out_dst may be empty), and row_ptr / col_src may be NULL.   */
     const int32_t *out_ptr;   /* [n_nodes + 1] or NULL                                     */
     const int32_t *out_dst;   /* [n_edges] or NULL                                         */
     /* hybrid mode (inference): for graphs that are neither complete nor small -- the Exphander

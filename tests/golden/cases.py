@@ -42,6 +42,12 @@ LOOPS3D = [
 TRAIN2D = [
     dict(name="train_rot144_g2", base="rot144_g2_sharp", mean="EPSILON", seed=11),
 ]
+# golden_v4.npz (make_golden_v4.py): the scripted TRAINING configuration -- exophormer arch on Exphander graphs with virtual
+# nodes (train_celeba_rot.sh:4-15) -- loss + every live gradient of the reference's p_losses
+TRAIN2D_V4 = [
+    dict(name="train_exo_expander_d6", base="exo_expander_d6", mean="START_X", seed=12),
+    dict(name="train_exo144_v8_g2", base="exo144_v8_g2", mean="EPSILON", seed=13),
+]
 # golden_v2.npz (make_golden_v2.py): the BENCHED sizes -- 900-piece dense (headline) and the scripted
 # Exphander degree d = 539 ("60 %", train_celeba_rot.sh:12) -- and the reference's own greedy_cost_assignment
 FWD2D_BIG = [
@@ -179,6 +185,11 @@ def load_golden():
 
 def load_golden2():
     return np.load(GOLDEN2_FILE)
+
+
+def load_golden4():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v4.npz"))
 
 
 def load_golden3():

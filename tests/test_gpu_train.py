@@ -186,6 +186,50 @@ def test_p_losses_gradients_match_reference_fixture(dev, golden, tr):
     assert n >= 28
 
 
+@pytest.mark.parametrize("path", ["edge_list", "hybrid"])
+@pytest.mark.parametrize("tr", C.TRAIN2D_V4, ids=lambda s: s["name"])
+def test_exophormer_p_losses_gradients_match_reference_fixture(dev, monkeypatch, tr, path):
+    """The scripted training configuration (exophormer arch, virtual nodes, Exphander edges; train_celeba_rot.sh:4-15)
+    against the reference's OWN p_losses + backward (tests/golden/golden_v4.npz, make_golden_v4.py): loss, head and digests
+    of all 46 live gradients (the virtual-node embedding included), through the edge-list kernels and through the hybrid
+    path (adjacency-masked grouped GEMMs + CSR remainder, forced on these small graphs)."""
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    from diffassemble_amd.graph_plan import build_plan
+    golden4 = C.load_golden4()
+    monkeypatch.setenv("DA_HYBRID", "force" if path == "hybrid" else "off")
+    spec = C.by_name(tr["base"])
+    case = C.build_case(spec)
+    assert bool(build_plan(case["edge_index"].to(dev), case["batch"].to(dev), spec["V"]).hybrid) == (path == "hybrid")
+    m = GNN_Diffusion(steps=spec["steps"], sampling="DDIM", rotation=True, visual_pretrained=False,
+                      model_mean_type=getattr(ModelMeanType, tr["mean"]), architecture=spec["arch"], virt_nodes=spec["V"])
+    m.model.load_state_dict(case["sd"], strict=False)
+    m = m.to(dev).train()
+    rng = np.random.default_rng(tr["seed"])
+    noise = torch.from_numpy(rng.standard_normal(tuple(case["x"].shape)).astype(np.float32)).to(dev)
+    loss = m.p_losses(case["x"].to(dev), case["t"].to(dev), noise=noise, loss_type="huber", cond=None,
+                      edge_index=case["edge_index"].to(dev), batch=case["batch"].to(dev), patch_feats=case["feats"].to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(loss, golden4[f"{tr['name']}/loss"]) < 1e-5
+
+    def stats(g):
+        g = g.double()
+        return torch.stack([g.sum(), g.abs().sum(), (g * g).sum()])
+
+    live = {k: p for k, p in m.model.named_parameters() if f"{tr['name']}/grad_head/{k}" in golden4.files}
+    assert len(live) == 46 and "gnn_backbone.virt_node_embedding.weight" in live
+    floor = 1e-4 * max(float(p.grad.abs().max()) for p in live.values())
+    for k, p in live.items():
+        ref = torch.from_numpy(golden4[f"{tr['name']}/grad_head/{k}"]).double()
+        got = p.grad.flatten()[: ref.numel()].double().cpu()
+        assert float((got - ref).abs().max()) / max(float(ref.abs().max()), floor) < GTOL, k
+        st_ref = golden4[f"{tr['name']}/grad_stats/{k}"]
+        st = stats(p.grad.cpu())
+        if float(st_ref[1]) > floor * p.numel() * 1e-2:
+            assert abs(float(st[1]) - float(st_ref[1])) / float(st_ref[1]) < GTOL, k
+            assert abs(float(st[2]) - float(st_ref[2])) / float(st_ref[2]) < 2 * GTOL, k
+
+
 @pytest.mark.parametrize("which", ["reference", "fused"])
 def test_training_step_with_optimizer_then_inference(dev, which):
     """One optimizer step with the reference's optimizer (Adafactor, spatial_diffusion.py:701-705) on the
@@ -307,6 +351,57 @@ def test_csr_training_path_on_complete_graphs_subprocess():
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "3 passed" in r.stdout
+
+
+def test_hybrid_training_path_forced_on_small_graphs_subprocess():
+    """The scripted training configuration (train_celeba_rot.sh:4-15: exophormer, Exphander edges, virtual nodes) trains on
+    the HYBRID attention: adjacency-masked grouped GEMMs over the regular edges + CSR remainder, one softmax over both
+    (da_train_dense.hip).  DA_HYBRID=force takes the small fixture graphs -- virtual-node quirk edges, duplicated pairs,
+    cross-graph pairs, an odd-degree expander without virtual nodes -- through it: forward, loss and every gradient against
+    the oracle's autograd, like the edge-list path."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DA_HYBRID="force")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
+                        "test_backward_matches_oracle_autograd and (exo144_v8_g2 or exo_expander_d6 or tr_expander_d7)"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "3 passed" in r.stdout
+
+
+def test_hybrid_training_at_900_pieces_equals_the_edge_list_path(dev, monkeypatch):
+    """One 900-piece Exphander puzzle of the scripted degree (d = 539) with 8 virtual nodes: the plan goes hybrid by itself;
+    loss and the whole flat gradient buffer against the SAME step through the edge-list kernels (DA_HYBRID=off), which
+    test_backward_matches_oracle_autograd ties to the oracle."""
+    from oracle import weights as W
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    from diffassemble_amd.graph_plan import build_plan
+    n, d, V = 900, 539, 8
+    torch.manual_seed(0)
+    sd = W.make_denoiser_state(100, 4, 4, arch="exophormer", virt_nodes=V, seed=61, qk_gain=3.0)
+    x, feats = W.make_inputs(n, 4, 1088, 61)
+    ei = W.random_regular_edge_index(n, d - (d * n) % 2, np.random.default_rng(9)).to(dev)
+    batch = torch.zeros(n, dtype=torch.long, device=dev)
+    t = torch.full((n,), 40, dtype=torch.long, device=dev)
+    noise = torch.from_numpy(np.random.default_rng(10).standard_normal((n, 4)).astype(np.float32)).to(dev)
+    res = {}
+    for mode in ("auto", "off"):
+        monkeypatch.setenv("DA_HYBRID", mode)
+        m = GNN_Diffusion(steps=100, sampling="DDIM", rotation=True, visual_pretrained=False, model_mean_type=ModelMeanType.EPSILON,
+                          architecture="exophormer", virt_nodes=V)
+        m.model.load_state_dict(sd, strict=False)
+        m = m.to(dev).train()
+        te = m.model.train_engine()
+        assert bool(build_plan(ei, batch, V).hybrid) == (mode == "auto")
+        loss = m.p_losses(x.to(dev), t, noise=noise, loss_type="huber", cond=None, edge_index=ei, batch=batch, patch_feats=feats.to(dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (float(loss), te.flat_grad.detach().clone())
+    assert abs(res["auto"][0] - res["off"][0]) < 1e-5 * abs(res["off"][0])
+    ga, go = res["auto"][1], res["off"][1]
+    assert float(go.abs().max()) > 0
+    assert rel(ga, go) < 2e-4, rel(ga, go)
 
 
 # ---------------------------------------------------------------------------- data parallelism through the module surface

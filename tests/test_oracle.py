@@ -272,6 +272,32 @@ def test_p_losses_and_gradients_match_reference(golden, tr):
     assert n >= 28
 
 
+@pytest.mark.parametrize("tr", C.TRAIN2D_V4, ids=lambda s: s["name"])
+def test_exophormer_p_losses_and_gradients_match_reference(tr):
+    """The oracle's training step on the SCRIPTED configuration (exophormer arch, virtual nodes, Exphander edges) against the
+    reference's own p_losses + backward (golden_v4.npz, make_golden_v4.py): pins the oracle where the hybrid training
+    kernels are checked against it (tests/test_gpu_train.py)."""
+    g4 = C.load_golden4()
+    spec = C.by_name(tr["base"])
+    case = C.build_case(spec)
+    sd = {k: v.clone().requires_grad_(True) for k, v in case["sd"].items()}
+    sch = DF.make_schedule(spec["steps"])
+    rng = np.random.default_rng(tr["seed"])
+    noise = torch.from_numpy(rng.standard_normal(tuple(case["x"].shape)).astype(np.float32))
+    loss = DF.p_losses(sd, sch, case["x"], case["t"], noise, case["edge_index"], case["feats"], case["batch"], tr["mean"],
+                       spec["arch"], spec["V"])
+    loss.backward()
+    assert rel_err(loss.detach(), g4[f"{tr['name']}/loss"]) < 1e-5
+    n = 0
+    for k, p in sd.items():
+        key = f"{tr['name']}/grad_head/{k}"
+        if key in g4.files:
+            assert rel_err(p.grad.flatten()[:64], g4[key]) < 1e-3, k
+            assert rel_err(stats(p.grad), g4[f"{tr['name']}/grad_stats/{k}"]) < 1e-3, k
+            n += 1
+    assert n == 46
+
+
 # ------------------------------------------------------------------ benched sizes (golden_v2.npz, make_golden_v2.py)
 @pytest.mark.parametrize("spec", C.FWD2D_BIG, ids=lambda s: s["name"])
 def test_oracle_at_the_benched_sizes_vs_reference_fixture(spec):
