@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""profiles/r02/r02_pmc_traffic_<tag>.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, summarised per kernel by
-profiles/rocpd_pmc.py) -> profiles/r02/pmc_traffic.json, the per-kernel-CLASS bytes-per-launch table bench.py attaches to
+"""profiles/<round>/<round>_pmc_traffic_<tag>.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, summarised per kernel by
+profiles/rocpd_pmc.py) -> profiles/<round>/pmc_traffic.json  (round = argv[1], default r03), the per-kernel-CLASS bytes-per-launch table bench.py attaches to
 its roofline entries.  Values stay in the counters' KiB; bench.py applies the gfx950 correction (FETCH_SIZE x 2,
 MI355X_MICROARCH.md) when it converts."""
 import json
@@ -9,7 +9,9 @@ import re
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 CLASS = [  # (regex on the kernel name, class)
+    (r"k_attn_opt", "attn_hidden"), (r"k_attn_dual<144", "attn_last"), (r"k_attn_dual<32", "attn_hidden"),
     (r"k_attn_dense<unsigned short, 32,", "attn_hidden"), (r"k_attn_dense<unsigned short, 144,", "attn_last"),
     (r"k_attn_csr<unsigned short, 4>", "attn_hidden"), (r"k_attn_csr<unsigned short, 18>", "attn_last"),
     (r"k_attn_csr_cont", "attn_hidden"),
@@ -47,8 +49,8 @@ def parse(path, want_csr):
 out = {"_comment": "KiB per launch, averaged over the launches of a kernel class in `python bench.py --steps 20 --warmup 2` "
                    "(tools/collect_profiles.sh); FETCH_SIZE is NOT yet doubled here"}
 for tag, (key, G, want_csr) in RUNS.items():
-    p = os.path.join(ROOT, "profiles", "r02", f"r02_pmc_traffic_{tag}.txt")
+    p = os.path.join(ROOT, "profiles", ROUND, f"{ROUND}_pmc_traffic_{tag}.txt")
     if os.path.exists(p):
         out.setdefault(key, {}).setdefault("bf16", {})[str(G)] = parse(p, want_csr)
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", ROUND, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
