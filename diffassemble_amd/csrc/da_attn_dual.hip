@@ -51,7 +51,7 @@ struct AttnDualParams {
     void *out;                      // folded: [H][n_rows][CV] normalised per-head rows; else [N][H*C] = act(attn + skip)
     const int32_t *graph_ptr, *pad_ptr;
     int n_pad, H, nqt, act, nodiag, n_rows;
-    int stagger, stagger_shift;     // experiment: delay half of the workgroups at start (cycles / which bit of the tile index)
+    int tpw;                        // query tiles per workgroup (consecutive tiles of one (graph, head); see the kernel)
     unsigned long long *prof;       // DA_DUAL_PROBE builds: per-workgroup cycle breakdown of wave 0 (tools/attn_bench)
 };
 
@@ -95,21 +95,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
     // the query tiles of one (graph, head) run back to back on it, sharing its L2 copy of K / V
     const int bid = blockIdx.x;
     const int h = bid & 7, s_ = bid >> 3;
-    const int qt = s_ % p.nqt, g = s_ / p.nqt;
+    // a workgroup owns p.tpw CONSECUTIVE query tiles of one (graph, head) and walks them with the K / V ring running across the
+    // tile boundaries (the next tile streams the same key blocks again): the per-tile prologue -- graph offsets, first DMA
+    // landing -- is paid once, and with tpw = all tiles of a graph the grid is exactly one round of workgroups at 64 puzzles
+    const int nchunk = (p.nqt + p.tpw - 1) / p.tpw;
+    const int chunk = s_ % nchunk, g = s_ / nchunk;
+    const int qt_b = chunk * p.tpw, qt_e = min(p.nqt, qt_b + p.tpw);
     const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
     const int nslab_g = (n_g + 31) >> 5;
-    const int s_lo = qt * nslab_g / p.nqt, s_hi = (qt + 1) * nslab_g / p.nqt;      // balanced split of the graph's slabs (<= 8 per tile)
-    if (s_lo >= s_hi) return;
-    if (p.stagger > 0 && ((s_ >> p.stagger_shift) & 1)) {
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(32);
-    }
+    int n_active = 0;                                            // tiles of this chunk that own at least one slab
+    for (int qt = qt_b; qt < qt_e; ++qt) n_active += (qt * nslab_g / p.nqt < (qt + 1) * nslab_g / p.nqt) ? 1 : 0;
+    if (n_active == 0) return;
 
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     DA_DUAL_DBG(unsigned long long c_sync = 0, c_r1 = 0, c_r2 = 0;)
     DA_DUAL_TICK(t_start);
-    const bool wave_on = s_lo + wid < s_hi, two = s_lo + wid + 4 < s_hi;
     const size_t np = (size_t)p.n_pad;
 
     // ---- LDS-DMA plan: instruction q (1 KB) of a block is issued by wave q % 4; lane -> 16-byte slot q * 64 + lane
@@ -152,38 +153,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
     const int vbase = CF::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
-    // Q fragments of both slabs stay in registers (rows beyond the graph zeroed: their scores stay finite)
-    int q0[2], qidx[2];
-    u32x4 qf[2][CF::NCH];
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        const int slab = min(s_lo + wid + 4 * sl, s_hi - 1);
-        q0[sl] = slab * 32;
-        qidx[sl] = q0[sl] + i;
-        const unsigned char *qrow = (const unsigned char *)p.Q + ((size_t)h * np + pad0 + qidx[sl]) * CF::ROWB;
-#pragma unroll
-        for (int ch = 0; ch < CF::NCH; ++ch) {
-            qf[sl][ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
-            if (qidx[sl] >= n_g) qf[sl][ch] = (u32x4){0u, 0u, 0u, 0u};
-        }
-    }
-
     // ---- block-level sync.  sync_block(blk) runs before the K fragments of block `blk` are read (for blk >= 1 that is the
     // top of iteration blk - 1).  Block `blk` must have landed for every wave: loads retire in order and this wave has issued
     // blocks up to `issued - 1`, so "at most (issued - 1 - blk) * myn of my DMA instructions outstanding" says my share is in
     // LDS; the barrier says everybody's is.  The same barrier says every wave has finished iteration blk - 2 (K fragments of
     // block blk - 2 consumed, its V fragments fenced before its PV products), so the stage of block blk - 2 is refilled right
     // after it; blocks blk - 1 (V reads) and blk (K reads) are the two in use.  In flight behind them: NST - 2 blocks.
+    // Block indices are GLOBAL over the chunk's tiles (tile k streams blocks k nb .. (k + 1) nb - 1, source block = index % nb).
+    const int total = n_active * nb;
     int issued = 0;
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
-        if (st < nb) { issue(st, st); ++issued; }
+        if (st < total) { issue(st % nb, st); ++issued; }
     auto sync_block = [&](int blk) {
         if (CF::NI % 4 == 0 && issued - 1 - blk == NST - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 3) * (CF::NI / 4)) : "memory");      // steady state
         else wait_vm((issued - 1 - blk) * myn);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (blk > 0 && issued < nb) { issue(issued, issued % NST); ++issued; }      // block blk + NST - 2 -> stage of block blk - 2
+        if (issued < total && issued - NST <= blk - 2) { issue(issued % nb, issued % NST); ++issued; }      // refills the stage of block blk - 2
     };
 
     // Softmax of one 32-key block of one slab.  s holds the scores in log2 units (Q is pre-scaled); p goes out packed as the
@@ -228,6 +215,30 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
         }
         return acc[0] + acc[1];
     };
+
+    int tile_idx = 0;
+    for (int qt = qt_b; qt < qt_e; ++qt) {
+    const int s_lo = qt * nslab_g / p.nqt, s_hi = (qt + 1) * nslab_g / p.nqt;      // balanced split of the graph's slabs (<= 8 per tile)
+    if (s_lo >= s_hi) continue;
+    const int gb0 = tile_idx * nb;                               // global index of this tile's key block 0
+    const bool first_tile = tile_idx == 0, more = tile_idx + 1 < n_active;
+    ++tile_idx;
+    const bool wave_on = s_lo + wid < s_hi, two = s_lo + wid + 4 < s_hi;
+    // Q fragments of both slabs stay in registers (rows beyond the graph zeroed: their scores stay finite)
+    int q0[2], qidx[2];
+    u32x4 qf[2][CF::NCH];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int slab = min(s_lo + wid + 4 * sl, s_hi - 1);
+        q0[sl] = slab * 32;
+        qidx[sl] = q0[sl] + i;
+        const unsigned char *qrow = (const unsigned char *)p.Q + ((size_t)h * np + pad0 + qidx[sl]) * CF::ROWB;
+#pragma unroll
+        for (int ch = 0; ch < CF::NCH; ++ch) {
+            qf[sl][ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
+            if (qidx[sl] >= n_g) qf[sl][ch] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
 
     auto run = [&](auto tag) {
         constexpr int NS = decltype(tag)::value;
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
         // at 256 B/clk the LDS carries both slabs' reads of a block with room to spare -- keeping the nine fragments of a
         // C = 144 block in registers for the second slab cost 36 VGPRs and spilled)
         auto chain = [&](int blk, int sl) {
-            const unsigned char *kp = smem + (blk % NST) * CF::STAGE + koff;
+            const unsigned char *kp = smem + ((gb0 + blk) % NST) * CF::STAGE + koff;
             u32x4 kf[CF::NCH];
 #pragma unroll
             for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(kp + ch * 32);
@@ -288,17 +299,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
             return s;
         };
         f32x16 sA, sB;
-        // ---- prologue: block 0 landed -> S(0, slab 0)
-        sync_block(0);
+        // ---- prologue: block 0 landed (a later tile's first block was synced under the previous tile's last block) -> S(0, slab 0)
+        if (first_tile) sync_block(gb0);
         sA = chain(0, 0);
 
         // one key block, generic form (any mode, masks, last block): (NS = 2) S(b, slab 1), softmax of S(b, slab 0), its PV,
         // S(b + 1, slab 0), softmax of S(b, slab 1), its PV; (NS = 1) S(b + 1), softmax of S(b), PV
         auto block = [&](int b, auto next_tag) {
             constexpr bool HAS_NEXT = decltype(next_tag)::value != 0;
-            if (HAS_NEXT) sync_block(b + 1);
+            if (HAS_NEXT || more) sync_block(gb0 + b + 1);            // (the tile's last block: keeps the ring running into the next tile)
             const int key0 = b * CF::BK;
-            const unsigned vb = lds0 + (unsigned)((b % NST) * CF::STAGE + vbase);
+            const unsigned vb = lds0 + (unsigned)(((gb0 + b) % NST) * CF::STAGE + vbase);
             u32x2 vlo[2], vhi[2];
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
@@ -371,10 +382,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
                 if (gen[0] || gen[1]) break;
                 const int key0 = b * CF::BK;
                 DA_DUAL_TICK(t0_);
-                sync_block(b + 1);
+                sync_block(gb0 + b + 1);
                 DA_DUAL_TICK(t1_);
-                unsigned kaddr = lds0 + (unsigned)((b % NST) * CF::STAGE + koff);
-                const unsigned vaddr = lds0 + (unsigned)((b % NST) * CF::STAGE + vbase);
+                unsigned kaddr = lds0 + (unsigned)(((gb0 + b) % NST) * CF::STAGE + koff);
+                const unsigned vaddr = lds0 + (unsigned)(((gb0 + b) % NST) * CF::STAGE + vbase);
                 mask_diag(sA, 0, key0);
                 if constexpr (C == 144) DA_DUAL_R1_C144(); else DA_DUAL_R1_C32();
                 {
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
                 }
                 DA_DUAL_TICK(t2_);
                 mask_diag(sB, 1, key0);
-                kaddr = lds0 + (unsigned)(((b + 1) % NST) * CF::STAGE + koff);
+                kaddr = lds0 + (unsigned)(((gb0 + b + 1) % NST) * CF::STAGE + koff);
                 if constexpr (C == 144) DA_DUAL_R2_C144(); else DA_DUAL_R2_C32();
                 {
                     const float tot = l[1] + accv;
@@ -443,12 +454,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
     else if (wave_on) run(SlabTag<1>());
     else {
         // no slab (tile with fewer than four): this wave only streams its share of K / V and keeps the barriers
-        sync_block(0);
-        for (int b = 0; b + 1 < nb; ++b) sync_block(b + 1);
+        if (first_tile) sync_block(gb0);
+        for (int b = 0; b + 1 < nb; ++b) sync_block(gb0 + b + 1);
+        if (more) sync_block(gb0 + nb);
         if (!FOLD) dma_barrier();
     }
-    DA_DUAL_DBG(if (p.prof && tid == 0) { DA_DUAL_TICK(t_end); unsigned long long *o = p.prof + 4 * blockIdx.x; o[0] = t_end - t_start; o[1] = c_sync; o[2] = c_r1; o[3] = c_r2; })
-    if (FOLD) return;
+    if (FOLD) continue;
     {
         // + skip, activation, 16-byte coalesced stores of whole output rows
         constexpr int RSOF = CV + 4;
@@ -491,6 +502,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
             }
         }
     }
+    }   // tiles of this workgroup
+    DA_DUAL_DBG(if (p.prof && tid == 0) { DA_DUAL_TICK(t_end); unsigned long long *o = p.prof + 4 * blockIdx.x; o[0] = t_end - t_start; o[1] = c_sync; o[2] = c_r1; o[3] = c_r2; })
 }
 
 template <int C, int CV, int NST, bool FOLD>
@@ -504,7 +517,15 @@ static int launch_dual_t(AttnDualParams p, int n_graphs, int max_nodes, hipStrea
     }
     const int nslab = (max_nodes + 31) / 32;
     p.nqt = (nslab + 7) / 8;
-    k_attn_dual<C, CV, NST, FOLD><<<p.nqt * p.H * n_graphs, 256, lds, st>>>(p);
+    // tiles per workgroup: all tiles of a (graph, head) when that still fills the chip's 512 workgroup slots (two per CU),
+    // else one (small Batches need the parallelism more than the shared prologue); the staging epilogue of the un-folded
+    // instance reuses the ring, so it keeps one tile per workgroup.  DA_DUAL_TPW overrides (A/B runs).
+    static int tpw_env = -1;
+    if (tpw_env < 0) { const char *e = getenv("DA_DUAL_TPW"); tpw_env = e ? atoi(e) : 0; }
+    p.tpw = 1;
+    if (FOLD) p.tpw = tpw_env > 0 ? tpw_env : ((size_t)p.H * n_graphs >= 512 ? p.nqt : ((size_t)p.H * n_graphs * 2 >= 512 && p.nqt >= 2 ? (p.nqt + 1) / 2 : 1));
+    const int nchunk = (p.nqt + p.tpw - 1) / p.tpw;
+    k_attn_dual<C, CV, NST, FOLD><<<nchunk * p.H * n_graphs, 256, lds, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -517,7 +538,6 @@ int launch_attn_dual(const DenseLayout &L, int heads, int C, int n_graphs, int m
     p.Q = L.Q; p.K = L.K; p.V = L.Vt; p.S = L.S; p.out = fold ? fold->out : out;
     p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.nqt = 0; p.act = act; p.nodiag = nodiag;
     p.n_rows = fold ? fold->n_rows : 0;
-    { const char *e = getenv("DA_DUAL_STAGGER"); p.stagger = e ? atoi(e) : 0; e = getenv("DA_DUAL_STAGGER_SHIFT"); p.stagger_shift = e ? atoi(e) : 0; }
     { const char *e = getenv("DA_DUAL_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     if (n_graphs <= 0 || max_graph_nodes <= 0) return 0;
     if (fold && C == 144 && fold->cv == 32) return launch_dual_t<144, 32, 6, true>(p, n_graphs, max_graph_nodes, st);

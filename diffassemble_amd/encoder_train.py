@@ -158,10 +158,29 @@ class EncoderTrainEngine:
             self.buffers[bn + ".num_batches_tracked"].add_(1)
 
     def _grad(self, name):
-        p = self.params[name]
+        """``param.grad`` as a view of ONE flat fp32 buffer (``flat_grad``, like ``TrainEngine.flat_grad``): the data-parallel
+        exchange is then a single all-reduce of that buffer, without re-flattening 11 M values every step.  A gradient the
+        caller dropped (``zero_grad(set_to_none=True)``) or replaced is re-attached, zeroed / carried over."""
+        if getattr(self, "flat_grad", None) is None:
+            offs, off = {}, 0
+            for n_, q in self.params.items():
+                offs[n_] = off
+                off += (q.numel() + 63) // 64 * 64
+            self.flat_grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+            self._grad_views = {n_: self.flat_grad[o:o + self.params[n_].numel()].view(self.params[n_].shape) for n_, o in offs.items()}
+        p, v = self.params[name], self._grad_views[name]
         if p.grad is None:
-            p.grad = torch.zeros_like(p, dtype=torch.float32)
-        return p.grad
+            v.zero_()
+            p.grad = v
+        elif p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)
+            p.grad = v
+        return v
+
+    def grads_attached(self):
+        """True when every parameter's ``.grad`` is its view of ``flat_grad`` (so the flat buffer IS the gradient)."""
+        views = getattr(self, "_grad_views", None)
+        return views is not None and all(p.grad is not None and p.grad.data_ptr() == views[n_].data_ptr() for n_, p in self.params.items())
 
     def _bn_backward(self, u, dZ, relu, dY, dRes=None):
         _, bn, _, planes, _, stride, H = self.units[u]

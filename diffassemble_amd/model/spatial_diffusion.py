@@ -330,8 +330,12 @@ class GNN_Diffusion(LightningModule):
             # the encoder's HIP backward also writes param.grad directly: one more flat all-reduce (11 M values)
             from ..sharding import allreduce_gradients
             import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            if multi and enc._train_engine.grads_attached():
+                allreduce_gradients(enc._train_engine.flat_grad, average=True)      # the gradients ARE views of this buffer
+                return
             grads = [p.grad for p in enc.parameters() if p.grad is not None]
-            if grads and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if grads and multi:
                 flat = torch.cat([g.reshape(-1) for g in grads])
                 allreduce_gradients(flat, average=True)
                 off = 0

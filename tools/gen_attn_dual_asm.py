@@ -14,11 +14,12 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# ---- register map (VGPR numbers); v0 .. v75 stay with the compiler
+# ---- register map (VGPR numbers); v0 .. v75 and v92 .. v99 stay with the compiler
 VADDR, KADDR, ONES, ACC = 76, 77, 78, 79
 ET = 80                     # exp temporaries: pair A = 80, 81; pair B = 82, 83
 VF = 84                     # V fragments: v0 = 84..87 (vlo0, vhi0), v1 = 88..91 (vlo1, vhi1)
-PFB = 92                    # packed P of slab 1: 92..99
+PFB = 248                   # packed P of slab 1: the SAME registers as slab 0's (R2 reads slab 0's P at its two PV MFMAs, slots 0 - 1, and writes
+                            # slab 1's packs from slot 2 on; MFMA operands are read at issue) -- frees v92..v99 for the compiler
 Q0, Q1 = 100, 136           # Q fragments, 9 x 4 registers per slab (C = 144); C = 32 uses the first 2 x 4 of each
 SA, SB = 172, 188           # score tuples
 O0, O1 = 204, 220           # output accumulators
@@ -60,7 +61,7 @@ def region(nch, s_out, q_base, s_in, pf, pre_pv=None, read_v=False, rsv=64):
         if 0 <= jj < 8:
             a = ET + 2 * (jj % 2)
             out.append(f"v_cvt_pk_bf16_f32 v{pf + jj}, v{a}, v{a + 1}")
-            out.append(f"v_dot2_f32_bf16 v{ACC}, v{pf + jj}, v{ONES}, " + ("0" if jj == 0 else f"v{ACC}"))
+            out.append(f"v_dot2_f32_bf16 v{ACC}, v{pf + jj}, %[ones], " + ("0" if jj == 0 else f"v{ACC}"))     # (1, 1) bf16 from an SGPR
         return out
 
     slot = 0
@@ -124,8 +125,13 @@ def stmt(name, lines, outs, ins, clob):
     lines = ablate(lines)
     lines = pad_nops(lines)
     body = " \\\n".join('        "' + ln + '\\n"' for ln in lines)
-    o = ", ".join(f'"{c}"({v})' for c, v in outs)
-    i = ", ".join(f'"{c}"({v})' for c, v in ins)
+    def op(c, v):
+        if c.startswith("["):                                   # "[name]constraint"
+            name, cons = c[1:].split("]")
+            return f'[{name}] "{cons}"({v})'
+        return f'"{c}"({v})'
+    o = ", ".join(op(c, v) for c, v in outs)
+    i = ", ".join(op(c, v) for c, v in ins)
     c = ", ".join(f'"{x}"' for x in clob)
     return f"#define {name}() asm volatile( \\\n{body} \\\n        : {o} \\\n        : {i} \\\n        : {c})\n"
 
@@ -148,10 +154,10 @@ def main():
         out.append(stmt(f"DA_DUAL_R1_C{c}", r1,
                         [("=" + R(SB, 16), "sB"), ("=" + R(PFA, 4), "pfA0"), ("=" + R(PFA + 4, 4), "pfA1"), ("=" + R(ACC), "accv"),
                          ("=" + R(VF, 4), "vf0"), ("=" + R(VF + 4, 4), "vf1")],
-                        [(R(SA, 16), "sA"), (R(KADDR), "kaddr"), (R(VADDR), "vaddr"), (R(ONES), "ones")] + q1, clob_common))
+                        [(R(SA, 16), "sA"), (R(KADDR), "kaddr"), (R(VADDR), "vaddr"), ("[ones]s", "ones")] + q1, clob_common))
         out.append(stmt(f"DA_DUAL_R2_C{c}", r2,
                         [("=" + R(SA, 16), "sA"), ("=" + R(PFB, 4), "pfB0"), ("=" + R(PFB + 4, 4), "pfB1"), ("=" + R(ACC), "accv"), ("+" + R(O0, 16), "Oa")],
-                        [(R(SB, 16), "sB"), (R(KADDR), "kaddr"), (R(ONES), "ones"), (R(PFA, 4), "pfA0"), (R(PFA + 4, 4), "pfA1"),
+                        [(R(SB, 16), "sB"), (R(KADDR), "kaddr"), ("[ones]s", "ones"), (R(PFA, 4), "pfA0"), (R(PFA + 4, 4), "pfA1"),
                          (R(VF, 4), "vf0"), (R(VF + 4, 4), "vf1")] + q0, clob_common))
         out.append(stmt(f"DA_DUAL_PV1_C{c}", pv1, [("+" + R(O1, 16), "Ob")],
                         [(R(PFB, 4), "pfB0"), (R(PFB + 4, 4), "pfB1"), (R(VF, 4), "vf0"), (R(VF + 4, 4), "vf1")], []))
