@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
-ABI_VERSION = 13
+ABI_VERSION = 14
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -116,6 +116,10 @@ PROTOTYPES = {
     "da_profile_read": (C.c_int, [_fp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "da_linear": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp,
                             C.c_int, _fp]),
+    "da_linear_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "da_linear_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp]),
+    "da_linear_packed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp,
+                                   C.c_int, _fp]),
     "da_attn_csr": (C.c_int, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp, _fp]),
     "da_attn_dense_scratch_bytes": (C.c_size_t, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int]),
     "da_conv_dense": (C.c_int, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int,

@@ -27,6 +27,7 @@ struct ConvW {
     // directly -- the softmax scale costs no instruction per score (scaled in fp32, before the rounding to the act dtype)
     void *wd = nullptr;
     float *bd = nullptr;
+    void *wdp = nullptr;   // wd in the fragment order of the row-panel projection kernel (da_gemm_xpanel.hip), bf16 only
     int din = 0, hc = 0, C = 0;
 };
 
@@ -97,6 +98,7 @@ struct da_denoiser {
     float *headc_b = nullptr;         // [32] = Wf0 . b2
     void *virt_qkvs = nullptr;        // exophormer: [V, 4*HC0] act dtype = virt_emb . Wcat0^T + bcat0 (constant per checkpoint)
     void *conv0c_wd = nullptr, *virt_qkvs_d = nullptr;      // their dense-path variants (Q pre-scaled, see ConvW)
+    void *conv0c_wdp = nullptr, *convLf_wp = nullptr;       // conv0c_wd / convLf_w packed for the row-panel kernel (see ConvW::wdp)
     float *conv0c_bd = nullptr;
     bool q_prescaled = false;
     // ... and the LAST conv's value / skip projections are folded with final_mlp.0 (its consumer, linear up to
@@ -319,7 +321,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             qs.Q = w.dq; qs.K = w.dk; qs.Vt = w.dvt; qs.S = nullptr;
             rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
                 return launch_gemm_mfma(prec, n, c.din, 2 * c.hc + d->heads * 32, xin, ldx, d->convLf_w, d->convLf_b, DA_ACT_NONE,
-                                        nullptr, nullptr, 0, &qs, st); });
+                                        nullptr, nullptr, 0, &qs, st, 0, nullptr, d->convLf_wp); });
             if (rc > 0) return rc;
             if (rc == 0) {
                 DenseLayout L;
@@ -377,8 +379,10 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             qs.Q = w.dq; qs.K = w.dk; qs.Vt = w.dvt; qs.S = w.dskip;
             const void *wdense = (fused && l == 0) ? d->conv0c_wd : c.wd;
             const float *bdense = (fused && l == 0) ? d->conv0c_bd : c.bd;
+            const void *wpanel = (fused && l == 0) ? d->conv0c_wdp : c.wdp;
             rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
-                return launch_gemm_mfma(prec, nproj, c.din, 4 * c.hc, xin, ldx, wdense, bdense, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st); });
+                return launch_gemm_mfma(prec, nproj, c.din, 4 * c.hc, xin, ldx, wdense, bdense, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st, 0,
+                                        nullptr, wpanel); });
             if (rc > 0) return rc;
             if (rc == 0 && virt0 &&
                 (rc = launch_scatter_virtual(prec, n - nr, d->V, d->heads, c.C, d->virt_qkvs_d, nr, g->row_map, g->n_pad, w.dq, w.dk,
@@ -497,6 +501,14 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
         if (!p || launch_convert(precision, n, src, p, st)) { rc = 2; return nullptr; }
         return p;
     };
+    // fragment-major copy of a projection weight for the row-panel kernel; nullptr when the shape has no packed form
+    auto pack_panel = [&](const void *wsrc, int K, int Nout) -> void * {
+        const size_t nb = xpanel_in_model() ? da_linear_packed_bytes(precision, K, Nout) : 0;
+        if (!nb || !wsrc) return nullptr;
+        void *p = alloc(nb);
+        if (!p || pack_w_xpanel(K, Nout, wsrc, K, p, st)) { rc = 2; return nullptr; }
+        return p;
+    };
     d->time_emb = copy_f32(w->time_emb, (size_t)w->steps * 32);
     d->pos_w0 = copy_f32(w->pos_w0, 16 * (size_t)w->c_in); d->pos_b0 = copy_f32(w->pos_b0, 16);
     d->pos_w1 = copy_f32(w->pos_w1, 32 * 16); d->pos_b1 = copy_f32(w->pos_b1, 32);
@@ -534,6 +546,8 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
             if (hipMemcpyAsync(c.bd, c.b, 4 * (size_t)c.hc * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(2);
             if (scale_block(c.bd, 1, c.hc, c.hc, q_scale_log2(c.C), st)) return fail(2);
         }
+        c.wdp = pack_panel(c.wd, c.din, 4 * c.hc);
+        if (rc) return fail(rc);
     }
     d->q_prescaled = q_prescale_on();
     if (d->V > 0) {
@@ -592,6 +606,7 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
                 if (scale_block(cw, hc0, hid, hid, q_scale_log2(d->conv[0].C), st)) return fail(2);
                 d->conv0c_wd = pack(cw, (size_t)4 * hc0 * hid);
             }
+            d->conv0c_wdp = pack_panel(d->conv0c_wd, hid, 4 * hc0);
             if (d->V > 0) {            // exophormer: conv-0 projections of the virtual rows (they bypass mlp)
                 float *vq = (float *)alloc((size_t)d->V * 4 * hc0 * 4);
                 if (!vq) return fail(2);
@@ -639,6 +654,7 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
                     if (scale_block(d->convLf_b, 1, hcL, hcL, q_scale_log2(CL), st)) return fail(2);
                 }
                 d->convLf_w = pack(lw, (size_t)nf * dinL);
+                d->convLf_wp = pack_panel(d->convLf_w, dinL, nf);
                 d->skipc_w = pack(sw, (size_t)32 * dinL);
                 if (rc) return fail(rc);
                 d->lastfold = true;
@@ -991,6 +1007,29 @@ int da_profile_read(da_denoiser *d, float *ms, int32_t *counts) {
 int da_linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, int act,
               const void *residual, void *out, int ldo, void *stream) {
     DA_REQUIRE(A && W && out, "da_linear: null argument");
+    return da::linear(prec, M, K, Nout, A, lda, W, bias, act, residual, out, ldo, (hipStream_t)stream);
+}
+
+size_t da_linear_packed_bytes(int prec, int K, int Nout) {
+    if (prec != DA_PREC_BF16 || (K != 128 && K != 256) || Nout < 512 || Nout > 4096 || (Nout & 31)) return 0;
+    return da::xpanel_packed_bytes(K, Nout);
+}
+
+int da_linear_pack(int prec, int K, int Nout, const void *W, int ldw, void *packed, void *stream) {
+    DA_REQUIRE(W && packed, "da_linear_pack: null argument");
+    DA_REQUIRE(da_linear_packed_bytes(prec, K, Nout) > 0, "da_linear_pack: no packed form for prec %d, K %d, Nout %d", prec, K, Nout);
+    DA_REQUIRE((((size_t)W) & 15) == 0 && (((size_t)packed) & 15) == 0 && ((ldw <= 0 ? K : ldw) & 7) == 0, "da_linear_pack: W / packed must be 16-byte aligned");
+    return da::pack_w_xpanel(K, Nout, W, ldw, packed, (hipStream_t)stream);
+}
+
+int da_linear_packed(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const void *packed,
+                     const float *bias, int act, const void *residual, void *out, int ldo, void *stream) {
+    DA_REQUIRE(A && W && out, "da_linear_packed: null argument");
+    if (!da::mfma_disabled()) {
+        const int rc = da::launch_gemm_mfma(prec, M, K, Nout, A, lda, W, bias, act, residual, out, ldo, nullptr, (hipStream_t)stream, 0, nullptr,
+                                            packed);
+        if (rc >= 0) return rc;
+    }
     return da::linear(prec, M, K, Nout, A, lda, W, bias, act, residual, out, ldo, (hipStream_t)stream);
 }
 

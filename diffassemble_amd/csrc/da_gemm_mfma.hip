@@ -223,11 +223,12 @@ static bool aligned16(const void *p) { return (((size_t)p) & 15) == 0; }
 
 int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st);   // da_gemm_astat.hip
 int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st);    // da_gemm_wreg.hip
+int launch_gemm_xpanel(int prec, const GemmParams &p0, const QkvScatter *qs, int act, const void *wpacked, hipStream_t st);   // da_gemm_xpanel.hip
 
 // returns 0 = launched, -1 = shape not supported by this kernel (caller falls back), >0 error
 int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
                      int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st, int ldw,
-                     const void *pre) {
+                     const void *pre, const void *wpacked) {
     const int es = (int)esize(prec), BK = 128 / es;
     if (M <= 0 || Nout <= 0) return 0;
     if (ldw <= 0) ldw = K;
@@ -255,6 +256,11 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     {   // short reductions: A-stationary kernel (da_gemm_astat.hip)
         static int off = -1;
         if (off < 0) { const char *e = getenv("DA_DISABLE_ASTAT"); off = (e && e[0] == '1') ? 1 : 0; }
+        if (K * es <= 512 && wpacked) {
+            // tall inputs at the benched batch sizes: row panel of A in LDS, pre-packed W fragments double-buffered in registers
+            const int rx = launch_gemm_xpanel(prec, p, qs, act, wpacked, st);
+            if (rx >= 0) return rx;
+        }
         if (K * es <= 512) {
             // tall inputs: W in registers, A tiles streamed by a producer wave (da_gemm_wreg.hip)
             const int rw = launch_gemm_wreg(prec, p, qs, act, st);

@@ -28,10 +28,85 @@ typedef __attribute__((ext_vector_type(16))) float f32x16w;
 #ifndef DA_WREG_NSTG
 #define DA_WREG_NSTG 4
 #endif
+#ifdef DA_WREG_PROBE
+// timeline of workgroup (0, 0): consumer waves 0 and 4 (one SIMD) and the producer, first 64 tiles, 4 stamps per tile
+#define DA_WTICK(w, t, k) do { if (p.prof && blockIdx.x == 0 && (t) < 64) p.prof[((w) * 64 + (t)) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DA_WTICK(w, t, k)
+#endif
 template <int N> __device__ __forceinline__ void wreg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int KIN, bool QKV, int ACT>
-__global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_wg) {
+// The producer wave of both kernels.  Its instruction stream shares a SIMD's issue port with two consumer waves' MFMAs, so it
+// must be SHORT: per DMA instruction one s_mov to M0 and the load itself, in the "SGPR base + 32-bit VGPR offset" form -- the
+// per-lane offsets inside a tile never change (16 VGPRs, computed once) and the tile's base is a scalar.  (Round 3 timeline,
+// conv 3 at 57 600 rows: with a 64-bit per-lane address rebuilt for every instruction -- 7 VALU, three of them quarter-rate --
+// issuing one tile took 1840 cycles (3400 beside the output stores) and the eight consumer waves, done after 1400, waited at
+// the barrier for it: tile period 2350 / 3500 cycles against 1024 of MFMA work per SIMD.)
+__device__ __forceinline__ void wreg_dma16(unsigned lds_addr, unsigned voff, const void *sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void wreg_dma4(unsigned lds_addr, unsigned voff, const void *sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+
+template <int KIN, bool QKV, int NSTG>
+__device__ __forceinline__ void wreg_producer(const GemmParams &p, unsigned char *ring, unsigned char *slots, int t0, int ntile, int lane) {
+    constexpr int ROWB = KIN * 2, TILEB = 32 * ROWB, NDMA = TILEB / 1024, CPR = ROWB / 16, PER = NDMA + 1;
+    const int rsub = lane / CPR, pc = lane % CPR;                 // row inside a DMA instruction, physical chunk
+    const unsigned ring_lds = (unsigned)(size_t)ring, slots_lds = (unsigned)(size_t)slots;
+    unsigned voff[NDMA];
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) {
+        const int row = q * (64 / CPR) + rsub;                    // row inside the tile
+        const int lc = pc ^ (row & 15);                           // logical chunk this LDS slot holds
+        voff[q] = (unsigned)row * (unsigned)p.lda * 2u + (unsigned)lc * 16u;
+    }
+    const unsigned voff_rm = (unsigned)min(lane, 31) * 4u;
+    auto issue = [&](int ti) {
+        if (p.debug & 1024) return;
+        const int row0 = (t0 + ti) * 32;
+        const unsigned buf = ring_lds + (unsigned)(ti % NSTG) * TILEB;
+        if (row0 + 32 <= p.M) {
+            const char *base = (const char *)p.A + (size_t)row0 * (size_t)p.lda * 2;
+#pragma unroll
+            for (int q = 0; q < NDMA; ++q) wreg_dma16(buf + q * 1024, voff[q], base);
+            // padded-row slots of the tile's nodes (QKV scatter); one 4-byte piece per lane, lanes >= 32 re-load row 31
+            wreg_dma4(slots_lds + (unsigned)(ti % NSTG) * 256, voff_rm, QKV ? (const void *)(p.row_map + row0) : (const void *)base);
+            return;
+        }
+        // the last, partial tile: rows past the end re-read row M - 1 (M0 is only ever written by these asm statements: no
+        // compiler-generated LDS-DMA in this function, whose M0 bookkeeping they would bypass)
+        const char *base = (const char *)p.A + (size_t)row0 * (size_t)p.lda * 2;
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) {
+            const int row = q * (64 / CPR) + rsub;
+            const int lc = pc ^ (row & 15);
+            wreg_dma16(buf + q * 1024, (unsigned)(min(row0 + row, p.M - 1) - row0) * (unsigned)p.lda * 2u + (unsigned)lc * 16u, base);
+        }
+        wreg_dma4(slots_lds + (unsigned)(ti % NSTG) * 256, (unsigned)(min(row0 + min(lane, 31), p.M - 1) - row0) * 4u,
+                  QKV ? (const void *)(p.row_map + row0) : (const void *)base);
+    };
+    const int pre = min(NSTG - 1, ntile);
+    for (int ti = 0; ti < pre; ++ti) issue(ti);
+    for (int i = 0; i < ntile; ++i) {
+        const int issued = min(ntile, i + NSTG - 1);              // tiles 0 .. issued-1 are in flight or landed
+        const int younger = issued - 1 - i;                       // tiles after i that may stay in flight: 0 .. NSTG - 2
+        static_assert((NSTG - 2) * PER <= 63, "vmcnt is a 6-bit counter");
+        DA_WTICK(2, i, 0);
+        if (NSTG >= 5 && younger >= 3) wreg_wait_vmcnt<(NSTG >= 5 ? 3 : 0) * PER>();
+        else if (younger >= 2) wreg_wait_vmcnt<2 * PER>();
+        else if (younger == 1) wreg_wait_vmcnt<PER>();
+        else wreg_wait_vmcnt<0>();
+        DA_WTICK(2, i, 1);
+        __builtin_amdgcn_s_barrier();                             // tile i is readable; everyone is done with tile i - 1
+        DA_WTICK(2, i, 2);
+        if (i + NSTG - 1 < ntile) issue(i + NSTG - 1);            // into the slot of tile i - 1
+        DA_WTICK(2, i, 3);
+    }
+}
+
+template <int KIN, bool QKV, int ACT, bool DIRECT>
+__global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_wg, int ncg, int cpx) {
     constexpr int KS = KIN / 16;                 // k-steps of 16
     constexpr int ROWB = KIN * 2;                // bytes of one A row
     constexpr int TILEB = 32 * ROWB;             // one 32-row tile
@@ -46,64 +121,48 @@ __global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_w
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nrt = (p.M + 31) >> 5;
-    const int t0 = blockIdx.y * tiles_per_wg, t1 = min(t0 + tiles_per_wg, nrt);
+    // XCD-aware map (workgroup L runs on XCD L % 8): the ncg column groups that walk the SAME rows sit on one XCD, so a tile of A
+    // comes over the fabric once per row chunk and the other ncg - 1 readers hit that XCD's L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cgi = slot % ncg, chunk = xcd * cpx + slot / ncg;
+    const int t0 = chunk * tiles_per_wg, t1 = min(t0 + tiles_per_wg, nrt);
     const int ntile = t1 - t0;
     if (ntile <= 0) return;
 
     if (wid == 8) {
-        // ------------------------------------------------ producer wave
-        const int rsub = lane / CPR, pc = lane % CPR;             // row inside a DMA instruction, physical chunk
-        auto issue = [&](int ti) {
-            if (p.debug & 1024) return;
-            const int row0 = (t0 + ti) * 32;
-            unsigned char *buf = ring + (ti % NSTG) * TILEB;
-#pragma unroll
-            for (int q = 0; q < NDMA; ++q) {
-                const int row = q * (64 / CPR) + rsub;            // row inside the tile
-                const int lc = pc ^ (row & 15);                   // logical chunk this LDS slot holds
-                const char *src = (const char *)p.A + (size_t)min(row0 + row, p.M - 1) * (size_t)p.lda * 2 + lc * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(buf + q * 1024), 16, 0, 0);
-            }
-            // padded-row slots of the tile's nodes (QKV scatter); one 4-byte piece per lane, lanes >= 32 re-load row 31
-            const int32_t *rm = QKV ? p.row_map + min(row0 + min(lane, 31), p.M - 1) : (const int32_t *)p.A;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rm,
-                                             (__attribute__((address_space(3))) void *)(slots + (ti % NSTG) * 256), 4, 0, 0);
-        };
-        constexpr int PER = NDMA + 1;
-        const int pre = min(NSTG - 1, ntile);
-        for (int ti = 0; ti < pre; ++ti) issue(ti);
-        for (int i = 0; i < ntile; ++i) {
-            const int issued = min(ntile, i + NSTG - 1);          // tiles 0 .. issued-1 are in flight or landed
-            const int younger = issued - 1 - i;                   // tiles after i that may stay in flight: 0 .. NSTG - 2
-            static_assert((NSTG - 2) * PER <= 63, "vmcnt is a 6-bit counter");
-            if (NSTG >= 5 && younger >= 3) wreg_wait_vmcnt<(NSTG >= 5 ? 3 : 0) * PER>();
-            else if (younger >= 2) wreg_wait_vmcnt<2 * PER>();
-            else if (younger == 1) wreg_wait_vmcnt<PER>();
-            else wreg_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();                         // tile i is readable; everyone is done with tile i - 1
-            if (i + NSTG - 1 < ntile) issue(i + NSTG - 1);        // into the slot of tile i - 1
-        }
+        wreg_producer<KIN, QKV, NSTG>(p, ring, slots, t0, ntile, lane);
         return;
     }
 
     // ---------------------------------------------------- consumer waves
     const int i32 = lane & 31, half = lane >> 5;
-    const int col0 = blockIdx.x * 256 + wid * 32;
+    const int col0 = cgi * 256 + wid * 32;
     const bool active = col0 < p.Nout;
     // this wave's 32 columns of W as A-operand fragments: lane (col, half), k-step s -> W[col][16 s + 8 half ..+8]
+    // DIRECT: MFMA row m of the A operand is fed W column col0 + pi(m), pi(8 j + 4 h + i) = 16 h + 4 j + i, so that the
+    // accumulator of lane (node, half) -- rows 8 j + 4 half + i in registers 4 j + i -- is the 16 CONSECUTIVE output
+    // columns col0 + 16 half + (0 .. 15) of its node: 32 bytes of bf16 that leave as two 16-byte stores straight from
+    // registers.
     u32x4 wf[KS];
     {
-        const char *wrow = (const char *)p.W + (size_t)min(col0 + i32, p.Nout - 1) * (size_t)p.ldw * 2 + half * 16;
+        const int wsel = DIRECT ? 16 * ((i32 >> 2) & 1) + 4 * (i32 >> 3) + (i32 & 3) : i32;
+        const char *wrow = (const char *)p.W + (size_t)min(col0 + wsel, p.Nout - 1) * (size_t)p.ldw * 2 + half * 16;
 #pragma unroll
         for (int s = 0; s < KS; ++s) wf[s] = *(const u32x4 *)(wrow + s * 32);
     }
     // row-major side of the epilogue: this lane stores the 16-byte chunk `ch` (8 columns) of rows rr and rr + 16
+    // (DIRECT: its node's columns colc .. colc + 15)
     const int ch = lane & 3, rr = lane >> 2;
-    const int colc = col0 + 8 * ch;
+    const int colc = DIRECT ? col0 + 16 * half : col0 + 8 * ch;
     float bz[8];
+    f32x16w bzv;
+    if (DIRECT) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bz[e] = (p.bias && active) ? p.bias[min(colc + e, p.Nout - 1)] : 0.f;
+        for (int e = 0; e < 16; ++e) bzv[e] = (p.bias && active) ? p.bias[min(colc + e, p.Nout - 1)] : 0.f;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bz[e] = (p.bias && active) ? p.bias[min(colc + e, p.Nout - 1)] : 0.f;
+    }
     bf16_t *dbase;
     size_t rstride;
     bool use_slot = false;
@@ -133,6 +192,7 @@ __global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_w
     for (int i = 0; i < ntile; ++i) {
         __builtin_amdgcn_s_barrier();                             // producer: tile i has landed
         if (!active) continue;
+        if ((wid & 3) == 0) DA_WTICK(wid >> 2, i, 0);
         const unsigned char *buf = ring + (i % NSTG) * TILEB + i32 * ROWB;
         f32x16w acc;
 #pragma unroll
@@ -156,6 +216,24 @@ __global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_w
                 if (!(p.debug & 512)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[gq * PF + s]),
                                                               __builtin_bit_cast(bf16x8, xa[gq & 1][s]), acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((wid & 3) == 0) DA_WTICK(wid >> 2, i, 1);
+        if (DIRECT) {
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o0[e] = (__bf16)apply_act(acc[e] + bzv[e], ACT);
+                o1[e] = (__bf16)apply_act(acc[8 + e] + bzv[8 + e], ACT);
+            }
+            const int m = (t0 + i) * 32 + i32;
+            if (m < p.M && !(p.debug & 256)) {
+                const size_t ridx = use_slot ? (size_t)((const int32_t *)(slots + (i % NSTG) * 256))[i32] : (size_t)m;
+                bf16_t *dst = dbase + ridx * rstride;
+                *(u32x4 *)dst = __builtin_bit_cast(u32x4, o0);
+                *(u32x4 *)(dst + 8) = __builtin_bit_cast(u32x4, o1);
+            }
+            if ((wid & 3) == 0) DA_WTICK(wid >> 2, i, 2);
+            continue;
         }
         // D^T[col][node]: lane (node = i32, half) holds columns 8 j + 4 half + (0..3) -> strip[node][col] fp32
 #pragma unroll
@@ -181,8 +259,8 @@ __global__ __launch_bounds__(576) void k_gemm_wreg(GemmParams p, int tiles_per_w
     }
 }
 
-template <int KIN, bool QKV, int ACT>
-__global__ __launch_bounds__(320) void k_gemm_wreg2(GemmParams p, int tiles_per_wg) {
+template <int KIN, bool QKV, int ACT, bool DIRECT>
+__global__ __launch_bounds__(320) void k_gemm_wreg2(GemmParams p, int tiles_per_wg, int ncg, int cpx) {
     constexpr int KS = KIN / 16;                 // k-steps of 16
     constexpr int ROWB = KIN * 2;                // bytes of one A row
     constexpr int TILEB = 32 * ROWB;             // one 32-row tile
@@ -197,65 +275,50 @@ __global__ __launch_bounds__(320) void k_gemm_wreg2(GemmParams p, int tiles_per_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nrt = (p.M + 31) >> 5;
-    const int t0 = blockIdx.y * tiles_per_wg, t1 = min(t0 + tiles_per_wg, nrt);
+    // XCD-aware map (workgroup L runs on XCD L % 8): the ncg column groups that walk the SAME rows sit on one XCD, so a tile of A
+    // comes over the fabric once per row chunk and the other ncg - 1 readers hit that XCD's L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cgi = slot % ncg, chunk = xcd * cpx + slot / ncg;
+    const int t0 = chunk * tiles_per_wg, t1 = min(t0 + tiles_per_wg, nrt);
     const int ntile = t1 - t0;
     if (ntile <= 0) return;
 
     if (wid == 4) {
-        // ------------------------------------------------ producer wave
-        const int rsub = lane / CPR, pc = lane % CPR;             // row inside a DMA instruction, physical chunk
-        auto issue = [&](int ti) {
-            if (p.debug & 1024) return;
-            const int row0 = (t0 + ti) * 32;
-            unsigned char *buf = ring + (ti % NSTG) * TILEB;
-#pragma unroll
-            for (int q = 0; q < NDMA; ++q) {
-                const int row = q * (64 / CPR) + rsub;            // row inside the tile
-                const int lc = pc ^ (row & 15);                   // logical chunk this LDS slot holds
-                const char *src = (const char *)p.A + (size_t)min(row0 + row, p.M - 1) * (size_t)p.lda * 2 + lc * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(buf + q * 1024), 16, 0, 0);
-            }
-            // padded-row slots of the tile's nodes (QKV scatter); one 4-byte piece per lane, lanes >= 32 re-load row 31
-            const int32_t *rm = QKV ? p.row_map + min(row0 + min(lane, 31), p.M - 1) : (const int32_t *)p.A;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rm,
-                                             (__attribute__((address_space(3))) void *)(slots + (ti % NSTG) * 256), 4, 0, 0);
-        };
-        constexpr int PER = NDMA + 1;
-        const int pre = min(NSTG - 1, ntile);
-        for (int ti = 0; ti < pre; ++ti) issue(ti);
-        for (int i = 0; i < ntile; ++i) {
-            const int issued = min(ntile, i + NSTG - 1);          // tiles 0 .. issued-1 are in flight or landed
-            const int younger = issued - 1 - i;                   // tiles after i that may stay in flight: 0 .. NSTG - 2
-            static_assert((NSTG - 2) * PER <= 63, "vmcnt is a 6-bit counter");
-            if (NSTG >= 5 && younger >= 3) wreg_wait_vmcnt<(NSTG >= 5 ? 3 : 0) * PER>();
-            else if (younger >= 2) wreg_wait_vmcnt<2 * PER>();
-            else if (younger == 1) wreg_wait_vmcnt<PER>();
-            else wreg_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();                         // tile i is readable; everyone is done with tile i - 1
-            if (i + NSTG - 1 < ntile) issue(i + NSTG - 1);        // into the slot of tile i - 1
-        }
+        wreg_producer<KIN, QKV, NSTG>(p, ring, slots, t0, ntile, lane);
         return;
     }
 
     // ---------------------------------------------------- consumer waves
     const int i32 = lane & 31, half = lane >> 5;
-    const int col0 = blockIdx.x * 256 + wid * 64;
+    const int col0 = cgi * 256 + wid * 64;
     const bool active = col0 < p.Nout;
     // this wave's 32 columns of W as A-operand fragments: lane (col, half), k-step s -> W[col][16 s + 8 half ..+8]
+    // DIRECT (see k_gemm_wreg): MFMA row 8 j + 4 h + i of column block cb is fed W column col0 + 32 h + 16 cb + 4 j + i, so lane
+    // (node, half) ends up with the 32 consecutive columns col0 + 32 half + (0 .. 31) of its node -- 64 bytes, four 16-byte stores
     u32x4 wf[2][KS];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-        const char *wrow = (const char *)p.W + (size_t)min(col0 + cb * 32 + i32, p.Nout - 1) * (size_t)p.ldw * 2 + half * 16;
+        const int wsel = DIRECT ? 32 * ((i32 >> 2) & 1) + 16 * cb + 4 * (i32 >> 3) + (i32 & 3) : cb * 32 + i32;
+        const char *wrow = (const char *)p.W + (size_t)min(col0 + wsel, p.Nout - 1) * (size_t)p.ldw * 2 + half * 16;
 #pragma unroll
         for (int s = 0; s < KS; ++s) wf[cb][s] = *(const u32x4 *)(wrow + s * 32);
     }
     // row-major side of the epilogue: this lane stores the 16-byte chunk `ch` (8 columns) of rows rr and rr + 16
+    // (DIRECT: its node's columns colc .. colc + 31)
     const int ch = lane & 7, rr = lane >> 3;
-    const int colc = col0 + 8 * ch;
+    const int colc = DIRECT ? col0 + 32 * half : col0 + 8 * ch;
     float bz[8];
+    f32x16w bzv, bzv2;
+    if (DIRECT) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bz[e] = (p.bias && active) ? p.bias[min(colc + e, p.Nout - 1)] : 0.f;
+        for (int e = 0; e < 16; ++e) {
+            bzv[e] = (p.bias && active) ? p.bias[min(colc + e, p.Nout - 1)] : 0.f;
+            bzv2[e] = (p.bias && active) ? p.bias[min(colc + 16 + e, p.Nout - 1)] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bz[e] = (p.bias && active) ? p.bias[min(colc + e, p.Nout - 1)] : 0.f;
+    }
     bf16_t *dbase;
     size_t rstride;
     bool use_slot = false;
@@ -309,7 +372,7 @@ __global__ __launch_bounds__(320) void k_gemm_wreg2(GemmParams p, int tiles_per_
         __builtin_amdgcn_s_barrier();                             // producer: tile i has landed
         if (!active) continue;
         const unsigned char *buf = ring + (i % NSTG) * TILEB + i32 * ROWB;
-        if (QKV) {
+        if (QKV && !DIRECT) {
             const int32_t *sl = (const int32_t *)(slots + (i % NSTG) * 256);
 #pragma unroll
             for (int k = 0; k < 4; ++k) slot_cur[k] = sl[rr + 8 * k];
@@ -340,6 +403,24 @@ __global__ __launch_bounds__(320) void k_gemm_wreg2(GemmParams p, int tiles_per_
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (DIRECT) {
+            bf16x8 o[4];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[0][e] = (__bf16)apply_act(acc[e] + bzv[e], ACT);
+                o[1][e] = (__bf16)apply_act(acc[8 + e] + bzv[8 + e], ACT);
+                o[2][e] = (__bf16)apply_act(acc2[e] + bzv2[e], ACT);
+                o[3][e] = (__bf16)apply_act(acc2[8 + e] + bzv2[8 + e], ACT);
+            }
+            const int m = (t0 + i) * 32 + i32;
+            if (m < p.M && !(p.debug & 256)) {
+                const size_t ridx = use_slot ? (size_t)((const int32_t *)(slots + (i % NSTG) * 256))[i32] : (size_t)m;
+                bf16_t *dst = dbase + ridx * rstride;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *(u32x4 *)(dst + 8 * e) = __builtin_bit_cast(u32x4, o[e]);
+            }
+            continue;
+        }
         if (i > 0) drain(i - 1);                                  // under the matrix pipe's work on tile i
         __builtin_amdgcn_sched_barrier(0);
         // D^T[col][node]: lane (node = i32, half) holds columns 8 j + 4 half + (0..3) -> strip[node][col] fp32
@@ -351,7 +432,7 @@ __global__ __launch_bounds__(320) void k_gemm_wreg2(GemmParams p, int tiles_per_
 #pragma unroll
         for (int k = 0; k < 4; ++k) slot_prev[k] = slot_cur[k];
     }
-    if (active && ntile > 0) drain(ntile - 1);
+    if (!DIRECT && active && ntile > 0) drain(ntile - 1);
 }
 
 static bool wreg_disabled() {
@@ -375,6 +456,13 @@ int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int a
     if (v2mode == -2) { const char *e = getenv("DA_WREG2"); v2mode = e ? (e[0] == '1' ? 1 : 0) : -1; }
     const bool v2 = v2mode == 1 || (v2mode == -1 && p.Nout < 1100);
     if ((p.K != 128 && p.K != 256) || p.pre || p.res || p.M < 4096 || (p.Nout & (v2 ? 63 : 31)) || p.Nout < (v2 ? 512 : 1100)) return -1;
+    // register-direct epilogue (DA_WREG_DIRECT=1; default the LDS-strip epilogue: 125 vs 139 us on conv 3, whose 64-byte row pieces it merges): a lane's 16 (32) consecutive columns must stay
+    // inside one column block and one head
+    static int dmode = -2;
+    if (dmode == -2) { const char *e = getenv("DA_WREG_DIRECT"); dmode = e ? (e[0] == '1' ? 1 : 0) : 0; }
+    const int lw = v2 ? 32 : 16;
+    bool direct = dmode == 1;
+    if (qs && ((qs->HC % lw) || (qs->C % lw) || (qs->Cv % lw))) direct = false;
     if (qs) {
         // a wave's 16-byte output chunk (8 columns) must not straddle a column block or a head
         if ((qs->HC & 31) || (qs->C & 7) || (qs->Cv & 7) || act != DA_ACT_NONE) return -1;
@@ -383,30 +471,36 @@ int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int a
     }
     const int nrt = (p.M + 31) / 32;
     const int ncg = (p.Nout + 255) / 256;
-    int nchunk = 256 / ncg;
-    nchunk = nchunk < 1 ? 1 : (nchunk > nrt ? nrt : nchunk);
+    // row chunks: cpx per XCD (32 CUs each, one workgroup per CU), every chunk crossed with all ncg column groups on that XCD
+    int cpx = 32 / ncg;
+    cpx = cpx < 1 ? 1 : cpx;
+    while (cpx > 1 && (size_t)8 * (cpx - 1) >= (size_t)nrt) --cpx;
+    const int nchunk = 8 * cpx;
     const int tiles = (nrt + nchunk - 1) / nchunk;
-    nchunk = (nrt + tiles - 1) / tiles;
-    const dim3 grid((unsigned)ncg, (unsigned)nchunk);
+    const dim3 grid((unsigned)(nchunk * ncg));
 #define DA_WREG(KK, QQ, AA)                                                                                              \
+    do {                                                                                                                  \
+        if (direct) DA_WREG_D(KK, QQ, AA, true); else DA_WREG_D(KK, QQ, AA, false);                                       \
+    } while (0)
+#define DA_WREG_D(KK, QQ, AA, DD)                                                                                         \
     do {                                                                                                                  \
         if (v2) {                                                                                                         \
             constexpr int lds2 = DA_WREG_NSTG * 32 * KK * 2 + DA_WREG_NSTG * 256 + 4 * 32 * 272;                          \
             static bool attr2 = false;                                                                                    \
             if (!attr2) {                                                                                                 \
-                DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_wreg2<KK, QQ, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2)); \
+                DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_wreg2<KK, QQ, AA, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2)); \
                 attr2 = true;                                                                                             \
             }                                                                                                             \
-            k_gemm_wreg2<KK, QQ, AA><<<grid, 320, lds2, st>>>(p, tiles);                                                  \
+            k_gemm_wreg2<KK, QQ, AA, DD><<<grid, 320, lds2, st>>>(p, tiles, ncg, cpx);                                                  \
             break;                                                                                                        \
         }                                                                                                                 \
         constexpr int lds = DA_WREG_NSTG * 32 * KK * 2 + DA_WREG_NSTG * 256 + 8 * 32 * 144;                                                     \
         static bool attr = false;                                                                                         \
         if (!attr) {                                                                                                      \
-            DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_wreg<KK, QQ, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_wreg<KK, QQ, AA, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
             attr = true;                                                                                                  \
         }                                                                                                                 \
-        k_gemm_wreg<KK, QQ, AA><<<grid, 576, lds, st>>>(p, tiles);                                                        \
+        k_gemm_wreg<KK, QQ, AA, DD><<<grid, 576, lds, st>>>(p, tiles, ncg, cpx);                                                        \
     } while (0)
     if (qs) {
         if (p.K == 256) DA_WREG(256, true, DA_ACT_NONE); else DA_WREG(128, true, DA_ACT_NONE);
@@ -418,6 +512,7 @@ int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int a
         return -1;
     }
 #undef DA_WREG
+#undef DA_WREG_D
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,287 @@
+// Row-panel MFMA linear kernel for SHORT reductions and TALL inputs (bf16, K in {128, 256}, M >= ~25 000 rows):
+// the fused Q | K | V (| skip) projections of the denoiser at the benched batch sizes.
+//
+// Why a third projection kernel (round 3).  The W-in-registers kernels (da_gemm_wreg.hip) stream the rows of A through
+// LDS while they store their outputs, and the two streams do not mix on this memory system: a load-free copy of
+// their store pattern writes conv 3's 295 MB in 44 us (6.7 TB/s), the loads alone take 16 - 33 us, but both together
+// take 110 - 125 us WITHOUT any arithmetic (tools/store_probe.hip, modes 1 / 6 / 5) -- as soon as the output stream
+// outgrows the 256 MB Infinity Cache it evicts A, and A's re-reads from HBM interleave with the write stream (mixed
+// with loads that always hit a cache the same stores take 49 us, mode 11).  k_gemm_wreg ran at exactly that 125 us.
+// So the roles are arranged to keep every load of the steady state a cache hit and to read A from memory only once,
+// BEFORE the first store:
+//   * a workgroup (8 waves, no producer wave) owns a PANEL of T 32-row tiles of A and pulls it into LDS once, by
+//     LDS-DMA, in the prologue (T <= 9 at K = 256: 144 KB of the CU's 160 KB) -- the only reads of A in the kernel;
+//   * it then walks the column groups (256 columns: 32 per wave): a wave's 32 columns of W sit in registers as the A
+//     operand of v_mfma_f32_32x32x16_bf16 (64 VGPRs at K = 256), DOUBLE-BUFFERED -- the fragments of column group
+//     g + 2 are requested when group g retires -- and come from a fragment-major copy of W made once per weight
+//     (pack_w_xpanel: every load instruction reads 1 KB contiguous; the 1.3 MB of conv 3's W stay in every XCD's L2);
+//   * per (group, tile): 16 MFMAs with the x fragments read from the panel (one conflict-free 16-byte LDS read per
+//     MFMA, the XOR swizzle of da_gemm_wreg.hip) and the register-direct
+//     epilogue (MFMA row m is fed W column pi(m), so a lane ends up with 16 CONSECUTIVE output columns of its node:
+//     two 16-byte stores straight from registers);
+//   * no barrier after the prologue: the panel is read-only, the waves run free, two per SIMD cover each other's
+//     epilogues.  The one s_waitcnt vmcnt(0) per column group (the next fragments must have landed; gfx950 counts
+//     loads and stores together) sits BEFORE the last tile's stores, so it waits for stores issued a tile earlier.
+// QKV scatter mode writes Q / K / V head-major at the padded row slots and skip row-major, like the other kernels.
+#include <stdlib.h>
+
+#include "da_gemm_common.h"
+
+namespace da {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16p;
+
+__device__ __forceinline__ void xp_dma16(unsigned lds_addr, unsigned voff, const void *sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void xp_dma4(unsigned lds_addr, unsigned voff, const void *sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+
+// MFMA row m = 8 j + 4 h + i of a wave's 32 x 32 block computes output column 16 h + 4 j + i of the block
+__host__ __device__ __forceinline__ int xp_pi(int m) { return 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3); }
+
+// Wp[((g * 8 + w) * KS + s) * 64 + lane] = the 16 bytes W[g * 256 + w * 32 + pi(lane & 31)][16 s + 8 (lane >> 5) .. + 7]
+__global__ void k_pack_w_xpanel(int Nout, int K, int ldw, const bf16_t *W, u32x4 *Wp) {
+    const int KS = K / 16;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)((Nout + 255) / 256) * 8 * KS * 64;
+    if (i >= total) return;
+    const int lane = (int)(i & 63), s = (int)((i >> 6) % KS);
+    const int gw = (int)((i >> 6) / KS);
+    const int col = gw * 32 + xp_pi(lane & 31);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (col < Nout) v = *(const u32x4 *)(W + (size_t)col * ldw + 16 * s + 8 * (lane >> 5));
+    Wp[i] = v;
+}
+
+size_t xpanel_packed_bytes(int K, int Nout) { return (size_t)((Nout + 255) / 256) * 256 * (size_t)K * 2; }
+
+int pack_w_xpanel(int K, int Nout, const void *W, int ldw, void *packed, hipStream_t st) {
+    if (ldw <= 0) ldw = K;
+    const size_t total = xpanel_packed_bytes(K, Nout) / 16;
+    k_pack_w_xpanel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Nout, K, ldw, (const bf16_t *)W, (u32x4 *)packed);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// The two 16-byte stores of a tile, their data pinned to one of four register sets used round-robin: a store's data registers
+// are read when the store leaves the CU, not when it issues, and with the write path backed up (it is: these kernels are
+// write-bound) the next instruction that overwrites them waits for that -- the next tile's accumulator, if the packed outputs
+// sit where hipcc puts them by default.  tools/store_probe.hip modes 12 / 15: 16 MFMAs + 2 stores per tile take 62.9 us for
+// conv 3's outputs when the stores read the registers the next chain writes, 53.1 us (the stores alone: 51) with four sets.
+template <int U> __device__ __forceinline__ void xp_store_rot(bf16_t *dst, u32x4 o0, u32x4 o1);
+#define DA_XP_STORE_ROT(U, R0, R1)                                                                                        \
+    template <> __device__ __forceinline__ void xp_store_rot<U>(bf16_t * dst, u32x4 o0, u32x4 o1) {                       \
+        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), R0(o0), R1(o1) : "memory"); \
+    }
+DA_XP_STORE_ROT(0, "{v[224:227]}", "{v[228:231]}")
+DA_XP_STORE_ROT(1, "{v[232:235]}", "{v[236:239]}")
+DA_XP_STORE_ROT(2, "{v[240:243]}", "{v[244:247]}")
+DA_XP_STORE_ROT(3, "{v[248:251]}", "{v[252:255]}")
+#undef DA_XP_STORE_ROT
+template <int U> struct XpSlot { static constexpr int value = U; };
+
+template <int KIN, bool QKV, int ACT>
+__global__ __launch_bounds__(512) void k_gemm_xpanel(GemmParams p, const u32x4 *__restrict__ Wp, int T, int ncg) {
+    constexpr int KS = KIN / 16;                 // k-steps of 16
+    constexpr int ROWB = KIN * 2;                // bytes of one A row
+    constexpr int TILEB = 32 * ROWB;             // one 32-row tile
+    constexpr int NDMA = TILEB / 1024;           // 1 KB DMA instructions per tile
+    constexpr int CPR = ROWB / 16;               // 16-byte chunks per row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *panel = smem;                                  // [T][TILEB]
+    unsigned char *slots = smem + T * TILEB;                      // [T][128 B]: padded-row slot of the tile's 32 nodes
+    float *bias_s = (float *)(slots + T * 128);                   // [ncg * 256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nrt = (p.M + 31) >> 5;
+    const int t0 = blockIdx.x * T;
+    const int ntile = min(T, nrt - t0);
+    if (ntile <= 0) return;
+    const int i32 = lane & 31, half = lane >> 5;
+
+    u32x4 wA[KS], wB[KS];
+    // The fragment loads are opaque to hipcc on purpose: for a compiler-visible load it puts an s_waitcnt in front of the
+    // first use, and across the tile loop (whose stores it cannot count) that wait is vmcnt(0) at the top of every group --
+    // which also waits for the OTHER buffer's loads, issued a few instructions earlier (a full L2 round trip per group).
+    // The waits that make these registers valid are the explicit vmcnt(0) of the prologue and of every group's last tile.
+    const unsigned wlane = (unsigned)lane * 16u;
+    auto load_w = [&](u32x4 (&wf)[KS], int g) {
+        const char *src = (const char *)(Wp + ((size_t)(g * 8 + wid) * KS) * 64);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wf[s]) : "v"(wlane), "s"(src + s * 1024) : "memory");
+    };
+    load_w(wA, 0);
+    // ------------------------------------------------ prologue: the panel, the row slots and the bias into LDS
+    {
+        const int rsub = lane / CPR, pc = lane % CPR;             // row inside a DMA instruction, physical chunk
+        const unsigned panel_lds = (unsigned)(size_t)panel, slots_lds = (unsigned)(size_t)slots;
+        for (int t = wid; t < ntile; t += 8) {
+            const int row0 = (t0 + t) * 32;
+            const char *base = (const char *)p.A + (size_t)row0 * (size_t)p.lda * 2;
+            const int rmax = p.M - 1 - row0;                      // rows past the end re-read row M - 1
+#pragma unroll
+            for (int q = 0; q < NDMA; ++q) {
+                const int row = q * (64 / CPR) + rsub;            // row inside the tile
+                const int lc = pc ^ (row & 15);                   // logical chunk this LDS slot holds
+                xp_dma16(panel_lds + t * TILEB + q * 1024, (unsigned)min(row, rmax) * (unsigned)p.lda * 2u + (unsigned)lc * 16u, base);
+            }
+            if (QKV && lane < 32) xp_dma4(slots_lds + t * 128, (unsigned)min(lane, rmax) * 4u, p.row_map + row0);
+        }
+        for (int c = tid; c < ncg * 256; c += 512) bias_s[c] = (p.bias && c < p.Nout) ? p.bias[c] : 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (ncg > 1) load_w(wB, 1);
+
+    // one column group: this wave's 32 columns (col0 ..) against every tile of the panel
+    auto run_group = [&](u32x4 (&wf)[KS], int g) {
+        const int col0 = g * 256 + wid * 32;
+        const bool active = col0 < p.Nout;
+        const int colc = col0 + 16 * half;                        // this lane's 16 consecutive columns
+        f32x16p bzv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 b = *(const f32x4 *)(bias_s + colc + 4 * e);
+            bzv[4 * e] = b[0]; bzv[4 * e + 1] = b[1]; bzv[4 * e + 2] = b[2]; bzv[4 * e + 3] = b[3];
+        }
+        bf16_t *dbase;
+        size_t rstride;
+        bool use_slot = false;
+        if (!QKV) {
+            dbase = (bf16_t *)p.out + colc;
+            rstride = (size_t)p.ldo;
+        } else {
+            const int which = min(colc / p.HC, 3), f = colc - which * p.HC;
+            if (which == 2 && p.Cv > 0) {
+                const int h = f / p.Cv, c = f - h * p.Cv;
+                dbase = (bf16_t *)p.Vt + (size_t)h * p.n_pad * p.Cv + c;
+                rstride = (size_t)p.Cv;
+                use_slot = true;
+            } else if (which == 3) {
+                dbase = (bf16_t *)p.S + f;
+                rstride = (size_t)p.HC;
+            } else {
+                const int h = f / p.C, c = f - h * p.C;
+                dbase = (bf16_t *)(which == 0 ? p.Q : (which == 1 ? p.Kb : p.Vt)) + (size_t)h * p.n_pad * p.C + c;
+                rstride = (size_t)p.C;
+                use_slot = true;
+            }
+        }
+        auto tile_body = [&](int t, auto slot) {
+            const unsigned char *buf = panel + t * TILEB + i32 * ROWB;
+            f32x16p acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // x fragments one group of four k-steps ahead of their MFMAs; sched_barrier keeps hipcc from sinking the reads
+            constexpr int PF = 4, NG = KS / PF;
+            u32x4 xa[2][PF];
+#pragma unroll
+            for (int s = 0; s < PF; ++s) xa[0][s] = *(const u32x4 *)(buf + (((2 * s + half) ^ (i32 & 15)) << 4));
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                if (gq + 1 < NG) {
+#pragma unroll
+                    for (int s = 0; s < PF; ++s)
+                        xa[(gq + 1) & 1][s] = *(const u32x4 *)(buf + (((2 * ((gq + 1) * PF + s) + half) ^ (i32 & 15)) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < PF; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[gq * PF + s]),
+                                                                  __builtin_bit_cast(bf16x8, xa[gq & 1][s]), acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o0[e] = (__bf16)apply_act(acc[e] + bzv[e], ACT);              // bias after the reduction, like every other linear kernel of
+                o1[e] = (__bf16)apply_act(acc[8 + e] + bzv[8 + e], ACT);      // the library: a puzzle's values do not depend on the batch it is in
+            }
+            const bool lastt = t == ntile - 1;
+            if (lastt) {
+                // the fragments of group g + 1 (requested a whole group ago) must be in their registers before the next
+                // group starts; waiting here, in front of this tile's stores, only waits for the stores of tile t - 1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const int m = (t0 + t) * 32 + i32;
+            if (active && m < p.M && !(p.debug & 256)) {
+                const size_t ridx = use_slot ? (size_t)((const int32_t *)(slots + t * 128))[i32] : (size_t)m;
+                bf16_t *dst = dbase + ridx * rstride;
+                xp_store_rot<decltype(slot)::value>(dst, __builtin_bit_cast(u32x4, o0), __builtin_bit_cast(u32x4, o1));
+            }
+        };
+        for (int t = 0; t < ntile; t += 4) {
+            tile_body(t, XpSlot<0>());
+            if (t + 1 < ntile) tile_body(t + 1, XpSlot<1>());
+            if (t + 2 < ntile) tile_body(t + 2, XpSlot<2>());
+            if (t + 3 < ntile) tile_body(t + 3, XpSlot<3>());
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < ncg) load_w(wf, g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int g = 0; g < ncg; g += 2) {
+        run_group(wA, g);
+        if (g + 1 < ncg) run_group(wB, g + 1);
+    }
+}
+
+// The denoiser uses this kernel for its projections only on request (DA_ENABLE_XPANEL=1): measured in the model (round 3, 64
+// puzzles of 900 pieces) the four projections take 230 us against 246 us for the W-in-registers kernels, but the attention
+// kernels that read Q / K / V next run 7 - 10 % slower behind it (+46 us per step; not understood: same bytes, same layouts),
+// so the step as a whole loses 30 us.  da_linear_packed always takes it.
+bool xpanel_in_model() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_ENABLE_XPANEL"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+// returns 0 = launched, -1 = not applicable (caller falls back to the W-in-registers / A-stationary / generic kernels)
+int launch_gemm_xpanel(int prec, const GemmParams &p0, const QkvScatter *qs, int act, const void *wpacked, hipStream_t st) {
+    if (prec != DA_PREC_BF16 || !wpacked) return -1;
+    GemmParams p = p0;
+    if ((p.K != 128 && p.K != 256) || p.pre || p.res || (p.Nout & 31) || p.Nout < 512 || p.Nout > 4096) return -1;
+    if (qs) {
+        // a lane's 16 consecutive columns must stay inside one column block and one head
+        if ((qs->HC & 15) || (qs->C & 15) || (qs->Cv & 15) || act != DA_ACT_NONE) return -1;
+    } else if ((p.ldo & 7) || (((size_t)p.out) & 15)) {
+        return -1;
+    }
+    const int nrt = (p.M + 31) / 32;
+    const int ncg = (p.Nout + 255) / 256;
+    const int tileb = 32 * p.K * 2;
+    // LDS: T tiles + T x 128 B of row slots + the bias; 160 KB per CU, one workgroup per CU
+    const int tmax = (160 * 1024 - ncg * 1024 - 512) / (tileb + 128);
+    int T = (nrt + 255) / 256;
+    if (T > tmax) T = tmax;
+    // short panels re-read W too often (W bytes per output byte = K / (32 T)): the W-in-registers kernels serve those
+    if (T < 4) return -1;
+    const int nwg = (nrt + T - 1) / T;
+    const int lds = T * (tileb + 128) + ncg * 1024;
+#define DA_XP(KK, QQ, AA)                                                                                                 \
+    do {                                                                                                                  \
+        static bool attr = false;                                                                                         \
+        if (!attr) {                                                                                                      \
+            DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_xpanel<KK, QQ, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr = true;                                                                                                  \
+        }                                                                                                                 \
+        k_gemm_xpanel<KK, QQ, AA><<<nwg, 512, lds, st>>>(p, (const u32x4 *)wpacked, T, ncg);                              \
+    } while (0)
+    if (qs) {
+        if (p.K == 256) DA_XP(256, true, DA_ACT_NONE); else DA_XP(128, true, DA_ACT_NONE);
+    } else if (act == DA_ACT_GELU) {
+        if (p.K == 256) DA_XP(256, false, DA_ACT_GELU); else DA_XP(128, false, DA_ACT_GELU);
+    } else if (act == DA_ACT_NONE) {
+        if (p.K == 256) DA_XP(256, false, DA_ACT_NONE); else DA_XP(128, false, DA_ACT_NONE);
+    } else {
+        return -1;
+    }
+#undef DA_XP
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace da

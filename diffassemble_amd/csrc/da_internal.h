@@ -98,9 +98,13 @@ struct DenseLayout {
     int n_pad;
     int q_prescaled = 0;       // Q rows already carry log2(e) / sqrt(C) (projection weights scaled at pack time, da_api.hip ConvW::wd)
 };
+// wpacked: optional fragment-major copy of W (pack_w_xpanel) for the row-panel kernel (da_gemm_xpanel.hip)
 int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
                      int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st, int ldw = 0,
-                     const void *pre = nullptr);
+                     const void *pre = nullptr, const void *wpacked = nullptr);
+size_t xpanel_packed_bytes(int K, int Nout);
+bool xpanel_in_model();          // DA_ENABLE_XPANEL=1 (off by default, see da_gemm_xpanel.hip)
+int pack_w_xpanel(int K, int Nout, const void *W, int ldw, void *packed, hipStream_t st);
 struct DenseMask {             // hybrid mode: adjacency bits of the regular edges + the remainder CSR (da_attn_dense.hip)
     const uint8_t *mask;
     const int64_t *mask_ptr;

@@ -340,6 +340,30 @@ def linear(x, weight, bias=None, act=_lib.ACT_NONE, residual=None, precision="fp
     return out
 
 
+class PackedLinear:
+    """A constant bf16 weight [N, K] packed once for the row-panel kernel (da_linear_pack / da_linear_packed,
+    da_gemm_xpanel.hip); shapes without a packed form, and inputs too short for it, run da_linear's kernels."""
+
+    def __init__(self, weight, bias=None):
+        self.weight = weight.to(torch.bfloat16).contiguous()
+        self.bias = None if bias is None else bias.float().contiguous()
+        self.N, self.K = self.weight.shape
+        nb = _lib.lib().da_linear_packed_bytes(_lib.PREC_BF16, self.K, self.N)
+        self.packed = None
+        if nb:
+            self.packed = torch.empty(nb, dtype=torch.uint8, device=self.weight.device)
+            _lib.check(_lib.lib().da_linear_pack(_lib.PREC_BF16, self.K, self.N, _lib.ptr(self.weight), self.K, _lib.ptr(self.packed),
+                                                 _lib.stream_ptr(self.weight.device)))
+
+    def __call__(self, x, act=_lib.ACT_NONE):
+        x = x.to(torch.bfloat16).contiguous()
+        out = torch.empty((x.shape[0], self.N), dtype=torch.bfloat16, device=x.device)
+        _lib.check(_lib.lib().da_linear_packed(_lib.PREC_BF16, x.shape[0], self.K, self.N, _lib.ptr(x), self.K, _lib.ptr(self.weight),
+                                               _lib.ptr(self.packed), _lib.ptr(self.bias), int(act), None, _lib.ptr(out), self.N,
+                                               _lib.stream_ptr(x.device)))
+        return out
+
+
 def attn_csr(plan: GraphPlan, qkvs, heads, C_head, residual=None, act=_lib.ACT_NONE, return_alpha=False,
              precision="fp32"):
     prec = _PREC[precision]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 13
+#define DA_ABI_VERSION 14
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -265,6 +265,16 @@ int da_profile_read(da_denoiser *d, float *ms /* [DA_PROF_NCLASS] host */,
  * in act dtype `prec`, bias fp32.  Replaces torch.nn.Linear on the path.                   */
 int da_linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W,
               const float *bias, int act, const void *residual, void *out, int ldo, void *stream);
+
+/* The same layer with a constant weight packed ONCE into the fragment order of the row-panel kernel
+ * (da_gemm_xpanel.hip: bf16, K in {128, 256}, 512 <= Nout <= 4096, Nout % 32 == 0) -- what the denoiser does with
+ * its Q | K | V | skip projection weights at da_denoiser_create.  da_linear_packed_bytes returns 0 when the shape has
+ * no packed form; da_linear_packed falls back to da_linear's kernels when the row-panel kernel does not apply (short
+ * inputs, a residual) and gives the same values as da_linear up to the order of the fp32 bias addition.            */
+size_t da_linear_packed_bytes(int prec, int K, int Nout);
+int da_linear_pack(int prec, int K, int Nout, const void *W, int ldw /* 0 = K */, void *packed, void *stream);
+int da_linear_packed(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const void *packed,
+                     const float *bias, int act, const void *residual, void *out, int ldo, void *stream);
 
 /* One PyG TransformerConv attention (Transformer_GNN.py:32,38) over a CSR graph:
  *   qkvs [n_nodes, 4*H*C] act dtype (Q | K | V | skip), out [n_nodes, H*C] act dtype

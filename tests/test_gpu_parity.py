@@ -82,6 +82,28 @@ def test_da_linear_tall_inputs_w_in_registers(dev, M, K, N, act):
     assert rel(out.float(), ex) < 6e-3
 
 
+@pytest.mark.parametrize("M,K,N,act", [(28800, 256, 2560, 0), (26003, 128, 1024, 1), (33000, 256, 1056, 0), (57600, 256, 1024, 1),
+                                        (900, 256, 1024, 0)])
+def test_da_linear_packed_row_panel_kernel(dev, M, K, N, act):
+    """da_linear_pack + da_linear_packed (k_gemm_xpanel, da_gemm_xpanel.hip: a row panel of A in LDS, pre-packed W fragments
+    double-buffered in registers, register-direct epilogue) give da_linear's values BIT FOR BIT (same reduction order, bias
+    added after it): ragged last tile, Nout not a multiple of the 256-column group, GELU, and an input too short for the
+    panel kernel (falls back to da_linear's kernels)."""
+    from diffassemble_amd import engine as E
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, generator=g)
+    lin = E.PackedLinear(w.to(dev), b.to(dev))
+    assert lin.packed is not None
+    out = lin(x.to(dev), act)
+    ref = E.linear(x.to(dev), w.to(dev), b.to(dev), act, None, "bf16")
+    assert torch.equal(out, ref)
+    ex = torch.nn.functional.linear(x[:2048].float(), w.float(), b)
+    ex = torch.nn.functional.gelu(ex) if act else ex
+    assert rel(out[:2048].float().cpu(), ex) < 1e-2
+
+
 @pytest.mark.parametrize("C_head,loops", [(144, True), (144, False), (32, True), (32, False)])
 def test_da_conv_dense_tall_batch_through_w_in_registers_projection(dev, monkeypatch, C_head, loops):
     """Five 900-piece puzzles (4500 nodes >= 4096): the fused Q|K|V|skip projection goes through the W-in-registers

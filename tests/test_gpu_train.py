@@ -13,6 +13,14 @@ import cases as C
 from oracle import denoiser as OD
 from oracle import diffusion as ODF
 
+def _free_port():
+    """an unused TCP port for the rendezvous of one spawned world (fixed numbers collide with sockets in TIME_WAIT)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 pytestmark = pytest.mark.gpu
 GTOL = 1e-3
 
@@ -463,8 +471,8 @@ def test_data_parallel_training_two_ranks_equals_full_batch(dev):
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_dp_train_worker, args=(2, 29561, ret), nprocs=2, join=True)
-    mp.spawn(_dp_train_worker, args=(1, 29563, ret), nprocs=1, join=True)
+    mp.spawn(_dp_train_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    mp.spawn(_dp_train_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
     a, b, full = ret["flat2_0"], ret["flat2_1"], ret["flat1_0"]
     assert torch.equal(a, b), "data-parallel replicas diverged"
     assert torch.equal(ret["grad2_0"], ret["grad2_1"])
@@ -530,7 +538,7 @@ def test_data_parallel_training_from_pixels_averages_encoder_gradients(dev):
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_dp_pixels_worker, args=(2, 29571, ret), nprocs=2, join=True)
+    mp.spawn(_dp_pixels_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     mean = 0.5 * (ret["local_0"] + ret["local_1"])
     assert torch.equal(ret["synced_0"], ret["synced_1"])
     assert float((ret["synced_0"] - mean).abs().max()) <= 1e-6 * float(mean.abs().max())
@@ -604,9 +612,9 @@ def test_real_ddp_wrapper_two_ranks(dev):
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_ddp_wrapper_worker, args=(2, 29581, True, ret), nprocs=2, join=True)
+    mp.spawn(_ddp_wrapper_worker, args=(2, _free_port(), True, ret), nprocs=2, join=True)
     assert ret["err_True_0"] == "" and ret["err_True_1"] == "", (ret["err_True_0"], ret["err_True_1"])
-    mp.spawn(_dp_train_worker, args=(1, 29583, ret), nprocs=1, join=True)                # the full batch in one process
+    mp.spawn(_dp_train_worker, args=(1, _free_port(), ret), nprocs=1, join=True)                # the full batch in one process
     a, b, full = ret["flat_True_0"], ret["flat_True_1"], ret["flat1_0"]
     assert torch.equal(a, b), "replicas under the DDP wrapper diverged"
     keep = torch.ones_like(full, dtype=torch.bool)
@@ -623,6 +631,6 @@ def test_real_ddp_wrapper_without_find_unused_parameters_fails_loudly(dev):
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_ddp_wrapper_worker, args=(2, 29585, False, ret), nprocs=2, join=True)
+    mp.spawn(_ddp_wrapper_worker, args=(2, _free_port(), False, ret), nprocs=2, join=True)
     for r in (0, 1):
         assert "Expected to have finished reduction" in ret[f"err_False_{r}"], ret[f"err_False_{r}"]

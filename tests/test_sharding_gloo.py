@@ -8,6 +8,14 @@ import torch.multiprocessing as mp
 
 from oracle import weights as W
 
+def _free_port():
+    """an unused TCP port for the rendezvous of one spawned world (fixed numbers collide with sockets in TIME_WAIT)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 
 def _fake_denoise(x, feats, edge_index, batch):
     """A stand-in with the path's dependency structure: each node's output depends on its own graph
@@ -40,7 +48,7 @@ def test_puzzle_sharding_world2_gloo():
     sizes = [5, 9, 4, 7, 6]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, 29533, sizes, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), sizes, ret), nprocs=2, join=True)
     assert torch.allclose(ret["full"], ret["ref"])
     assert abs(ret["t"] - 0.2) < 1e-9
 
@@ -94,6 +102,6 @@ def _dp_worker(rank, world, port, ret):
 def test_data_parallel_gradient_allreduce_world2_gloo():
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_dp_worker, args=(2, 29541, ret), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     err = float((ret["dp"] - ret["full"]).abs().max() / ret["full"].abs().max())
     assert err < 1e-5, err
