@@ -99,13 +99,7 @@ __device__ __forceinline__ int select_topk(const float *row, int Npad, int k, in
 // scalar instruction per cycle per CU): bracketing tau between the k-th largest lane maximum and the maximum (fewer
 // 16-register rounds, 32 one-register rounds more) and searching two queries of a wave jointly both measured SLOWER (+13 %).
 template <int NR>
-__device__ __forceinline__ void select_set(const float *row, int Npad, int N, int k, int lane, int32_t *dst) {
-    unsigned u[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const unsigned b = __builtin_bit_cast(unsigned, r * 64 < Npad ? row[r * 64 + lane] : -INFINITY);
-        u[r] = b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
-    }
+__device__ __forceinline__ void select_set_keys(const unsigned (&u)[NR], int N, int k, int lane, int32_t *dst) {
     unsigned tau = 0;
     bool exact = false;                                 // exactly k keys >= tau: the set is known, stop refining
     for (int bit = 31; bit >= 0 && !exact; --bit) {
@@ -136,6 +130,72 @@ __device__ __forceinline__ void select_set(const float *row, int Npad, int N, in
         og += __builtin_popcountll(mg);
         oe += __builtin_popcountll(me);
     }
+}
+
+// The selection the encoder runs (round 3).  The full-width search above costs 32 rounds x NR compares + NR scalar bit
+// counts; almost all of it is spent on keys that are nowhere near the top.  Here a cheap lower bound of the threshold
+// comes first: every lane's largest key (NR - 1 v_max), and a value L that at least k of those 64 lane maxima reach (a
+// bit search over ONE register per lane) -- so at least k keys are >= L, and for keys spread over the lanes at random about
+// 1.2 k - 2 k of them are.  The keys >= L are compacted (in index order) into the row's own LDS space, which is dead once the
+// keys sit in registers, and ranked against each other there: candidate p's rank = the number of candidates with a larger
+// key, or an equal key and a lower index -- the tie rule of the ordered variant; ranks < k are the answer, written at
+// dst[rank], i.e. in decreasing order.  More than 128 candidates (keys bunched in few lanes): the full search.
+template <int NR>
+__device__ __forceinline__ void select_set(float *row, int Npad, int N, int k, int lane, int32_t *dst) {
+    unsigned u[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const unsigned b = __builtin_bit_cast(unsigned, r * 64 < Npad ? row[r * 64 + lane] : -INFINITY);
+        u[r] = b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+    }
+    if (Npad < 256) {                                   // rows shorter than the 256-entry scratch: full search
+        select_set_keys<NR>(u, N, k, lane, dst);
+        return;
+    }
+    unsigned m = u[0];
+#pragma unroll
+    for (int r = 1; r < NR; ++r) m = max(m, u[r]);
+    unsigned L = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = L | (1u << bit);
+        const int c = __builtin_popcountll(__ballot(m >= cand));
+        if (c >= k) {
+            L = cand;
+            if (c <= k + 2) break;                      // (nearly) as tight as lane maxima get
+        }
+    }
+    unsigned *ck = (unsigned *)row;
+    int *ci = (int *)row + 128;
+    int ct = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool ge = u[r] >= L;
+        const unsigned long long mk = __ballot(ge);
+        const int pos = ct + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+        if (ge && pos < 128) { ck[pos] = u[r]; ci[pos] = r * 64 + lane; }
+        ct += __builtin_popcountll(mk);
+    }
+    if (ct > 128) {
+        select_set_keys<NR>(u, N, k, lane, dst);
+        return;
+    }
+    const unsigned c0 = lane < ct ? ck[lane] : 0u, c1 = lane + 64 < ct ? ck[lane + 64] : 0u;
+    const int i0 = ci[lane], i1 = ci[lane + 64];
+    int r0 = 0, r1 = 0;
+    if (ct <= 64) {
+        for (int j = 0; j < ct; ++j) {
+            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)c0, j);
+            r0 += (kj > c0 || (kj == c0 && j < lane)) ? 1 : 0;
+        }
+    } else {
+        for (int j = 0; j < ct; ++j) {
+            const unsigned kj = ck[j];
+            r0 += (kj > c0 || (kj == c0 && j < lane)) ? 1 : 0;
+            r1 += (kj > c1 || (kj == c1 && j < lane + 64)) ? 1 : 0;
+        }
+    }
+    if (lane < ct && r0 < k) dst[r0] = min(i0, N - 1);
+    if (lane + 64 < ct && r1 < k) dst[r1] = min(i1, N - 1);
 }
 
 // Same selection for rows that do not fit the registers: the scores stay in LDS, the winner is overwritten.
@@ -305,13 +365,18 @@ __device__ __forceinline__ void vn_act(float &p0, float &p1, float &p2, float d0
 template <bool HAS_B>
 __global__ __launch_bounds__(128, 1) void k_pcd_edge(const float *__restrict__ T, const int32_t *__restrict__ idx,
                                                      const float *__restrict__ bn_a, const float *__restrict__ wb, int N,
-                                                     long long total, float *__restrict__ Xout) {
+                                                     int clouds, float *__restrict__ Xout) {
     // The point's own U / Ud rows stay in 126 registers (re-reading them per neighbour doubled the divergent 16-byte
     // loads the kernel is bound by: 5.4 ms vs 2.3 ms per 640 000 points); one wave per SIMD, overflow into AGPRs.
     constexpr bool PIN_U = true;
-    const long long p = (long long)blockIdx.x * 128 + threadIdx.x;
-    if (p >= total) return;
-    const long long base = p / N * N;
+    // XCD-aware block map (workgroup L runs on XCD L % 8): the blocks of ONE cloud share an XCD, so the cloud's A | Ad rows
+    // (512 B x N = 512 KB at N = 1000), which its N x 20 gathers hit at random, are filled into one L2 once instead of into
+    // all eight
+    const int nb = (N + 127) >> 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cloud = (slot / nb) * 8 + xcd, i = (slot % nb) * 128 + (int)threadIdx.x;
+    if (cloud >= clouds || i >= N) return;
+    const long long base = (long long)cloud * N, p = base + i;
     float acc[V3];
 #pragma unroll
     for (int e = 0; e < V3; ++e) acc[e] = 0.f;
@@ -555,9 +620,9 @@ int da_pcd_encoder_forward(const da_pcd_encoder_weights *w, int n_parts, int n_p
             if (s == 0) k_pcd_premap<1><<<nb, 256, 0, st>>>(xin, ldx, w->premap[s], total, T);
             else k_pcd_premap<VC><<<nb, 256, 0, st>>>(xin, ldx, w->premap[s], total, T);
             DA_LAUNCH_CHECK();
-            const int ne = (int)((total + 127) / 128);
-            if (w->conv_b[s]) k_pcd_edge<true><<<ne, 128, 0, st>>>(T, idx, w->bn_a[s], w->conv_b[s], n_points, total, X[s]);
-            else k_pcd_edge<false><<<ne, 128, 0, st>>>(T, idx, w->bn_a[s], nullptr, n_points, total, X[s]);
+            const int ne = ((B + 7) / 8) * 8 * ((n_points + 127) / 128);
+            if (w->conv_b[s]) k_pcd_edge<true><<<ne, 128, 0, st>>>(T, idx, w->bn_a[s], w->conv_b[s], n_points, B, X[s]);
+            else k_pcd_edge<false><<<ne, 128, 0, st>>>(T, idx, w->bn_a[s], nullptr, n_points, B, X[s]);
             DA_LAUNCH_CHECK();
         }
         k_pcd_conv6<<<dim3(nblk, B), 256, 0, st>>>(X[0], X[1], X[2], w->conv6, feat, n_points, partial);

@@ -1,0 +1,29 @@
+#!/bin/bash
+# GPU box: everything the round's tables quote, in one call -- rocprofv3 kernel statistics + PMC traffic of the headline and the
+# configuration-3 variants, SQ counters of the attention and projection kernels, and one bench line per configuration / mode.
+# Outputs go to gpurun_out/<round>_*; copy them to profiles/<round>/ afterwards.    usage: ROUND=r03 bash tools/collect_round.sh
+set -u
+export ROUND=${ROUND:-r03}
+O=gpurun_out
+bash tools/collect_profiles.sh headline --config 3p
+bash tools/collect_profiles.sh config3_d539 --config 3
+bash tools/collect_profiles.sh config3_d90 --config 3 --degree 90
+DA_HYBRID=off bash tools/collect_profiles.sh config3_d539_csr_only --config 3 --steps 4
+DA_HYBRID=off bash tools/collect_profiles.sh config3_d90_csr_only --config 3 --degree 90 --steps 4
+bash tools/collect_attn_pmc.sh > /dev/null 2>&1
+bash tools/collect_gemm_pmc.sh model > /dev/null 2>&1
+b() { tag=$1; shift; python bench.py "$@" > $O/${ROUND}_bench_$tag.json 2> $O/${ROUND}_bench_$tag.err; tail -c 300 $O/${ROUND}_bench_$tag.json | head -c 0; echo "bench $tag rc=$?"; }
+b config_3p --steps 100 --warmup 10
+b config_1 --config 1
+b config_2 --config 2
+b config_3 --config 3
+b config_3_d90 --config 3 --degree 90
+b config_4 --config 4
+b config_5 --config 5
+b config_5_exophormer_d539 --config 5 --arch exophormer --train-side 30 --degree 539 --train-puzzles 16
+b config_5_pixels --config 5 --pixels
+b e2e --mode e2e
+b encode --mode encode
+b pcd_encode --mode encode --config 4
+b config_3p_cpu_1_thread --steps 20 --warmup 5 --cpu-baseline-full --no-parity-mode --replays 5
+ls $O | grep ${ROUND}_ | wc -l
