@@ -10,13 +10,16 @@
 //   chamfer_distance.py:148-149         pytorch3d knn_points(K = 1) both ways (utils_3d.py:1089-1129 calc_part_acc)
 // The reference materialises the [P, N, N] distance matrix, the [P, 2C, 3, N, 20] edge tensor and ~10 elementwise
 // temporaries of that size per layer (fp32; 20 x 42 x 3 floats per point and layer).  Here:
-//   * k_pcd_knn keeps a 32-query x N slab of the distance matrix in LDS and selects the 20 nearest per query by 20
-//     wave-wide arg-max rounds: the matrix never reaches HBM, only the int32 neighbour lists do;
+//   * k_pcd_knn / k_pcd_knn64_mfma keep a 16- / 32-query x N slab of the distance matrix in LDS (the 63-dimensional stages
+//     compute it on the matrix cores in fp32) and select the 20 nearest per query there (select_set: a lower bound of the
+//     threshold from the lanes' maxima, the few keys above it compacted and ranked): the matrix never reaches HBM, only the
+//     int32 neighbour lists do;
 //   * the first layer of a stage is linear in cat(x_j - x_i, x_i), so it is evaluated PER POINT once
 //     (k_pcd_premap: A = W[:, :C] x, U = (W[:, C:] - W[:, :C]) x, for the feature and the direction maps) and an edge
 //     costs two vector adds: p = A_j + U_i.  20x fewer multiplies than the reference's per-edge matmul;
-//   * k_pcd_edge (one thread per point) walks the 20 neighbours, applies BatchNorm-of-the-norm + the vector leaky
-//     projection, the stage's second VN layer (weights through scalar loads) and the mean over neighbours in registers;
+//   * k_pcd_edge (one thread per point) walks the 20 neighbours -- their rows requested one neighbour ahead of use --,
+//     applies BatchNorm-of-the-norm + the vector leaky projection, the stage's second VN layer (weights through scalar
+//     loads) and the mean over neighbours in registers;
 //   * k_pcd_conv6 fuses the concat, conv6, its activation and the mean over points (wave reduction -> per-block
 //     partials, summed in a fixed order: deterministic).
 // All arithmetic is fp32 on the vector ALU: the neighbour selection is discrete, and the whole encoder runs once per
@@ -227,9 +230,9 @@ __device__ __forceinline__ int select_topk_lds(volatile float *row, int Npad, in
 // grid (ceil(N / QB), clouds), 256 threads.  LDS: the QB squared query norms and QB x Npad scores.
 // score(i, j) = -|xi|^2 + 2 xi.xj - |xj|^2, the reference's formula (vn_dgcnn.py:115-117); the k LARGEST are kept,
 // in decreasing order (topk), ties broken towards the lower index.  Non-finite scores rank last.
-template <int F>
-__global__ __launch_bounds__(256) void k_pcd_knn(const float *__restrict__ X, int ldx, int N, int QB, int Npad, int k,
-                                                 int ordered, int32_t *__restrict__ idx) {
+template <int F, int NT = 256>
+__global__ __launch_bounds__(NT) void k_pcd_knn(const float *__restrict__ X, int ldx, int N, int QB, int Npad, int k,
+                                                int ordered, int32_t *__restrict__ idx) {
     extern __shared__ float smem[];
     float *qxx = smem, *score = qxx + ((QB + 3) & ~3);
     const int cloud = blockIdx.y, q0 = blockIdx.x * QB, tid = threadIdx.x;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void k_pcd_knn(const float *__restrict__ X, in
     __syncthreads();
     // Scores of this thread's candidates against the block's queries.  A query row is wave-uniform: it comes through
     // the scalar cache into SGPRs (no LDS traffic), the candidate row sits in VGPRs, the dot product is packed fp32 FMAs.
-    for (int j = tid; j < Npad; j += 256) {
+    for (int j = tid; j < Npad; j += NT) {
         if (j < N) {
             if constexpr (F == 64) {
                 f32x2 c[32];
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void k_pcd_knn(const float *__restrict__ X, in
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
-    for (int q = wave; q < QB && q0 + q < N; q += 4) {
+    for (int q = wave; q < QB && q0 + q < N; q += NT / 64) {
         float *row = score + q * Npad;
         int32_t *dst = idx + ((size_t)cloud * N + q0 + q) * k;
         if (!ordered && Npad <= 1024) {
@@ -300,6 +303,92 @@ __global__ __launch_bounds__(256) void k_pcd_knn(const float *__restrict__ X, in
         else if (Npad <= 1024) r = select_topk<16>(row, Npad, k, lane);
         else r = select_topk_lds(row, Npad, k, lane);
         if (lane < k) dst[lane] = min(r, N - 1);
+    }
+}
+
+// The same neighbour search for the 63-dimensional stages with the Gram matrix on the matrix cores (round 3): the scores of a
+// block are a [32 queries] x [N candidates] x 64 product; on the vector ALU the query row streams through SGPRs, one s_load
+// burst per query with nothing to hide it behind at two waves per SIMD.  v_mfma_f32_32x32x2_f32 (full fp32 products and sums)
+// does a 32-candidate x 32-query tile in 32 instructions.  640 clouds of 1000 points: k_pcd_knn<64> 2.49 ms -> 1.97 ms here;
+// by ablation 0.3 ms is loading and 0.75 ms the MFMA phase (floor 0.62 ms: 82 GFLOP at the 137 TFLOP/s fp32 matrix rate), the
+// rest the selection.  The squared norms come from the kernel that produced the rows (k_pcd_edge writes |row|^2 next to them):
+// computing them here, per block, re-read the whole cloud once more and cost 0.7 ms.  Operands: the MFMA's k pair of step s is (s, 32 + s), so lane (row, kk)
+// holds the CONTIGUOUS half [32 kk, 32 kk + 32) of its row -- eight 16-byte loads; A = candidates, B = queries, so that a
+// lane ends up with 4 x 4 consecutive candidates of ONE query and writes them as four 16-byte LDS stores (row stride
+// Npad + 4 floats: conflict-free).  grid (ceil(N / 32), clouds), 512 threads, one block per CU (the 32 x N slab is 129 KB at
+// N = 1000); the selection that follows is select_set, one query per wave at a time.
+typedef float f32x16k __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(1024) void k_pcd_knn64_mfma(const float *__restrict__ X, const float *__restrict__ XN, int N, int Npad, int k,
+                                                         int32_t *__restrict__ idx) {
+    extern __shared__ float smem[];
+    const int RS = Npad + 4;                              // score row stride (floats)
+    float *score = smem, *cxx = score + 32 * RS, *qxx = cxx + Npad;
+    const int cloud = blockIdx.y, q0 = blockIdx.x * 32, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *Xc = X + (size_t)cloud * N * VROW, *XNc = XN + (size_t)cloud * N;
+    // squared norms of the candidates and of the block's queries: written next to the rows by the kernel that produced them
+    for (int j = tid; j < Npad + 32; j += 1024) {
+        if (j < Npad) cxx[j] = XNc[min(j, N - 1)];
+        else qxx[j - Npad] = XNc[min(q0 + j - Npad, N - 1)];
+    }
+    const int rl = lane & 31, kk = lane >> 5;
+    float qr[32];
+    {
+        const float4 *r = (const float4 *)(Xc + (size_t)min(q0 + rl, N - 1) * VROW + 32 * kk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float4 v = r[e]; qr[4 * e] = v.x; qr[4 * e + 1] = v.y; qr[4 * e + 2] = v.z; qr[4 * e + 3] = v.w; }
+    }
+    auto load_tile = [&](float4 (&cr)[8], int c0) {
+        const float4 *r = (const float4 *)(Xc + (size_t)min(c0 + rl, N - 1) * VROW + 32 * kk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cr[e] = r[e];
+    };
+    __syncthreads();
+    const float nq = -qxx[rl];
+    auto do_tile = [&](const float4 (&cr)[8], int c0) {
+        f32x16k acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cr[e].x, qr[4 * e], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cr[e].y, qr[4 * e + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cr[e].z, qr[4 * e + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cr[e].w, qr[4 * e + 3], acc, 0, 0, 0);
+        }
+        // lane (query rl, half kk) holds candidates c0 + 8 a + 4 kk + b in acc[4 a + b]
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int cb = c0 + 8 * a + 4 * kk;
+            const float4 cx = *(const float4 *)(cxx + cb);
+            float o[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float sc = (nq - (-2.f * acc[4 * a + b])) - (b == 0 ? cx.x : b == 1 ? cx.y : b == 2 ? cx.z : cx.w);
+                o[b] = cb + b < N ? (fabsf(sc) <= FLT_MAX ? sc + 0.f : -FLT_MAX) : -INFINITY;   // NaN / inf rank last, the padding after them
+            }
+            *(float4 *)(score + rl * RS + cb) = float4{o[0], o[1], o[2], o[3]};
+        }
+    };
+    // the wave's candidate tiles, the next tile's rows in flight under the current tile's MFMAs
+    float4 ca[8], cb2[8];
+    int c0 = wave * 32;
+    if (c0 < Npad) load_tile(ca, c0);
+    for (; c0 < Npad; c0 += 1024) {
+        if (c0 + 512 < Npad) load_tile(cb2, c0 + 512);
+        do_tile(ca, c0);
+        if (c0 + 512 < Npad) {
+            if (c0 + 1024 < Npad) load_tile(ca, c0 + 1024);
+            do_tile(cb2, c0 + 512);
+        }
+    }
+    __syncthreads();
+    for (int q = wave; q < 32 && q0 + q < N; q += 16) {
+        float *row = score + q * RS;
+        int32_t *dst = idx + ((size_t)cloud * N + q0 + q) * k;
+        if (Npad <= 256) select_set<4>(row, Npad, N, k, lane, dst);
+        else if (Npad <= 512) select_set<8>(row, Npad, N, k, lane, dst);
+        else select_set<16>(row, Npad, N, k, lane, dst);
     }
 }
 
@@ -365,13 +454,12 @@ __device__ __forceinline__ void vn_act(float &p0, float &p1, float &p2, float d0
 template <bool HAS_B>
 __global__ __launch_bounds__(128, 1) void k_pcd_edge(const float *__restrict__ T, const int32_t *__restrict__ idx,
                                                      const float *__restrict__ bn_a, const float *__restrict__ wb, int N,
-                                                     int clouds, float *__restrict__ Xout) {
+                                                     int clouds, float *__restrict__ Xout, float *__restrict__ xn) {
     // The point's own U / Ud rows stay in 126 registers (re-reading them per neighbour doubled the divergent 16-byte
     // loads the kernel is bound by: 5.4 ms vs 2.3 ms per 640 000 points); one wave per SIMD, overflow into AGPRs.
-    constexpr bool PIN_U = true;
     // XCD-aware block map (workgroup L runs on XCD L % 8): the blocks of ONE cloud share an XCD, so the cloud's A | Ad rows
     // (512 B x N = 512 KB at N = 1000), which its N x 20 gathers hit at random, are filled into one L2 once instead of into
-    // all eight
+    // all eight (same box, 640 x 1000 points: 2.23 vs 2.36 ms with the second layer, 1.02 vs 1.12 without)
     const int nb = (N + 127) >> 7;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cloud = (slot / nb) * 8 + xcd, i = (slot % nb) * 128 + (int)threadIdx.x;
@@ -380,38 +468,50 @@ __global__ __launch_bounds__(128, 1) void k_pcd_edge(const float *__restrict__ T
     float acc[V3];
 #pragma unroll
     for (int e = 0; e < V3; ++e) acc[e] = 0.f;
-    float4 uu[PIN_U ? 16 : 1], ud[PIN_U ? 16 : 1];
-    if constexpr (PIN_U) {
+    float4 uu[16], ud[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            uu[e] = *(const float4 *)(T + p * 4 * VROW + 2 * VROW + 4 * e);
-            ud[e] = *(const float4 *)(T + p * 4 * VROW + 3 * VROW + 4 * e);
-        }
+    for (int e = 0; e < 16; ++e) {
+        uu[e] = *(const float4 *)(T + p * 4 * VROW + 2 * VROW + 4 * e);
+        ud[e] = *(const float4 *)(T + p * 4 * VROW + 3 * VROW + 4 * e);
+    }
+    // The neighbour rows run one neighbour AHEAD of their use (round 3): chunk c of neighbour r + 1 is requested into the
+    // registers chunk c of neighbour r was just read from, so a divergent 16-byte gather has a whole neighbour's arithmetic
+    // (11 k cycles with the second layer) to land instead of being waited for on the spot -- at one wave per SIMD nothing else
+    // covered that wait: -13 % with the second layer, -9 % without (2.03 -> 1.77 and 1.35 -> 1.23 ms per 640 000 points on the
+    // same kind of box).  What is left above the ~1.15 ms of vector arithmetic is the second layer's weight stream (64 s_load per
+    // neighbour, 53 waits on them).
+    float4 ga[16], gd[16];
+    {
+        const float *t0 = T + (base + idx[p * KNN]) * 4 * VROW;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { ga[e] = *(const float4 *)(t0 + 4 * e); gd[e] = *(const float4 *)(t0 + VROW + 4 * e); }
     }
 #pragma unroll 1
     for (int r = 0; r < KNN; ++r) {
-        const int j = idx[p * KNN + r];
-        const float *tj = T + (base + j) * 4 * VROW;
-        int toff = 0, woff = 0;                           // opaque zeros: keep the U / Ud loads and the weight loads
+        const bool more = r + 1 < KNN;
+        const float *tn = T + (base + idx[p * KNN + (more ? r + 1 : r)]) * 4 * VROW;
+        int toff = 0, woff = 0;                           // opaque zeros: keep the next row's loads and the weight loads
         asm volatile("" : "+v"(toff));                    // inside the loop (not hoisted into ~1000 live registers)
         asm volatile("" : "+s"(woff));
-        const float *ti = T + p * 4 * VROW + 2 * VROW + toff;
+        tn += toff;
         const float *wl = wb + woff;
         // h[k][c / 2] holds the channel pair (c, c + 1) of component k: the operand layout of the packed second layer
         f32x2 h[3][VC / 2 + 1];
         h[0][VC / 2] = h[1][VC / 2] = h[2][VC / 2] = f32x2{0.f, 0.f};
-        // first layer, four channels (12 floats = three 16-byte loads per operand) at a time; channel 20 + the pad last
+        // first layer, four channels (12 floats = three 16-byte pieces per operand) at a time; channel 20 + the pad last
 #pragma unroll
         for (int e0 = 0; e0 < VROW; e0 += 12) {
             float a[12], ad[12];
 #pragma unroll
             for (int e = 0; e < 12 && e0 + e < VROW; e += 4) {
-                const float4 x = *(const float4 *)(tj + e0 + e), xd = *(const float4 *)(tj + VROW + e0 + e);
-                float4 y, yd;
-                if constexpr (PIN_U) { y = uu[(e0 + e) / 4]; yd = ud[(e0 + e) / 4]; }
-                else { y = *(const float4 *)(ti + e0 + e); yd = *(const float4 *)(ti + VROW + e0 + e); }
+                const float4 x = ga[(e0 + e) / 4], xd = gd[(e0 + e) / 4];
+                const float4 y = uu[(e0 + e) / 4], yd = ud[(e0 + e) / 4];
                 a[e] = x.x + y.x; a[e + 1] = x.y + y.y; a[e + 2] = x.z + y.z; a[e + 3] = x.w + y.w;
                 ad[e] = xd.x + yd.x; ad[e + 1] = xd.y + yd.y; ad[e + 2] = xd.z + yd.z; ad[e + 3] = xd.w + yd.w;
+                if (more) {
+                    ga[(e0 + e) / 4] = *(const float4 *)(tn + e0 + e);
+                    gd[(e0 + e) / 4] = *(const float4 *)(tn + VROW + e0 + e);
+                }
             }
 #pragma unroll
             for (int cc = 0; cc < 4 && e0 / 3 + cc < VC; ++cc) {
@@ -422,7 +522,7 @@ __global__ __launch_bounds__(128, 1) void k_pcd_edge(const float *__restrict__ T
                 else if (c & 1) { h[0][c / 2].y = p0; h[1][c / 2].y = p1; h[2][c / 2].y = p2; }
                 else { h[0][c / 2].x = p0; h[1][c / 2].x = p1; h[2][c / 2].x = p2; }
             }
-            __builtin_amdgcn_sched_barrier(0);            // do not hoist every chunk's loads to the top (VGPR budget)
+            __builtin_amdgcn_sched_barrier(0);            // keep every chunk's reloads behind its reads
         }
         if constexpr (HAS_B) {
             constexpr int WR = VC / 2 + 1;                 // 11 weight pairs per (zero-padded) row of 22
@@ -446,9 +546,11 @@ __global__ __launch_bounds__(128, 1) void k_pcd_edge(const float *__restrict__ T
         }
     }
     float *xo = Xout + p * VROW;
+    float nn = 0.f;                                       // |row|^2 for the next stage's neighbour search (k_pcd_knn64_mfma)
 #pragma unroll
-    for (int e = 0; e < V3; ++e) xo[e] = acc[e] / (float)KNN;
+    for (int e = 0; e < V3; ++e) { const float v = acc[e] / (float)KNN; xo[e] = v; nn += v * v; }
     xo[V3] = 0.f;
+    if (xn) xn[p] = nn;
 }
 
 // conv6 (63 -> feat channels, ONE shared direction) over cat(x1, x2, x3), its activation, and the sum over the
@@ -536,11 +638,23 @@ __global__ __launch_bounds__(256) void k_nearest_sq(const float *__restrict__ a,
     if (i < N) out[(size_t)cloud * N + i] = best;
 }
 
-static int knn_launch(int clouds, int N, int dim, const float *x, int ldx, int k, int ordered, int32_t *idx, hipStream_t st) {
+static int knn_launch(int clouds, int N, int dim, const float *x, int ldx, int k, int ordered, int32_t *idx, hipStream_t st,
+                      const float *xn = nullptr) {
     const int F = dim <= 3 ? 3 : 64;
     const int Npad = (N + 63) & ~63;
+    static int mfma_knn = -1;
+    if (mfma_knn < 0) { const char *e = getenv("DA_PCD_KNN_VALU"); mfma_knn = (e && e[0] == '1') ? 0 : 1; }
+    if (F == 64 && !ordered && ldx == VROW && Npad <= 1024 && mfma_knn && xn) {
+        const size_t lds = (size_t)(32 * (Npad + 4) + Npad + 32) * sizeof(float);
+        static bool attrm = false;
+        if (!attrm) { DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn64_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); attrm = true; }
+        k_pcd_knn64_mfma<<<dim3((N + 31) / 32, clouds), 1024, lds, st>>>(x, xn, N, Npad, k, idx);
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
     int QB = 32;
     auto bytes = [&](int qb) { return (size_t)(((qb + 3) & ~3) + (size_t)qb * Npad) * sizeof(float); };
+    // (one 1024-thread block of 32 queries per CU instead of two 256-thread blocks of 16: 1.11 vs 0.93 ms for the 3-D stage)
     while (QB > 1 && bytes(QB) > 64 * 1024) QB >>= 1;          // two blocks per CU
     DA_REQUIRE(bytes(QB) <= 160 * 1024 - 512, "kNN: %d points per cloud do not fit the LDS slab", N);
     const dim3 grid((N + QB - 1) / QB, clouds);
@@ -583,7 +697,7 @@ int da_nearest_sq(int n_clouds, int n, int m, const float *a, const float *b, fl
 size_t da_pcd_encoder_workspace_bytes(int n_points, int chunk, int feat_dim) {
     const size_t pts = (size_t)chunk * n_points, nblk = (n_points + 255) / 256;
     return align_up(pts * VROW * 4, 256) * 3 + align_up(pts * 4 * VROW * 4, 256) + align_up(pts * KNN * 4, 256) +
-           align_up((size_t)chunk * nblk * feat_dim * 3 * 4, 256);
+           align_up((size_t)chunk * nblk * feat_dim * 3 * 4, 256) + 2 * align_up(pts * 4, 256);
 }
 
 int da_pcd_encoder_forward(const da_pcd_encoder_weights *w, int n_parts, int n_points, const float *points, int inv,
@@ -606,6 +720,9 @@ int da_pcd_encoder_forward(const da_pcd_encoder_weights *w, int n_parts, int n_p
     float *T = (float *)(base + 3 * align_up(cp * VROW * 4, 256));
     int32_t *idx = (int32_t *)((char *)T + align_up(cp * 4 * VROW * 4, 256));
     float *partial = (float *)((char *)idx + align_up(cp * KNN * 4, 256));
+    float *xnorm[2];                                      // |row|^2 of X[0] / X[1], written by the edge kernel of that stage
+    xnorm[0] = (float *)((char *)partial + align_up((size_t)chunk * ((n_points + 255) / 256) * feat * 3 * 4, 256));
+    xnorm[1] = (float *)((char *)xnorm[0] + align_up(cp * 4, 256));
     const int nblk = (n_points + 255) / 256;
     for (int p0 = 0; p0 < n_parts; p0 += chunk) {
         const int B = n_parts - p0 < chunk ? n_parts - p0 : chunk;
@@ -614,15 +731,16 @@ int da_pcd_encoder_forward(const da_pcd_encoder_weights *w, int n_parts, int n_p
         for (int s = 0; s < 3; ++s) {
             const float *xin = s == 0 ? pts : X[s - 1];
             const int ldx = s == 0 ? 3 : VROW;
-            int rc = knn_launch(B, n_points, s == 0 ? 3 : V3, xin, ldx, KNN, 0, idx, st);      // the pooling is order-free
+            int rc = knn_launch(B, n_points, s == 0 ? 3 : V3, xin, ldx, KNN, 0, idx, st, s == 0 ? nullptr : xnorm[s - 1]);      // the pooling is order-free
             if (rc) return rc;
             const int nb = (int)((total + 255) / 256);
             if (s == 0) k_pcd_premap<1><<<nb, 256, 0, st>>>(xin, ldx, w->premap[s], total, T);
             else k_pcd_premap<VC><<<nb, 256, 0, st>>>(xin, ldx, w->premap[s], total, T);
             DA_LAUNCH_CHECK();
             const int ne = ((B + 7) / 8) * 8 * ((n_points + 127) / 128);
-            if (w->conv_b[s]) k_pcd_edge<true><<<ne, 128, 0, st>>>(T, idx, w->bn_a[s], w->conv_b[s], n_points, B, X[s]);
-            else k_pcd_edge<false><<<ne, 128, 0, st>>>(T, idx, w->bn_a[s], nullptr, n_points, B, X[s]);
+            float *xno = s < 2 ? xnorm[s] : nullptr;
+            if (w->conv_b[s]) k_pcd_edge<true><<<ne, 128, 0, st>>>(T, idx, w->bn_a[s], w->conv_b[s], n_points, B, X[s], xno);
+            else k_pcd_edge<false><<<ne, 128, 0, st>>>(T, idx, w->bn_a[s], nullptr, n_points, B, X[s], xno);
             DA_LAUNCH_CHECK();
         }
         k_pcd_conv6<<<dim3(nblk, B), 256, 0, st>>>(X[0], X[1], X[2], w->conv6, feat, n_points, partial);
