@@ -13,14 +13,19 @@
 //     two-stage ring) and every K fragment read from LDS feeds two MFMA chains;
 //   * the ring holds 32-key blocks (12 KB at C = 144), six of them: four blocks in flight per workgroup, one barrier per
 //     block, two workgroups per CU (144 KB of LDS);
-//   * software pipeline inside a wave: the chain S(b, slab 1) is issued interleaved with the exponentials of S(b, slab 0),
-//     the chain S(b + 1, slab 0) with those of S(b, slab 1); the K fragments of block b + 1 replace those of block b one
-//     by one, each behind the MFMA that consumed the old value;
-//   * the softmax shift costs no instruction: Q arrives PRE-SCALED by log2(e) / sqrt(C) (folded into the projection
-//     weights at pack time), and the running reference -m enters as the INITIAL VALUE of the S^T accumulator (a 16-register
-//     tuple per slab, rewritten only when the reference moves), so p = exp2(acc) directly;
-//   * the first block takes its true row max as the reference; afterwards the reference only moves when a block's sum says
-//     it is stale (> 2^14), as in k_attn_dense.
+//   * software pipeline inside a wave: the chain S(b, slab 1) is issued interleaved, instruction by instruction, with the
+//     exponentials of S(b, slab 0), the chain S(b + 1, slab 0) with those of S(b, slab 1); the K fragments stream through a
+//     three-deep register ring, each read three MFMAs ahead of its use.  hipcc issues such chains as bursts, so the two
+//     straight-line regions of the steady-state block are GENERATED inline asm with pinned registers
+//     (tools/gen_attn_dual_asm.py -> da_attn_dual_asm.inc: register map, slot schedule and the hazards it pads by hand);
+//   * the softmax shift costs no instruction in the common case: Q arrives PRE-SCALED by log2(e) / sqrt(C) (folded into the
+//     projection weights at pack time), so p = exp2(s) directly.  FAST mode runs without any shift and checks every block's row
+//     sums against [2^-60, 2^60]; a block outside that range sends the workgroup -- one way, for the rest of the tile -- to the
+//     GENERIC path (block(): running maximum, rescale, the round-2 arithmetic), which also serves the first / last / ragged
+//     blocks and the diagonal of self-loop-free graphs;
+//   * a workgroup is PERSISTENT over `tpw` consecutive query tiles of one (graph, head) (all of them when there are >= 512
+//     (graph, head) pairs): the ring keeps streaming across tile boundaries (block indices are global, the refill rule is
+//     `issued - NST <= blk - 2`), only Q is reloaded; measured 1 % over one tile per workgroup.
 #include <stdlib.h>
 
 #include "da_common.h"

@@ -17,8 +17,7 @@
 //   * the first layer of a stage is linear in cat(x_j - x_i, x_i), so it is evaluated PER POINT once
 //     (k_pcd_premap: A = W[:, :C] x, U = (W[:, C:] - W[:, :C]) x, for the feature and the direction maps) and an edge
 //     costs two vector adds: p = A_j + U_i.  20x fewer multiplies than the reference's per-edge matmul;
-//   * k_pcd_edge (one thread per point) walks the 20 neighbours -- their rows requested one neighbour ahead of use --,
-//     applies BatchNorm-of-the-norm + the vector leaky projection, the stage's second VN layer (weights through scalar
+//   * k_pcd_edge (one thread per point) walks the 20 neighbours, applies BatchNorm-of-the-norm + the vector leaky projection, the stage's second VN layer (weights through scalar
 //     loads) and the mean over neighbours in registers;
 //   * k_pcd_conv6 fuses the concat, conv6, its activation and the mean over points (wave reduction -> per-block
 //     partials, summed in a fixed order: deterministic).
@@ -455,11 +454,15 @@ template <bool HAS_B>
 __global__ __launch_bounds__(128, 1) void k_pcd_edge(const float *__restrict__ T, const int32_t *__restrict__ idx,
                                                      const float *__restrict__ bn_a, const float *__restrict__ wb, int N,
                                                      int clouds, float *__restrict__ Xout, float *__restrict__ xn) {
+    // (Round 3, tried and withdrawn: requesting chunk c of neighbour r + 1 into the registers chunk c of neighbour r was just read
+    // from -- 460 VGPRs, 32 gathers in flight per thread.  1.77 vs 2.03 ms per 640 000 points on one kind of box of the pool,
+    // 2.91 vs 2.23 ms on another: 32 MB of outstanding gathers chip-wide is more than the slower boxes' memory side digests.)
     // The point's own U / Ud rows stay in 126 registers (re-reading them per neighbour doubled the divergent 16-byte
     // loads the kernel is bound by: 5.4 ms vs 2.3 ms per 640 000 points); one wave per SIMD, overflow into AGPRs.
+    constexpr bool PIN_U = true;
     // XCD-aware block map (workgroup L runs on XCD L % 8): the blocks of ONE cloud share an XCD, so the cloud's A | Ad rows
     // (512 B x N = 512 KB at N = 1000), which its N x 20 gathers hit at random, are filled into one L2 once instead of into
-    // all eight (same box, 640 x 1000 points: 2.23 vs 2.36 ms with the second layer, 1.02 vs 1.12 without)
+    // all eight
     const int nb = (N + 127) >> 7;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cloud = (slot / nb) * 8 + xcd, i = (slot % nb) * 128 + (int)threadIdx.x;
@@ -468,50 +471,38 @@ __global__ __launch_bounds__(128, 1) void k_pcd_edge(const float *__restrict__ T
     float acc[V3];
 #pragma unroll
     for (int e = 0; e < V3; ++e) acc[e] = 0.f;
-    float4 uu[16], ud[16];
+    float4 uu[PIN_U ? 16 : 1], ud[PIN_U ? 16 : 1];
+    if constexpr (PIN_U) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        uu[e] = *(const float4 *)(T + p * 4 * VROW + 2 * VROW + 4 * e);
-        ud[e] = *(const float4 *)(T + p * 4 * VROW + 3 * VROW + 4 * e);
-    }
-    // The neighbour rows run one neighbour AHEAD of their use (round 3): chunk c of neighbour r + 1 is requested into the
-    // registers chunk c of neighbour r was just read from, so a divergent 16-byte gather has a whole neighbour's arithmetic
-    // (11 k cycles with the second layer) to land instead of being waited for on the spot -- at one wave per SIMD nothing else
-    // covered that wait: -13 % with the second layer, -9 % without (2.03 -> 1.77 and 1.35 -> 1.23 ms per 640 000 points on the
-    // same kind of box).  What is left above the ~1.15 ms of vector arithmetic is the second layer's weight stream (64 s_load per
-    // neighbour, 53 waits on them).
-    float4 ga[16], gd[16];
-    {
-        const float *t0 = T + (base + idx[p * KNN]) * 4 * VROW;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { ga[e] = *(const float4 *)(t0 + 4 * e); gd[e] = *(const float4 *)(t0 + VROW + 4 * e); }
+        for (int e = 0; e < 16; ++e) {
+            uu[e] = *(const float4 *)(T + p * 4 * VROW + 2 * VROW + 4 * e);
+            ud[e] = *(const float4 *)(T + p * 4 * VROW + 3 * VROW + 4 * e);
+        }
     }
 #pragma unroll 1
     for (int r = 0; r < KNN; ++r) {
-        const bool more = r + 1 < KNN;
-        const float *tn = T + (base + idx[p * KNN + (more ? r + 1 : r)]) * 4 * VROW;
-        int toff = 0, woff = 0;                           // opaque zeros: keep the next row's loads and the weight loads
+        const int j = idx[p * KNN + r];
+        const float *tj = T + (base + j) * 4 * VROW;
+        int toff = 0, woff = 0;                           // opaque zeros: keep the U / Ud loads and the weight loads
         asm volatile("" : "+v"(toff));                    // inside the loop (not hoisted into ~1000 live registers)
         asm volatile("" : "+s"(woff));
-        tn += toff;
+        const float *ti = T + p * 4 * VROW + 2 * VROW + toff;
         const float *wl = wb + woff;
         // h[k][c / 2] holds the channel pair (c, c + 1) of component k: the operand layout of the packed second layer
         f32x2 h[3][VC / 2 + 1];
         h[0][VC / 2] = h[1][VC / 2] = h[2][VC / 2] = f32x2{0.f, 0.f};
-        // first layer, four channels (12 floats = three 16-byte pieces per operand) at a time; channel 20 + the pad last
+        // first layer, four channels (12 floats = three 16-byte loads per operand) at a time; channel 20 + the pad last
 #pragma unroll
         for (int e0 = 0; e0 < VROW; e0 += 12) {
             float a[12], ad[12];
 #pragma unroll
             for (int e = 0; e < 12 && e0 + e < VROW; e += 4) {
-                const float4 x = ga[(e0 + e) / 4], xd = gd[(e0 + e) / 4];
-                const float4 y = uu[(e0 + e) / 4], yd = ud[(e0 + e) / 4];
+                const float4 x = *(const float4 *)(tj + e0 + e), xd = *(const float4 *)(tj + VROW + e0 + e);
+                float4 y, yd;
+                if constexpr (PIN_U) { y = uu[(e0 + e) / 4]; yd = ud[(e0 + e) / 4]; }
+                else { y = *(const float4 *)(ti + e0 + e); yd = *(const float4 *)(ti + VROW + e0 + e); }
                 a[e] = x.x + y.x; a[e + 1] = x.y + y.y; a[e + 2] = x.z + y.z; a[e + 3] = x.w + y.w;
                 ad[e] = xd.x + yd.x; ad[e + 1] = xd.y + yd.y; ad[e + 2] = xd.z + yd.z; ad[e + 3] = xd.w + yd.w;
-                if (more) {
-                    ga[(e0 + e) / 4] = *(const float4 *)(tn + e0 + e);
-                    gd[(e0 + e) / 4] = *(const float4 *)(tn + VROW + e0 + e);
-                }
             }
 #pragma unroll
             for (int cc = 0; cc < 4 && e0 / 3 + cc < VC; ++cc) {
@@ -522,7 +513,7 @@ __global__ __launch_bounds__(128, 1) void k_pcd_edge(const float *__restrict__ T
                 else if (c & 1) { h[0][c / 2].y = p0; h[1][c / 2].y = p1; h[2][c / 2].y = p2; }
                 else { h[0][c / 2].x = p0; h[1][c / 2].x = p1; h[2][c / 2].x = p2; }
             }
-            __builtin_amdgcn_sched_barrier(0);            // keep every chunk's reloads behind its reads
+            __builtin_amdgcn_sched_barrier(0);            // do not hoist every chunk's loads to the top (VGPR budget)
         }
         if constexpr (HAS_B) {
             constexpr int WR = VC / 2 + 1;                 // 11 weight pairs per (zero-padded) row of 22

@@ -15,7 +15,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # ---- register map (VGPR numbers); v0 .. v75 and v92 .. v99 stay with the compiler
-VADDR, KADDR, ONES, ACC = 76, 77, 78, 79
+VADDR, KADDR, ACC = 76, 77, 79            # (v78 is free: the (1, 1) bf16 constant of the row sums is an SGPR operand)
 ET = 80                     # exp temporaries: pair A = 80, 81; pair B = 82, 83
 VF = 84                     # V fragments: v0 = 84..87 (vlo0, vhi0), v1 = 88..91 (vlo1, vhi1)
 PFB = 248                   # packed P of slab 1: the SAME registers as slab 0's (R2 reads slab 0's P at its two PV MFMAs, slots 0 - 1, and writes
