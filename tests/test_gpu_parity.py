@@ -518,6 +518,19 @@ def test_dense_path_is_deterministic_under_load(dev, G):
         assert torch.equal(alone, ref[g * n:(g + 1) * n]), g
 
 
+def test_row_panel_projection_kernel_in_the_model_subprocess(dev):
+    """DA_ENABLE_XPANEL=1 (read once per process): the denoiser's four Q | K | V (| skip) projections of the 64-puzzle
+    Batch go through k_gemm_xpanel's QKV scatter (K = 128 and 256; 32-wide heads, 144-wide heads, folded value heads) --
+    and must give, BIT FOR BIT, what the same puzzles give alone through the other projection kernels."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DA_ENABLE_XPANEL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_dense_path_is_deterministic_under_load and 64"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_900_piece_expander_vs_oracle_single_layer(dev, prec):
     """Config 3 graph (30x30, random 90-regular + V=8 virtual nodes): the full forward on the GPU (hybrid
