@@ -278,6 +278,7 @@ class GNN_Diffusion(LightningModule):
                                       mean_type=self._mean_type(), keep_trajectory=True,
                                       use_graph=self.use_hip_graph, sampler=self.sampling, eta=float(self.eta),
                                       cfg_w=(float(self.classifier_free_w) if self.classifier_free_prob > 0.0 and self.sampling == "DDIM" else None))
+            self.model._release_dense_plan_key()          # do not pin this Batch's edge list until the next one is planned
             return list(traj.clone().unbind(0)), [None] * len(its)
         imgs, attentions = [], []
         b = shape[0]

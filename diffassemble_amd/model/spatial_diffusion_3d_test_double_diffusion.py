@@ -157,6 +157,7 @@ class GNN_Diffusion(LightningModule):
             traj, _ = eng.sample_loop(plan, self._schedule(), img, pcd_feats, ratio=self.inference_ratio,
                                       mean_type=self._mean_type(), keep_trajectory=True,
                                       use_graph=self.use_hip_graph)
+            self.model._release_dense_plan_key()          # do not pin this Batch's edge list until the next one is planned
             return list(traj.clone().unbind(0)), [None] * len(its)
         imgs, attentions = [], []
         for i in its:
