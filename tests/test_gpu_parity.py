@@ -518,6 +518,19 @@ def test_dense_path_is_deterministic_under_load(dev, G):
         assert torch.equal(alone, ref[g * n:(g + 1) * n]), g
 
 
+def test_w_in_registers_register_direct_epilogue_subprocess(dev):
+    """DA_WREG_DIRECT=1 (read once per process): k_gemm_wreg / k_gemm_wreg2 with the register-direct epilogue (W columns
+    permuted so that a lane owns 16 / 32 consecutive output columns, no LDS strip) on the tall-input shapes and the QKV
+    scatter of the five-puzzle Batch."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DA_WREG_DIRECT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "w_in_registers and not subprocess"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_row_panel_projection_kernel_in_the_model_subprocess(dev):
     """DA_ENABLE_XPANEL=1 (read once per process): the denoiser's four Q | K | V (| skip) projections of the 64-puzzle
     Batch go through k_gemm_xpanel's QKV scatter (K = 128 and 256; 32-wide heads, 144-wide heads, folded value heads) --
