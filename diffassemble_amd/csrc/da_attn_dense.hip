@@ -1305,9 +1305,15 @@ static int launch_tc(const AttnDenseParams &p, hipStream_t st) {
 }
 
 // DA_ATTN_DUAL=0: the folded last layer on k_attn_dense instead of the two-slab kernel (da_attn_dual.hip), for A/B runs
+// k_attn_dual (da_attn_dual.hip) for the folded last layer is OPT-IN (DA_ATTN_DUAL=1).  Alone it is the faster kernel (harness,
+// four boxes: 221 - 225 us against 224 - 230 for k_attn_dense's FAST path), inside the step it is the slower choice on every
+// box measured at the end of round 3 (A/B/A/B, five boxes: 0.729 - 0.768 ms per step without it, 0.749 - 0.780 with it, -2 % each
+// time): the step runs at the package power cap, and what the denser kernel saves it takes back, and more, from the
+// kernels that follow it.  (Earlier in the round, with the lighter round-2 kernels on the hidden layers, the same switch measured
+// +3.4 % for the dual kernel.)
 static int attn_dual_env() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_ATTN_DUAL"); v = e ? atoi(e) : 1; }
+    if (v < 0) { const char *e = getenv("DA_ATTN_DUAL"); v = e ? atoi(e) : 0; }
     return v;
 }
 // returns 0 = launched, -1 = configuration not supported (caller uses the CSR kernel)

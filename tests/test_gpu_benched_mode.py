@@ -108,6 +108,21 @@ def test_rot900_ddim_trajectory_vs_reference_fixture(dev, golden2):
             assert rel(traj, ref) < tol, (prec, use_graph)
 
 
+def test_rot900_with_the_dual_slab_last_layer_kernel_subprocess(dev):
+    """DA_ATTN_DUAL=1 (read once per process): the folded last layer through k_attn_dual (two query slabs per wave, generated
+    asm regions, persistent workgroups; opt-in since the end of round 3) on the 900-piece fixture, its DDIM trajectory and
+    the 64-puzzle determinism check."""
+    env = dict(os.environ, DA_ATTN_DUAL="1")
+    root = os.path.dirname(os.path.dirname(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
+                        "test_rot900_dense_forward_vs_reference_fixture or test_rot900_ddim_trajectory_vs_reference_fixture"],
+                       env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
+                        "test_dense_path_is_deterministic_under_load"], env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_rot900_with_folds_off_subprocess(dev):
     """The layer-by-layer path (no algebraic folds) on the 900-piece fixture."""
     env = dict(os.environ, DA_DISABLE_MLP2_FUSION="1", DA_DISABLE_LAST_FOLD="1")
