@@ -1,0 +1,15 @@
+"""da_linear in a tight loop (for tools/kernel_power_probe.sh): M K N iters."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffassemble_amd import _lib
+M, K, N, iters = [int(a) for a in sys.argv[1:5]]
+dev = torch.device('cuda:0')
+x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16(); b = torch.randn(N, device=dev)
+out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+lib = _lib.lib()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(iters):
+    _lib.check(lib.da_linear(_lib.PREC_BF16, M, K, N, _lib.ptr(x), K, _lib.ptr(w), _lib.ptr(b), 0, None, _lib.ptr(out), N, _lib.stream_ptr(dev)))
+e.record(); torch.cuda.synchronize()
+print(f"M={M} K={K} N={N}: {s.elapsed_time(e) / iters * 1e3:.1f} us per launch over {iters} launches")
