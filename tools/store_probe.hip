@@ -156,11 +156,12 @@ int main(int argc, char **argv) {
         if (only >= 0 && mode != only) continue;
         for (int r = 0; r < 3; ++r) k_store<<<grid, threads>>>(out, M, N, mode, tiles_k, xin, ncg, cpx);
         CK(hipDeviceSynchronize());
+        const int iters = getenv("STORE_PROBE_ITERS") ? atoi(getenv("STORE_PROBE_ITERS")) : 20;   // long loops: power sampling
         CK(hipEventRecord(a));
-        for (int r = 0; r < 20; ++r) k_store<<<grid, threads>>>(out, M, N, mode, tiles_k, xin, ncg, cpx);
+        for (int r = 0; r < iters; ++r) k_store<<<grid, threads>>>(out, M, N, mode, tiles_k, xin, ncg, cpx);
         CK(hipEventRecord(b)); CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, a, b));
-        printf("M=%d N=%d mode %d grid %dx%d: %.1f us  %.2f TB/s\n", M, N, mode, ncg, nchunk, ms / 20 * 1e3, (double)M * N * 2 / (ms / 20 * 1e-3) / 1e12);
+        printf("M=%d N=%d mode %d grid %dx%d: %.1f us  %.2f TB/s\n", M, N, mode, ncg, nchunk, ms / iters * 1e3, (double)M * N * 2 / (ms / iters * 1e-3) / 1e12);
     }
     // per-CU store rate when the chip is NOT saturated: `nwg` workgroups (one per CU), each streaming 4 MB in the linear shape,
     // with 8 / 4 / 2 / 1 waves per workgroup active
