@@ -889,7 +889,8 @@ def sample_bench(args, world, rank, dev):
             "first_replay": {"value": world * G * K / dt_first, "ms_per_step": dt_first / K * 1e3},
             "distributed": dist_info(world, rank_ms),
             "config": {"workload": wl, "baseline_config": args.config, "puzzles_per_gpu": G, "global_puzzles": world * G,
-                       "parallelism": f"puzzle-sharded x{world}", "loop": "hipGraph replay",
+                       "parallelism": f"puzzle-sharded x{world}",
+                       "loop": "hipGraph replay" + (", two half Batches as parallel branches (da_sample_loop_pair)" if eng._two_branch(plan, False, True) else ""),
                        "attention_path": "dense MFMA" if plan.dense else ("hybrid: adjacency-masked MFMA + CSR remainder" if plan.hybrid else "edge list (CSR gather)")},
             "batch_steps_per_s": world * K / dt,
             "algorithmic_tflops": world * (N * f_node + E * f_edge) * K / dt / 1e12,

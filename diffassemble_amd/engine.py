@@ -266,18 +266,24 @@ class DenoiserEngine:
 
     # ------------------------------------------------------------------ two-branch loop
     def _two_branch(self, plan, keep_trajectory, use_graph):
-        """Opt-in (DA_TWO_BRANCH=1): Batches of at least DA_TWO_BRANCH_MIN_GRAPHS (64) complete graphs run as TWO half
-        Batches on two parallel branches of one hipGraph (da_sample_loop_pair), so that one half's projections and
-        tail kernels overlap the other half's attention.  Bit-identical poses; measured +0.4 % at 64 puzzles of 900
-        pieces (79 424 / 80 215 against 79 060 / 79 895 puzzle-steps/s, alternating runs on one box) -- the step
-        already runs at the board's power limit, there is little idle silicon to fill -- hence not the default."""
+        """Large Batches of complete graphs run as TWO half Batches on two parallel branches of one hipGraph
+        (da_sample_loop_pair), so that one half's projections and tail kernels overlap the other half's attention.
+        Bit-identical poses.  Default ("auto") from 40 000 nodes up (DA_TWO_BRANCH_MIN_NODES): measured at the end of round 3,
+        A/B on one box, 900-piece puzzles: 48 per GPU 81.0 k -> 83.8 k puzzle-steps/s, 64 per GPU 85.7 k -> 88.6 k (+3.4 %, three
+        rounds), 128: 88.8 k; but 32: 77.7 k -> 75.8 k and 16: 64.0 k -> 60.9 k (half Batches that no longer fill the chip);
+        BASELINE config 2 (512 puzzles of 144 pieces) 738 k -> 790 k.  (In round 2 the same switch measured +0.4 %: the step sits
+        at the package power cap, and what two interleaved kernel streams buy depends on the kernels.)  DA_TWO_BRANCH=0 turns it
+        off, =1 forces it from DA_TWO_BRANCH_MIN_GRAPHS (64) graphs up."""
         if keep_trajectory or not use_graph or self._profiling or not self.dense_only:
             return False
-        if not plan.dense or plan.hybrid or plan.n_nodes != plan.n_real:
+        if not plan.dense or plan.hybrid or plan.n_nodes != plan.n_real or plan.n_graphs < 2:
             return False
-        if os.environ.get("DA_TWO_BRANCH", "0") != "1":
+        mode = os.environ.get("DA_TWO_BRANCH", "auto")
+        if mode == "0":
             return False
-        return plan.n_graphs >= int(os.environ.get("DA_TWO_BRANCH_MIN_GRAPHS", "64"))
+        if mode == "1":
+            return plan.n_graphs >= int(os.environ.get("DA_TWO_BRANCH_MIN_GRAPHS", "64"))
+        return plan.n_real >= int(os.environ.get("DA_TWO_BRANCH_MIN_NODES", "40000"))
 
     def _sample_loop_pair(self, plan, sched, x_init, feats, ratio, mean_type, n_iters, restage):
         from .graph_plan import split_complete

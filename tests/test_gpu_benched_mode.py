@@ -574,7 +574,7 @@ def test_expander_mask_kernel_odd_sizes(dev, n, d, G, monkeypatch):
 @pytest.mark.parametrize("sizes,loops", [([144] * 4, True), ([36, 144, 100, 64, 9], False), ([900, 900], True)],
                          ids=["4x144", "ragged5_noloops", "2x900"])
 def test_two_branch_loop_equals_one_branch(dev, monkeypatch, prec, sizes, loops):
-    """da_sample_loop_pair (two half Batches as parallel branches of one hipGraph; the default from 64 puzzles up): the
+    """da_sample_loop_pair (two half Batches as parallel branches of one hipGraph; the default from 40 000 nodes up): the
     final poses of every puzzle are BIT-identical to the one-branch loop over the whole Batch -- same kernels, same
     reduction orders, the halves only share the weights -- for even and odd splits, ragged sizes, graphs without
     self loops, restaged and re-used features, and on replay of the cached graph."""
@@ -611,6 +611,11 @@ def test_two_branch_loop_equals_one_branch(dev, monkeypatch, prec, sizes, loops)
     assert not eng._two_branch(plan, True, True) and not eng._two_branch(plan, False, False)
     monkeypatch.setenv("DA_TWO_BRANCH_MIN_GRAPHS", "64")
     assert not eng._two_branch(plan, False, True)
+    # default ("auto"): by node count
+    monkeypatch.delenv("DA_TWO_BRANCH")
+    assert not eng._two_branch(plan, False, True)
+    monkeypatch.setenv("DA_TWO_BRANCH_MIN_NODES", "10")
+    assert eng._two_branch(plan, False, True) and not eng._two_branch(plan, True, True)
 
 
 _TAIL_SCRIPT = r"""
