@@ -71,6 +71,7 @@ struct LoopKey {
     void *ws;
     size_t ws_bytes;
     da_loop_opts opts;        // zero for the plain DDIM loop
+    size_t traj_stride;       // elements between consecutive iterations of `traj` (0 = n_real * c)
 };
 
 }  // namespace da
@@ -766,7 +767,7 @@ int da_ddpm_step(const da_schedule *s, int n, int c, const float *x, const float
 
 static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int mean_type, int ratio,
                         int n_iters, const float *x_init, float *traj, float *x_final, const Workspace &w,
-                        hipStream_t st, const da_loop_opts *o = nullptr) {
+                        hipStream_t st, const da_loop_opts *o = nullptr, size_t traj_stride = 0) {
     const int nr = g->n_real;
     const int c = d->variant == DA_VARIANT_3D ? 7 : d->c_in;
     const size_t bytes = (size_t)nr * c * sizeof(float);
@@ -782,7 +783,7 @@ static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s,
     const float eta = o ? o->eta : 0.f;
     const bool plain = !cfg && !ddpm && eta == 0.f;
     for (int i = first; i >= 0 && it < n_iters; i -= ratio, ++it) {
-        float *nxt = traj ? traj + (size_t)it * nr * c : ((it & 1) ? w.xbuf1 : w.xbuf0);
+        float *nxt = traj ? traj + (size_t)it * (traj_stride ? traj_stride : (size_t)nr * c) : ((it & 1) ? w.xbuf1 : w.xbuf0);
         const int nonneg = (i - ratio) >= 0;
         DdimFuse df;
         df.s = ds; df.mean_type = mean_type; df.ratio = ratio; df.prev_all_nonneg = nonneg; df.t = i; df.x = cur; df.x_prev = nxt;
@@ -875,16 +876,19 @@ int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int 
 // Two independent halves of one Batch as two parallel branches of ONE hipGraph: each branch is the complete loop of
 // da_sample_loop over its own graphs, poses and workspace; the branches share nothing but the weights, so the runtime
 // overlaps one half's projections / tail kernels with the other half's attention.
-int da_sample_loop_pair(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio, int max_iters,
-                        const da_graph *g_a, const float *x_init_a, float *x_final_a, void *workspace_a, size_t workspace_a_bytes,
-                        const da_graph *g_b, const float *x_init_b, float *x_final_b, void *workspace_b, size_t workspace_b_bytes,
-                        void *stream) {
+int da_sample_loop_pair_traj(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio, int max_iters,
+                             const da_graph *g_a, const float *x_init_a, float *x_final_a, void *workspace_a, size_t workspace_a_bytes,
+                             const da_graph *g_b, const float *x_init_b, float *x_final_b, void *workspace_b, size_t workspace_b_bytes,
+                             float *traj_a, float *traj_b, size_t traj_stride, void *stream) {
     DA_REQUIRE(d && s && g_a && g_b && x_init_a && x_init_b && x_final_a && x_final_b && workspace_a && workspace_b,
                "da_sample_loop_pair: null argument");
     DA_REQUIRE(inference_ratio >= 1 && s->steps >= 1, "da_sample_loop_pair: bad ratio/steps");
     DA_REQUIRE(d->variant == DA_VARIANT_3D || d->c_in == d->c_out, "da_sample_loop_pair: c_in != c_out");
     DA_REQUIRE(!g_a->hybrid && !g_b->hybrid, "da_sample_loop_pair: hybrid graphs fork a side stream of their own");
     DA_REQUIRE(!d->prof_on, "da_sample_loop_pair: not available while profiling (event bracketing is not capturable)");
+    DA_REQUIRE((traj_a == nullptr) == (traj_b == nullptr), "da_sample_loop_pair_traj: both trajectory pointers or none");
+    DA_REQUIRE(!traj_a || traj_stride >= (size_t)(g_a->n_real + g_b->n_real) * (d->variant == DA_VARIANT_3D ? 7 : d->c_in),
+               "da_sample_loop_pair_traj: traj_stride smaller than one iteration of both halves");
     int rc = check_graph(d, g_a);
     if (rc) return rc;
     if ((rc = check_graph(d, g_b))) return rc;
@@ -896,15 +900,15 @@ int da_sample_loop_pair(da_denoiser *d, const da_schedule *s, int mean_type, int
     }
     const int total = (s->steps + inference_ratio - 1) / inference_ratio;
     const int n_iters = (max_iters > 0 && max_iters < total) ? max_iters : total;
-    auto make_key = [&](const da_graph *g, const float *xi, float *xf, void *ws, size_t wsb) {
+    auto make_key = [&](const da_graph *g, const float *xi, float *xf, void *ws, size_t wsb, float *tr) {
         LoopKey k;
         memset(&k, 0, sizeof(k));
         k.g = *g; k.s = *s; k.mean_type = mean_type; k.ratio = inference_ratio; k.max_iters = n_iters;
-        k.x_init = xi; k.traj = nullptr; k.x_final = xf; k.ws = ws; k.ws_bytes = wsb;
+        k.x_init = xi; k.traj = tr; k.x_final = xf; k.ws = ws; k.ws_bytes = wsb; k.traj_stride = tr ? traj_stride : 0;
         return k;
     };
-    const LoopKey ka = make_key(g_a, x_init_a, x_final_a, workspace_a, workspace_a_bytes);
-    const LoopKey kb = make_key(g_b, x_init_b, x_final_b, workspace_b, workspace_b_bytes);
+    const LoopKey ka = make_key(g_a, x_init_a, x_final_a, workspace_a, workspace_a_bytes, traj_a);
+    const LoopKey kb = make_key(g_b, x_init_b, x_final_b, workspace_b, workspace_b_bytes, traj_b);
     hipGraphExec_t exec = nullptr;
     for (auto &e : d->pair_loops)
         if (memcmp(&ka, &e.a, sizeof(ka)) == 0 && memcmp(&kb, &e.b, sizeof(kb)) == 0) exec = e.exec;
@@ -926,8 +930,8 @@ int da_sample_loop_pair(da_denoiser *d, const da_schedule *s, int mean_type, int
         if (e == hipSuccess) e = hipStreamWaitEvent(ps, d->ev_pair_fork, 0);                 // ps joins the capture
         int rca = 0, rcb = 0;
         if (e == hipSuccess) {
-            rca = enqueue_loop(d, g_a, s, mean_type, inference_ratio, n_iters, x_init_a, nullptr, x_final_a, wa, cs);
-            rcb = enqueue_loop(d, g_b, s, mean_type, inference_ratio, n_iters, x_init_b, nullptr, x_final_b, wb, ps);
+            rca = enqueue_loop(d, g_a, s, mean_type, inference_ratio, n_iters, x_init_a, traj_a, x_final_a, wa, cs, nullptr, traj_stride);
+            rcb = enqueue_loop(d, g_b, s, mean_type, inference_ratio, n_iters, x_init_b, traj_b, x_final_b, wb, ps, nullptr, traj_stride);
             e = hipEventRecord(d->ev_pair_join, ps);
             if (e == hipSuccess) e = hipStreamWaitEvent(cs, d->ev_pair_join, 0);
         }
@@ -945,6 +949,14 @@ int da_sample_loop_pair(da_denoiser *d, const da_schedule *s, int mean_type, int
     }
     DA_CHECK_HIP(hipGraphLaunch(exec, (hipStream_t)stream));
     return 0;
+}
+
+int da_sample_loop_pair(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio, int max_iters,
+                        const da_graph *g_a, const float *x_init_a, float *x_final_a, void *workspace_a, size_t workspace_a_bytes,
+                        const da_graph *g_b, const float *x_init_b, float *x_final_b, void *workspace_b, size_t workspace_b_bytes,
+                        void *stream) {
+    return da_sample_loop_pair_traj(d, s, mean_type, inference_ratio, max_iters, g_a, x_init_a, x_final_a, workspace_a, workspace_a_bytes,
+                                    g_b, x_init_b, x_final_b, workspace_b, workspace_b_bytes, nullptr, nullptr, 0, stream);
 }
 
 size_t da_attn_dense_scratch_bytes(int prec, const da_graph *g, int heads, int C) {

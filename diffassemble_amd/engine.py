@@ -220,7 +220,7 @@ class DenoiserEngine:
         n_iters = min(max_iters, total) if max_iters and max_iters > 0 else total
         ex = sampler == "DDPM" or eta > 0 or cfg_w is not None
         if not ex and self._two_branch(plan, keep_trajectory, use_graph):
-            return None, self._sample_loop_pair(plan, sched, x_init, feats, ratio, mean_type, n_iters, restage)
+            return self._sample_loop_pair(plan, sched, x_init, feats, ratio, mean_type, n_iters, restage, keep_trajectory)
         if restage:
             g, ws = self.set_features(plan, feats)
         else:
@@ -273,8 +273,9 @@ class DenoiserEngine:
         rounds), 128: 88.8 k; but 32: 77.7 k -> 75.8 k and 16: 64.0 k -> 60.9 k (half Batches that no longer fill the chip);
         BASELINE config 2 (512 puzzles of 144 pieces) 738 k -> 790 k.  (In round 2 the same switch measured +0.4 %: the step sits
         at the package power cap, and what two interleaved kernel streams buy depends on the kernels.)  DA_TWO_BRANCH=0 turns it
-        off, =1 forces it from DA_TWO_BRANCH_MIN_GRAPHS (64) graphs up."""
-        if keep_trajectory or not use_graph or self._profiling or not self.dense_only:
+        off, =1 forces it from DA_TWO_BRANCH_MIN_GRAPHS (64) graphs up.  Loops that keep their trajectory (the module's p_sample_loop) take it
+        too: each half writes its row range of every iteration (da_sample_loop_pair_traj)."""
+        if not use_graph or self._profiling or not self.dense_only:
             return False
         if not plan.dense or plan.hybrid or plan.n_nodes != plan.n_real or plan.n_graphs < 2:
             return False
@@ -285,7 +286,7 @@ class DenoiserEngine:
             return plan.n_graphs >= int(os.environ.get("DA_TWO_BRANCH_MIN_GRAPHS", "64"))
         return plan.n_real >= int(os.environ.get("DA_TWO_BRANCH_MIN_NODES", "40000"))
 
-    def _sample_loop_pair(self, plan, sched, x_init, feats, ratio, mean_type, n_iters, restage):
+    def _sample_loop_pair(self, plan, sched, x_init, feats, ratio, mean_type, n_iters, restage, keep_trajectory=False):
         from .graph_plan import split_complete
         pa, pb, n0 = split_complete(plan, plan.n_graphs // 2)
         c = x_init.shape[1]
@@ -310,11 +311,18 @@ class DenoiserEngine:
         xi, xf = st["xi"], st["xf"]
         xi.copy_(x_init)
         (ga, gb), (wa, wb) = st["g"], st["ws"]
-        _lib.check(self.lib.da_sample_loop_pair(
+        traj = None
+        if keep_trajectory:
+            # the trajectory p_sample_loop returns: one [n_iters, N, c] buffer, each half writes its own row range of every iteration
+            traj = st.get("traj")
+            if traj is None or traj.shape[0] != n_iters:
+                traj = st["traj"] = torch.empty((n_iters, plan.n_real, c), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.da_sample_loop_pair_traj(
             self.handle, C.byref(sched.c), int(mean_type), int(ratio), int(n_iters),
             C.byref(ga), _lib.ptr(xi), _lib.ptr(xf), _lib.ptr(wa), wa.numel(),
-            C.byref(gb), _lib.ptr(xi[n0:]), _lib.ptr(xf[n0:]), _lib.ptr(wb), wb.numel(), _lib.stream_ptr(self.device)))
-        return xf
+            C.byref(gb), _lib.ptr(xi[n0:]), _lib.ptr(xf[n0:]), _lib.ptr(wb), wb.numel(),
+            _lib.ptr(traj), None if traj is None else _lib.ptr(traj[0, n0:]), plan.n_real * c, _lib.stream_ptr(self.device)))
+        return traj, xf
 
     # ------------------------------------------------------------------ measurement
     def profile(self, on=True):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 14
+#define DA_ABI_VERSION 15
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -235,6 +235,16 @@ int da_sample_loop_pair(da_denoiser *d, const da_schedule *s, int mean_type, int
                         void *workspace_a, size_t workspace_a_bytes,
                         const da_graph *g_b, const float *x_init_b, float *x_final_b,
                         void *workspace_b, size_t workspace_b_bytes, void *stream);
+/* The same two-branch loop keeping the trajectory the reference's p_sample_loop returns (spatial_diffusion.py:635-676 appends
+ * every x_{t-1}): iteration i of half a / b is written to traj_a / traj_b + i * traj_stride (floats; the two halves normally are
+ * row ranges of one [n_iters, N, c] buffer: traj_b = traj_a + n_real_a * c, traj_stride = N * c).  Both NULL = da_sample_loop_pair. */
+int da_sample_loop_pair_traj(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio,
+                             int max_iters,
+                             const da_graph *g_a, const float *x_init_a, float *x_final_a,
+                             void *workspace_a, size_t workspace_a_bytes,
+                             const da_graph *g_b, const float *x_init_b, float *x_final_b,
+                             void *workspace_b, size_t workspace_b_bytes,
+                             float *traj_a, float *traj_b, size_t traj_stride, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart: the reference has no profiler hooks).

@@ -606,16 +606,23 @@ def test_two_branch_loop_equals_one_branch(dev, monkeypatch, prec, sizes, loops)
     monkeypatch.setenv("DA_TWO_BRANCH", "0")
     _, ref = eng.sample_loop(plan, sch, xd, fd, **kw)
     assert torch.equal(half, ref) and not torch.equal(half, one)
-    # trajectories, eager loops and small Batches keep the one-branch path
+    # kept trajectories go through the pair loop too (each half writes its rows of every iteration): bit-identical again
+    monkeypatch.setenv("DA_TWO_BRANCH", "0")
+    t1, f1 = eng.sample_loop(plan, sch, xd, fd, ratio=10, mean_type=_lib.MEAN_START_X, keep_trajectory=True, use_graph=True)
+    t1, f1 = t1.clone(), f1.clone()
     monkeypatch.setenv("DA_TWO_BRANCH", "1")
-    assert not eng._two_branch(plan, True, True) and not eng._two_branch(plan, False, False)
+    assert eng._two_branch(plan, True, True)
+    t2, f2 = eng.sample_loop(plan, sch, xd, fd, ratio=10, mean_type=_lib.MEAN_START_X, keep_trajectory=True, use_graph=True)
+    assert t2.shape == t1.shape and torch.equal(t2, t1) and torch.equal(f2, f1) and torch.equal(t2[-1], f2)
+    # eager loops and small Batches keep the one-branch path
+    assert not eng._two_branch(plan, False, False)
     monkeypatch.setenv("DA_TWO_BRANCH_MIN_GRAPHS", "64")
     assert not eng._two_branch(plan, False, True)
     # default ("auto"): by node count
     monkeypatch.delenv("DA_TWO_BRANCH")
     assert not eng._two_branch(plan, False, True)
     monkeypatch.setenv("DA_TWO_BRANCH_MIN_NODES", "10")
-    assert eng._two_branch(plan, False, True) and not eng._two_branch(plan, True, True)
+    assert eng._two_branch(plan, False, True) and eng._two_branch(plan, True, True)
 
 
 _TAIL_SCRIPT = r"""
