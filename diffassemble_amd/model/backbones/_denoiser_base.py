@@ -91,6 +91,9 @@ class DenoiserBase(nn.Module):
         validation loop.  The next call re-plans (~4 ms per 64 x 900 Batch, against a 76 ms loop)."""
         plan = getattr(self, "_plan", None)
         if plan is not None and getattr(plan, "dense", 0):
+            # the engine keeps the plan object alive for its cached hipGraph (device arrays of the plan), so the edge list has to
+            # leave the plan itself; nothing reads it again (alpha is only returned by the per-step path, which plans afresh)
+            plan._edge_index = None
             self._plan_key = self._feat_key = None
             self._plan = None
 
