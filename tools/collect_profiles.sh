@@ -12,6 +12,11 @@ export TMPDIR=/tmp
 W=/tmp/prof_$TAG
 rm -rf $W; mkdir -p $W
 cd /tmp
+# DA_TWO_BRANCH=0: every launch at the full Batch size, so that per-launch averages (durations, PMC KiB) describe ONE kernel shape --
+# the shape bench.py's `roofline` object is about (its per-class times come from an eager one-branch pass); the default two-branch
+# loop launches every kernel twice at half size and, under --kernel-trace, runs the branches serially (tools/graph_idle_probe.py).
+# profiles/r03/r03_rocprof_kernel_stats_headline_two_branch.txt is the same collection with the default loop.
+export DA_TWO_BRANCH=${DA_TWO_BRANCH:-0}
 BENCH="python $REPO/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-parity-mode --replays 0 $*"
 rocprofv3 --kernel-trace --stats -d $W/stats -o s -- $BENCH > $W/stats.log 2>&1
 DB=$(find $W/stats -name "*results.db" | head -1)
