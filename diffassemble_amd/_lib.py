@@ -13,12 +13,14 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
-ABI_VERSION = 15
+ABI_VERSION = 16
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
 MEAN_EPSILON, MEAN_START_X = 0, 1
 ACT_NONE, ACT_GELU, ACT_LEAKY02 = 0, 1, 2
+CONV_Q_PRESCALED, CONV_FOLDED_V32 = 1, 2
+DBG_COUNTERS = ("opt_gen_workgroups", "dense_fast_exits", "dual_gen_slabs", "opt_masked_gen_workgroups")
 PROF_CLASSES = ("embed", "linear_mlp", "linear_qkvs", "attn_hidden", "attn_last", "head", "update", "conv_fused")
 
 _fp = C.c_void_p        # device pointers travel as integers
@@ -127,6 +129,9 @@ PROTOTYPES = {
     "da_attn_dense_scratch_bytes": (C.c_size_t, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int]),
     "da_conv_dense": (C.c_int, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int,
                                 _fp, _fp, _fp]),
+    "da_conv_dense_ex": (C.c_int, [C.c_int, C.POINTER(DaGraph), C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int,
+                                   _fp, _fp, C.c_int, _fp]),
+    "da_debug_counters": (C.c_int, [C.POINTER(C.c_int64), C.c_int, C.c_int]),
     "da_train_workspace_bytes": (C.c_size_t, [C.POINTER(DaWeights), C.POINTER(DaGraph)]),
     "da_train_forward": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
     "da_adafactor_step": (C.c_int, [C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_float,

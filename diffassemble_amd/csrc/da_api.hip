@@ -993,6 +993,49 @@ int da_conv_dense(int prec, const da_graph *g, int heads, int C, int Din, const 
     return 0;
 }
 
+int da_conv_dense_ex(int prec, const da_graph *g, int heads, int C, int Din, const void *x, const void *w, const float *b,
+                     const void *residual, int act, void *out, void *scratch, int flags, void *stream) {
+    DA_REQUIRE(g && x && w && out && scratch, "da_conv_dense_ex: null argument");
+    DA_REQUIRE(dense_ok(g, heads, C), "da_conv_dense_ex: graph is not dense or head width %d unsupported", C);
+    const bool folded = (flags & DA_CONV_FOLDED_V32) != 0;
+    DA_REQUIRE(!folded || (C == 144 && !residual && act == DA_ACT_NONE), "da_conv_dense_ex: folded value heads need C = 144, no residual, no activation");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t s = esize(prec), hc = (size_t)heads * C;
+    const size_t hb = align_up(((size_t)g->n_pad + 64) * hc * s, 256);
+    char *base = (char *)scratch;
+    QkvScatter qs;
+    qs.HC = (int)hc; qs.C = C; qs.n_pad = g->n_pad; qs.row_map = g->row_map;
+    qs.Q = base; qs.K = base + hb; qs.Vt = base + 2 * hb; qs.S = folded ? nullptr : base + 3 * hb;
+    qs.Cv = folded ? 32 : 0;
+    const int nout = folded ? 2 * (int)hc + heads * 32 : 4 * (int)hc;
+    int rc = launch_gemm_mfma(prec, g->n_nodes, Din, nout, x, Din, w, b, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st);
+    DA_REQUIRE(rc == 0, "da_conv_dense_ex: projection shape (Din=%d, Nout=%d) not supported by the MFMA kernels", Din, nout);
+    DenseLayout L;
+    L.Q = qs.Q; L.K = qs.K; L.Vt = qs.Vt; L.S = qs.S; L.n_pad = g->n_pad; L.q_prescaled = (flags & DA_CONV_Q_PRESCALED) ? 1 : 0;
+    DenseFold fo;
+    fo.cv = 32; fo.out = out; fo.n_rows = g->n_real;
+    DenseMask mk;
+    mk.mask = g->mask; mk.mask_ptr = g->mask_ptr; mk.irr_row_ptr = g->irr_row_ptr; mk.irr_col_src = g->irr_col_src; mk.row_map = g->row_map;
+    rc = launch_attn_dense(prec, L, heads, C, g->n_graphs, g->max_graph_nodes, g->graph_ptr, g->pad_ptr, g->dense == 2, residual, act,
+                           folded ? nullptr : out, st, g->hybrid ? &mk : nullptr, folded ? &fo : nullptr);
+    DA_REQUIRE(rc == 0, "da_conv_dense_ex: attention launch failed (%d)", rc);
+    return 0;
+}
+
+int da_debug_counters(int64_t *out, int n, int reset) {
+    DA_REQUIRE(out && n >= DA_DBG_NCOUNTERS, "da_debug_counters: need room for %d counters", DA_DBG_NCOUNTERS);
+    unsigned long long a[4] = {0, 0, 0, 0}, b2[2] = {0, 0};
+    int rc;
+    if ((rc = da::attn_dense_counters(a, reset))) return rc;
+    if ((rc = da::attn_dual_counters(b2, reset))) return rc;
+    for (int k = 0; k < n; ++k) out[k] = 0;
+    out[DA_DBG_OPT_GEN_WORKGROUPS] = (int64_t)a[0];
+    out[DA_DBG_DENSE_FAST_EXITS] = (int64_t)a[1];
+    out[DA_DBG_DUAL_GEN_SLABS] = (int64_t)b2[0];
+    out[DA_DBG_OPT_MASKED_GEN_WORKGROUPS] = (int64_t)a[2];
+    return 0;
+}
+
 int da_profile_enable(da_denoiser *d, int on) {
     DA_REQUIRE(d, "da_profile_enable: null denoiser");
     d->prof_on = on != 0;

@@ -61,6 +61,7 @@ struct AttnDenseParams {
     unsigned long long *prof;       // DA_ATTN_PROBE: per-workgroup cycle breakdown of wave 0
     int fast;                       // Q pre-scaled (sc == 1): start every wave in the shift-free softmax mode (see k_attn_dense)
     int debug;                      // DA_ATTN_DEBUG bits (timing experiments): 1 no DMA, 2 no softmax, 4 no PV, 8 no QK
+    int force_gen;                  // DA_ATTN_FORCE_GEN=1 (tests): the shift-free kernels start in their running-max fallback mode
     // hybrid (MASKED) mode: adjacency bits of the regular edges; the remainder edges are folded in by the epilogue
     const unsigned char *mask;      // rows of graph g at mask_ptr[g], row stride (pad_ptr[g+1] - pad_ptr[g]) / 8 bytes
     const long long *mask_ptr;
@@ -187,6 +188,16 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
     }
 }
 
+// Fallback bookkeeping of the shift-free softmax paths (tests assert that the branches they aim at really ran;
+// da_debug_counters): [0] k_attn_opt workgroups re-run with the running-max recurrence, [1] k_attn_dense waves that left
+// FAST mode.  Only touched inside the (rare) fallback branches.
+__device__ unsigned long long g_attn_fallbacks[4];
+
+// An UN-SHIFTED softmax state (weights exp2(s), reference 0) handed to the running-max recurrence: re-reference it by the
+// exact power of two e = floor(log2(row sum)), so that the sum restarts in [1, 2) -- from there on PyG's `+ 1e-16` is as
+// invisible as it is in the reference (where it is added to sum exp(a - max) >= 1), whatever the scores' offset.
+__device__ __forceinline__ float pow2_floor_exp(float lq) { return (float)((int)((__builtin_bit_cast(unsigned, lq) >> 23) & 0xffu) - 127); }
+
 template <typename T, int C, bool MASKED, int CV, int NST, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
     using CF = Cfg<T, C, CV>;
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[cb][r] = 0.f;
     float m = -1e30f, l = 0.f;               // finite reference (see the softmax below); only the slow path moves it
-    bool fast = !MASKED && p.fast;          // shift-free mode (wave-uniform, one way out)
+    bool fast = !MASKED && p.fast == 1;     // shift-free mode (wave-uniform, one way out); p.fast == 2: DA_ATTN_FORCE_GEN
 
     // ---- LDS-DMA plan: instruction q (1 KB) of a tile is issued by wave q % NW; lane -> slot q*64+lane
     const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
@@ -439,8 +450,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
                     if (__any(!(bsum < 1.152921504606847e18f) || !(l + bsum > 8.673617379884035e-19f))) {
                         fast = false;
                         redo = true;
+                        // what was accumulated so far is relative to the reference 0: move it to the reference
+                        // e = floor(log2(row sum)) (exact scaling), i.e. sum in [1, 2); nothing accumulated: start afresh
                         const float lq = l + __shfl_xor(l, 32);
-                        m = lq > 0.f ? 0.f : -1e30f;
+                        const float e_ = lq > 0.f ? pow2_floor_exp(lq) : 0.f;
+                        const float c_ = __builtin_amdgcn_exp2f(-e_);
+                        m = lq > 0.f ? e_ : -1e30f;                     // (FAST mode implies sc == 1: m is in the scores' units)
+                        l *= c_;
+#pragma unroll
+                        for (int cb = 0; cb < CF::NCB; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) O[cb][r] *= c_;
+                        if (lane == 0) atomicAdd(&g_attn_fallbacks[1], 1ull);
                     }
                 }
                 if (redo) bsum = exp_block(m * p.sc);
@@ -509,15 +530,20 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
     // 256 threads stream whole output rows: 16-byte coalesced reads of skip (+ residual), activation,
     // 16-byte coalesced stores.  (Written straight from the accumulator layout every access is an
     // 8-byte piece in one of 32 different rows: that cost 25 % of the kernel.)
+    // PyG normalises by (sum exp(a - max) + 1e-16), a sum >= 1 where the epsilon is below fp32 resolution.  A wave still
+    // in FAST mode holds the UN-SHIFTED sum (any size inside [2^-60, 2^65]): there the epsilon must not be added (it would
+    // be 1e-16 at the wrong scale: rows whose logits all sit near -38 nat came out 2e-3 low, round-3 verdict); the referenced
+    // path keeps its sum >= 1 and PyG's formula.
     const float lt = l + __shfl_xor(l, 32);
-    const float inv = MASKED ? 1.0f : (lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f);
+    const float eps_l = fast ? 0.f : 1e-16f;
+    const float inv = MASKED ? 1.0f : (lt > 0.f ? 1.0f / (lt + eps_l) : 0.f);
     if (CV != C && !MASKED) {
         // folded value heads: the caller projected V with the next linear layer's weight block of this head
         // (softmax(QK^T) (V W^T) == (softmax(QK^T) V) W^T), so the output is CV wide and goes out normalised,
         // per head, for the tail kernel to sum over heads -- no skip, no activation, no LDS staging
         static_assert(CV == C || CF::NCB == 1, "folded value heads are one 32-channel block");
         if (wave_on && qidx < n_g) {
-            const float invf = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+            const float invf = inv;
             T *dst = (T *)p.fold_out + ((size_t)h * p.n_rows + node0 + qidx) * CV;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -988,8 +1014,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense2(AttnDenseParams p) {
 //     block, on the final row sums (an overflow anywhere shows up there as inf / NaN, total underflow as 0).  A workgroup
 //     whose check fails -- logits beyond +-41 before the 1/sqrt(C), not seen at a fresh model's near-uniform attention --
 //     re-runs its tile with the classic running-max recurrence (same loop, `gen` switched on: row max, rescale, shift);
-//   * the row sums come off the matrix pipe: l^T += 1 . P^T, two more MFMAs per block against an all-ones A operand (the
-//     pipe is two-thirds idle in this kernel), instead of seven packed adds + the range test on the vector port.
+//   * the row sums are eight v_dot2_f32_bf16 of the packed P against (1, 1) per block: they sum exactly the bf16 values the
+//     PV product weighs with, on the vector port but at half the instruction count of fp32 adds (row sums on the matrix
+//     pipe -- two more MFMAs per block against an all-ones operand -- measured slower: 113.6 vs 100.5 us per layer);
+//   * an optimistic pass normalises by 1 / sum, WITHOUT PyG's + 1e-16: the sum is un-shifted there (anything in
+//     [2^-60, 2^100]) while the reference adds its epsilon to sum exp(a - max) >= 1, where it is below fp32 resolution.
 // Same LDS image, DMA ring, fragment layouts and epilogue as k_attn_dense<bf16_t, 32, false, 32, 4, 4>.
 __global__ __launch_bounds__(256, 4) void k_attn_opt(AttnDenseParams p) {
     using T = bf16_t;
@@ -1060,7 +1089,7 @@ __global__ __launch_bounds__(256, 4) void k_attn_opt(AttnDenseParams p) {
     f32x16 O;
     float ls = 0.f;               // this lane's share of the row sum (16 of the block's 32 keys)
     float m = 0.f;                // GEN mode only: running row max (log2 units)
-    bool gen = false;             // false: optimistic pass
+    bool gen = p.force_gen != 0;  // false: optimistic pass
     for (int attempt = 0; attempt < 2; ++attempt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[r] = 0.f;
@@ -1163,11 +1192,12 @@ __global__ __launch_bounds__(256, 4) void k_attn_opt(AttnDenseParams p) {
         __syncthreads();
         if (!redo) break;
         gen = true;
+        if (tid == 0) atomicAdd(&g_attn_fallbacks[0], 1ull);
     }
 
     // ---- epilogue (as k_attn_dense): normalise, stage [query][c] fp32 rows through LDS, + skip, activation, 16-byte stores
     const float lt = ls + __shfl_xor(ls, 32);
-    const float inv = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+    const float inv = lt > 0.f ? 1.0f / (lt + (gen ? 1e-16f : 0.f)) : 0.f;      // (see the header: no epsilon on an un-shifted sum)
     constexpr int RSOF = C + 4;
     static_assert(QT * RSOF * 4 <= NST * CF::STAGE, "O staging must fit in the K/V ring");
     float *so = (float *)smem;
@@ -1333,11 +1363,14 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.irr_row_ptr = mk ? mk->irr_row_ptr : nullptr; p.irr_col_src = mk ? mk->irr_col_src : nullptr;
     p.row_map = mk ? mk->row_map : nullptr;
     { const char *e = getenv("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
+    { static int fg = -1; if (fg < 0) { const char *e = getenv("DA_ATTN_FORCE_GEN"); fg = (e && e[0] == '1') ? 1 : 0; } p.force_gen = fg; if (fg) p.fast = p.fast ? 2 : 0; }
     { const char *e = getenv("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     if (n_graphs <= 0 || max_graph_nodes <= 0) return 0;
     p.fold_out = nullptr; p.n_rows = 0;
     if (fold) {           // value heads folded to 32 channels (last layer of the 2D transformer arch)
         if (C != 144 || fold->cv != 32) return -1;
+        // DA_ATTN_LAST_FAST=0: the last layer on the referenced (round-2) recurrence while the hidden layers keep k_attn_opt (A/B)
+        { static int lf = -1; if (lf < 0) { const char *e = getenv("DA_ATTN_LAST_FAST"); lf = e ? atoi(e) : 1; } if (!lf) p.fast = 0; }
         p.fold_out = fold->out; p.n_rows = fold->n_rows;
         if (!mk && prec == DA_PREC_BF16 && L.q_prescaled && attn_dual_env() DA_ATTN_DBG(&& !p.debug && !p.prof)) {
             const int r2 = launch_attn_dual(L, heads, C, n_graphs, max_graph_nodes, graph_ptr, pad_ptr, nodiag, act, out, fold, st);
@@ -1352,6 +1385,13 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
         return launch_attn_dense2(p, heads, n_graphs, max_graph_nodes, st);
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, st) : launch_tc<bf16_t, 144>(p, st);
     return C == 32 ? launch_tc<float, 32>(p, st) : launch_tc<float, 144>(p, st);
+}
+
+// da_debug_counters: [0] k_attn_opt workgroups re-run in GEN mode, [1] k_attn_dense waves that left FAST mode, since the last reset
+int attn_dense_counters(unsigned long long *out4, int reset) {
+    DA_CHECK_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_attn_fallbacks), 4 * sizeof(unsigned long long)));
+    if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; DA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_fallbacks), z, sizeof(z))); }
+    return 0;
 }
 
 }  // namespace da

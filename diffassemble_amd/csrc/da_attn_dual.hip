@@ -58,6 +58,7 @@ struct AttnDualParams {
     int n_pad, H, nqt, act, nodiag, n_rows;
     int tpw;                        // query tiles per workgroup (consecutive tiles of one (graph, head); see the kernel)
     unsigned long long *prof;       // DA_DUAL_PROBE builds: per-workgroup cycle breakdown of wave 0 (tools/attn_bench)
+    int force_gen;                  // DA_ATTN_FORCE_GEN=1 (tests): every slab starts in GEN mode (running-max recurrence)
 };
 
 template <int C, int CV> struct DualCfg {
@@ -90,6 +91,12 @@ __device__ __forceinline__ void wait_vm(int n) {
 }
 
 template <int V> struct SlabTag { static constexpr int value = V; };
+
+// slabs that left FAST mode (tests: da_debug_counters); touched only inside that rare branch
+__device__ unsigned long long g_dual_fallbacks[2];
+// floor(log2(x)) of a positive finite x as a float: the exact power of two an un-shifted softmax state is re-referenced by when
+// it is handed to the running-max recurrence (its sum restarts in [1, 2), where PyG's + 1e-16 is invisible as in the reference)
+__device__ __forceinline__ float pow2_floor_exp(float lq) { return (float)((int)((__builtin_bit_cast(unsigned, lq) >> 23) & 0xffu) - 127); }
 
 template <int C, int CV, int NST, bool FOLD>
 __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
             O[sl] = zero16;
-            m[sl] = 0.f; l[sl] = 0.f; gen[sl] = false;
+            m[sl] = 0.f; l[sl] = 0.f; gen[sl] = p.force_gen != 0;
         }
         auto softmax = [&](f32x16 &s, int sl, int key0, bf16x8 &pf0, bf16x8 &pf1) {
             const int kbase = key0 + 16 * half;
@@ -264,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = (kbase + r >= n_g || (p.nodiag && kbase + r == qidx[sl])) ? -INFINITY : s[r];
             }
+            bool entering = false;
             if (!gen[sl]) {
                 const float bsum = exp_block0(s, pf0, pf1);
                 const float tot = l[sl] + bsum;
@@ -272,12 +280,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
                     return;
                 }
                 gen[sl] = true;
+                entering = true;
+                if (lane == 0) atomicAdd(&g_dual_fallbacks[0], 1ull);
             }
             // GEN: online softmax with a running row max (per query: both halves agree on it)
             const float lq = l[sl] + __shfl_xor(l[sl], 32);
             const float mloc = rowmax(s);
+            if (entering) m[sl] = lq > 0.f ? pow2_floor_exp(lq) : 0.f;       // un-shifted state (reference 0) -> reference floor(log2(sum)): sum in [1, 2)
+            const float mold = entering ? 0.f : m[sl];
             const float mnew = (lq > 0.f) ? fmaxf(m[sl], mloc) : fmaxf(mloc, -1e30f);      // nothing accumulated yet: free choice
-            const float corr = (lq > 0.f) ? __builtin_amdgcn_exp2f(m[sl] - mnew) : 1.0f;
+            const float corr = (lq > 0.f) ? __builtin_amdgcn_exp2f(mold - mnew) : 1.0f;
             m[sl] = mnew;
             l[sl] *= corr;
 #pragma unroll
@@ -343,11 +355,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
         // matrix pipe idles under the softmax of the same wave.  The range test sits at the end of each region; a slab that
         // trips it is redone in GEN mode from its intact scores and every later block takes the generic path above.
         auto gen_fix = [&](f32x16 &s, int sl, bf16x8 &pf0, bf16x8 &pf1) {
-            gen[sl] = true;
+            gen[sl] = true;                                                    // (only ever called on a slab still in FAST mode)
+            if (lane == 0) atomicAdd(&g_dual_fallbacks[0], 1ull);
             const float lq = l[sl] + __shfl_xor(l[sl], 32);
             const float mloc = rowmax(s);
+            m[sl] = lq > 0.f ? pow2_floor_exp(lq) : 0.f;                       // re-reference the un-shifted state (see softmax())
             const float mnew = (lq > 0.f) ? fmaxf(m[sl], mloc) : fmaxf(mloc, -1e30f);
-            const float corr = (lq > 0.f) ? __builtin_amdgcn_exp2f(m[sl] - mnew) : 1.0f;
+            const float corr = (lq > 0.f) ? __builtin_amdgcn_exp2f(0.f - mnew) : 1.0f;
             m[sl] = mnew;
             l[sl] *= corr;
 #pragma unroll
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl) {
                 const float lt = l[sl] + __shfl_xor(l[sl], 32);
-                const float invf = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+                const float invf = lt > 0.f ? 1.0f / (lt + (gen[sl] ? 1e-16f : 0.f)) : 0.f;      // no epsilon on an un-shifted sum (k_attn_opt's header)
                 if (qidx[sl] < n_g) {
                     bf16_t *dst = (bf16_t *)p.out + ((size_t)h * p.n_rows + node0 + qidx[sl]) * CV;
 #pragma unroll
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_dual(AttnDualParams p) {
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl) {
                 const float lt = l[sl] + __shfl_xor(l[sl], 32);
-                const float inv = lt > 0.f ? 1.0f / (lt + 1e-16f) : 0.f;
+                const float inv = lt > 0.f ? 1.0f / (lt + (gen[sl] ? 1e-16f : 0.f)) : 0.f;
                 float *orow = so + ((wid + 4 * sl) * 32 + i) * RSOF;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -544,10 +558,18 @@ int launch_attn_dual(const DenseLayout &L, int heads, int C, int n_graphs, int m
     p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.nqt = 0; p.act = act; p.nodiag = nodiag;
     p.n_rows = fold ? fold->n_rows : 0;
     { const char *e = getenv("DA_DUAL_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
+    { static int fg = -1; if (fg < 0) { const char *e = getenv("DA_ATTN_FORCE_GEN"); fg = (e && e[0] == '1') ? 1 : 0; } p.force_gen = fg; }
     if (n_graphs <= 0 || max_graph_nodes <= 0) return 0;
     if (fold && C == 144 && fold->cv == 32) return launch_dual_t<144, 32, 6, true>(p, n_graphs, max_graph_nodes, st);
     if (!fold && C == 32) return launch_dual_t<32, 32, 8, false>(p, n_graphs, max_graph_nodes, st);
     return -1;
+}
+
+// da_debug_counters: slabs of k_attn_dual that left FAST mode since the last reset
+int attn_dual_counters(unsigned long long *out2, int reset) {
+    DA_CHECK_HIP(hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_dual_fallbacks), 2 * sizeof(unsigned long long)));
+    if (reset) { const unsigned long long z[2] = {0, 0}; DA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dual_fallbacks), z, sizeof(z))); }
+    return 0;
 }
 
 }  // namespace da

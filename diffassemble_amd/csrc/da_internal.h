@@ -121,6 +121,9 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
 // da_attn_dual.hip: bf16, complete graphs, two query slabs per wave; Q must arrive pre-scaled by log2(e) / sqrt(C)
 int launch_attn_dual(const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes, const int32_t *graph_ptr,
                      const int32_t *pad_ptr, int nodiag, int act, void *out, const DenseFold *fold, hipStream_t st);
+// fallback counters of the shift-free softmax kernels (da_debug_counters)
+int attn_dense_counters(unsigned long long *out4, int reset);
+int attn_dual_counters(unsigned long long *out2, int reset);
 // hybrid mode: the rows the masked kernel does not own (virtual nodes) over their remainder edges
 int launch_attn_csr_cont(int prec, int n_nodes, int n_real, const int32_t *irr_row_ptr, const int32_t *irr_col_src,
                          const int32_t *row_map, int heads, int C, int n_pad, const DenseLayout &L,

@@ -412,6 +412,48 @@ def conv_dense(plan: GraphPlan, x, weight, bias, heads, C_head, residual=None, a
     return out
 
 
+def conv_dense_ex(plan: GraphPlan, x, weight, bias, heads, C_head, residual=None, act=_lib.ACT_NONE, precision="fp32",
+                  prescale_q=True, folded=False):
+    """da_conv_dense_ex: the layer in the forms the packed denoiser runs it.  ``weight`` / ``bias`` arrive UNSCALED in fp32
+    (rows Q | K | V | skip, or Q | K | V' [H * 32] when ``folded``); with ``prescale_q=True`` the Q rows are multiplied
+    by log2(e) / sqrt(C) here, in fp32, before the rounding to the activation dtype -- what da_denoiser_create does
+    (da_api.hip ConvW::wd) -- and the kernels take their shift-free softmax paths (``"done"``: the caller's Q rows
+    already carry the factor; ``False``: plain da_conv_dense semantics).  Returns [N, H*C] or, folded,
+    [H, n_real, 32] (per-head normalised outputs)."""
+    import math
+    prec = _PREC[precision]
+    dt = torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32
+    HC = heads * C_head
+    weight, bias = weight.float().clone(), bias.float().clone()
+    if prescale_q is True:                          # "done": the caller already scaled the Q rows
+        sc = math.log2(math.e) / math.sqrt(C_head)
+        weight[:HC] *= sc
+        bias[:HC] *= sc
+    x = x.to(dt).contiguous()
+    weight = weight.to(dt).contiguous()
+    bias = bias.contiguous()
+    g = plan.c_struct(need_csr=False)
+    lib = _lib.lib()
+    nbytes = int(lib.da_attn_dense_scratch_bytes(prec, C.byref(g), heads, C_head))
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
+    out = (torch.empty((heads, plan.n_real, 32), dtype=dt, device=x.device) if folded
+           else torch.empty((plan.n_nodes, HC), dtype=dt, device=x.device))
+    r = None if residual is None else residual.to(dt).contiguous()
+    flags = (_lib.CONV_Q_PRESCALED if prescale_q else 0) | (_lib.CONV_FOLDED_V32 if folded else 0)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.da_conv_dense_ex(prec, C.byref(g), heads, C_head, x.shape[1], _lib.ptr(x), _lib.ptr(weight),
+                                        _lib.ptr(bias), _lib.ptr(r), int(act), _lib.ptr(out), _lib.ptr(scratch), flags,
+                                        _lib.stream_ptr(x.device)))
+    return out
+
+
+def debug_counters(reset=True):
+    """da_debug_counters as a dict (fallback events of the shift-free softmax kernels since the last reset)."""
+    buf = (C.c_int64 * 8)()
+    _lib.check(_lib.lib().da_debug_counters(buf, 8, 1 if reset else 0))
+    return {name: int(buf[k]) for k, name in enumerate(_lib.DBG_COUNTERS)}
+
+
 def greedy_assign(pos1, pos2, ptr1=None, ptr2=None):
     """greedy_cost_assignment (spatial_diffusion.py:179-216) for one puzzle or a whole Batch in ONE launch
     (da_greedy_assign): pos1 [N, >=2], pos2 [M, >=2] fp32 on a ROCm device; ptr1 / ptr2 int32 [G + 1] row

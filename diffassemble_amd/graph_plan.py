@@ -85,9 +85,10 @@ class GraphPlan:
         """Add the by-source orientation of the same edge list (da_graph.out_ptr / out_dst), which
         the attention backward walks to form dK / dV without atomics."""
         import os
-        if self.dense and os.environ.get("DA_TRAIN_DISABLE_DENSE") != "1":
+        edge_list_only = os.environ.get("DA_TRAIN_DISABLE_DENSE") == "1"      # the library then walks the FULL edge list
+        if self.dense and not edge_list_only:
             return self                        # complete graphs train on the grouped GEMMs: no edge list is walked
-        if self.out_ptr is None and self.hybrid:
+        if self.out_ptr is None and self.hybrid and not edge_list_only:
             # hybrid graphs: only the REMAINDER edges are walked (the regular ones run as adjacency-masked grouped GEMMs,
             # da_train_dense.hip), so the by-source orientation is built from irr_row_ptr / irr_col_src alone -- the
             # 15 M regular edges of a Batch of 60 % Exphander graphs are never sorted

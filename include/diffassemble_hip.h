@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 15
+#define DA_ABI_VERSION 16
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -301,6 +301,30 @@ int da_attn_csr(int prec, const da_graph *g, int heads, int C, const void *qkvs,
 size_t da_attn_dense_scratch_bytes(int prec, const da_graph *g, int heads, int C);
 int da_conv_dense(int prec, const da_graph *g, int heads, int C, int Din, const void *x, const void *w,
                   const float *b, const void *residual, int act, void *out, void *scratch, void *stream);
+
+/* The same layer in the two forms the packed denoiser runs it in (da_denoiser_create): with the Q rows of w / b
+ * PRE-SCALED by log2(e) / sqrt(C) (DA_CONV_Q_PRESCALED: the attention kernels then take their shift-free softmax paths --
+ * exp2 of the raw scores, verified row sums, running-max fallback), and with the value heads FOLDED to 32 channels
+ * (DA_CONV_FOLDED_V32, C = 144: w = Wq | Wk | V' [2*H*C + H*32, Din], no skip; out = [H][n_real][32] per-head normalised
+ * sum_j softmax_j(q_i.k_j / sqrt(C)) v'_j in the act dtype -- the last conv of the 2D transformer arch composed with
+ * final_mlp.0).  Also takes hybrid graphs (adjacency mask + remainder CSR of g).  No reference counterpart
+ * beyond da_conv_dense's (Transformer_GNN.py:32,38): kernel-level test entry for those paths.                          */
+#define DA_CONV_Q_PRESCALED 1
+#define DA_CONV_FOLDED_V32 2
+int da_conv_dense_ex(int prec, const da_graph *g, int heads, int C, int Din, const void *x, const void *w,
+                     const float *b, const void *residual, int act, void *out, void *scratch, int flags,
+                     void *stream);
+
+/* Fallback bookkeeping of the shift-free softmax kernels (no reference counterpart; lets a test assert that the branch it
+ * aims at really ran): out[k] = events since the last reset.  Synchronises the device.                                  */
+enum {
+    DA_DBG_OPT_GEN_WORKGROUPS = 0,         /* k_attn_opt workgroups whose optimistic pass failed its verification   */
+    DA_DBG_DENSE_FAST_EXITS = 1,           /* k_attn_dense waves that left the shift-free FAST mode                 */
+    DA_DBG_DUAL_GEN_SLABS = 2,             /* k_attn_dual query slabs that left FAST mode                            */
+    DA_DBG_OPT_MASKED_GEN_WORKGROUPS = 3,  /* adjacency-masked optimistic kernel: workgroups re-run                  */
+    DA_DBG_NCOUNTERS = 8
+};
+int da_debug_counters(int64_t *out /* host [n] */, int n, int reset);
 
 /* ---------------------------------------------------------------------------------------
  * Training: the denoiser forward with saved activations and its backward, fp32.

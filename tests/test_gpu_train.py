@@ -378,6 +378,22 @@ def test_hybrid_training_path_forced_on_small_graphs_subprocess():
     assert "3 passed" in r.stdout
 
 
+def test_hybrid_plan_on_the_edge_list_switch_subprocess():
+    """DA_TRAIN_DISABLE_DENSE=1 (the documented debugging switch) on HYBRID plans: the library then
+    walks the full edge list in the backward, so the plan's by-source CSR must hold EVERY edge, not just the remainder
+    (round-3 advisor finding: dK / dV silently lost every regular edge).  Same fixture cases as the hybrid test, with the
+    plans still forced hybrid, against the oracle's autograd."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DA_HYBRID="force", DA_TRAIN_DISABLE_DENSE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
+                        "test_backward_matches_oracle_autograd and (exo144_v8_g2 or exo_expander_d6 or tr_expander_d7)"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "3 passed" in r.stdout
+
+
 def test_hybrid_training_at_900_pieces_equals_the_edge_list_path(dev, monkeypatch):
     """One 900-piece Exphander puzzle of the scripted degree (d = 539) with 8 virtual nodes: the plan goes hybrid by itself;
     loss and the whole flat gradient buffer against the SAME step through the edge-list kernels (DA_HYBRID=off), which
