@@ -29,8 +29,7 @@
 // XCD and share its L2 copy of K / V.
 #include <stdlib.h>
 
-#include "da_common.h"
-#include "da_internal.h"
+#include "da_attn_common.h"
 
 namespace da {
 
@@ -43,160 +42,10 @@ namespace da {
 #define DA_TICK(var)
 #endif
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-struct AttnDenseParams {
-    const void *Q, *K, *Vt, *S;     // [H][n_pad][C] each (Vt holds V ROW-major since the tr_b16 rewrite), [N][H*C]
-    const void *res;                // [N][H*C] or null
-    void *out;                      // [N][H*C]
-    const int32_t *graph_ptr, *pad_ptr;
-    int n_pad, H, n_graphs, nqt, act, nodiag;       // nqt = query tiles per graph (set by the launcher: depends on the waves per workgroup)
-    int max_nodes;                                  // largest graph of the batch
-    float sc;                       // log2(e) / sqrt(C)
-    unsigned long long *prof;       // DA_ATTN_PROBE: per-workgroup cycle breakdown of wave 0
-    int fast;                       // Q pre-scaled (sc == 1): start every wave in the shift-free softmax mode (see k_attn_dense)
-    int debug;                      // DA_ATTN_DEBUG bits (timing experiments): 1 no DMA, 2 no softmax, 4 no PV, 8 no QK
-    int force_gen;                  // DA_ATTN_FORCE_GEN=1 (tests): the shift-free kernels start in their running-max fallback mode
-    // hybrid (MASKED) mode: adjacency bits of the regular edges; the remainder edges are folded in by the epilogue
-    const unsigned char *mask;      // rows of graph g at mask_ptr[g], row stride (pad_ptr[g+1] - pad_ptr[g]) / 8 bytes
-    const long long *mask_ptr;
-    const int32_t *irr_row_ptr;     // remainder edges (virtual nodes, duplicates, cross-graph pairs): CSR by destination
-    const int32_t *irr_col_src;
-    const int32_t *row_map;         // node -> padded slot (for the sources of remainder edges)
-    void *fold_out;                 // CV != C: [H][n_rows][CV] normalised per-head outputs in the activation dtype (no skip / activation here)
-    int n_rows;
-};
-
-template <typename T, int C, int CV = C> struct Cfg {
-    static constexpr int ES = (int)sizeof(T);
-    static constexpr int ROWB = C * ES;                       // bytes of one K / Q row
-    static constexpr int ROWBV = CV * ES;                     // bytes of one V row (CV != C: value heads folded with the
-                                                              // next linear layer, see launch_attn_dense)
-    static constexpr int NCH = ROWB / 32;                     // 32-byte K-dim chunks
-    static constexpr int RS = ROWB + (((ROWB / 16) & 1) ? 0 : 16);   // odd number of 16-B slots
-    static constexpr int KSPR = RS / 16;                      // LDS slots per K row
-    static constexpr int KVALID = ROWB / 16;                  // of which carry data
-    static constexpr int BKEYS = ES == 2 ? 64 : 32;           // keys per LDS tile
-    static constexpr int KB = BKEYS / 32;
-    // V rows (row-major, like K).  bf16: the PV operand is fetched with ds_read_b64_tr_b16, whose 16-lane
-    // groups read [4 keys][16 channels] blocks; two groups share an LDS cycle, and their 8 x 32-byte
-    // pieces tile all 64 banks exactly when the row stride is 64 (mod 256) bytes.  fp32: scalar reads,
-    // the two 32-lane halves sit 16 rows apart -> stride 32 (mod 64) bytes keeps them on disjoint banks.
-    static constexpr int RSV = ES == 2 ? ((ROWBV - 64 + 255) / 256 * 256 + 64) : ((ROWBV - 32 + 63) / 64 * 64 + 32);
-    static constexpr int KVALIDV = ROWBV / 16;
-    static constexpr int VSPR = RSV / 16;
-    static constexpr int NCB = (CV + 31) / 32;
-    static constexpr int NIK = (BKEYS * KSPR + 63) / 64;      // DMA instructions (1 KB each) per tile
-    static constexpr int NIV = (BKEYS * VSPR + 63) / 64;
-    static constexpr int NI = NIK + NIV;
-    static constexpr int MAXI = (NI + 3) / 4;                 // per wave
-    static constexpr int KBYTES = NIK * 1024, VBYTES = NIV * 1024, STAGE = KBYTES + VBYTES;
-    static_assert(ROWB % 32 == 0, "head width must be a multiple of 32 bytes");
-};
-
-// ---- S^T += Kfrag . Qfrag over one 32-byte chunk
-__device__ __forceinline__ f32x16 mma_chunk(bf16_t, const u32x4 &a, const u32x4 &b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mma_chunk(float, const u32x4 &a, const u32x4 &b, f32x16 c) {
-    const f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(x[0], y[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(x[1], y[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(x[2], y[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(x[3], y[3], c, 0, 0, 0);
-    return c;
-}
-
-// ---- PV operand fetch.  bf16: two transposing reads give this lane 8 consecutive keys of ONE channel
-// (the A operand of v_mfma_f32_32x32x16_bf16) out of the row-major [key][channel] tile: lane i' of a
-// 16-lane group supplies the address of key (i' >> 2), channels 4 (i' & 3)..+3, and receives channel i'
-// of keys 0..3 (measured with tools/tr_probe.hip).
-// Issued as inline asm: hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of the builtin form, i.e.
-// it waits for the LDS-DMA of the NEXT tile (just issued) before every V fetch and serialises the
-// pipeline.  The asm form is invisible to that pass, so the result must be fenced by hand: tr_fence()
-// (s_waitcnt lgkmcnt(0) carrying the fragment registers as operands) before the first MFMA that uses it.
-__device__ __forceinline__ u32x2 tr_read(unsigned lds_byte_addr, int imm) {      // imm folds to a constant after unrolling
-    u32x2 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(imm));
-    return r;
-}
-// fp32: O^T[cb] += V rows . P^T for one 32-key block with exact-fp32 MFMAs; vcol points at key 0 of the
-// block, this lane's channel; p[16] = this lane's probabilities for keys 16*half + 0..15.
-template <int RSV>
-__device__ __forceinline__ f32x16 mma_pv_f32(const unsigned char *vcol, int half, const float (&p)[16], f32x16 o) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const float v = *(const float *)(vcol + (16 * half + e) * RSV);
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(v, p[e], o, 0, 0, 0);
-    }
-    return o;
-}
-
-__device__ __forceinline__ void ld4(const float *s, float v[4]) { const f32x4 f = *(const f32x4 *)s; v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3]; }
-__device__ __forceinline__ void ld4(const bf16_t *s, float v[4]) {
-    const u32x2 u = *(const u32x2 *)s;
-    v[0] = bf2f((bf16_t)(u[0] & 0xffff)); v[1] = bf2f((bf16_t)(u[0] >> 16));
-    v[2] = bf2f((bf16_t)(u[1] & 0xffff)); v[3] = bf2f((bf16_t)(u[1] >> 16));
-}
-__device__ __forceinline__ void st4(float *d, const float v[4]) { *(f32x4 *)d = (f32x4){v[0], v[1], v[2], v[3]}; }
-__device__ __forceinline__ void st4(bf16_t *d, const float v[4]) {
-    const bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-    *(u32x2 *)d = __builtin_bit_cast(u32x2, b);
-}
-
-// one 16-byte chunk: 4 fp32 or 8 bf16
-__device__ __forceinline__ void unpack_chunk(float, const u32x4 &u, float (&v)[4]) {
-    const f32x4 f = __builtin_bit_cast(f32x4, u);
-    v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
-}
-__device__ __forceinline__ void unpack_chunk(bf16_t, const u32x4 &u, float (&v)[8]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { v[2 * k] = bf2f((bf16_t)(u[k] & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(u[k] >> 16)); }
-}
-__device__ __forceinline__ void ldc(const float *s, float (&v)[4]) { const f32x4 f = *(const f32x4 *)s; v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3]; }
-__device__ __forceinline__ void ldc(const bf16_t *s, float (&v)[8]) {
-    const u32x4 u = *(const u32x4 *)s;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { v[2 * k] = bf2f((bf16_t)(u[k] & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(u[k] >> 16)); }
-}
-__device__ __forceinline__ void stc(float *d, const float (&v)[4]) { *(f32x4 *)d = (f32x4){v[0], v[1], v[2], v[3]}; }
-__device__ __forceinline__ void stc(bf16_t *d, const float (&v)[8]) {
-    bf16x8 b;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) b[k] = (__bf16)v[k];
-    *(u32x4 *)d = __builtin_bit_cast(u32x4, b);
-}
-
-// NST = stages of the K / V ring.  An LDS-DMA takes ~2 us from issue to landing under load (measured), longer than a
-// wave spends on one 64-key tile of the C = 32 layers: with two stages (one tile in flight) every tile waited for its own
-// DMA and the kernel ran at the DMA latency (15 tiles x ~2 us per workgroup, 8 workgroups per CU in two rounds = the
-// measured 55-61 us).  NST - 1 tiles are kept in flight instead, waited for with a COUNTED vmcnt.
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-#define DA_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        DA_VMCNT_CASE(1) DA_VMCNT_CASE(2) DA_VMCNT_CASE(3) DA_VMCNT_CASE(4) DA_VMCNT_CASE(5) DA_VMCNT_CASE(6) DA_VMCNT_CASE(7) DA_VMCNT_CASE(8)
-        DA_VMCNT_CASE(9) DA_VMCNT_CASE(10) DA_VMCNT_CASE(11) DA_VMCNT_CASE(12) DA_VMCNT_CASE(13) DA_VMCNT_CASE(14) DA_VMCNT_CASE(15) DA_VMCNT_CASE(16)
-        DA_VMCNT_CASE(17) DA_VMCNT_CASE(18) DA_VMCNT_CASE(19) DA_VMCNT_CASE(20) DA_VMCNT_CASE(21) DA_VMCNT_CASE(22) DA_VMCNT_CASE(23) DA_VMCNT_CASE(24)
-#undef DA_VMCNT_CASE
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // 0, or more than the cases cover: wait for everything
-    }
-}
-
 // Fallback bookkeeping of the shift-free softmax paths (tests assert that the branches they aim at really ran;
-// da_debug_counters): [0] k_attn_opt workgroups re-run with the running-max recurrence, [1] k_attn_dense waves that left
-// FAST mode.  Only touched inside the (rare) fallback branches.
+// da_debug_counters): [1] k_attn_dense waves that left FAST mode ([0] / [2] are filled from da_attn_opt.hip's counters).
+// Only touched inside the (rare) fallback branch.
 __device__ unsigned long long g_attn_fallbacks[4];
-
-// An UN-SHIFTED softmax state (weights exp2(s), reference 0) handed to the running-max recurrence: re-reference it by the
-// exact power of two e = floor(log2(row sum)), so that the sum restarts in [1, 2) -- from there on PyG's `+ 1e-16` is as
-// invisible as it is in the reference (where it is added to sum exp(a - max) >= 1), whatever the scores' offset.
-__device__ __forceinline__ float pow2_floor_exp(float lq) { return (float)((int)((__builtin_bit_cast(unsigned, lq) >> 23) & 0xffu) - 127); }
 
 template <typename T, int C, bool MASKED, int CV, int NST, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
@@ -590,95 +439,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
         // sub, sub + 8, ... of the C-wide rows (vector loads); the CSR metadata of the four queries a lane
         // group serves (rm_*) was fetched at kernel start, and the Q / K / V rows of all four first edges are
         // requested before any is consumed: the pass used to be a chain of ~5 dependent global loads per query.
-        constexpr int NCK = CF::ROWB / 16, MAXT = (NCK + 7) / 8, EPK = 16 / CF::ES;
-        constexpr int NCKV = CF::ROWBV / 16, MAXTV = (NCKV + 7) / 8;       // V rows may be narrower (folded heads)
-        const int sub = lane & 7;
-        const float scale = p.sc * 0.6931471805599453f;          // 1 / sqrt(C)
-        auto load_row = [&](const void *base, size_t row, u32x4 (&dst)[MAXT]) {
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const int ck = sub + 8 * t;
-                dst[t] = ck < NCK ? *(const u32x4 *)((const unsigned char *)base + row * CF::ROWB + ck * 16) : (u32x4){0u, 0u, 0u, 0u};
-            }
-        };
-        auto load_vrow = [&](size_t row, u32x4 (&dst)[MAXTV]) {
-#pragma unroll
-            for (int t = 0; t < MAXTV; ++t) {
-                const int ck = sub + 8 * t;
-                dst[t] = ck < NCKV ? *(const u32x4 *)((const unsigned char *)p.Vt + row * CF::ROWBV + ck * 16) : (u32x4){0u, 0u, 0u, 0u};
-            }
-        };
-        if (wave_on) {
-            u32x4 qr[4][MAXT], kr[4][MAXT], vr[4][MAXTV];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qg = min(qt * QT + wid * 32 + (lane >> 3) + 8 * r, n_g - 1);
-                load_row(p.Q, (size_t)h * np + pad0 + qg, qr[r]);
-                load_row(p.K, (size_t)h * np + rm_slot[r], kr[r]);
-                load_vrow((size_t)h * np + rm_slot[r], vr[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (rm_end[r] <= rm_beg[r]) continue;
-                const int ql = wid * 32 + (lane >> 3) + 8 * r;
-                float *orow = so + ql * RSOF;
-                float mm = orow[CO], ll = orow[CO + 1];
-                if (!(ll > 0.f)) { mm = -INFINITY; ll = 0.f; }
-                float qv[MAXT][EPK], acc[MAXTV][EPK];
-#pragma unroll
-                for (int t = 0; t < MAXT; ++t) {
-                    unpack_chunk(T(), qr[r][t], qv[t]);
-#pragma unroll
-                    for (int x = 0; x < EPK; ++x) qv[t][x] *= scale;
-                }
-#pragma unroll
-                for (int t = 0; t < MAXTV; ++t)
-#pragma unroll
-                    for (int x = 0; x < EPK; ++x) acc[t][x] = (sub + 8 * t < NCKV) ? orow[(sub + 8 * t) * EPK + x] : 0.f;
-                for (int e = rm_beg[r]; e < rm_end[r]; ++e) {
-                    u32x4 k2[MAXT], v2[MAXTV];
-                    if (e > rm_beg[r]) {                              // beyond the prefetched first edge (rare)
-                        const size_t sj = (size_t)h * np + (size_t)p.row_map[p.irr_col_src[e]];
-                        load_row(p.K, sj, k2);
-                        load_vrow(sj, v2);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < MAXT; ++t) k2[t] = kr[r][t];
-#pragma unroll
-                        for (int t = 0; t < MAXTV; ++t) v2[t] = vr[r][t];
-                    }
-                    float sc_ = 0.f;
-#pragma unroll
-                    for (int t = 0; t < MAXT; ++t) {
-                        float kk[EPK];
-                        unpack_chunk(T(), k2[t], kk);
-#pragma unroll
-                        for (int x = 0; x < EPK; ++x) sc_ = fmaf(qv[t][x], kk[x], sc_);
-                    }
-                    sc_ += __shfl_xor(sc_, 1);
-                    sc_ += __shfl_xor(sc_, 2);
-                    sc_ += __shfl_xor(sc_, 4);
-                    const float mn = fmaxf(mm, sc_);
-                    const float corr = expf(mm - mn), pe = expf(sc_ - mn);
-                    ll = ll * corr + pe;
-#pragma unroll
-                    for (int t = 0; t < MAXTV; ++t) {
-                        float vv[EPK];
-                        unpack_chunk(T(), v2[t], vv);
-#pragma unroll
-                        for (int x = 0; x < EPK; ++x) acc[t][x] = fmaf(pe, vv[x], acc[t][x] * corr);
-                    }
-                    mm = mn;
-                }
-#pragma unroll
-                for (int t = 0; t < MAXTV; ++t)
-                    if (sub + 8 * t < NCKV) {
-#pragma unroll
-                        for (int x = 0; x < EPK; ++x) orow[(sub + 8 * t) * EPK + x] = acc[t][x];
-                    }
-                if (sub == 0) { orow[CO] = mm; orow[CO + 1] = ll; }
-            }
-        }
+        remainder_edges<T, CF, CO, RSOF>(p, so, h, np, pad0, n_g, qt * QT, wid, lane, wave_on, rm_beg, rm_end, rm_slot);
         __syncthreads();
     }
     if (CV != C) {                // MASKED + folded value heads: normalised per-head rows for the tail kernel
@@ -1004,268 +765,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense2(AttnDenseParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// k_attn_opt: the C = 32 bf16 instance on complete graphs with Q pre-scaled (the three hidden layers of the 2D arch), written
-// around what the round-3 measurements say bounds it: the SIMD's vector issue port (v_exp_f32 ~13-16 cycles, packs ~6.4,
-// every MFMA ~12 cycles of the same port; DESIGN.md "Measured, round 3").  Per score only the exponential and the pack are
-// left on that port:
-//   * OPTIMISTIC softmax: p = exp2(s) with no reference, no per-block range test, in place.  fp32 / bf16 carry 8 exponent
-//     bits, so this is exact whenever the row sums stay inside [2^-60, 2^100]; that is VERIFIED once, after the last key
-//     block, on the final row sums (an overflow anywhere shows up there as inf / NaN, total underflow as 0).  A workgroup
-//     whose check fails -- logits beyond +-41 before the 1/sqrt(C), not seen at a fresh model's near-uniform attention --
-//     re-runs its tile with the classic running-max recurrence (same loop, `gen` switched on: row max, rescale, shift);
-//   * the row sums are eight v_dot2_f32_bf16 of the packed P against (1, 1) per block: they sum exactly the bf16 values the
-//     PV product weighs with, on the vector port but at half the instruction count of fp32 adds (row sums on the matrix
-//     pipe -- two more MFMAs per block against an all-ones operand -- measured slower: 113.6 vs 100.5 us per layer);
-//   * an optimistic pass normalises by 1 / sum, WITHOUT PyG's + 1e-16: the sum is un-shifted there (anything in
-//     [2^-60, 2^100]) while the reference adds its epsilon to sum exp(a - max) >= 1, where it is below fp32 resolution.
-// Same LDS image, DMA ring, fragment layouts and epilogue as k_attn_dense<bf16_t, 32, false, 32, 4, 4>.
-__global__ __launch_bounds__(256, 4) void k_attn_opt(AttnDenseParams p) {
-    using T = bf16_t;
-    constexpr int C = 32, NST = 4, NW = 4, QT = 128, NT = 256;
-    using CF = Cfg<T, C, C>;
-    constexpr int MAXI = (CF::NI + NW - 1) / NW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *flags = (int *)(smem + NST * CF::STAGE);               // one word per wave: "my optimistic pass failed"
-
-    const int bid = blockIdx.x;
-    const int h = bid & 7, s_ = bid >> 3;
-    const int qt = s_ % p.nqt, g = s_ / p.nqt;
-    const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
-    if (qt * QT >= n_g) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q0 = qt * QT + wid * 32;
-    const bool wave_on = q0 < n_g;
-    const int HC = p.H * C;
-    const size_t np = (size_t)p.n_pad;
-
-    u32x4 qf[CF::NCH];
-    {
-        const unsigned char *qrow = (const unsigned char *)p.Q + ((size_t)h * np + pad0 + min(q0, n_g - 1) / 32 * 32 + i) * CF::ROWB;
-#pragma unroll
-        for (int ch = 0; ch < CF::NCH; ++ch) qf[ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
-    }
-    const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
-    const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWBV;
-    unsigned soff[MAXI];
-#pragma unroll
-    for (int x = 0; x < MAXI; ++x) {
-        const int q = wid + NW * x;
-        unsigned o = 0;
-        if (q < CF::NIK) {
-            const int s = q * 64 + lane, row = s / CF::KSPR, col = s - row * CF::KSPR;
-            if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
-        } else {
-            const int s = (q - CF::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
-            if (row < CF::BKEYS && col < CF::KVALIDV) o = (unsigned)(row * CF::ROWBV + col * 16);
-        }
-        soff[x] = o;
-    }
-    auto issue = [&](int kt, int stage) {
-        unsigned char *sb = smem + stage * CF::STAGE;
-        const unsigned char *kb_ = Kg + (size_t)kt * CF::BKEYS * CF::ROWB;
-        const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ROWBV;
-#pragma unroll
-        for (int x = 0; x < MAXI; ++x) {
-            const int q = wid + NW * x;
-            if (NW * x + NW - 1 < CF::NI || q < CF::NI) {
-                const unsigned char *src = (q < CF::NIK ? kb_ : vb_) + soff[x];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
-            }
-        }
-    };
-    const int myn = (CF::NI - wid + NW - 1) / NW;
-    const int nkt = (n_g + CF::BKEYS - 1) / CF::BKEYS;
-    const int qidx = q0 + i;
-    const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);
-    const int koff = pi_i * CF::RS + half * 16;
-    const int li = lane & 15;
-    const int vbase = CF::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-
-    f32x16 O;
-    float ls = 0.f;               // this lane's share of the row sum (16 of the block's 32 keys)
-    float m = 0.f;                // GEN mode only: running row max (log2 units)
-    bool gen = p.force_gen != 0;  // false: optimistic pass
-    for (int attempt = 0; attempt < 2; ++attempt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) O[r] = 0.f;
-        ls = 0.f;
-        m = -1e30f;
-#pragma unroll
-        for (int st = 0; st < NST - 1; ++st)
-            if (st < nkt) issue(st, st);
-        for (int kt = 0; kt < nkt; ++kt) {
-            {
-                const int younger = min(nkt - 1 - kt, NST - 2);
-                if (younger == NST - 2) { if (myn == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-                else wait_vmcnt(younger * myn);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            if (kt + NST - 1 < nkt) issue(kt + NST - 1, (kt + NST - 1) % NST);
-            if (!wave_on) continue;
-            const unsigned char *stg = smem + (kt % NST) * CF::STAGE;
-#pragma unroll
-            for (int kb = 0; kb < CF::KB; ++kb) {
-                const int key0 = kt * CF::BKEYS + kb * 32;
-                if (key0 >= n_g) break;
-                u32x4 kf[CF::NCH];
-#pragma unroll
-                for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + koff + kb * 32 * CF::RS + ch * 32);
-                __builtin_amdgcn_sched_barrier(0);
-                f32x16 s;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-                for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), kf[ch], qf[ch], s);
-                u32x2 vlo[2], vhi[2];
-                const unsigned vb = lds0 + (unsigned)((kt % NST) * CF::STAGE + vbase + kb * 32 * CF::RSV);
-#pragma unroll
-                for (int mm = 0; mm < 2; ++mm) {
-                    vlo[mm] = tr_read(vb, (8 * mm) * CF::RSV);
-                    vhi[mm] = tr_read(vb, (8 * mm + 4) * CF::RSV);
-                }
-                const int kbase = key0 + 16 * half;
-                const bool tail = key0 + 32 > n_g;
-                const bool diag = p.nodiag && key0 < q0 + 32 && key0 + 32 > q0;
-                if (tail || diag) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
-                }
-                if (gen) {
-                    // classic recurrence: new reference = max(old, block max); state rescaled when it moves
-                    const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
-                    const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
-                    const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
-                    const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
-                    const float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));      // >= -1e30: finite
-                    if (__any(mnew > m)) {
-                        const float corr = __builtin_amdgcn_exp2f(m - mnew);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) O[r] *= corr;
-                        ls *= corr;
-                        m = mnew;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[r] -= m;
-                }
-                bf16x8 pf0, pf1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {               // pair by pair, so that at most two exponentials wait for their pack
-                    const float x0 = __builtin_amdgcn_exp2f(s[2 * e]), x1 = __builtin_amdgcn_exp2f(s[2 * e + 1]);
-                    pf0[2 * e] = (__bf16)x0; pf0[2 * e + 1] = (__bf16)x1;
-                    const float y0 = __builtin_amdgcn_exp2f(s[8 + 2 * e]), y1 = __builtin_amdgcn_exp2f(s[8 + 2 * e + 1]);
-                    pf1[2 * e] = (__bf16)y0; pf1[2 * e + 1] = (__bf16)y1;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]));
-                const u32x4 v0 = {vlo[0][0], vlo[0][1], vhi[0][0], vhi[0][1]};
-                const u32x4 v1 = {vlo[1][0], vlo[1][1], vhi[1][0], vhi[1][1]};
-                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O, 0, 0, 0);
-                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
-                {
-                    // row sum of the bf16-rounded p (what the PV product weighs with): eight v_dot2_f32_bf16 against (1, 1)
-                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-                    const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bf16x2 pa = {pf0[2 * e], pf0[2 * e + 1]}, pb = {pf1[2 * e], pf1[2 * e + 1]};
-                        ls = __builtin_amdgcn_fdot2_f32_bf16(pa, one2, ls, false);
-                        ls = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, ls, false);
-                    }
-                }
-            }
-        }
-        if (gen) break;
-        // ---- verification of the optimistic pass (workgroup-uniform verdict: the waves share the K / V stream)
-        const float lt0 = ls + __shfl_xor(ls, 32);
-        const bool bad = wave_on && __any(!(lt0 > 8.673617379884035e-19f && lt0 < 1.2676506002282294e30f) && qidx < n_g);      // 2^-60, 2^100; NaN fails
-        dma_barrier();
-        if (lane == 0) flags[wid] = bad ? 1 : 0;
-        __syncthreads();
-        const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
-        __syncthreads();
-        if (!redo) break;
-        gen = true;
-        if (tid == 0) atomicAdd(&g_attn_fallbacks[0], 1ull);
-    }
-
-    // ---- epilogue (as k_attn_dense): normalise, stage [query][c] fp32 rows through LDS, + skip, activation, 16-byte stores
-    const float lt = ls + __shfl_xor(ls, 32);
-    const float inv = lt > 0.f ? 1.0f / (lt + (gen ? 1e-16f : 0.f)) : 0.f;      // (see the header: no epsilon on an un-shifted sum)
-    constexpr int RSOF = C + 4;
-    static_assert(QT * RSOF * 4 <= NST * CF::STAGE, "O staging must fit in the K/V ring");
-    float *so = (float *)smem;
-    dma_barrier();
-    if (wave_on) {
-        float *orow = so + (wid * 32 + i) * RSOF;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int c0 = 8 * jj + 4 * half;
-            *(f32x4 *)(orow + c0) = (f32x4){O[4 * jj] * inv, O[4 * jj + 1] * inv, O[4 * jj + 2] * inv, O[4 * jj + 3] * inv};
-        }
-    }
-    dma_barrier();
-    constexpr int EPC = 8, CPR = C / EPC;
-    const int nq = min(QT, n_g - qt * QT);
-    constexpr int NB = 3;
-    for (int it0 = tid; it0 < nq * CPR; it0 += NT * NB) {
-        u32x4 skv[NB], rsv[NB];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int it = it0 + NT * k;
-            if (it < nq * CPR) {
-                const int q = it / CPR, ch = it - q * CPR;
-                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
-                skv[k] = *(const u32x4 *)((const T *)p.S + off);
-                if (p.res) rsv[k] = *(const u32x4 *)((const T *)p.res + off);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int it = it0 + NT * k;
-            if (it < nq * CPR) {
-                const int q = it / CPR, ch = it - q * CPR;
-                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
-                const float *src = so + q * RSOF + ch * EPC;
-                float v[EPC], sk[EPC];
-                const f32x4 a = *(const f32x4 *)src, b2 = *(const f32x4 *)(src + 4);
-                v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b2[0]; v[5] = b2[1]; v[6] = b2[2]; v[7] = b2[3];
-                unpack_chunk(T(), skv[k], sk);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] += sk[e];
-                if (p.res) {
-                    unpack_chunk(T(), rsv[k], sk);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[e] += sk[e];
-                }
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] = apply_act(v[e], p.act);
-                stc((T *)p.out + off, v);
-            }
-        }
-    }
-}
-
 // DA_ATTN_OPT=0: hidden layers on k_attn_dense's FAST path instead (A/B runs)
+static int attn_opt_last_env() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_ATTN_OPT_LAST"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static int attn_opt_masked_env() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_ATTN_OPT_MASKED"); v = e ? atoi(e) : 1; }
+    return v;
+}
 static int attn_opt_env() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("DA_ATTN_OPT"); v = e ? atoi(e) : 1; }
     return v;
 }
-static int launch_attn_opt(AttnDenseParams p, hipStream_t st) {
-    using CF = Cfg<bf16_t, 32, 32>;
-    p.nqt = (p.max_nodes + 127) / 128;
-    k_attn_opt<<<p.nqt * p.H * p.n_graphs, 256, 4 * CF::STAGE + 64, st>>>(p);
-    DA_LAUNCH_CHECK();
-    return 0;
-}
-
 // opt-in (DA_ATTN2=1): measured EQUAL to the one-slab kernel at 64 puzzles (173 vs 174 us per conv) and slower at 32
 // (95.5 vs 89.1) -- kept as the record of the experiment, see DESIGN.md
 static int attn2_env() {
@@ -1376,11 +891,16 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
             const int r2 = launch_attn_dual(L, heads, C, n_graphs, max_graph_nodes, graph_ptr, pad_ptr, nodiag, act, out, fold, st);
             if (r2 >= 0) return r2;
         }
+        // bf16 with pre-scaled Q: the optimistic kernels (da_attn_opt.hip); DA_ATTN_OPT_LAST=0 / DA_ATTN_OPT_MASKED=0 keep
+        // this layer on k_attn_dense (A/B runs)
+        if (prec == DA_PREC_BF16 && L.q_prescaled && p.fast && attn_opt_env() && attn_opt_last_env() && (!p.mask || attn_opt_masked_env())
+            DA_ATTN_DBG(&& !p.debug && !p.prof))
+            return launch_attn_opt(p, C, st);
         if (mk) return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, true, 32>(p, st) : launch_tcm<float, 144, true, 32>(p, st);
         return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, false, 32>(p, st) : launch_tcm<float, 144, false, 32>(p, st);
     }
-    if (prec == DA_PREC_BF16 && C == 32 && !p.mask && L.q_prescaled && p.fast && attn_opt_env() DA_ATTN_DBG(&& !p.debug && !p.prof))
-        return launch_attn_opt(p, st);
+    if (prec == DA_PREC_BF16 && C == 32 && L.q_prescaled && p.fast && attn_opt_env() && (!p.mask || attn_opt_masked_env()) DA_ATTN_DBG(&& !p.debug && !p.prof))
+        return launch_attn_opt(p, C, st);
     if (prec == DA_PREC_BF16 && C == 32 && !p.mask && attn2_env() DA_ATTN_DBG(&& !p.debug && !p.prof))
         return launch_attn_dense2(p, heads, n_graphs, max_graph_nodes, st);
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, st) : launch_tc<bf16_t, 144>(p, st);
@@ -1391,6 +911,11 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
 int attn_dense_counters(unsigned long long *out4, int reset) {
     DA_CHECK_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_attn_fallbacks), 4 * sizeof(unsigned long long)));
     if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; DA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_fallbacks), z, sizeof(z))); }
+    unsigned long long o2[2] = {0, 0};
+    const int rc = attn_opt_counters(o2, reset);
+    if (rc) return rc;
+    out4[0] = o2[0];        // k_attn_optt workgroups re-run in GEN mode: complete graphs ...
+    out4[2] = o2[1];        // ... and adjacency-masked
     return 0;
 }
 

@@ -1,0 +1,416 @@
+// Optimistic-softmax block-diagonal attention on the matrix cores (bf16, Q PRE-SCALED by log2(e) / sqrt(C), 32-wide value
+// heads): one PyG TransformerConv attention (reference call sites backbones/Transformer_GNN.py:32,38;
+// backbones/exophormer_gnn.py:203,205) per launch, for
+//   k_attn_optt<32, false, false>   hidden layers on complete graphs (the class with the largest share of the sampling step)
+//   k_attn_optt<144, true, false>   the last layer on complete graphs, value heads folded with final_mlp.0
+//   k_attn_optt<32, false, true>    hidden layers of hybrid graphs (adjacency-masked: Exphander + exophormer, config 3)
+//   k_attn_optt<144, true, true>    their folded last layer
+// Same LDS image, DMA ring, fragment layouts and epilogues as k_attn_dense (da_attn_dense.hip; geometry in da_attn_common.h).
+// Written around what the round-3 measurements say bounds these kernels -- the SIMD's vector issue port (v_exp_f32 ~13-16
+// cycles, packs ~6.4, every MFMA ~12 cycles of the same port; DESIGN.md "Measured, round 3") -- and, for C = 144, the
+// register budget (the FAST mode of k_attn_dense keeps scores AND exponentials alive for its per-block fallback: 176 VGPRs,
+// two waves per SIMD where round 2 had three).  Per score only the exponential and the pack are left on that port:
+//   * OPTIMISTIC softmax: p = exp2(s) with no reference, no per-block test, in place.  fp32 / bf16 carry 8 exponent bits,
+//     so this is exact whenever the row sums stay inside [2^-60, 2^100]; that is VERIFIED once, after the last key block,
+//     on the final row sums (an overflow anywhere shows up there as inf / NaN, total underflow as 0).  A workgroup whose
+//     check fails -- logits beyond +-41 nat -- re-runs its tile with the classic running-max recurrence (same loop, `gen`
+//     switched on: row max, rescale, shift).  MASKED: a row sum of exactly 0 is legitimate when the row has no regular
+//     edge (the OR of its adjacency words says so); with edges it means total underflow and fails the check;
+//   * the row sums are eight v_dot2_f32_bf16 of the packed P against (1, 1) per block: they sum exactly the bf16 values the
+//     PV product weighs with, at half the instruction count of fp32 adds (row sums on the matrix pipe -- two more MFMAs per
+//     block against an all-ones operand -- measured slower: 113.6 vs 100.5 us per layer);
+//   * an optimistic pass normalises by 1 / sum, WITHOUT PyG's + 1e-16: the sum is un-shifted there (anything inside the
+//     window) while the reference adds its epsilon to sum exp(a - max) >= 1, where it is below fp32 resolution.  The GEN
+//     pass keeps its sum >= 1 and PyG's formula;
+//   * MASKED: the adjacency bits enter as the initial value of the S^T accumulator (0 / -inf from a 16-entry LDS table,
+//     k_attn_dense's scheme); exp2(-inf) = 0 needs no special case.  The lane's adjacency words travel through plain
+//     global loads issued as inline asm one tile ahead, so that the compiler's own s_waitcnt for them (a vmcnt(0) at the top
+//     of every tile, which serialised the K / V DMA ring of k_attn_dense<MASKED>) is replaced by the counted wait the ring
+//     uses anyway.  The state handed to the remainder-edge epilogue is re-referenced to (ln(sum), 1): rows normalised by
+//     their dense part, so the epilogue's own online softmax starts from a sum of 1 whatever the logits' offset.
+#include <stdlib.h>
+
+#include "da_attn_common.h"
+
+namespace da {
+
+// da_debug_counters: workgroups whose optimistic pass failed its verification ([0] complete graphs, [1] adjacency-masked)
+__device__ unsigned long long g_opt_fallbacks[2];
+
+template <int C, bool FOLD, bool MASKED, int NST, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
+    using T = bf16_t;
+    constexpr int CV = 32, NW = 4, QT = 128, NT = 256;
+    using CF = Cfg<T, C, CV>;
+    static_assert(CF::NCB == 1, "one 32-channel value block");
+    constexpr int MAXI = (CF::NI + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *flags = (int *)(smem + NST * CF::STAGE);               // one word per wave: "my optimistic pass failed"
+    float *mlut = (float *)(smem + NST * CF::STAGE + 64);       // MASKED: nibble -> four accumulator initial values
+    if (MASKED && threadIdx.x < 64) {
+        const int e = threadIdx.x >> 2, b = threadIdx.x & 3;
+        mlut[threadIdx.x] = ((e >> b) & 1) ? 0.f : -INFINITY;
+    }
+    // (visible to every wave after the first barrier of the tile loop)
+
+    // XCD-aware remap (as k_attn_dense): XCD x takes head x of every graph, the query tiles of one (graph, head) run back to back on it
+    const int bid = blockIdx.x;
+    const int h = bid & 7, s_ = bid >> 3;
+    const int qt = s_ % p.nqt, g = s_ / p.nqt;
+    const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
+    if (qt * QT >= n_g) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0 = qt * QT + wid * 32;
+    const bool wave_on = q0 < n_g;
+    const int HC = p.H * C;
+    const size_t np = (size_t)p.n_pad;
+
+    u32x4 qf[CF::NCH];
+    {
+        const unsigned char *qrow = (const unsigned char *)p.Q + ((size_t)h * np + pad0 + min(q0, n_g - 1) / 32 * 32 + i) * CF::ROWB;
+#pragma unroll
+        for (int ch = 0; ch < CF::NCH; ++ch) qf[ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
+    }
+    const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
+    const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWBV;
+    unsigned soff[MAXI];
+#pragma unroll
+    for (int x = 0; x < MAXI; ++x) {
+        const int q = wid + NW * x;
+        unsigned o = 0;
+        if (q < CF::NIK) {
+            const int s = q * 64 + lane, row = s / CF::KSPR, col = s - row * CF::KSPR;
+            if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
+        } else {
+            const int s = (q - CF::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
+            if (row < CF::BKEYS && col < CF::KVALIDV) o = (unsigned)(row * CF::ROWBV + col * 16);
+        }
+        soff[x] = o;
+    }
+    auto issue = [&](int kt, int stage) {
+        unsigned char *sb = smem + stage * CF::STAGE;
+        const unsigned char *kb_ = Kg + (size_t)kt * CF::BKEYS * CF::ROWB;
+        const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ROWBV;
+#pragma unroll
+        for (int x = 0; x < MAXI; ++x) {
+            const int q = wid + NW * x;
+            if (NW * x + NW - 1 < CF::NI || q < CF::NI) {
+                const unsigned char *src = (q < CF::NIK ? kb_ : vb_) + soff[x];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+    const int myn = (CF::NI - wid + NW - 1) / NW;             // DMA instructions this wave issues per tile
+    const int nkt = (n_g + CF::BKEYS - 1) / CF::BKEYS;
+    const int qidx = q0 + i;
+    const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);
+    const int koff = pi_i * CF::RS + half * 16;
+    const int li = lane & 15;
+    const int vbase = CF::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    // MASKED: this lane's row of the adjacency bit matrix (bit j = edge j -> this query); the 8 bytes of key tile kt sit at
+    // mrow + 8 kt (rows are 8-byte aligned: the padded slot count is a multiple of 64).  Remainder-edge metadata of the four
+    // queries this 8-lane group finishes in the epilogue.
+    const unsigned char *mrow = nullptr;
+    int rm_beg[4] = {0, 0, 0, 0}, rm_end[4] = {0, 0, 0, 0}, rm_slot[4] = {0, 0, 0, 0};
+    if (MASKED) {
+        mrow = p.mask + p.mask_ptr[g] + (size_t)min(qidx, n_g - 1) * (size_t)((p.pad_ptr[g + 1] - pad0) >> 3);
+        if (wave_on) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qg = qt * QT + wid * 32 + (lane >> 3) + 8 * r;
+                if (qg < n_g) {
+                    rm_beg[r] = p.irr_row_ptr[node0 + qg];
+                    rm_end[r] = p.irr_row_ptr[node0 + qg + 1];
+                }
+                rm_slot[r] = pad0;                                       // any valid slot when there is no edge
+                if (rm_end[r] > rm_beg[r]) rm_slot[r] = p.row_map[p.irr_col_src[rm_beg[r]]];
+            }
+        }
+    }
+    // adjacency words of one key tile, requested as inline asm (see the header): the destination is only valid after a
+    // counted wait that covers it
+    // ("+v": the loop-carried word keeps ONE register across the asm, so no copy of it can be scheduled before its wait)
+    auto mask_load = [&](u32x2 &r, int kt) {
+        asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(r) : "v"(mrow + 8 * (size_t)kt) : "memory");
+    };
+
+    f32x16 O;
+    float ls = 0.f;               // this lane's share of the row sum (16 of the block's 32 keys)
+    float m = 0.f;                // GEN mode only: running row max (log2 units)
+    unsigned anym = 0;            // MASKED: OR of this lane's adjacency words
+    bool gen = p.force_gen != 0;  // false: optimistic pass
+    for (int attempt = 0; attempt < 2; ++attempt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] = 0.f;
+        ls = 0.f;
+        m = -1e30f;
+        anym = 0;
+        if (MASKED && wave_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // remainder metadata landed: the counted waits below start from zero
+        // Order of this wave's VMEM operations: [M(0)] D(0) D(1) .. D(NST-2) | tile kt: [M(kt+1)] D(kt+NST-1).  MASKED waves
+        // wait for M(kt+1) at the top of tile kt + 1, i.e. for everything but D(kt+NST-1): one tile less in flight than the ring holds.
+        u32x2 mw_nxt = {0u, 0u};
+        if (MASKED && wave_on) mask_load(mw_nxt, 0);
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nkt) issue(st, st);
+        for (int kt = 0; kt < nkt; ++kt) {
+            {
+                // tiles that may stay in flight behind tile kt (each is `myn` operations of this wave; myn is LO or LO + 1)
+                int younger = min(nkt - 1 - kt, NST - 2);
+                // MASKED: M(kt) must have landed too, and the only operation behind it is D(kt + NST - 2), issued right after it
+                if (MASKED && wave_on && kt > 0) younger = (NST > 2 && kt + NST - 2 < nkt) ? 1 : 0;
+                constexpr int LO = CF::NI / NW;
+                if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (younger == 1) { if (myn == LO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO + 1) : "memory"); }
+                else if (younger == 2) { if (myn == LO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LO) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LO + 2) : "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (NST <= 4: not reached)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            u32x2 mw_cur = {0u, 0u};
+            if (MASKED && wave_on) {
+                mw_cur = mw_nxt;                                              // landed (covered by the wait above)
+                if (kt + 1 < nkt) mask_load(mw_nxt, kt + 1);
+            }
+            if (kt + NST - 1 < nkt) issue(kt + NST - 1, (kt + NST - 1) % NST);
+            if (!wave_on) continue;
+            const unsigned char *stg = smem + (kt % NST) * CF::STAGE;
+#pragma unroll
+            for (int kb = 0; kb < CF::KB; ++kb) {
+                const int key0 = kt * CF::BKEYS + kb * 32;
+                if (key0 >= n_g) break;
+                u32x4 kf[CF::NCH];
+#pragma unroll
+                for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + koff + kb * 32 * CF::RS + ch * 32);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 s;
+                if (MASKED) {
+                    const unsigned mw = (mw_cur[kb] >> (16 * half)) & 0xffffu;      // this lane's 16 keys of the block
+                    anym |= mw;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 b4 = *(const f32x4 *)((const unsigned char *)mlut + (((mw >> (4 * j)) & 15u) << 4));
+                        s[4 * j] = b4[0]; s[4 * j + 1] = b4[1]; s[4 * j + 2] = b4[2]; s[4 * j + 3] = b4[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                }
+#pragma unroll
+                for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), kf[ch], qf[ch], s);
+                u32x2 vlo[2], vhi[2];
+                const unsigned vb = lds0 + (unsigned)((kt % NST) * CF::STAGE + vbase + kb * 32 * CF::RSV);
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    vlo[mm] = tr_read(vb, (8 * mm) * CF::RSV);
+                    vhi[mm] = tr_read(vb, (8 * mm + 4) * CF::RSV);
+                }
+                if (!MASKED) {                      // MASKED: non-edges already sit at -inf (bits beyond n_g and on a missing diagonal are 0)
+                    const int kbase = key0 + 16 * half;
+                    const bool tail = key0 + 32 > n_g;
+                    const bool diag = p.nodiag && key0 < q0 + 32 && key0 + 32 > q0;
+                    if (tail || diag) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
+                    }
+                }
+                if (gen) {
+                    // classic recurrence: new reference = max(old, block max); state rescaled when it moves
+                    const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
+                    const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
+                    const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+                    const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
+                    const float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));      // >= -1e30: finite
+                    if (__any(mnew > m)) {
+                        const float corr = __builtin_amdgcn_exp2f(m - mnew);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[r] *= corr;
+                        ls *= corr;
+                        m = mnew;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] -= m;
+                }
+                bf16x8 pf0, pf1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {               // pair by pair, so that at most two exponentials wait for their pack
+                    const float x0 = __builtin_amdgcn_exp2f(s[2 * e]), x1 = __builtin_amdgcn_exp2f(s[2 * e + 1]);
+                    pf0[2 * e] = (__bf16)x0; pf0[2 * e + 1] = (__bf16)x1;
+                    const float y0 = __builtin_amdgcn_exp2f(s[8 + 2 * e]), y1 = __builtin_amdgcn_exp2f(s[8 + 2 * e + 1]);
+                    pf1[2 * e] = (__bf16)y0; pf1[2 * e + 1] = (__bf16)y1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]));
+                const u32x4 v0 = {vlo[0][0], vlo[0][1], vhi[0][0], vhi[0][1]};
+                const u32x4 v1 = {vlo[1][0], vlo[1][1], vhi[1][0], vhi[1][1]};
+                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O, 0, 0, 0);
+                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
+                {
+                    // row sum of the bf16-rounded p (what the PV product weighs with): eight v_dot2_f32_bf16 against (1, 1)
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                    const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16x2 pa = {pf0[2 * e], pf0[2 * e + 1]}, pb = {pf1[2 * e], pf1[2 * e + 1]};
+                        ls = __builtin_amdgcn_fdot2_f32_bf16(pa, one2, ls, false);
+                        ls = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, ls, false);
+                    }
+                }
+            }
+        }
+        if (gen) break;
+        // ---- verification of the optimistic pass (workgroup-uniform verdict: the waves share the K / V stream)
+        const float lt0 = ls + __shfl_xor(ls, 32);
+        bool ok = lt0 > 8.673617379884035e-19f && lt0 < 1.2676506002282294e30f;        // 2^-60, 2^100; NaN fails
+        if (MASKED) {
+            const unsigned had = anym | (unsigned)__shfl_xor((int)anym, 32);
+            ok = ok || (lt0 == 0.f && had == 0u);                                        // a row without regular edges
+        }
+        const bool bad = wave_on && __any(!ok && qidx < n_g);
+        dma_barrier();
+        if (lane == 0) flags[wid] = bad ? 1 : 0;
+        __syncthreads();
+        const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+        __syncthreads();
+        if (!redo) break;
+        gen = true;
+        if (tid == 0) atomicAdd(&g_opt_fallbacks[MASKED ? 1 : 0], 1ull);
+    }
+
+    // ---- epilogue
+    const float lt = ls + __shfl_xor(ls, 32);
+    const float inv = lt > 0.f ? 1.0f / (lt + ((gen && !MASKED) ? 1e-16f : 0.f)) : 0.f;      // (see the header: no epsilon on an un-shifted sum;
+                                                                                              //  MASKED rows are normalised again after their remainder edges)
+    if (FOLD && !MASKED) {
+        // folded value heads: CV-wide normalised rows per head, summed over heads by the tail kernel -- no skip, no
+        // activation, straight from the accumulator layout
+        if (wave_on && qidx < n_g) {
+            T *dst = (T *)p.fold_out + ((size_t)h * p.n_rows + node0 + qidx) * CV;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int c0 = 8 * jj + 4 * half;
+                const float v4[4] = {O[4 * jj] * inv, O[4 * jj + 1] * inv, O[4 * jj + 2] * inv, O[4 * jj + 3] * inv};
+                st4(dst + c0, v4);
+            }
+        }
+        return;
+    }
+    constexpr int CO = CV, RSOF = CO + 4;
+    static_assert(QT * RSOF * 4 <= NST * CF::STAGE, "O staging must fit in the K/V ring");
+    float *so = (float *)smem;
+    dma_barrier();
+    if (wave_on) {
+        float *orow = so + (wid * 32 + i) * RSOF;
+        if (MASKED && half == 0) {
+            // state for the remainder edges, re-referenced to (ln(sum), 1): reference in nat, rows already normalised by
+            // their dense part
+            orow[CO] = lt > 0.f ? (gen ? m : 0.f) * 0.6931471805599453f + __logf(lt) : 0.f;
+            orow[CO + 1] = lt > 0.f ? 1.0f : 0.f;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int c0 = 8 * jj + 4 * half;
+            *(f32x4 *)(orow + c0) = (f32x4){O[4 * jj] * inv, O[4 * jj + 1] * inv, O[4 * jj + 2] * inv, O[4 * jj + 3] * inv};
+        }
+    }
+    dma_barrier();
+    const int nq = min(QT, n_g - qt * QT);
+    if (MASKED) {
+        remainder_edges<T, CF, CO, RSOF>(p, so, h, np, pad0, n_g, qt * QT, wid, lane, wave_on, rm_beg, rm_end, rm_slot);
+        __syncthreads();
+    }
+    if (FOLD) {                   // MASKED + folded value heads: normalised per-head rows for the tail kernel
+        constexpr int CQ = CV / 4;
+        for (int it = tid; it < nq * CQ; it += NT) {
+            const int q = it / CQ, ch = it - q * CQ;
+            const float lr = so[q * RSOF + CO + 1];
+            const float ir = lr > 0.f ? 1.0f / (lr + 1e-16f) : 0.f;
+            const f32x4 a = *(const f32x4 *)(so + q * RSOF + ch * 4);
+            const float v4[4] = {a[0] * ir, a[1] * ir, a[2] * ir, a[3] * ir};
+            st4((T *)p.fold_out + ((size_t)h * p.n_rows + node0 + qt * QT + q) * CV + ch * 4, v4);
+        }
+        return;
+    }
+    constexpr int EPC = 8, CPR = C / EPC;
+    constexpr int NB = 3;
+    for (int it0 = tid; it0 < nq * CPR; it0 += NT * NB) {
+        u32x4 skv[NB], rsv[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int it = it0 + NT * k;
+            if (it < nq * CPR) {
+                const int q = it / CPR, ch = it - q * CPR;
+                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                skv[k] = *(const u32x4 *)((const T *)p.S + off);
+                if (p.res) rsv[k] = *(const u32x4 *)((const T *)p.res + off);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int it = it0 + NT * k;
+            if (it < nq * CPR) {
+                const int q = it / CPR, ch = it - q * CPR;
+                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                const float *src = so + q * RSOF + ch * EPC;
+                float v[EPC], sk[EPC];
+                const f32x4 a = *(const f32x4 *)src, b2 = *(const f32x4 *)(src + 4);
+                v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b2[0]; v[5] = b2[1]; v[6] = b2[2]; v[7] = b2[3];
+                if (MASKED) {                                     // rows carry the sum over dense part + remainder edges
+                    const float lr = so[q * RSOF + CO + 1];
+                    const float ir = lr > 0.f ? 1.0f / (lr + 1e-16f) : 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] *= ir;
+                }
+                unpack_chunk(T(), skv[k], sk);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+                if (p.res) {
+                    unpack_chunk(T(), rsv[k], sk);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] += sk[e];
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = apply_act(v[e], p.act);
+                stc((T *)p.out + off, v);
+            }
+        }
+    }
+}
+
+template <int C, bool FOLD, bool MASKED, int NST, int MINB>
+static int launch_optt(AttnDenseParams p, hipStream_t st) {
+    using CF = Cfg<bf16_t, C, 32>;
+    const int lds = NST * CF::STAGE + 64 + (MASKED ? 256 : 0);
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_optt<C, FOLD, MASKED, NST, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    p.nqt = (p.max_nodes + 127) / 128;
+    k_attn_optt<C, FOLD, MASKED, NST, MINB><<<p.nqt * p.H * p.n_graphs, 256, lds, st>>>(p);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// bf16, Q pre-scaled, heads of 32 value channels: C = 32 (hidden layers) or C = 144 with p.fold_out (folded last layer);
+// p.mask selects the adjacency-masked instances.  Returns 0 = launched, -1 = shape not covered.
+int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
+    const bool fold = p.fold_out != nullptr, masked = p.mask != nullptr;
+    if (C == 32 && !fold) return masked ? launch_optt<32, false, true, 4, 4>(p, st) : launch_optt<32, false, false, 4, 4>(p, st);
+    if (C == 144 && fold) return masked ? launch_optt<144, true, true, 2, 3>(p, st) : launch_optt<144, true, false, 2, 3>(p, st);
+    return -1;
+}
+
+int attn_opt_counters(unsigned long long *out2, int reset) {
+    DA_CHECK_HIP(hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_opt_fallbacks), 2 * sizeof(unsigned long long)));
+    if (reset) { const unsigned long long z[2] = {0, 0}; DA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_opt_fallbacks), z, sizeof(z))); }
+    return 0;
+}
+
+}  // namespace da
