@@ -291,14 +291,18 @@ class DenoiserEngine:
         pa, pb, n0 = split_complete(plan, plan.n_graphs // 2)
         c = x_init.shape[1]
         st = self._pair_state
-        key = (id(plan), c)
+        # keyed on the Batch's SHAPE (graph sizes), not on the plan object: the module re-plans every Batch (it releases the
+        # edge list after each loop), and a same-shaped Batch must find its half plans, workspaces, pose buffers and --
+        # through their addresses -- the cached two-branch hipGraph again
+        key = (plan._shape_sig, c)
         if st is None or st["key"] != key:
             need = [int(self.lib.da_denoiser_workspace_bytes(self.handle, C.byref(q.c_struct(False)))) for q in (pa, pb)]
             st = self._pair_state = {
-                "key": key, "plan": plan, "g": (pa.c_struct(False), pb.c_struct(False)),
+                "key": key, "halves": (pa, pb), "g": (pa.c_struct(False), pb.c_struct(False)),
                 "ws": tuple(torch.empty(nb, dtype=torch.uint8, device=self.device) for nb in need),
                 "xi": torch.empty((plan.n_real, c), dtype=torch.float32, device=self.device),
                 "xf": torch.empty((plan.n_real, c), dtype=torch.float32, device=self.device), "staged": None}
+        pa, pb = st["halves"]                      # (the cached graph reads THESE plans' device arrays)
         fkey = None if feats is None else (feats.data_ptr(), feats._version, tuple(feats.shape))
         if restage or st["staged"] is None or (fkey is not None and st["staged"] != fkey):
             f = _f32(feats, self.device)

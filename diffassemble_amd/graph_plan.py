@@ -157,6 +157,7 @@ def split_complete(plan: GraphPlan, g_split: int):
             row_map=(plan.row_map[n0:n1] - p0).contiguous(), _edge_index=None))
     out = (halves[0], halves[1], gph[g_split])
     plan._halves = (g_split, out)
+    plan._shape_sig = (plan.dense, tuple(gph))          # host-side signature of the Batch's shape (two-branch loop cache)
     return out
 
 

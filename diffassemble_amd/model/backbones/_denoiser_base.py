@@ -94,6 +94,11 @@ class DenoiserBase(nn.Module):
             # the engine keeps the plan object alive for its cached hipGraph (device arrays of the plan), so the edge list has to
             # leave the plan itself; nothing reads it again (alpha is only returned by the per-step path, which plans afresh)
             plan._edge_index = None
+
+            def _gone():
+                raise RuntimeError("this GraphPlan's edge list was released after its sampling loop (complete graphs do not "
+                                   "need it); plan the Batch again to get attention weights / a CSR")
+            plan.edge_index_fn = _gone
             self._plan_key = self._feat_key = None
             self._plan = None
 

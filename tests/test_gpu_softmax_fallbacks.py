@@ -121,24 +121,29 @@ def run_layer(dev, sizes, loops, C, folded, prec, x, ws, bs):
 
 
 def offsets_for(kind, sizes):
-    """(row offsets [N], key outliers [N] or None, must_fall_back) in log2 units; integers, multiples of 1/8 after the / 8."""
+    """(row offsets [N], key outliers [N] or None, who must fall back) in log2 units (integers: multiples of 1/8 after
+    the / 8 of the carrier features).  "all": every shift-free kernel; "fast": only the kernels with a per-block test
+    (k_attn_dense FAST, k_attn_dual) -- the optimistic kernels judge the FINAL row sums, which stay inside their window
+    there; "none": nobody."""
     N = sum(sizes)
-    row, key = torch.zeros(N), None
+    row, key, who = torch.zeros(N), None, "all"
     if kind == "m44":                      # -30.5 nat: inside every window
         row[:] = -44.0
+        who = "none"
     elif kind == "m55":                    # -38.1 nat: inside the windows, where + 1e-16 on the raw sum was 2e-3 off
         row[:] = -55.0
-    elif kind == "m65":                    # -45.1 nat: sums below 2^-60 -> fallback everywhere
-        row[:] = -65.0
+        who = "none"
+    elif kind == "m80":                    # -55 nat: sums far below 2^-60 -> fallback everywhere
+        row[:] = -80.0
     elif kind == "p110":                   # +76 nat on every logit: sums above 2^100 -> fallback everywhere
         row[:] = 110.0
-    elif kind == "one_wave":               # queries 32..63 of every graph (one wave of the first query tile) at -65
+    elif kind == "one_wave":               # queries 32..63 of every graph (one wave of the first query tile) at -80
         o = 0
         for n in sizes:
-            row[o + 32:o + min(n, 64)] = -65.0
+            row[o + 32:o + min(n, 64)] = -80.0
             o += n
-    elif kind == "mixed":                  # neighbouring queries at -65 / 0 / +110: both failures inside one wave
-        row[0::3] = -65.0
+    elif kind == "mixed":                  # neighbouring queries at -80 / 0 / +110: both failures inside one wave
+        row[0::3] = -80.0
         row[1::3] = 110.0
     elif kind == "late_outlier":           # one key near the END of every graph at +115 (~ +80 nat): the overflow arrives
         key = torch.zeros(N)               # after FAST mode accumulated a healthy state (hand-off with l > 0)
@@ -146,19 +151,20 @@ def offsets_for(kind, sizes):
         for n in sizes:
             key[o + (n * 7) // 8] = 115.0
             o += n
-    elif kind == "late_outlier_after_underflow":   # rows at -55 whose last keys sit at +115
-        row[:] = -55.0
-        key = torch.zeros(N)
+    elif kind == "late_outlier_after_small_sums":   # rows at -55 (tiny but accepted sums) whose LAST key sits at +115: a
+        row[:] = -55.0                              # per-block test hands a state with a very negative reference over;
+        key = torch.zeros(N)                        # the final sums (~2^60) are inside the optimistic window
+        who = "fast"
         o = 0
         for n in sizes:
             key[o + n - 1] = 115.0
             o += n
     else:
         raise ValueError(kind)
-    return row, key, kind not in ("m44", "m55")
+    return row, key, who
 
 
-KINDS = ["m44", "m55", "m65", "p110", "one_wave", "mixed", "late_outlier", "late_outlier_after_underflow"]
+KINDS = ["m44", "m55", "m80", "p110", "one_wave", "mixed", "late_outlier", "late_outlier_after_small_sums"]
 SHAPES = [
     # C, folded
     pytest.param(32, False, id="c32"),
@@ -167,9 +173,15 @@ SHAPES = [
 ]
 
 
+def optimistic_kernel(C, folded, prec):
+    """Which family takes the layer by default: the optimistic kernels (da_attn_opt.hip: bf16, C = 32 or the folded
+    C = 144) or k_attn_dense's FAST mode (fp32, un-folded C = 144); DA_ATTN_DUAL=1 moves the folded bf16 layer to k_attn_dual."""
+    return prec == "bf16" and (C == 32 or folded) and not (folded and os.environ.get("DA_ATTN_DUAL") == "1")
+
+
 def _case(dev, sizes, loops, C, folded, prec, kind, seed=0):
     bf16 = prec == "bf16"
-    row, key, must_fall_back = offsets_for(kind, sizes)
+    row, key, who = offsets_for(kind, sizes)
     x, ws, bs = build_layer(sizes, C, folded, seed, row, key, bf16)
     ref = reference(x, ws, bs, sizes, loops, C, folded, bf16)
     out, cnt = run_layer(dev, sizes, loops, C, folded, prec, x, ws, bs)
@@ -178,15 +190,16 @@ def _case(dev, sizes, loops, C, folded, prec, kind, seed=0):
     err = rel(out, ref)
     assert err < tol, (kind, prec, err)
     fell = sum(cnt.values())
-    if must_fall_back:
-        assert fell > 0, (kind, cnt)              # the branch under test really ran
+    opt = optimistic_kernel(C, folded, prec)
+    if who == "all" or (who == "fast" and not opt):
+        assert fell > 0, (kind, cnt)              # the branch under test really ran ...
+        assert cnt["opt_gen_workgroups" if opt else ("dual_gen_slabs" if os.environ.get("DA_ATTN_DUAL") == "1" and folded and bf16
+                                                     else "dense_fast_exits")] > 0, (kind, cnt)      # ... in the kernel it was aimed at
     else:
         # ... and the common path does not take it.  (k_attn_dense's per-block test looks at each LANE's 16 keys of a block:
         # in graphs of <= 16 pieces the upper half-lanes see only masked keys, a partial sum of 0, and the wave -- one per
         # head -- leaves FAST mode; harmless, and not the benched shape.)
         assert fell <= 8 * sum(1 for n in sizes if n <= 16), (kind, cnt)
-    if os.environ.get("DA_TEST_EXPECT_DUAL") == "1" and must_fall_back and sum(sizes) > 64:
-        assert cnt["dual_gen_slabs"] > 0, cnt     # (test_dual_slab_kernel_fallbacks_subprocess: the dual kernel took the layer)
     return out, cnt
 
 
@@ -198,7 +211,7 @@ def test_logit_offsets_ragged_batch(dev, C, folded, prec, kind):
     _case(dev, [130, 37, 64, 1, 200], True, C, folded, prec, kind)
 
 
-@pytest.mark.parametrize("kind", ["m55", "m65", "one_wave", "late_outlier"])
+@pytest.mark.parametrize("kind", ["m55", "m80", "one_wave", "late_outlier"])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("C,folded", SHAPES)
 def test_logit_offsets_without_self_loops(dev, C, folded, prec, kind):
@@ -207,7 +220,7 @@ def test_logit_offsets_without_self_loops(dev, C, folded, prec, kind):
     _case(dev, [70, 1, 2, 129], False, C, folded, prec, kind)
 
 
-@pytest.mark.parametrize("kind", ["m55", "m65", "one_wave", "late_outlier", "p110"])
+@pytest.mark.parametrize("kind", ["m55", "m80", "one_wave", "late_outlier", "p110"])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("C,folded", [pytest.param(32, False, id="c32"), pytest.param(144, True, id="c144_folded")])
 def test_logit_offsets_900_pieces(dev, C, folded, prec, kind):
@@ -229,6 +242,76 @@ def test_optimistic_path_is_offset_invariant_bit_for_bit(dev, C, folded):
         assert sum(cnt.values()) <= 8, cnt          # (the 1-piece graph: see _case)
         outs.append(out)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def hybrid_graph(sizes, seed):
+    """Random in-graph edges (each ordered pair with probability 1/2, self loops included), a node without any incoming
+    edge per graph, and duplicated pairs (both copies leave the adjacency mask and travel as remainder edges)."""
+    g = torch.Generator().manual_seed(seed)
+    eis, o = [], 0
+    for n in sizes:
+        a = torch.rand(n, n, generator=g) < 0.5                       # a[i, j]: edge j -> i
+        a[n // 2, :] = False                                          # this target has no regular edge at all
+        if n > 3:
+            a[1, :] = False                                           # ... and this one only gets duplicated (remainder) edges
+        dst, src = a.nonzero(as_tuple=True)
+        ei = torch.stack([src, dst])
+        dup = ei[:, torch.randperm(ei.shape[1], generator=g)[: max(1, n // 4)]]
+        extra = torch.tensor([[0, min(2, n - 1)], [min(1, n - 1), min(1, n - 1)]])   # edges 0 -> 1 and 2 -> 1, each twice
+        eis.append(torch.cat([ei, dup, dup, extra, extra], 1) + o)
+        o += n
+    return torch.cat(eis, 1), torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+
+
+def reference_edges(x, ws, bs, ei, C, folded, bf16):
+    """fp64 PyG TransformerConv on an edge list (multi-edges count twice): alpha_e = exp(a_e - max_i) / (sum_i + 1e-16)."""
+    xd = x.double()
+    N = x.shape[0]
+    q, k, v = [xd @ w_.double().T + b_.double() for w_, b_ in zip(ws[:3], bs[:3])]
+    if bf16:
+        q, k, v = [t.float().bfloat16().double() for t in (q, k, v)]
+    cv = 32 if folded else C
+    src, dst = ei[0], ei[1]
+    a = (q.view(N, H, C)[dst] * k.view(N, H, C)[src]).sum(-1) * math.log(2.0)          # [E, H]
+    m = torch.full((N, H), float("-inf"), dtype=torch.float64).scatter_reduce(0, dst[:, None].expand(-1, H), a, "amax")
+    e = torch.exp(a - m[dst])
+    den = torch.zeros(N, H, dtype=torch.float64).index_add_(0, dst, e) + 1e-16
+    out = torch.zeros(N, H, cv, dtype=torch.float64).index_add_(0, dst, (e / den[dst])[:, :, None] * v.view(N, H, cv)[src])
+    if folded:
+        return out.permute(1, 0, 2).contiguous()
+    skip = xd @ ws[3].double().T + bs[3].double()
+    if bf16:
+        skip = skip.float().bfloat16().double()
+    return out.reshape(N, H * C) + skip
+
+
+@pytest.mark.parametrize("kind", ["m44", "m55", "m80", "p110", "mixed", "one_wave"])
+@pytest.mark.parametrize("C,folded", [pytest.param(32, False, id="c32"), pytest.param(144, True, id="c144_folded")])
+def test_logit_offsets_hybrid_graphs_masked_optimistic_kernel(dev, C, folded, kind):
+    """k_attn_optt<MASKED> (bf16 hybrid graphs: adjacency-masked regular edges + remainder edges in the epilogue, the path of
+    the Exphander / exophormer configuration): rows without any regular edge (sum 0 is legitimate there), rows fed by
+    duplicated edges only, all under the logit offsets; fallback = a workgroup re-run with the running-max recurrence."""
+    from diffassemble_amd import engine as E
+    from diffassemble_amd.graph_plan import build_plan
+    sizes = [130, 70, 200]
+    row, key, who = offsets_for(kind, sizes)
+    x, ws, bs = build_layer(sizes, C, folded, 5, row, key, True)
+    ei, batch = hybrid_graph(sizes, 7)
+    ref = reference_edges(x, ws, bs, ei, C, folded, True)
+    plan = build_plan(ei.to(dev), batch.to(dev), 0, hybrid="force")
+    assert plan.hybrid == 1
+    E.debug_counters(reset=True)
+    out = E.conv_dense_ex(plan, x.to(dev), torch.cat(ws).to(dev), torch.cat(bs).to(dev), H, C, None, 0, "bf16",
+                          prescale_q="done", folded=folded)
+    torch.cuda.synchronize()
+    cnt = E.debug_counters(reset=True)
+    out = out.float().cpu()
+    assert torch.isfinite(out).all()
+    assert rel(out, ref) < 1e-2, (kind, rel(out, ref))
+    if who == "all":
+        assert cnt["opt_masked_gen_workgroups"] > 0, cnt
+    else:
+        assert sum(cnt.values()) == 0, cnt
 
 
 def test_force_gen_switch_runs_the_fixture_suite_through_the_fallbacks_subprocess():
