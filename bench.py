@@ -323,6 +323,9 @@ def train_bench(args, world, rank, dev):
     else:
         ei, batch = dense_batch(G, n, dev)
     te = m.model.train_engine(dev)
+    # --precision bf16: the denoiser's matrix-core GEMMs take bf16 operands (fp32 storage and accumulation,
+    # TrainEngine.precision / DA_TRAIN_MMA_BF16); fp32 = exact products, the mode of the reference's gradient fixtures
+    te.precision = args.precision or "fp32"
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     acc = [0.0, 0.0, 0.0]
 
@@ -369,9 +372,10 @@ def train_bench(args, world, rank, dev):
         # 3 x the forward's (backward = dX and dW products of every forward product) over the HIP-event time of
         # that phase; the encoder (--pixels) is outside this count
         fb_s = acc[0] / kp * 1e-3
-        roof = {"bound": "mfma", "kernel": "forward + backward (fp32 MFMA linears, grouped attention GEMMs, dW GEMMs)",
-                "achieved": 3 * flop_fwd / fb_s / 1e12, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
-                "frac": 3 * flop_fwd / fb_s / 1e12 / PEAK_TFLOPS["fp32"], "traffic": None,
+        tp = te.precision
+        roof = {"bound": "mfma", "kernel": f"forward + backward ({'bf16-operand' if tp == 'bf16' else 'fp32'} MFMA linears, grouped attention GEMMs, dW GEMMs)",
+                "achieved": 3 * flop_fwd / fb_s / 1e12, "peak": PEAK_TFLOPS[tp], "unit": "TFLOP/s",
+                "frac": 3 * flop_fwd / fb_s / 1e12 / PEAK_TFLOPS[tp], "traffic": None,
                 "phase_share": {"forward+backward": acc[0] / sum(acc), "gradient_allreduce": acc[1] / sum(acc), "optimizer": acc[2] / sum(acc)},
                 "note": "denoiser FLOP only" + (" (the encoder's convolutions run in the same phase and are not counted)" if pixels else "")}
         cpu = None
@@ -406,7 +410,8 @@ def train_bench(args, world, rank, dev):
                       f"training steps/sec ({side}x{side} rot, {'exophormer V=8, Exphander d=' + str(degree) if exo else 'dense'}, Huber, Adafactor)",
             "value": world * G * K / dt, "unit": "puzzle-train-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32" if not (pixels and args.precision == "bf16") else "bf16 encoder maps + fp32 denoiser", "data": "synthetic",
+            "dtype": ("fp32" if te.precision != "bf16" else "bf16 MFMA operands (fp32 storage, fp32 accumulation)") + (" + bf16 encoder maps" if (pixels and args.precision == "bf16") else ""),
+            "data": "synthetic",
             "config": {"workload": ("BASELINE config 5: 12x12 rot dense (N=144, E=20736), G per GPU below, huber, EPSILON, one Adafactor step; "
                                     if (side == 12 and not exo) else
                                     f"training step, {side}x{side} rot puzzles (N={n}), " + (f"exophormer arch with 8 virtual nodes on Exphander graphs of degree {degree} "

@@ -20,6 +20,7 @@ ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
 MEAN_EPSILON, MEAN_START_X = 0, 1
 ACT_NONE, ACT_GELU, ACT_LEAKY02 = 0, 1, 2
 CONV_Q_PRESCALED, CONV_FOLDED_V32 = 1, 2
+TRAIN_MMA_FP32, TRAIN_MMA_BF16 = 0, 1
 DBG_COUNTERS = ("opt_gen_workgroups", "dense_fast_exits", "dual_gen_slabs", "opt_masked_gen_workgroups")
 PROF_CLASSES = ("embed", "linear_mlp", "linear_qkvs", "attn_hidden", "attn_last", "head", "update", "conv_fused")
 
@@ -134,6 +135,9 @@ PROTOTYPES = {
     "da_debug_counters": (C.c_int, [C.POINTER(C.c_int64), C.c_int, C.c_int]),
     "da_train_workspace_bytes": (C.c_size_t, [C.POINTER(DaWeights), C.POINTER(DaGraph)]),
     "da_train_forward": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "da_train_forward_ex": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
+    "da_train_backward_ex": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp,
+                                       _fp, C.c_size_t, C.c_int, _fp]),
     "da_adafactor_step": (C.c_int, [C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_float,
                                     C.c_float, C.c_float, C.c_float, _fp]),
     "da_greedy_assign": (C.c_int, [C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),

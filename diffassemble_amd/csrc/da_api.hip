@@ -208,7 +208,7 @@ int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void 
         const int rc = launch_gemm_mfma(prec, M, K, Nout, A, lda, W, bias, act, res, out, ldo, nullptr, st);
         if (rc >= 0) return rc;
     }
-    return launch_gemm_simple(prec, M, K, Nout, A, lda, W, bias, act, res, out, ldo, st);
+    return launch_gemm_simple(prec == DA_PREC_F32_BF16MMA ? DA_PREC_F32 : prec, M, K, Nout, A, lda, W, bias, act, res, out, ldo, st);
 }
 
 static bool dense_disabled() {

@@ -106,6 +106,9 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
     }
 }
 
+// internal precision code of the training path's DA_TRAIN_MMA_BF16 mode: fp32 STORAGE everywhere (esize = 4), GEMM operands
+// rounded to bf16 on their way into the matrix cores, fp32 accumulation (da_gemm_common.h Mma16<float, true>)
+#define DA_PREC_F32_BF16MMA 2
 inline size_t esize(int prec) { return prec == DA_PREC_BF16 ? 2 : 4; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -10,13 +10,27 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
-template <typename T> struct Mma16;
-template <> struct Mma16<bf16_t> {
+// BFC ("bf16 compute", T = float only): fp32 operands in memory and LDS, rounded to bf16 (RNE) in registers on their way
+// into the matrix core, fp32 accumulation -- the training path's DA_TRAIN_MMA_BF16 mode (da_train.hip).  The lane's four
+// consecutive fp32 K-values are exactly the four K-slots lane group (lane >> 4) feeds v_mfma_f32_16x16x16_bf16: one MFMA
+// (16 cycles) + four packs replace four exact-fp32 16x16x4 MFMAs (128 cycles).
+template <typename T, bool BFC = false> struct Mma16;
+template <> struct Mma16<float, true> {
+    static __device__ __forceinline__ f32x4 run(const u32x4 &x, const u32x4 &y, f32x4 c) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+        typedef __attribute__((ext_vector_type(4))) short s16x4_;
+        const f32x4 a = __builtin_bit_cast(f32x4, x), b = __builtin_bit_cast(f32x4, y);
+        const bf16x4_ ab = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+        const bf16x4_ bb = {(__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_, ab), __builtin_bit_cast(s16x4_, bb), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<bf16_t, false> {
     static __device__ __forceinline__ f32x4 run(const u32x4 &x, const u32x4 &y, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
     }
 };
-template <> struct Mma16<float> {
+template <> struct Mma16<float, false> {
     static __device__ __forceinline__ f32x4 run(const u32x4 &x, const u32x4 &y, f32x4 c) {
         const f32x4 a = __builtin_bit_cast(f32x4, x), b = __builtin_bit_cast(f32x4, y);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
@@ -47,7 +61,7 @@ __device__ __forceinline__ void load4(const bf16_t *src, float v[4]) {
 // One K stage (128 bytes of K) of the 128 x 128 tile: A and W tiles share one LDS layout (128 rows x 128 B, 16-byte
 // chunks XOR-swizzled by row & 7); waves 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles.  Used by the linear kernel
 // (da_gemm_mfma.hip) and the implicit-GEMM group convolution (da_encoder.hip).
-template <typename T>
+template <typename T, bool BFC = false>
 __device__ __forceinline__ void mma_block(const unsigned char *sA, const unsigned char *sW, int wm, int wn, int lane,
                                           f32x4 (&acc)[4][4]) {
 #pragma unroll
@@ -65,7 +79,7 @@ __device__ __forceinline__ void mma_block(const unsigned char *sA, const unsigne
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = Mma16<T>::run(fw[ni], fa[mi], acc[mi][ni]);    // a lane owns one row, 4 consecutive features
+                acc[mi][ni] = Mma16<T, BFC>::run(fw[ni], fa[mi], acc[mi][ni]);    // a lane owns one row, 4 consecutive features
     }
 }
 

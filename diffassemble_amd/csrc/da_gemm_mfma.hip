@@ -113,7 +113,7 @@ __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (
     }
 }
 
-template <typename T, bool QKV, int ACT>
+template <typename T, bool QKV, int ACT, bool BFC = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     // two stages x (A tile 16 KB + W tile 16 KB), filled by LDS-DMA (global_load_lds_dwordx4).  A
     // workgroup owns one 128-row tile of A and walks `nt` consecutive 128-column tiles of W as ONE
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
             dma_barrier();                   // own DMA landed (vmcnt(0)) + everyone done with the other slot
             if (s + 1 < S && !(p.debug & 4)) issue(s + 1);
             const unsigned char *sA = smem + (s & 1) * 32768;
-            if (!(p.debug & 2)) mma_block<T>(sA, sA + 16384, wm, wn, lane, acc);
+            if (!(p.debug & 2)) mma_block<T, BFC>(sA, sA + 16384, wm, wn, lane, acc);
         }
 
         // -------------------------------------------------------------- epilogue of this column tile
@@ -229,6 +229,9 @@ int launch_gemm_xpanel(int prec, const GemmParams &p0, const QkvScatter *qs, int
 int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
                      int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st, int ldw,
                      const void *pre, const void *wpacked) {
+    // DA_PREC_F32_BF16MMA (training): fp32 storage, operands rounded to bf16 inside the matrix-core kernel (Mma16<float, true>)
+    const bool bfc = prec == DA_PREC_F32_BF16MMA;
+    if (bfc && (qs || act != DA_ACT_NONE || pre)) return -1;
     const int es = (int)esize(prec), BK = 128 / es;
     if (M <= 0 || Nout <= 0) return 0;
     if (ldw <= 0) ldw = K;
@@ -253,7 +256,7 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     } else if (((size_t)ldo * es) % 16 != 0 || !aligned16(out) || (res && !aligned16(res))) {
         return -1;
     }
-    {   // short reductions: A-stationary kernel (da_gemm_astat.hip)
+    if (!bfc) {   // short reductions: A-stationary kernel (da_gemm_astat.hip)
         static int off = -1;
         if (off < 0) { const char *e = getenv("DA_DISABLE_ASTAT"); off = (e && e[0] == '1') ? 1 : 0; }
         if (K * es <= 512 && wpacked) {
@@ -301,6 +304,7 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     if (!qs) {
         const dim3 grid = plan2((Nout + 127) / 128);
         if (prec == DA_PREC_BF16) DA_GEMM_ACT(bf16_t, grid);
+        else if (bfc) k_gemm_mfma<float, false, DA_ACT_NONE, true><<<grid, 256, 0, st>>>(p);
         else DA_GEMM_ACT(float, grid);
     } else {
         const dim3 g = plan2(Nout / 128);                        // Q | K | V (| skip) column blocks, one launch

@@ -57,7 +57,7 @@ int launch_convert(int prec, size_t n, const float *src, void *dst, hipStream_t 
 int launch_transpose_f32(int rows, int cols, const float *src, float *dst, hipStream_t st);      // da_train.hip
 // C (+)= A^T B over rows (A [M, N], B [M, K] row-major; split-row partials through `partial`, >= 16 M floats)
 int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, float *partial,
-                   hipStream_t st);
+                   hipStream_t st, bool bfc = false);      // bfc: operands rounded to bf16 inside the kernel (DA_TRAIN_MMA_BF16)
 int launch_gemm_tn_bf16(int M, int N, int K, const bf16_t *A, int lda, const bf16_t *B, int ldb, float *C, int ldc, float *partial,
                         hipStream_t st);
 int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch, hipStream_t st);   // out[c] += sum_m A[m][c]

@@ -96,6 +96,11 @@ __device__ __forceinline__ f32x4 load_row4(const float *base, int ld, int row, i
     return v;
 }
 
+// BFC: the fp32 tiles are rounded to bf16 in registers and multiplied with v_mfma_f32_16x16x16_bf16 (one MFMA per 16-row
+// stage and tile pair instead of four exact-fp32 ones; training's DA_TRAIN_MMA_BF16 mode); lane group g = lane >> 4 takes the
+// stage rows g, g + 4, g + 8, g + 12 (any assignment works as long as both operands use it: rows one apart keep the four
+// groups on different banks)
+template <bool BFC>
 __global__ __launch_bounds__(256) void k_gemm_tn(int M, int N, int K, const float *__restrict__ A, int lda,
                                                  const float *__restrict__ B, int ldb, float *C, int ldc,
                                                  float *partial, int Mc) {
@@ -122,6 +127,26 @@ __global__ __launch_bounds__(256) void k_gemm_tn(int M, int N, int K, const floa
             ra = load_row4(A, lda, m0 + 16 + lrow, n0 + lc4, m_end, N, vecA);
             rb = load_row4(B, ldb, m0 + 16 + lrow, k0 + lc4, m_end, K, vecB);
         }
+        if (BFC) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+            typedef __attribute__((ext_vector_type(4))) short s16x4_;
+            s16x4_ a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bf16x4_ ta, tb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ta[e] = (__bf16)As[(4 * e + (lane >> 4)) * LS + wr * 32 + i * 16 + (lane & 15)];
+                    tb[e] = (__bf16)Bs[(4 * e + (lane >> 4)) * LS + wc * 32 + i * 16 + (lane & 15)];
+                }
+                a[i] = __builtin_bit_cast(s16x4_, ta);
+                b[i] = __builtin_bit_cast(s16x4_, tb);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 4) {
             float a[2], b[2];
@@ -134,6 +159,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(int M, int N, int K, const floa
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
         }
         __syncthreads();
     }
@@ -177,7 +203,7 @@ __global__ __launch_bounds__(256) void k_reduce_partial(int splits, int N, int K
 constexpr size_t PART_CAP = (size_t)16 << 20;        // floats of split-reduction scratch (64 MB)
 
 int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
-                          float *partial, hipStream_t st) {
+                          float *partial, hipStream_t st, bool bfc) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int tn = (N + 63) / 64, tk = (K + 63) / 64;
     long splits = 2048 / ((long)tn * tk);
@@ -189,9 +215,11 @@ int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B,
     splits = (M + Mc - 1) / Mc;
     const dim3 grid((unsigned)tk, (unsigned)tn, (unsigned)splits);
     if (splits == 1) {
-        k_gemm_tn<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, nullptr, Mc);
+        if (bfc) k_gemm_tn<true><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, nullptr, Mc);
+        else k_gemm_tn<false><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, nullptr, Mc);
     } else {
-        k_gemm_tn<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, partial, Mc);
+        if (bfc) k_gemm_tn<true><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, partial, Mc);
+        else k_gemm_tn<false><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, partial, Mc);
         const size_t NK = (size_t)N * K;
         k_reduce_partial<<<(unsigned)((NK + 255) / 256 > 4096 ? 4096 : (NK + 255) / 256), 256, 0, st>>>((int)splits, N, K, partial, C, ldc);
     }
@@ -483,14 +511,14 @@ __global__ __launch_bounds__(256) void k_virt_grad(int rows, int V, int D, const
 size_t dense_pair_floats(const da_graph *g, int H);
 int dense_train_prepare(const da_graph *g, int H, long long *poff, int32_t *node_graph, hipStream_t st);
 int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P,
-                         const long long *poff, const int32_t *node_graph, hipStream_t st);
+                         const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc);
 int dense_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
-                         float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st);
+                         float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc);
 // hybrid graphs (adjacency-masked grouped GEMMs over the regular edges + CSR remainder, one softmax over both)
 int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P, float *stats,
-                          const long long *poff, const int32_t *node_graph, hipStream_t st);
+                          const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc);
 int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
-                          const float *stats, float *Dd, float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st);
+                          const float *stats, float *Dd, float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc);
 
 static bool train_dense_disabled() {
     static int v = -1;
@@ -518,10 +546,12 @@ struct Dims {
     bool gelu_between;
     bool dense;                // complete graphs: grouped-GEMM attention (da_train_dense.hip)
     bool hybrid;               // hybrid graphs: masked grouped GEMMs + CSR remainder (da_train_dense.hip)
+    bool bfc;                  // DA_TRAIN_MMA_BF16: GEMM operands rounded to bf16 inside the matrix-core kernels (storage stays fp32)
     size_t pair_floats;
 };
 
-static int dims_of(const da_weights *w, const da_graph *g, Dims &d) {
+static int dims_of(const da_weights *w, const da_graph *g, Dims &d, int mma = DA_TRAIN_MMA_FP32) {
+    d.bfc = mma == DA_TRAIN_MMA_BF16;
     DA_REQUIRE(w && g, "training: null argument");
     DA_REQUIRE(w->variant == DA_VARIANT_2D, "training: only the 2D denoiser is implemented");
     DA_REQUIRE(w->heads == 8 && w->n_layers >= 2 && w->n_layers <= DA_MAX_LAYERS, "training: bad heads / n_layers");
@@ -636,13 +666,13 @@ int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch
 
 // Linear backward: dW += dY^T X, db += colsum(dY), and (if dX) dX = dY @ W (+ res)
 static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, const float *W,
-                      float *dW, float *db, float *dX, int lddx, const float *res, TrainWs &ws, hipStream_t st) {
+                      float *dW, float *db, float *dX, int lddx, const float *res, TrainWs &ws, hipStream_t st, bool bfc) {
     int rc;
-    if ((rc = launch_gemm_tn(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, st))) return rc;
+    if ((rc = launch_gemm_tn(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, st, bfc))) return rc;
     if (db && (rc = colsum_add(M, N, dY, ldy, db, ws.csum, st))) return rc;
     if (dX) {
         if ((rc = launch_transpose_f32(N, K, W, ws.wt, st))) return rc;                      // W [N, K] -> W^T [K, N]
-        if ((rc = linear(DA_PREC_F32, M, N, K, dY, ldy, ws.wt, nullptr, DA_ACT_NONE, res, dX, lddx, st))) return rc;
+        if ((rc = linear(bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32, M, N, K, dY, ldy, ws.wt, nullptr, DA_ACT_NONE, res, dX, lddx, st))) return rc;
     }
     return 0;
 }
@@ -661,21 +691,28 @@ size_t da_train_workspace_bytes(const da_weights *w, const da_graph *g) {
 
 int da_train_forward(const da_weights *w, const da_graph *g, const float *x, const int64_t *t, const float *feats,
                      float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    return da_train_forward_ex(w, g, x, t, feats, out, workspace, workspace_bytes, DA_TRAIN_MMA_FP32, stream);
+}
+
+int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, const int64_t *t, const float *feats,
+                        float *out, void *workspace, size_t workspace_bytes, int mma_precision, void *stream) {
     Dims d;
     int rc;
-    if ((rc = dims_of(w, g, d))) return rc;
+    DA_REQUIRE(mma_precision == DA_TRAIN_MMA_FP32 || mma_precision == DA_TRAIN_MMA_BF16, "da_train_forward: unknown mma_precision %d", mma_precision);
+    if ((rc = dims_of(w, g, d, mma_precision))) return rc;
     DA_REQUIRE(x && t && feats && out && workspace, "da_train_forward: null argument");
     if ((rc = check_fused(w, d, "da_train_forward"))) return rc;
     TrainWs ws = carve_train(d, workspace);
     DA_REQUIRE(workspace_bytes >= ws.total, "training workspace too small: %zu < %zu", workspace_bytes, ws.total);
     hipStream_t st = (hipStream_t)stream;
     const int P = DA_PREC_F32, nr = d.nr, n = d.n, D = d.D;
+    const int PL = d.bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32;          // precision code of the linear layers (storage is fp32 either way)
     if ((rc = launch_set_feats(P, nr, d.F, D, feats, ws.comb_in, st))) return rc;
     if ((rc = launch_embed_pos_time(P, nr, d.c_in, d.F, D, x, t, 0, w->steps, w->time_emb, w->pos_w0, w->pos_b0, w->pos_w1,
                                     w->pos_b1, ws.comb_in, st))) return rc;
-    if ((rc = linear(P, nr, D, d.hid, ws.comb_in, D, w->mlp_w0, w->mlp_b0, DA_ACT_NONE, nullptr, ws.m1pre, d.hid, st))) return rc;
+    if ((rc = linear(PL, nr, D, d.hid, ws.comb_in, D, w->mlp_w0, w->mlp_b0, DA_ACT_NONE, nullptr, ws.m1pre, d.hid, st))) return rc;
     if ((rc = gelu_fwd((size_t)nr * d.hid, ws.m1pre, ws.m1, st))) return rc;
-    if ((rc = linear(P, nr, d.hid, D, ws.m1, d.hid, w->mlp_w1, w->mlp_b1, DA_ACT_NONE, nullptr, ws.h0, D, st))) return rc;
+    if ((rc = linear(PL, nr, d.hid, D, ws.m1, d.hid, w->mlp_w1, w->mlp_b1, DA_ACT_NONE, nullptr, ws.h0, D, st))) return rc;
     if (d.V > 0) {
         DA_REQUIRE(w->virt_emb, "exophormer: virt_emb missing");
         if ((rc = launch_set_virtual_rows(P, n - nr, d.V, D, w->virt_emb, ws.h0 + (size_t)nr * D, st))) return rc;
@@ -684,16 +721,16 @@ int da_train_forward(const da_weights *w, const da_graph *g, const float *x, con
     int ldx = D;
     for (int l = 0; l < d.L; ++l) {
         const bool last = l == d.L - 1;
-        if ((rc = linear(P, n, d.din[l], 4 * d.hc[l], xin, ldx, w->conv_wq[l], w->conv_bq[l], DA_ACT_NONE, nullptr,
+        if ((rc = linear(PL, n, d.din[l], 4 * d.hc[l], xin, ldx, w->conv_wq[l], w->conv_bq[l], DA_ACT_NONE, nullptr,
                          ws.qkvs[l], 4 * d.hc[l], st))) return rc;
         if (d.dense) {
             if (l == 0 && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
             if ((rc = dense_train_attn_fwd(g, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr, ws.o[l], ws.P[l], ws.poff,
-                                           ws.node_graph, st))) return rc;
+                                           ws.node_graph, st, d.bfc))) return rc;
         } else if (d.hybrid) {
             if (l == 0 && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
             if ((rc = hybrid_train_attn_fwd(g, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr, ws.o[l], ws.P[l], ws.stats[l],
-                                            ws.poff, ws.node_graph, st))) return rc;
+                                            ws.poff, ws.node_graph, st, d.bfc))) return rc;
         } else if ((rc = launch_attn_csr(P, n, g->row_ptr, g->col_src, nullptr, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr,
                                          DA_ACT_NONE, ws.o[l], nullptr, ws.stats[l], st))) return rc;
         if (!last && d.gelu_between) {
@@ -705,7 +742,7 @@ int da_train_forward(const da_weights *w, const da_graph *g, const float *x, con
         ldx = d.hc[l];
     }
     const float *z = ws.o[d.L - 1];                           // conv output + combined (efficient_gat.py:144)
-    if ((rc = linear(P, nr, D, 32, z, D, w->head_w0, w->head_b0, DA_ACT_NONE, nullptr, ws.f1pre, 32, st))) return rc;
+    if ((rc = linear(PL, nr, D, 32, z, D, w->head_w0, w->head_b0, DA_ACT_NONE, nullptr, ws.f1pre, 32, st))) return rc;
     if ((rc = gelu_fwd((size_t)nr * 32, ws.f1pre, ws.f1, st))) return rc;
     return launch_head2d(P, nr, d.c_out, ws.f1, w->head_w1, w->head_b1, out, st);
 }
@@ -713,9 +750,16 @@ int da_train_forward(const da_weights *w, const da_graph *g, const float *x, con
 int da_train_backward(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
                       const int64_t *t, const float *d_out, float *d_feats, void *workspace, size_t workspace_bytes,
                       void *stream) {
+    return da_train_backward_ex(w, grads, g, x, t, d_out, d_feats, workspace, workspace_bytes, DA_TRAIN_MMA_FP32, stream);
+}
+
+int da_train_backward_ex(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
+                         const int64_t *t, const float *d_out, float *d_feats, void *workspace, size_t workspace_bytes,
+                         int mma_precision, void *stream) {
     Dims d;
     int rc;
-    if ((rc = dims_of(w, g, d))) return rc;
+    DA_REQUIRE(mma_precision == DA_TRAIN_MMA_FP32 || mma_precision == DA_TRAIN_MMA_BF16, "da_train_backward: unknown mma_precision %d", mma_precision);
+    if ((rc = dims_of(w, g, d, mma_precision))) return rc;
     DA_REQUIRE(grads && x && t && d_out && workspace, "da_train_backward: null argument");
     DA_REQUIRE(d.dense || (g->out_ptr && (g->out_dst || d.hybrid)), "da_train_backward: the graph needs the by-source CSR (out_ptr / "
                "out_dst; of the remainder edges for hybrid graphs, where out_dst may be empty)");
@@ -729,12 +773,12 @@ int da_train_backward(const da_weights *w, const da_weights *grads, const da_gra
 
     // ---- head: final_mlp.2, GELU, final_mlp.0 (efficient_gat.py:145)
     if ((rc = linear_bwd(nr, d.c_out, 32, d_out, d.c_out, ws.f1, 32, w->head_w1, G(grads->head_w1), G(grads->head_b1),
-                         ws.df1, 32, nullptr, ws, st))) return rc;
+                         ws.df1, 32, nullptr, ws, st, d.bfc))) return rc;
     if ((rc = gelu_bwd((size_t)nr * 32, ws.f1pre, ws.df1, ws.df1, st))) return rc;
     const float *z = ws.o[L - 1];
     if (n > nr) DA_CHECK_HIP(hipMemsetAsync(ws.dz + (size_t)nr * D, 0, (size_t)(n - nr) * D * 4, st));
     if ((rc = linear_bwd(nr, 32, D, ws.df1, 32, z, D, w->head_w0, G(grads->head_w0), G(grads->head_b0), ws.dz, D, nullptr,
-                         ws, st))) return rc;
+                         ws, st, d.bfc))) return rc;
     // residual: z = conv_out + h0  ->  both get dz
     DA_CHECK_HIP(hipMemcpyAsync(ws.dh0, ws.dz, (size_t)n * D * 4, hipMemcpyDeviceToDevice, st));
 
@@ -743,16 +787,16 @@ int da_train_backward(const da_weights *w, const da_weights *grads, const da_gra
     for (int l = L - 1; l >= 0; --l) {
         const int hc = d.hc[l], din = d.din[l];
         if (d.dense) {
-            if ((rc = dense_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.dY4, ws.poff, ws.node_graph, st))) return rc;
+            if ((rc = dense_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.dY4, ws.poff, ws.node_graph, st, d.bfc))) return rc;
         } else if (d.hybrid) {
             if ((rc = hybrid_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.stats[l], ws.Dd, ws.dY4, ws.poff,
-                                            ws.node_graph, st))) return rc;
+                                            ws.node_graph, st, d.bfc))) return rc;
         } else if ((rc = launch_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.stats[l], ws.Dd, ws.dY4, st))) return rc;
         const float *xin = l == 0 ? ws.h0 : (d.gelu_between ? ws.hact[l - 1] : ws.o[l - 1]);
         float *dx = (l & 1) ? ws.dxa : ws.dxb;
         // l == 0: the input is h0, whose gradient also carries the residual branch
         if ((rc = linear_bwd(n, 4 * hc, din, ws.dY4, 4 * hc, xin, din, w->conv_wq[l], G(grads->conv_wq[l]), G(grads->conv_bq[l]),
-                             l == 0 ? ws.dh0 : dx, din, l == 0 ? ws.dh0 : nullptr, ws, st))) return rc;
+                             l == 0 ? ws.dh0 : dx, din, l == 0 ? ws.dh0 : nullptr, ws, st, d.bfc))) return rc;
         if (l > 0) {
             if (d.gelu_between && (rc = gelu_bwd((size_t)n * din, ws.o[l - 1], dx, dx, st))) return rc;
             d_o = dx;
@@ -766,10 +810,10 @@ int da_train_backward(const da_weights *w, const da_weights *grads, const da_gra
     }
     // ---- mlp.2, GELU, mlp.0 (efficient_gat.py:135)
     if ((rc = linear_bwd(nr, D, d.hid, ws.dh0, D, ws.m1, d.hid, w->mlp_w1, G(grads->mlp_w1), G(grads->mlp_b1), ws.dm1, d.hid,
-                         nullptr, ws, st))) return rc;
+                         nullptr, ws, st, d.bfc))) return rc;
     if ((rc = gelu_bwd((size_t)nr * d.hid, ws.m1pre, ws.dm1, ws.dm1, st))) return rc;
     if ((rc = linear_bwd(nr, d.hid, D, ws.dm1, d.hid, ws.comb_in, D, w->mlp_w0, G(grads->mlp_w0), G(grads->mlp_b0), ws.dcomb, D,
-                         nullptr, ws, st))) return rc;
+                         nullptr, ws, st, d.bfc))) return rc;
     // ---- concat pieces: [feats | pos | time]
     if (d_feats) {
         k_copy_cols<<<grid_for((size_t)nr * d.F), 256, 0, st>>>(nr, d.F, ws.dcomb, D, d_feats);
@@ -781,10 +825,10 @@ int da_train_backward(const da_weights *w, const da_weights *grads, const da_gra
     k_pos_hidden<<<(nr * 16 + 255) / 256, 256, 0, st>>>(nr, d.c_in, x, w->pos_w0, w->pos_b0, ws.pa, ws.p1);
     DA_LAUNCH_CHECK();
     if ((rc = linear_bwd(nr, 32, 16, ws.dcomb + d.F, D, ws.p1, 16, w->pos_w1, G(grads->pos_w1), G(grads->pos_b1), ws.dp1, 16,
-                         nullptr, ws, st))) return rc;
+                         nullptr, ws, st, d.bfc))) return rc;
     if ((rc = gelu_bwd((size_t)nr * 16, ws.pa, ws.dp1, ws.dp1, st))) return rc;
     return linear_bwd(nr, 16, d.c_in, ws.dp1, 16, x, d.c_in, w->pos_w0, G(grads->pos_w0), G(grads->pos_b0), nullptr, 0,
-                      nullptr, ws, st);
+                      nullptr, ws, st, d.bfc);
 }
 
 }  // extern "C"

@@ -33,6 +33,7 @@ struct GGemm {
     float alpha;
     int accumulate;
     int H;
+    int bfc;                     // operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16 (training's DA_TRAIN_MMA_BF16 mode)
     const int32_t *gp;           // [G + 1] node offsets
     const long long *poff;       // [G + 1] pair-matrix offsets (floats)
 };
@@ -57,6 +58,7 @@ __device__ __forceinline__ f32x4 ld4z(const float *p, int rs, int r, int c, int 
     return v;
 }
 
+template <bool BFC>
 __global__ __launch_bounds__(256) void k_ggemm(GGemm p) {
     constexpr int LS = 80;
     __shared__ __attribute__((aligned(16))) float As[16 * LS];
@@ -100,6 +102,28 @@ __global__ __launch_bounds__(256) void k_ggemm(GGemm p) {
         put(Bs, p.transB == 0, rb);
         __syncthreads();
         if (k0 + 16 < K) { ra = loadA(k0 + 16); rb = loadB(k0 + 16); }
+        if (BFC) {
+            // one v_mfma_f32_16x16x16_bf16 per tile pair and stage: lane group g = lane >> 4 feeds the stage's k rows
+            // g, g + 4, g + 8, g + 12 (both operands alike; rows one apart keep the four groups on different banks)
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+            typedef __attribute__((ext_vector_type(4))) short s16x4_;
+            s16x4_ a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bf16x4_ ta, tb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ta[e] = (__bf16)As[(4 * e + (lane >> 4)) * LS + wr * 32 + i * 16 + (lane & 15)];
+                    tb[e] = (__bf16)Bs[(4 * e + (lane >> 4)) * LS + wc * 32 + i * 16 + (lane & 15)];
+                }
+                a[i] = __builtin_bit_cast(s16x4_, ta);
+                b[i] = __builtin_bit_cast(s16x4_, tb);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 4) {
             float a[2], b[2];
@@ -112,6 +136,7 @@ __global__ __launch_bounds__(256) void k_ggemm(GGemm p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
         }
         __syncthreads();
     }
@@ -209,7 +234,8 @@ static unsigned gridsz(size_t n) { const size_t b = (n + 255) / 256; return (uns
 
 static int ggemm(const GGemm &p, int G, int H, int maxn, hipStream_t st) {
     const int Mx = p.dimM ? p.dimM : maxn, Nx = p.dimN ? p.dimN : maxn;
-    k_ggemm<<<dim3((Nx + 63) / 64, (Mx + 63) / 64, G * H), 256, 0, st>>>(p);
+    if (p.bfc) k_ggemm<true><<<dim3((Nx + 63) / 64, (Mx + 63) / 64, G * H), 256, 0, st>>>(p);
+    else k_ggemm<false><<<dim3((Nx + 63) / 64, (Mx + 63) / 64, G * H), 256, 0, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -229,9 +255,10 @@ int dense_train_prepare(const da_graph *g, int H, long long *poff, int32_t *node
 
 // forward: o = softmax(scale q k^T) v + skip (+ res); P kept for the backward
 int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P,
-                         const long long *poff, const int32_t *node_graph, hipStream_t st) {
+                         const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc) {
     const int n = g->n_nodes, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
     GGemm s;
+    s.bfc = bfc;
     s.A = {(float *)qkvs, 0, 4 * HC, C};
     s.B = {(float *)qkvs + HC, 0, 4 * HC, C};
     s.C = {P, 1, 0, 0};
@@ -243,6 +270,7 @@ int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, con
     k_init_out<<<gridsz((size_t)n * HC), 256, 0, st>>>(n, HC, qkvs, res, o);
     DA_LAUNCH_CHECK();
     GGemm pv;
+    pv.bfc = bfc;
     pv.A = {P, 1, 0, 0};
     pv.B = {(float *)qkvs + 2 * HC, 0, 4 * HC, C};
     pv.C = {o, 0, HC, C};
@@ -253,11 +281,12 @@ int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, con
 
 // backward: dY4 = [dq | dk | dv | d_o] from d_o [n, HC], the saved P and the projection buffer
 int dense_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
-                         float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st) {
+                         float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc) {
     const int n = g->n_nodes, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
     const float scale = 1.0f / sqrtf((float)C);
     int rc;
     GGemm q;
+    q.bfc = bfc;
     q.H = H; q.gp = g->graph_ptr; q.poff = poff; q.accumulate = 0;
     // dV = P^T dO
     q.A = {(float *)P, 1, 0, 0}; q.B = {(float *)d_o, 0, HC, C}; q.C = {dY4 + 2 * HC, 0, 4 * HC, C};
@@ -517,9 +546,10 @@ __global__ __launch_bounds__(256) void k_zero_kv_grad(int r0, int r1, int HC, fl
 
 // forward: o = softmax over (regular edges U remainder edges) . v + skip (+ res); P (dense part) and stats kept
 int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P, float *stats,
-                          const long long *poff, const int32_t *node_graph, hipStream_t st) {
+                          const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc) {
     const int n = g->n_nodes, nr = g->n_real, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
     GGemm s;
+    s.bfc = bfc;
     s.A = {(float *)qkvs, 0, 4 * HC, C};
     s.B = {(float *)qkvs + HC, 0, 4 * HC, C};
     s.C = {P, 1, 0, 0};
@@ -533,6 +563,7 @@ int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, co
     k_init_out<<<gridsz((size_t)n * HC), 256, 0, st>>>(n, HC, qkvs, res, o);
     DA_LAUNCH_CHECK();
     GGemm pv;
+    pv.bfc = bfc;
     pv.A = {P, 1, 0, 0};
     pv.B = {(float *)qkvs + 2 * HC, 0, 4 * HC, C};
     pv.C = {o, 0, HC, C};
@@ -549,12 +580,13 @@ int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, co
 
 // backward: dY4 = [dq | dk | dv | d_o]
 int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
-                          const float *stats, float *Dd, float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st) {
+                          const float *stats, float *Dd, float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc) {
     const int n = g->n_nodes, nr = g->n_real, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
     const float scale = 1.0f / sqrtf((float)C);
     const int grid = (int)(((size_t)n * 64 + 255) / 256);
     int rc;
     GGemm q;
+    q.bfc = bfc;
     q.H = H; q.gp = g->graph_ptr; q.poff = poff; q.accumulate = 0;
     // dV (regular edges) = P^T dO ; virtual rows' dk | dv start from zero
     q.A = {(float *)P, 1, 0, 0}; q.B = {(float *)d_o, 0, HC, C}; q.C = {dY4 + 2 * HC, 0, 4 * HC, C};

@@ -15,9 +15,15 @@ The kernels ADD into ``flat_grad``.  When a parameter's ``.grad`` is not (or no 
 ``zero_grad(set_to_none=True)``) the engine's view, the next backward starts from zero and re-attaches the
 views; otherwise it accumulates, like autograd does.
 
-fp32 only (the parity mode): the reference trains in fp32 and its gradient fixtures are fp32.
+Precision.  Storage is fp32 throughout (the reference trains in fp32; its gradient fixtures are fp32).  ``TrainEngine.precision``
+chooses how the matrix-core GEMMs of a step take their operands: ``"fp32"`` (default: exact products, the mode of the
+fixtures) or ``"bf16"`` (operands rounded to bf16 on their way into the matrix cores, fp32 accumulation --
+``DA_TRAIN_MMA_BF16`` of include/diffassemble_hip.h; what ``torch.autocast(bfloat16)`` does to the reference's Linear /
+matmul calls).  Default from the environment (``DIFFASSEMBLE_TRAIN_PRECISION``, the switch the piece encoder's training
+path reads too), settable per engine / through ``Eff_GAT.train_precision``.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -87,6 +93,7 @@ class TrainEngine:
         self._ws_key = None
         # the one parameter autograd sees (DenoiserTrainFn): the smallest trainable tensor
         self.anchor = min((p for p in self.params if p.requires_grad), key=lambda p: p.numel(), default=self.params[0])
+        self.precision = os.environ.get("DIFFASSEMBLE_TRAIN_PRECISION", "fp32") or "fp32"      # "fp32" | "bf16" (module docstring)
         self.version = 0              # bumped by every raw-pointer update of ``flat`` (FusedAdafactor.step)
         self.grads_synced = False     # True between sync_gradients() and the next backward
 
@@ -157,9 +164,15 @@ class TrainEngine:
         ws = self._workspace(plan)
         g = self._cg(plan)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.da_train_forward(C.byref(self.w), C.byref(g), _lib.ptr(x), _lib.ptr(t), _lib.ptr(feats),
-                                                 _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self.device)))
+            _lib.check(self.lib.da_train_forward_ex(C.byref(self.w), C.byref(g), _lib.ptr(x), _lib.ptr(t), _lib.ptr(feats),
+                                                    _lib.ptr(out), _lib.ptr(ws), ws.numel(), self._mma(), _lib.stream_ptr(self.device)))
+        self._fwd_mma = self._mma()
         return out
+
+    def _mma(self):
+        if self.precision not in ("fp32", "bf16"):
+            raise _lib.DaError(f"TrainEngine.precision must be 'fp32' or 'bf16', not {self.precision!r}")
+        return _lib.TRAIN_MMA_BF16 if self.precision == "bf16" else _lib.TRAIN_MMA_FP32
 
     def backward(self, plan: GraphPlan, x, t, d_out, want_dfeats=False):
         """da_train_backward: adds every parameter gradient into ``flat_grad`` (and attaches the views
@@ -177,9 +190,10 @@ class TrainEngine:
         ws = self._workspace(plan)
         g = self._cg(plan)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.da_train_backward(C.byref(self.w), C.byref(self.gw), C.byref(g), _lib.ptr(x), _lib.ptr(t),
-                                                  _lib.ptr(d_out), _lib.ptr(d_feats), _lib.ptr(ws), ws.numel(),
-                                                  _lib.stream_ptr(self.device)))
+            _lib.check(self.lib.da_train_backward_ex(C.byref(self.w), C.byref(self.gw), C.byref(g), _lib.ptr(x), _lib.ptr(t),
+                                                     _lib.ptr(d_out), _lib.ptr(d_feats), _lib.ptr(ws), ws.numel(),
+                                                     getattr(self, "_fwd_mma", self._mma()),      # the mode of the forward it follows
+                                                     _lib.stream_ptr(self.device)))
         if not attached:
             for p, gv in zip(self.params, self.grad_views):
                 p.grad = gv

@@ -342,12 +342,29 @@ int da_debug_counters(int64_t *out /* host [n] */, int n, int reset);
  * backward on the same workspace.
  * ------------------------------------------------------------------------------------- */
 size_t da_train_workspace_bytes(const da_weights *w, const da_graph *g);
+/* mma_precision of the _ex forms: how the matrix-core GEMMs of the step (every Linear forward / dX / dW and the grouped
+ * attention GEMMs of complete and hybrid graphs) take their operands.  Storage is fp32 in both modes -- parameters,
+ * activations, gradients, the flat buffers the optimizer and the gradient all-reduce see.
+ *   DA_TRAIN_MMA_FP32  exact fp32 products (v_mfma_f32_16x16x4_f32): the reference's precision, the mode of the gradient
+ *                      fixtures; da_train_forward / da_train_backward are this mode.
+ *   DA_TRAIN_MMA_BF16  operands rounded to bf16 (round to nearest even) in registers on their way into the matrix cores,
+ *                      products accumulated in fp32 (v_mfma_f32_16x16x16_bf16): what autocast(bfloat16) does to the
+ *                      reference's Linear / matmul calls.  Softmax, GELU, bias sums, the CSR edge kernels and the optimizer
+ *                      stay fp32.  Use the same mode for the forward and the backward of a step.                       */
+#define DA_TRAIN_MMA_FP32 0
+#define DA_TRAIN_MMA_BF16 1
 int da_train_forward(const da_weights *w, const da_graph *g, const float *x, const int64_t *t,
                      const float *feats, float *out, void *workspace, size_t workspace_bytes,
                      void *stream);
 int da_train_backward(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
                       const int64_t *t, const float *d_out, float *d_feats, void *workspace,
                       size_t workspace_bytes, void *stream);
+int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, const int64_t *t,
+                        const float *feats, float *out, void *workspace, size_t workspace_bytes,
+                        int mma_precision, void *stream);
+int da_train_backward_ex(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
+                         const int64_t *t, const float *d_out, float *d_feats, void *workspace,
+                         size_t workspace_bytes, int mma_precision, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused Adafactor step over the flat parameter / gradient buffers (one call = one optimizer

@@ -228,20 +228,30 @@ def test_logit_offsets_900_pieces(dev, C, folded, prec, kind):
     _case(dev, [900], True, C, folded, prec, kind)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("C,folded", SHAPES)
-def test_optimistic_path_is_offset_invariant_bit_for_bit(dev, C, folded):
-    """Inside the window the shift-free kernels compute exp2(s + k) = exp2(s) 2^k for the integer offsets used here: the
-    bf16 outputs at -44 and -55 log2-units equal the offset-free outputs exactly (before the epsilon fix the -55 rows came
-    out 2e-3 low), and no fallback ran."""
+def test_shift_free_paths_are_offset_invariant(dev, C, folded, prec):
+    """Softmax is shift invariant: inside the exponent window the shift-free kernels must give the offset-free answer at
+    -44 and -55 log2-units too, and without any fallback.  (Before the epsilon fix the -55 rows came out 2e-3 LOW: `+ 1e-16`
+    on an un-shifted sum of ~2^-50.)  fp32: 2e-5 norm-wise (the fp32 accumulation of s + offset rounds at a coarser ulp).
+    bf16: single outputs may differ by one bf16 ulp (the same rounding of s reaches P), so the test is on the MEAN signed
+    relative deviation over the significant outputs -- a systematic 2e-3 shows there, rounding flips average out."""
     sizes = [130, 37, 64, 1, 200]
     outs = []
     for off in (0.0, -44.0, -55.0):
         row = torch.full((sum(sizes),), off)
-        x, ws, bs = build_layer(sizes, C, folded, 3, row, None, True)
-        out, cnt = run_layer(dev, sizes, True, C, folded, "bf16", x, ws, bs)
+        x, ws, bs = build_layer(sizes, C, folded, 3, row, None, prec == "bf16")
+        out, cnt = run_layer(dev, sizes, True, C, folded, prec, x, ws, bs)
         assert sum(cnt.values()) <= 8, cnt          # (the 1-piece graph: see _case)
-        outs.append(out)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        outs.append(out.double())
+    big = outs[0].abs() > 0.1 * outs[0].abs().max()
+    for o in outs[1:]:
+        dev_rel = ((o - outs[0]) / outs[0])[big]
+        if prec == "fp32":
+            assert rel(o, outs[0]) < 2e-5
+        else:
+            assert rel(o, outs[0]) < 8e-3                                   # one bf16 ulp of the largest output
+            assert abs(float(dev_rel.mean())) < 2e-4, float(dev_rel.mean())
 
 
 def hybrid_graph(sizes, seed):

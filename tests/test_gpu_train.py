@@ -101,6 +101,55 @@ def test_backward_matches_oracle_autograd(dev, name):
     assert all(lo <= params[k].grad.data_ptr() < hi for k in g_ref)
 
 
+@pytest.mark.parametrize("name", ["rot144_g2_sharp", "ragged_dense", "exo144_v8_g2", "exo_expander_d6"])
+def test_bf16_mma_training_mode_against_the_fp32_oracle(dev, monkeypatch, name):
+    """TrainEngine.precision = "bf16" (DA_TRAIN_MMA_BF16: every Linear forward / dX / dW product and the grouped attention
+    GEMMs take operands rounded to bf16, fp32 accumulation, fp32 storage; what autocast(bfloat16) does to the reference's
+    nn.Linear / matmul calls) against the oracle's fp32 autograd: prediction and loss within 1.5e-2 / 5e-3, every gradient
+    with more than rounding-noise magnitude within 6 % norm-wise AND cosine similarity > 0.998 -- bf16 operands carry 8
+    mantissa bits (relative rounding 2^-9 per operand, averaged over the reduction), no tighter bound is meaningful;
+    a wrong K-slot assignment or a missing term shows as an O(1) error.  Complete graphs (dense grouped GEMMs) and, forced,
+    the hybrid path (masked grouped GEMMs + CSR remainder); the exact mode of the same engine still meets GTOL afterwards."""
+    if name.startswith("exo"):
+        monkeypatch.setenv("DA_HYBRID", "force")
+    spec = C.by_name(name)
+    case = C.build_case(spec)
+    rng = np.random.default_rng(17)
+    target = torch.from_numpy(rng.standard_normal(tuple(case["x"].shape)).astype(np.float32))
+    pred_ref, loss_ref, g_ref, gf_ref = oracle_grads(spec, case, case["x"], target)
+    m = make_module(spec, case, dev)
+    te = m.train_engine(dev)
+
+    def run(precision):
+        te.precision = precision
+        m.zero_grad(set_to_none=True)
+        feats = case["feats"].to(dev).requires_grad_(True)
+        out, _ = m.forward_with_feats(case["x"].to(dev), case["t"].to(dev), None, case["edge_index"].to(dev), feats, case["batch"].to(dev))
+        loss = F.smooth_l1_loss(target.to(dev), out)
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach(), loss.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, feats.grad
+
+    out, loss, grads, gf = run("bf16")
+    assert rel(out, pred_ref) < 1.5e-2 and rel(loss, loss_ref) < 5e-3
+    floor = 1e-3 * max(float(g.abs().max()) for g in g_ref.values())
+    worst = 0.0
+    for k, gr in g_ref.items():
+        got = grads[k].double().cpu()
+        if float(gr.abs().max()) < floor:
+            continue                                  # identically-zero gradients (lin_key.bias): rounding noise on both sides
+        err = float((got - gr.double()).abs().max()) / float(gr.abs().max())
+        cos = float((got * gr.double()).sum() / (got.norm() * gr.double().norm()))
+        worst = max(worst, err)
+        assert err < 6e-2 and cos > 0.998, (k, err, cos)
+    assert rel(gf, gf_ref) < 6e-2
+    assert worst > 1e-5                               # ... and the mode really is a different arithmetic
+    out32, loss32, grads32, _ = run("fp32")
+    assert rel(out32, pred_ref) < 1e-4 and rel(loss32, loss_ref) < 1e-5
+    k = "gnn_backbone.module_list.0.lin_query.weight"
+    assert rel(grads32[k], g_ref[k]) < GTOL
+
+
 def test_large_batch_dense_training_rows_beyond_the_grid_cap(dev):
     """30 puzzles of 12x12 = 4 320 nodes x 8 heads = 34 560 attention rows: more than the 32 768 rows the capped launch of
     the dense training softmax covers in one pass (the rows beyond it used to keep raw scores instead of probabilities --
