@@ -332,9 +332,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                 // hybrid graphs: adjacency-masked, remainder edges of the real rows folded in the epilogue; the
                 // virtual rows' outputs of the LAST layer are dropped by the model (exophormer_gnn.py:209), so the
                 // CSR-side kernels are not needed here
-                DenseMask mk;
-                mk.mask = g->mask; mk.mask_ptr = g->mask_ptr; mk.irr_row_ptr = g->irr_row_ptr;
-                mk.irr_col_src = g->irr_col_src; mk.row_map = g->row_map;
+                const DenseMask mk = dense_mask_of(g);
                 rc = timed(d, DA_PROF_ATTN_LAST, st, [&] {
                     return launch_attn_dense(prec, L, d->heads, c.C, g->n_graphs, g->max_graph_nodes, g->graph_ptr,
                                              g->pad_ptr, g->dense == 2, nullptr, DA_ACT_NONE, nullptr, st,
@@ -394,9 +392,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                 if (g->hybrid) {
                     // sparse-but-heavy graphs: masked MFMA attention over the regular edges (partial softmax
                     // state), then the remaining edges + normalisation + skip / activation on the CSR side
-                    DenseMask mk;
-                    mk.mask = g->mask; mk.mask_ptr = g->mask_ptr; mk.irr_row_ptr = g->irr_row_ptr;
-                    mk.irr_col_src = g->irr_col_src; mk.row_map = g->row_map;
+                    const DenseMask mk = dense_mask_of(g);
                     if (d->side_stream && !d->prof_on && n > nr) {
                         // fork: virtual rows on the side stream, real rows here, join before the next projection
                         DA_CHECK_HIP(hipEventRecord(d->ev_fork, st));
@@ -1014,8 +1010,7 @@ int da_conv_dense_ex(int prec, const da_graph *g, int heads, int C, int Din, con
     L.Q = qs.Q; L.K = qs.K; L.Vt = qs.Vt; L.S = qs.S; L.n_pad = g->n_pad; L.q_prescaled = (flags & DA_CONV_Q_PRESCALED) ? 1 : 0;
     DenseFold fo;
     fo.cv = 32; fo.out = out; fo.n_rows = g->n_real;
-    DenseMask mk;
-    mk.mask = g->mask; mk.mask_ptr = g->mask_ptr; mk.irr_row_ptr = g->irr_row_ptr; mk.irr_col_src = g->irr_col_src; mk.row_map = g->row_map;
+    const DenseMask mk = dense_mask_of(g);
     rc = launch_attn_dense(prec, L, heads, C, g->n_graphs, g->max_graph_nodes, g->graph_ptr, g->pad_ptr, g->dense == 2, residual, act,
                            folded ? nullptr : out, st, g->hybrid ? &mk : nullptr, folded ? &fo : nullptr);
     DA_REQUIRE(rc == 0, "da_conv_dense_ex: attention launch failed (%d)", rc);

@@ -32,6 +32,10 @@ struct AttnDenseParams {
     const int32_t *irr_row_ptr;     // remainder edges (virtual nodes, duplicates, cross-graph pairs): CSR by destination
     const int32_t *irr_col_src;
     const int32_t *row_map;         // node -> padded slot (for the sources of remainder edges)
+    const int32_t *slot_node;       // hybrid, banded layout: padded slot -> node (null: slot pad0 + i holds node node0 + i)
+    const unsigned char *blk_class; // hybrid: class of every (32-query slab, 32-key block) of a graph: 0 empty, 1 partial, 2 full (or null)
+    const long long *blk_class_ptr; // [G + 1] byte offsets of the graphs' class tables
+    int blk_class_stride;           // bytes per slab row of a class table
     void *fold_out;                 // CV != C: [H][n_rows][CV] normalised per-head outputs in the activation dtype (no skip / activation here)
     int n_rows;
 };

@@ -136,6 +136,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
     // MASKED: this lane's row of the adjacency bit matrix (bit j = edge j -> this query)
     const unsigned char *mrow = nullptr;
     if (MASKED) mrow = p.mask + p.mask_ptr[g] + (size_t)min(qidx, n_g - 1) * (size_t)((p.pad_ptr[g + 1] - pad0) >> 3);
+    // MASKED: slot -> node (banded expander plans order a graph's slots by position; see k_attn_optt in da_attn_opt.hip)
+    auto node_of = [&](int ql) { return (MASKED && p.slot_node) ? p.slot_node[pad0 + ql] : node0 + ql; };
     // MASKED: remainder-edge metadata of the four queries this 8-lane group finishes in the epilogue
     int rm_beg[4] = {0, 0, 0, 0}, rm_end[4] = {0, 0, 0, 0}, rm_slot[4] = {0, 0, 0, 0};
     if (MASKED && wave_on) {
@@ -143,8 +145,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
         for (int r = 0; r < 4; ++r) {
             const int qg = qt * QT + wid * 32 + (lane >> 3) + 8 * r;
             if (qg < n_g) {
-                rm_beg[r] = p.irr_row_ptr[node0 + qg];
-                rm_end[r] = p.irr_row_ptr[node0 + qg + 1];
+                const int nd = node_of(qg);
+                rm_beg[r] = p.irr_row_ptr[nd];
+                rm_end[r] = p.irr_row_ptr[nd + 1];
             }
             rm_slot[r] = pad0;                                       // any valid slot when there is no edge
             if (rm_end[r] > rm_beg[r]) rm_slot[r] = p.row_map[p.irr_col_src[rm_beg[r]]];
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
             const float ir = lr > 0.f ? 1.0f / (lr + 1e-16f) : 0.f;
             const f32x4 a = *(const f32x4 *)(so + q * RSOF + ch * 4);
             const float v4[4] = {a[0] * ir, a[1] * ir, a[2] * ir, a[3] * ir};
-            st4((T *)p.fold_out + ((size_t)h * p.n_rows + node0 + qt * QT + q) * CV + ch * 4, v4);
+            st4((T *)p.fold_out + ((size_t)h * p.n_rows + node_of(qt * QT + q)) * CV + ch * 4, v4);
         }
         return;
     }
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
             const int it = it0 + NT * k;
             if (it < nq * CPR) {
                 const int q = it / CPR, ch = it - q * CPR;
-                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                const size_t off = (size_t)node_of(qt * QT + q) * HC + (size_t)h * C + ch * EPC;
                 skv[k] = *(const u32x4 *)((const T *)p.S + off);
                 if (p.res) rsv[k] = *(const u32x4 *)((const T *)p.res + off);
             }
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
             const int it = it0 + NT * k;
             if (it < nq * CPR) {
                 const int q = it / CPR, ch = it - q * CPR;
-                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                const size_t off = (size_t)node_of(qt * QT + q) * HC + (size_t)h * C + ch * EPC;
                 const float *src = so + q * RSOF + ch * EPC;
                 float v[EPC], sk[EPC];
                 {
@@ -877,6 +880,9 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.mask = mk ? mk->mask : nullptr; p.mask_ptr = mk ? (const long long *)mk->mask_ptr : nullptr;
     p.irr_row_ptr = mk ? mk->irr_row_ptr : nullptr; p.irr_col_src = mk ? mk->irr_col_src : nullptr;
     p.row_map = mk ? mk->row_map : nullptr;
+    p.slot_node = mk ? mk->slot_node : nullptr;
+    p.blk_class = mk ? mk->blk_class : nullptr; p.blk_class_ptr = mk ? (const long long *)mk->blk_class_ptr : nullptr;
+    p.blk_class_stride = mk ? mk->blk_class_stride : 0;
     { const char *e = getenv("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
     { static int fg = -1; if (fg < 0) { const char *e = getenv("DA_ATTN_FORCE_GEN"); fg = (e && e[0] == '1') ? 1 : 0; } p.force_gen = fg; if (fg) p.fast = p.fast ? 2 : 0; }
     { const char *e = getenv("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }

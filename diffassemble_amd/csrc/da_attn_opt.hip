@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     static_assert(CF::NCB == 1, "one 32-channel value block");
     constexpr int MAXI = (CF::NI + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *flags = (int *)(smem + NST * CF::STAGE);               // one word per wave: "my optimistic pass failed"
+    int *flags = (int *)(smem + NST * CF::STAGE);               // one word per wave: "my optimistic pass failed"; [4 .. 11]: the waves' tile masks
     float *mlut = (float *)(smem + NST * CF::STAGE + 64);       // MASKED: nibble -> four accumulator initial values
     if (MASKED && threadIdx.x < 64) {
         const int e = threadIdx.x >> 2, b = threadIdx.x & 3;
@@ -115,6 +115,12 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     // MASKED: this lane's row of the adjacency bit matrix (bit j = edge j -> this query); the 8 bytes of key tile kt sit at
     // mrow + 8 kt (rows are 8-byte aligned: the padded slot count is a multiple of 64).  Remainder-edge metadata of the four
     // queries this 8-lane group finishes in the epilogue.
+    // Slots vs nodes.  Rows of Q / K / V and of the adjacency matrix live in SLOT space (the padded per-graph row ranges the
+    // projection scatters into through row_map).  Normally slot pad0 + i holds node node0 + i; an expander plan in the banded
+    // layout (graph_plan.expander_plan) orders a graph's slots by the nodes' POSITIONS in the generator's permutation, which
+    // turns the adjacency into a circulant band (whole 32 x 32 blocks empty or full), and hands slot_node[] to find the node
+    // -- skip / output rows, remainder edges -- of a slot.
+    auto node_of = [&](int ql) { return (MASKED && p.slot_node) ? p.slot_node[pad0 + ql] : node0 + ql; };       // ql < n_g
     const unsigned char *mrow = nullptr;
     int rm_beg[4] = {0, 0, 0, 0}, rm_end[4] = {0, 0, 0, 0}, rm_slot[4] = {0, 0, 0, 0};
     if (MASKED) {
@@ -124,8 +130,9 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int qg = qt * QT + wid * 32 + (lane >> 3) + 8 * r;
                 if (qg < n_g) {
-                    rm_beg[r] = p.irr_row_ptr[node0 + qg];
-                    rm_end[r] = p.irr_row_ptr[node0 + qg + 1];
+                    const int nd = node_of(qg);
+                    rm_beg[r] = p.irr_row_ptr[nd];
+                    rm_end[r] = p.irr_row_ptr[nd + 1];
                 }
                 rm_slot[r] = pad0;                                       // any valid slot when there is no edge
                 if (rm_end[r] > rm_beg[r]) rm_slot[r] = p.row_map[p.irr_col_src[rm_beg[r]]];
@@ -137,6 +144,40 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     // ("+v": the loop-carried word keeps ONE register across the asm, so no copy of it can be scheduled before its wait)
     auto mask_load = [&](u32x2 &r, int kt) {
         asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(r) : "v"(mrow + 8 * (size_t)kt) : "memory");
+    };
+
+    // MASKED with block classes (da_graph.blk_class: per 32-query slab and 32-key block 0 = no edge, 1 = some, 2 = all): a wave
+    // skips the empty blocks of its slab outright, runs the full ones without the adjacency words, and the workgroup walks only
+    // the key tiles in which at least one of its slabs has an edge (d = 539 of 900: 63 % of the tiles' blocks survive, 14 % of
+    // them partial; d = 90: 13 %).  Without classes every block counts as partial.
+    const unsigned char *crow = nullptr;        // this wave's class row (wave-uniform address)
+    unsigned long long tmask = 0;                // key tiles the workgroup needs (bit kt)
+    int ntl = nkt;                               // ... and their number
+    if (MASKED) {
+        tmask = nkt >= 64 ? ~0ull : ((1ull << nkt) - 1ull);
+        if (p.blk_class) {
+            crow = p.blk_class + p.blk_class_ptr[g] + (size_t)(qt * 4 + wid) * (size_t)p.blk_class_stride;
+            unsigned long long mine = 0;
+            if (wave_on) {
+                for (int dw = 0; 2 * dw < nkt; ++dw) {             // one dword = four blocks = two tiles
+                    const unsigned c4 = *(const unsigned *)(crow + 4 * dw);
+                    if (c4 & 0xffffu) mine |= 1ull << (2 * dw);
+                    if (c4 >> 16) mine |= 1ull << (2 * dw + 1);
+                }
+            }
+            if (lane == 0) { flags[4 + 2 * wid] = (int)(unsigned)mine; flags[5 + 2 * wid] = (int)(unsigned)(mine >> 32); }
+            __syncthreads();
+            const unsigned lo = (unsigned)(flags[4] | flags[6] | flags[8] | flags[10]), hi = (unsigned)(flags[5] | flags[7] | flags[9] | flags[11]);
+            tmask &= ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane(lo);
+            ntl = __builtin_popcountll(tmask);
+        }
+    }
+    // the j-th tile of the walk: j itself, or the j-th set bit of tmask (cursor masks, scalar arithmetic)
+    auto next_tile = [&](unsigned long long &rem, int seq) {
+        if (!MASKED) return seq;
+        const int k = __builtin_ctzll(rem);
+        rem &= rem - 1ull;
+        return k;
     };
 
     f32x16 O;
@@ -153,17 +194,19 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         if (MASKED && wave_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // remainder metadata landed: the counted waits below start from zero
         // Order of this wave's VMEM operations: [M(0)] D(0) D(1) .. D(NST-2) | tile kt: [M(kt+1)] D(kt+NST-1).  MASKED waves
         // wait for M(kt+1) at the top of tile kt + 1, i.e. for everything but D(kt+NST-1): one tile less in flight than the ring holds.
+        unsigned long long rem_cur = tmask, rem_pf = tmask;
         u32x2 mw_nxt = {0u, 0u};
-        if (MASKED && wave_on) mask_load(mw_nxt, 0);
+        if (MASKED && wave_on && ntl > 0) mask_load(mw_nxt, __builtin_ctzll(tmask));
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
-            if (st < nkt) issue(st, st);
-        for (int kt = 0; kt < nkt; ++kt) {
+            if (st < ntl) issue(next_tile(rem_pf, st), st);
+        for (int j = 0; j < ntl; ++j) {
+            const int kt = next_tile(rem_cur, j);
             {
-                // tiles that may stay in flight behind tile kt (each is `myn` operations of this wave; myn is LO or LO + 1)
-                int younger = min(nkt - 1 - kt, NST - 2);
-                // MASKED: M(kt) must have landed too, and the only operation behind it is D(kt + NST - 2), issued right after it
-                if (MASKED && wave_on && kt > 0) younger = (NST > 2 && kt + NST - 2 < nkt) ? 1 : 0;
+                // tiles that may stay in flight behind this one (each is `myn` operations of this wave; myn is LO or LO + 1)
+                int younger = min(ntl - 1 - j, NST - 2);
+                // MASKED: M(j) must have landed too, and the only operation behind it is D(j + NST - 2), issued right after it
+                if (MASKED && wave_on && j > 0) younger = (NST > 2 && j + NST - 2 < ntl) ? 1 : 0;
                 constexpr int LO = CF::NI / NW;
                 if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (younger == 1) { if (myn == LO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO + 1) : "memory"); }
@@ -175,21 +218,29 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             u32x2 mw_cur = {0u, 0u};
             if (MASKED && wave_on) {
                 mw_cur = mw_nxt;                                              // landed (covered by the wait above)
-                if (kt + 1 < nkt) mask_load(mw_nxt, kt + 1);
+                if (j + 1 < ntl) mask_load(mw_nxt, __builtin_ctzll(rem_cur));  // the next tile of the walk
             }
-            if (kt + NST - 1 < nkt) issue(kt + NST - 1, (kt + NST - 1) % NST);
+            if (j + NST - 1 < ntl) issue(next_tile(rem_pf, j + NST - 1), (j + NST - 1) % NST);
             if (!wave_on) continue;
-            const unsigned char *stg = smem + (kt % NST) * CF::STAGE;
+            // classes of this slab's two blocks in the tile (1 = partial when the plan has no class table)
+            const unsigned cls2 = (MASKED && crow) ? *(const unsigned short *)(crow + 2 * kt) : 0x0101u;
+            const unsigned char *stg = smem + (j % NST) * CF::STAGE;
 #pragma unroll
             for (int kb = 0; kb < CF::KB; ++kb) {
                 const int key0 = kt * CF::BKEYS + kb * 32;
                 if (key0 >= n_g) break;
+                const unsigned cls = MASKED ? ((cls2 >> (8 * kb)) & 3u) : 1u;      // wave-uniform
+                if (MASKED && cls == 0u) continue;                                  // no edge between this slab and these keys
                 u32x4 kf[CF::NCH];
 #pragma unroll
                 for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + koff + kb * 32 * CF::RS + ch * 32);
                 __builtin_amdgcn_sched_barrier(0);
                 f32x16 s;
-                if (MASKED) {
+                if (MASKED && cls == 2u) {                                           // every pair of the block is an edge
+                    anym = 1u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                } else if (MASKED) {
                     const unsigned mw = (mw_cur[kb] >> (16 * half)) & 0xffffu;      // this lane's 16 keys of the block
                     anym |= mw;
 #pragma unroll
@@ -204,7 +255,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
 #pragma unroll
                 for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), kf[ch], qf[ch], s);
                 u32x2 vlo[2], vhi[2];
-                const unsigned vb = lds0 + (unsigned)((kt % NST) * CF::STAGE + vbase + kb * 32 * CF::RSV);
+                const unsigned vb = lds0 + (unsigned)((j % NST) * CF::STAGE + vbase + kb * 32 * CF::RSV);
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm) {
                     vlo[mm] = tr_read(vb, (8 * mm) * CF::RSV);
@@ -333,7 +384,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             const float ir = lr > 0.f ? 1.0f / (lr + 1e-16f) : 0.f;
             const f32x4 a = *(const f32x4 *)(so + q * RSOF + ch * 4);
             const float v4[4] = {a[0] * ir, a[1] * ir, a[2] * ir, a[3] * ir};
-            st4((T *)p.fold_out + ((size_t)h * p.n_rows + node0 + qt * QT + q) * CV + ch * 4, v4);
+            st4((T *)p.fold_out + ((size_t)h * p.n_rows + node_of(qt * QT + q)) * CV + ch * 4, v4);
         }
         return;
     }
@@ -346,7 +397,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             const int it = it0 + NT * k;
             if (it < nq * CPR) {
                 const int q = it / CPR, ch = it - q * CPR;
-                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                const size_t off = (size_t)node_of(qt * QT + q) * HC + (size_t)h * C + ch * EPC;
                 skv[k] = *(const u32x4 *)((const T *)p.S + off);
                 if (p.res) rsv[k] = *(const u32x4 *)((const T *)p.res + off);
             }
@@ -356,7 +407,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             const int it = it0 + NT * k;
             if (it < nq * CPR) {
                 const int q = it / CPR, ch = it - q * CPR;
-                const size_t off = ((size_t)node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                const size_t off = (size_t)node_of(qt * QT + q) * HC + (size_t)h * C + ch * EPC;
                 const float *src = so + q * RSOF + ch * EPC;
                 float v[EPC], sk[EPC];
                 const f32x4 a = *(const f32x4 *)src, b2 = *(const f32x4 *)(src + 4);

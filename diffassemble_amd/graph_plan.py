@@ -68,6 +68,11 @@ class GraphPlan:
     irr_row_ptr: torch.Tensor = None   # int32 [n_nodes + 1]
     irr_col_src: torch.Tensor = None   # int32 [E_irregular]
     edge_index_fn: object = None       # () -> the edge list, for plans built without one (expander_plan)
+    # banded layout of expander plans (optional): slots of a graph ordered by the nodes' positions in the generator's permutation
+    slot_node: torch.Tensor = None     # int32 [n_pad]: padded slot -> node (-1 = padding); None = slot order is node order
+    blk_class: torch.Tensor = None     # uint8: per (32-slot query slab, 32-slot key block) 0 = no regular edge, 1 = some, 2 = all
+    blk_class_ptr: torch.Tensor = None  # int64 [G + 1] byte offsets of the graphs' class tables (graphs of one shape share one)
+    blk_class_stride: int = 0
 
     @property
     def edge_index(self):
@@ -133,6 +138,10 @@ class GraphPlan:
         if self.hybrid:
             g.mask, g.mask_ptr = self.mask.data_ptr(), self.mask_ptr.data_ptr()
             g.irr_row_ptr, g.irr_col_src = self.irr_row_ptr.data_ptr(), self.irr_col_src.data_ptr()
+            if self.slot_node is not None:
+                g.slot_node = self.slot_node.data_ptr()
+            if self.blk_class is not None:
+                g.blk_class, g.blk_class_ptr, g.blk_class_stride = self.blk_class.data_ptr(), self.blk_class_ptr.data_ptr(), self.blk_class_stride
         return g
 
 
@@ -338,7 +347,8 @@ def expander_plan(perms, degree, batch_device=None, virt_nodes=0):
     E = N * d + n_virt_edges
     if not dup_free or mode == "off" or not (_hybrid_worth_it(n, N * d, E, G * n * n) or mode == "force"):
         batch = torch.arange(G, device=dev).repeat_interleave(n)
-        return build_plan(edge_list(), batch, V)                          # generic route (multi-edges, tiny graphs, ...)
+        # generic route (multi-edges, tiny graphs, ...): build_plan appends the virtual-node edges itself
+        return build_plan(expander.regular_edge_index(perms, d)[0], batch, V)
     # everything but the adjacency bits depends on the Batch SHAPE only: built once per (G, n, V, device)
     key = (G, n, V, str(dev))
     sh = _EXPANDER_SHAPES.get(key)
@@ -366,6 +376,8 @@ def expander_plan(perms, degree, batch_device=None, virt_nodes=0):
         if len(_EXPANDER_SHAPES) > 16:
             _EXPANDER_SHAPES.clear()
         _EXPANDER_SHAPES[key] = sh
+    if _expander_layout() == "banded" and int(sh["padded"][0]) <= 4096:
+        return _expander_plan_banded(perms, d, V, sh, edge_list, E)
     if dev.type == "cuda":
         # two launches: inverse permutations, then the bit rows (csrc/da_graph.hip)
         from . import _lib
@@ -391,6 +403,82 @@ def expander_plan(perms, degree, batch_device=None, virt_nodes=0):
 
 
 _EXPANDER_SHAPES = {}
+_EXPANDER_BANDS = {}
+
+
+def _expander_layout():
+    """"banded" (default): a graph's padded slots hold its nodes in POSITION order (position in the generator's permutation),
+    which turns the adjacency into a circulant band -- whole 32 x 32 blocks of pairs are empty or full, and the masked
+    attention skips / un-masks them (da_attn_opt.hip).  "natural" (DA_EXPANDER_LAYOUT=natural): slot order = node order, the
+    plan ``build_plan`` derives from the edge list (every block partial)."""
+    import os
+    return os.environ.get("DA_EXPANDER_LAYOUT", "banded")
+
+
+def band_adjacency(n, d, device):
+    """[n, n] bool, entry (a, b) = the nodes at positions a and b of an Exphander permutation are neighbours
+    (puzzle_dataset.py:115-152: positions p and (p - k) mod n, k = 1 .. d // 2, plus p and p + n / 2 for odd d)."""
+    a = torch.arange(n, device=device)
+    dist = (a[:, None] - a[None, :]) % n
+    cd = torch.minimum(dist, n - dist)
+    adj = (cd >= 1) & (cd <= d // 2)
+    if d % 2 == 1:
+        adj |= cd * 2 == n
+    return adj
+
+
+def block_classes(adj, padded):
+    """uint8 [padded / 32, stride]: class of every (32-row slab, 32-column block) of a [rows <= padded, cols <= padded] bool
+    adjacency (rows / columns beyond it count as "no edge"): 0 = empty, 1 = partial, 2 = full; stride = blocks per row
+    rounded up to 16 bytes."""
+    dev = adj.device
+    nb = padded // 32
+    stride = (nb + 15) // 16 * 16
+    full = torch.zeros((padded, padded), dtype=torch.bool, device=dev)
+    full[: adj.shape[0], : adj.shape[1]] = adj
+    blk = full.view(nb, 32, nb, 32)
+    cls = blk.any(3).any(1).to(torch.uint8) + blk.all(3).all(1).to(torch.uint8)
+    out = torch.zeros((nb, stride), dtype=torch.uint8, device=dev)
+    out[:, :nb] = cls
+    return out.contiguous(), stride
+
+
+def _expander_plan_banded(perms, d, V, sh, edge_list, E):
+    """The banded layout of ``expander_plan``: per Batch only the node <-> slot maps are computed (two small index ops);
+    the adjacency bit rows and the block-class table live in SLOT space, where they depend on (n, d) alone -- ONE copy,
+    shared by every graph of every Batch of that shape (115 KB at n = 900: it stays in the L2)."""
+    dev = perms.device
+    G, n = perms.shape
+    N = G * n
+    padded = int(sh["padded"][0])
+    bkey = (n, d, padded, str(dev))
+    band = _EXPANDER_BANDS.get(bkey)
+    if band is None:
+        adj = band_adjacency(n, d, dev)
+        counts1 = torch.full((1,), n, dtype=torch.int64, device=dev)
+        mask, _ = _pack_mask(counts1, torch.full((1,), padded, dtype=torch.int64, device=dev), None, uniform_bool=adj[None])
+        cls, stride = block_classes(adj, padded)
+        band = dict(mask=mask, cls=cls, stride=stride)
+        if len(_EXPANDER_BANDS) > 16:
+            _EXPANDER_BANDS.clear()
+        _EXPANDER_BANDS[bkey] = band
+    perms = perms.to(torch.int64)
+    pos = torch.empty_like(perms)
+    pos.scatter_(1, perms, torch.arange(n, device=dev).expand(G, n))          # pos[g, node] = its position in the permutation
+    pad0 = sh["pad_ptr"][:-1].to(torch.int64)
+    row_map = (pad0[:, None] + pos).reshape(-1).to(torch.int32)
+    slot_node = torch.full((G, padded), -1, dtype=torch.int32, device=dev)
+    slot_node[:, :n] = (perms + (torch.arange(G, device=dev) * n)[:, None]).to(torch.int32)
+    if V > 0:
+        row_map = torch.cat([row_map, sh["row_map"][N:]])
+        slot_node[:, n:n + V] = (N + torch.arange(G, device=dev)[:, None] * V + torch.arange(V, device=dev)[None, :]).to(torch.int32)
+    zero_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    return GraphPlan(
+        n_pad=sh["n_pad"], pad_ptr=sh["pad_ptr"], row_map=row_map.contiguous(),
+        n_nodes=N + V * G, n_real=N, n_graphs=G, dense=0, n_edges=E, max_graph_nodes=n,
+        row_ptr=None, col_src=None, edge_id=None, graph_ptr=sh["graph_ptr32"], _edge_index=None,
+        edge_index_fn=edge_list, hybrid=1, mask=band["mask"], mask_ptr=zero_ptr, irr_row_ptr=sh["irr_ptr"], irr_col_src=sh["irr_src"],
+        slot_node=slot_node.reshape(-1).contiguous(), blk_class=band["cls"], blk_class_ptr=zero_ptr, blk_class_stride=band["stride"])
 
 
 def _detect_dense(edge_index, batch, counts):

@@ -125,6 +125,17 @@ typedef struct da_graph {
     const int64_t *mask_ptr;  /* [n_graphs + 1] byte offsets                               */
     const int32_t *irr_row_ptr; /* [n_nodes + 1] remainder CSR                             */
     const int32_t *irr_col_src; /* [remainder edges]                                       */
+    /* hybrid mode, optional (NULL = not given).  slot_node: the graph's padded slots may hold its nodes in any order
+     * (row_map[node] = slot); slot_node[slot] = node is the inverse (-1 for padding), and the adjacency rows / bits are
+     * then indexed by SLOT.  An Exphander graph (puzzle_dataset.py:115-152) laid out by its generator's permutation is a
+     * circulant band in slot space.  blk_class: per graph a table of one byte per (32-slot query slab, 32-slot key block):
+     * 0 = no regular edge, 1 = some, 2 = all 1024 pairs; rows of blk_class_stride bytes (a multiple of 4), graph g's table
+     * at byte blk_class_ptr[g] (graphs of one shape may share a table, and mask_ptr[] entries may coincide likewise).     */
+    const int32_t *slot_node;
+    const uint8_t *blk_class;
+    const int64_t *blk_class_ptr;
+    int32_t blk_class_stride;
+    int32_t reserved1;
 } da_graph;
 
 typedef struct da_denoiser da_denoiser;

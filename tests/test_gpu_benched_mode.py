@@ -538,20 +538,79 @@ def test_3d_module_p_sample_loop_and_eval_hooks(dev):
     assert len(out[0]) == 30
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_exo900_d539_banded_expander_plan_vs_reference_fixture(dev, golden2, prec):
+    """The SAME 900-piece Exphander d = 539 / exophormer V = 8 case as above, planned from the generator's permutation
+    (graph_plan.expander_plan, banded layout: slots in position order, shared slot-space adjacency bits, block classes --
+    the masked optimistic kernel skips the empty 32 x 32 blocks and runs the full ones un-masked) instead of from the edge
+    list: the reference's own output must come out (the permutation is the first n senders of generate_random_regular_graph's
+    edge list, puzzle_dataset.py:136-147), in the exact mode through k_attn_dense<MASKED> with the slot -> node map."""
+    spec = C.by_name("exo900_d539_v8")
+    case = C.build_case(spec)
+    ref = golden2["exo900_d539_v8/out"]
+    eng = make_engine(case, spec, prec, dev)
+    perm = case["edge_index"][0, :900].clone()
+    assert sorted(perm.tolist()) == list(range(900))
+    plan = eng.plan_expander(perm[None].to(dev), 539)
+    assert plan.hybrid == 1 and plan.slot_node is not None and plan.blk_class is not None and plan.n_edges == 493264
+    out = eng.forward(plan, case["x"].to(dev), case["t"].to(dev), case["feats"].to(dev))
+    assert rel(out, ref) < (RTOL32 if prec == "fp32" else RTOLBF)
+    if prec == "fp32":
+        assert rel_elem(out, ref) < ELEM32
+    # ... and equals the plan built from the edge list (natural slot order) to rounding
+    out_n = eng.forward(eng.plan(case["edge_index"], case["batch"]), case["x"].to(dev), case["t"].to(dev), case["feats"].to(dev))
+    assert rel(out, out_n) < (2e-5 if prec == "fp32" else RTOLBF)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("n,d,V,G,arch", [(900, 90, 8, 3, "exophormer"), (900, 539, 8, 2, "exophormer"), (320, 81, 4, 3, "exophormer"),
+                                           (256, 201, 0, 4, "transformer"), (1000, 31, 0, 1, "transformer")])
+def test_banded_expander_plans_equal_natural_plans(dev, monkeypatch, n, d, V, G, arch, prec):
+    """expander_plan in its two layouts (DA_EXPANDER_LAYOUT natural / banded) on several Batches: forwards and a 4-step
+    DDIM loop agree (fp32: 2e-5; bf16: within the bf16 bound), sparse degree (most key tiles skipped), odd degree (the
+    antipodal matching: a second diagonal of partial blocks), sizes that are not multiples of 32 / 64, no virtual nodes."""
+    monkeypatch.setenv("DA_HYBRID", "force")
+    from diffassemble_amd import DenoiserEngine, Schedule, _lib, expander
+    from oracle import diffusion as ODF
+    from oracle import weights as OW
+    sd = OW.make_denoiser_state(100, 4, 4, D=1152, hidden=128, variant="2d", arch=arch, virt_nodes=V, seed=n + d, qk_gain=3.0)
+    eng = DenoiserEngine(sd, variant="2d", arch=arch, virt_nodes=V, precision=prec, device=dev)
+    perms = expander.draw_permutations(n, G, np.random.default_rng(d)).to(dev)
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(G * n, 4, generator=g).to(dev)
+    feats = torch.randn(G * n, 1088, generator=g).to(dev)
+    t = torch.randint(0, 100, (G,), generator=g).repeat_interleave(n).to(dev)
+    outs, trajs = [], []
+    for layout in ("natural", "banded"):
+        monkeypatch.setenv("DA_EXPANDER_LAYOUT", layout)
+        plan = eng.plan_expander(perms, d)
+        assert plan.hybrid == 1 and (plan.slot_node is not None) == (layout == "banded")
+        outs.append(eng.forward(plan, x, t, feats).clone())
+        sch = Schedule(ODF.make_schedule(100), dev)
+        traj, _ = eng.sample_loop(plan, sch, x, feats, ratio=25, mean_type=_lib.MEAN_START_X, use_graph=True)
+        trajs.append(traj.clone())
+    tol = 2e-5 if prec == "fp32" else RTOLBF
+    assert torch.isfinite(outs[1]).all()
+    assert rel(outs[1], outs[0]) < tol
+    assert rel(trajs[1], trajs[0]) < (1e-4 if prec == "fp32" else 2 * RTOLBF)
+
+
+@pytest.mark.parametrize("layout", ["natural", "banded"])
 @pytest.mark.parametrize("n,d,V,G", [(900, 539, 8, 3), (900, 90, 8, 2), (320, 81, 4, 2), (256, 200, 0, 4)])
-def test_expander_mask_kernel_equals_host_closed_form(dev, n, d, V, G, monkeypatch):
+def test_expander_mask_kernel_equals_host_closed_form(dev, n, d, V, G, layout, monkeypatch):
     """graph_plan.expander_plan on the device (da_expander_mask: inverse permutations + bit rows, two launches; the
     shape-only parts cached) against the same function on host tensors (torch closed form, itself checked against the plan
     built from the reference generator's edge list in tests/test_host.py): every plan array bit for bit, odd degrees and
     a second Batch of the same shape included."""
     monkeypatch.setenv("DIFFASSEMBLE_HYBRID", "force")
+    monkeypatch.setenv("DA_EXPANDER_LAYOUT", layout)         # natural: da_expander_mask builds the bit rows; banded: index maps only
     from diffassemble_amd import expander, graph_plan as GP
     for seed in (0, 1):
         perms = expander.draw_permutations(n, G, np.random.default_rng(seed))
         a = GP.expander_plan(perms.to(dev), d, virt_nodes=V)
         b = GP.expander_plan(perms, d, virt_nodes=V)
         assert a.hybrid == b.hybrid == 1 and a.n_edges == b.n_edges and a.n_pad == b.n_pad
-        for f in ("mask", "mask_ptr", "row_map", "pad_ptr", "graph_ptr", "irr_row_ptr", "irr_col_src"):
+        for f in ("mask", "mask_ptr", "row_map", "pad_ptr", "graph_ptr", "irr_row_ptr", "irr_col_src") + (("slot_node", "blk_class", "blk_class_ptr") if layout == "banded" else ()):
             assert torch.equal(getattr(a, f).cpu(), getattr(b, f)), (f, seed)
 
 
@@ -560,6 +619,7 @@ def test_expander_mask_kernel_odd_sizes(dev, n, d, G, monkeypatch):
     """Node counts that are not multiples of 8 / 64 (ragged last mask byte), the densest degree (n - 1), odd degrees (the
     antipodal matching needs an even n) and a sparse one under the forced hybrid mode: device plan == host closed form."""
     monkeypatch.setenv("DIFFASSEMBLE_HYBRID", "force")
+    monkeypatch.setenv("DA_EXPANDER_LAYOUT", "natural")
     from diffassemble_amd import expander, graph_plan as GP
     perms = expander.draw_permutations(n, G, np.random.default_rng(n + d))
     a, b = GP.expander_plan(perms.to(dev), d, virt_nodes=4), GP.expander_plan(perms, d, virt_nodes=4)

@@ -306,6 +306,7 @@ def test_expander_plan_closed_form_equals_plan_from_edge_list(monkeypatch):
     build_plan keeps duplicated / cross-graph edges on the CSR side."""
     from diffassemble_amd import expander, graph_plan as GP
     monkeypatch.setenv("DA_HYBRID", "force")
+    monkeypatch.setenv("DA_EXPANDER_LAYOUT", "natural")          # slot order = node order: the layout build_plan produces
     rng = np.random.default_rng(5)
     perms = expander.draw_permutations(70, 3, rng)
     for d, V in ((10, 4), (7, 0), (20, 8)):
@@ -332,3 +333,48 @@ def test_expander_plan_closed_form_equals_plan_from_edge_list(monkeypatch):
     assert p.hybrid == 1
     assert p.irr_col_src.numel() == 100 + 2                      # both copies of a duplicated pair + the cross-graph edges
     assert int(np.unpackbits(p.mask.numpy()).sum()) == ei.shape[1] - 50
+
+
+def test_expander_plan_banded_layout_is_the_natural_plan_relabelled(monkeypatch):
+    """The default layout of graph_plan.expander_plan orders a graph's padded slots by the nodes' POSITIONS in the generator's
+    permutation (puzzle_dataset.py:136: nodes = rng.permutation(n); neighbours are positions p and (p - k) mod n): row_map /
+    slot_node are inverse maps, the slot-space adjacency bits are the natural plan's bits relabelled (one shared copy: they
+    depend on (n, d) only), the remainder CSR is untouched (node indices), and the block-class table says exactly which
+    32 x 32 blocks of slot pairs are empty / partial / full -- odd degree (antipodal matching) and virtual nodes included."""
+    from diffassemble_amd import expander, graph_plan as GP
+    monkeypatch.setenv("DA_HYBRID", "force")
+    rng = np.random.default_rng(9)
+    for n, G, d, V in ((70, 3, 10, 4), (100, 2, 7, 0), (200, 2, 121, 8), (96, 2, 40, 0)):
+        perms = expander.draw_permutations(n, G, rng)
+        monkeypatch.setenv("DA_EXPANDER_LAYOUT", "natural")
+        pn = GP.expander_plan(perms, d, virt_nodes=V)
+        monkeypatch.setenv("DA_EXPANDER_LAYOUT", "banded")
+        pb = GP.expander_plan(perms, d, virt_nodes=V)
+        assert pn.slot_node is None and pb.slot_node is not None and pb.hybrid == pn.hybrid == 1
+        for f in ("irr_row_ptr", "irr_col_src", "pad_ptr", "graph_ptr"):
+            assert torch.equal(getattr(pn, f), getattr(pb, f)), f
+        assert (pn.n_edges, pn.n_nodes, pn.n_pad) == (pb.n_edges, pb.n_nodes, pb.n_pad)
+        assert torch.equal(pn.edge_index, pb.edge_index)
+        padded = int(pb.pad_ptr[1] - pb.pad_ptr[0])
+        stride = padded // 8
+        # inverse maps; padding slots are -1; virtual rows sit behind the real ones in both layouts
+        assert torch.equal(pb.slot_node[pb.row_map.long()], torch.arange(pb.n_nodes, dtype=torch.int32))
+        assert int((pb.slot_node >= 0).sum()) == pb.n_nodes
+        assert torch.equal(pb.row_map[G * n:], pn.row_map[G * n:])
+        for g in range(G):
+            pos = torch.empty(n, dtype=torch.long)
+            pos[perms[g]] = torch.arange(n)
+            assert torch.equal(pb.row_map[g * n:(g + 1) * n].long(), int(pb.pad_ptr[g]) + pos)
+            nat = np.unpackbits(pn.mask[int(pn.mask_ptr[g]):int(pn.mask_ptr[g]) + n * stride].numpy().reshape(n, stride), axis=-1, bitorder="little")[:, :padded]
+            ban = np.unpackbits(pb.mask[int(pb.mask_ptr[g]):int(pb.mask_ptr[g]) + n * stride].numpy().reshape(n, stride), axis=-1, bitorder="little")[:, :padded]
+            assert not ban[:, n:].any()                                  # no bit beyond the real slots
+            assert np.array_equal(nat[:, :n], ban[pos.numpy()][:, pos.numpy()])      # adjacency(node i, node j) = band(pos i, pos j)
+            # block classes against the brute-force count of the bits
+            full = np.zeros((padded, padded), dtype=np.uint8)
+            full[:n] = ban
+            cnt = full.reshape(padded // 32, 32, padded // 32, 32).sum((1, 3))
+            want = (cnt > 0).astype(np.uint8) + (cnt == 1024).astype(np.uint8)
+            tab = pb.blk_class[int(pb.blk_class_ptr[g]):].numpy()[: (padded // 32) * pb.blk_class_stride].reshape(padded // 32, pb.blk_class_stride)
+            assert np.array_equal(tab[:, : padded // 32], want) and not tab[:, padded // 32:].any()
+        assert pb.blk_class_stride % 4 == 0
+
