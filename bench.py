@@ -50,7 +50,7 @@ F_NODE = 6_432_128          # FLOP per piece per step (SURVEY 8d / BASELINE.md)
 F_EDGE = 7_680              # FLOP per edge per step, all 4 layers
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0                            # MI355X_MICROARCH.md (HBM3E spec; ~6300 achievable)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 CONFIGS = {
     "1": dict(name="6x6 translation-only (N=36, K36 without self loops, E=1260), DDIM T=50, EPSILON, c=2, transformer arch",
@@ -151,6 +151,11 @@ def roofline_report(prof, kp, work, prec, traffic_file, cfg_key, G, gather_path=
         pmc = json.load(open(traffic_file)).get(cfg_key, {}).get(prec, {}).get(str(G), {})
     except (OSError, ValueError):
         pass
+    sq = {}
+    try:    # SQ counters of the attention kernels at this launch shape (tools/collect_attn_pmc.sh -> profiles/<round>/pmc_attention_sq.json)
+        sq = json.load(open(os.path.join(os.path.dirname(traffic_file), "pmc_attention_sq.json"))).get(prec, {}).get(str(G), {})
+    except (OSError, ValueError):
+        pass
     classes = {}
     for k, (ms, n) in prof.items():
         if not n or k not in work:
@@ -171,6 +176,9 @@ def roofline_report(prof, kp, work, prec, traffic_file, cfg_key, G, gather_path=
             t = (2.0 * pmc[k]["fetch_kib"] + pmc[k]["write_kib"]) * 1024.0
             ent["pmc_traffic_bytes_per_launch"] = t
             ent["pmc_traffic_GBps"] = t / (ms / n * 1e-3) / 1e9
+        if k in sq:       # measured: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x the SAME run's kernel duration x 2.4 GHz)
+            ent["mfma_busy_counter"] = sq[k]["mfma_busy"]
+            ent["mfma_busy_counter_source"] = sq[k]["source"]
         classes[k] = ent
     dom = max(classes, key=lambda k: classes[k]["time_share"])
     d = classes[dom]
@@ -282,6 +290,18 @@ def cpu_baseline(cfg, sd, degree, full=False):
         out["value_1_thread"] = 1.0 / steps(real, k_real)
     else:
         out["value_1_thread"] = None
+        # one thread at N = 900 takes minutes per step: not re-measured in the default run; the committed full-size measurement
+        # (python bench.py --cpu-baseline-full, profiles/<round>/<round>_bench_config_3p_cpu_1_thread.json) is quoted instead
+        for rnd in (PROFILE_ROUND, "r03"):
+            try:
+                ref = json.load(open(os.path.join(ROOT, "profiles", rnd, f"{rnd}_bench_config_3p_cpu_1_thread.json")))
+                v1 = ref["cpu_baseline"]["value_1_thread"]
+                if v1 and cfg["graph"] == "dense" and n == 900:
+                    out["value_1_thread"] = v1
+                    out["value_1_thread_source"] = f"profiles/{rnd}/{rnd}_bench_config_3p_cpu_1_thread.json (measured with --cpu-baseline-full on a box of the same pool; not re-timed in this run)"
+                    break
+            except (OSError, ValueError, KeyError, TypeError):
+                continue
         out["value_1_thread_note"] = "k=1 at N=900 takes minutes: see thread_sweep['1'] (N=300) or run --cpu-baseline-full"
     torch.set_num_threads(allc)
     return out
@@ -810,15 +830,48 @@ def sample_bench(args, world, rank, dev):
     flags = int(eng.flags)
     if not args.no_roofline:
         kp = min(K, 20, its)
-        eng.profile(True)
-        run(kp, False)
-        prof = eng.profile_read()
-        eng.profile(False)
-        work = work_model(cfg, G, E, plan.n_nodes, flags, prec, bool(plan.hybrid), prof.get("conv_fused", (0, 0))[1] > 0)
         tf = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic.json")
         pmc_key = args.config + (f"_d{args.degree}" if cfg["graph"] == "regular" else "")
-        roof = roofline_report(prof, kp, work, prec, tf, pmc_key, G, gather_path=not (plan.dense or plan.hybrid))
-        roof["whole_step_tflops_in_kernels"] = sum(w["alg"] for w in work.values()) / (roof["kernel_ms_per_step"] * 1e-3) / 1e12
+        two_branch = eng._two_branch(plan, False, True)
+
+        def profile_pass(p, Gp, feats_p, x_p):
+            """HIP events around every launch of an eager pass over plan `p` -> the per-class roofline report."""
+            eng.set_features(p, feats_p)
+            eng.sample_loop(p, sch, x_p, feats_p, ratio=cfg["ratio"], mean_type=mt, max_iters=2, keep_trajectory=False, use_graph=False, restage=False)
+            eng.profile(True)
+            eng.sample_loop(p, sch, x_p, feats_p, ratio=cfg["ratio"], mean_type=mt, max_iters=kp, keep_trajectory=False, use_graph=False, restage=False)
+            prof_ = eng.profile_read()
+            eng.profile(False)
+            work_ = work_model(cfg, Gp, int(p.n_edges), p.n_nodes, flags, prec, bool(p.hybrid), prof_.get("conv_fused", (0, 0))[1] > 0)
+            r = roofline_report(prof_, kp, work_, prec, tf, pmc_key, Gp, gather_path=not (p.dense or p.hybrid))
+            r["whole_step_tflops_in_kernels"] = sum(w["alg"] for w in work_.values()) / (r["kernel_ms_per_step"] * 1e-3) / 1e12
+            return r
+
+        if two_branch:
+            # The timed graph replays da_sample_loop_pair: every kernel TWICE per step at HALF the Batch, on two concurrent
+            # branches.  The roofline therefore describes that launch shape: an eager pass over the first half Batch alone
+            # (per-launch figures of the shape that runs; inside the graph the two branches share the chip, so a launch takes
+            # longer there -- which no per-kernel timer can see: rocprof serialises the branches).  Reconciliation:
+            # kernel_ms_per_step_per_branch <= ms_per_step <= kernel_ms_per_step (= both branches back to back).
+            from diffassemble_amd.graph_plan import split_complete
+            pa, _, n0 = split_complete(plan, plan.n_graphs // 2)
+            roof = profile_pass(pa, pa.n_graphs, feats[:n0].contiguous(), x_T[:n0].contiguous())
+            roof["launch_shape"] = f"half Batch ({pa.n_graphs} puzzles per launch): what each branch of the timed two-branch graph replays"
+            roof["kernel_ms_per_step_per_branch"] = roof["kernel_ms_per_step"]
+            roof["kernel_ms_per_step"] = 2.0 * roof["kernel_ms_per_step_per_branch"]
+            roof["branch_overlap"] = {"ms_per_step_timed_graph": dt / K * 1e3, "both_branches_back_to_back_ms": roof["kernel_ms_per_step"],
+                                      "gain": roof["kernel_ms_per_step"] / (dt / K * 1e3)}
+            full = profile_pass(plan, G, feats, x_T)
+            roof["one_branch_full_batch"] = {"note": f"the same step as ONE branch at {G} puzzles per launch (DA_TWO_BRANCH=0 runs this), eager pass",
+                                             "kernel_ms_per_step": full["kernel_ms_per_step"],
+                                             "classes": {k: {"avg_launch_us": v["avg_launch_us"], "us_per_step": v["us_per_step"],
+                                                             "frac_mfma_peak_alg": v["frac_mfma_peak_alg"], "frac_mfma_peak_exec": v["frac_mfma_peak_exec"],
+                                                             **({"mfma_busy_counter": v["mfma_busy_counter"]} if "mfma_busy_counter" in v else {})}
+                                                         for k, v in full["classes"].items()},
+                                             "attention_total": full.get("attention_total")}
+        else:
+            roof = profile_pass(plan, G, feats, x_T)
+            roof["launch_shape"] = f"whole Batch ({G} puzzles per launch), one branch: what the timed graph replays"
         roof["folds"] = {"mlp2_composed": bool(flags & 1), "value_heads_folded": bool(flags & 2)}
         try:        # measured ceilings of the box (tools/measure_peaks.py)
             mp = json.load(open(os.path.join(ROOT, "profiles", "r01", "measured_peaks.json")))

@@ -36,6 +36,7 @@ struct AttnDenseParams {
     const unsigned char *blk_class; // hybrid: class of every (32-query slab, 32-key block) of a graph: 0 empty, 1 partial, 2 full (or null)
     const long long *blk_class_ptr; // [G + 1] byte offsets of the graphs' class tables
     int blk_class_stride;           // bytes per slab row of a class table
+    const int32_t *rm_meta;         // hybrid: [n_pad][4] per-slot { remainder begin, end, slot of the first remainder source, node } (or null)
     void *fold_out;                 // CV != C: [H][n_rows][CV] normalised per-head outputs in the activation dtype (no skip / activation here)
     int n_rows;
 };

@@ -883,6 +883,7 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.slot_node = mk ? mk->slot_node : nullptr;
     p.blk_class = mk ? mk->blk_class : nullptr; p.blk_class_ptr = mk ? (const long long *)mk->blk_class_ptr : nullptr;
     p.blk_class_stride = mk ? mk->blk_class_stride : 0;
+    p.rm_meta = mk ? mk->rm_meta : nullptr;
     { const char *e = getenv("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
     { static int fg = -1; if (fg < 0) { const char *e = getenv("DA_ATTN_FORCE_GEN"); fg = (e && e[0] == '1') ? 1 : 0; } p.force_gen = fg; if (fg) p.fast = p.fast ? 2 : 0; }
     { const char *e = getenv("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }

@@ -23,11 +23,14 @@
 //     window) while the reference adds its epsilon to sum exp(a - max) >= 1, where it is below fp32 resolution.  The GEN
 //     pass keeps its sum >= 1 and PyG's formula;
 //   * MASKED: the adjacency bits enter as the initial value of the S^T accumulator (0 / -inf from a 16-entry LDS table,
-//     k_attn_dense's scheme); exp2(-inf) = 0 needs no special case.  The lane's adjacency words travel through plain
-//     global loads issued as inline asm one tile ahead, so that the compiler's own s_waitcnt for them (a vmcnt(0) at the top
-//     of every tile, which serialised the K / V DMA ring of k_attn_dense<MASKED>) is replaced by the counted wait the ring
-//     uses anyway.  The state handed to the remainder-edge epilogue is re-referenced to (ln(sum), 1): rows normalised by
-//     their dense part, so the epilogue's own online softmax starts from a sum of 1 whatever the logits' offset.
+//     k_attn_dense's scheme); exp2(-inf) = 0 needs no special case.  The adjacency words ride the K / V ring: one more
+//     LDS-DMA instruction per wave and tile (4 bytes per lane: the 32 bits of the lane's query row for one of the tile's two
+//     key blocks) into a wave-private 256-byte slot of the stage, read back with two ds_read_u16 after the tile's wait.  As
+//     ordinary global loads they cost the compiler's own `s_waitcnt vmcnt(0)` in front of every tile (k_attn_dense<MASKED>:
+//     the DMA ring is drained every tile); as inline-asm loads the register allocator, which cannot know that their
+//     destination is written asynchronously, reused it for DMA addresses (a memory fault, found the hard way).  The state
+//     handed to the remainder-edge epilogue is re-referenced to (ln(sum), 1): rows normalised by their dense part, so the
+//     epilogue's own online softmax starts from a sum of 1 whatever the logits' offset.
 #include <stdlib.h>
 
 #include "da_attn_common.h"
@@ -45,8 +48,10 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     static_assert(CF::NCB == 1, "one 32-channel value block");
     constexpr int MAXI = (CF::NI + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *flags = (int *)(smem + NST * CF::STAGE);               // one word per wave: "my optimistic pass failed"; [4 .. 11]: the waves' tile masks
-    float *mlut = (float *)(smem + NST * CF::STAGE + 64);       // MASKED: nibble -> four accumulator initial values
+    constexpr int MSTAGE = CF::STAGE + (MASKED ? 1024 : 0);     // MASKED: + the four waves' adjacency-word slots (256 B each)
+    int *flags = (int *)(smem + NST * MSTAGE);                  // one word per wave: "my optimistic pass failed"; [4 .. 11]: the waves' tile masks
+    float *mlut = (float *)(smem + NST * MSTAGE + 64);          // MASKED: nibble -> four accumulator initial values
+    unsigned char *lcls = smem + NST * MSTAGE + 64 + 256;       // MASKED: the four waves' block-class rows (128 B each)
     if (MASKED && threadIdx.x < 64) {
         const int e = threadIdx.x >> 2, b = threadIdx.x & 3;
         mlut[threadIdx.x] = ((e >> b) & 1) ? 0.f : -INFINITY;
@@ -89,8 +94,9 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         }
         soff[x] = o;
     }
+    const unsigned char *mrow4 = nullptr;       // MASKED: this lane's source of the adjacency-word DMA (set below)
     auto issue = [&](int kt, int stage) {
-        unsigned char *sb = smem + stage * CF::STAGE;
+        unsigned char *sb = smem + stage * MSTAGE;
         const unsigned char *kb_ = Kg + (size_t)kt * CF::BKEYS * CF::ROWB;
         const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ROWBV;
 #pragma unroll
@@ -102,8 +108,11 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                                                  (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
             }
         }
+        if (MASKED)         // lane (i, half) fetches the 32 adjacency bits of query row i for key block `half` of the tile
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(mrow4 + 8 * (size_t)kt),
+                                             (__attribute__((address_space(3))) void *)(sb + CF::STAGE + wid * 256), 4, 0, 0);
     };
-    const int myn = (CF::NI - wid + NW - 1) / NW;             // DMA instructions this wave issues per tile
+    const int myn = (CF::NI - wid + NW - 1) / NW + (MASKED ? 1 : 0);      // DMA instructions this wave issues per tile
     const int nkt = (n_g + CF::BKEYS - 1) / CF::BKEYS;
     const int qidx = q0 + i;
     const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);
@@ -113,7 +122,8 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     // MASKED: this lane's row of the adjacency bit matrix (bit j = edge j -> this query); the 8 bytes of key tile kt sit at
-    // mrow + 8 kt (rows are 8-byte aligned: the padded slot count is a multiple of 64).  Remainder-edge metadata of the four
+    // mrow + 8 kt (rows are 8-byte aligned: the padded slot count is a multiple of 64); waves without queries fetch the
+    // graph's last row (every wave issues the same number of DMA instructions per tile).  Remainder-edge metadata of the four
     // queries this 8-lane group finishes in the epilogue.
     // Slots vs nodes.  Rows of Q / K / V and of the adjacency matrix live in SLOT space (the padded per-graph row ranges the
     // projection scatters into through row_map).  Normally slot pad0 + i holds node node0 + i; an expander plan in the banded
@@ -123,9 +133,25 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     auto node_of = [&](int ql) { return (MASKED && p.slot_node) ? p.slot_node[pad0 + ql] : node0 + ql; };       // ql < n_g
     const unsigned char *mrow = nullptr;
     int rm_beg[4] = {0, 0, 0, 0}, rm_end[4] = {0, 0, 0, 0}, rm_slot[4] = {0, 0, 0, 0};
+    int my_node = node0 + min(qidx, n_g - 1);       // MASKED: the node this lane's query slot holds (for the epilogue's row addresses)
     if (MASKED) {
         mrow = p.mask + p.mask_ptr[g] + (size_t)min(qidx, n_g - 1) * (size_t)((p.pad_ptr[g + 1] - pad0) >> 3);
-        if (wave_on) {
+        if (wave_on && p.rm_meta) {
+            // one 16-byte record per query (da_graph.rm_meta), none of it needed before the epilogue: the loads stay in flight
+            // under the key loop.  (Walking slot_node -> irr_row_ptr -> irr_col_src -> row_map here, and waiting for it, put four
+            // dependent L2 round trips in front of every workgroup: ~14 of the ~19 us a workgroup lived at d = 90.)
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            const i32x4 *meta = (const i32x4 *)p.rm_meta + pad0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qg = qt * QT + wid * 32 + (lane >> 3) + 8 * r;
+                const i32x4 mt = meta[min(qg, n_g - 1)];
+                rm_beg[r] = qg < n_g ? mt[0] : 0;
+                rm_end[r] = qg < n_g ? mt[1] : 0;
+                rm_slot[r] = mt[2];
+            }
+            my_node = ((const int *)(meta + min(qidx, n_g - 1)))[3];
+        } else if (wave_on) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qg = qt * QT + wid * 32 + (lane >> 3) + 8 * r;
@@ -137,14 +163,10 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                 rm_slot[r] = pad0;                                       // any valid slot when there is no edge
                 if (rm_end[r] > rm_beg[r]) rm_slot[r] = p.row_map[p.irr_col_src[rm_beg[r]]];
             }
+            my_node = node_of(min(qidx, n_g - 1));
         }
     }
-    // adjacency words of one key tile, requested as inline asm (see the header): the destination is only valid after a
-    // counted wait that covers it
-    // ("+v": the loop-carried word keeps ONE register across the asm, so no copy of it can be scheduled before its wait)
-    auto mask_load = [&](u32x2 &r, int kt) {
-        asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(r) : "v"(mrow + 8 * (size_t)kt) : "memory");
-    };
+    if (MASKED) mrow4 = mrow + 4 * half;
 
     // MASKED with block classes (da_graph.blk_class: per 32-query slab and 32-key block 0 = no edge, 1 = some, 2 = all): a wave
     // skips the empty blocks of its slab outright, runs the full ones without the adjacency words, and the workgroup walks only
@@ -156,11 +178,16 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     if (MASKED) {
         tmask = nkt >= 64 ? ~0ull : ((1ull << nkt) - 1ull);
         if (p.blk_class) {
-            crow = p.blk_class + p.blk_class_ptr[g] + (size_t)(qt * 4 + wid) * (size_t)p.blk_class_stride;
+            // the wave's class row goes to LDS once (a per-tile global load of it would put a compiler-managed vmcnt(0) in
+            // front of every tile and drain the DMA ring: measured, that cancelled the whole gain of the skipped blocks)
+            const unsigned char *grow = p.blk_class + p.blk_class_ptr[g] + (size_t)(qt * 4 + wid) * (size_t)p.blk_class_stride;
+            crow = lcls + wid * 128;
+            if (lane < 32) ((unsigned *)crow)[lane] = (4 * lane < p.blk_class_stride) ? ((const unsigned *)grow)[lane] : 0u;
+            __syncthreads();
             unsigned long long mine = 0;
             if (wave_on) {
                 for (int dw = 0; 2 * dw < nkt; ++dw) {             // one dword = four blocks = two tiles
-                    const unsigned c4 = *(const unsigned *)(crow + 4 * dw);
+                    const unsigned c4 = ((const unsigned *)crow)[dw];
                     if (c4 & 0xffffu) mine |= 1ull << (2 * dw);
                     if (c4 >> 16) mine |= 1ull << (2 * dw + 1);
                 }
@@ -191,12 +218,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         ls = 0.f;
         m = -1e30f;
         anym = 0;
-        if (MASKED && wave_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // remainder metadata landed: the counted waits below start from zero
-        // Order of this wave's VMEM operations: [M(0)] D(0) D(1) .. D(NST-2) | tile kt: [M(kt+1)] D(kt+NST-1).  MASKED waves
-        // wait for M(kt+1) at the top of tile kt + 1, i.e. for everything but D(kt+NST-1): one tile less in flight than the ring holds.
         unsigned long long rem_cur = tmask, rem_pf = tmask;
-        u32x2 mw_nxt = {0u, 0u};
-        if (MASKED && wave_on && ntl > 0) mask_load(mw_nxt, __builtin_ctzll(tmask));
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < ntl) issue(next_tile(rem_pf, st), st);
@@ -204,27 +226,19 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             const int kt = next_tile(rem_cur, j);
             {
                 // tiles that may stay in flight behind this one (each is `myn` operations of this wave; myn is LO or LO + 1)
-                int younger = min(ntl - 1 - j, NST - 2);
-                // MASKED: M(j) must have landed too, and the only operation behind it is D(j + NST - 2), issued right after it
-                if (MASKED && wave_on && j > 0) younger = (NST > 2 && j + NST - 2 < ntl) ? 1 : 0;
-                constexpr int LO = CF::NI / NW;
+                constexpr int LO = CF::NI / NW + (MASKED ? 1 : 0);
+                const int younger = min(ntl - 1 - j, NST - 2);
                 if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (younger == 1) { if (myn == LO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO + 1) : "memory"); }
-                else if (younger == 2) { if (myn == LO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LO) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LO + 2) : "memory"); }
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (NST <= 4: not reached)
+                else { if (myn == LO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LO) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LO + 2) : "memory"); }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-            }
-            u32x2 mw_cur = {0u, 0u};
-            if (MASKED && wave_on) {
-                mw_cur = mw_nxt;                                              // landed (covered by the wait above)
-                if (j + 1 < ntl) mask_load(mw_nxt, __builtin_ctzll(rem_cur));  // the next tile of the walk
             }
             if (j + NST - 1 < ntl) issue(next_tile(rem_pf, j + NST - 1), (j + NST - 1) % NST);
             if (!wave_on) continue;
             // classes of this slab's two blocks in the tile (1 = partial when the plan has no class table)
-            const unsigned cls2 = (MASKED && crow) ? *(const unsigned short *)(crow + 2 * kt) : 0x0101u;
-            const unsigned char *stg = smem + (j % NST) * CF::STAGE;
+            const unsigned cls2 = (MASKED && crow) ? (unsigned)__builtin_amdgcn_readfirstlane((int)*(const unsigned short *)(crow + 2 * kt)) : 0x0101u;
+            const unsigned char *stg = smem + (j % NST) * MSTAGE;
 #pragma unroll
             for (int kb = 0; kb < CF::KB; ++kb) {
                 const int key0 = kt * CF::BKEYS + kb * 32;
@@ -241,7 +255,8 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[r] = 0.f;
                 } else if (MASKED) {
-                    const unsigned mw = (mw_cur[kb] >> (16 * half)) & 0xffffu;      // this lane's 16 keys of the block
+                    // this lane's 16 keys of the block: half `half` of the dword lane (i, kb) fetched for the tile
+                    const unsigned mw = *(const unsigned short *)(stg + CF::STAGE + wid * 256 + (kb * 32 + i) * 4 + 2 * half);
                     anym |= mw;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
 #pragma unroll
                 for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), kf[ch], qf[ch], s);
                 u32x2 vlo[2], vhi[2];
-                const unsigned vb = lds0 + (unsigned)((j % NST) * CF::STAGE + vbase + kb * 32 * CF::RSV);
+                const unsigned vb = lds0 + (unsigned)((j % NST) * MSTAGE + vbase + kb * 32 * CF::RSV);
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm) {
                     vlo[mm] = tr_read(vb, (8 * mm) * CF::RSV);
@@ -353,16 +368,17 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         return;
     }
     constexpr int CO = CV, RSOF = CO + 4;
-    static_assert(QT * RSOF * 4 <= NST * CF::STAGE, "O staging must fit in the K/V ring");
+    static_assert(QT * RSOF * 4 <= NST * MSTAGE, "O staging must fit in the K/V ring");
     float *so = (float *)smem;
     dma_barrier();
     if (wave_on) {
         float *orow = so + (wid * 32 + i) * RSOF;
         if (MASKED && half == 0) {
             // state for the remainder edges, re-referenced to (ln(sum), 1): reference in nat, rows already normalised by
-            // their dense part
+            // their dense part; and the row's node, for the output addresses below
             orow[CO] = lt > 0.f ? (gen ? m : 0.f) * 0.6931471805599453f + __logf(lt) : 0.f;
             orow[CO + 1] = lt > 0.f ? 1.0f : 0.f;
+            orow[CO + 2] = __builtin_bit_cast(float, my_node);
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             const float ir = lr > 0.f ? 1.0f / (lr + 1e-16f) : 0.f;
             const f32x4 a = *(const f32x4 *)(so + q * RSOF + ch * 4);
             const float v4[4] = {a[0] * ir, a[1] * ir, a[2] * ir, a[3] * ir};
-            st4((T *)p.fold_out + ((size_t)h * p.n_rows + node_of(qt * QT + q)) * CV + ch * 4, v4);
+            st4((T *)p.fold_out + ((size_t)h * p.n_rows + __builtin_bit_cast(int, so[q * RSOF + CO + 2])) * CV + ch * 4, v4);
         }
         return;
     }
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             const int it = it0 + NT * k;
             if (it < nq * CPR) {
                 const int q = it / CPR, ch = it - q * CPR;
-                const size_t off = (size_t)node_of(qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                const size_t off = (size_t)(MASKED ? __builtin_bit_cast(int, so[q * RSOF + CO + 2]) : node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
                 skv[k] = *(const u32x4 *)((const T *)p.S + off);
                 if (p.res) rsv[k] = *(const u32x4 *)((const T *)p.res + off);
             }
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             const int it = it0 + NT * k;
             if (it < nq * CPR) {
                 const int q = it / CPR, ch = it - q * CPR;
-                const size_t off = (size_t)node_of(qt * QT + q) * HC + (size_t)h * C + ch * EPC;
+                const size_t off = (size_t)(MASKED ? __builtin_bit_cast(int, so[q * RSOF + CO + 2]) : node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC;
                 const float *src = so + q * RSOF + ch * EPC;
                 float v[EPC], sk[EPC];
                 const f32x4 a = *(const f32x4 *)src, b2 = *(const f32x4 *)(src + 4);
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
 template <int C, bool FOLD, bool MASKED, int NST, int MINB>
 static int launch_optt(AttnDenseParams p, hipStream_t st) {
     using CF = Cfg<bf16_t, C, 32>;
-    const int lds = NST * CF::STAGE + 64 + (MASKED ? 256 : 0);
+    const int lds = NST * (CF::STAGE + (MASKED ? 1024 : 0)) + 64 + (MASKED ? 256 + 512 : 0);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_optt<C, FOLD, MASKED, NST, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -113,11 +113,13 @@ struct DenseMask {             // hybrid mode: adjacency bits of the regular edg
     const uint8_t *blk_class = nullptr;            // block classes (da_graph.blk_class*)
     const int64_t *blk_class_ptr = nullptr;
     int blk_class_stride = 0;
+    const int32_t *rm_meta = nullptr;              // per-slot remainder metadata (da_graph.rm_meta)
 };
 inline DenseMask dense_mask_of(const da_graph *g) {
     DenseMask mk;
     mk.mask = g->mask; mk.mask_ptr = g->mask_ptr; mk.irr_row_ptr = g->irr_row_ptr; mk.irr_col_src = g->irr_col_src; mk.row_map = g->row_map;
     mk.slot_node = g->slot_node;
+    mk.rm_meta = g->rm_meta;
     const bool cls = g->blk_class && g->blk_class_ptr && g->blk_class_stride > 0;
     mk.blk_class = cls ? g->blk_class : nullptr; mk.blk_class_ptr = cls ? g->blk_class_ptr : nullptr; mk.blk_class_stride = cls ? g->blk_class_stride : 0;
     return mk;

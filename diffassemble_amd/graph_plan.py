@@ -73,6 +73,7 @@ class GraphPlan:
     blk_class: torch.Tensor = None     # uint8: per (32-slot query slab, 32-slot key block) 0 = no regular edge, 1 = some, 2 = all
     blk_class_ptr: torch.Tensor = None  # int64 [G + 1] byte offsets of the graphs' class tables (graphs of one shape share one)
     blk_class_stride: int = 0
+    rm_meta: torch.Tensor = None       # int32 [n_pad, 4]: per slot (remainder begin, end, slot of the first remainder source, node)
 
     @property
     def edge_index(self):
@@ -140,9 +141,41 @@ class GraphPlan:
             g.irr_row_ptr, g.irr_col_src = self.irr_row_ptr.data_ptr(), self.irr_col_src.data_ptr()
             if self.slot_node is not None:
                 g.slot_node = self.slot_node.data_ptr()
+            if self.rm_meta is None:
+                self.rm_meta = _remainder_meta(self)
+            g.rm_meta = self.rm_meta.data_ptr()
             if self.blk_class is not None:
                 g.blk_class, g.blk_class_ptr, g.blk_class_stride = self.blk_class.data_ptr(), self.blk_class_ptr.data_ptr(), self.blk_class_stride
         return g
+
+
+def _remainder_meta(plan: GraphPlan):
+    """da_graph.rm_meta of a hybrid plan: int32 [n_pad, 4], one record per padded slot -- (begin, end) of the node's remainder
+    edges in irr_col_src, the slot of the first remainder source (any valid slot when there is none) and the node itself
+    (-1 for padding and virtual slots, whose rows the masked attention does not own).  Index arithmetic only."""
+    dev = plan.row_map.device
+    n_pad = int(plan.n_pad)
+    if plan.slot_node is not None:
+        sn = plan.slot_node.to(torch.int64)
+    else:
+        sn = torch.full((n_pad,), -1, dtype=torch.int64, device=dev)
+        sn[plan.row_map.to(torch.int64)] = torch.arange(plan.n_nodes, device=dev)
+    real = (sn >= 0) & (sn < plan.n_real)
+    nd = torch.where(real, sn, torch.zeros_like(sn))
+    rp = plan.irr_row_ptr.to(torch.int64)
+    beg, end = rp[nd], rp[nd + 1]
+    has = real & (end > beg)
+    n_irr = int(plan.irr_col_src.numel())
+    if n_irr > 0:
+        src = plan.irr_col_src.to(torch.int64)[torch.where(has, beg, torch.zeros_like(beg)).clamp(max=n_irr - 1)]
+        first = plan.row_map.to(torch.int64)[src]
+    else:
+        first = torch.zeros_like(sn)
+    slot = torch.arange(n_pad, device=dev)
+    first = torch.where(has, first, torch.where(real, slot, torch.zeros_like(slot)))      # own slot: always a valid row
+    z = torch.zeros_like(beg)
+    meta = torch.stack([torch.where(real, beg, z), torch.where(real, end, z), first, torch.where(real, sn, torch.full_like(sn, -1))], 1)
+    return meta.to(torch.int32).contiguous()
 
 
 def split_complete(plan: GraphPlan, g_split: int):

@@ -136,6 +136,12 @@ typedef struct da_graph {
     const int64_t *blk_class_ptr;
     int32_t blk_class_stride;
     int32_t reserved1;
+    /* hybrid mode, optional: per padded SLOT the remainder-edge metadata the masked attention's epilogue needs, gathered
+     * once per Batch so that the kernel reads ONE 16-byte record per query instead of walking slot_node -> irr_row_ptr ->
+     * irr_col_src -> row_map (four dependent loads in front of every workgroup):
+     *   rm_meta[slot] = { irr_row_ptr[node], irr_row_ptr[node + 1], row_map[irr_col_src[irr_row_ptr[node]]] (the slot of the
+     *   first remainder source; any valid slot when there is none), node }; node = -1 for padding / virtual slots.        */
+    const int32_t *rm_meta;   /* [n_pad][4] or NULL                                        */
 } da_graph;
 
 typedef struct da_denoiser da_denoiser;

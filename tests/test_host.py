@@ -377,4 +377,19 @@ def test_expander_plan_banded_layout_is_the_natural_plan_relabelled(monkeypatch)
             tab = pb.blk_class[int(pb.blk_class_ptr[g]):].numpy()[: (padded // 32) * pb.blk_class_stride].reshape(padded // 32, pb.blk_class_stride)
             assert np.array_equal(tab[:, : padded // 32], want) and not tab[:, padded // 32:].any()
         assert pb.blk_class_stride % 4 == 0
+        # per-slot remainder metadata (da_graph.rm_meta) of both layouts against the arrays it is gathered from
+        for pl in (pn, pb):
+            meta = GP._remainder_meta(pl)
+            assert meta.shape == (pl.n_pad, 4) and meta.dtype == torch.int32
+            for node in list(range(0, G * n, 7)) + [G * n - 1]:
+                slot = int(pl.row_map[node])
+                b, e = int(pl.irr_row_ptr[node]), int(pl.irr_row_ptr[node + 1])
+                assert meta[slot, :2].tolist() == [b, e] and int(meta[slot, 3]) == node
+                if e > b:
+                    assert int(meta[slot, 2]) == int(pl.row_map[int(pl.irr_col_src[b])])
+                else:
+                    assert 0 <= int(meta[slot, 2]) < pl.n_pad
+            virt_and_pad = torch.ones(pl.n_pad, dtype=torch.bool)
+            virt_and_pad[pl.row_map[: G * n].long()] = False
+            assert bool((meta[virt_and_pad, 3] == -1).all()) and bool((meta[virt_and_pad, :2] == 0).all())
 

@@ -3,9 +3,11 @@
 # configuration-3 variants, SQ counters of the attention and projection kernels, and one bench line per configuration / mode.
 # Outputs go to gpurun_out/<round>_*; copy them to profiles/<round>/ afterwards.    usage: ROUND=r03 bash tools/collect_round.sh
 set -u
-export ROUND=${ROUND:-r03}
+export ROUND=${ROUND:-r04}
 O=gpurun_out
 bash tools/collect_profiles.sh headline --config 3p
+bash tools/collect_profiles.sh headline_half --config 3p --puzzles 32     # the launch shape of each branch of the default two-branch loop
+DA_TWO_BRANCH=1 bash tools/collect_profiles.sh headline_two_branch --config 3p
 bash tools/collect_profiles.sh config3_d539 --config 3
 bash tools/collect_profiles.sh config3_d90 --config 3 --degree 90
 DA_HYBRID=off bash tools/collect_profiles.sh config3_d539_csr_only --config 3 --steps 4
@@ -20,7 +22,9 @@ b config_3 --config 3
 b config_3_d90 --config 3 --degree 90
 b config_4 --config 4
 b config_5 --config 5
+b config_5_bf16mma --config 5 --precision bf16
 b config_5_exophormer_d539 --config 5 --arch exophormer --train-side 30 --degree 539 --train-puzzles 16
+b config_5_exophormer_d539_bf16mma --config 5 --arch exophormer --train-side 30 --degree 539 --train-puzzles 16 --precision bf16
 b config_5_pixels --config 5 --pixels
 b e2e --mode e2e
 b encode --mode encode
