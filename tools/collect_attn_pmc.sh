@@ -12,7 +12,7 @@ for CASE in "32 0 2" "144 1 2" "144 1 1"; do        # C, fold, kernel choice (2 
   if [ "$GP" = 32 ] && [ "$3" = 1 ]; then continue; fi
   for GRP in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     W=/tmp/pmc_attn_${GP}_$1_$3_$(echo $GRP | cut -c1-12 | tr ' ' _); rm -rf $W; mkdir -p $W
-    rocprofv3 --kernel-trace --pmc $GRP -d $W -o p -- $REPO/tools/bin/attn_bench $GP 900 $1 $2 5 0 0 1 $3 > $W/log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $GRP -d $W -o p -- $REPO/tools/bin/attn_bench $GP 900 $1 $2 5 0 0 1 $3 > $W/log 2>&1
     DB=$(find $W -name "*results.db" | head -1)
     echo "== G=$GP C=$1 fold=$2 kernel=$3 : $GRP" >> $F
     python $REPO/profiles/rocpd_pmc.py $DB k_attn >> $F 2>&1

@@ -18,11 +18,11 @@ cd /tmp
 # profiles/r03/r03_rocprof_kernel_stats_headline_two_branch.txt is the same collection with the default loop.
 export DA_TWO_BRANCH=${DA_TWO_BRANCH:-0}
 BENCH="python $REPO/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-parity-mode --replays 0 $*"
-rocprofv3 --kernel-trace --stats -d $W/stats -o s -- $BENCH > $W/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $W/stats -o s -- $BENCH > $W/stats.log 2>&1
 DB=$(find $W/stats -name "*results.db" | head -1)
 python $REPO/profiles/rocpd_stats.py $DB > $OUT/${ROUND}_rocprof_kernel_stats_$TAG.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d $W/$C -o p -- $BENCH > $W/$C.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $C -d $W/$C -o p -- $BENCH > $W/$C.log 2>&1
   DB=$(find $W/$C -name "*results.db" | head -1)
   python $REPO/profiles/rocpd_pmc.py $DB k_ >> $OUT/${ROUND}_pmc_traffic_$TAG.txt 2>&1
 done

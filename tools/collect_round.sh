@@ -13,8 +13,12 @@ bash tools/collect_profiles.sh config3_d90 --config 3 --degree 90
 DA_HYBRID=off bash tools/collect_profiles.sh config3_d539_csr_only --config 3 --steps 4
 DA_HYBRID=off bash tools/collect_profiles.sh config3_d90_csr_only --config 3 --degree 90 --steps 4
 bash tools/collect_attn_pmc.sh > /dev/null 2>&1
-bash tools/collect_gemm_pmc.sh model > /dev/null 2>&1
-b() { tag=$1; shift; python bench.py "$@" > $O/${ROUND}_bench_$tag.json 2> $O/${ROUND}_bench_$tag.err; tail -c 300 $O/${ROUND}_bench_$tag.json | head -c 0; echo "bench $tag rc=$?"; }
+# the counter tables feed the bench lines' `traffic` / `mfma_busy_counter` fields: summarise them BEFORE the lines are produced
+mkdir -p profiles/$ROUND
+cp $O/${ROUND}_pmc_*.txt $O/${ROUND}_rocprof_*.txt profiles/$ROUND/ 2>/dev/null
+python tools/make_pmc_json.py $ROUND > $O/${ROUND}_make_pmc_json.log 2>&1
+cp profiles/$ROUND/pmc_traffic.json profiles/$ROUND/pmc_attention_sq.json $O/ 2>/dev/null
+b() { tag=$1; shift; timeout 900 python bench.py "$@" > $O/${ROUND}_bench_$tag.json 2> $O/${ROUND}_bench_$tag.err; tail -c 300 $O/${ROUND}_bench_$tag.json | head -c 0; echo "bench $tag rc=$?"; }
 b config_3p --steps 100 --warmup 10
 b config_1 --config 1
 b config_2 --config 2
