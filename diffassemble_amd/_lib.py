@@ -55,7 +55,7 @@ class DaGraph(C.Structure):
         ("hybrid", C.c_int32), ("reserved0", C.c_int32),
         ("mask", _fp), ("mask_ptr", _fp), ("irr_row_ptr", _fp), ("irr_col_src", _fp),
         ("slot_node", _fp), ("blk_class", _fp), ("blk_class_ptr", _fp), ("blk_class_stride", C.c_int32), ("reserved1", C.c_int32),
-        ("rm_meta", _fp),
+        ("rm_meta", _fp), ("agg_row_ptr", _fp), ("agg_col_src", _fp), ("agg_mult", _fp),
     ]
 
 

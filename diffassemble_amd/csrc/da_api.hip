@@ -397,8 +397,8 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                         // fork: virtual rows on the side stream, real rows here, join before the next projection
                         DA_CHECK_HIP(hipEventRecord(d->ev_fork, st));
                         DA_CHECK_HIP(hipStreamWaitEvent(d->side_stream, d->ev_fork, 0));
-                        rc = launch_attn_csr_cont(prec, n, nr, g->irr_row_ptr, g->irr_col_src, g->row_map, d->heads, c.C,
-                                                  g->n_pad, L, resid, act, dst, d->side_stream);
+                        rc = launch_attn_csr_cont(prec, n, nr, g->agg_row_ptr ? g->agg_row_ptr : g->irr_row_ptr, g->agg_row_ptr ? g->agg_col_src : g->irr_col_src,
+                                                  g->row_map, d->heads, c.C, g->n_pad, L, resid, act, dst, d->side_stream, g->agg_row_ptr ? g->agg_mult : nullptr);
                         if (rc) return rc < 0 ? 1 : rc;
                         DA_CHECK_HIP(hipEventRecord(d->ev_join, d->side_stream));
                         rc = launch_attn_dense(prec, L, d->heads, c.C, g->n_graphs, g->max_graph_nodes, g->graph_ptr,
@@ -412,8 +412,8 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                         int r2 = launch_attn_dense(prec, L, d->heads, c.C, g->n_graphs, g->max_graph_nodes, g->graph_ptr,
                                                    g->pad_ptr, 0, resid, act, dst, st, &mk);
                         if (r2) return r2;
-                        return launch_attn_csr_cont(prec, n, nr, g->irr_row_ptr, g->irr_col_src, g->row_map, d->heads, c.C,
-                                                    g->n_pad, L, resid, act, dst, st); });
+                        return launch_attn_csr_cont(prec, n, nr, g->agg_row_ptr ? g->agg_row_ptr : g->irr_row_ptr, g->agg_row_ptr ? g->agg_col_src : g->irr_col_src,
+                                                    g->row_map, d->heads, c.C, g->n_pad, L, resid, act, dst, st, g->agg_row_ptr ? g->agg_mult : nullptr); });
                     if (rc) return rc < 0 ? 1 : rc;
                     xin = dst; ldx = c.hc;
                     continue;

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
                                                               size_t n_pad, const T *__restrict__ Q,
                                                               const T *__restrict__ K, const T *__restrict__ V,
                                                               const T *__restrict__ skip, const T *__restrict__ residual,
-                                                              int act, T *__restrict__ out, float scale) {
+                                                              int act, T *__restrict__ out, float scale,
+                                                              const float *__restrict__ mult) {
     extern __shared__ float hsm[];                       // [HEAVY_WAVES][64 * EPL] acc, then [HEAVY_WAVES][64][2] (m, l)
     const int i = n_real + blockIdx.x;
     if (i >= n_nodes) return;
@@ -177,11 +178,13 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
     for (int e0 = beg + wv; e0 < end; e0 += HEAVY_WAVES * U) {
         size_t sj[U];
         bool ok[U];
+        float wgt[U];                                        // multiplicity of the (aggregated) edge, 1 without `mult`
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int e = e0 + u * HEAVY_WAVES;
             ok[u] = e < end;
             sj[u] = hb + (size_t)row_map[col_src[ok[u] ? e : beg]];
+            wgt[u] = mult ? mult[ok[u] ? e : beg] : 1.0f;
         }
         float kk[U][EPL], vv[U][EPL];
 #pragma unroll
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
             s += __shfl_xor(s, 4);
             const float mn = fmaxf(m, s);
             const float corr = expf(m - mn);
-            const float pr = expf(s - mn);
+            const float pr = expf(s - mn) * wgt[u];
             l = l * corr + pr;
 #pragma unroll
             for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pr, vv[u][x], acc[x] * corr);
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void k_attn_csr_cont(int n_nodes, int n_real, 
                                                        const T *__restrict__ Q, const T *__restrict__ K,
                                                        const T *__restrict__ V, const T *__restrict__ skip,
                                                        const T *__restrict__ residual, int act, T *__restrict__ out,
-                                                       float scale) {
+                                                       float scale, const float *__restrict__ mult) {
     const int lane = threadIdx.x & 63;
     const int i = n_real + (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n_nodes) return;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256) void k_attn_csr_cont(int n_nodes, int n_real, 
         s += __shfl_xor(s, 4);
         const float mn = fmaxf(m, s);
         const float corr = expf(m - mn);
-        const float pr = expf(s - mn);
+        const float pr = expf(s - mn) * (mult ? mult[e] : 1.0f);
         l = l * corr + pr;
 #pragma unroll
         for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pr, vv[x], acc[x] * corr);
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void k_attn_csr_cont(int n_nodes, int n_real, 
 
 template <typename T>
 static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32_t *cs, const int32_t *row_map, int H, int C,
-                         int n_pad, const DenseLayout &L, const T *residual, int act, T *out, hipStream_t st) {
+                         int n_pad, const DenseLayout &L, const T *residual, int act, T *out, hipStream_t st, const float *mult) {
     if (n_nodes <= n_real) return 0;
     const float scale = L.q_prescaled ? 0.6931471805599453f : 1.0f / sqrtf((float)C);      // pre-scaled Q: q . k is in log2 units
     const int grid = (int)(((size_t)(n_nodes - n_real) * 64 + 255) / 256);
@@ -302,11 +305,11 @@ static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32
             }                                                                                                    \
             k_attn_csr_cont_heavy<T, E><<<n_nodes - n_real, 1024, lds, st>>>(                                    \
                 n_nodes, n_real, rp, cs, row_map, H, C, (size_t)n_pad, (const T *)L.Q, (const T *)L.K,           \
-                (const T *)L.Vt, (const T *)L.S, residual, act, out, scale);                                     \
+                (const T *)L.Vt, (const T *)L.S, residual, act, out, scale, mult);                               \
         }                                                                                                        \
         k_attn_csr_cont<T, E><<<grid, 256, 0, st>>>(n_nodes, n_real, rp, cs, row_map, H, C, (size_t)n_pad,       \
                                                     (const T *)L.Q, (const T *)L.K, (const T *)L.Vt, (const T *)L.S, \
-                                                    residual, act, out, scale);                                  \
+                                                    residual, act, out, scale, mult);                            \
         break;
     switch (C / 8) {
         DA_CONT_CASE(4) DA_CONT_CASE(18)
@@ -321,14 +324,14 @@ static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32
 
 int launch_attn_csr_cont(int prec, int n_nodes, int n_real, const int32_t *irr_row_ptr, const int32_t *irr_col_src,
                          const int32_t *row_map, int heads, int C, int n_pad, const DenseLayout &L,
-                         const void *residual, int act, void *out, hipStream_t st) {
+                         const void *residual, int act, void *out, hipStream_t st, const float *mult) {
     if (n_nodes <= 0) return 0;
     DA_REQUIRE(heads == 8 && C % 8 == 0, "da_attn_csr_cont: heads must be 8 and C a multiple of 8");
     if (prec == DA_PREC_BF16)
         return launch_cont_t<bf16_t>(n_nodes, n_real, irr_row_ptr, irr_col_src, row_map, heads, C, n_pad, L,
-                                     (const bf16_t *)residual, act, (bf16_t *)out, st);
+                                     (const bf16_t *)residual, act, (bf16_t *)out, st, mult);
     return launch_cont_t<float>(n_nodes, n_real, irr_row_ptr, irr_col_src, row_map, heads, C, n_pad, L,
-                                (const float *)residual, act, (float *)out, st);
+                                (const float *)residual, act, (float *)out, st, mult);
 }
 
 int launch_attn_csr(int prec, int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id,

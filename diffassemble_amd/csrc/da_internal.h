@@ -141,7 +141,8 @@ int attn_dual_counters(unsigned long long *out2, int reset);
 // hybrid mode: the rows the masked kernel does not own (virtual nodes) over their remainder edges
 int launch_attn_csr_cont(int prec, int n_nodes, int n_real, const int32_t *irr_row_ptr, const int32_t *irr_col_src,
                          const int32_t *row_map, int heads, int C, int n_pad, const DenseLayout &L,
-                         const void *residual, int act, void *out, hipStream_t st);
+                         const void *residual, int act, void *out, hipStream_t st,
+                         const float *mult = nullptr /* multiplicity per (aggregated) remainder edge, or NULL = 1 */);
 
 // da_conv_fused.hip: one hidden conv (projection + attention of a (graph, head)) as ONE kernel, K / V resident in LDS
 bool conv_fused_applicable(int prec, int heads, int C, int kin, int max_graph_nodes, int ldo);

@@ -70,12 +70,19 @@ __global__ __launch_bounds__(256) void k_colsum_partial(int M, int N, const floa
     __syncthreads();
     if (ty == 0 && c < N) partial[(size_t)blockIdx.y * N + c] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
+// 64 columns per block, four threads per column: thread (tx, ty) adds the chunks ty, ty + 4, ... in ascending order, the four
+// sub-sums are combined as (s0 + s1) + (s2 + s3) -- a fixed order (data-parallel replicas must produce identical bits), a
+// quarter of the dependent loads per thread (one thread per column walked all chunks: 15 - 18 us per call, 8 calls per step)
 __global__ __launch_bounds__(256) void k_colsum_finish(int chunks, int N, const float *__restrict__ partial, float *out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[(size_t)k * N + c];
-    out[c] += s;
+    if (c < N)
+        for (int k = ty; k < chunks; k += 4) s += partial[(size_t)k * N + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < N) out[c] += (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -657,9 +664,10 @@ int launch_transpose_f32(int rows, int cols, const float *src, float *dst, hipSt
     return 0;
 }
 int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch, hipStream_t st) {
-    const int rows_per = 128, chunks = (M + rows_per - 1) / rows_per;      // chunks * N floats of scratch
+    // at most ~32 row chunks (never more than the 128-row chunks the scratch is sized for): chunks * N floats of scratch
+    const int rows_per = max(128, ((M + 31) / 32 + 3) / 4 * 4), chunks = (M + rows_per - 1) / rows_per;
     k_colsum_partial<<<dim3((N + 63) / 64, chunks), 256, 0, st>>>(M, N, A, lda, rows_per, scratch);
-    k_colsum_finish<<<(N + 255) / 256, 256, 0, st>>>(chunks, N, scratch, out);
+    k_colsum_finish<<<(N + 63) / 64, 256, 0, st>>>(chunks, N, scratch, out);
     DA_LAUNCH_CHECK();
     return 0;
 }

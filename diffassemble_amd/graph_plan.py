@@ -74,6 +74,7 @@ class GraphPlan:
     blk_class_ptr: torch.Tensor = None  # int64 [G + 1] byte offsets of the graphs' class tables (graphs of one shape share one)
     blk_class_stride: int = 0
     rm_meta: torch.Tensor = None       # int32 [n_pad, 4]: per slot (remainder begin, end, slot of the first remainder source, node)
+    agg: tuple = None                  # (row_ptr int32 [n_nodes + 1], col_src int32, mult float32): virtual rows' remainder edges, duplicates merged
 
     @property
     def edge_index(self):
@@ -144,9 +145,28 @@ class GraphPlan:
             if self.rm_meta is None:
                 self.rm_meta = _remainder_meta(self)
             g.rm_meta = self.rm_meta.data_ptr()
+            if self.agg is None and self.n_nodes > self.n_real:
+                self.agg = _aggregate_virtual_rows(self.irr_row_ptr, self.irr_col_src, self.n_real, self.n_nodes)
+            if self.agg is not None:
+                g.agg_row_ptr, g.agg_col_src, g.agg_mult = (t.data_ptr() for t in self.agg)
             if self.blk_class is not None:
                 g.blk_class, g.blk_class_ptr, g.blk_class_stride = self.blk_class.data_ptr(), self.blk_class_ptr.data_ptr(), self.blk_class_stride
         return g
+
+
+def _aggregate_virtual_rows(irr_row_ptr, irr_col_src, n_real, n_nodes):
+    """da_graph.agg_*: the remainder edges of the rows >= n_real (exophormer virtual nodes) with duplicated (source, target)
+    pairs merged into one entry + multiplicity (one sort of the virtual rows' edges only; shape-only for expander plans)."""
+    dev = irr_col_src.device
+    rp = irr_row_ptr.to(torch.int64)
+    lo, hi = int(rp[n_real]), int(rp[n_nodes])
+    cnt = rp[n_real + 1:] - rp[n_real:-1]
+    dst = torch.repeat_interleave(torch.arange(n_real, n_nodes, device=dev), cnt)
+    key = dst * n_nodes + irr_col_src[lo:hi].to(torch.int64)
+    uk, mult = torch.unique(key, return_counts=True)                     # sorted: grouped by destination, sources ascending
+    ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(torch.bincount(uk // n_nodes, minlength=n_nodes), 0)
+    return ptr.to(torch.int32).contiguous(), (uk % n_nodes).to(torch.int32).contiguous(), mult.to(torch.float32).contiguous()
 
 
 def _remainder_meta(plan: GraphPlan):

@@ -142,6 +142,14 @@ typedef struct da_graph {
      *   rm_meta[slot] = { irr_row_ptr[node], irr_row_ptr[node + 1], row_map[irr_col_src[irr_row_ptr[node]]] (the slot of the
      *   first remainder source; any valid slot when there is none), node }; node = -1 for padding / virtual slots.        */
     const int32_t *rm_meta;   /* [n_pad][4] or NULL                                        */
+    /* hybrid mode, optional: the remainder edges of the rows the masked attention does NOT own (the exophormer's virtual
+     * nodes, exophormer_gnn.py:183-200) with duplicated (source, target) pairs merged: CSR by destination over ALL nodes (real
+     * rows empty), one entry per distinct source and its multiplicity -- PyG's softmax counts a duplicated edge k times, i.e.
+     * weighs exp(score) by k in numerator and denominator.  The pairing quirk of the reference makes most virtual -> virtual
+     * edges duplicates (at V = 8, n = 900, 32 puzzles: 232 448 edges into virtual nodes, 29 256 distinct pairs).          */
+    const int32_t *agg_row_ptr;   /* [n_nodes + 1] or NULL                                 */
+    const int32_t *agg_col_src;   /* [distinct pairs]                                      */
+    const float *agg_mult;        /* [distinct pairs] multiplicities                       */
 } da_graph;
 
 typedef struct da_denoiser da_denoiser;

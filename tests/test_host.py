@@ -393,3 +393,24 @@ def test_expander_plan_banded_layout_is_the_natural_plan_relabelled(monkeypatch)
             virt_and_pad[pl.row_map[: G * n].long()] = False
             assert bool((meta[virt_and_pad, 3] == -1).all()) and bool((meta[virt_and_pad, :2] == 0).all())
 
+
+def test_virtual_rows_remainder_edges_aggregated_with_multiplicities():
+    """da_graph.agg_*: the exophormer's edges into virtual nodes (exophormer_gnn.py:183-200: mostly duplicated virtual ->
+    virtual pairs) merged to one entry per distinct source + multiplicity -- as a multiset exactly the remainder CSR's rows;
+    real rows stay empty."""
+    from diffassemble_amd import graph_plan as GP
+    for G, n, V in ((3, 70, 4), (2, 130, 8)):
+        N = G * n
+        batch = torch.arange(G).repeat_interleave(n)
+        ve = GP.exophormer_edge_index(torch.zeros((2, 0), dtype=torch.long), batch, V, G)
+        ptr, src = GP._irregular_csr(ve[0], ve[1], N + G * V)
+        ap, asrc, am = GP._aggregate_virtual_rows(ptr, src, N, N + G * V)
+        assert int(ap[N]) == 0 and float(am.sum()) == float(ptr[-1] - ptr[N]) and am.dtype == torch.float32
+        assert asrc.numel() < (ptr[-1] - ptr[N]) // 2            # the quirk's duplicates really merge
+        for i in range(N, N + G * V):
+            want = sorted(src[int(ptr[i]):int(ptr[i + 1])].tolist())
+            got = []
+            for e in range(int(ap[i]), int(ap[i + 1])):
+                got += [int(asrc[e])] * int(am[e])
+            assert want == sorted(got), i
+
