@@ -901,13 +901,17 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
         // bf16 with pre-scaled Q: the optimistic kernels (da_attn_opt.hip); DA_ATTN_OPT_LAST=0 / DA_ATTN_OPT_MASKED=0 keep
         // this layer on k_attn_dense (A/B runs)
         if (prec == DA_PREC_BF16 && L.q_prescaled && p.fast && attn_opt_env() && attn_opt_last_env() && (!p.mask || attn_opt_masked_env())
-            DA_ATTN_DBG(&& !p.debug && !p.prof))
-            return launch_attn_opt(p, C, st);
+            DA_ATTN_DBG(&& !p.debug && !p.prof)) {
+            const int ro = launch_attn_opt(p, C, st);
+            if (ro >= 0) return ro;                        // (-1: shape not covered, e.g. masked graphs beyond 4096 pieces)
+        }
         if (mk) return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, true, 32>(p, st) : launch_tcm<float, 144, true, 32>(p, st);
         return prec == DA_PREC_BF16 ? launch_tcm<bf16_t, 144, false, 32>(p, st) : launch_tcm<float, 144, false, 32>(p, st);
     }
-    if (prec == DA_PREC_BF16 && C == 32 && L.q_prescaled && p.fast && attn_opt_env() && (!p.mask || attn_opt_masked_env()) DA_ATTN_DBG(&& !p.debug && !p.prof))
-        return launch_attn_opt(p, C, st);
+    if (prec == DA_PREC_BF16 && C == 32 && L.q_prescaled && p.fast && attn_opt_env() && (!p.mask || attn_opt_masked_env()) DA_ATTN_DBG(&& !p.debug && !p.prof)) {
+        const int ro = launch_attn_opt(p, C, st);
+        if (ro >= 0) return ro;
+    }
     if (prec == DA_PREC_BF16 && C == 32 && !p.mask && attn2_env() DA_ATTN_DBG(&& !p.debug && !p.prof))
         return launch_attn_dense2(p, heads, n_graphs, max_graph_nodes, st);
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, st) : launch_tc<bf16_t, 144>(p, st);

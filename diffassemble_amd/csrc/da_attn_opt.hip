@@ -178,25 +178,13 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     if (MASKED) {
         tmask = nkt >= 64 ? ~0ull : ((1ull << nkt) - 1ull);
         if (p.blk_class) {
-            // the wave's class row goes to LDS once (a per-tile global load of it would put a compiler-managed vmcnt(0) in
-            // front of every tile and drain the DMA ring: measured, that cancelled the whole gain of the skipped blocks)
-            const unsigned char *grow = p.blk_class + p.blk_class_ptr[g] + (size_t)(qt * 4 + wid) * (size_t)p.blk_class_stride;
-            crow = lcls + wid * 128;
-            if (lane < 32) ((unsigned *)crow)[lane] = (4 * lane < p.blk_class_stride) ? ((const unsigned *)grow)[lane] : 0u;
-            __syncthreads();
-            unsigned long long mine = 0;
-            if (wave_on) {
-                for (int dw = 0; 2 * dw < nkt; ++dw) {             // one dword = four blocks = two tiles
-                    const unsigned c4 = ((const unsigned *)crow)[dw];
-                    if (c4 & 0xffffu) mine |= 1ull << (2 * dw);
-                    if (c4 >> 16) mine |= 1ull << (2 * dw + 1);
-                }
-            }
-            if (lane == 0) { flags[4 + 2 * wid] = (int)(unsigned)mine; flags[5 + 2 * wid] = (int)(unsigned)(mine >> 32); }
-            __syncthreads();
-            const unsigned lo = (unsigned)(flags[4] | flags[6] | flags[8] | flags[10]), hi = (unsigned)(flags[5] | flags[7] | flags[9] | flags[11]);
-            tmask &= ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | (unsigned long long)__builtin_amdgcn_readfirstlane(lo);
+            // behind the graph's class rows the plan keeps one 64-bit word per query tile: the key tiles in which some slab
+            // of the tile has an edge (ONE scalar load; computing it here cost two barrier rounds in front of the first DMA)
+            const int nsl = (p.pad_ptr[g + 1] - pad0) >> 5;
+            const unsigned char *tab = p.blk_class + p.blk_class_ptr[g];
+            tmask &= ((const unsigned long long *)(tab + (size_t)nsl * (size_t)p.blk_class_stride))[qt];
             ntl = __builtin_popcountll(tmask);
+            crow = lcls + wid * 128;             // filled below, once the first DMA stages are on their way
         }
     }
     // the j-th tile of the walk: j itself, or the j-th set bit of tmask (cursor masks, scalar arithmetic)
@@ -222,6 +210,12 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < ntl) issue(next_tile(rem_pf, st), st);
+        if (MASKED && crow && attempt == 0) {
+            // the wave's class row -> its private LDS slot (read back per tile as a broadcast ds_read; a per-tile GLOBAL load of
+            // it put a compiler-managed vmcnt(0) in front of every tile and drained the DMA ring)
+            const unsigned char *grow = p.blk_class + p.blk_class_ptr[g] + (size_t)(qt * 4 + wid) * (size_t)p.blk_class_stride;
+            if (lane < 32) ((unsigned *)crow)[lane] = (4 * lane < p.blk_class_stride) ? ((const unsigned *)grow)[lane] : 0u;
+        }
         for (int j = 0; j < ntl; ++j) {
             const int kt = next_tile(rem_cur, j);
             {
@@ -469,6 +463,8 @@ static int launch_optt(AttnDenseParams p, hipStream_t st) {
 // p.mask selects the adjacency-masked instances.  Returns 0 = launched, -1 = shape not covered.
 int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
     const bool fold = p.fold_out != nullptr, masked = p.mask != nullptr;
+    if (masked && p.max_nodes > 4096) return -1;          // the masked walk keeps its key tiles in a 64-bit mask
+    if (masked && p.blk_class && p.blk_class_stride > 128) return -1;      // class rows are staged in 128-byte LDS slots
     if (C == 32 && !fold) return masked ? launch_optt<32, false, true, 4, 4>(p, st) : launch_optt<32, false, false, 4, 4>(p, st);
     if (C == 144 && fold) return masked ? launch_optt<144, true, true, 2, 3>(p, st) : launch_optt<144, true, false, 2, 3>(p, st);
     return -1;

@@ -429,7 +429,7 @@ def expander_plan(perms, degree, batch_device=None, virt_nodes=0):
         if len(_EXPANDER_SHAPES) > 16:
             _EXPANDER_SHAPES.clear()
         _EXPANDER_SHAPES[key] = sh
-    if _expander_layout() == "banded" and int(sh["padded"][0]) <= 4096:
+    if _expander_layout() == "banded" and int(sh["padded"][0]) <= 3968:
         return _expander_plan_banded(perms, d, V, sh, edge_list, E)
     if dev.type == "cuda":
         # two launches: inverse permutations, then the bit rows (csrc/da_graph.hip)
@@ -493,7 +493,17 @@ def block_classes(adj, padded):
     cls = blk.any(3).any(1).to(torch.uint8) + blk.all(3).all(1).to(torch.uint8)
     out = torch.zeros((nb, stride), dtype=torch.uint8, device=dev)
     out[:, :nb] = cls
-    return out.contiguous(), stride
+    # behind the rows: one 64-bit word per 128-slot query tile (four slabs), bit kt = some slab of the tile has an edge into
+    # 64-key tile kt -- the key tiles a workgroup of the masked attention walks (read with one scalar load)
+    nqt, nkt = (nb + 3) // 4, (nb + 1) // 2
+    anyb = torch.zeros((nqt * 4, nkt * 2), dtype=torch.bool, device=dev)
+    anyb[:nb, :nb] = cls > 0
+    need = anyb.view(nqt, 4, nkt, 2).any(3).any(1)                                   # [query tile, key tile]
+    words = (need.to(torch.int64) << torch.arange(nkt, device=dev, dtype=torch.int64)[None, :]).sum(1) if nkt <= 62 else None
+    if words is None:
+        raise ValueError("block classes cover graphs of up to 62 key tiles")
+    tail = words.view(torch.uint8).reshape(-1) if words.numel() else torch.zeros(0, dtype=torch.uint8, device=dev)
+    return torch.cat([out.reshape(-1), tail]).contiguous(), stride
 
 
 def _expander_plan_banded(perms, d, V, sh, edge_list, E):
@@ -511,6 +521,12 @@ def _expander_plan_banded(perms, d, V, sh, edge_list, E):
         counts1 = torch.full((1,), n, dtype=torch.int64, device=dev)
         mask, _ = _pack_mask(counts1, torch.full((1,), padded, dtype=torch.int64, device=dev), None, uniform_bool=adj[None])
         cls, stride = block_classes(adj, padded)
+        import os
+        dbg = os.environ.get("DA_EXPANDER_CLS_DEBUG")          # TIMING experiments only (wrong results): every block "full" / "partial"
+        if dbg in ("full", "partial"):
+            nb_ = padded // 32
+            rows = cls[: nb_ * stride].view(nb_, stride)
+            rows[:, :nb_] = torch.where(rows[:, :nb_] > 0, torch.full_like(rows[:, :nb_], 2 if dbg == "full" else 1), rows[:, :nb_])
         band = dict(mask=mask, cls=cls, stride=stride)
         if len(_EXPANDER_BANDS) > 16:
             _EXPANDER_BANDS.clear()

@@ -376,6 +376,15 @@ def test_expander_plan_banded_layout_is_the_natural_plan_relabelled(monkeypatch)
             want = (cnt > 0).astype(np.uint8) + (cnt == 1024).astype(np.uint8)
             tab = pb.blk_class[int(pb.blk_class_ptr[g]):].numpy()[: (padded // 32) * pb.blk_class_stride].reshape(padded // 32, pb.blk_class_stride)
             assert np.array_equal(tab[:, : padded // 32], want) and not tab[:, padded // 32:].any()
+            # behind the rows: per 128-slot query tile the 64-key tiles some slab of it has an edge into (one 64-bit word each)
+            nb = padded // 32
+            words = pb.blk_class[int(pb.blk_class_ptr[g]) + nb * pb.blk_class_stride:].numpy()[: 8 * ((nb + 3) // 4)].view(np.int64)
+            for qt in range((nb + 3) // 4):
+                bits = 0
+                for kt in range((nb + 1) // 2):
+                    if want[4 * qt:4 * qt + 4, 2 * kt:2 * kt + 2].any():
+                        bits |= 1 << kt
+                assert int(words[qt]) == bits, (qt, hex(int(words[qt])), hex(bits))
         assert pb.blk_class_stride % 4 == 0
         # per-slot remainder metadata (da_graph.rm_meta) of both layouts against the arrays it is gathered from
         for pl in (pn, pb):
