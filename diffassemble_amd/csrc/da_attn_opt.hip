@@ -40,15 +40,33 @@ namespace da {
 // da_debug_counters: workgroups whose optimistic pass failed its verification ([0] complete graphs, [1] adjacency-masked)
 __device__ unsigned long long g_opt_fallbacks[2];
 
+// K tile geometry of these kernels.  C = 144: Cfg's padded rows (288 B + one 16-byte pad slot: an odd number of slots keeps the
+// fragment reads conflict-free).  C = 32 (round 4): rows of exactly 64 B, their four 16-byte slots XOR-SWIZZLED instead of padded --
+// slot s of key row r lives at position s ^ f(r), f(r) = bit 2 of r + 2 * bit 4 of r: the four rows a 16-lane group of a fragment
+// read meets in one 64-byte quarter of the 256-byte bank window (r, r + 4, r + 16, r + 20 under the pi permutation) get four
+// different positions.  The swizzle is applied to the LDS-DMA's per-lane SOURCE address, as in the GEMM kernels.  It saves the
+// 1 KB of pad slots per 64-key stage (and one DMA instruction per tile): with the adjacency-word slots of the masked instance a
+// stage is 9 KB again and four workgroups fit a CU -- at three, the 2048 workgroups of a 32-puzzle launch needed three rounds
+// instead of two (measured: 92 us against 55 us for the un-masked kernel, with the masking itself costing nothing).
+template <int C> struct OptK {
+    using CF = Cfg<bf16_t, C, 32>;
+    static constexpr bool SWZ = C == 32;
+    static constexpr int RS = SWZ ? CF::ROWB : CF::RS, KSPR = RS / 16;
+    static constexpr int NIK = (CF::BKEYS * KSPR + 63) / 64, NI = NIK + CF::NIV;
+    static constexpr int KBYTES = NIK * 1024, STAGE = KBYTES + CF::VBYTES;
+    static __device__ __forceinline__ int f(int row) { return SWZ ? (((row >> 2) & 1) | (((row >> 4) & 1) << 1)) : 0; }
+};
+
 template <int C, bool FOLD, bool MASKED, int NST, int MINB>
 __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     using T = bf16_t;
     constexpr int CV = 32, NW = 4, QT = 128, NT = 256;
     using CF = Cfg<T, C, CV>;
+    using KG = OptK<C>;
     static_assert(CF::NCB == 1, "one 32-channel value block");
-    constexpr int MAXI = (CF::NI + NW - 1) / NW;
+    constexpr int MAXI = (KG::NI + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int MSTAGE = CF::STAGE + (MASKED ? 1024 : 0);     // MASKED: + the four waves' adjacency-word slots (256 B each)
+    constexpr int MSTAGE = KG::STAGE + (MASKED ? 1024 : 0);     // MASKED: + the four waves' adjacency-word slots (256 B each)
     int *flags = (int *)(smem + NST * MSTAGE);                  // one word per wave: "my optimistic pass failed"; [4 .. 11]: the waves' tile masks
     float *mlut = (float *)(smem + NST * MSTAGE + 64);          // MASKED: nibble -> four accumulator initial values
     unsigned char *lcls = smem + NST * MSTAGE + 64 + 256;       // MASKED: the four waves' block-class rows (128 B each)
@@ -85,11 +103,12 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     for (int x = 0; x < MAXI; ++x) {
         const int q = wid + NW * x;
         unsigned o = 0;
-        if (q < CF::NIK) {
-            const int s = q * 64 + lane, row = s / CF::KSPR, col = s - row * CF::KSPR;
-            if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
+        if (q < KG::NIK) {
+            const int s = q * 64 + lane, row = s / KG::KSPR, col = s - row * KG::KSPR;
+            if (KG::SWZ) o = (unsigned)(row * CF::ROWB + (col ^ KG::f(row)) * 16);          // LDS position col holds slot col ^ f(row)
+            else if (row < CF::BKEYS && col < CF::KVALID) o = (unsigned)(row * CF::ROWB + col * 16);
         } else {
-            const int s = (q - CF::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
+            const int s = (q - KG::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
             if (row < CF::BKEYS && col < CF::KVALIDV) o = (unsigned)(row * CF::ROWBV + col * 16);
         }
         soff[x] = o;
@@ -102,23 +121,26 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
 #pragma unroll
         for (int x = 0; x < MAXI; ++x) {
             const int q = wid + NW * x;
-            if (NW * x + NW - 1 < CF::NI || q < CF::NI) {
-                const unsigned char *src = (q < CF::NIK ? kb_ : vb_) + soff[x];
+            if (NW * x + NW - 1 < KG::NI || q < KG::NI) {
+                const unsigned char *src = (q < KG::NIK ? kb_ : vb_) + soff[x];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
             }
         }
         if (MASKED)         // lane (i, half) fetches the 32 adjacency bits of query row i for key block `half` of the tile
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(mrow4 + 8 * (size_t)kt),
-                                             (__attribute__((address_space(3))) void *)(sb + CF::STAGE + wid * 256), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(sb + KG::STAGE + wid * 256), 4, 0, 0);
     };
-    const int myn = (CF::NI - wid + NW - 1) / NW + (MASKED ? 1 : 0);      // DMA instructions this wave issues per tile
+    const int myn = (KG::NI - wid + NW - 1) / NW + (MASKED ? 1 : 0);      // DMA instructions this wave issues per tile
     const int nkt = (n_g + CF::BKEYS - 1) / CF::BKEYS;
     const int qidx = q0 + i;
     const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);
-    const int koff = pi_i * CF::RS + half * 16;
+    // byte offsets of this lane's K fragments (chunk ch = logical slot 2 ch + half of key row pi_i) inside a 32-key block
+    int kfo[CF::NCH];
+#pragma unroll
+    for (int ch = 0; ch < CF::NCH; ++ch) kfo[ch] = pi_i * KG::RS + (KG::SWZ ? (((2 * ch + half) ^ KG::f(pi_i)) * 16) : (ch * 32 + half * 16));
     const int li = lane & 15;
-    const int vbase = CF::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+    const int vbase = KG::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     // MASKED: this lane's row of the adjacency bit matrix (bit j = edge j -> this query); the 8 bytes of key tile kt sit at
@@ -220,7 +242,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             const int kt = next_tile(rem_cur, j);
             {
                 // tiles that may stay in flight behind this one (each is `myn` operations of this wave; myn is LO or LO + 1)
-                constexpr int LO = CF::NI / NW + (MASKED ? 1 : 0);
+                constexpr int LO = KG::NI / NW + (MASKED ? 1 : 0);
                 const int younger = min(ntl - 1 - j, NST - 2);
                 if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (younger == 1) { if (myn == LO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO + 1) : "memory"); }
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                 if (MASKED && cls == 0u) continue;                                  // no edge between this slab and these keys
                 u32x4 kf[CF::NCH];
 #pragma unroll
-                for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + koff + kb * 32 * CF::RS + ch * 32);
+                for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(stg + kfo[ch] + kb * 32 * KG::RS);
                 __builtin_amdgcn_sched_barrier(0);
                 f32x16 s;
                 if (MASKED && cls == 2u) {                                           // every pair of the block is an edge
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                     for (int r = 0; r < 16; ++r) s[r] = 0.f;
                 } else if (MASKED) {
                     // this lane's 16 keys of the block: half `half` of the dword lane (i, kb) fetched for the tile
-                    const unsigned mw = *(const unsigned short *)(stg + CF::STAGE + wid * 256 + (kb * 32 + i) * 4 + 2 * half);
+                    const unsigned mw = *(const unsigned short *)(stg + KG::STAGE + wid * 256 + (kb * 32 + i) * 4 + 2 * half);
                     anym |= mw;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -447,7 +469,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
 template <int C, bool FOLD, bool MASKED, int NST, int MINB>
 static int launch_optt(AttnDenseParams p, hipStream_t st) {
     using CF = Cfg<bf16_t, C, 32>;
-    const int lds = NST * (CF::STAGE + (MASKED ? 1024 : 0)) + 64 + (MASKED ? 256 + 512 : 0);
+    const int lds = NST * (OptK<C>::STAGE + (MASKED ? 1024 : 0)) + 64 + (MASKED ? 256 + 512 : 0);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_optt<C, FOLD, MASKED, NST, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
