@@ -16,6 +16,8 @@
 // [k][n], row stride 80 floats) so the single-float MFMA fragments (row = lane & 15, k = lane >> 4) are
 // conflict-free 4-byte LDS reads whatever the memory orientation; the global side always moves 16 bytes
 // per lane along the contiguous axis.
+#include <stdlib.h>
+
 #include "da_gemm_common.h"
 
 namespace da {
@@ -34,6 +36,12 @@ struct GGemm {
     int accumulate;
     int H;
     int bfc;                     // operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16 (training's DA_TRAIN_MMA_BF16 mode)
+    int epi = 0;                 // k_ggemm_small only: 0 = plain; 1 = row softmax of the product (C = P, PyG: exp(s - max) / (sum + 1e-16),
+                                 // diagonal excluded when nodiag); 2 = C = E o (product - rowsum(E o product)) with E = the kept P (dS)
+    int nodiag = 0;
+    const float *E = nullptr;    // epi == 2: pair matrix P (same layout as C)
+    int gs_pitch = 0, gs_rows_a = 0;      // k_ggemm_small: LDS row pitch (elements) and rows reserved for the A image (set by the launcher)
+    int pair_bf16 = 0;           // k_ggemm_small: pair matrices (kind 1 operands, E) are stored as bf16 (same element offsets, half the bytes)
     const int32_t *gp;           // [G + 1] node offsets
     const long long *poff;       // [G + 1] pair-matrix offsets (floats)
 };
@@ -155,6 +163,168 @@ __global__ __launch_bounds__(256) void k_ggemm(GGemm p) {
             }
 }
 
+// k_ggemm_small (round 4, bf16-operand mode only): the same grouped product for SMALL groups -- every dimension <= 160, i.e. the
+// 12 x 12 puzzles of BASELINE configuration 5 (M, N, K in {144, 32}) -- as ONE 10-wave workgroup per (graph, head) instead of a
+// 64 x 64 tile per workgroup: k_ggemm cut such a product into nine workgroups of which five are 16 / 64 full and each runs two to
+// nine 16-deep stages behind a barrier pair -- launch- and latency-bound whatever the MFMA costs (46.6 -> 41.2 us when the
+// operands went to bf16).  Here both operands are converted to bf16 ONCE into LDS, k-contiguous ([m][k] and [n][k], row pitch
+// K + 8 elements: 8-byte fragment reads on distinct banks), and the waves walk the 16 x 16 output tiles with
+// v_mfma_f32_16x16x16_bf16 straight out of LDS: no barrier after the staging.
+constexpr int GS_MAX = 160;
+constexpr int GS_WAVES = 10;          // ten waves: one per 16-row band of a 160-row product (nine busy at n = 144)
+__global__ __launch_bounds__(64 * GS_WAVES) void k_ggemm_small(GGemm p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short gs_lds[];      // A_s [Mmax][pitch] | B_s [Nmax][pitch]
+    const int GS_PITCH = p.gs_pitch;                      // K rounded up to 16, + 8 elements (the launcher sizes the LDS with it)
+    unsigned short *As = gs_lds, *Bs = gs_lds + p.gs_rows_a * GS_PITCH;
+    const int g = blockIdx.x / p.H, h = blockIdx.x - g * p.H;
+    const int n_g = p.gp[g + 1] - p.gp[g];
+    const int M = p.dimM ? p.dimM : n_g, N = p.dimN ? p.dimN : n_g, K = p.dimK ? p.dimK : n_g;
+    if (M <= 0 || N <= 0) return;
+    int rsA, rsB, rsC;
+    const float *A = op_ptr(p.A, g, h, n_g, p.gp, p.poff, rsA);
+    const float *B = op_ptr(p.B, g, h, n_g, p.gp, p.poff, rsB);
+    float *C = (float *)op_ptr(p.C, g, h, n_g, p.gp, p.poff, rsC);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Mp = (M + 15) & ~15, Np = (N + 15) & ~15, Kp = (K + 15) & ~15;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+    typedef __attribute__((ext_vector_type(4))) short s16x4_;
+    // stage one operand: X(r, k) for r < R (rows of the LDS image), k < K; `kmajor` = the memory is [k][r] (r contiguous)
+    auto stage = [&](unsigned short *S, const float *X, int rs, bool kmajor, int R, int Rp) {
+        if (!kmajor) {                      // memory [r][k]: 4 consecutive k per thread -> one 8-byte LDS store
+            const int kq = Kp >> 2;
+            for (int idx = tid; idx < Rp * kq; idx += 64 * GS_WAVES) {
+                const int r = idx / kq, k = (idx - r * kq) * 4;
+                const f32x4 v = ld4z(X, rs, r, k, R, K);
+                const bf16x4_ b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *(s16x4_ *)(S + r * GS_PITCH + k) = __builtin_bit_cast(s16x4_, b);
+            }
+        } else {                            // memory [k][r]: 4 consecutive r of one k per thread (one 16-byte load) -> four 2-byte LDS
+            const int rq = Rp >> 2;         // stores four rows apart.  (Tried: 4 consecutive k of one r per thread, four 4-byte loads -> one
+            for (int idx = tid; idx < Kp * rq; idx += 64 * GS_WAVES) {      // conflict-free 8-byte store: 39.9 vs 28.8 us per launch.)
+                const int k = idx / rq, r = (idx - k * rq) * 4;
+                const f32x4 v = ld4z(X, rs, k, r, K, R);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const __bf16 b = (__bf16)v[e]; S[(r + e) * GS_PITCH + k] = __builtin_bit_cast(unsigned short, b); }
+            }
+        }
+    };
+    // the same from a pair matrix kept in bf16 (pair_bf16: P and dS of the dense small-group path -- they are rounded to bf16 on
+    // their way into the MFMA anyway, so storing them rounded changes no product and halves the traffic these launches are bound by)
+    auto stage_h = [&](unsigned short *S, const unsigned short *X, int rs, bool kmajor, int R, int Rp) {
+        const int q0 = kmajor ? (Rp >> 2) : (Kp >> 2), n0 = kmajor ? Kp : Rp;
+        for (int idx = tid; idx < n0 * q0; idx += 64 * GS_WAVES) {
+            const int a = idx / q0, b4 = (idx - a * q0) * 4;             // memory row a, 4 consecutive columns from b4
+            const int rows = kmajor ? K : R, cols = kmajor ? R : K;
+            unsigned short e[4] = {0, 0, 0, 0};
+            if (a < rows) {
+                const unsigned short *q = X + (size_t)a * rs + b4;
+                if (b4 + 3 < cols) { const u32x2 u = *(const u32x2 *)q; e[0] = u[0] & 0xffff; e[1] = u[0] >> 16; e[2] = u[1] & 0xffff; e[3] = u[1] >> 16; }
+                else for (int x = 0; x < 4; ++x) if (b4 + x < cols) e[x] = q[x];
+            }
+            if (!kmajor) *(u32x2 *)(S + a * GS_PITCH + b4) = (u32x2){(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16)};
+            else { S[(b4 + 0) * GS_PITCH + a] = e[0]; S[(b4 + 1) * GS_PITCH + a] = e[1]; S[(b4 + 2) * GS_PITCH + a] = e[2]; S[(b4 + 3) * GS_PITCH + a] = e[3]; }
+        }
+    };
+    const bool hA = p.pair_bf16 && p.A.kind == 1, hC = p.pair_bf16 && p.C.kind == 1;
+    const size_t pair_off = (size_t)p.poff[g] + (size_t)h * n_g * ((n_g + 3) & ~3);      // element offset of this group's pair matrix
+    if (hA) stage_h(As, (const unsigned short *)p.A.base + pair_off, rsA, p.transA != 0, M, Mp);
+    else stage(As, A, rsA, p.transA != 0, M, Mp);     // A(m, k) = opA[k][m] if transA
+    stage(Bs, B, rsB, p.transB == 0, N, Np);          // B(k, n) = opB[n][k] if transB (k contiguous), else memory [k][n]
+    __syncthreads();
+    const int tn_n = Np >> 4, tm_n = Mp >> 4;
+    if (p.epi == 0) {                                   // (node-matrix outputs only: pair matrices leave through the row epilogues)
+        for (int t = wid; t < tm_n * tn_n; t += GS_WAVES) {
+            const int tm = t / tn_n, tn = t - tm * tn_n;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const unsigned short *ap = As + (tm * 16 + (lane & 15)) * GS_PITCH + 4 * (lane >> 4);
+            const unsigned short *bp = Bs + (tn * 16 + (lane & 15)) * GS_PITCH + 4 * (lane >> 4);
+            for (int k0 = 0; k0 < Kp; k0 += 16)
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*(const s16x4_ *)(ap + k0), *(const s16x4_ *)(bp + k0), acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = tm * 16 + 4 * (lane >> 4) + r, n = tn * 16 + (lane & 15);
+                if (m < M && n < N) {
+                    float *d = C + (size_t)m * rsC + n;
+                    const float v = p.alpha * acc[r];
+                    *d = p.accumulate ? *d + v : v;
+                }
+            }
+        }
+        return;
+    }
+    // Row epilogues (pair-matrix outputs, N = n_g <= 160): a wave owns WHOLE 16-row bands of the product -- ten 16 x 16 tiles in
+    // registers -- so a row's N values sit in the 16 lanes of one lane group (lane & 15 = column inside a tile) times the tiles:
+    // row max / sums are four xor-shuffles + a loop over the tiles, and the score / dP matrices never travel to HBM and back
+    // through a separate row kernel (k_pair_rows read and wrote 84 - 126 MB per layer at configuration 5).
+    constexpr int TN_MAX = GS_MAX / 16;
+    const float *E = nullptr;
+    if (p.epi == 2) { int rsE; GOp eo = p.C; eo.base = (float *)p.E; E = op_ptr(eo, g, h, n_g, p.gp, p.poff, rsE); }
+    for (int tm = wid; tm < tm_n; tm += GS_WAVES) {
+        f32x4 acc[TN_MAX];
+        const unsigned short *ap = As + (tm * 16 + (lane & 15)) * GS_PITCH + 4 * (lane >> 4);
+#pragma unroll
+        for (int tn = 0; tn < TN_MAX; ++tn) {
+            acc[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (tn < tn_n) {
+                const unsigned short *bp = Bs + (tn * 16 + (lane & 15)) * GS_PITCH + 4 * (lane >> 4);
+                for (int k0 = 0; k0 < Kp; k0 += 16)
+                    acc[tn] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*(const s16x4_ *)(ap + k0), *(const s16x4_ *)(bp + k0), acc[tn], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = tm * 16 + 4 * (lane >> 4) + r;                 // this lane's row (shared by its 16-lane group)
+            const bool rowok = m < M;
+            if (p.epi == 1) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int tn = 0; tn < TN_MAX; ++tn) {
+                    const int n = tn * 16 + (lane & 15);
+                    const bool ok = tn < tn_n && n < N && !(p.nodiag && n == m);
+                    acc[tn][r] = ok ? p.alpha * acc[tn][r] : -INFINITY;
+                    mx = fmaxf(mx, acc[tn][r]);
+                }
+                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                float sum = 0.f;
+#pragma unroll
+                for (int tn = 0; tn < TN_MAX; ++tn) {
+                    acc[tn][r] = (mx > -INFINITY) ? expf(acc[tn][r] - mx) : 0.f;      // exp(-inf) = 0 for the excluded entries
+                    sum += acc[tn][r];
+                }
+                for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                const float inv = (mx > -INFINITY) ? 1.0f / (sum + 1e-16f) : 0.f;
+#pragma unroll
+                for (int tn = 0; tn < TN_MAX; ++tn) {
+                    const int n = tn * 16 + (lane & 15);
+                    if (rowok && tn < tn_n && n < N) {
+                        if (hC) ((unsigned short *)p.C.base + pair_off)[(size_t)m * rsC + n] = f2bf(acc[tn][r] * inv);
+                        else C[(size_t)m * rsC + n] = acc[tn][r] * inv;
+                    }
+                }
+            } else {
+                float pe[TN_MAX], D = 0.f;
+#pragma unroll
+                for (int tn = 0; tn < TN_MAX; ++tn) {
+                    const int n = tn * 16 + (lane & 15);
+                    const bool ok = rowok && tn < tn_n && n < N;
+                    pe[tn] = !ok ? 0.f : (p.pair_bf16 ? bf2f(((const unsigned short *)p.E + pair_off)[(size_t)m * rsC + n]) : E[(size_t)m * rsC + n]);
+                    acc[tn][r] = ok ? p.alpha * acc[tn][r] : 0.f;
+                    D = fmaf(pe[tn], acc[tn][r], D);
+                }
+                for (int o = 8; o > 0; o >>= 1) D += __shfl_xor(D, o);
+#pragma unroll
+                for (int tn = 0; tn < TN_MAX; ++tn) {
+                    const int n = tn * 16 + (lane & 15);
+                    if (rowok && tn < tn_n && n < N) {
+                        if (hC) ((unsigned short *)p.C.base + pair_off)[(size_t)m * rsC + n] = f2bf(pe[tn] * (acc[tn][r] - D));
+                        else C[(size_t)m * rsC + n] = pe[tn] * (acc[tn][r] - D);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // poff[g] = sum_{g' < g} H * n_g' * round4(n_g')   (one thread; G is a few hundred at most)
 __global__ void k_pair_offsets(int G, int H, const int32_t *__restrict__ gp, long long *__restrict__ poff) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -232,8 +402,28 @@ __global__ __launch_bounds__(256) void k_node_graph(int G, const int32_t *__rest
 
 static unsigned gridsz(size_t n) { const size_t b = (n + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
+// the one-workgroup-per-group kernel takes a product (bf16-operand mode, every dimension <= 160; DA_GGEMM_SMALL=0: never)
+static bool ggemm_small_ok(const GGemm &p, int maxn) {
+    const int Mx = p.dimM ? p.dimM : maxn, Nx = p.dimN ? p.dimN : maxn, Kx = p.dimK ? p.dimK : maxn;
+    static int small_off = -1;
+    if (small_off < 0) { const char *e = getenv("DA_GGEMM_SMALL"); small_off = (e && e[0] == '0') ? 1 : 0; }
+    return p.bfc && !small_off && Mx <= GS_MAX && Nx <= GS_MAX && Kx <= GS_MAX;
+}
 static int ggemm(const GGemm &p, int G, int H, int maxn, hipStream_t st) {
     const int Mx = p.dimM ? p.dimM : maxn, Nx = p.dimN ? p.dimN : maxn;
+    if (ggemm_small_ok(p, maxn)) {
+        const int Kx = p.dimK ? p.dimK : maxn;
+        GGemm q = p;
+        q.gs_pitch = ((Kx + 15) & ~15) + 8;
+        q.gs_rows_a = (Mx + 15) & ~15;
+        const int lds = (q.gs_rows_a + ((Nx + 15) & ~15)) * q.gs_pitch * 2;           // 23 KB (K = 32) ... 97 KB (three 160s)
+        static bool attr = false;
+        if (!attr) { DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_ggemm_small, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GS_MAX * (GS_MAX + 8) * 2)); attr = true; }
+        k_ggemm_small<<<G * H, 64 * GS_WAVES, lds, st>>>(q);
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
+    if (p.epi) { set_error("grouped GEMM: row epilogues exist in the small-group kernel only"); return 1; }
     if (p.bfc) k_ggemm<true><<<dim3((Nx + 63) / 64, (Mx + 63) / 64, G * H), 256, 0, st>>>(p);
     else k_ggemm<false><<<dim3((Nx + 63) / 64, (Mx + 63) / 64, G * H), 256, 0, st>>>(p);
     DA_LAUNCH_CHECK();
@@ -265,8 +455,10 @@ int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, con
     s.transA = 0; s.transB = 1; s.dimM = 0; s.dimN = 0; s.dimK = C; s.alpha = 1.0f / sqrtf((float)C); s.accumulate = 0;
     s.H = H; s.gp = g->graph_ptr; s.poff = poff;
     int rc;
+    const bool fused_rows = ggemm_small_ok(s, mx);       // small groups: the row softmax runs in the product's epilogue
+    if (fused_rows) { s.epi = 1; s.nodiag = g->dense == 2; s.pair_bf16 = 1; }
     if ((rc = ggemm(s, G, H, mx, st))) return rc;
-    k_pair_rows<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(0, n, H, g->dense == 2, g->graph_ptr, node_graph, poff, P, nullptr);
+    if (!fused_rows) k_pair_rows<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(0, n, H, g->dense == 2, g->graph_ptr, node_graph, poff, P, nullptr);
     k_init_out<<<gridsz((size_t)n * HC), 256, 0, st>>>(n, HC, qkvs, res, o);
     DA_LAUNCH_CHECK();
     GGemm pv;
@@ -276,6 +468,7 @@ int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, con
     pv.C = {o, 0, HC, C};
     pv.transA = 0; pv.transB = 0; pv.dimM = 0; pv.dimN = C; pv.dimK = 0; pv.alpha = 1.0f; pv.accumulate = 1;
     pv.H = H; pv.gp = g->graph_ptr; pv.poff = poff;
+    pv.pair_bf16 = fused_rows ? 1 : 0;                  // (ggemm_small_ok(pv) == ggemm_small_ok(s): same dimensions)
     return ggemm(pv, G, H, mx, st);
 }
 
@@ -291,13 +484,17 @@ int dense_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, con
     // dV = P^T dO
     q.A = {(float *)P, 1, 0, 0}; q.B = {(float *)d_o, 0, HC, C}; q.C = {dY4 + 2 * HC, 0, 4 * HC, C};
     q.transA = 1; q.transB = 0; q.dimM = 0; q.dimN = C; q.dimK = 0; q.alpha = 1.0f;
+    q.pair_bf16 = ggemm_small_ok(q, mx) ? 1 : 0;        // the forward of this mode kept P in bf16 (dense_train_attn_fwd)
     if ((rc = ggemm(q, G, H, mx, st))) return rc;
     // dP = dO V^T
     q.A = {(float *)d_o, 0, HC, C}; q.B = {(float *)qkvs + 2 * HC, 0, 4 * HC, C}; q.C = {dP, 1, 0, 0};
     q.transA = 0; q.transB = 1; q.dimM = 0; q.dimN = 0; q.dimK = C; q.alpha = 1.0f;
+    // dS = P o (dP - rowsum(P o dP)): small groups in the product's epilogue, else in place over dP by the row kernel
+    const bool fused_rows = ggemm_small_ok(q, mx);
+    if (fused_rows) { q.epi = 2; q.E = P; }
     if ((rc = ggemm(q, G, H, mx, st))) return rc;
-    // dS = P o (dP - rowsum(P o dP)), in place over dP
-    k_pair_rows<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(1, n, H, 0, g->graph_ptr, node_graph, poff, (float *)P, dP);
+    q.epi = 0; q.E = nullptr;
+    if (!fused_rows) k_pair_rows<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(1, n, H, 0, g->graph_ptr, node_graph, poff, (float *)P, dP);
     DA_LAUNCH_CHECK();
     // dQ = scale dS K
     q.A = {dP, 1, 0, 0}; q.B = {(float *)qkvs + HC, 0, 4 * HC, C}; q.C = {dY4, 0, 4 * HC, C};
