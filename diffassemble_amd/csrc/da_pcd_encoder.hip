@@ -457,6 +457,9 @@ __global__ __launch_bounds__(128, 1) void k_pcd_edge(const float *__restrict__ T
     // (Round 3, tried and withdrawn: requesting chunk c of neighbour r + 1 into the registers chunk c of neighbour r was just read
     // from -- 460 VGPRs, 32 gathers in flight per thread.  1.77 vs 2.03 ms per 640 000 points on one kind of box of the pool,
     // 2.91 vs 2.23 ms on another: 32 MB of outstanding gathers chip-wide is more than the slower boxes' memory side digests.)
+    // (Round 4, tried and withdrawn: the second layer's 966 weights staged in LDS and read from there with broadcast reads instead of
+    // streaming through SGPRs -- the round-3 analysis blamed the 64 s_load_dwordx16 per neighbour: 3.03 vs 2.24 ms per 640 000
+    // points; a scalar weight pair is a free operand of v_pk_fma_f32, an LDS one costs a VGPR pair and an LDS instruction each.)
     // The point's own U / Ud rows stay in 126 registers (re-reading them per neighbour doubled the divergent 16-byte
     // loads the kernel is bound by: 5.4 ms vs 2.3 ms per 640 000 points); one wave per SIMD, overflow into AGPRs.
     constexpr bool PIN_U = true;
