@@ -127,3 +127,35 @@ def test_module_runs_every_sampler_through_the_captured_loop(dev, monkeypatch):
             assert calls[0]["cfg_w"] is None
         else:
             assert calls[0]["cfg_w"] == pytest.approx(want["cfg_w"])
+
+
+def test_guided_module_loop_without_the_mfma_hoist_subprocess():
+    """Round-3 advisor finding: `GNN_Diffusion.p_sample_loop` sends every sampler through the captured loop, whose unconditional
+    (zero-feature) pass exists on the hoisted mlp.0 path only; with DA_DISABLE_MFMA=1 the library reports "unconditional pass
+    ... not available" and the module must fall back to its per-step path (which runs the second pass through
+    forward_with_feats on zero features) instead of failing.  Same poses as the default configuration to fp32 rounding."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, "tests/golden")
+import cases as C
+from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+spec = C.by_name("k36_loop_sharp"); case = C.build_case(spec); dev = torch.device("cuda:0")
+m = GNN_Diffusion(steps=50, sampling="DDIM", rotation=False, visual_pretrained=False, model_mean_type=ModelMeanType.START_X,
+                  classifier_free_prob=0.1, classifier_free_w=0.5, inference_ratio=10)
+m.model.load_state_dict(case["sd"], strict=False); m = m.to(dev).eval(); m.model.precision = "fp32"; m.noise_weight = 0.0
+imgs, _ = m.p_sample_loop(tuple(case["x"].shape), None, case["edge_index"].to(dev), case["batch"].to(dev), patch_feats=case["feats"].to(dev))
+torch.save(torch.stack(imgs).cpu(), sys.argv[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for k, extra in enumerate(({}, {"DA_DISABLE_MFMA": "1"})):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"da_cfg_fallback_{os.getpid()}_{k}.pt")
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **extra), capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(torch.load(path))
+        os.remove(path)
+    assert outs[0].shape == (5, 36, 2) and torch.isfinite(outs[1]).all()
+    assert rel(outs[1], outs[0]) < 1e-4
