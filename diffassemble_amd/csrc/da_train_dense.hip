@@ -325,6 +325,331 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_ggemm_small(GGemm p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Small groups, bf16-operand mode, second step (round 4): the WHOLE attention of a (graph, head) group in one workgroup, forward
+// and backward, flash-style -- no pair matrix ever leaves the CU.  k_ggemm_small above still ran the layer as 2 + 4 launches of
+// 30 - 50 us that each staged their operands again and carried P / dS through HBM; here K, V (then Q, dO) of the group are
+// converted to bf16 into LDS once, row-major, and everything else happens in registers:
+//   forward   a wave owns a 16-query band; its Q rows go from HBM straight into B fragments.  S^T tiles (A = K rows, B = Q rows:
+//             the accumulator then holds, per lane, four consecutive KEYS of one query -- the A-operand layout of the next
+//             product), row softmax over registers + two shuffles, O = P V with V fragments fetched by ds_read_b64_tr_b16 (the
+//             transposition happens in the LDS read: no transposed image is ever built), epilogue adds the skip projection
+//             (+ residual): k_init_out is gone too;
+//   backward  phase A, wave = query band (Q, dO bands in registers; K, V in LDS): S^T and dP^T tiles, the softmax statistics
+//             recomputed (the forward keeps nothing), D_i = sum_j P dP, dS -> dQ = scale dS K (K by transposing reads); (max,
+//             1 / sum, D) of the band go to LDS.  Then Q, dO replace K, V in LDS.  Phase B, wave = key band (K, V bands in
+//             registers): the same scores in the other orientation (rows = queries), P^T and dS^T as A operands, dV = P^T dO,
+//             dK = scale dS^T Q.  The skip gradient (a copy of dO) is written while the dO bands are fetched: k_copy_skip_grad
+//             is gone as well.
+// Products and roundings are those of the k_ggemm_small route (operands bf16, accumulation fp32, P and dS rounded to bf16 as
+// operands).  CT = 16-wide channel tiles (C <= 16 CT, zero-padded); limits: n_g <= 160, C <= 160.  DA_ATTN_SMALL_FUSED=0 keeps
+// the grouped-GEMM route.
+constexpr int AS_MAXN = 160, AS_WAVES = 10, AS_TN = AS_MAXN / 16;
+struct AttnSmall {
+    const float *qkvs;           // [n, 4 HC]  Q | K | V | skip
+    const float *res;            // forward: residual [n, HC] or null
+    float *o;                    // forward: [n, HC]
+    const float *d_o;            // backward: [n, HC]
+    float *dY4;                  // backward: [n, 4 HC]  dq | dk | dv | d_o
+    const int32_t *gp;
+    int H, C, HC, nodiag, np;    // np: max_graph_nodes rounded up to 16 (sizes the LDS images)
+    float scale;
+};
+typedef __attribute__((ext_vector_type(4))) __bf16 as_bf16x4;
+typedef __attribute__((ext_vector_type(4))) short as_s16x4;
+
+__device__ __forceinline__ as_s16x4 as_pack(float a, float b, float c, float d) {
+    const as_bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    return __builtin_bit_cast(as_s16x4, v);
+}
+// rows [0, np) x 16 CT columns of a node matrix (memory [row][ld], fp32, C valid columns, n_g valid rows) as a row-major bf16
+// image of pitch 16 CT + 8, zero beyond the valid part
+template <int CT>
+__device__ __forceinline__ void as_stage(const float *X, int ld, int n_g, int np, int C, unsigned short *R, int tid) {
+    constexpr int kq = CT * 4, pr = CT * 16 + 8;
+    for (int idx = tid; idx < np * kq; idx += 64 * AS_WAVES) {
+        const int r = idx / kq, k = (idx - r * kq) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < n_g && k < C) v = *(const f32x4 *)(X + (size_t)r * ld + k);
+        *(as_s16x4 *)(R + r * pr + k) = as_pack(v[0], v[1], v[2], v[3]);
+    }
+}
+// the 16 rows [r0, r0 + 16) as B (or A) fragments straight from memory: lane (l15, lg) takes row r0 + l15, columns 16 kt + 4 lg ..+3
+template <int CT>
+__device__ __forceinline__ void as_band(const float *X, int ld, int n_g, int C, int r0, int l15, int lg, as_s16x4 (&f)[CT],
+                                        float *copy, int ldc) {
+    const int r = r0 + l15;
+#pragma unroll
+    for (int kt = 0; kt < CT; ++kt) {
+        const int k = kt * 16 + 4 * lg;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < n_g && k < C) {
+            v = *(const f32x4 *)(X + (size_t)r * ld + k);
+            if (copy) *(f32x4 *)(copy + (size_t)r * ldc + k) = v;
+        }
+        f[kt] = as_pack(v[0], v[1], v[2], v[3]);
+    }
+}
+// B fragment (k = rows r0 + 4 lg ..+3, n = column c0 + l15) of a row-major image by a transposing read: within a 16-lane group
+// lane i' supplies the address of row (i' >> 2), columns 4 (i' & 3) ..+3 and receives column i' of the four rows
+__device__ __forceinline__ as_s16x4 as_tr(const unsigned short *img, int pr, int r0, int c0, int l15, int lg) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) as_s16x4 *)(img + (r0 + 4 * lg + (l15 >> 2)) * pr + c0 + 4 * (l15 & 3)));
+}
+#define AS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+
+// scores of one query band against every key, transposed tiles: s[tn][r] = score(query i, key 16 tn + 4 lg + r); softmax over
+// the band's rows in place (s becomes exp(s - max)); returns (max, 1 / (sum + 1e-16)) of this lane's query (PyG's softmax)
+__device__ __forceinline__ void as_softmax(f32x4 (&s)[AS_TN], int tn_n, int n_g, int i, int lg, float scale, int nodiag,
+                                           float &mx, float &inv) {
+    mx = -INFINITY;
+#pragma unroll
+    for (int tn = 0; tn < AS_TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = tn * 16 + 4 * lg + r;
+            const bool ok = tn < tn_n && j < n_g && !(nodiag && j == i);
+            s[tn][r] = ok ? scale * s[tn][r] : -INFINITY;
+            mx = fmaxf(mx, s[tn][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < AS_TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[tn][r] = (mx > -INFINITY) ? expf(s[tn][r] - mx) : 0.f;
+            sum += s[tn][r];
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    inv = (mx > -INFINITY) ? 1.0f / (sum + 1e-16f) : 0.f;
+}
+
+template <int CT>
+__global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_fwd(AttnSmall p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short as_lds[];
+    const int g = blockIdx.x / p.H, h = blockIdx.x - g * p.H;
+    const int n0 = p.gp[g], n_g = p.gp[g + 1] - n0;
+    if (n_g <= 0) return;
+    constexpr int pr = CT * 16 + 8;
+    const int C = p.C, np = p.np, ld = 4 * p.HC;
+    unsigned short *Ks = as_lds, *Vs = Ks + np * pr;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const float *base = p.qkvs + (size_t)n0 * ld + h * C;
+    as_stage<CT>(base + p.HC, ld, n_g, np, C, Ks, tid);
+    as_stage<CT>(base + 2 * p.HC, ld, n_g, np, C, Vs, tid);
+    const int tn_n = (n_g + 15) >> 4;
+    as_s16x4 qf[CT];
+    if (wid < tn_n) as_band<CT>(base, ld, n_g, C, wid * 16, l15, lg, qf, nullptr, 0);
+    __syncthreads();
+    for (int tm = wid; tm < tn_n; tm += AS_WAVES) {                    // (one band per wave: n_g <= 160)
+        const int i = tm * 16 + l15;                                   // this lane's query
+        f32x4 acc[AS_TN];
+#pragma unroll
+        for (int tn = 0; tn < AS_TN; ++tn) {
+            acc[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (tn < tn_n) {
+                const unsigned short *kp = Ks + (tn * 16 + l15) * pr + 4 * lg;
+#pragma unroll
+                for (int kt = 0; kt < CT; ++kt) acc[tn] = AS_MFMA(*(const as_s16x4 *)(kp + kt * 16), qf[kt], acc[tn]);
+            }
+        }
+        float mx, inv;
+        as_softmax(acc, tn_n, n_g, i, lg, p.scale, p.nodiag, mx, inv);
+        f32x4 oacc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tn = 0; tn < AS_TN; ++tn) {
+            if (tn < tn_n) {
+                const as_s16x4 pa = as_pack(acc[tn][0] * inv, acc[tn][1] * inv, acc[tn][2] * inv, acc[tn][3] * inv);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) oacc[ct] = AS_MFMA(pa, as_tr(Vs, pr, tn * 16, ct * 16, l15, lg), oacc[ct]);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int io = tm * 16 + 4 * lg + r, c = ct * 16 + l15;
+                if (c < C && io < n_g) {
+                    const size_t node = (size_t)(n0 + io);
+                    float v = oacc[ct][r] + p.qkvs[node * ld + 3 * p.HC + h * C + c];
+                    if (p.res) v += p.res[node * p.HC + h * C + c];
+                    p.o[node * p.HC + h * C + c] = v;
+                }
+            }
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short as_lds[];
+    const int g = blockIdx.x / p.H, h = blockIdx.x - g * p.H;
+    const int n0 = p.gp[g], n_g = p.gp[g + 1] - n0;
+    if (n_g <= 0) return;
+    constexpr int pr = CT * 16 + 8;
+    const int C = p.C, np = p.np, ld = 4 * p.HC;
+    unsigned short *I0 = as_lds, *I1 = I0 + np * pr;                  // phase A: K, V ; phase B: Q, dO
+    float *st_m = (float *)(I1 + np * pr), *st_inv = st_m + np, *st_D = st_inv + np;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const float *base = p.qkvs + (size_t)n0 * ld + h * C;
+    const float *dob = p.d_o + (size_t)n0 * p.HC + h * C;
+    float *dyb = p.dY4 + (size_t)n0 * ld + h * C;
+    as_stage<CT>(base + p.HC, ld, n_g, np, C, I0, tid);
+    as_stage<CT>(base + 2 * p.HC, ld, n_g, np, C, I1, tid);
+    const int tn_n = (n_g + 15) >> 4;
+    // ---- phase A: query bands (one per wave)
+    {
+        as_s16x4 qf[CT], gf[CT];
+        if (wid < tn_n) {
+            as_band<CT>(base, ld, n_g, C, wid * 16, l15, lg, qf, nullptr, 0);
+            as_band<CT>(dob, p.HC, n_g, C, wid * 16, l15, lg, gf, dyb + 3 * p.HC, ld);      // + the skip projection's gradient
+        }
+        __syncthreads();
+        if (wid < tn_n) {
+            const int tm = wid, i = tm * 16 + l15;
+            f32x4 sa[AS_TN], da[AS_TN];
+#pragma unroll
+            for (int tn = 0; tn < AS_TN; ++tn) {
+                sa[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                da[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (tn < tn_n) {
+                    const unsigned short *kp = I0 + (tn * 16 + l15) * pr + 4 * lg, *vp = I1 + (tn * 16 + l15) * pr + 4 * lg;
+#pragma unroll
+                    for (int kt = 0; kt < CT; ++kt) {
+                        sa[tn] = AS_MFMA(*(const as_s16x4 *)(kp + kt * 16), qf[kt], sa[tn]);
+                        da[tn] = AS_MFMA(*(const as_s16x4 *)(vp + kt * 16), gf[kt], da[tn]);
+                    }
+                }
+            }
+            float mx, inv;
+            as_softmax(sa, tn_n, n_g, i, lg, p.scale, p.nodiag, mx, inv);
+            float D = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < AS_TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // P enters the products rounded to bf16 (as the kept P of the grouped-GEMM route was); D uses the same values
+                    sa[tn][r] = bf2f(f2bf(sa[tn][r] * inv));
+                    D = fmaf(sa[tn][r], da[tn][r], D);
+                }
+            D += __shfl_xor(D, 16);
+            D += __shfl_xor(D, 32);
+            if (lg == 0) { st_m[i] = mx; st_inv[i] = inv; st_D[i] = D; }
+            f32x4 qacc[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) qacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tn = 0; tn < AS_TN; ++tn) {
+                if (tn < tn_n) {
+                    const as_s16x4 dsa = as_pack(sa[tn][0] * (da[tn][0] - D), sa[tn][1] * (da[tn][1] - D),
+                                                 sa[tn][2] * (da[tn][2] - D), sa[tn][3] * (da[tn][3] - D));
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) qacc[ct] = AS_MFMA(dsa, as_tr(I0, pr, tn * 16, ct * 16, l15, lg), qacc[ct]);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int io = tm * 16 + 4 * lg + r, c = ct * 16 + l15;
+                    if (c < C && io < n_g) dyb[(size_t)io * ld + c] = p.scale * qacc[ct][r];
+                }
+        }
+    }
+    __syncthreads();
+    as_stage<CT>(base, ld, n_g, np, C, I0, tid);
+    as_stage<CT>(dob, p.HC, n_g, np, C, I1, tid);
+    // ---- phase B: key bands (one per wave)
+    as_s16x4 kf[CT], vf[CT];
+    if (wid < tn_n) {
+        as_band<CT>(base + p.HC, ld, n_g, C, wid * 16, l15, lg, kf, nullptr, 0);
+        as_band<CT>(base + 2 * p.HC, ld, n_g, C, wid * 16, l15, lg, vf, nullptr, 0);
+    }
+    __syncthreads();
+    if (wid < tn_n) {
+        const int tj = wid, j = tj * 16 + l15;                         // this lane's key
+        f32x4 vacc[CT], kacc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { vacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; kacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int ti = 0; ti < tn_n; ++ti) {
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
+            const unsigned short *qp = I0 + (ti * 16 + l15) * pr + 4 * lg, *gpp = I1 + (ti * 16 + l15) * pr + 4 * lg;
+#pragma unroll
+            for (int kt = 0; kt < CT; ++kt) {
+                s4 = AS_MFMA(*(const as_s16x4 *)(qp + kt * 16), kf[kt], s4);
+                d4 = AS_MFMA(*(const as_s16x4 *)(gpp + kt * 16), vf[kt], d4);
+            }
+            const f32x4 m4 = *(const f32x4 *)(st_m + ti * 16 + 4 * lg), i4 = *(const f32x4 *)(st_inv + ti * 16 + 4 * lg),
+                        D4 = *(const f32x4 *)(st_D + ti * 16 + 4 * lg);
+            float pv[4], dsv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + 4 * lg + r;
+                const bool ok = i < n_g && j < n_g && !(p.nodiag && j == i) && m4[r] > -INFINITY;
+                pv[r] = ok ? bf2f(f2bf(expf(p.scale * s4[r] - m4[r]) * i4[r])) : 0.f;
+                dsv[r] = pv[r] * (d4[r] - D4[r]);
+            }
+            const as_s16x4 pa = as_pack(pv[0], pv[1], pv[2], pv[3]), dsa = as_pack(dsv[0], dsv[1], dsv[2], dsv[3]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                vacc[ct] = AS_MFMA(pa, as_tr(I1, pr, ti * 16, ct * 16, l15, lg), vacc[ct]);
+                kacc[ct] = AS_MFMA(dsa, as_tr(I0, pr, ti * 16, ct * 16, l15, lg), kacc[ct]);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jo = tj * 16 + 4 * lg + r, c = ct * 16 + l15;
+                if (c < C && jo < n_g) {
+                    float *row = dyb + (size_t)jo * ld + c;
+                    row[p.HC] = p.scale * kacc[ct][r];
+                    row[2 * p.HC] = vacc[ct][r];
+                }
+            }
+    }
+}
+#undef AS_MFMA
+
+static int as_tiles(int C) { const int ct = (C + 15) / 16; return ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : ct <= 9 ? 9 : 10; }
+static bool attn_small_ok(const da_graph *g, int C, bool bfc) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("DA_ATTN_SMALL_FUSED"); off = (e && e[0] == '0') ? 1 : 0; }
+    return bfc && !off && g->max_graph_nodes <= AS_MAXN && C <= 160 && C % 4 == 0;
+}
+template <int CT>
+static int attn_small_launch_ct(const da_graph *g, AttnSmall &a, bool bwd, hipStream_t st) {
+    constexpr int pr = CT * 16 + 8;
+    const int lds = 2 * a.np * pr * 2 + (bwd ? 3 * a.np * 4 : 0);
+    static bool attr = false;
+    if (!attr) {
+        const int cap = 2 * AS_MAXN * pr * 2 + 3 * AS_MAXN * 4;
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_bwd<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_fwd<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        attr = true;
+    }
+    if (bwd) k_attn_small_bwd<CT><<<g->n_graphs * a.H, 64 * AS_WAVES, lds, st>>>(a);
+    else k_attn_small_fwd<CT><<<g->n_graphs * a.H, 64 * AS_WAVES, lds, st>>>(a);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+static int attn_small_launch(const da_graph *g, int H, int C, AttnSmall &a, bool bwd, hipStream_t st) {
+    a.gp = g->graph_ptr; a.H = H; a.C = C; a.HC = H * C; a.nodiag = g->dense == 2;
+    a.np = (g->max_graph_nodes + 15) & ~15;
+    a.scale = 1.0f / sqrtf((float)C);
+    switch (as_tiles(C)) {
+    case 1: return attn_small_launch_ct<1>(g, a, bwd, st);
+    case 2: return attn_small_launch_ct<2>(g, a, bwd, st);
+    case 4: return attn_small_launch_ct<4>(g, a, bwd, st);
+    case 9: return attn_small_launch_ct<9>(g, a, bwd, st);
+    default: return attn_small_launch_ct<10>(g, a, bwd, st);
+    }
+}
+
 // poff[g] = sum_{g' < g} H * n_g' * round4(n_g')   (one thread; G is a few hundred at most)
 __global__ void k_pair_offsets(int G, int H, const int32_t *__restrict__ gp, long long *__restrict__ poff) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -447,6 +772,11 @@ int dense_train_prepare(const da_graph *g, int H, long long *poff, int32_t *node
 int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P,
                          const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc) {
     const int n = g->n_nodes, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
+    if (attn_small_ok(g, C, bfc)) {       // small groups: the whole layer in one launch, P never stored (k_attn_small_fwd)
+        AttnSmall a{};
+        a.qkvs = qkvs; a.res = res; a.o = o;
+        return attn_small_launch(g, H, C, a, false, st);
+    }
     GGemm s;
     s.bfc = bfc;
     s.A = {(float *)qkvs, 0, 4 * HC, C};
@@ -478,6 +808,11 @@ int dense_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, con
     const int n = g->n_nodes, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
     const float scale = 1.0f / sqrtf((float)C);
     int rc;
+    if (attn_small_ok(g, C, bfc)) {       // matches dense_train_attn_fwd's choice: that forward kept no P
+        AttnSmall a{};
+        a.qkvs = qkvs; a.d_o = d_o; a.dY4 = dY4;
+        return attn_small_launch(g, H, C, a, true, st);
+    }
     GGemm q;
     q.bfc = bfc;
     q.H = H; q.gp = g->graph_ptr; q.poff = poff; q.accumulate = 0;

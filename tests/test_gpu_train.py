@@ -101,7 +101,7 @@ def test_backward_matches_oracle_autograd(dev, name):
     assert all(lo <= params[k].grad.data_ptr() < hi for k in g_ref)
 
 
-@pytest.mark.parametrize("name", ["rot144_g2_sharp", "ragged_dense", "exo144_v8_g2", "exo_expander_d6"])
+@pytest.mark.parametrize("name", ["k36_noloop_eps", "rot144_g2_sharp", "ragged_dense", "exo144_v8_g2", "exo_expander_d6"])
 def test_bf16_mma_training_mode_against_the_fp32_oracle(dev, monkeypatch, name):
     """TrainEngine.precision = "bf16" (DA_TRAIN_MMA_BF16: every Linear forward / dX / dW product and the grouped attention
     GEMMs take operands rounded to bf16, fp32 accumulation, fp32 storage; what autocast(bfloat16) does to the reference's
