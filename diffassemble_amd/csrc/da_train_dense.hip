@@ -366,12 +366,20 @@ __device__ __forceinline__ as_s16x4 as_pack(float a, float b, float c, float d) 
 // image of pitch 16 CT + 8, zero beyond the valid part
 template <int CT>
 __device__ __forceinline__ void as_stage(const float *X, int ld, int n_g, int np, int C, unsigned short *R, int tid) {
-    constexpr int kq = CT * 4, pr = CT * 16 + 8;
-    for (int idx = tid; idx < np * kq; idx += 64 * AS_WAVES) {
-        const int r = idx / kq, k = (idx - r * kq) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < n_g && k < C) v = *(const f32x4 *)(X + (size_t)r * ld + k);
-        *(as_s16x4 *)(R + r * pr + k) = as_pack(v[0], v[1], v[2], v[3]);
+    constexpr int kq = CT * 4, pr = CT * 16 + 8, NB = CT >= 4 ? 4 : 2;      // NB loads in flight per thread before the first LDS store
+    for (int i0 = tid; i0 < np * kq; i0 += 64 * AS_WAVES * NB) {
+        f32x4 v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = i0 + u * 64 * AS_WAVES, r = idx / kq, k = (idx - r * kq) * 4;
+            v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (r < n_g && k < C) v[u] = *(const f32x4 *)(X + (size_t)r * ld + k);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = i0 + u * 64 * AS_WAVES, r = idx / kq, k = (idx - r * kq) * 4;
+            if (idx < np * kq) *(as_s16x4 *)(R + r * pr + k) = as_pack(v[u][0], v[u][1], v[u][2], v[u][3]);
+        }
     }
 }
 // the 16 rows [r0, r0 + 16) as B (or A) fragments straight from memory: lane (l15, lg) takes row r0 + l15, columns 16 kt + 4 lg ..+3
@@ -466,21 +474,29 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_fwd(AttnSmall p) {
             if (tn < tn_n) {
                 const as_s16x4 pa = as_pack(acc[tn][0] * inv, acc[tn][1] * inv, acc[tn][2] * inv, acc[tn][3] * inv);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) oacc[ct] = AS_MFMA(pa, as_tr(Vs, pr, tn * 16, ct * 16, l15, lg), oacc[ct]);
+                for (int ct = 0; ct < CT; ++ct) oacc[ct] = AS_MFMA(as_tr(Vs, pr, tn * 16, ct * 16, l15, lg), pa, oacc[ct]);
             }
         }
+        // O^T tiles (A = V^T by the transposing read, B = P^T): a lane holds four consecutive CHANNELS of its query, so the skip
+        // projection, the residual and o move as 16-byte pieces, all loads issued before the first use
+        if (i < n_g) {
+            // (channel offsets beyond C are clamped to 0 instead of guarded: guarded loads compile to load -> wait round trips)
+            const float *skp = base + 3 * p.HC + (size_t)i * ld;
+            f32x4 sk[CT], rs[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct) sk[ct] = *(const f32x4 *)(skp + (ct * 16 + 4 * lg < C ? ct * 16 + 4 * lg : 0));
+            if (p.res) {
+                const float *rsp = p.res + (size_t)(n0 + i) * p.HC + h * C;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int io = tm * 16 + 4 * lg + r, c = ct * 16 + l15;
-                if (c < C && io < n_g) {
-                    const size_t node = (size_t)(n0 + io);
-                    float v = oacc[ct][r] + p.qkvs[node * ld + 3 * p.HC + h * C + c];
-                    if (p.res) v += p.res[node * p.HC + h * C + c];
-                    p.o[node * p.HC + h * C + c] = v;
-                }
+                for (int ct = 0; ct < CT; ++ct) rs[ct] = *(const f32x4 *)(rsp + (ct * 16 + 4 * lg < C ? ct * 16 + 4 * lg : 0));
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) sk[ct] += rs[ct];
             }
+            float *ob = p.o + (size_t)(n0 + i) * p.HC + h * C + 4 * lg;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (ct * 16 + 4 * lg < C) *(f32x4 *)(ob + ct * 16) = oacc[ct] + sk[ct];
+        }
     }
 }
 
@@ -548,16 +564,14 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
                     const as_s16x4 dsa = as_pack(sa[tn][0] * (da[tn][0] - D), sa[tn][1] * (da[tn][1] - D),
                                                  sa[tn][2] * (da[tn][2] - D), sa[tn][3] * (da[tn][3] - D));
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) qacc[ct] = AS_MFMA(dsa, as_tr(I0, pr, tn * 16, ct * 16, l15, lg), qacc[ct]);
+                    for (int ct = 0; ct < CT; ++ct) qacc[ct] = AS_MFMA(as_tr(I0, pr, tn * 16, ct * 16, l15, lg), dsa, qacc[ct]);
                 }
             }
+            if (i < n_g) {                                            // dQ^T tiles: four consecutive channels of query i per lane
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int io = tm * 16 + 4 * lg + r, c = ct * 16 + l15;
-                    if (c < C && io < n_g) dyb[(size_t)io * ld + c] = p.scale * qacc[ct][r];
-                }
+                for (int ct = 0; ct < CT; ++ct)
+                    if (ct * 16 + 4 * lg < C) *(f32x4 *)(dyb + (size_t)i * ld + ct * 16 + 4 * lg) = p.scale * qacc[ct];
+            }
         }
     }
     __syncthreads();
@@ -596,21 +610,19 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
             const as_s16x4 pa = as_pack(pv[0], pv[1], pv[2], pv[3]), dsa = as_pack(dsv[0], dsv[1], dsv[2], dsv[3]);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                vacc[ct] = AS_MFMA(pa, as_tr(I1, pr, ti * 16, ct * 16, l15, lg), vacc[ct]);
-                kacc[ct] = AS_MFMA(dsa, as_tr(I0, pr, ti * 16, ct * 16, l15, lg), kacc[ct]);
+                vacc[ct] = AS_MFMA(as_tr(I1, pr, ti * 16, ct * 16, l15, lg), pa, vacc[ct]);
+                kacc[ct] = AS_MFMA(as_tr(I0, pr, ti * 16, ct * 16, l15, lg), dsa, kacc[ct]);
             }
         }
+        if (j < n_g) {                                                // dK^T, dV^T tiles: four consecutive channels of key j per lane
+            float *row = dyb + (size_t)j * ld + 4 * lg;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int jo = tj * 16 + 4 * lg + r, c = ct * 16 + l15;
-                if (c < C && jo < n_g) {
-                    float *row = dyb + (size_t)jo * ld + c;
-                    row[p.HC] = p.scale * kacc[ct][r];
-                    row[2 * p.HC] = vacc[ct][r];
+            for (int ct = 0; ct < CT; ++ct)
+                if (ct * 16 + 4 * lg < C) {
+                    *(f32x4 *)(row + p.HC + ct * 16) = p.scale * kacc[ct];
+                    *(f32x4 *)(row + 2 * p.HC + ct * 16) = vacc[ct];
                 }
-            }
+        }
     }
 }
 #undef AS_MFMA
