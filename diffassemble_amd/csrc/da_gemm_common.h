@@ -98,6 +98,7 @@ struct GemmParams {
     void *Q, *Kb, *Vt, *S;
     int nct, nt;     // column tiles of this launch, column tiles per workgroup
     int xcd_groups;  // > 0: 1-D grid, XCD-aware (row tile, column group) mapping with this many column groups
+    int ksplit, kchunk;   // ksplit > 1 (XCD-aware grid only): blockIdx.y = reduction split z over [z kchunk, (z + 1) kchunk); out = partial [ksplit][M][ldo]
     unsigned long long *prof;   // DA_GEMM_PROBE builds: per-workgroup cycle breakdown [total, wait, mma, epilogue]
     int debug;   // DA_GEMM_DEBUG bits: 1 = no global stores, 2 = no MFMA, 4 = no DMA (timing experiments only)
 };

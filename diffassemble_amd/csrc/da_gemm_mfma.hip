@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     }
     const int row0 = by * 128;
     constexpr int ES = (int)sizeof(T), EPC = 16 / ES, BK = 128 / ES;
+    const int zs = p.ksplit > 1 ? (int)blockIdx.y : 0;                       // reduction split (XCD-aware 1-D grid: blockIdx.y is free)
+    const size_t koff = (size_t)zs * p.kchunk * ES;
     constexpr int ROWS = ES == 4 ? 32 : 64, PASSES = 128 / ROWS, CPR = 128 * ES / 16, NIT = ROWS * CPR / 256;
     const int t_beg = bx * p.nt, t_end = min(t_beg + p.nt, p.nct);
 
@@ -144,13 +146,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     // The DMA writes lane l at (wave-uniform base) + 16 l, i.e. row (l >> 3), slot (l & 7); the XOR
     // swizzle is therefore applied on the SOURCE: slot s of row r holds logical chunk s ^ (r & 7).
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
-    const char *Wb = (const char *)p.W + lc * 16;
+    const char *Wb = (const char *)p.W + lc * 16 + koff;
     const size_t ldaB = (size_t)p.lda * sizeof(T), ldwB = (size_t)p.ldw * sizeof(T);
     const char *ap[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        ap[j] = (const char *)p.A + lc * 16 + (size_t)min(row0 + 32 * wid + 8 * j + lr, p.M - 1) * ldaB;
-    const int nk = p.K / BK;
+        ap[j] = (const char *)p.A + lc * 16 + koff + (size_t)min(row0 + 32 * wid + 8 * j + lr, p.M - 1) * ldaB;
+    const int nk = (p.ksplit > 1 ? p.kchunk : p.K) / BK;
     const int S = (t_end - t_beg) * nk;                       // stages of this workgroup
     auto issue = [&](int s) {
         const int ti = s / nk, kt = s - ti * nk;
@@ -215,6 +217,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
         // row (or, for V columns, 4 consecutive nodes of one feature): 8-byte pieces scattered over 16
         // rows per instruction, ~1 TB/s if written directly.  Staging area = the ring slot just consumed.
         unsigned char *stg = smem + ((ti * nk + nk - 1) & 1) * 32768;
+        if (p.ksplit > 1) {                                   // this split's partial image (bias / residual are added by the reduction)
+            GemmParams q = p;
+            q.out = (char *)p.out + (size_t)zs * p.M * p.ldo * ES;
+            mfma_epilogue<T, ACT, PASSES, NIT>(q, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
+        } else
         mfma_epilogue<T, ACT, PASSES, NIT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
     }
 }
@@ -242,6 +249,7 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     p.ldw = ldw; p.pre = pre; p.Cv = 0; p.Cvmagic = 0;
     p.out = out; p.ldo = ldo; p.qkv = 0; p.HC = 1; p.C = 1; p.n_pad = 0; p.row_map = nullptr; p.Cmagic = 0;
     p.xcd_groups = 0;
+    p.ksplit = 0; p.kchunk = 0;
     p.Q = p.Kb = p.Vt = p.S = nullptr;
     { const char *e = getenv("DA_GEMM_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     { const char *e = getenv("DA_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
@@ -313,6 +321,52 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     }
 #undef DA_GEMM_ACT
 #undef DA_GEMM_LAUNCH
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[m][c] = sum_z partial[z][m][c] (+ bias[c]) (+ res[m][c]): fixed order
+__global__ __launch_bounds__(256) void k_splitk_reduce(int splits, int M, int N, const float *__restrict__ partial,
+                                                       const float *__restrict__ bias, const float *res, float *out, int ldo) {
+    const size_t MN = (size_t)M * N, n4 = MN / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 s = *(const f32x4 *)(partial + 4 * i);
+        for (int z = 1; z < splits; ++z) s += *(const f32x4 *)(partial + (size_t)z * MN + 4 * i);
+        const size_t m = 4 * i / N, c = 4 * i - m * N;
+        if (bias) s += *(const f32x4 *)(bias + c);
+        if (res) s += *(const f32x4 *)(res + m * ldo + c);
+        *(f32x4 *)(out + m * ldo + c) = s;
+    }
+}
+
+// Skinny outputs with a long reduction in the bf16-operand training mode (dX of the conv projections: Nout = 256, K = 1024 ...
+// 4608 at BASELINE configuration 5): 72 row tiles x 2 column tiles leave 44 % of the CUs without a workgroup.  The reduction is
+// cut into `splits` pieces that run as separate workgroups of ONE launch (partial images [split][M][Nout], fp32) and a second
+// kernel adds them in a fixed order together with bias and residual.  Returns -1 when the shape does not qualify.
+int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, const void *res,
+                            void *out, int ldo, float *partial, size_t partial_floats, hipStream_t st) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("DA_GEMM_SPLITK"); off = (e && e[0] == '0') ? 1 : 0; }
+    const int nrt = (M + 127) / 128, nct = (Nout + 127) / 128;
+    if (off || !partial || nct < 2 || 8 * ((nrt + 7) / 8) * nct > 320 || K < 1024 || K % 128 != 0 || Nout % 4 != 0 || ldo % 4 != 0 ||
+        !aligned16(A) || !aligned16(W) || !aligned16(out) || (res && !aligned16(res)) || (bias && !aligned16(bias)) ||
+        ((size_t)lda * 4) % 16 != 0 || ((size_t)K * 4) % 16 != 0)
+        return -1;
+    int splits = 4;
+    while (splits > 1 && (K % (splits * 32) != 0 || (size_t)splits * M * Nout > partial_floats)) --splits;
+    if (splits < 2) return -1;
+    GemmParams p;
+    p.M = M; p.K = K; p.Nout = Nout; p.A = A; p.lda = lda; p.W = W; p.bias = nullptr; p.act = DA_ACT_NONE; p.res = nullptr;
+    p.ldw = K; p.pre = nullptr; p.Cv = 0; p.Cvmagic = 0;
+    p.out = partial; p.ldo = Nout; p.qkv = 0; p.HC = 1; p.C = 1; p.n_pad = 0; p.row_map = nullptr; p.Cmagic = 0;
+    p.Q = p.Kb = p.Vt = p.S = nullptr;
+    p.prof = nullptr; p.debug = 0;
+    p.nct = nct; p.nt = 1; p.xcd_groups = nct;
+    p.ksplit = splits; p.kchunk = K / splits;
+    k_gemm_mfma<float, false, DA_ACT_NONE, true><<<dim3((unsigned)(8 * ((nrt + 7) / 8) * nct), (unsigned)splits), 256, 0, st>>>(p);
+    const size_t n4 = (size_t)M * Nout / 4;
+    k_splitk_reduce<<<(unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256), 256, 0, st>>>(splits, M, Nout, partial, bias,
+                                                                                                   (const float *)res, (float *)out, ldo);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -235,6 +235,129 @@ int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B,
 }
 
 // ---------------------------------------------------------------------------------------------
+// dW + db in ONE pass for the bf16-operand training mode (round 4): C[n][k] += sum_m A[m][n] B[m][k] and, if db,
+// db[n] += sum_m A[m][n] (A = dY, B = X, fp32 row-major).  k_gemm_tn<true> above is bound by what its 64 x 64 tiles pull through
+// the L2 (every dY column block is re-read K / 64 times, every X column block N / 64 times: 1.36 GB per call at BASELINE
+// configuration 5's conv 3) and the bias gradient read dY once more in its own two kernels.  Here: 128 x 128 tiles (half the
+// operand traffic), 32 rows of m per stage, the fp32 tiles rounded to bf16 on their way into LDS (row-major [m][col], 8-byte
+// stores) and fetched as MFMA fragments by ds_read_b64_tr_b16 (one read per 16 x 16 operand block instead of four scalar reads +
+// four conversions); the workgroups of the first k tile also add up their dY columns in fp32 (exact values, fixed order) while
+// they stage them.  grid = (ceil(K/128), ceil(N/128), splits).
+typedef __attribute__((ext_vector_type(4))) short tn_s16x4;
+__global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                    const float *__restrict__ B, int ldb, float *C, int ldc,
+                                                    float *partial, float *bpartial, int Mc) {
+    constexpr int PT = 136;                                      // LDS row pitch (bf16 elements): 272 B
+    __shared__ __attribute__((aligned(16))) unsigned short As[32 * PT];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[32 * PT];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1, l15 = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
+    const int m_beg = blockIdx.z * Mc, m_end = min(M, m_beg + Mc);
+    const int lrow = tid >> 5, lc4 = (tid & 31) * 4;             // stage rows lrow + 8 u, columns lc4 ..+3
+    const bool vecA = (lda % 4 == 0) && (((size_t)A & 15) == 0), vecB = (ldb % 4 == 0) && (((size_t)B & 15) == 0);
+    const bool want_db = bpartial != nullptr && blockIdx.x == 0;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[4], rb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        ra[u] = load_row4(A, lda, m_beg + lrow + 8 * u, n0 + lc4, m_end, N, vecA);
+        rb[u] = load_row4(B, ldb, m_beg + lrow + 8 * u, k0 + lc4, m_end, K, vecB);
+    }
+    auto pack = [](const f32x4 &v) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+        const bf16x4_ b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        return __builtin_bit_cast(tn_s16x4, b);
+    };
+    for (int m0 = m_beg; m0 < m_end; m0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *(tn_s16x4 *)(As + (lrow + 8 * u) * PT + lc4) = pack(ra[u]);
+            *(tn_s16x4 *)(Bs + (lrow + 8 * u) * PT + lc4) = pack(rb[u]);
+            csum += ra[u];
+        }
+        __syncthreads();
+        if (m0 + 32 < m_end) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ra[u] = load_row4(A, lda, m0 + 32 + lrow + 8 * u, n0 + lc4, m_end, N, vecA);
+                rb[u] = load_row4(B, ldb, m0 + 32 + lrow + 8 * u, k0 + lc4, m_end, K, vecB);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            tn_s16x4 a[4], b[4];
+            // fragment (k = rows 16 ks + 4 lg ..+3, n = column c0 + l15): lane i' of a 16-lane group supplies the address of
+            // row (i' >> 2), columns 4 (i' & 3) ..+3 and receives column i' of the four rows
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4 *)(
+                    As + (16 * ks + 4 * lg + (l15 >> 2)) * PT + wr * 64 + i * 16 + 4 * (l15 & 3)));
+                b[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4 *)(
+                    Bs + (16 * ks + 4 * lg + (l15 >> 2)) * PT + wc * 64 + i * 16 + 4 * (l15 & 3)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float *dst = partial ? partial + (size_t)blockIdx.z * N * K : C;
+    const int ldd = partial ? K : ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wr * 64 + i * 16 + 4 * lg + r, k = k0 + wc * 64 + j * 16 + l15;
+                if (n < N && k < K) {
+                    if (partial) dst[(size_t)n * ldd + k] = acc[i][j][r];
+                    else dst[(size_t)n * ldd + k] += acc[i][j][r];
+                }
+            }
+    if (want_db) {                                              // the eight row groups' sums of each column, fixed order
+        float *red = (float *)As;                               // [8][128] floats = 4 KB of the 8.5 KB tile
+        *(f32x4 *)(red + lrow * 128 + lc4) = csum;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += red[g * 128 + tid];
+            bpartial[(size_t)blockIdx.z * N + n0 + tid] = s;
+        }
+    }
+}
+
+// dW (+ db) of the bf16-operand mode.  bscratch: splits * N floats
+int launch_gemm_tn_db(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                      float *partial, float *db, float *bscratch, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int tn = (N + 127) / 128, tk = (K + 127) / 128;
+    long splits = 640 / ((long)tn * tk);
+    const long by_rows = (M + 255) / 256, by_cap = (long)(PART_CAP / ((size_t)N * K));
+    splits = splits > by_rows ? by_rows : splits;
+    splits = splits > by_cap ? by_cap : splits;
+    if (splits < 1) splits = 1;
+    int Mc = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
+    splits = (M + Mc - 1) / Mc;
+    const dim3 grid((unsigned)tk, (unsigned)tn, (unsigned)splits);
+    k_gemm_tn_db<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc);
+    if (splits > 1) {
+        const size_t NK = (size_t)N * K;
+        k_reduce_partial<<<(unsigned)((NK + 255) / 256 > 4096 ? 4096 : (NK + 255) / 256), 256, 0, st>>>((int)splits, N, K, partial, C, ldc);
+    }
+    if (db) k_colsum_finish<<<(N + 63) / 64, 256, 0, st>>>((int)splits, N, bscratch, db);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // bf16 variant of the dW kernel (the encoder's bf16 training mode): C[n][k] (+)= sum_m A[m][n] B[m][k], A / B bf16
 // row-major, fp32 accumulation and output.  v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE reduction indices per lane,
 // and the reduction index m is the slow one in memory, so the tiles are transposed on their way into LDS: a thread loads
@@ -676,10 +799,20 @@ int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch
 static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, const float *W,
                       float *dW, float *db, float *dX, int lddx, const float *res, TrainWs &ws, hipStream_t st, bool bfc) {
     int rc;
-    if ((rc = launch_gemm_tn(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, st, bfc))) return rc;
-    if (db && (rc = colsum_add(M, N, dY, ldy, db, ws.csum, st))) return rc;
+    static int tn_db = -1;
+    if (tn_db < 0) { const char *e = getenv("DA_TRAIN_TN_DB"); tn_db = (e && e[0] == '0') ? 0 : 1; }
+    if (bfc && tn_db) {                                     // dW and db from one pass over dY (k_gemm_tn_db)
+        if ((rc = launch_gemm_tn_db(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, db, ws.csum, st))) return rc;
+    } else {
+        if ((rc = launch_gemm_tn(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, st, bfc))) return rc;
+        if (db && (rc = colsum_add(M, N, dY, ldy, db, ws.csum, st))) return rc;
+    }
     if (dX) {
         if ((rc = launch_transpose_f32(N, K, W, ws.wt, st))) return rc;                      // W [N, K] -> W^T [K, N]
+        if (bfc) {                                          // skinny dX with a long reduction: split over the reduction (one launch + a fixed-order sum)
+            rc = launch_gemm_mfma_splitk(M, N, K, dY, ldy, ws.wt, nullptr, res, dX, lddx, ws.partial, PART_CAP, st);
+            if (rc >= 0) return rc;
+        }
         if ((rc = linear(bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32, M, N, K, dY, ldy, ws.wt, nullptr, DA_ACT_NONE, res, dX, lddx, st))) return rc;
     }
     return 0;
