@@ -348,7 +348,7 @@ int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, cons
     static int off = -1;
     if (off < 0) { const char *e = getenv("DA_GEMM_SPLITK"); off = (e && e[0] == '0') ? 1 : 0; }
     const int nrt = (M + 127) / 128, nct = (Nout + 127) / 128;
-    if (off || !partial || nct < 2 || 8 * ((nrt + 7) / 8) * nct > 320 || K < 1024 || K % 128 != 0 || Nout % 4 != 0 || ldo % 4 != 0 ||
+    if (off || !partial || 8 * ((nrt + 7) / 8) * nct > 320 || K < 1024 || K % 128 != 0 || Nout % 4 != 0 || ldo % 4 != 0 ||
         !aligned16(A) || !aligned16(W) || !aligned16(out) || (res && !aligned16(res)) || (bias && !aligned16(bias)) ||
         ((size_t)lda * 4) % 16 != 0 || ((size_t)K * 4) % 16 != 0)
         return -1;

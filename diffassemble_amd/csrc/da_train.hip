@@ -246,16 +246,27 @@ int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B,
 typedef __attribute__((ext_vector_type(4))) short tn_s16x4;
 __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const float *__restrict__ A, int lda,
                                                     const float *__restrict__ B, int ldb, float *C, int ldc,
-                                                    float *partial, float *bpartial, int Mc) {
+                                                    float *partial, float *bpartial, int Mc, int xcd_tk) {
     constexpr int PT = 136;                                      // LDS row pitch (bf16 elements): 272 B
     __shared__ __attribute__((aligned(16))) unsigned short As[32 * PT];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[32 * PT];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1, l15 = lane & 15, lg = lane >> 4;
-    const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
-    const int m_beg = blockIdx.z * Mc, m_end = min(M, m_beg + Mc);
+    // xcd_tk > 0: 1-D grid with the row split = id % splits (splits a multiple of 8: workgroups are dealt round-robin over the
+    // 8 XCDs, so ALL tiles of one row range run on one XCD, start together and walk the rows at the same pace -- the operand
+    // rows one of them pulls in are L2 hits for the others; with the 3-D grid the tiles of a row range were spread over the XCDs
+    // and every one of them fetched its operands from the fabric)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (xcd_tk > 0) {
+        const int splits = (M + Mc - 1) / Mc, tile = blockIdx.x / splits;
+        bz = blockIdx.x - tile * splits;
+        by = tile / xcd_tk;
+        bx = tile - by * xcd_tk;
+    }
+    const int n0 = by * 128, k0 = bx * 128;
+    const int m_beg = bz * Mc, m_end = min(M, m_beg + Mc);
     const int lrow = tid >> 5, lc4 = (tid & 31) * 4;             // stage rows lrow + 8 u, columns lc4 ..+3
     const bool vecA = (lda % 4 == 0) && (((size_t)A & 15) == 0), vecB = (ldb % 4 == 0) && (((size_t)B & 15) == 0);
-    const bool want_db = bpartial != nullptr && blockIdx.x == 0;
+    const bool want_db = bpartial != nullptr && bx == 0;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const f
         }
         __syncthreads();
     }
-    float *dst = partial ? partial + (size_t)blockIdx.z * N * K : C;
+    float *dst = partial ? partial + (size_t)bz * N * K : C;
     const int ldd = partial ? K : ldc;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const f
             float s = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += red[g * 128 + tid];
-            bpartial[(size_t)blockIdx.z * N + n0 + tid] = s;
+            bpartial[(size_t)bz * N + n0 + tid] = s;
         }
     }
 }
@@ -344,10 +355,18 @@ int launch_gemm_tn_db(int M, int N, int K, const float *A, int lda, const float 
     splits = splits > by_rows ? by_rows : splits;
     splits = splits > by_cap ? by_cap : splits;
     if (splits < 1) splits = 1;
+    static int xcd_off = -1;
+    if (xcd_off < 0) { const char *e = getenv("DA_TN_NO_XCD_MAP"); xcd_off = (e && e[0] == '1') ? 1 : 0; }
+    // several tiles and enough rows: exactly 8 (or 16) row ranges, one (two) per XCD (see the kernel)
+    const bool xcd = !xcd_off && tn * tk >= 8 && by_rows >= 8 && by_cap >= 8;
+    if (xcd) splits = (tn * tk <= 24 && by_rows >= 16 && by_cap >= 16) ? 16 : 8;
     int Mc = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
+    const long want = splits;
     splits = (M + Mc - 1) / Mc;
-    const dim3 grid((unsigned)tk, (unsigned)tn, (unsigned)splits);
-    k_gemm_tn_db<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc);
+    const bool xmap = xcd && splits == want;
+    const dim3 grid = xmap ? dim3((unsigned)(tk * tn * splits)) : dim3((unsigned)tk, (unsigned)tn, (unsigned)splits);
+    k_gemm_tn_db<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc,
+                                       xmap ? tk : 0);
     if (splits > 1) {
         const size_t NK = (size_t)N * K;
         k_reduce_partial<<<(unsigned)((NK + 255) / 256 > 4096 ? 4096 : (NK + 255) / 256), 256, 0, st>>>((int)splits, N, K, partial, C, ldc);
@@ -818,6 +837,17 @@ static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float
     return 0;
 }
 
+// forward Linear of the training path: the bf16-operand mode tries the reduction-split launch first (skinny outputs with a
+// long reduction: mlp.0 and the head's first layer leave most CUs idle otherwise)
+static int linear_fw(const Dims &d, TrainWs &ws, int M, int K, int Nout, const float *A, int lda, const float *W, const float *bias,
+                     float *out, int ldo, hipStream_t st) {
+    if (d.bfc) {
+        const int rc = launch_gemm_mfma_splitk(M, K, Nout, A, lda, W, bias, nullptr, out, ldo, ws.partial, PART_CAP, st);
+        if (rc >= 0) return rc;
+    }
+    return linear(d.bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32, M, K, Nout, A, lda, W, bias, DA_ACT_NONE, nullptr, out, ldo, st);
+}
+
 }  // namespace da
 
 using namespace da;
@@ -851,7 +881,7 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
     if ((rc = launch_set_feats(P, nr, d.F, D, feats, ws.comb_in, st))) return rc;
     if ((rc = launch_embed_pos_time(P, nr, d.c_in, d.F, D, x, t, 0, w->steps, w->time_emb, w->pos_w0, w->pos_b0, w->pos_w1,
                                     w->pos_b1, ws.comb_in, st))) return rc;
-    if ((rc = linear(PL, nr, D, d.hid, ws.comb_in, D, w->mlp_w0, w->mlp_b0, DA_ACT_NONE, nullptr, ws.m1pre, d.hid, st))) return rc;
+    if ((rc = linear_fw(d, ws, nr, D, d.hid, ws.comb_in, D, w->mlp_w0, w->mlp_b0, ws.m1pre, d.hid, st))) return rc;
     if ((rc = gelu_fwd((size_t)nr * d.hid, ws.m1pre, ws.m1, st))) return rc;
     if ((rc = linear(PL, nr, d.hid, D, ws.m1, d.hid, w->mlp_w1, w->mlp_b1, DA_ACT_NONE, nullptr, ws.h0, D, st))) return rc;
     if (d.V > 0) {
@@ -883,7 +913,7 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
         ldx = d.hc[l];
     }
     const float *z = ws.o[d.L - 1];                           // conv output + combined (efficient_gat.py:144)
-    if ((rc = linear(PL, nr, D, 32, z, D, w->head_w0, w->head_b0, DA_ACT_NONE, nullptr, ws.f1pre, 32, st))) return rc;
+    if ((rc = linear_fw(d, ws, nr, D, 32, z, D, w->head_w0, w->head_b0, ws.f1pre, 32, st))) return rc;
     if ((rc = gelu_fwd((size_t)nr * 32, ws.f1pre, ws.f1, st))) return rc;
     return launch_head2d(P, nr, d.c_out, ws.f1, w->head_w1, w->head_b1, out, st);
 }
