@@ -113,7 +113,9 @@ __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (
     }
 }
 
-template <typename T, bool QKV, int ACT, bool BFC = false>
+// TO: element type of out / res / pre (default: the operand type T).  T = float + BFC with TO = bf16_t, and T = bf16_t with
+// TO = float, are the two mixed forms of the training path's bf16 projection buffers (da_train.hip, q16 mode).
+template <typename T, bool QKV, int ACT, bool BFC = false, typename TO = T>
 __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     // two stages x (A tile 16 KB + W tile 16 KB), filled by LDS-DMA (global_load_lds_dwordx4).  A
     // workgroup owns one 128-row tile of A and walks `nt` consecutive 128-column tiles of W as ONE
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     constexpr int ES = (int)sizeof(T), EPC = 16 / ES, BK = 128 / ES;
     const int zs = p.ksplit > 1 ? (int)blockIdx.y : 0;                       // reduction split (XCD-aware 1-D grid: blockIdx.y is free)
     const size_t koff = (size_t)zs * p.kchunk * ES;
-    constexpr int ROWS = ES == 4 ? 32 : 64, PASSES = 128 / ROWS, CPR = 128 * ES / 16, NIT = ROWS * CPR / 256;
+    constexpr int EO = (int)sizeof(TO);
+    constexpr int ROWS = EO == 4 ? 32 : 64, PASSES = 128 / ROWS, CPR = 128 * EO / 16, NIT = ROWS * CPR / 256;
     const int t_beg = bx * p.nt, t_end = min(t_beg + p.nt, p.nct);
 
     // Staging by LDS-DMA: wave w fills rows [32w, 32w+32) of both tiles, 8 rows (1 KB) per instruction.
@@ -219,10 +222,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
         unsigned char *stg = smem + ((ti * nk + nk - 1) & 1) * 32768;
         if (p.ksplit > 1) {                                   // this split's partial image (bias / residual are added by the reduction)
             GemmParams q = p;
-            q.out = (char *)p.out + (size_t)zs * p.M * p.ldo * ES;
-            mfma_epilogue<T, ACT, PASSES, NIT>(q, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
+            q.out = (char *)p.out + (size_t)zs * p.M * p.ldo * EO;
+            mfma_epilogue<TO, ACT, PASSES, NIT>(q, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
         } else
-        mfma_epilogue<T, ACT, PASSES, NIT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
+        mfma_epilogue<TO, ACT, PASSES, NIT>(p, acc, bz, stg, rs, row0, col0, which, wm, wn, lane, tid);
     }
 }
 
@@ -344,16 +347,17 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(int splits, int M, int N,
 // cut into `splits` pieces that run as separate workgroups of ONE launch (partial images [split][M][Nout], fp32) and a second
 // kernel adds them in a fixed order together with bias and residual.  Returns -1 when the shape does not qualify.
 int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, const void *res,
-                            void *out, int ldo, float *partial, size_t partial_floats, hipStream_t st) {
+                            void *out, int ldo, float *partial, size_t partial_floats, hipStream_t st, bool in16) {
+    const int es = in16 ? 2 : 4;                             // in16: A and W are bf16 (out / res / partial stay fp32)
     static int off = -1;
     if (off < 0) { const char *e = getenv("DA_GEMM_SPLITK"); off = (e && e[0] == '0') ? 1 : 0; }
     const int nrt = (M + 127) / 128, nct = (Nout + 127) / 128;
     if (off || !partial || 8 * ((nrt + 7) / 8) * nct > 320 || K < 1024 || K % 128 != 0 || Nout % 4 != 0 || ldo % 4 != 0 ||
         !aligned16(A) || !aligned16(W) || !aligned16(out) || (res && !aligned16(res)) || (bias && !aligned16(bias)) ||
-        ((size_t)lda * 4) % 16 != 0 || ((size_t)K * 4) % 16 != 0)
+        ((size_t)lda * es) % 16 != 0 || ((size_t)K * es) % 16 != 0)
         return -1;
     int splits = 4;
-    while (splits > 1 && (K % (splits * 32) != 0 || (size_t)splits * M * Nout > partial_floats)) --splits;
+    while (splits > 1 && (K % (splits * (128 / es)) != 0 || (size_t)splits * M * Nout > partial_floats)) --splits;
     if (splits < 2) return -1;
     GemmParams p;
     p.M = M; p.K = K; p.Nout = Nout; p.A = A; p.lda = lda; p.W = W; p.bias = nullptr; p.act = DA_ACT_NONE; p.res = nullptr;
@@ -363,10 +367,49 @@ int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, cons
     p.prof = nullptr; p.debug = 0;
     p.nct = nct; p.nt = 1; p.xcd_groups = nct;
     p.ksplit = splits; p.kchunk = K / splits;
-    k_gemm_mfma<float, false, DA_ACT_NONE, true><<<dim3((unsigned)(8 * ((nrt + 7) / 8) * nct), (unsigned)splits), 256, 0, st>>>(p);
+    const dim3 grid((unsigned)(8 * ((nrt + 7) / 8) * nct), (unsigned)splits);
+    if (in16) k_gemm_mfma<bf16_t, false, DA_ACT_NONE, false, float><<<grid, 256, 0, st>>>(p);
+    else k_gemm_mfma<float, false, DA_ACT_NONE, true><<<grid, 256, 0, st>>>(p);
     const size_t n4 = (size_t)M * Nout / 4;
     k_splitk_reduce<<<(unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256), 256, 0, st>>>(splits, M, Nout, partial, bias,
                                                                                                    (const float *)res, (float *)out, ldo);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+// The mixed forms of the training path's q16 mode (plain row-major out, no activation):
+//   in16 = false, out16 = true : fp32 A and W (operands rounded to bf16 in registers), bf16 out  (conv projections -> bf16 Q | K | V | skip)
+//   in16 = true,  out16 = false: bf16 A and W, fp32 out (+ fp32 res)                           (dX from the bf16 projection gradient)
+// Returns -1 when the shape / alignment is not covered.
+int launch_gemm_mfma_mixed(bool in16, bool out16, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
+                           const void *res, void *out, int ldo, hipStream_t st) {
+    if (in16 == out16) return -1;
+    const int es = in16 ? 2 : 4, eo = out16 ? 2 : 4, BK = 128 / es;
+    if (M <= 0 || Nout <= 0) return 0;
+    if (K % BK != 0 || (Nout % (16 / eo)) || !aligned16(A) || !aligned16(W) || ((size_t)lda * es) % 16 != 0 || ((size_t)K * es) % 16 != 0 ||
+        ((size_t)ldo * eo) % 16 != 0 || !aligned16(out) || (res && !aligned16(res)) || (bias && !aligned16(bias)))
+        return -1;
+    GemmParams p;
+    p.M = M; p.K = K; p.Nout = Nout; p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.act = DA_ACT_NONE; p.res = res;
+    p.ldw = K; p.pre = nullptr; p.Cv = 0; p.Cvmagic = 0;
+    p.out = out; p.ldo = ldo; p.qkv = 0; p.HC = 1; p.C = 1; p.n_pad = 0; p.row_map = nullptr; p.Cmagic = 0;
+    p.Q = p.Kb = p.Vt = p.S = nullptr;
+    p.prof = nullptr; p.debug = 0; p.ksplit = 0; p.kchunk = 0; p.xcd_groups = 0;
+    const int nrt = (M + 127) / 128, nct = (Nout + 127) / 128;
+    dim3 grid;
+    if (nct > 1 && (size_t)K * es > 512) {                  // long reduction: column groups of a row tile co-resident on one XCD
+        p.nct = nct; p.nt = 1; p.xcd_groups = nct;
+        grid = dim3((unsigned)(8 * ((nrt + 7) / 8) * nct), 1u);
+    } else {
+        int groups = 512 / nrt;
+        groups = groups > nct ? nct : (groups < 1 ? 1 : groups);
+        const int ntile = (nct + groups - 1) / groups;
+        groups = (nct + ntile - 1) / ntile;
+        p.nct = nct; p.nt = ntile;
+        grid = dim3((unsigned)groups, (unsigned)nrt);
+    }
+    if (in16) k_gemm_mfma<bf16_t, false, DA_ACT_NONE, false, float><<<grid, 256, 0, st>>>(p);
+    else k_gemm_mfma<float, false, DA_ACT_NONE, true, bf16_t><<<grid, 256, 0, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -37,6 +37,23 @@ __global__ __launch_bounds__(256) void k_gelu_bwd(size_t n, const float *__restr
         dx[i] = dy[i] * gelu_grad(pre[i]);
 }
 
+// dst[c][r] = src[r][c], rounded to bf16 (the W^T operand of the q16 mode's dX products)
+__global__ __launch_bounds__(256) void k_transpose_h(int rows, int cols, const float *__restrict__ src, bf16_t *__restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[(size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < rows && c < cols) dst[(size_t)c * rows + r] = f2bf(tile[tx][ty + 8 * k]);
+    }
+}
 // dst[c][r] = src[r][c]
 __global__ __launch_bounds__(256) void k_transpose(int rows, int cols, const float *__restrict__ src, float *__restrict__ dst) {
     __shared__ float tile[32][33];
@@ -244,7 +261,23 @@ int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B,
 // four conversions); the workgroups of the first k tile also add up their dY columns in fp32 (exact values, fixed order) while
 // they stage them.  grid = (ceil(K/128), ceil(N/128), splits).
 typedef __attribute__((ext_vector_type(4))) short tn_s16x4;
-__global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const float *__restrict__ A, int lda,
+// 4 consecutive bf16 of a row-major matrix as fp32, zero beyond (rows, cols)
+__device__ __forceinline__ f32x4 load_row4_h(const bf16_t *base, int ld, int row, int col, int rows, int cols, bool vec) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row >= rows) return v;
+    const bf16_t *p = base + (size_t)row * ld + col;
+    if (vec && col + 3 < cols) {
+        const u32x2 u = *(const u32x2 *)p;
+        return (f32x4){bf2f((bf16_t)(u[0] & 0xffff)), bf2f((bf16_t)(u[0] >> 16)), bf2f((bf16_t)(u[1] & 0xffff)), bf2f((bf16_t)(u[1] >> 16))};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (col + r < cols) v[r] = bf2f(p[r]);
+    return v;
+}
+// A16: A (dY) is stored as bf16 (the q16 mode's projection gradient)
+template <bool A16>
+__global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const void *__restrict__ Av, int lda,
                                                     const float *__restrict__ B, int ldb, float *C, int ldc,
                                                     float *partial, float *bpartial, int Mc, int xcd_tk) {
     constexpr int PT = 136;                                      // LDS row pitch (bf16 elements): 272 B
@@ -265,7 +298,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const f
     const int n0 = by * 128, k0 = bx * 128;
     const int m_beg = bz * Mc, m_end = min(M, m_beg + Mc);
     const int lrow = tid >> 5, lc4 = (tid & 31) * 4;             // stage rows lrow + 8 u, columns lc4 ..+3
-    const bool vecA = (lda % 4 == 0) && (((size_t)A & 15) == 0), vecB = (ldb % 4 == 0) && (((size_t)B & 15) == 0);
+    const bool vecA = (lda % 4 == 0) && (((size_t)Av & 15) == 0), vecB = (ldb % 4 == 0) && (((size_t)B & 15) == 0);
+    auto loadA = [&](int row) {
+        if (A16) return load_row4_h((const bf16_t *)Av, lda, row, n0 + lc4, m_end, N, vecA);
+        return load_row4((const float *)Av, lda, row, n0 + lc4, m_end, N, vecA);
+    };
     const bool want_db = bpartial != nullptr && bx == 0;
     f32x4 acc[4][4];
 #pragma unroll
@@ -276,7 +313,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const f
     f32x4 ra[4], rb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        ra[u] = load_row4(A, lda, m_beg + lrow + 8 * u, n0 + lc4, m_end, N, vecA);
+        ra[u] = loadA(m_beg + lrow + 8 * u);
         rb[u] = load_row4(B, ldb, m_beg + lrow + 8 * u, k0 + lc4, m_end, K, vecB);
     }
     auto pack = [](const f32x4 &v) {
@@ -295,7 +332,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const f
         if (m0 + 32 < m_end) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                ra[u] = load_row4(A, lda, m0 + 32 + lrow + 8 * u, n0 + lc4, m_end, N, vecA);
+                ra[u] = loadA(m0 + 32 + lrow + 8 * u);
                 rb[u] = load_row4(B, ldb, m0 + 32 + lrow + 8 * u, k0 + lc4, m_end, K, vecB);
             }
         }
@@ -346,8 +383,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const f
 }
 
 // dW (+ db) of the bf16-operand mode.  bscratch: splits * N floats
-int launch_gemm_tn_db(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
-                      float *partial, float *db, float *bscratch, hipStream_t st) {
+int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const float *B, int ldb, float *C, int ldc,
+                      float *partial, float *db, float *bscratch, hipStream_t st, bool a16) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     long splits = 640 / ((long)tn * tk);
@@ -365,8 +402,10 @@ int launch_gemm_tn_db(int M, int N, int K, const float *A, int lda, const float 
     splits = (M + Mc - 1) / Mc;
     const bool xmap = xcd && splits == want;
     const dim3 grid = xmap ? dim3((unsigned)(tk * tn * splits)) : dim3((unsigned)tk, (unsigned)tn, (unsigned)splits);
-    k_gemm_tn_db<<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc,
-                                       xmap ? tk : 0);
+    if (a16) k_gemm_tn_db<true><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc,
+                                                   xmap ? tk : 0);
+    else k_gemm_tn_db<false><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc,
+                                                   xmap ? tk : 0);
     if (splits > 1) {
         const size_t NK = (size_t)N * K;
         k_reduce_partial<<<(unsigned)((NK + 255) / 256 > 4096 ? 4096 : (NK + 255) / 256), 256, 0, st>>>((int)splits, N, K, partial, C, ldc);
@@ -660,9 +699,10 @@ __global__ __launch_bounds__(256) void k_virt_grad(int rows, int V, int D, const
 size_t dense_pair_floats(const da_graph *g, int H);
 int dense_train_prepare(const da_graph *g, int H, long long *poff, int32_t *node_graph, hipStream_t st);
 int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P,
-                         const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc);
+                         const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc, bool q16);
 int dense_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
-                         float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc);
+                         float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc, bool q16);
+bool attn_small_ok(const da_graph *g, int C, bool bfc);      // the one-workgroup-per-group attention kernels take this layer
 // hybrid graphs (adjacency-masked grouped GEMMs over the regular edges + CSR remainder, one softmax over both)
 int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P, float *stats,
                           const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc);
@@ -696,6 +736,10 @@ struct Dims {
     bool dense;                // complete graphs: grouped-GEMM attention (da_train_dense.hip)
     bool hybrid;               // hybrid graphs: masked grouped GEMMs + CSR remainder (da_train_dense.hip)
     bool bfc;                  // DA_TRAIN_MMA_BF16: GEMM operands rounded to bf16 inside the matrix-core kernels (storage stays fp32)
+    bool q16;                  // bf16-operand mode on small complete graphs: the projection buffers Q | K | V | skip and their gradient dY4 are
+                               // STORED as bf16 (what autocast(bfloat16) makes of the reference's lin_query / key / value / skip outputs): they
+                               // are only ever read as bf16 operands (k_attn_small_*, the dX and dW products), and at BASELINE configuration 5
+                               // the last layer's two [n, 4608] buffers alone are 340 MB of fp32 per step
     size_t pair_floats;
 };
 
@@ -721,6 +765,13 @@ static int dims_of(const da_weights *w, const da_graph *g, Dims &d, int mma = DA
                g->pad_ptr && g->max_graph_nodes > 0;
     DA_REQUIRE(d.dense || d.hybrid || g->row_ptr, "training: this graph walks the edge list but the CSR arrays are missing");
     d.pair_floats = (d.dense || d.hybrid) ? dense_pair_floats(g, d.H) : 0;
+    static int q16_off = -1;
+    if (q16_off < 0) {
+        const char *e = getenv("DA_TRAIN_Q16"), *e2 = getenv("DA_TRAIN_TN_DB");
+        q16_off = ((e && e[0] == '0') || (e2 && e2[0] == '0')) ? 1 : 0;
+    }
+    d.q16 = d.bfc && d.dense && !q16_off;
+    for (int l = 0; l < d.L && d.q16; ++l) d.q16 = attn_small_ok(g, d.C[l], true) && d.din[l] % 32 == 0 && d.C[l] % 8 == 0;
     return 0;
 }
 
@@ -816,8 +867,19 @@ int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch
 
 // Linear backward: dW += dY^T X, db += colsum(dY), and (if dX) dX = dY @ W (+ res)
 static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, const float *W,
-                      float *dW, float *db, float *dX, int lddx, const float *res, TrainWs &ws, hipStream_t st, bool bfc) {
+                      float *dW, float *db, float *dX, int lddx, const float *res, TrainWs &ws, hipStream_t st, bool bfc,
+                      bool dy16 = false) {
     int rc;
+    if (dy16) {                                             // q16 mode: dY is bf16 (written by k_attn_small_bwd)
+        if ((rc = launch_gemm_tn_db(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, db, ws.csum, st, true))) return rc;
+        if (!dX) return 0;
+        k_transpose_h<<<dim3((K + 31) / 32, (N + 31) / 32), 256, 0, st>>>(N, K, W, (bf16_t *)ws.wt);       // W [N, K] -> W^T [K, N] bf16
+        DA_LAUNCH_CHECK();
+        rc = launch_gemm_mfma_splitk(M, N, K, dY, ldy, ws.wt, nullptr, res, dX, lddx, ws.partial, PART_CAP, st, true);
+        if (rc < 0) rc = launch_gemm_mfma_mixed(true, false, M, N, K, dY, ldy, ws.wt, nullptr, res, dX, lddx, st);
+        if (rc < 0) { set_error("training (q16): dX product %d x %d x %d not covered", M, N, K); return 1; }
+        return rc;
+    }
     static int tn_db = -1;
     if (tn_db < 0) { const char *e = getenv("DA_TRAIN_TN_DB"); tn_db = (e && e[0] == '0') ? 0 : 1; }
     if (bfc && tn_db) {                                     // dW and db from one pass over dY (k_gemm_tn_db)
@@ -892,12 +954,18 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
     int ldx = D;
     for (int l = 0; l < d.L; ++l) {
         const bool last = l == d.L - 1;
+        if (d.q16) {                                        // bf16 projection buffer (same allocation, half used)
+            rc = launch_gemm_mfma_mixed(false, true, n, d.din[l], 4 * d.hc[l], xin, ldx, w->conv_wq[l], w->conv_bq[l], nullptr,
+                                        ws.qkvs[l], 4 * d.hc[l], st);
+            if (rc < 0) { set_error("training (q16): projection %d x %d x %d not covered", n, d.din[l], 4 * d.hc[l]); return 1; }
+            if (rc) return rc;
+        } else
         if ((rc = linear(PL, n, d.din[l], 4 * d.hc[l], xin, ldx, w->conv_wq[l], w->conv_bq[l], DA_ACT_NONE, nullptr,
                          ws.qkvs[l], 4 * d.hc[l], st))) return rc;
         if (d.dense) {
             if (l == 0 && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
             if ((rc = dense_train_attn_fwd(g, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr, ws.o[l], ws.P[l], ws.poff,
-                                           ws.node_graph, st, d.bfc))) return rc;
+                                           ws.node_graph, st, d.bfc, d.q16))) return rc;
         } else if (d.hybrid) {
             if (l == 0 && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
             if ((rc = hybrid_train_attn_fwd(g, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr, ws.o[l], ws.P[l], ws.stats[l],
@@ -958,7 +1026,7 @@ int da_train_backward_ex(const da_weights *w, const da_weights *grads, const da_
     for (int l = L - 1; l >= 0; --l) {
         const int hc = d.hc[l], din = d.din[l];
         if (d.dense) {
-            if ((rc = dense_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.dY4, ws.poff, ws.node_graph, st, d.bfc))) return rc;
+            if ((rc = dense_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.dY4, ws.poff, ws.node_graph, st, d.bfc, d.q16))) return rc;
         } else if (d.hybrid) {
             if ((rc = hybrid_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.stats[l], ws.Dd, ws.dY4, ws.poff,
                                             ws.node_graph, st, d.bfc))) return rc;
@@ -967,7 +1035,7 @@ int da_train_backward_ex(const da_weights *w, const da_weights *grads, const da_
         float *dx = (l & 1) ? ws.dxa : ws.dxb;
         // l == 0: the input is h0, whose gradient also carries the residual branch
         if ((rc = linear_bwd(n, 4 * hc, din, ws.dY4, 4 * hc, xin, din, w->conv_wq[l], G(grads->conv_wq[l]), G(grads->conv_bq[l]),
-                             l == 0 ? ws.dh0 : dx, din, l == 0 ? ws.dh0 : nullptr, ws, st, d.bfc))) return rc;
+                             l == 0 ? ws.dh0 : dx, din, l == 0 ? ws.dh0 : nullptr, ws, st, d.bfc, d.q16))) return rc;
         if (l > 0) {
             if (d.gelu_between && (rc = gelu_bwd((size_t)n * din, ws.o[l - 1], dx, dx, st))) return rc;
             d_o = dx;

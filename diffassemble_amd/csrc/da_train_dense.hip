@@ -346,11 +346,11 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_ggemm_small(GGemm p) {
 // the grouped-GEMM route.
 constexpr int AS_MAXN = 160, AS_WAVES = 10, AS_TN = AS_MAXN / 16;
 struct AttnSmall {
-    const float *qkvs;           // [n, 4 HC]  Q | K | V | skip
+    const void *qkvs;            // [n, 4 HC]  Q | K | V | skip   (fp32; bf16 in the q16 instances)
     const float *res;            // forward: residual [n, HC] or null
     float *o;                    // forward: [n, HC]
     const float *d_o;            // backward: [n, HC]
-    float *dY4;                  // backward: [n, 4 HC]  dq | dk | dv | d_o
+    void *dY4;                   // backward: [n, 4 HC]  dq | dk | dv | d_o   (fp32; bf16 in the q16 instances)
     const int32_t *gp;
     int H, C, HC, nodiag, np;    // np: max_graph_nodes rounded up to 16 (sizes the LDS images)
     float scale;
@@ -362,40 +362,52 @@ __device__ __forceinline__ as_s16x4 as_pack(float a, float b, float c, float d) 
     const as_bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
     return __builtin_bit_cast(as_s16x4, v);
 }
-// rows [0, np) x 16 CT columns of a node matrix (memory [row][ld], fp32, C valid columns, n_g valid rows) as a row-major bf16
-// image of pitch 16 CT + 8, zero beyond the valid part
-template <int CT>
-__device__ __forceinline__ void as_stage(const float *X, int ld, int n_g, int np, int C, unsigned short *R, int tid) {
+// Q16 = the projection buffer / its gradient are bf16 (q16 mode of da_train.hip): four consecutive elements at element offset e
+template <bool Q16> __device__ __forceinline__ as_s16x4 as_ld_pack(const void *base, size_t e) {
+    if (Q16) return *(const as_s16x4 *)((const unsigned short *)base + e);
+    const f32x4 v = *(const f32x4 *)((const float *)base + e);
+    return as_pack(v[0], v[1], v[2], v[3]);
+}
+template <bool Q16> __device__ __forceinline__ f32x4 as_ld4(const void *base, size_t e) {
+    if (Q16) {
+        const u32x2 u = *(const u32x2 *)((const unsigned short *)base + e);
+        return (f32x4){bf2f((bf16_t)(u[0] & 0xffff)), bf2f((bf16_t)(u[0] >> 16)), bf2f((bf16_t)(u[1] & 0xffff)), bf2f((bf16_t)(u[1] >> 16))};
+    }
+    return *(const f32x4 *)((const float *)base + e);
+}
+template <bool Q16> __device__ __forceinline__ void as_st4(void *base, size_t e, const f32x4 &v) {
+    if (Q16) *(as_s16x4 *)((unsigned short *)base + e) = as_pack(v[0], v[1], v[2], v[3]);
+    else *(f32x4 *)((float *)base + e) = v;
+}
+// rows [0, np) x 16 CT columns of a node matrix (memory [row][ld] from element offset e0, C valid columns, n_g valid rows) as a
+// row-major bf16 image of pitch 16 CT + 8, zero beyond the valid part
+template <int CT, bool Q16>
+__device__ __forceinline__ void as_stage(const void *X, size_t e0, int ld, int n_g, int np, int C, unsigned short *R, int tid) {
     constexpr int kq = CT * 4, pr = CT * 16 + 8, NB = CT >= 4 ? 4 : 2;      // NB loads in flight per thread before the first LDS store
     for (int i0 = tid; i0 < np * kq; i0 += 64 * AS_WAVES * NB) {
-        f32x4 v[NB];
+        as_s16x4 v[NB];
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int idx = i0 + u * 64 * AS_WAVES, r = idx / kq, k = (idx - r * kq) * 4;
-            v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (r < n_g && k < C) v[u] = *(const f32x4 *)(X + (size_t)r * ld + k);
+            v[u] = (as_s16x4){0, 0, 0, 0};
+            if (r < n_g && k < C) v[u] = as_ld_pack<Q16>(X, e0 + (size_t)r * ld + k);
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int idx = i0 + u * 64 * AS_WAVES, r = idx / kq, k = (idx - r * kq) * 4;
-            if (idx < np * kq) *(as_s16x4 *)(R + r * pr + k) = as_pack(v[u][0], v[u][1], v[u][2], v[u][3]);
+            if (idx < np * kq) *(as_s16x4 *)(R + r * pr + k) = v[u];
         }
     }
 }
 // the 16 rows [r0, r0 + 16) as B (or A) fragments straight from memory: lane (l15, lg) takes row r0 + l15, columns 16 kt + 4 lg ..+3
-template <int CT>
-__device__ __forceinline__ void as_band(const float *X, int ld, int n_g, int C, int r0, int l15, int lg, as_s16x4 (&f)[CT],
-                                        float *copy, int ldc) {
+template <int CT, bool Q16>
+__device__ __forceinline__ void as_band(const void *X, size_t e0, int ld, int n_g, int C, int r0, int l15, int lg, as_s16x4 (&f)[CT]) {
     const int r = r0 + l15;
 #pragma unroll
     for (int kt = 0; kt < CT; ++kt) {
         const int k = kt * 16 + 4 * lg;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < n_g && k < C) {
-            v = *(const f32x4 *)(X + (size_t)r * ld + k);
-            if (copy) *(f32x4 *)(copy + (size_t)r * ldc + k) = v;
-        }
-        f[kt] = as_pack(v[0], v[1], v[2], v[3]);
+        f[kt] = (as_s16x4){0, 0, 0, 0};
+        if (r < n_g && k < C) f[kt] = as_ld_pack<Q16>(X, e0 + (size_t)r * ld + k);
     }
 }
 // B fragment (k = rows r0 + 4 lg ..+3, n = column c0 + l15) of a row-major image by a transposing read: within a 16-lane group
@@ -435,7 +447,7 @@ __device__ __forceinline__ void as_softmax(f32x4 (&s)[AS_TN], int tn_n, int n_g,
     inv = (mx > -INFINITY) ? 1.0f / (sum + 1e-16f) : 0.f;
 }
 
-template <int CT>
+template <int CT, bool Q16>
 __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_fwd(AttnSmall p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short as_lds[];
     const int g = blockIdx.x / p.H, h = blockIdx.x - g * p.H;
@@ -445,12 +457,12 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_fwd(AttnSmall p) {
     const int C = p.C, np = p.np, ld = 4 * p.HC;
     unsigned short *Ks = as_lds, *Vs = Ks + np * pr;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-    const float *base = p.qkvs + (size_t)n0 * ld + h * C;
-    as_stage<CT>(base + p.HC, ld, n_g, np, C, Ks, tid);
-    as_stage<CT>(base + 2 * p.HC, ld, n_g, np, C, Vs, tid);
+    const size_t e0 = (size_t)n0 * ld + h * C;                         // element offset of (node n0, head h) in the projection buffer
+    as_stage<CT, Q16>(p.qkvs, e0 + p.HC, ld, n_g, np, C, Ks, tid);
+    as_stage<CT, Q16>(p.qkvs, e0 + 2 * p.HC, ld, n_g, np, C, Vs, tid);
     const int tn_n = (n_g + 15) >> 4;
     as_s16x4 qf[CT];
-    if (wid < tn_n) as_band<CT>(base, ld, n_g, C, wid * 16, l15, lg, qf, nullptr, 0);
+    if (wid < tn_n) as_band<CT, Q16>(p.qkvs, e0, ld, n_g, C, wid * 16, l15, lg, qf);
     __syncthreads();
     for (int tm = wid; tm < tn_n; tm += AS_WAVES) {                    // (one band per wave: n_g <= 160)
         const int i = tm * 16 + l15;                                   // this lane's query
@@ -478,13 +490,13 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_fwd(AttnSmall p) {
             }
         }
         // O^T tiles (A = V^T by the transposing read, B = P^T): a lane holds four consecutive CHANNELS of its query, so the skip
-        // projection, the residual and o move as 16-byte pieces, all loads issued before the first use
+        // projection, the residual and o move as 16-byte (8-byte bf16) pieces, all loads issued before the first use
+        // (channel offsets beyond C are clamped to 0 instead of guarded: guarded loads compile to load -> wait round trips)
         if (i < n_g) {
-            // (channel offsets beyond C are clamped to 0 instead of guarded: guarded loads compile to load -> wait round trips)
-            const float *skp = base + 3 * p.HC + (size_t)i * ld;
+            const size_t es = e0 + 3 * p.HC + (size_t)i * ld;
             f32x4 sk[CT], rs[CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) sk[ct] = *(const f32x4 *)(skp + (ct * 16 + 4 * lg < C ? ct * 16 + 4 * lg : 0));
+            for (int ct = 0; ct < CT; ++ct) sk[ct] = as_ld4<Q16>(p.qkvs, es + (ct * 16 + 4 * lg < C ? ct * 16 + 4 * lg : 0));
             if (p.res) {
                 const float *rsp = p.res + (size_t)(n0 + i) * p.HC + h * C;
 #pragma unroll
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_fwd(AttnSmall p) {
     }
 }
 
-template <int CT>
+template <int CT, bool Q16>
 __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short as_lds[];
     const int g = blockIdx.x / p.H, h = blockIdx.x - g * p.H;
@@ -511,18 +523,28 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
     unsigned short *I0 = as_lds, *I1 = I0 + np * pr;                  // phase A: K, V ; phase B: Q, dO
     float *st_m = (float *)(I1 + np * pr), *st_inv = st_m + np, *st_D = st_inv + np;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-    const float *base = p.qkvs + (size_t)n0 * ld + h * C;
-    const float *dob = p.d_o + (size_t)n0 * p.HC + h * C;
-    float *dyb = p.dY4 + (size_t)n0 * ld + h * C;
-    as_stage<CT>(base + p.HC, ld, n_g, np, C, I0, tid);
-    as_stage<CT>(base + 2 * p.HC, ld, n_g, np, C, I1, tid);
+    const size_t e0 = (size_t)n0 * ld + h * C;                         // (node n0, head h) in the projection buffer and in dY4
+    const size_t g0 = (size_t)n0 * p.HC + h * C;                       // ... in d_o
+    as_stage<CT, Q16>(p.qkvs, e0 + p.HC, ld, n_g, np, C, I0, tid);
+    as_stage<CT, Q16>(p.qkvs, e0 + 2 * p.HC, ld, n_g, np, C, I1, tid);
     const int tn_n = (n_g + 15) >> 4;
     // ---- phase A: query bands (one per wave)
     {
         as_s16x4 qf[CT], gf[CT];
         if (wid < tn_n) {
-            as_band<CT>(base, ld, n_g, C, wid * 16, l15, lg, qf, nullptr, 0);
-            as_band<CT>(dob, p.HC, n_g, C, wid * 16, l15, lg, gf, dyb + 3 * p.HC, ld);      // + the skip projection's gradient
+            as_band<CT, Q16>(p.qkvs, e0, ld, n_g, C, wid * 16, l15, lg, qf);
+            // dO band, and its copy = the skip projection's gradient (columns 3 HC .. of dY4)
+            const int r = wid * 16 + l15;
+#pragma unroll
+            for (int kt = 0; kt < CT; ++kt) {
+                const int k = kt * 16 + 4 * lg;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < n_g && k < C) {
+                    v = *(const f32x4 *)(p.d_o + g0 + (size_t)r * p.HC + k);
+                    as_st4<Q16>(p.dY4, e0 + 3 * p.HC + (size_t)r * ld + k, v);
+                }
+                gf[kt] = as_pack(v[0], v[1], v[2], v[3]);
+            }
         }
         __syncthreads();
         if (wid < tn_n) {
@@ -570,18 +592,18 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
             if (i < n_g) {                                            // dQ^T tiles: four consecutive channels of query i per lane
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
-                    if (ct * 16 + 4 * lg < C) *(f32x4 *)(dyb + (size_t)i * ld + ct * 16 + 4 * lg) = p.scale * qacc[ct];
+                    if (ct * 16 + 4 * lg < C) as_st4<Q16>(p.dY4, e0 + (size_t)i * ld + ct * 16 + 4 * lg, p.scale * qacc[ct]);
             }
         }
     }
     __syncthreads();
-    as_stage<CT>(base, ld, n_g, np, C, I0, tid);
-    as_stage<CT>(dob, p.HC, n_g, np, C, I1, tid);
+    as_stage<CT, Q16>(p.qkvs, e0, ld, n_g, np, C, I0, tid);
+    as_stage<CT, false>(p.d_o, g0, p.HC, n_g, np, C, I1, tid);
     // ---- phase B: key bands (one per wave)
     as_s16x4 kf[CT], vf[CT];
     if (wid < tn_n) {
-        as_band<CT>(base + p.HC, ld, n_g, C, wid * 16, l15, lg, kf, nullptr, 0);
-        as_band<CT>(base + 2 * p.HC, ld, n_g, C, wid * 16, l15, lg, vf, nullptr, 0);
+        as_band<CT, Q16>(p.qkvs, e0 + p.HC, ld, n_g, C, wid * 16, l15, lg, kf);
+        as_band<CT, Q16>(p.qkvs, e0 + 2 * p.HC, ld, n_g, C, wid * 16, l15, lg, vf);
     }
     __syncthreads();
     if (wid < tn_n) {
@@ -615,12 +637,12 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
             }
         }
         if (j < n_g) {                                                // dK^T, dV^T tiles: four consecutive channels of key j per lane
-            float *row = dyb + (size_t)j * ld + 4 * lg;
+            const size_t er = e0 + (size_t)j * ld + 4 * lg;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
                 if (ct * 16 + 4 * lg < C) {
-                    *(f32x4 *)(row + p.HC + ct * 16) = p.scale * kacc[ct];
-                    *(f32x4 *)(row + 2 * p.HC + ct * 16) = vacc[ct];
+                    as_st4<Q16>(p.dY4, er + p.HC + ct * 16, p.scale * kacc[ct]);
+                    as_st4<Q16>(p.dY4, er + 2 * p.HC + ct * 16, vacc[ct]);
                 }
         }
     }
@@ -628,38 +650,42 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
 #undef AS_MFMA
 
 static int as_tiles(int C) { const int ct = (C + 15) / 16; return ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : ct <= 9 ? 9 : 10; }
-static bool attn_small_ok(const da_graph *g, int C, bool bfc) {
+bool attn_small_ok(const da_graph *g, int C, bool bfc) {
     static int off = -1;
     if (off < 0) { const char *e = getenv("DA_ATTN_SMALL_FUSED"); off = (e && e[0] == '0') ? 1 : 0; }
     return bfc && !off && g->max_graph_nodes <= AS_MAXN && C <= 160 && C % 4 == 0;
 }
-template <int CT>
+template <int CT, bool Q16>
 static int attn_small_launch_ct(const da_graph *g, AttnSmall &a, bool bwd, hipStream_t st) {
     constexpr int pr = CT * 16 + 8;
     const int lds = 2 * a.np * pr * 2 + (bwd ? 3 * a.np * 4 : 0);
     static bool attr = false;
     if (!attr) {
         const int cap = 2 * AS_MAXN * pr * 2 + 3 * AS_MAXN * 4;
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_bwd<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_fwd<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_bwd<CT, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_fwd<CT, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         attr = true;
     }
-    if (bwd) k_attn_small_bwd<CT><<<g->n_graphs * a.H, 64 * AS_WAVES, lds, st>>>(a);
-    else k_attn_small_fwd<CT><<<g->n_graphs * a.H, 64 * AS_WAVES, lds, st>>>(a);
+    if (bwd) k_attn_small_bwd<CT, Q16><<<g->n_graphs * a.H, 64 * AS_WAVES, lds, st>>>(a);
+    else k_attn_small_fwd<CT, Q16><<<g->n_graphs * a.H, 64 * AS_WAVES, lds, st>>>(a);
     DA_LAUNCH_CHECK();
     return 0;
 }
-static int attn_small_launch(const da_graph *g, int H, int C, AttnSmall &a, bool bwd, hipStream_t st) {
+template <bool Q16>
+static int attn_small_launch_q(const da_graph *g, int C, AttnSmall &a, bool bwd, hipStream_t st) {
+    switch (as_tiles(C)) {
+    case 1: return attn_small_launch_ct<1, Q16>(g, a, bwd, st);
+    case 2: return attn_small_launch_ct<2, Q16>(g, a, bwd, st);
+    case 4: return attn_small_launch_ct<4, Q16>(g, a, bwd, st);
+    case 9: return attn_small_launch_ct<9, Q16>(g, a, bwd, st);
+    default: return attn_small_launch_ct<10, Q16>(g, a, bwd, st);
+    }
+}
+static int attn_small_launch(const da_graph *g, int H, int C, AttnSmall &a, bool bwd, bool q16, hipStream_t st) {
     a.gp = g->graph_ptr; a.H = H; a.C = C; a.HC = H * C; a.nodiag = g->dense == 2;
     a.np = (g->max_graph_nodes + 15) & ~15;
     a.scale = 1.0f / sqrtf((float)C);
-    switch (as_tiles(C)) {
-    case 1: return attn_small_launch_ct<1>(g, a, bwd, st);
-    case 2: return attn_small_launch_ct<2>(g, a, bwd, st);
-    case 4: return attn_small_launch_ct<4>(g, a, bwd, st);
-    case 9: return attn_small_launch_ct<9>(g, a, bwd, st);
-    default: return attn_small_launch_ct<10>(g, a, bwd, st);
-    }
+    return q16 ? attn_small_launch_q<true>(g, C, a, bwd, st) : attn_small_launch_q<false>(g, C, a, bwd, st);
 }
 
 // poff[g] = sum_{g' < g} H * n_g' * round4(n_g')   (one thread; G is a few hundred at most)
@@ -782,13 +808,14 @@ int dense_train_prepare(const da_graph *g, int H, long long *poff, int32_t *node
 
 // forward: o = softmax(scale q k^T) v + skip (+ res); P kept for the backward
 int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P,
-                         const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc) {
+                         const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc, bool q16) {
     const int n = g->n_nodes, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
     if (attn_small_ok(g, C, bfc)) {       // small groups: the whole layer in one launch, P never stored (k_attn_small_fwd)
         AttnSmall a{};
         a.qkvs = qkvs; a.res = res; a.o = o;
-        return attn_small_launch(g, H, C, a, false, st);
+        return attn_small_launch(g, H, C, a, false, q16, st);
     }
+    if (q16) { set_error("training: bf16 projection buffers exist on the small-group attention route only"); return 1; }
     GGemm s;
     s.bfc = bfc;
     s.A = {(float *)qkvs, 0, 4 * HC, C};
@@ -816,15 +843,16 @@ int dense_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, con
 
 // backward: dY4 = [dq | dk | dv | d_o] from d_o [n, HC], the saved P and the projection buffer
 int dense_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
-                         float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc) {
+                         float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc, bool q16) {
     const int n = g->n_nodes, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
     const float scale = 1.0f / sqrtf((float)C);
     int rc;
     if (attn_small_ok(g, C, bfc)) {       // matches dense_train_attn_fwd's choice: that forward kept no P
         AttnSmall a{};
         a.qkvs = qkvs; a.d_o = d_o; a.dY4 = dY4;
-        return attn_small_launch(g, H, C, a, true, st);
+        return attn_small_launch(g, H, C, a, true, q16, st);
     }
+    if (q16) { set_error("training: bf16 projection buffers exist on the small-group attention route only"); return 1; }
     GGemm q;
     q.bfc = bfc;
     q.H = H; q.gp = g->graph_ptr; q.poff = poff; q.accumulate = 0;
