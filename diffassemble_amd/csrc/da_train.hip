@@ -16,6 +16,8 @@
 // split over node chunks with a deterministic second-pass reduction.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "da_gemm_common.h"
 
 namespace da {
@@ -256,7 +258,7 @@ int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B,
 // db[n] += sum_m A[m][n] (A = dY, B = X, fp32 row-major).  k_gemm_tn<true> above is bound by what its 64 x 64 tiles pull through
 // the L2 (every dY column block is re-read K / 64 times, every X column block N / 64 times: 1.36 GB per call at BASELINE
 // configuration 5's conv 3) and the bias gradient read dY once more in its own two kernels.  Here: 128 x 128 tiles (half the
-// operand traffic), 32 rows of m per stage, the fp32 tiles rounded to bf16 on their way into LDS (row-major [m][col], 8-byte
+// operand traffic), 64 rows of m per stage (one stage of register prefetch: the bytes in flight per workgroup are what hides the load latency at two to three workgroups per CU), the fp32 tiles rounded to bf16 on their way into LDS (row-major [m][col], 8-byte
 // stores) and fetched as MFMA fragments by ds_read_b64_tr_b16 (one read per 16 x 16 operand block instead of four scalar reads +
 // four conversions); the workgroups of the first k tile also add up their dY columns in fp32 (exact values, fixed order) while
 // they stage them.  grid = (ceil(K/128), ceil(N/128), splits).
@@ -281,8 +283,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const v
                                                     const float *__restrict__ B, int ldb, float *C, int ldc,
                                                     float *partial, float *bpartial, int Mc, int xcd_tk) {
     constexpr int PT = 136;                                      // LDS row pitch (bf16 elements): 272 B
-    __shared__ __attribute__((aligned(16))) unsigned short As[32 * PT];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[32 * PT];
+    constexpr int SR = 64, NU = SR / 8;                          // rows of m per stage; 8-byte / 16-byte pieces per thread, operand and stage
+    __shared__ __attribute__((aligned(16))) unsigned short As[SR * PT];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[SR * PT];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1, l15 = lane & 15, lg = lane >> 4;
     // xcd_tk > 0: 1-D grid with the row split = id % splits (splits a multiple of 8: workgroups are dealt round-robin over the
     // 8 XCDs, so ALL tiles of one row range run on one XCD, start together and walk the rows at the same pace -- the operand
@@ -299,9 +302,21 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const v
     const int m_beg = bz * Mc, m_end = min(M, m_beg + Mc);
     const int lrow = tid >> 5, lc4 = (tid & 31) * 4;             // stage rows lrow + 8 u, columns lc4 ..+3
     const bool vecA = (lda % 4 == 0) && (((size_t)Av & 15) == 0), vecB = (ldb % 4 == 0) && (((size_t)B & 15) == 0);
-    auto loadA = [&](int row) {
-        if (A16) return load_row4_h((const bf16_t *)Av, lda, row, n0 + lc4, m_end, N, vecA);
-        return load_row4((const float *)Av, lda, row, n0 + lc4, m_end, N, vecA);
+    auto pack = [](const f32x4 &v) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+        const bf16x4_ b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        return __builtin_bit_cast(tn_s16x4, b);
+    };
+    // A pieces stay in the form they are stored in (bf16: the bits go to LDS untouched; fp32: rounded when they are written there)
+    typedef typename std::conditional<A16, tn_s16x4, f32x4>::type RA;
+    auto loadA = [&](int row) -> RA {
+        if constexpr (A16) {
+            const bf16_t *q = (const bf16_t *)Av + (size_t)row * lda + n0 + lc4;
+            if (row < m_end && vecA && n0 + lc4 + 3 < N) return *(const tn_s16x4 *)q;
+            return pack(load_row4_h((const bf16_t *)Av, lda, row, n0 + lc4, m_end, N, false));
+        } else {
+            return load_row4((const float *)Av, lda, row, n0 + lc4, m_end, N, vecA);
+        }
     };
     const bool want_db = bpartial != nullptr && bx == 0;
     f32x4 acc[4][4];
@@ -310,34 +325,40 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const v
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ra[4], rb[4];
+    RA ra[NU];
+    f32x4 rb[NU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
         ra[u] = loadA(m_beg + lrow + 8 * u);
         rb[u] = load_row4(B, ldb, m_beg + lrow + 8 * u, k0 + lc4, m_end, K, vecB);
     }
-    auto pack = [](const f32x4 &v) {
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
-        const bf16x4_ b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        return __builtin_bit_cast(tn_s16x4, b);
-    };
-    for (int m0 = m_beg; m0 < m_end; m0 += 32) {
+    for (int m0 = m_beg; m0 < m_end; m0 += SR) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            *(tn_s16x4 *)(As + (lrow + 8 * u) * PT + lc4) = pack(ra[u]);
+        for (int u = 0; u < NU; ++u) {
+            if constexpr (A16) {
+                *(tn_s16x4 *)(As + (lrow + 8 * u) * PT + lc4) = ra[u];
+                if (want_db) {
+                    const unsigned lo = (unsigned)(unsigned short)ra[u][0] | ((unsigned)(unsigned short)ra[u][1] << 16);
+                    const unsigned hi = (unsigned)(unsigned short)ra[u][2] | ((unsigned)(unsigned short)ra[u][3] << 16);
+                    csum += (f32x4){__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                                    __uint_as_float(hi & 0xffff0000u)};
+                }
+            } else {
+                *(tn_s16x4 *)(As + (lrow + 8 * u) * PT + lc4) = pack(ra[u]);
+                csum += ra[u];
+            }
             *(tn_s16x4 *)(Bs + (lrow + 8 * u) * PT + lc4) = pack(rb[u]);
-            csum += ra[u];
         }
         __syncthreads();
-        if (m0 + 32 < m_end) {
+        if (m0 + SR < m_end) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ra[u] = loadA(m0 + 32 + lrow + 8 * u);
-                rb[u] = load_row4(B, ldb, m0 + 32 + lrow + 8 * u, k0 + lc4, m_end, K, vecB);
+            for (int u = 0; u < NU; ++u) {
+                ra[u] = loadA(m0 + SR + lrow + 8 * u);
+                rb[u] = load_row4(B, ldb, m0 + SR + lrow + 8 * u, k0 + lc4, m_end, K, vecB);
             }
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < SR / 16; ++ks) {
             tn_s16x4 a[4], b[4];
             // fragment (k = rows 16 ks + 4 lg ..+3, n = column c0 + l15): lane i' of a 16-lane group supplies the address of
             // row (i' >> 2), columns 4 (i' & 3) ..+3 and receives column i' of the four rows
@@ -370,7 +391,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const v
                 }
             }
     if (want_db) {                                              // the eight row groups' sums of each column, fixed order
-        float *red = (float *)As;                               // [8][128] floats = 4 KB of the 8.5 KB tile
+        float *red = (float *)As;                               // [8][128] floats = 4 KB of the 17 KB tile
         *(f32x4 *)(red + lrow * 128 + lc4) = csum;
         __syncthreads();
         if (tid < 128 && n0 + tid < N) {
@@ -397,7 +418,7 @@ int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const float *
     // several tiles and enough rows: exactly 8 (or 16) row ranges, one (two) per XCD (see the kernel)
     const bool xcd = !xcd_off && tn * tk >= 8 && by_rows >= 8 && by_cap >= 8;
     if (xcd) splits = (tn * tk <= 24 && by_rows >= 16 && by_cap >= 16) ? 16 : 8;
-    int Mc = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
+    int Mc = (int)(((M + splits - 1) / splits + 63) / 64 * 64);
     const long want = splits;
     splits = (M + Mc - 1) / Mc;
     const bool xmap = xcd && splits == want;
