@@ -39,6 +39,21 @@ __global__ __launch_bounds__(256) void k_gelu_bwd(size_t n, const float *__restr
         dx[i] = dy[i] * gelu_grad(pre[i]);
 }
 
+// dst = bf16(src), 8 elements per thread and pass (n a multiple of 8; both 16-byte aligned)
+__global__ __launch_bounds__(256) void k_cast_h(size_t n8, const float *__restrict__ src, bf16_t *__restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *(const f32x4 *)(src + 8 * i), b = *(const f32x4 *)(src + 8 * i + 4);
+        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_;
+        const bf16x8_ v = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+        *(u32x4 *)(dst + 8 * i) = __builtin_bit_cast(u32x4, v);
+    }
+}
+static int cast_h(size_t n, const float *src, bf16_t *dst, hipStream_t st) {
+    const size_t n8 = n / 8, blocks = (n8 + 255) / 256;
+    k_cast_h<<<(unsigned)(blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks)), 256, 0, st>>>(n8, src, dst);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
 // dst[c][r] = src[r][c], rounded to bf16 (the W^T operand of the q16 mode's dX products)
 __global__ __launch_bounds__(256) void k_transpose_h(int rows, int cols, const float *__restrict__ src, bf16_t *__restrict__ dst) {
     __shared__ float tile[32][33];
@@ -976,6 +991,20 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
     for (int l = 0; l < d.L; ++l) {
         const bool last = l == d.L - 1;
         if (d.q16) {                                        // bf16 projection buffer (same allocation, half used)
+            // input and weight are rounded to bf16 ONCE, by a pass of their own (into dY4 and wt: scratch of the backward, idle
+            // here), and the projection runs on the bf16 kernels of the inference path (W in registers / a 64-deep LDS ring
+            // instead of 128 x 128 fp32 tiles re-streamed through the L2 by every column group); the products are the same
+            // bf16 x bf16 -> fp32 ones.  DA_TRAIN_Q16_CAST=0: fp32 operands rounded inside the kernel (launch_gemm_mfma_mixed)
+            static int cast_on = -1;
+            if (cast_on < 0) { const char *e = getenv("DA_TRAIN_Q16_CAST"); cast_on = (e && e[0] == '0') ? 0 : 1; }
+            rc = -1;
+            if (cast_on && ldx == d.din[l] && ((size_t)n * d.din[l]) % 8 == 0 && ((size_t)d.din[l] * 4 * d.hc[l]) % 8 == 0) {
+                if ((rc = cast_h((size_t)n * d.din[l], xin, (bf16_t *)ws.dY4, st))) return rc;
+                if ((rc = cast_h((size_t)d.din[l] * 4 * d.hc[l], w->conv_wq[l], (bf16_t *)ws.wt, st))) return rc;
+                rc = launch_gemm_mfma(DA_PREC_BF16, n, d.din[l], 4 * d.hc[l], ws.dY4, d.din[l], ws.wt, w->conv_bq[l], DA_ACT_NONE,
+                                      nullptr, ws.qkvs[l], 4 * d.hc[l], nullptr, st);
+            }
+            if (rc < 0)
             rc = launch_gemm_mfma_mixed(false, true, n, d.din[l], 4 * d.hc[l], xin, ldx, w->conv_wq[l], w->conv_bq[l], nullptr,
                                         ws.qkvs[l], 4 * d.hc[l], st);
             if (rc < 0) { set_error("training (q16): projection %d x %d x %d not covered", n, d.din[l], 4 * d.hc[l]); return 1; }
