@@ -356,8 +356,11 @@ int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, cons
         !aligned16(A) || !aligned16(W) || !aligned16(out) || (res && !aligned16(res)) || (bias && !aligned16(bias)) ||
         ((size_t)lda * es) % 16 != 0 || ((size_t)K * es) % 16 != 0)
         return -1;
+    // as many splits (<= 4) as keep the launch inside ONE round of the 512 resident workgroups (2 per CU): a second round with a
+    // few workgroups costs a whole extra pass over the split's stages
+    const int base = 8 * ((nrt + 7) / 8) * nct;
     int splits = 4;
-    while (splits > 1 && (K % (splits * (128 / es)) != 0 || (size_t)splits * M * Nout > partial_floats)) --splits;
+    while (splits > 1 && (K % (splits * (128 / es)) != 0 || (size_t)splits * M * Nout > partial_floats || (base * splits > 512 && splits > 2))) --splits;
     if (splits < 2) return -1;
     GemmParams p;
     p.M = M; p.K = K; p.Nout = Nout; p.A = A; p.lda = lda; p.W = W; p.bias = nullptr; p.act = DA_ACT_NONE; p.res = nullptr;

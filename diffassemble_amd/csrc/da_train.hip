@@ -432,8 +432,8 @@ int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const float *
     if (xcd_off < 0) { const char *e = getenv("DA_TN_NO_XCD_MAP"); xcd_off = (e && e[0] == '1') ? 1 : 0; }
     // several tiles and enough rows: exactly 8 (or 16) row ranges, one (two) per XCD (see the kernel)
     const bool xcd = !xcd_off && tn * tk >= 8 && by_rows >= 8 && by_cap >= 8;
-    if (xcd) splits = (tn * tk <= 24 && by_rows >= 16 && by_cap >= 16) ? 16 : 8;
-    int Mc = (int)(((M + splits - 1) / splits + 63) / 64 * 64);
+    if (xcd) splits = (tn * tk <= 12 && by_rows >= 32 && by_cap >= 32) ? 32 : (tn * tk <= 24 && by_rows >= 16 && by_cap >= 16) ? 16 : 8;
+    int Mc = (int)(((M + splits - 1) / splits + 7) / 8 * 8);      // (a last partial stage is zero-filled: no multiple of the stage needed)
     const long want = splits;
     splits = (M + Mc - 1) / Mc;
     const bool xmap = xcd && splits == want;

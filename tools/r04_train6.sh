@@ -7,7 +7,7 @@ set -x
 timeout 900 python -m pytest tests/test_gpu_train.py -x -q -m gpu 2>&1 | tail -15
 timeout 300 python -m pytest tests/test_gpu_samplers.py -x -q -m gpu -k "without_the_mfma_hoist" 2>&1 | tail -5
 for rep in 1 2; do
-for cfg in "DA_X=1" "DA_TRAIN_Q16_CAST=0"; do
+for cfg in "DA_X=1" "DA_X=2"; do
   env $cfg timeout 300 python bench.py --config 5 --precision bf16 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > /tmp/o.json
   python -c "import json; d=json.load(open('/tmp/o.json')); print('config5 bf16 $cfg', round(d['value']), round(d['ms_per_step'],3), d.get('phases_ms'))"
 done
