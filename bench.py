@@ -393,7 +393,9 @@ def train_bench(args, world, rank, dev):
         # that phase; the encoder (--pixels) is outside this count
         fb_s = acc[0] / kp * 1e-3
         tp = te.precision
-        roof = {"bound": "mfma", "kernel": f"forward + backward ({'bf16-operand' if tp == 'bf16' else 'fp32'} MFMA linears, grouped attention GEMMs, dW GEMMs)",
+        kdesc = ("bf16-operand MFMA linears, bf16 projection buffers, one-workgroup attention kernels k_attn_small_fwd / bwd, dW + db in k_gemm_tn_db"
+                 if tp == "bf16" and not exo else ("bf16-operand" if tp == "bf16" else "fp32") + " MFMA linears, grouped attention GEMMs, dW GEMMs")
+        roof = {"bound": "mfma", "kernel": f"forward + backward ({kdesc})",
                 "achieved": 3 * flop_fwd / fb_s / 1e12, "peak": PEAK_TFLOPS[tp], "unit": "TFLOP/s",
                 "frac": 3 * flop_fwd / fb_s / 1e12 / PEAK_TFLOPS[tp], "traffic": None,
                 "phase_share": {"forward+backward": acc[0] / sum(acc), "gradient_allreduce": acc[1] / sum(acc), "optimizer": acc[2] / sum(acc)},
