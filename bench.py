@@ -432,7 +432,7 @@ def train_bench(args, world, rank, dev):
                       f"training steps/sec ({side}x{side} rot, {'exophormer V=8, Exphander d=' + str(degree) if exo else 'dense'}, Huber, Adafactor)",
             "value": world * G * K / dt, "unit": "puzzle-train-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp32" if te.precision != "bf16" else "bf16 MFMA operands (fp32 storage, fp32 accumulation)") + (" + bf16 encoder maps" if (pixels and args.precision == "bf16") else ""),
+            "dtype": ("fp32" if te.precision != "bf16" else "bf16 MFMA operands, fp32 accumulation (storage fp32; on small complete graphs the projection buffers Q|K|V|skip and their gradient are bf16)") + (" + bf16 encoder maps" if (pixels and args.precision == "bf16") else ""),
             "data": "synthetic",
             "config": {"workload": ("BASELINE config 5: 12x12 rot dense (N=144, E=20736), G per GPU below, huber, EPSILON, one Adafactor step; "
                                     if (side == 12 and not exo) else
