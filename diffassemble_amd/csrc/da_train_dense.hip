@@ -931,29 +931,32 @@ __global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int n_nodes,
                 const float mn = fmaxf(m, s);
                 if (mn > -INFINITY) { z = z * expf(m - mn) + (on ? expf(s - mn) : 0.f); m = mn; }
             }
-            // ... and this row's remainder edges (score on the fly: lanes over the head's channels)
+            // ... and this row's remainder edges, a LANE per edge (64 at a time; the lane walks the head's C channels): one wave
+            // reduction per edge and a dependent load chain per edge made the 900-edge rows of the virtual nodes 1.7 ms launches
             const int eb = irr_ptr[node], ee = irr_ptr[node + 1];
             const float *qp = qkvs + (size_t)node * 4 * HC + (size_t)h * C;
             float mi = -INFINITY, zi = 0.f;
-            for (int e = eb; e < ee; ++e) {
+            for (int e = eb + lane; e < ee; e += 64) {
                 const float *kp = qkvs + (size_t)irr_src[e] * 4 * HC + HC + (size_t)h * C;
                 float s = 0.f;
-                for (int c = lane; c < C; c += 64) s = fmaf(qp[c], kp[c], s);
-                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                for (int c = 0; c < C; c += 4) {
+                    const f32x4 qv = *(const f32x4 *)(qp + c), kv = *(const f32x4 *)(kp + c);
+                    s = fmaf(qv[0], kv[0], s); s = fmaf(qv[1], kv[1], s); s = fmaf(qv[2], kv[2], s); s = fmaf(qv[3], kv[3], s);
+                }
                 s *= scale;
                 const float mn = fmaxf(mi, s);
                 zi = zi * expf(mi - mn) + expf(s - mn);
                 mi = mn;
             }
-            // merge the lanes' partial (m, z) of the dense part, then the remainder's
-            for (int o = 32; o > 0; o >>= 1) {
-                const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
-                const float mn = fmaxf(m, m2);
-                if (mn > -INFINITY) { z = z * expf(m - mn) + z2 * expf(m2 - mn); m = mn; }
-            }
+            // the lane's remainder part joins its dense part, then the lanes merge
             {
                 const float mn = fmaxf(m, mi);
                 if (mn > -INFINITY) { z = (m > -INFINITY ? z * expf(m - mn) : 0.f) + (mi > -INFINITY ? zi * expf(mi - mn) : 0.f); m = mn; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
+                const float mn = fmaxf(m, m2);
+                if (mn > -INFINITY) { z = (m > -INFINITY ? z * expf(m - mn) : 0.f) + (m2 > -INFINITY ? z2 * expf(m2 - mn) : 0.f); m = mn; }
             }
             const float inv = (m > -INFINITY) ? 1.0f / (z + 1e-16f) : 0.f;
             const float mfin = (m > -INFINITY) ? m : 0.f;
@@ -979,24 +982,34 @@ __global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int n_nodes,
     }
 }
 
+// Heavy rows of the remainder CSR (round 4).  The three kernels below walk a row's edges one after the other in ONE wave, each
+// edge a dependent load chain (index -> K / V or Q / dO row) of about a microsecond: fine for the 8 - 20 remainder edges of a
+// piece, 0.8 - 2.1 ms per launch for the exophormer's virtual nodes (900 edges each way; 12 launches per step = half the scripted
+// training step).  Every sum over edges is plain (the softmax statistics are known), so a row with more than IRR_HEAVY edges
+// is taken by a WORKGROUP of IRR_NW waves instead (HEAVY instances: one block per row, rows below the threshold return at
+// once; the wave-per-row instances skip the rows above it): wave w takes edges beg + w, beg + w + IRR_NW, ..., the partial sums
+// meet in LDS and are added in wave order -- deterministic, no atomics.
+constexpr int IRR_HEAVY = 96, IRR_NW = 8;
+
 // o[i, :] += sum over i's remainder edges of p_e v_src, p_e = exp(s_e - m_i) inv_i from the combined statistics.  Wave per
 // destination, lane = EPL contiguous channels of the H*C-wide rows (8 lanes per head), as the CSR kernels of da_train.hip.
-template <int EPL>
-__global__ __launch_bounds__(256) void k_attn_irr_fwd(int n_nodes, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
+template <int EPL, bool HEAVY>
+__global__ __launch_bounds__(HEAVY ? 64 * IRR_NW : 256) void k_attn_irr_fwd(int n_nodes, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
                                                       int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ stats,
                                                       float *__restrict__ o, float scale) {
-    const int lane = threadIdx.x & 63;
-    const int i = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    __shared__ float red[HEAVY ? IRR_NW : 1][HEAVY ? 64 * EPL : 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = HEAVY ? (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n_nodes) return;
     const int beg = irr_ptr[i], end = irr_ptr[i + 1];
-    if (beg == end) return;
+    if (HEAVY ? end - beg <= IRR_HEAVY : (beg == end || end - beg > IRR_HEAVY)) return;
     const size_t ld = (size_t)4 * HC;
     const int off = lane * EPL, head = lane >> 3;
     float q[EPL], acc[EPL];
 #pragma unroll
     for (int x = 0; x < EPL; ++x) { q[x] = qkvs[(size_t)i * ld + off + x] * scale; acc[x] = 0.f; }
     const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
-    for (int e = beg; e < end; ++e) {
+    for (int e = HEAVY ? beg + wv : beg; e < end; e += HEAVY ? IRR_NW : 1) {
         const float *kp = qkvs + (size_t)irr_src[e] * ld + HC + off;
         const float *vp = kp + HC;
         float s = 0.f;
@@ -1007,20 +1020,35 @@ __global__ __launch_bounds__(256) void k_attn_irr_fwd(int n_nodes, const int32_t
 #pragma unroll
         for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vp[x], acc[x]);
     }
+    if (HEAVY) {
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) red[wv][x * 64 + lane] = acc[x];
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) {
+            float t = red[0][x * 64 + lane];
+            for (int w = 1; w < IRR_NW; ++w) t += red[w][x * 64 + lane];
+            acc[x] = t;
+        }
+    }
 #pragma unroll
     for (int x = 0; x < EPL; ++x) o[(size_t)i * HC + off + x] += acc[x];
 }
 
 // backward over the remainder edges, destination side: D_i total = Dd[i] (dense part, on entry) + sum_e p_e dp_e; writes
 // D_i total back, dq_i of the remainder edges into dY4 (the dense dQ GEMM ACCUMULATES on top afterwards) and the skip gradient.
-template <int EPL>
-__global__ __launch_bounds__(256) void k_attn_irr_bwd_dst(int n_nodes, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
+template <int EPL, bool HEAVY>
+__global__ __launch_bounds__(HEAVY ? 64 * IRR_NW : 256) void k_attn_irr_bwd_dst(int n_nodes, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
                                                           int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ d_o,
                                                           const float *__restrict__ stats, float *__restrict__ dY4, float *__restrict__ Dd,
                                                           float scale) {
-    const int lane = threadIdx.x & 63;
-    const int i = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    __shared__ float red[HEAVY ? IRR_NW : 1][HEAVY ? 64 * (EPL + 1) : 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = HEAVY ? (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n_nodes) return;
+    const int beg = irr_ptr[i], end = irr_ptr[i + 1];
+    if (HEAVY ? end - beg <= IRR_HEAVY : end - beg > IRR_HEAVY) return;      // (rows without edges still get their skip gradient)
     const size_t ld = (size_t)4 * HC;
     const int off = lane * EPL, head = lane >> 3;
     float q[EPL], g[EPL], a1[EPL], a2[EPL];
@@ -1032,8 +1060,7 @@ __global__ __launch_bounds__(256) void k_attn_irr_bwd_dst(int n_nodes, const int
     }
     const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
     float D = 0.f;
-    const int beg = irr_ptr[i], end = irr_ptr[i + 1];
-    for (int e = beg; e < end; ++e) {
+    for (int e = HEAVY ? beg + wv : beg; e < end; e += HEAVY ? IRR_NW : 1) {
         const float *kp = qkvs + (size_t)irr_src[e] * ld + HC + off;
         const float *vp = kp + HC;
         float kk[EPL], s = 0.f, dp = 0.f;
@@ -1047,6 +1074,34 @@ __global__ __launch_bounds__(256) void k_attn_irr_bwd_dst(int n_nodes, const int
 #pragma unroll
         for (int x = 0; x < EPL; ++x) { a1[x] = fmaf(pd, kk[x], a1[x]); a2[x] = fmaf(pe, kk[x], a2[x]); }
     }
+    if (HEAVY) {                                            // two rounds through the same LDS: (a1, D), then a2
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) red[wv][x * 64 + lane] = a1[x];
+        red[wv][EPL * 64 + lane] = D;
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) {
+                float t = red[0][x * 64 + lane];
+                for (int w = 1; w < IRR_NW; ++w) t += red[w][x * 64 + lane];
+                a1[x] = t;
+            }
+            float t = red[0][EPL * 64 + lane];
+            for (int w = 1; w < IRR_NW; ++w) t += red[w][EPL * 64 + lane];
+            D = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) red[wv][x * 64 + lane] = a2[x];
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) {
+            float t = red[0][x * 64 + lane];
+            for (int w = 1; w < IRR_NW; ++w) t += red[w][x * 64 + lane];
+            a2[x] = t;
+        }
+    }
     const float Dt = D + Dd[(size_t)i * H + head];
 #pragma unroll
     for (int x = 0; x < EPL; ++x) {
@@ -1057,16 +1112,17 @@ __global__ __launch_bounds__(256) void k_attn_irr_bwd_dst(int n_nodes, const int
 }
 
 // source side over the remainder edges (CSR by source): dk_j, dv_j ADDED to what the dense GEMMs wrote
-template <int EPL>
-__global__ __launch_bounds__(256) void k_attn_irr_bwd_src(int n_nodes, const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_dst,
+template <int EPL, bool HEAVY>
+__global__ __launch_bounds__(HEAVY ? 64 * IRR_NW : 256) void k_attn_irr_bwd_src(int n_nodes, const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_dst,
                                                           int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ d_o,
                                                           const float *__restrict__ stats, const float *__restrict__ Dd,
                                                           float *__restrict__ dY4, float scale) {
-    const int lane = threadIdx.x & 63;
-    const int j = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    __shared__ float red[HEAVY ? IRR_NW : 1][HEAVY ? 64 * EPL : 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = HEAVY ? (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (j >= n_nodes) return;
     const int beg = out_ptr[j], end = out_ptr[j + 1];
-    if (beg == end) return;
+    if (HEAVY ? end - beg <= IRR_HEAVY : (beg == end || end - beg > IRR_HEAVY)) return;
     const size_t ld = (size_t)4 * HC;
     const int off = lane * EPL, head = lane >> 3;
     float kk[EPL], vv[EPL], dk[EPL], dv[EPL];
@@ -1076,7 +1132,7 @@ __global__ __launch_bounds__(256) void k_attn_irr_bwd_src(int n_nodes, const int
         vv[x] = qkvs[(size_t)j * ld + 2 * (size_t)HC + off + x];
         dk[x] = dv[x] = 0.f;
     }
-    for (int e = beg; e < end; ++e) {
+    for (int e = HEAVY ? beg + wv : beg; e < end; e += HEAVY ? IRR_NW : 1) {
         const int i = out_dst[e];
         float q[EPL], g[EPL], s = 0.f, dp = 0.f;
 #pragma unroll
@@ -1092,6 +1148,30 @@ __global__ __launch_bounds__(256) void k_attn_irr_bwd_src(int n_nodes, const int
         const float pe = expf(s - m) * inv, ds = pe * (dp - D);
 #pragma unroll
         for (int x = 0; x < EPL; ++x) { dk[x] = fmaf(ds, q[x], dk[x]); dv[x] = fmaf(pe, g[x], dv[x]); }
+    }
+    if (HEAVY) {                                            // two rounds through the same LDS: dk, then dv
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) red[wv][x * 64 + lane] = dk[x];
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) {
+                float t = red[0][x * 64 + lane];
+                for (int w = 1; w < IRR_NW; ++w) t += red[w][x * 64 + lane];
+                dk[x] = t;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) red[wv][x * 64 + lane] = dv[x];
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) {
+            float t = red[0][x * 64 + lane];
+            for (int w = 1; w < IRR_NW; ++w) t += red[w][x * 64 + lane];
+            dv[x] = t;
+        }
     }
 #pragma unroll
     for (int x = 0; x < EPL; ++x) {
@@ -1144,8 +1224,10 @@ int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, co
     if ((rc = ggemm(pv, G, H, mx, st))) return rc;
     const float scale = 1.0f / sqrtf((float)C);
     const int grid = (int)(((size_t)n * 64 + 255) / 256);
-    DA_HYB_SWITCH(C, (k_attn_irr_fwd<4><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)),
-                  (k_attn_irr_fwd<18><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, false><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)),
+                  (k_attn_irr_fwd<18, false><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)),
+                  (k_attn_irr_fwd<18, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)))
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -1173,8 +1255,10 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
                                                                     (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs,
                                                                     (float *)P, dP, nullptr, Dd);
     // remainder, destination side: D total, dq of the remainder edges, skip gradient
-    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)),
-                  (k_attn_irr_bwd_dst<18><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)),
+                  (k_attn_irr_bwd_dst<18, false><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)),
+                  (k_attn_irr_bwd_dst<18, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)))
     // dS = P o (dP - D) over the regular edges
     k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(1, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
                                                                     (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs,
@@ -1188,8 +1272,10 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
     q.transA = 1; q.transB = 0; q.dimM = 0; q.dimN = C; q.dimK = 0; q.alpha = scale; q.accumulate = 0;
     if ((rc = ggemm(q, G, H, mx, st))) return rc;
     // remainder, source side: += dk, dv
-    DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4><<<grid, 256, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
-                  (k_attn_irr_bwd_src<18><<<grid, 256, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, false><<<grid, 256, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
+                  (k_attn_irr_bwd_src<18, false><<<grid, 256, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
+                  (k_attn_irr_bwd_src<18, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
     DA_LAUNCH_CHECK();
     return 0;
 }
