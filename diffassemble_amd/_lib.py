@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 DA_MAX_LAYERS = 8
-ABI_VERSION = 16
+ABI_VERSION = 17
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -120,6 +120,10 @@ PROTOTYPES = {
     "da_sample_loop_pair_traj": (C.c_int, [_fp, C.POINTER(DaSchedule), C.c_int, C.c_int, C.c_int,
                                            C.POINTER(DaGraph), _fp, _fp, _fp, C.c_size_t,
                                            C.POINTER(DaGraph), _fp, _fp, _fp, C.c_size_t, _fp, _fp, C.c_size_t, _fp]),
+    "da_sample_loop_pair_ex": (C.c_int, [_fp, C.POINTER(DaSchedule), C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(DaGraph), _fp, _fp, _fp, C.c_size_t,
+                                         C.POINTER(DaGraph), _fp, _fp, _fp, C.c_size_t, _fp, _fp, C.c_size_t,
+                                         C.POINTER(DaLoopOpts), _fp, C.c_size_t, _fp]),
     "da_profile_enable": (C.c_int, [_fp, C.c_int]),
     "da_profile_read": (C.c_int, [_fp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "da_linear": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp,

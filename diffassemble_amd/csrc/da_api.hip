@@ -72,6 +72,7 @@ struct LoopKey {
     size_t ws_bytes;
     da_loop_opts opts;        // zero for the plain DDIM loop
     size_t traj_stride;       // elements between consecutive iterations of `traj` (0 = n_real * c)
+    size_t noise_stride;      // the same for opts.noise (two-branch loops read row ranges of one [n_iters, N, c] buffer)
 };
 
 }  // namespace da
@@ -763,7 +764,7 @@ int da_ddpm_step(const da_schedule *s, int n, int c, const float *x, const float
 
 static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int mean_type, int ratio,
                         int n_iters, const float *x_init, float *traj, float *x_final, const Workspace &w,
-                        hipStream_t st, const da_loop_opts *o = nullptr, size_t traj_stride = 0) {
+                        hipStream_t st, const da_loop_opts *o = nullptr, size_t traj_stride = 0, size_t noise_stride = 0) {
     const int nr = g->n_real;
     const int c = d->variant == DA_VARIANT_3D ? 7 : d->c_in;
     const size_t bytes = (size_t)nr * c * sizeof(float);
@@ -795,7 +796,7 @@ static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s,
             k_cfg_combine<<<(unsigned)((ne + 255) / 256), 256, 0, st>>>(ne, o->cfg_w, w.model_out, w.model_out_unc);
             DA_LAUNCH_CHECK();
         }
-        const float *nz = (o && o->noise) ? o->noise + (size_t)it * nr * c : nullptr;
+        const float *nz = (o && o->noise) ? o->noise + (size_t)it * (noise_stride ? noise_stride : (size_t)nr * c) : nullptr;
         rc = timed(d, DA_PROF_UPDATE, st, [&] {
             if (d->variant == DA_VARIANT_3D)
                 return launch_ddim3d(ds, mean_type, nr, cur, w.model_out, nullptr, i, ratio, nonneg, nxt, st);
@@ -872,12 +873,23 @@ int da_sample_loop(da_denoiser *d, const da_graph *g, const da_schedule *s, int 
 // Two independent halves of one Batch as two parallel branches of ONE hipGraph: each branch is the complete loop of
 // da_sample_loop over its own graphs, poses and workspace; the branches share nothing but the weights, so the runtime
 // overlaps one half's projections / tail kernels with the other half's attention.
-int da_sample_loop_pair_traj(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio, int max_iters,
-                             const da_graph *g_a, const float *x_init_a, float *x_final_a, void *workspace_a, size_t workspace_a_bytes,
-                             const da_graph *g_b, const float *x_init_b, float *x_final_b, void *workspace_b, size_t workspace_b_bytes,
-                             float *traj_a, float *traj_b, size_t traj_stride, void *stream) {
+int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio, int max_iters,
+                           const da_graph *g_a, const float *x_init_a, float *x_final_a, void *workspace_a, size_t workspace_a_bytes,
+                           const da_graph *g_b, const float *x_init_b, float *x_final_b, void *workspace_b, size_t workspace_b_bytes,
+                           float *traj_a, float *traj_b, size_t traj_stride, const da_loop_opts *opts, const float *noise_b,
+                           size_t noise_stride, void *stream) {
     DA_REQUIRE(d && s && g_a && g_b && x_init_a && x_init_b && x_final_a && x_final_b && workspace_a && workspace_b,
                "da_sample_loop_pair: null argument");
+    // the samplers of da_sample_loop_ex on both branches: one option set, half a reads opts->noise, half b noise_b (row ranges
+    // of one [n_iters, N, c] draw: the poses then equal the one-branch loop's bit for bit)
+    da_loop_opts oa, ob;
+    memset(&oa, 0, sizeof(oa));
+    if (opts) { oa.sampler = opts->sampler; oa.eta = opts->eta; oa.cfg = opts->cfg; oa.cfg_w = opts->cfg_w; oa.noise = opts->noise; }
+    ob = oa;
+    ob.noise = noise_b;
+    DA_REQUIRE(oa.sampler == 0 || oa.sampler == 1, "da_sample_loop_pair_ex: sampler must be 0 (DDIM) or 1 (DDPM)");
+    DA_REQUIRE(!(oa.sampler == 1 || oa.eta > 0.f) || (oa.noise && ob.noise), "da_sample_loop_pair_ex: eta > 0 / DDPM need both noise pointers");
+    DA_REQUIRE(d->variant == DA_VARIANT_2D || (!oa.cfg && oa.sampler == 0 && oa.eta == 0.f), "da_sample_loop_pair_ex: the 3D loop has no guidance / stochastic variant");
     DA_REQUIRE(inference_ratio >= 1 && s->steps >= 1, "da_sample_loop_pair: bad ratio/steps");
     DA_REQUIRE(d->variant == DA_VARIANT_3D || d->c_in == d->c_out, "da_sample_loop_pair: c_in != c_out");
     DA_REQUIRE(!g_a->hybrid && !g_b->hybrid, "da_sample_loop_pair: hybrid graphs fork a side stream of their own");
@@ -903,8 +915,10 @@ int da_sample_loop_pair_traj(da_denoiser *d, const da_schedule *s, int mean_type
         k.x_init = xi; k.traj = tr; k.x_final = xf; k.ws = ws; k.ws_bytes = wsb; k.traj_stride = tr ? traj_stride : 0;
         return k;
     };
-    const LoopKey ka = make_key(g_a, x_init_a, x_final_a, workspace_a, workspace_a_bytes, traj_a);
-    const LoopKey kb = make_key(g_b, x_init_b, x_final_b, workspace_b, workspace_b_bytes, traj_b);
+    LoopKey ka = make_key(g_a, x_init_a, x_final_a, workspace_a, workspace_a_bytes, traj_a);
+    LoopKey kb = make_key(g_b, x_init_b, x_final_b, workspace_b, workspace_b_bytes, traj_b);
+    ka.opts = oa; kb.opts = ob;
+    ka.noise_stride = oa.noise ? noise_stride : 0; kb.noise_stride = ob.noise ? noise_stride : 0;
     hipGraphExec_t exec = nullptr;
     for (auto &e : d->pair_loops)
         if (memcmp(&ka, &e.a, sizeof(ka)) == 0 && memcmp(&kb, &e.b, sizeof(kb)) == 0) exec = e.exec;
@@ -926,8 +940,8 @@ int da_sample_loop_pair_traj(da_denoiser *d, const da_schedule *s, int mean_type
         if (e == hipSuccess) e = hipStreamWaitEvent(ps, d->ev_pair_fork, 0);                 // ps joins the capture
         int rca = 0, rcb = 0;
         if (e == hipSuccess) {
-            rca = enqueue_loop(d, g_a, s, mean_type, inference_ratio, n_iters, x_init_a, traj_a, x_final_a, wa, cs, nullptr, traj_stride);
-            rcb = enqueue_loop(d, g_b, s, mean_type, inference_ratio, n_iters, x_init_b, traj_b, x_final_b, wb, ps, nullptr, traj_stride);
+            rca = enqueue_loop(d, g_a, s, mean_type, inference_ratio, n_iters, x_init_a, traj_a, x_final_a, wa, cs, &oa, traj_stride, noise_stride);
+            rcb = enqueue_loop(d, g_b, s, mean_type, inference_ratio, n_iters, x_init_b, traj_b, x_final_b, wb, ps, &ob, traj_stride, noise_stride);
             e = hipEventRecord(d->ev_pair_join, ps);
             if (e == hipSuccess) e = hipStreamWaitEvent(cs, d->ev_pair_join, 0);
         }
@@ -945,6 +959,15 @@ int da_sample_loop_pair_traj(da_denoiser *d, const da_schedule *s, int mean_type
     }
     DA_CHECK_HIP(hipGraphLaunch(exec, (hipStream_t)stream));
     return 0;
+}
+
+int da_sample_loop_pair_traj(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio, int max_iters,
+                             const da_graph *g_a, const float *x_init_a, float *x_final_a, void *workspace_a, size_t workspace_a_bytes,
+                             const da_graph *g_b, const float *x_init_b, float *x_final_b, void *workspace_b, size_t workspace_b_bytes,
+                             float *traj_a, float *traj_b, size_t traj_stride, void *stream) {
+    return da_sample_loop_pair_ex(d, s, mean_type, inference_ratio, max_iters, g_a, x_init_a, x_final_a, workspace_a, workspace_a_bytes,
+                                  g_b, x_init_b, x_final_b, workspace_b, workspace_b_bytes, traj_a, traj_b, traj_stride, nullptr, nullptr, 0,
+                                  stream);
 }
 
 int da_sample_loop_pair(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio, int max_iters,

@@ -219,8 +219,12 @@ class DenoiserEngine:
         total = (sched.steps + ratio - 1) // ratio
         n_iters = min(max_iters, total) if max_iters and max_iters > 0 else total
         ex = sampler == "DDPM" or eta > 0 or cfg_w is not None
-        if not ex and self._two_branch(plan, keep_trajectory, use_graph):
-            return self._sample_loop_pair(plan, sched, x_init, feats, ratio, mean_type, n_iters, restage, keep_trajectory)
+        if self._two_branch(plan, keep_trajectory, use_graph):
+            opts = None
+            if ex:                                  # the other samplers of the reference on both branches (da_sample_loop_pair_ex)
+                opts = dict(sampler=1 if sampler == "DDPM" else 0, eta=float(eta), cfg_w=cfg_w, noise=noise, generator=generator,
+                            stochastic=sampler == "DDPM" or eta > 0)
+            return self._sample_loop_pair(plan, sched, x_init, feats, ratio, mean_type, n_iters, restage, keep_trajectory, opts)
         if restage:
             g, ws = self.set_features(plan, feats)
         else:
@@ -286,7 +290,7 @@ class DenoiserEngine:
             return plan.n_graphs >= int(os.environ.get("DA_TWO_BRANCH_MIN_GRAPHS", "64"))
         return plan.n_real >= int(os.environ.get("DA_TWO_BRANCH_MIN_NODES", "40000"))
 
-    def _sample_loop_pair(self, plan, sched, x_init, feats, ratio, mean_type, n_iters, restage, keep_trajectory=False):
+    def _sample_loop_pair(self, plan, sched, x_init, feats, ratio, mean_type, n_iters, restage, keep_trajectory=False, opts=None):
         from .graph_plan import split_complete
         pa, pb, n0 = split_complete(plan, plan.n_graphs // 2)
         c = x_init.shape[1]
@@ -321,11 +325,28 @@ class DenoiserEngine:
             traj = st.get("traj")
             if traj is None or traj.shape[0] != n_iters:
                 traj = st["traj"] = torch.empty((n_iters, plan.n_real, c), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.da_sample_loop_pair_traj(
+        o, nz_b = None, None
+        if opts is not None:
+            o = _lib.DaLoopOpts()
+            o.sampler, o.eta = opts["sampler"], opts["eta"]
+            o.cfg, o.cfg_w = (0, 0.0) if opts["cfg_w"] is None else (1, float(opts["cfg_w"]))
+            if opts["stochastic"]:
+                # ONE [n_iters, N, c] draw for the whole Batch (what the one-branch loop reads), the halves take their row ranges
+                nb = st.get("noise")
+                if nb is None or nb.shape[0] != n_iters:
+                    nb = st["noise"] = torch.empty((n_iters, plan.n_real, c), dtype=torch.float32, device=self.device)
+                if opts["noise"] is not None:
+                    nb.copy_(opts["noise"])
+                else:
+                    nb.normal_(generator=opts["generator"])
+                o.noise = nb.data_ptr()
+                nz_b = _lib.ptr(nb[0, n0:])
+        _lib.check(self.lib.da_sample_loop_pair_ex(
             self.handle, C.byref(sched.c), int(mean_type), int(ratio), int(n_iters),
             C.byref(ga), _lib.ptr(xi), _lib.ptr(xf), _lib.ptr(wa), wa.numel(),
             C.byref(gb), _lib.ptr(xi[n0:]), _lib.ptr(xf[n0:]), _lib.ptr(wb), wb.numel(),
-            _lib.ptr(traj), None if traj is None else _lib.ptr(traj[0, n0:]), plan.n_real * c, _lib.stream_ptr(self.device)))
+            _lib.ptr(traj), None if traj is None else _lib.ptr(traj[0, n0:]), plan.n_real * c,
+            None if o is None else C.byref(o), nz_b, plan.n_real * c, _lib.stream_ptr(self.device)))
         return traj, xf
 
     # ------------------------------------------------------------------ measurement

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 16
+#define DA_ABI_VERSION 17
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -270,6 +270,18 @@ int da_sample_loop_pair_traj(da_denoiser *d, const da_schedule *s, int mean_type
                              const da_graph *g_b, const float *x_init_b, float *x_final_b,
                              void *workspace_b, size_t workspace_b_bytes,
                              float *traj_a, float *traj_b, size_t traj_stride, void *stream);
+/* ... and with the samplers of da_sample_loop_ex on both branches (ABI 17; spatial_diffusion.py:485-510,568-589,620-627):
+ * `opts` as there, with opts->noise = half a's noise rows and noise_b = half b's, iteration i read at + i * noise_stride floats
+ * (normally row ranges of ONE [n_iters, N, c] draw: noise_b = opts->noise + n_real_a * c, noise_stride = N * c -- the poses then
+ * equal the one-branch loop's bit for bit).  opts == NULL is da_sample_loop_pair_traj. */
+int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, int inference_ratio,
+                           int max_iters,
+                           const da_graph *g_a, const float *x_init_a, float *x_final_a,
+                           void *workspace_a, size_t workspace_a_bytes,
+                           const da_graph *g_b, const float *x_init_b, float *x_final_b,
+                           void *workspace_b, size_t workspace_b_bytes,
+                           float *traj_a, float *traj_b, size_t traj_stride,
+                           const da_loop_opts *opts, const float *noise_b, size_t noise_stride, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart: the reference has no profiler hooks).

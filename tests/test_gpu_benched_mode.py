@@ -685,6 +685,47 @@ def test_two_branch_loop_equals_one_branch(dev, monkeypatch, prec, sizes, loops)
     assert eng._two_branch(plan, False, True) and eng._two_branch(plan, True, True)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("kind", ["cfg", "eta", "ddpm", "cfg_eta"])
+def test_two_branch_loop_with_the_other_samplers_equals_one_branch(dev, monkeypatch, prec, kind):
+    """da_sample_loop_pair_ex (ABI 17): classifier-free guidance, DDIM eta > 0 and DDPM on the two-branch loop -- both halves read
+    their row ranges of ONE [n_iters, N, c] noise draw, the unconditional pass uses each half's own zero-feature projection --
+    give the one-branch da_sample_loop_ex poses and trajectory BIT for bit (uneven split, ragged sizes), also on replay of
+    the cached graph with a fresh draw."""
+    from diffassemble_amd import DenoiserEngine, Schedule, _lib
+    sizes = [144, 100, 64, 36, 144]
+    N = sum(sizes)
+    sd = W.make_denoiser_state(100, 4, 4, seed=47, qk_gain=3.0)
+    x, feats = W.make_inputs(N, 4, 1088, 47)
+    ei, batch = W.collate([W.dense_edge_index(n, True) for n in sizes], sizes)
+    sch = Schedule(ODF.make_schedule(100), dev)
+    eng = DenoiserEngine(sd, precision=prec, device=dev)
+    plan = eng.plan(ei, batch)
+    xd, fd = x.to(dev), feats.to(dev)
+    n_it = 10
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    kw = dict(ratio=10, mean_type=_lib.MEAN_EPSILON if kind == "ddpm" else _lib.MEAN_START_X, keep_trajectory=True, use_graph=True)
+    if kind in ("cfg", "cfg_eta"):
+        kw["cfg_w"] = 1.5
+    if kind in ("eta", "cfg_eta"):
+        kw["eta"] = 0.7
+    if kind == "ddpm":
+        kw["sampler"] = "DDPM"
+    for rep in range(2):
+        noise = None if kind == "cfg" else torch.randn((n_it, N, 4), generator=gen).to(dev)
+        monkeypatch.setenv("DA_TWO_BRANCH", "0")
+        t1, f1 = eng.sample_loop(plan, sch, xd, fd, noise=noise, **kw)
+        t1, f1 = t1.clone(), f1.clone()
+        monkeypatch.setenv("DA_TWO_BRANCH", "1")
+        monkeypatch.setenv("DA_TWO_BRANCH_MIN_GRAPHS", "2")
+        assert eng._two_branch(plan, True, True)
+        t2, f2 = eng.sample_loop(plan, sch, xd, fd, noise=noise, **kw)
+        assert torch.isfinite(f2).all() and torch.equal(t2, t1) and torch.equal(f2, f1)
+    if kind != "cfg":       # a different draw moves the poses (the buffer really is read)
+        t3, f3 = eng.sample_loop(plan, sch, xd, fd, noise=torch.randn((n_it, N, 4), generator=gen).to(dev), **kw)
+        assert not torch.equal(f3, f1)
+
+
 _TAIL_SCRIPT = r"""
 import sys, os, torch
 root = sys.argv[1]
