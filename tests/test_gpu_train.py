@@ -176,6 +176,39 @@ def test_large_batch_dense_training_rows_beyond_the_grid_cap(dev):
     assert rel(feats.grad, gf_ref) < GTOL and rel(feats.grad[-144:], gf_ref[-144:]) < 10 * GTOL
 
 
+@pytest.mark.parametrize("sizes,graph", [([150, 37, 160], "dense"), ([159, 16, 1, 81], "dense_noloop"), ([161, 30], "dense")],
+                         ids=["150_37_160", "159_16_1_81_noloop", "161_30_beyond_the_small_group_kernels"])
+def test_bf16_mode_group_sizes_around_the_small_group_limit(dev, sizes, graph):
+    """The one-workgroup attention kernels of the bf16-operand mode (k_attn_small_*, q16 buffers) take graphs of up to 160
+    nodes: sizes that are no multiple of the 16-row tile, the full 160, a single-node graph (its only possible key is
+    itself: excluded without self loops -> zero attention output, skip path only), and a Batch with a 161-node graph, which
+    must fall back to the grouped-GEMM route as a whole.  Forward, loss and gradients against the oracle's fp32 autograd at
+    the mode's documented tolerance."""
+    spec = dict(name="bf16_sizes", sizes=sizes, arch="transformer", V=0, graph=graph, c=4, steps=100, seed=91, qk_gain=3.0)
+    case = C.build_case(spec)
+    rng = np.random.default_rng(19)
+    target = torch.from_numpy(rng.standard_normal(tuple(case["x"].shape)).astype(np.float32))
+    pred_ref, loss_ref, g_ref, gf_ref = oracle_grads(spec, case, case["x"], target)
+    m = make_module(spec, case, dev)
+    m.train_engine(dev).precision = "bf16"
+    feats = case["feats"].to(dev).requires_grad_(True)
+    out, _ = m.forward_with_feats(case["x"].to(dev), case["t"].to(dev), None, case["edge_index"].to(dev), feats, case["batch"].to(dev))
+    loss = F.smooth_l1_loss(target.to(dev), out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and rel(out, pred_ref) < 1.5e-2 and rel(loss, loss_ref) < 5e-3
+    params = dict(m.named_parameters())
+    floor = 1e-3 * max(float(g.abs().max()) for g in g_ref.values())
+    for k, gr in g_ref.items():
+        if float(gr.abs().max()) < floor:
+            continue
+        got = params[k].grad.double().cpu()
+        err = float((got - gr.double()).abs().max()) / float(gr.abs().max())
+        cos = float((got * gr.double()).sum() / (got.norm() * gr.double().norm()))
+        assert err < 6e-2 and cos > 0.998, (k, err, cos)
+    assert rel(feats.grad, gf_ref) < 6e-2
+
+
 def test_gradient_accumulation_and_zeroing(dev):
     """Two backward passes accumulate like autograd; zero_grad(set_to_none=True) restarts from zero."""
     spec = C.by_name("k36_loop_sharp")
