@@ -1067,6 +1067,9 @@ def main():
             dist.init_process_group(backend)
 
     if args.mode == "train":
+        # benched default: the bf16-operand mode (the contract's compute dtype; encoder maps in bf16 with --pixels);
+        # --precision fp32 = exact products, the reference's arithmetic and the mode of the gradient fixtures
+        args.precision = args.precision or "bf16"
         return train_bench(args, world, rank, dev)
     if args.mode == "encode" and args.config == "4":
         args.puzzles = args.puzzles or 32

@@ -25,13 +25,22 @@ b config_2 --config 2
 b config_3 --config 3
 b config_3_d90 --config 3 --degree 90
 b config_4 --config 4
+# training lines: the benched default is the bf16-operand mode (--precision fp32 = the reference's arithmetic)
 b config_5 --config 5
-b config_5_bf16mma --config 5 --precision bf16
+b config_5_fp32 --config 5 --precision fp32
 b config_5_exophormer_d539 --config 5 --arch exophormer --train-side 30 --degree 539 --train-puzzles 16
-b config_5_exophormer_d539_bf16mma --config 5 --arch exophormer --train-side 30 --degree 539 --train-puzzles 16 --precision bf16
+b config_5_exophormer_d539_fp32 --config 5 --arch exophormer --train-side 30 --degree 539 --train-puzzles 16 --precision fp32
 b config_5_pixels --config 5 --pixels
+b config_5_pixels_fp32 --config 5 --pixels --precision fp32
+export TMPDIR=/tmp
+( cd /tmp && rm -rf /tmp/prof_t5 && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_t5 -o s -- python $GRAFT_REPO_ROOT/bench.py --config 5 --steps 20 --warmup 2 --no-cpu-baseline > /tmp/prof_t5.log 2>&1 )
+python profiles/rocpd_stats.py $(find /tmp/prof_t5 -name "*results.db" | head -1) > $O/${ROUND}_rocprof_kernel_stats_config5_bf16mma.txt 2>&1
+( cd /tmp && rm -rf /tmp/prof_exo && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_exo -o s -- python $GRAFT_REPO_ROOT/bench.py --config 5 --arch exophormer --train-side 30 --degree 539 --train-puzzles 16 --steps 5 --warmup 2 --no-cpu-baseline > /tmp/prof_exo.log 2>&1 )
+python profiles/rocpd_stats.py $(find /tmp/prof_exo -name "*results.db" | head -1) > $O/${ROUND}_rocprof_kernel_stats_config5_exophormer_d539_bf16mma.txt 2>&1
 b e2e --mode e2e
 b encode --mode encode
 b pcd_encode --mode encode --config 4
+( cd /tmp && rm -rf /tmp/prof_pcd && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_pcd -o s -- python $GRAFT_REPO_ROOT/bench.py --mode encode --config 4 --no-cpu-baseline > /tmp/prof_pcd.log 2>&1 )
+python profiles/rocpd_stats.py $(find /tmp/prof_pcd -name "*results.db" | head -1) > $O/${ROUND}_rocprof_kernel_stats_pcd_encode.txt 2>&1
 b config_3p_cpu_1_thread --steps 20 --warmup 5 --cpu-baseline-full --no-parity-mode --replays 5
 ls $O | grep ${ROUND}_ | wc -l
