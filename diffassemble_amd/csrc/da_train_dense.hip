@@ -520,18 +520,45 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
     if (n_g <= 0) return;
     constexpr int pr = CT * 16 + 8;
     const int C = p.C, np = p.np, ld = 4 * p.HC;
-    unsigned short *I0 = as_lds, *I1 = I0 + np * pr;                  // phase A: K, V ; phase B: Q, dO
-    float *st_m = (float *)(I1 + np * pr), *st_inv = st_m + np, *st_D = st_inv + np;
+    // ALL4 (narrow heads: four images are 46 KB at n = 144): K, V, Q AND dO are staged at once -- one load round trip instead of
+    // two, no band loads from HBM (the bands are rows of the images), no second staging pass between the phases
+    constexpr bool ALL4 = CT <= 2;
+    unsigned short *I0 = as_lds, *I1 = I0 + np * pr;                  // phase A: K, V ; phase B: Q, dO (ALL4: K, V stay, Q, dO in J0, J1)
+    unsigned short *J0 = ALL4 ? I1 + np * pr : I0, *J1 = ALL4 ? J0 + np * pr : I1;
+    float *st_m = (float *)(J1 + np * pr), *st_inv = st_m + np, *st_D = st_inv + np;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, lg = lane >> 4;
     const size_t e0 = (size_t)n0 * ld + h * C;                         // (node n0, head h) in the projection buffer and in dY4
     const size_t g0 = (size_t)n0 * p.HC + h * C;                       // ... in d_o
     as_stage<CT, Q16>(p.qkvs, e0 + p.HC, ld, n_g, np, C, I0, tid);
     as_stage<CT, Q16>(p.qkvs, e0 + 2 * p.HC, ld, n_g, np, C, I1, tid);
     const int tn_n = (n_g + 15) >> 4;
+    if constexpr (ALL4) {
+        as_stage<CT, Q16>(p.qkvs, e0, ld, n_g, np, C, J0, tid);
+        // dO image + its copy = the skip projection's gradient (columns 3 HC .. of dY4)
+        constexpr int kq = CT * 4;
+        for (int idx = tid; idx < np * kq; idx += 64 * AS_WAVES) {
+            const int r = idx / kq, k = (idx - r * kq) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < n_g && k < C) {
+                v = *(const f32x4 *)(p.d_o + g0 + (size_t)r * p.HC + k);
+                as_st4<Q16>(p.dY4, e0 + 3 * p.HC + (size_t)r * ld + k, v);
+            }
+            *(as_s16x4 *)(J1 + r * pr + k) = as_pack(v[0], v[1], v[2], v[3]);
+        }
+    }
     // ---- phase A: query bands (one per wave)
     {
         as_s16x4 qf[CT], gf[CT];
-        if (wid < tn_n) {
+        if (ALL4) {
+            __syncthreads();
+            if (wid < tn_n) {
+#pragma unroll
+                for (int kt = 0; kt < CT; ++kt) {
+                    qf[kt] = *(const as_s16x4 *)(J0 + (wid * 16 + l15) * pr + kt * 16 + 4 * lg);
+                    gf[kt] = *(const as_s16x4 *)(J1 + (wid * 16 + l15) * pr + kt * 16 + 4 * lg);
+                }
+            }
+        } else if (wid < tn_n) {
             as_band<CT, Q16>(p.qkvs, e0, ld, n_g, C, wid * 16, l15, lg, qf);
             // dO band, and its copy = the skip projection's gradient (columns 3 HC .. of dY4)
             const int r = wid * 16 + l15;
@@ -546,7 +573,7 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
                 gf[kt] = as_pack(v[0], v[1], v[2], v[3]);
             }
         }
-        __syncthreads();
+        if (!ALL4) __syncthreads();
         if (wid < tn_n) {
             const int tm = wid, i = tm * 16 + l15;
             f32x4 sa[AS_TN], da[AS_TN];
@@ -597,15 +624,25 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
         }
     }
     __syncthreads();
-    as_stage<CT, Q16>(p.qkvs, e0, ld, n_g, np, C, I0, tid);
-    as_stage<CT, false>(p.d_o, g0, p.HC, n_g, np, C, I1, tid);
     // ---- phase B: key bands (one per wave)
     as_s16x4 kf[CT], vf[CT];
-    if (wid < tn_n) {
-        as_band<CT, Q16>(p.qkvs, e0 + p.HC, ld, n_g, C, wid * 16, l15, lg, kf);
-        as_band<CT, Q16>(p.qkvs, e0 + 2 * p.HC, ld, n_g, C, wid * 16, l15, lg, vf);
+    if constexpr (ALL4) {
+        if (wid < tn_n) {
+#pragma unroll
+            for (int kt = 0; kt < CT; ++kt) {
+                kf[kt] = *(const as_s16x4 *)(I0 + (wid * 16 + l15) * pr + kt * 16 + 4 * lg);
+                vf[kt] = *(const as_s16x4 *)(I1 + (wid * 16 + l15) * pr + kt * 16 + 4 * lg);
+            }
+        }
+    } else {
+        as_stage<CT, Q16>(p.qkvs, e0, ld, n_g, np, C, I0, tid);
+        as_stage<CT, false>(p.d_o, g0, p.HC, n_g, np, C, I1, tid);
+        if (wid < tn_n) {
+            as_band<CT, Q16>(p.qkvs, e0 + p.HC, ld, n_g, C, wid * 16, l15, lg, kf);
+            as_band<CT, Q16>(p.qkvs, e0 + 2 * p.HC, ld, n_g, C, wid * 16, l15, lg, vf);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (wid < tn_n) {
         const int tj = wid, j = tj * 16 + l15;                         // this lane's key
         f32x4 vacc[CT], kacc[CT];
@@ -613,7 +650,7 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
         for (int ct = 0; ct < CT; ++ct) { vacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; kacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         for (int ti = 0; ti < tn_n; ++ti) {
             f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
-            const unsigned short *qp = I0 + (ti * 16 + l15) * pr + 4 * lg, *gpp = I1 + (ti * 16 + l15) * pr + 4 * lg;
+            const unsigned short *qp = J0 + (ti * 16 + l15) * pr + 4 * lg, *gpp = J1 + (ti * 16 + l15) * pr + 4 * lg;
 #pragma unroll
             for (int kt = 0; kt < CT; ++kt) {
                 s4 = AS_MFMA(*(const as_s16x4 *)(qp + kt * 16), kf[kt], s4);
@@ -632,8 +669,8 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
             const as_s16x4 pa = as_pack(pv[0], pv[1], pv[2], pv[3]), dsa = as_pack(dsv[0], dsv[1], dsv[2], dsv[3]);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                vacc[ct] = AS_MFMA(as_tr(I1, pr, ti * 16, ct * 16, l15, lg), pa, vacc[ct]);
-                kacc[ct] = AS_MFMA(as_tr(I0, pr, ti * 16, ct * 16, l15, lg), dsa, kacc[ct]);
+                vacc[ct] = AS_MFMA(as_tr(J1, pr, ti * 16, ct * 16, l15, lg), pa, vacc[ct]);
+                kacc[ct] = AS_MFMA(as_tr(J0, pr, ti * 16, ct * 16, l15, lg), dsa, kacc[ct]);
             }
         }
         if (j < n_g) {                                                // dK^T, dV^T tiles: four consecutive channels of key j per lane
@@ -658,10 +695,10 @@ bool attn_small_ok(const da_graph *g, int C, bool bfc) {
 template <int CT, bool Q16>
 static int attn_small_launch_ct(const da_graph *g, AttnSmall &a, bool bwd, hipStream_t st) {
     constexpr int pr = CT * 16 + 8;
-    const int lds = 2 * a.np * pr * 2 + (bwd ? 3 * a.np * 4 : 0);
+    const int lds = ((bwd && CT <= 2) ? 4 : 2) * a.np * pr * 2 + (bwd ? 3 * a.np * 4 : 0);       // (narrow-head backward: four images)
     static bool attr = false;
     if (!attr) {
-        const int cap = 2 * AS_MAXN * pr * 2 + 3 * AS_MAXN * 4;
+        const int cap = (CT <= 2 ? 4 : 2) * AS_MAXN * pr * 2 + 3 * AS_MAXN * 4;
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_bwd<CT, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_fwd<CT, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         attr = true;
