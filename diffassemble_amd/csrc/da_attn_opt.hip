@@ -488,12 +488,9 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
     if (masked && p.max_nodes > 4096) return -1;          // the masked walk keeps its key tiles in a 64-bit mask
     if (masked && p.blk_class && p.blk_class_stride > 128) return -1;      // class rows are staged in 128-byte LDS slots
     if (C == 32 && !fold) return masked ? launch_optt<32, false, true, 4, 4>(p, st) : launch_optt<32, false, false, 4, 4>(p, st);
-    if (C == 144 && fold) {
-        static int nst3 = -1;            // experiment switch: three ring stages at two workgroups per CU (default: two stages, three workgroups)
-        if (nst3 < 0) { const char *e = getenv("DA_ATTN_OPT_LAST_NST"); nst3 = (e && e[0] == '3') ? 1 : 0; }
-        if (nst3 && !masked) return launch_optt<144, true, false, 3, 2>(p, st);
-        return masked ? launch_optt<144, true, true, 2, 3>(p, st) : launch_optt<144, true, false, 2, 3>(p, st);
-    }
+    // (two ring stages at three workgroups per CU; measured at the end of round 4: three stages at two workgroups per CU 189 - 191 us
+    // against 178 in the harness at 64 puzzles, 99 against 92 at 32, the sampling step 0.717 against 0.703 ms -- occupancy, not ring depth)
+    if (C == 144 && fold) return masked ? launch_optt<144, true, true, 2, 3>(p, st) : launch_optt<144, true, false, 2, 3>(p, st);
     return -1;
 }
 

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_fwd(AttnSmall p) {
     }
 }
 
-template <int CT, bool Q16>
+template <int CT, bool Q16, bool A4>
 __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short as_lds[];
     const int g = blockIdx.x / p.H, h = blockIdx.x - g * p.H;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
     const int C = p.C, np = p.np, ld = 4 * p.HC;
     // ALL4 (narrow heads: four images are 46 KB at n = 144): K, V, Q AND dO are staged at once -- one load round trip instead of
     // two, no band loads from HBM (the bands are rows of the images), no second staging pass between the phases
-    constexpr bool ALL4 = CT <= 2;
+    constexpr bool ALL4 = A4;
     unsigned short *I0 = as_lds, *I1 = I0 + np * pr;                  // phase A: K, V ; phase B: Q, dO (ALL4: K, V stay, Q, dO in J0, J1)
     unsigned short *J0 = ALL4 ? I1 + np * pr : I0, *J1 = ALL4 ? J0 + np * pr : I1;
     float *st_m = (float *)(J1 + np * pr), *st_inv = st_m + np, *st_D = st_inv + np;
@@ -695,15 +695,20 @@ bool attn_small_ok(const da_graph *g, int C, bool bfc) {
 template <int CT, bool Q16>
 static int attn_small_launch_ct(const da_graph *g, AttnSmall &a, bool bwd, hipStream_t st) {
     constexpr int pr = CT * 16 + 8;
-    const int lds = ((bwd && CT <= 2) ? 4 : 2) * a.np * pr * 2 + (bwd ? 3 * a.np * 4 : 0);       // (narrow-head backward: four images)
+    static int a4_off = -1;
+    if (a4_off < 0) { const char *e = getenv("DA_ATTN_SMALL_ALL4"); a4_off = (e && e[0] == '0') ? 1 : 0; }
+    const bool a4 = CT <= 2 && !a4_off;                                   // narrow-head backward: four images, one staging pass
+    const int lds = ((bwd && a4) ? 4 : 2) * a.np * pr * 2 + (bwd ? 3 * a.np * 4 : 0);
     static bool attr = false;
     if (!attr) {
         const int cap = (CT <= 2 ? 4 : 2) * AS_MAXN * pr * 2 + 3 * AS_MAXN * 4;
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_bwd<CT, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_bwd<CT, Q16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        if (CT <= 2) DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_bwd<CT, Q16, CT <= 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_small_fwd<CT, Q16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         attr = true;
     }
-    if (bwd) k_attn_small_bwd<CT, Q16><<<g->n_graphs * a.H, 64 * AS_WAVES, lds, st>>>(a);
+    if (bwd && a4) k_attn_small_bwd<CT, Q16, CT <= 2><<<g->n_graphs * a.H, 64 * AS_WAVES, lds, st>>>(a);
+    else if (bwd) k_attn_small_bwd<CT, Q16, false><<<g->n_graphs * a.H, 64 * AS_WAVES, lds, st>>>(a);
     else k_attn_small_fwd<CT, Q16><<<g->n_graphs * a.H, 64 * AS_WAVES, lds, st>>>(a);
     DA_LAUNCH_CHECK();
     return 0;
