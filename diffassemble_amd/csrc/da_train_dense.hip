@@ -1028,29 +1028,34 @@ __global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int n_nodes,
 // edge a dependent load chain (index -> K / V or Q / dO row) of about a microsecond: fine for the 8 - 20 remainder edges of a
 // piece, 0.8 - 2.1 ms per launch for the exophormer's virtual nodes (900 edges each way; 12 launches per step = half the scripted
 // training step).  Every sum over edges is plain (the softmax statistics are known), so a row with more than IRR_HEAVY edges
-// is taken by a WORKGROUP of IRR_NW waves instead (HEAVY instances: one block per row, rows below the threshold return at
-// once; the wave-per-row instances skip the rows above it): wave w takes edges beg + w, beg + w + IRR_NW, ..., the partial sums
+// is taken by a WORKGROUP of 8 - 16 waves instead (HEAVY instances: one block per row, rows below the threshold return at
+// once; the wave-per-row instances skip the rows above it; HEAVY launches cover the rows behind the real nodes only -- the
+// virtual nodes -- and the wave-per-row instances keep every real row whatever its degree: a grid over all rows spent
+// 80 - 280 us per launch dispatching empty workgroups): wave w takes edges beg + w, beg + w + IRR_NW, ..., the partial sums
 // meet in LDS and are added in wave order -- deterministic, no atomics.
-constexpr int IRR_HEAVY = 96, IRR_NW = 8;
+constexpr int IRR_HEAVY = 96;
+template <int EPL> struct IrrNW { static constexpr int v = 16; };     // waves of a heavy row's workgroup (LDS: v x 64 x (EPL + 1) floats)
 
 // o[i, :] += sum over i's remainder edges of p_e v_src, p_e = exp(s_e - m_i) inv_i from the combined statistics.  Wave per
 // destination, lane = EPL contiguous channels of the H*C-wide rows (8 lanes per head), as the CSR kernels of da_train.hip.
 template <int EPL, bool HEAVY>
-__global__ __launch_bounds__(HEAVY ? 64 * IRR_NW : 256) void k_attn_irr_fwd(int n_nodes, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
+__global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_fwd(int n_nodes, int n_real, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
                                                       int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ stats,
                                                       float *__restrict__ o, float scale) {
+    constexpr int IRR_NW = IrrNW<EPL>::v;
     __shared__ float red[HEAVY ? IRR_NW : 1][HEAVY ? 64 * EPL : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i = HEAVY ? (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int i = HEAVY ? n_real + (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n_nodes) return;
     const int beg = irr_ptr[i], end = irr_ptr[i + 1];
-    if (HEAVY ? end - beg <= IRR_HEAVY : (beg == end || end - beg > IRR_HEAVY)) return;
+    if (HEAVY ? end - beg <= IRR_HEAVY : (beg == end || (i >= n_real && end - beg > IRR_HEAVY))) return;
     const size_t ld = (size_t)4 * HC;
     const int off = lane * EPL, head = lane >> 3;
     float q[EPL], acc[EPL];
 #pragma unroll
     for (int x = 0; x < EPL; ++x) { q[x] = qkvs[(size_t)i * ld + off + x] * scale; acc[x] = 0.f; }
     const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
+#pragma unroll 2
     for (int e = HEAVY ? beg + wv : beg; e < end; e += HEAVY ? IRR_NW : 1) {
         const float *kp = qkvs + (size_t)irr_src[e] * ld + HC + off;
         const float *vp = kp + HC;
@@ -1081,16 +1086,17 @@ __global__ __launch_bounds__(HEAVY ? 64 * IRR_NW : 256) void k_attn_irr_fwd(int 
 // backward over the remainder edges, destination side: D_i total = Dd[i] (dense part, on entry) + sum_e p_e dp_e; writes
 // D_i total back, dq_i of the remainder edges into dY4 (the dense dQ GEMM ACCUMULATES on top afterwards) and the skip gradient.
 template <int EPL, bool HEAVY>
-__global__ __launch_bounds__(HEAVY ? 64 * IRR_NW : 256) void k_attn_irr_bwd_dst(int n_nodes, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
+__global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_bwd_dst(int n_nodes, int n_real, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
                                                           int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ d_o,
                                                           const float *__restrict__ stats, float *__restrict__ dY4, float *__restrict__ Dd,
                                                           float scale) {
+    constexpr int IRR_NW = IrrNW<EPL>::v;
     __shared__ float red[HEAVY ? IRR_NW : 1][HEAVY ? 64 * (EPL + 1) : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i = HEAVY ? (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int i = HEAVY ? n_real + (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (i >= n_nodes) return;
     const int beg = irr_ptr[i], end = irr_ptr[i + 1];
-    if (HEAVY ? end - beg <= IRR_HEAVY : end - beg > IRR_HEAVY) return;      // (rows without edges still get their skip gradient)
+    if (HEAVY ? end - beg <= IRR_HEAVY : (i >= n_real && end - beg > IRR_HEAVY)) return;      // (rows without edges still get their skip gradient)
     const size_t ld = (size_t)4 * HC;
     const int off = lane * EPL, head = lane >> 3;
     float q[EPL], g[EPL], a1[EPL], a2[EPL];
@@ -1102,6 +1108,7 @@ __global__ __launch_bounds__(HEAVY ? 64 * IRR_NW : 256) void k_attn_irr_bwd_dst(
     }
     const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
     float D = 0.f;
+#pragma unroll 2
     for (int e = HEAVY ? beg + wv : beg; e < end; e += HEAVY ? IRR_NW : 1) {
         const float *kp = qkvs + (size_t)irr_src[e] * ld + HC + off;
         const float *vp = kp + HC;
@@ -1155,16 +1162,17 @@ __global__ __launch_bounds__(HEAVY ? 64 * IRR_NW : 256) void k_attn_irr_bwd_dst(
 
 // source side over the remainder edges (CSR by source): dk_j, dv_j ADDED to what the dense GEMMs wrote
 template <int EPL, bool HEAVY>
-__global__ __launch_bounds__(HEAVY ? 64 * IRR_NW : 256) void k_attn_irr_bwd_src(int n_nodes, const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_dst,
+__global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_bwd_src(int n_nodes, int n_real, const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_dst,
                                                           int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ d_o,
                                                           const float *__restrict__ stats, const float *__restrict__ Dd,
                                                           float *__restrict__ dY4, float scale) {
+    constexpr int IRR_NW = IrrNW<EPL>::v;
     __shared__ float red[HEAVY ? IRR_NW : 1][HEAVY ? 64 * EPL : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int j = HEAVY ? (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int j = HEAVY ? n_real + (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (j >= n_nodes) return;
     const int beg = out_ptr[j], end = out_ptr[j + 1];
-    if (HEAVY ? end - beg <= IRR_HEAVY : (beg == end || end - beg > IRR_HEAVY)) return;
+    if (HEAVY ? end - beg <= IRR_HEAVY : (beg == end || (j >= n_real && end - beg > IRR_HEAVY))) return;
     const size_t ld = (size_t)4 * HC;
     const int off = lane * EPL, head = lane >> 3;
     float kk[EPL], vv[EPL], dk[EPL], dv[EPL];
@@ -1174,6 +1182,7 @@ __global__ __launch_bounds__(HEAVY ? 64 * IRR_NW : 256) void k_attn_irr_bwd_src(
         vv[x] = qkvs[(size_t)j * ld + 2 * (size_t)HC + off + x];
         dk[x] = dv[x] = 0.f;
     }
+#pragma unroll 2
     for (int e = HEAVY ? beg + wv : beg; e < end; e += HEAVY ? IRR_NW : 1) {
         const int i = out_dst[e];
         float q[EPL], g[EPL], s = 0.f, dp = 0.f;
@@ -1266,10 +1275,10 @@ int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, co
     if ((rc = ggemm(pv, G, H, mx, st))) return rc;
     const float scale = 1.0f / sqrtf((float)C);
     const int grid = (int)(((size_t)n * 64 + 255) / 256);
-    DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, false><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)),
-                  (k_attn_irr_fwd<18, false><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)))
-    DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)),
-                  (k_attn_irr_fwd<18, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)),
+                  (k_attn_irr_fwd<18, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)))
+    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)),
+                  (k_attn_irr_fwd<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)))
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -1297,10 +1306,10 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
                                                                     (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs,
                                                                     (float *)P, dP, nullptr, Dd);
     // remainder, destination side: D total, dq of the remainder edges, skip gradient
-    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)),
-                  (k_attn_irr_bwd_dst<18, false><<<grid, 256, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)))
-    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)),
-                  (k_attn_irr_bwd_dst<18, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)),
+                  (k_attn_irr_bwd_dst<18, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)))
+    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)),
+                  (k_attn_irr_bwd_dst<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)))
     // dS = P o (dP - D) over the regular edges
     k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(1, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
                                                                     (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs,
@@ -1314,10 +1323,10 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
     q.transA = 1; q.transB = 0; q.dimM = 0; q.dimN = C; q.dimK = 0; q.alpha = scale; q.accumulate = 0;
     if ((rc = ggemm(q, G, H, mx, st))) return rc;
     // remainder, source side: += dk, dv
-    DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, false><<<grid, 256, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
-                  (k_attn_irr_bwd_src<18, false><<<grid, 256, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
-    DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
-                  (k_attn_irr_bwd_src<18, true><<<n, 64 * IRR_NW, 0, st>>>(n, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, false><<<grid, 256, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
+                  (k_attn_irr_bwd_src<18, false><<<grid, 256, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
+    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
+                  (k_attn_irr_bwd_src<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
     DA_LAUNCH_CHECK();
     return 0;
 }
