@@ -964,14 +964,28 @@ __global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int n_nodes,
         }
         if (mode == 0) {
             // online max / sum over the masked dense row ...
+            // (sixteen 64-element groups per pass: all their loads are issued before the first use -- one load per lane in
+            // flight made the pass a chain of ~30 dependent round trips per row, 0.85 ms per launch at 16 x 900 pieces)
             float m = -INFINITY, z = 0.f;
-            for (int j0 = 0; j0 < n_g; j0 += 64) {
-                const int j = j0 + lane;
-                const unsigned long long bits = *(const unsigned long long *)(mrow + (j0 >> 3));
-                const bool on = j < n_g && ((bits >> lane) & 1ull);
-                const float s = on ? row[j] : -INFINITY;
-                const float mn = fmaxf(m, s);
-                if (mn > -INFINITY) { z = z * expf(m - mn) + (on ? expf(s - mn) : 0.f); m = mn; }
+            for (int jb = 0; jb < n_g; jb += 1024) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {          // unconditional loads at clamped positions (guarded ones compile to load -> wait chains)
+                    const int j0 = jb + 64 * u, j = j0 + lane, jl = n_g - 1;
+                    const unsigned long long bits = *(const unsigned long long *)(mrow + (min(j0, jl & ~63) >> 3));
+                    const float rv = row[min(j, jl)];
+                    v[u] = (j < n_g && ((bits >> lane) & 1ull)) ? rv : -INFINITY;
+                }
+                float mc = m;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) mc = fmaxf(mc, v[u]);
+                if (mc > -INFINITY) {
+                    float zc = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) zc += v[u] > -INFINITY ? expf(v[u] - mc) : 0.f;
+                    z = (m > -INFINITY ? z * expf(m - mc) : 0.f) + zc;
+                    m = mc;
+                }
             }
             // ... and this row's remainder edges, a LANE per edge (64 at a time; the lane walks the head's C channels): one wave
             // reduction per edge and a dependent load chain per edge made the 900-edge rows of the virtual nodes 1.7 ms launches
@@ -1002,10 +1016,20 @@ __global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int n_nodes,
             }
             const float inv = (m > -INFINITY) ? 1.0f / (z + 1e-16f) : 0.f;
             const float mfin = (m > -INFINITY) ? m : 0.f;
-            for (int j0 = 0; j0 < n_g; j0 += 64) {
-                const int j = j0 + lane;
-                const unsigned long long bits = *(const unsigned long long *)(mrow + (j0 >> 3));
-                if (j < n_g) row[j] = ((bits >> lane) & 1ull) ? expf(row[j] - mfin) * inv : 0.f;
+            for (int jb = 0; jb < n_g; jb += 1024) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {          // unconditional loads at clamped positions (guarded ones compile to load -> wait chains)
+                    const int j0 = jb + 64 * u, j = j0 + lane, jl = n_g - 1;
+                    const unsigned long long bits = *(const unsigned long long *)(mrow + (min(j0, jl & ~63) >> 3));
+                    const float rv = row[min(j, jl)];
+                    v[u] = (j < n_g && ((bits >> lane) & 1ull)) ? rv : -INFINITY;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int j = jb + 64 * u + lane;
+                    if (j < n_g) row[j] = v[u] > -INFINITY ? expf(v[u] - mfin) * inv : 0.f;
+                }
             }
             if (lane == 0) { stats[((size_t)node * H + h) * 2] = mfin; stats[((size_t)node * H + h) * 2 + 1] = inv; }
         } else if (mode == 2) {
