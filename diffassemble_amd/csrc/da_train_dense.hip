@@ -10,6 +10,9 @@
 //             dQ = scale dS K ; dK = scale dS^T Q
 // operating directly on the row-major [n, 4HC] projection buffer (Q | K | V | skip) and writing dQ|dK|dV
 // into the fused [n, 4HC] gradient, so the dense and the CSR training paths share every other kernel.
+// (That is the exact-fp32 route and the route of graphs beyond 160 nodes.  In the bf16-operand mode, groups of up to 160
+// nodes -- BASELINE configuration 5 -- take k_attn_small_fwd / k_attn_small_bwd further down instead: the whole attention of a
+// (graph, head) in one workgroup, nothing but O kept, the softmax recomputed in the backward.)
 //
 // k_ggemm: C(m, n) = alpha * sum_k A(m, k) B(k, n) (+ C), 64 x 64 tile, 16 k per stage, 4 waves as 2 x 2,
 // v_mfma_f32_16x16x4_f32.  Operands may be transposed views; both tiles are staged k-major ([k][m] and
