@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int n_nodes,
 // 80 - 280 us per launch dispatching empty workgroups): wave w takes edges beg + w, beg + w + IRR_NW, ..., the partial sums
 // meet in LDS and are added in wave order -- deterministic, no atomics.
 constexpr int IRR_HEAVY = 96;
-template <int EPL> struct IrrNW { static constexpr int v = 16; };     // waves of a heavy row's workgroup (LDS: v x 64 x (EPL + 1) floats)
+template <int EPL> struct IrrNW { static constexpr int v = EPL <= 4 ? 16 : 8; };      // (eight at C = 144: the pipelined loop wants more than the 128 registers of a 1024-thread block)     // waves of a heavy row's workgroup (LDS: v x 64 x (EPL + 1) floats)
 
 // o[i, :] += sum over i's remainder edges of p_e v_src, p_e = exp(s_e - m_i) inv_i from the combined statistics.  Wave per
 // destination, lane = EPL contiguous channels of the H*C-wide rows (8 lanes per head), as the CSR kernels of da_train.hip.
@@ -1082,17 +1082,35 @@ __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_f
 #pragma unroll
     for (int x = 0; x < EPL; ++x) { q[x] = qkvs[(size_t)i * ld + off + x] * scale; acc[x] = 0.f; }
     const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
-#pragma unroll 2
-    for (int e = HEAVY ? beg + wv : beg; e < end; e += HEAVY ? IRR_NW : 1) {
+    // software pipeline: the rows of edge e + 1 are requested before edge e is consumed, its index one edge earlier still (the
+    // loop was two dependent round trips per edge: index -> rows)
+    constexpr int ST = HEAVY ? IRR_NW : 1;
+    int e = HEAVY ? beg + wv : beg;
+    float kn[EPL], vn[EPL];
+    int s1 = 0;
+    if (e < end) {
         const float *kp = qkvs + (size_t)irr_src[e] * ld + HC + off;
-        const float *vp = kp + HC;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { kn[x] = kp[x]; vn[x] = kp[HC + x]; }
+        if (e + ST < end) s1 = irr_src[e + ST];
+    }
+    for (; e < end; e += ST) {
+        float kk[EPL], vv[EPL];
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { kk[x] = kn[x]; vv[x] = vn[x]; }
+        if (e + ST < end) {
+            const float *kp = qkvs + (size_t)s1 * ld + HC + off;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) { kn[x] = kp[x]; vn[x] = kp[HC + x]; }
+            if (e + 2 * ST < end) s1 = irr_src[e + 2 * ST];
+        }
         float s = 0.f;
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kp[x], s);
+        for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[x], s);
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
         const float pe = expf(s - m) * inv;
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vp[x], acc[x]);
+        for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vv[x], acc[x]);
     }
     if (HEAVY) {
 #pragma unroll
@@ -1135,13 +1153,28 @@ __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_b
     }
     const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
     float D = 0.f;
-#pragma unroll 2
-    for (int e = HEAVY ? beg + wv : beg; e < end; e += HEAVY ? IRR_NW : 1) {
+    constexpr int ST = HEAVY ? IRR_NW : 1;                 // (software pipeline as in k_attn_irr_fwd)
+    int e = HEAVY ? beg + wv : beg;
+    float kn[EPL], vn[EPL];
+    int s1 = 0;
+    if (e < end) {
         const float *kp = qkvs + (size_t)irr_src[e] * ld + HC + off;
-        const float *vp = kp + HC;
-        float kk[EPL], s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { kk[x] = kp[x]; s = fmaf(q[x], kk[x], s); dp = fmaf(g[x], vp[x], dp); }
+        for (int x = 0; x < EPL; ++x) { kn[x] = kp[x]; vn[x] = kp[HC + x]; }
+        if (e + ST < end) s1 = irr_src[e + ST];
+    }
+    for (; e < end; e += ST) {
+        float kk[EPL], vv[EPL], s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { kk[x] = kn[x]; vv[x] = vn[x]; }
+        if (e + ST < end) {
+            const float *kp = qkvs + (size_t)s1 * ld + HC + off;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) { kn[x] = kp[x]; vn[x] = kp[HC + x]; }
+            if (e + 2 * ST < end) s1 = irr_src[e + 2 * ST];
+        }
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { s = fmaf(q[x], kk[x], s); dp = fmaf(g[x], vv[x], dp); }
         s += __shfl_xor(s, 1); dp += __shfl_xor(dp, 1);
         s += __shfl_xor(s, 2); dp += __shfl_xor(dp, 2);
         s += __shfl_xor(s, 4); dp += __shfl_xor(dp, 4);
@@ -1209,17 +1242,31 @@ __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_b
         vv[x] = qkvs[(size_t)j * ld + 2 * (size_t)HC + off + x];
         dk[x] = dv[x] = 0.f;
     }
-#pragma unroll 2
-    for (int e = HEAVY ? beg + wv : beg; e < end; e += HEAVY ? IRR_NW : 1) {
-        const int i = out_dst[e];
+    constexpr int ST = HEAVY ? IRR_NW : 1;                 // (software pipeline as in k_attn_irr_fwd)
+    int e = HEAVY ? beg + wv : beg;
+    float qn[EPL], gn[EPL], mn = 0.f, invn = 0.f, Dn = 0.f;
+    int s1 = 0;
+    auto fetch = [&](int i) {
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { qn[x] = qkvs[(size_t)i * ld + off + x]; gn[x] = d_o[(size_t)i * HC + off + x]; }
+        mn = stats[((size_t)i * H + head) * 2]; invn = stats[((size_t)i * H + head) * 2 + 1];
+        Dn = Dd[(size_t)i * H + head];
+    };
+    if (e < end) {
+        fetch(out_dst[e]);
+        if (e + ST < end) s1 = out_dst[e + ST];
+    }
+    for (; e < end; e += ST) {
         float q[EPL], g[EPL], s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) {
-            q[x] = qkvs[(size_t)i * ld + off + x] * scale; g[x] = d_o[(size_t)i * HC + off + x];
-            s = fmaf(q[x], kk[x], s); dp = fmaf(g[x], vv[x], dp);
+        for (int x = 0; x < EPL; ++x) { q[x] = qn[x] * scale; g[x] = gn[x]; }
+        const float m = mn, inv = invn, D = Dn;
+        if (e + ST < end) {
+            fetch(s1);
+            if (e + 2 * ST < end) s1 = out_dst[e + 2 * ST];
         }
-        const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
-        const float D = Dd[(size_t)i * H + head];
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { s = fmaf(q[x], kk[x], s); dp = fmaf(g[x], vv[x], dp); }
         s += __shfl_xor(s, 1); dp += __shfl_xor(dp, 1);
         s += __shfl_xor(s, 2); dp += __shfl_xor(dp, 2);
         s += __shfl_xor(s, 4); dp += __shfl_xor(dp, 4);
