@@ -11,9 +11,10 @@ import os
 
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
+LIB_PATH = os.environ.get("DA_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
+# (DA_LIB_PATH: an alternate BUILD of the same library -- compile-flag A/Bs, tools/build_ab.sh; never a different implementation)
 DA_MAX_LAYERS = 8
-ABI_VERSION = 17
+ABI_VERSION = 18
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -21,6 +22,7 @@ MEAN_EPSILON, MEAN_START_X = 0, 1
 ACT_NONE, ACT_GELU, ACT_LEAKY02 = 0, 1, 2
 CONV_Q_PRESCALED, CONV_FOLDED_V32 = 1, 2
 TRAIN_MMA_FP32, TRAIN_MMA_BF16 = 0, 1
+TRAIN_BWD_ALL, TRAIN_BWD_EARLY, TRAIN_BWD_LATE = 0, 1, 2
 DBG_COUNTERS = ("opt_gen_workgroups", "dense_fast_exits", "dual_gen_slabs", "opt_masked_gen_workgroups")
 PROF_CLASSES = ("embed", "linear_mlp", "linear_qkvs", "attn_hidden", "attn_last", "head", "update", "conv_fused")
 
@@ -144,6 +146,8 @@ PROTOTYPES = {
     "da_train_forward_ex": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
     "da_train_backward_ex": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp,
                                        _fp, C.c_size_t, C.c_int, _fp]),
+    "da_train_backward_stage": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp,
+                                          _fp, C.c_size_t, C.c_int, C.c_int, _fp]),
     "da_adafactor_step": (C.c_int, [C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_float,
                                     C.c_float, C.c_float, C.c_float, _fp]),
     "da_greedy_assign": (C.c_int, [C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),

@@ -41,7 +41,7 @@ struct AttnDenseParams {
     int n_rows;
 };
 
-template <typename T, int C, int CV = C> struct Cfg {
+template <typename T, int C, int CV = C, int BK = 0> struct Cfg {
     static constexpr int ES = (int)sizeof(T);
     static constexpr int ROWB = C * ES;                       // bytes of one K / Q row
     static constexpr int ROWBV = CV * ES;                     // bytes of one V row (CV != C: value heads folded with the
@@ -50,7 +50,7 @@ template <typename T, int C, int CV = C> struct Cfg {
     static constexpr int RS = ROWB + (((ROWB / 16) & 1) ? 0 : 16);   // odd number of 16-B slots
     static constexpr int KSPR = RS / 16;                      // LDS slots per K row
     static constexpr int KVALID = ROWB / 16;                  // of which carry data
-    static constexpr int BKEYS = ES == 2 ? 64 : 32;           // keys per LDS tile
+    static constexpr int BKEYS = BK ? BK : (ES == 2 ? 64 : 32);   // keys per LDS tile (BK = 0: the default of the element size)
     static constexpr int KB = BKEYS / 32;
     // V rows (row-major, like K).  bf16: the PV operand is fetched with ds_read_b64_tr_b16, whose 16-lane
     // groups read [4 keys][16 channels] blocks; two groups share an LDS cycle, and their 8 x 32-byte

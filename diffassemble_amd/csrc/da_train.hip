@@ -811,6 +811,9 @@ static int dims_of(const da_weights *w, const da_graph *g, Dims &d, int mma = DA
     d.dense = !train_dense_disabled() && g->dense != 0 && g->graph_ptr && d.V == 0 && g->max_graph_nodes > 0;
     d.hybrid = !d.dense && !train_dense_disabled() && g->hybrid && g->mask && g->mask_ptr && g->irr_row_ptr && g->graph_ptr &&
                g->pad_ptr && g->max_graph_nodes > 0;
+    // the hybrid training kernels index the adjacency bits by NODE (row i = node - graph_ptr[g]); a plan in the banded slot layout
+    // (graph_plan.expander_plan: bits in SLOT space, slot_node != NULL) would be read in the wrong order -- refuse it loudly
+    DA_REQUIRE(!(d.hybrid && g->slot_node), "training: hybrid graph in the banded slot layout (slot_node set); train on a natural-layout plan (build_plan / expander_plan(..., banded=False))");
     DA_REQUIRE(d.dense || d.hybrid || g->row_ptr, "training: this graph walks the edge list but the CSR arrays are missing");
     d.pair_floats = (d.dense || d.hybrid) ? dense_pair_floats(g, d.H) : 0;
     static int q16_off = -1;
@@ -1057,7 +1060,19 @@ int da_train_backward(const da_weights *w, const da_weights *grads, const da_gra
 int da_train_backward_ex(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
                          const int64_t *t, const float *d_out, float *d_feats, void *workspace, size_t workspace_bytes,
                          int mma_precision, void *stream) {
+    return da_train_backward_stage(w, grads, g, x, t, d_out, d_feats, workspace, workspace_bytes, mma_precision, DA_TRAIN_BWD_ALL, stream);
+}
+
+// The backward in two halves, cut where the gradients of final_mlp and of every conv but the first are complete (the data-parallel
+// exchange of that bucket -- 1.7 M of the 3.2 M parameters -- can then run on a side stream under the largest dW / dX products
+// of the step, conv 0's, and the mlp / embedding tail): DA_TRAIN_BWD_EARLY = head, convs L-1 .. 1; DA_TRAIN_BWD_LATE = conv 0,
+// virtual-node embedding, mlp, concat pieces.  EARLY then LATE on one stream == DA_TRAIN_BWD_ALL, launch for launch.
+int da_train_backward_stage(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
+                            const int64_t *t, const float *d_out, float *d_feats, void *workspace, size_t workspace_bytes,
+                            int mma_precision, int stage, void *stream) {
     Dims d;
+    DA_REQUIRE(stage == DA_TRAIN_BWD_ALL || stage == DA_TRAIN_BWD_EARLY || stage == DA_TRAIN_BWD_LATE, "da_train_backward_stage: unknown stage %d", stage);
+    const bool do_early = stage != DA_TRAIN_BWD_LATE, do_late = stage != DA_TRAIN_BWD_EARLY;
     int rc;
     DA_REQUIRE(mma_precision == DA_TRAIN_MMA_FP32 || mma_precision == DA_TRAIN_MMA_BF16, "da_train_backward: unknown mma_precision %d", mma_precision);
     if ((rc = dims_of(w, g, d, mma_precision))) return rc;
@@ -1072,6 +1087,8 @@ int da_train_backward_ex(const da_weights *w, const da_weights *grads, const da_
     const int nr = d.nr, n = d.n, D = d.D, L = d.L;
     auto G = [](const float *p) { return (float *)p; };       // grads: same struct, written by the library
 
+    const bool dh0_copy = n > nr;
+    if (do_early) {
     // ---- head: final_mlp.2, GELU, final_mlp.0 (efficient_gat.py:145)
     if ((rc = linear_bwd(nr, d.c_out, 32, d_out, d.c_out, ws.f1, 32, w->head_w1, G(grads->head_w1), G(grads->head_b1),
                          ws.df1, 32, nullptr, ws, st, d.bfc))) return rc;
@@ -1082,12 +1099,12 @@ int da_train_backward_ex(const da_weights *w, const da_weights *grads, const da_
                          ws, st, d.bfc))) return rc;
     // residual: z = conv_out + h0  ->  both get dz.  Without virtual rows dh0 = dz is not materialised: layer 0's dX product
     // takes dz as its residual operand and writes dh0 (dz is read-only from here on)
-    const bool dh0_copy = n > nr;
     if (dh0_copy) DA_CHECK_HIP(hipMemcpyAsync(ws.dh0, ws.dz, (size_t)n * D * 4, hipMemcpyDeviceToDevice, st));
+    }
 
-    // ---- graph transformer layers, last to first
-    const float *d_o = ws.dz;
-    for (int l = L - 1; l >= 0; --l) {
+    // ---- graph transformer layers, last to first (EARLY: L-1 .. 1; LATE: 0, whose incoming gradient is layer 1's dX buffer)
+    const float *d_o = do_early ? ws.dz : (L > 1 ? ws.dxa : ws.dz);
+    for (int l = do_early ? L - 1 : 0; l >= (do_late ? 0 : 1); --l) {
         const int hc = d.hc[l], din = d.din[l];
         if (d.dense) {
             if ((rc = dense_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.dY4, ws.poff, ws.node_graph, st, d.bfc, d.q16))) return rc;
@@ -1105,6 +1122,7 @@ int da_train_backward_ex(const da_weights *w, const da_weights *grads, const da_
             d_o = dx;
         }
     }
+    if (!do_late) return 0;
     // ---- virtual-node embedding (exophormer_gnn.py:169-178)
     if (d.V > 0) {
         DA_REQUIRE(grads->virt_emb, "exophormer: virt_emb gradient pointer missing");

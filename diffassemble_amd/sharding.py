@@ -57,13 +57,20 @@ def max_over_ranks(seconds, device=None):
     return float(t)
 
 
+def exchange_active():
+    """True when a gradient exchange has to run: an initialised process group with more than one rank -- or a ONE-rank
+    RCCL ("nccl") group, where the collective is executed anyway (it costs one small launch) so that a single-GPU box
+    exercises the very call the 8-GPU node makes."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or dist.get_backend() == "nccl")
+
+
 def allreduce_gradients(flat_grad, average=True):
     """Data-parallel training exchange: ONE all-reduce of the flat fp32 gradient buffer
     (``TrainEngine.flat_grad``, 12.9 MB for the 2D denoiser) per optimizer step -- a single fused bucket,
     sized for xGMI's point-to-point links, instead of Lightning-DDP's per-bucket hooks.  Every rank holds
     an equal number of equally sized puzzles, so the mean over ranks of the per-rank mean losses'
     gradients is the global-batch gradient (spatial_diffusion.py:707-721 under DDP)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not exchange_active():
         return flat_grad
     if flat_grad.is_cuda and dist.get_backend() == "gloo":
         # test configuration only (several ranks sharing one GPU cannot use RCCL): stage through the host

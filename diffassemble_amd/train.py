@@ -36,12 +36,14 @@ def _param_order(module):
     names = ["time_emb.weight", "pos_mlp.0.weight", "pos_mlp.0.bias", "pos_mlp.2.weight", "pos_mlp.2.bias",
              "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias"]
     n_layers = len(module.gnn_backbone.module_list)
+    # (the virtual-node embedding sits in FRONT of the convs: its gradient is produced after conv 0's, so it belongs to the
+    #  late bucket of the data-parallel exchange -- everything before conv 1 -- see TrainEngine.backward)
+    if hasattr(module.gnn_backbone, "virt_node_embedding"):
+        names.append("gnn_backbone.virt_node_embedding.weight")
     for l in range(n_layers):
         p = f"gnn_backbone.module_list.{l}."
         names += [p + f"lin_{k}.weight" for k in ("query", "key", "value", "skip")]
         names += [p + f"lin_{k}.bias" for k in ("query", "key", "value", "skip")]
-    if hasattr(module.gnn_backbone, "virt_node_embedding"):
-        names.append("gnn_backbone.virt_node_embedding.weight")
     names += ["final_mlp.0.weight", "final_mlp.0.bias", "final_mlp.2.weight", "final_mlp.2.bias"]
     return names, n_layers
 
@@ -67,6 +69,9 @@ class TrainEngine:
             offs.append(off)
             off += p.numel()
         self.total = (off + 63) // 64 * 64
+        # data-parallel buckets, in the order backward completes them: EARLY = [early_off, total) = convs 1 .. L-1 and final_mlp
+        # (final once da_train_backward_stage(EARLY) has run), LATE = [0, early_off) = embeddings, mlp, virtual nodes, conv 0
+        self.early_off = offs[names.index("gnn_backbone.module_list.1.lin_query.weight")]
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.views, self.grad_views = [], []
@@ -96,15 +101,47 @@ class TrainEngine:
         self.precision = os.environ.get("DIFFASSEMBLE_TRAIN_PRECISION", "fp32") or "fp32"      # "fp32" | "bf16" (module docstring)
         self.version = 0              # bumped by every raw-pointer update of ``flat`` (FusedAdafactor.step)
         self.grads_synced = False     # True between sync_gradients() and the next backward
+        # bucketed exchange (Lightning DDP's reducer overlaps its buckets with backward, train_script.py:215-218): on by default
+        # whenever a gradient exchange is active; DIFFASSEMBLE_OVERLAP_ALLREDUCE=0 = one serial all-reduce after backward
+        self.overlap_exchange = os.environ.get("DIFFASSEMBLE_OVERLAP_ALLREDUCE", "1") != "0"
+        self._side = None             # side stream of the early bucket's all-reduce
+        self._early_pending = False   # the early bucket is being / has been averaged on the side stream since the last sync
 
     def sync_gradients(self, average=True):
         """Data-parallel exchange (the reference gets it from Lightning's ``strategy="ddp"``,
         train_script.py:215-218): ONE all-reduce of ``flat_grad`` over the default process group, at most once
         per set of accumulated backward passes.  No-op without an initialised multi-rank group."""
-        from .sharding import allreduce_gradients
-        if not self.grads_synced:
+        from .sharding import allreduce_gradients, exchange_active
+        if self.grads_synced:
+            return
+        if self._early_pending:
+            # the early bucket was averaged on the side stream while the rest of backward ran; what is left is the late bucket
+            allreduce_gradients(self.flat_grad[:self.early_off], average=average)
+            self._join_side()
+            if not average and exchange_active():
+                import torch.distributed as dist
+                self.flat_grad[self.early_off:].mul_(dist.get_world_size())
+        else:
             allreduce_gradients(self.flat_grad, average=average)
-            self.grads_synced = True
+        self.grads_synced = True
+
+    def _join_side(self):
+        """The caller's stream waits for the early bucket's exchange (before anything rewrites ``flat_grad``)."""
+        if self._early_pending:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._early_pending = False
+
+    def _exchange_early(self):
+        """Average the early bucket over the ranks on the side stream, behind everything the caller's stream holds so far
+        (= da_train_backward_stage(EARLY)).  AVERAGED here, not summed: with gradient accumulation every backward exchanges
+        its early bucket, and avg(avg(g1) + g2_r) = avg(g1) + avg(g2) where a sum would count g1 world-size times."""
+        from .sharding import allreduce_gradients
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._side):
+            allreduce_gradients(self.flat_grad[self.early_off:], average=True)
+        self._early_pending = True
 
     def _weights_struct(self, by):
         w = _lib.DaWeights()
@@ -177,7 +214,9 @@ class TrainEngine:
     def backward(self, plan: GraphPlan, x, t, d_out, want_dfeats=False):
         """da_train_backward: adds every parameter gradient into ``flat_grad`` (and attaches the views
         as ``.grad``); returns d_feats [n_real, F] or None."""
+        from .sharding import exchange_active
         plan.with_source_csr()
+        self._join_side()             # (accumulation: the previous backward's early bucket must have landed before this one adds to it)
         attached = all(p.grad is not None and p.grad.data_ptr() == gv.data_ptr()
                        for p, gv in zip(self.params, self.grad_views))
         if not attached:
@@ -189,11 +228,15 @@ class TrainEngine:
         d_feats = torch.empty((plan.n_real, self.F), dtype=torch.float32, device=self.device) if want_dfeats else None
         ws = self._workspace(plan)
         g = self._cg(plan)
+        mma = getattr(self, "_fwd_mma", self._mma())       # the mode of the forward it follows
+        overlap = self.overlap_exchange and exchange_active()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.da_train_backward_ex(C.byref(self.w), C.byref(self.gw), C.byref(g), _lib.ptr(x), _lib.ptr(t),
-                                                     _lib.ptr(d_out), _lib.ptr(d_feats), _lib.ptr(ws), ws.numel(),
-                                                     getattr(self, "_fwd_mma", self._mma()),      # the mode of the forward it follows
-                                                     _lib.stream_ptr(self.device)))
+            for stage in ((_lib.TRAIN_BWD_EARLY, _lib.TRAIN_BWD_LATE) if overlap else (_lib.TRAIN_BWD_ALL,)):
+                _lib.check(self.lib.da_train_backward_stage(C.byref(self.w), C.byref(self.gw), C.byref(g), _lib.ptr(x), _lib.ptr(t),
+                                                            _lib.ptr(d_out), _lib.ptr(d_feats), _lib.ptr(ws), ws.numel(), mma, stage,
+                                                            _lib.stream_ptr(self.device)))
+                if stage == _lib.TRAIN_BWD_EARLY:
+                    self._exchange_early()
         if not attached:
             for p, gv in zip(self.params, self.grad_views):
                 p.grad = gv
@@ -338,6 +381,7 @@ class FusedAdafactor(torch.optim.Optimizer):
         """One fill of the flat gradient buffer (the views stay attached as ``.grad``) instead of one
         launch per parameter; parameters outside the engine are handled the usual way."""
         mine = {id(p) for p in self.engine.params}
+        self.engine._join_side()
         self.engine.flat_grad.zero_()
         for group in self.param_groups:
             for p in group["params"]:

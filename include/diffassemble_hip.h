@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 17
+#define DA_ABI_VERSION 18
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -402,6 +402,17 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
 int da_train_backward_ex(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
                          const int64_t *t, const float *d_out, float *d_feats, void *workspace,
                          size_t workspace_bytes, int mma_precision, void *stream);
+/* ABI 18: the backward in two halves for a BUCKETED data-parallel exchange (the reference gets this from Lightning's DDP reducer,
+ * train_script.py:215-218: gradient buckets all-reduced while the rest of backward still runs).  DA_TRAIN_BWD_EARLY enqueues
+ * final_mlp and the convs L-1 .. 1 -- afterwards their gradients are final and may be exchanged on another stream --,
+ * DA_TRAIN_BWD_LATE conv 0, the virtual-node embedding, mlp, pos_mlp, time_emb (and d_feats).  EARLY followed by LATE on one
+ * stream enqueues exactly the launches of DA_TRAIN_BWD_ALL (= da_train_backward_ex).                                       */
+#define DA_TRAIN_BWD_ALL 0
+#define DA_TRAIN_BWD_EARLY 1
+#define DA_TRAIN_BWD_LATE 2
+int da_train_backward_stage(const da_weights *w, const da_weights *grads, const da_graph *g, const float *x,
+                            const int64_t *t, const float *d_out, float *d_feats, void *workspace,
+                            size_t workspace_bytes, int mma_precision, int stage, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused Adafactor step over the flat parameter / gradient buffers (one call = one optimizer

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     for name in declared:
         assert getattr(h, name) is not None
-    assert h.da_abi_version() == _lib.ABI_VERSION == 17
+    assert h.da_abi_version() == _lib.ABI_VERSION == 18
 
 
 def test_single_hip_runtime_is_mapped():

@@ -84,8 +84,8 @@ int main(int argc, char **argv) {
     da::DenseLayout L; L.Q = dq; L.K = dk; L.Vt = dv; L.S = fold ? nullptr : ds; L.n_pad = n_pad; L.q_prescaled = dual ? 1 : 0;
     da::DenseFold fo; fo.cv = 32; fo.out = dout; fo.n_rows = N;
     auto run = [&]() {
-        if (dual == 1) return da::launch_attn_dual(L, H, C, G, n, dgp, dpp, nodiag, fold ? DA_ACT_NONE : DA_ACT_GELU, fold ? nullptr : dout, fold ? &fo : nullptr, st);
-        return da::launch_attn_dense(DA_PREC_BF16, L, H, C, G, n, dgp, dpp, nodiag, nullptr, fold ? DA_ACT_NONE : DA_ACT_GELU, fold ? nullptr : dout, st,
+        if (dual == 1) return da::launch_attn_dual(L, H, C, G, n, dgp, dpp, nodiag, (fold || getenv("ACT_NONE")) ? DA_ACT_NONE : DA_ACT_GELU, fold ? nullptr : dout, fold ? &fo : nullptr, st);
+        return da::launch_attn_dense(DA_PREC_BF16, L, H, C, G, n, dgp, dpp, nodiag, nullptr, (fold || getenv("ACT_NONE")) ? DA_ACT_NONE : DA_ACT_GELU, fold ? nullptr : dout, st,
                                      nullptr, fold ? &fo : nullptr);
     };
     int rc = run();
