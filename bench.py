@@ -98,7 +98,7 @@ def work_model(cfg, G, E, n_nodes_ext, flags, prec, hybrid, fused_hidden=False):
     threed = cfg["variant"] == "3d"
     D, Hd = (832, 256) if threed else (1152, 128)
     c = 7 if threed else (4 if cfg["rotation"] else 2)
-    N = G * cfg["n"]
+    N = cfg.get("N_total") or G * cfg["n"]          # (ragged Batches carry their totals: N_total pieces, pairs_total = sum n_g^2)
     Nx = n_nodes_ext                     # + virtual rows (exophormer)
     s = 2 if prec == "bf16" else 4
     mlp2_fused, last_fold = bool(flags & 1), bool(flags & 2)
@@ -115,8 +115,8 @@ def work_model(cfg, G, E, n_nodes_ext, flags, prec, hybrid, fused_hidden=False):
     W["linear_qkvs"] = dict(alg=Nx * 2 * (D * 1024 + 256 * 1024 * 2 + 256 * 4 * D), exe=exe_q,
                             bytes=Nx * s * ((k0 + 1024) + 2 * (256 + 1024) + (256 + n3)))
     cv = 32 if last_fold else D // 8
-    if hybrid or E == G * cfg["n"] ** 2 or E == G * cfg["n"] * (cfg["n"] - 1):
-        pairs = G * cfg["n"] ** 2        # the matrix-core kernels multiply every (query, key) pair of a graph
+    if hybrid or (cfg["n"] and (E == G * cfg["n"] ** 2 or E == G * cfg["n"] * (cfg["n"] - 1))):
+        pairs = cfg.get("pairs_total") or G * cfg["n"] ** 2        # the matrix-core kernels multiply every (query, key) pair of a graph
         W["attn_hidden"] = dict(alg=E * 3 * 4 * 256, exe=pairs * 3 * 4 * 256, bytes=3 * Nx * s * 5 * 256)
         W["attn_last"] = dict(alg=E * 4 * D, exe=pairs * 2 * 8 * (D // 8 + cv),
                               bytes=Nx * s * (2 * D + 8 * cv) + N * (8 * cv * s if last_fold else 2 * D * s))
@@ -985,6 +985,177 @@ def sample_bench(args, world, rank, dev):
         torch.distributed.destroy_process_group()
 
 
+def ragged_bench(args, world, rank, dev):
+    """--config scripted: the reference's SCRIPTED workload (singularity/gianscarpe/train_celeba_rot.sh:4-15): a ragged Batch of 8
+    puzzles with sides drawn from {6, 8, .., 20}, exophormer architecture with 8 virtual nodes on Exphander graphs of degree 60 %,
+    DDIM T = 300 / inference_ratio 10 (30 denoising steps per loop), START_X -- the sampling loop as the timed region, plus one
+    training step (p_losses -> backward -> Adafactor) on the same Batch as a side figure.
+    --config csr: the regime in which the edge-list kernel k_attn_csr IS the product path (every puzzle below the 256-node
+    threshold of graph_plan._hybrid_worth_it): G x 12x12 exophormer puzzles of degree 60 % (G = 512 by default: the last layer's
+    K | V rows, 0.34 GB in bf16, exceed the 256 MB Infinity Cache -- SURVEY 8d), DDIM T = 100."""
+    import numpy as np
+    from diffassemble_amd import _lib, expander
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    scripted = args.config == "scripted"
+    prec = args.precision or "bf16"
+    K, Wm = args.steps, args.warmup
+    rng = np.random.default_rng(20 + rank)
+    if scripted:
+        G = args.puzzles or 8
+        sides = [int(v) for v in rng.choice(np.arange(6, 21, 2), size=G)]
+        T, ratio = 300, 10
+    else:
+        G = args.puzzles or 512
+        sides = [12] * G
+        T, ratio = 100, 1
+    pct = 60
+    cfg = dict(name="", variant="2d", arch="exophormer", V=8, n=None, graph="ragged_regular", rotation=True, T=T, ratio=ratio,
+               mean="START_X", G=G, prec=prec, N_total=sum(v * v for v in sides), pairs_total=sum(v ** 4 for v in sides))
+    model = build_module(cfg, dev, prec)
+    eng = model.model.engine(dev)
+    sd = {k: v.detach().cpu() for k, v in model.model._denoiser_state().items()}
+    ei, batch, degs = expander.ragged_regular_batch(sides, pct, rng, dev)
+    N = cfg["N_total"]
+    gen = torch.Generator(device=dev).manual_seed(77 + rank)
+    feats = torch.randn((N, 1088), generator=gen, device=dev)
+    x_T = torch.randn((N, 4), generator=gen, device=dev)
+    plan = eng.plan(ei, batch)
+    torch.cuda.synchronize()
+    tp0 = time.perf_counter()
+    plan = eng.plan(ei, batch)
+    torch.cuda.synchronize()
+    plan_ms = (time.perf_counter() - tp0) * 1e3
+    E = int(plan.n_edges)
+    sch = model._schedule()
+    its = (T + ratio - 1) // ratio
+
+    def run(n_iters, graph):
+        return eng.sample_loop(plan, sch, x_T, feats, ratio=ratio, mean_type=_lib.MEAN_START_X, max_iters=n_iters,
+                               keep_trajectory=False, use_graph=graph, restage=False)
+    eng.set_features(plan, feats)
+    chunks = [its] * (K // its) + ([K % its] if K % its else [])
+    if Wm > 0:
+        run(min(Wm, its), False)
+    for ck in sorted(set(chunks)):
+        run(ck, True)
+    torch.cuda.synchronize()
+
+    def timed_pass():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for ck in chunks:
+            _, xf = run(ck, True)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        return time.perf_counter() - t0, xf
+    local = []
+    for _ in range(1 + max(args.replays, 0)):
+        dt_i, x_final = timed_pass()
+        local.append(dt_i)
+    from diffassemble_amd import sharding as S
+    passes = [S.max_over_ranks(v, dev) for v in local] if world > 1 else local
+    dt = statistics.median(passes)
+    assert torch.isfinite(x_final).all(), "non-finite poses"
+    path = "dense MFMA" if plan.dense else ("hybrid: adjacency-masked MFMA + CSR remainder" if plan.hybrid else "edge list (CSR gather: k_attn_csr)")
+
+    roof = None
+    flags = int(eng.flags)
+    if not args.no_roofline:
+        kp = min(K, 20, its)
+        run(2, False)
+        eng.profile(True)
+        run(kp, False)
+        prof = eng.profile_read()
+        eng.profile(False)
+        work = work_model(cfg, G, E, plan.n_nodes, flags, prec, bool(plan.hybrid))
+        tf = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic.json")
+        roof = roofline_report(prof, kp, work, prec, tf, args.config, G, gather_path=not (plan.dense or plan.hybrid))
+        roof["launch_shape"] = f"whole Batch ({G} puzzles, {N} pieces, {E} edges per launch), one branch: what the timed graph replays"
+
+    # ---- one training step on the same Batch (the scripted run TRAINS on these Batches: spatial_diffusion.py:707-721)
+    train = None
+    if scripted and not args.no_train_side:
+        mt = GNN_Diffusion(steps=T, sampling="DDIM", inference_ratio=ratio, rotation=True, visual_pretrained=False,
+                           model_mean_type=ModelMeanType.START_X, architecture="exophormer", virt_nodes=8).to(dev).train()
+        opt = mt.configure_optimizers()
+        te = mt.model.train_engine(dev)
+        res = {}
+        for tprec in ("bf16", "fp32"):
+            te.precision = tprec
+
+            def tstep():
+                t = torch.randint(0, T, (G,), generator=gen, device=dev)[batch]
+                opt.zero_grad()
+                loss = mt.p_losses(x_T, t, loss_type="huber", cond=None, edge_index=ei, batch=batch, patch_feats=feats)
+                loss.backward()
+                mt.sync_gradients()
+                opt.step()
+                return loss
+            for _ in range(3):
+                tstep()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                loss = tstep()
+            torch.cuda.synchronize()
+            assert torch.isfinite(loss)
+            res[tprec] = (time.perf_counter() - t0) / 10 * 1e3
+        train = {"ms_per_step_bf16_operands": res["bf16"], "ms_per_step_fp32": res["fp32"],
+                 "puzzle_train_steps_per_s_bf16_operands": G / res["bf16"] * 1e3,
+                 "what": "p_losses (q_sample + denoiser forward) -> backward -> gradient exchange hook -> fused Adafactor, piece features synthetic"}
+        del mt, opt, te
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            # the oracle on the SAME Batch (scripted: all 8 puzzles) or on 8 puzzles of the csr Batch, a few DDIM steps
+            from oracle import diffusion as ODF
+            nsub = min(G, 8)
+            nn = sum(v * v for v in sides[:nsub])
+            keep = (batch[ei[0]] < nsub)
+            eic, bc = ei[:, keep].cpu(), batch[:nn].cpu()
+            xc, fc = x_T[:nn].cpu(), feats[:nn].cpu()
+            schc = ODF.make_schedule(T)
+            threads = min(16, os.cpu_count() or 1)
+            torch.set_num_threads(threads)
+            kc = 2
+
+            def csteps():
+                t0 = time.perf_counter()
+                ODF.p_sample_loop(sd, schc, xc, eic, fc, bc, T, ratio, "START_X", "exophormer", 8, max_iters=kc)
+                return (time.perf_counter() - t0) / kc
+            csteps()
+            reps = sorted(csteps() for _ in range(3))
+            cpu = {"value": nsub / reps[1], "unit": "puzzle-steps/s", "cores": threads, "kind": "port",
+                   "sample": f"the first {nsub} puzzles of the Batch ({nn} pieces), {kc} DDIM steps per repeat, 1 warm-up + 3 repeats, median "
+                             f"{reps[1]:.3f} s/step, oracle/ torch fp32, {threads} threads"}
+        wl = ((f"the reference's scripted run (train_celeba_rot.sh:4-15): ragged Batch of {G} puzzles, sides {sides} ({N} pieces), exophormer V=8, "
+               f"Exphander degree 60 % (d per puzzle {degs}), DDIM T=300 / ratio 10, START_X, rot+trans c=4")
+              if scripted else
+              (f"edge-list regime: {G} x 12x12 puzzles ({N} pieces), exophormer V=8, Exphander degree 60 % (d={degs[0]}), DDIM T=100, START_X; "
+               f"every graph below the 256-node hybrid threshold, so k_attn_csr is the product path"))
+        print(json.dumps({
+            "metric": f"denoising steps/sec ({'scripted ragged exophormer Batch' if scripted else 'edge-list (CSR) regime, 12x12 exophormer'})",
+            "value": world * G * K / dt, "unit": "puzzle-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "value_is": f"median of {len(passes)} timed K-step passes",
+            "distributed": dist_info(world),
+            "config": {"workload": wl, "baseline_config": args.config, "puzzles_per_gpu": G, "global_puzzles": world * G,
+                       "pieces": N, "edges_incl_virtual": E, "loop": "hipGraph replay", "attention_path": path,
+                       "parallelism": f"puzzle-sharded x{world}"},
+            "batch_steps_per_s": world * K / dt,
+            "pieces_steps_per_s": world * N * K / dt,
+            "algorithmic_tflops": world * (N * F_NODE + E * F_EDGE) * K / dt / 1e12,
+            "graph_plan_ms": plan_ms, "training_step_same_batch": train,
+            "roofline": roof, "cpu_baseline": cpu,
+        }))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def self_launch(n):
     """``python bench.py --gpus N`` without a launcher around it: start the N ranks ourselves, the way the reference's
     Trainer spawns its own (train_script.py:215-218, strategy="ddp"): one process per GPU through
@@ -1034,7 +1205,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default=os.environ.get("BENCH_CONFIG", "3p"), choices=["1", "2", "3", "3p", "4", "5"],
+    ap.add_argument("--config", default=os.environ.get("BENCH_CONFIG", "3p"), choices=["1", "2", "3", "3p", "4", "5", "scripted", "csr"],
                     help="BASELINE configuration (default 3p = the headline metric; 5 = --mode train)")
     ap.add_argument("--puzzles", type=int, default=int(os.environ.get("BENCH_PUZZLES", 0)),
                     help="independent puzzles per GPU (the batch of one step); 0 = the configuration's default")
@@ -1058,6 +1229,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle with ONE thread at full size")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train-side", action="store_true", help="--config scripted: skip the training step on the same Batch")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp32 (parity-mode) replay of the sampling configurations")
     args = ap.parse_args()
     args.degree_given = any(a == "--degree" or a.startswith("--degree=") for a in sys.argv[1:]) or "BENCH_DEGREE" in os.environ
@@ -1086,6 +1258,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.config in ("scripted", "csr"):
+        return ragged_bench(args, world, rank, dev)
     if args.mode == "train":
         # benched default: the bf16-operand mode (the contract's compute dtype; encoder maps in bf16 with --pixels);
         # --precision fp32 = exact products, the reference's arithmetic and the mode of the gradient fixtures

@@ -39,6 +39,16 @@
 
 namespace da {
 
+// DA_OPT_PROBE builds (tools/build_ab.sh probe da_attn_opt.hip "-fno-slp-vectorize -DDA_OPT_PROBE"): cycle breakdown of every
+// wave-0 of the classic (non-pipelined) tile loop into DA_OPT_PROF_PTR: [0] whole kernel, [1] waiting for the tile (vmcnt +
+// barrier), [2] issuing the DMA, [3] K-fragment reads until their data is there, [4] the rest of the block (QK, softmax, PV),
+// [5] epilogue, [6] blocks, [7] 1.  (s_memtime; every stamp drains lgkmcnt, i.e. the V reads are not overlapped in this build.)
+#ifdef DA_OPT_PROBE
+#define DA_OPB(...) __VA_ARGS__
+#else
+#define DA_OPB(...)
+#endif
+
 // da_debug_counters: workgroups whose optimistic pass failed its verification ([0] complete graphs, [1] adjacency-masked)
 __device__ unsigned long long g_opt_fallbacks[2];
 
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         return k;
     };
 
+    DA_OPB(unsigned long long pb_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long pb_start = __builtin_readcyclecounter(); unsigned long long pb_t = pb_start;)
     f32x16 O;
     float ls = 0.f;               // this lane's share of the row sum (16 of the block's 32 keys)
     float ls2 = 0.f;              // VAR & 1: second chain of the row sum
@@ -401,6 +412,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         }
         for (int j = 0; j < ntl; ++j) {
             const int kt = next_tile(rem_cur, j);
+            DA_OPB(pb_t = __builtin_readcyclecounter();)
             {
                 // tiles that may stay in flight behind this one (each is `myn` operations of this wave; myn is LO or LO + 1)
                 constexpr int LO = KG::NI / NW + (MASKED ? 1 : 0);
@@ -412,7 +424,9 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
+            DA_OPB({ const unsigned long long t_ = __builtin_readcyclecounter(); pb_[1] += t_ - pb_t; pb_t = t_; })
             if (j + NST - 1 < ntl) issue(next_tile(rem_pf, j + NST - 1), (j + NST - 1) % NST);
+            DA_OPB({ const unsigned long long t_ = __builtin_readcyclecounter(); pb_[2] += t_ - pb_t; pb_t = t_; })
             if (!wave_on) continue;
             // classes of this slab's two blocks in the tile (1 = partial when the plan has no class table)
             const unsigned cls2 = (MASKED && crow) ? (unsigned)__builtin_amdgcn_readfirstlane((int)*(const unsigned short *)(crow + 2 * kt)) : 0x0101u;
@@ -428,6 +442,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                 for (int ch = 0; ch < CF::NCH; ++ch)
                     if (!(VAR & 16) || (j == 0 && kb == 0)) kf[ch] = *(const u32x4 *)(stg + kfo[ch] + kb * 32 * KG::RS);
                 __builtin_amdgcn_sched_barrier(0);
+                DA_OPB({ asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[CF::NCH - 1])); const unsigned long long t_ = __builtin_readcyclecounter(); pb_[3] += t_ - pb_t; pb_t = t_; })
                 f32x16 s;
                 if (MASKED && cls == 2u) {                                           // every pair of the block is an edge
                     anym = 1u;
@@ -515,6 +530,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                     O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O, 0, 0, 0);
                     O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
                 }
+                DA_OPB({ asm volatile("" : "+v"(O)); const unsigned long long t_ = __builtin_readcyclecounter(); pb_[4] += t_ - pb_t; pb_t = t_; pb_[6] += 1; })
                 if (!(VAR & 1)) {
                     // row sum of the bf16-rounded p (what the PV product weighs with): eight v_dot2_f32_bf16 against (1, 1)
                     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -550,6 +566,9 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     }
 
     // ---- epilogue
+    DA_OPB(const unsigned long long pb_ep = __builtin_readcyclecounter();)
+    DA_OPB(auto pb_out = [&]() { if (p.prof && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); unsigned long long *o_ = p.prof + 8 * (size_t)blockIdx.x;
+                                 o_[0] = t_ - pb_start; o_[1] = pb_[1]; o_[2] = pb_[2]; o_[3] = pb_[3]; o_[4] = pb_[4]; o_[5] = t_ - pb_ep; o_[6] = pb_[6]; o_[7] = 1; } };)
     const float lt = ls + __shfl_xor(ls, 32);
     const float inv = lt > 0.f ? 1.0f / (lt + ((gen && !MASKED) ? 1e-16f : 0.f)) : 0.f;      // (see the header: no epsilon on an un-shifted sum;
                                                                                               //  MASKED rows are normalised again after their remainder edges)
@@ -565,6 +584,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                 st4(dst + c0, v4);
             }
         }
+        DA_OPB(pb_out();)
         return;
     }
     constexpr int CO = CV, RSOF = CO + 4;
@@ -648,6 +668,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             }
         }
     }
+    DA_OPB(pb_out();)
 }
 
 template <int C, bool FOLD, bool MASKED, int NST, int MINB, int BK = 64, int VAR = 0>
@@ -661,6 +682,7 @@ static int launch_optt(AttnDenseParams p, hipStream_t st) {
         attr_done[dev & 15] = true;
     }
     p.nqt = (p.max_nodes + 127) / 128;
+    DA_OPB({ const char *e = getenv("DA_OPT_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; })
     k_attn_optt<C, FOLD, MASKED, NST, MINB, BK, VAR><<<p.nqt * p.H * p.n_graphs, 256, lds, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;

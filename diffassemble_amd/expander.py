@@ -55,3 +55,28 @@ def regular_edge_index(perms, degree, device=None):
     r = torch.cat([rolled, tiled], 1) + off
     batch = torch.arange(G, device=dev).repeat_interleave(n)
     return torch.stack([s.reshape(-1), r.reshape(-1)]), batch
+
+
+def percent_degree(n, percent):
+    """``Puzzle_Dataset``'s "--degree P%" for an n-piece puzzle (puzzle_dataset.py:46-47): round(P (n - 1) / 100), made even-sum
+    (n * d must be even for a d-regular graph: one less when it is not)."""
+    d = int(round(percent * (n - 1) / 100.0))
+    d = max(min(d, n - 1), 2)
+    return d - (d * n) % 2
+
+
+def ragged_regular_batch(sides, percent, rng, device=None):
+    """The PyG ``Batch`` graph of a RAGGED set of puzzles, as the reference's DataLoader collates it for the scripted run
+    (train_celeba_rot.sh:4-15: ``-puzzle_sizes 6 8 .. 20 -batch_size 8 --degree 60%``): puzzle g has sides[g]^2 pieces and its own
+    Exphander graph of degree ``percent_degree(n_g, percent)``.  -> (edge_index [2, E] int64 with node offsets, batch [N] int64,
+    degrees list)."""
+    eis, batches, degs, off = [], [], [], 0
+    for g, side in enumerate(sides):
+        n = int(side) * int(side)
+        d = percent_degree(n, percent)
+        ei, _ = regular_edge_index(draw_permutations(n, 1, rng), d, device)
+        eis.append(ei + off)
+        batches.append(torch.full((n,), g, dtype=torch.int64, device=ei.device))
+        degs.append(d)
+        off += n
+    return torch.cat(eis, 1), torch.cat(batches), degs

@@ -230,12 +230,13 @@ class TrainEngine:
         g = self._cg(plan)
         mma = getattr(self, "_fwd_mma", self._mma())       # the mode of the forward it follows
         overlap = self.overlap_exchange and exchange_active()
+        staged = overlap or getattr(self, "force_staged", False)       # (force_staged: tests -- the two halves without a process group)
         with torch.cuda.device(self.device):
-            for stage in ((_lib.TRAIN_BWD_EARLY, _lib.TRAIN_BWD_LATE) if overlap else (_lib.TRAIN_BWD_ALL,)):
+            for stage in ((_lib.TRAIN_BWD_EARLY, _lib.TRAIN_BWD_LATE) if staged else (_lib.TRAIN_BWD_ALL,)):
                 _lib.check(self.lib.da_train_backward_stage(C.byref(self.w), C.byref(self.gw), C.byref(g), _lib.ptr(x), _lib.ptr(t),
                                                             _lib.ptr(d_out), _lib.ptr(d_feats), _lib.ptr(ws), ws.numel(), mma, stage,
                                                             _lib.stream_ptr(self.device)))
-                if stage == _lib.TRAIN_BWD_EARLY:
+                if stage == _lib.TRAIN_BWD_EARLY and overlap:
                     self._exchange_early()
         if not attached:
             for p, gv in zip(self.params, self.grad_views):

@@ -46,11 +46,15 @@ def test_one_rank_rccl_group_runs_the_gradient_exchange(tmp_path):
     # the early bucket really went through the side stream in the overlapped runs, and never in the serial ones
     assert all(nccl["early_pending_seen_overlap_1"]) and not any(nccl["early_pending_seen_overlap_0"])
     assert 0 < nccl["bucket_split"][0] < nccl["bucket_split"][1]
-    assert nccl["overlap_equals_serial_grad"] and nccl["overlap_equals_serial_params"]
+    # equal up to the summation order of the time_emb gradient's atomics (k_time_scatter): 1e-6 of the buffer's max-abs
+    assert nccl["overlap_vs_serial_grad"] < 1e-6 and nccl["overlap_vs_serial_params"] < 1e-5
     assert nccl["grad_abs_sum_overlap_1"] > 0
-    assert torch.equal(dn["grad"][True], dr["grad"][False])       # exchanged over one rank == not exchanged, bit for bit
-    assert torch.equal(dn["flat"][True], dr["flat"][False])       # ... and so are the parameters after three fused Adafactor steps
-    assert nccl["losses_overlap_1"] == ref["losses_overlap_0"]
+
+    def reldiff(a, b):
+        return float((a - b).abs().max() / b.abs().max())
+    assert reldiff(dn["grad"][True], dr["grad"][False]) < 1e-6       # exchanged over one rank == not exchanged
+    assert reldiff(dn["flat"][True], dr["flat"][False]) < 1e-5       # ... and so are the parameters after three fused Adafactor steps
+    assert max(abs(a - b) for a, b in zip(nccl["losses_overlap_1"], ref["losses_overlap_0"])) < 1e-5
 
 
 @pytest.mark.gpu

@@ -1,0 +1,110 @@
+"""The reference's SCRIPTED workload (singularity/gianscarpe/train_celeba_rot.sh:4-15: ragged Batches of 8 puzzles, sides
+6 .. 20, exophormer with 8 virtual nodes, Exphander degree 60 %, T = 300 / inference_ratio 10) -- what `bench.py --config scripted`
+times -- against the CPU oracle: forward (fp32 at the 1e-4 bound, bf16 at the bf16 bound), the first DDIM steps of the loop, and one
+training step's loss and gradients.  Two Batches: a mixed one (some puzzle >= 256 pieces: the plan goes hybrid, adjacency-masked
+matrix-core attention over every graph + CSR remainder) and a small one (all puzzles < 256 pieces: the edge-list kernel
+k_attn_csr is the product path -- the `bench.py --config csr` regime)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser as OD
+from oracle import diffusion as ODF
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+RTOL32, RTOLBF = 1e-4, 8e-3
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _batch(sides, seed):
+    from diffassemble_amd import expander
+    rng = np.random.default_rng(seed)
+    ei, batch, degs = expander.ragged_regular_batch(sides, 60, rng)
+    n = int(batch.numel())
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 4, generator=g)
+    feats = torch.randn(n, 1088, generator=g)
+    t = torch.randint(0, 300, (len(sides),), generator=g)[batch]
+    return ei, batch, degs, x, feats, t
+
+
+CASES = {"mixed_hybrid": ([6, 16, 10, 20, 8, 18, 12, 14], True), "small_csr": ([6, 8, 10, 12, 14, 12, 10, 6], False)}
+
+
+def test_percent_degree_matches_the_dataset_rule():
+    from diffassemble_amd import expander
+    for side in range(6, 21, 2):
+        n = side * side
+        d = expander.percent_degree(n, 60)
+        assert (n * d) % 2 == 0 and abs(d - 0.6 * (n - 1)) <= 1.5 and 2 <= d < n
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_scripted_batch_forward_and_loop_vs_oracle(dev, name, prec):
+    from diffassemble_amd import DenoiserEngine, Schedule, _lib
+    sides, hybrid = CASES[name]
+    ei, batch, degs, x, feats, t = _batch(sides, 5)
+    V = 8
+    sd = W.make_denoiser_state(300, 4, 4, arch="exophormer", virt_nodes=V, seed=71, qk_gain=3.0)
+    ref, _ = OD.eff_gat_forward_with_feats(sd, x, t, ei, feats, batch, arch="exophormer", virt_nodes=V)
+    eng = DenoiserEngine(sd, variant="2d", arch="exophormer", virt_nodes=V, precision=prec, device=dev)
+    plan = eng.plan(ei.to(dev), batch.to(dev))
+    assert bool(plan.hybrid) == hybrid and not plan.dense
+    n = int(batch.numel())
+    assert plan.n_edges == sum(s * s * d for s, d in zip(sides, degs)) + n + sum(V * (s * s + V) for s in sides)
+    out = eng.forward(plan, x.to(dev), t.to(dev), feats.to(dev))
+    tol = RTOL32 if prec == "fp32" else RTOLBF
+    assert rel(out, ref) < tol, rel(out, ref)
+    # the first three DDIM steps of the scripted loop (T = 300, ratio 10, START_X, noise_weight 0 -> x_T = 0 in the script;
+    # a random start here exercises more) through the captured graph
+    sch_c = ODF.make_schedule(300)
+    imgs, _ = ODF.p_sample_loop(sd, sch_c, x, ei, feats, batch, 300, 10, "START_X", "exophormer", V, max_iters=3)
+    traj, _ = eng.sample_loop(plan, Schedule(sch_c, dev), x.to(dev), feats.to(dev), ratio=10, mean_type=_lib.MEAN_START_X, max_iters=3,
+                              use_graph=True)
+    assert rel(traj, torch.stack(imgs)) < (5e-4 if prec == "fp32" else 2e-2)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_scripted_batch_training_step_vs_oracle_autograd(dev, name):
+    """p_losses on the ragged Batch: loss and every live parameter's gradient against the oracle's autograd (fp32 mode)."""
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+    sides, hybrid = CASES[name]
+    ei, batch, degs, x, feats, t = _batch(sides, 9)
+    V = 8
+    sd = W.make_denoiser_state(300, 4, 4, arch="exophormer", virt_nodes=V, seed=73, qk_gain=3.0)
+    noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(3))
+    sdc = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss_c = ODF.p_losses(sdc, ODF.make_schedule(300), x, t, noise, ei, feats, batch, "START_X", arch="exophormer", virt_nodes=V)
+    loss_c.backward()
+    m = GNN_Diffusion(steps=300, sampling="DDIM", inference_ratio=10, rotation=True, visual_pretrained=False,
+                      model_mean_type=ModelMeanType.START_X, architecture="exophormer", virt_nodes=V)
+    m.model.load_state_dict(sd, strict=False)
+    m = m.to(dev).train()
+    loss = m.p_losses(x.to(dev), t.to(dev), noise=noise.to(dev), loss_type="huber", cond=None, edge_index=ei.to(dev), batch=batch.to(dev),
+                      patch_feats=feats.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_c)) < 1e-4 * abs(float(loss_c)) + 1e-7
+    params = dict(m.model.named_parameters())
+    worst = 0.0
+    for k, v in sdc.items():
+        if v.grad is None or k not in params or params[k].grad is None:
+            continue
+        gmax = float(v.grad.abs().max())
+        if gmax < 1e-9:
+            continue
+        worst = max(worst, rel(params[k].grad, v.grad))
+    assert 0 < worst < 2e-4, worst

@@ -71,8 +71,10 @@ def main():
         out[f"grad_abs_sum_overlap_{int(overlap)}"] = float(res["grad"][overlap].double().abs().sum())
         out["bucket_split"] = [int(te.early_off), int(te.total)]
     if mode != "nodist":
-        out["overlap_equals_serial_grad"] = bool(torch.equal(res["grad"][True], res["grad"][False]))
-        out["overlap_equals_serial_params"] = bool(torch.equal(res["flat"][True], res["flat"][False]))
+        # (not bit-equal: k_time_scatter adds the time_emb rows' gradients with atomics, in whatever order the chunks arrive)
+        reldiff = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
+        out["overlap_vs_serial_grad"] = reldiff(res["grad"][True], res["grad"][False])
+        out["overlap_vs_serial_params"] = reldiff(res["flat"][True], res["flat"][False])
         # the RCCL branch of the plain helper on a scratch tensor
         v = torch.arange(1024, dtype=torch.float32, device=dev)
         S.allreduce_gradients(v, average=True)

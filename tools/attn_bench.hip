@@ -129,6 +129,21 @@ int main(int argc, char **argv) {
         printf("probe (wave 0, %d workgroups, 100 MHz ticks): total %.0f  sync %.0f  region1 %.0f  region2+pv1 %.0f\n", cnt, tot[0] / cnt, tot[1] / cnt, tot[2] / cnt, tot[3] / cnt);
         unsetenv("DA_DUAL_PROF_PTR");
     }
+    if (getenv("PROBE2")) {         // DA_OPT_PROBE build of the library (da_attn_opt.hip): cycle breakdown of wave 0 of every workgroup
+        const int nwg = 8 * G * 8;
+        unsigned long long *dprof; CK(hipMalloc(&dprof, nwg * 8 * 8)); CK(hipMemset(dprof, 0, nwg * 8 * 8));
+        char buf[64]; snprintf(buf, sizeof buf, "%llu", (unsigned long long)dprof); setenv("DA_OPT_PROF_PTR", buf, 1);
+        for (int i = 0; i < 4; ++i) run();
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hp(nwg * 8); CK(hipMemcpy(hp.data(), dprof, nwg * 8 * 8, hipMemcpyDeviceToHost));
+        double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int cnt = 0;
+        for (int w = 0; w < nwg; ++w) if (hp[8 * w + 7] && hp[8 * w + 6] > 8) { for (int k = 0; k < 8; ++k) tot[k] += hp[8 * w + k]; ++cnt; }
+        printf("probe2 (wave 0 of %d full workgroups, cycles): kernel %.0f | tile wait+barrier %.0f | DMA issue %.0f | K-fragment reads %.0f | QK+softmax+PV %.0f | epilogue %.0f | blocks %.1f\n",
+               cnt, tot[0] / cnt, tot[1] / cnt, tot[2] / cnt, tot[3] / cnt, tot[4] / cnt, tot[5] / cnt, tot[6] / cnt);
+        printf("   per block: wait %.0f  dma %.0f  kread %.0f  math %.0f   (prologue+rest %.0f)\n", tot[1] / tot[6], tot[2] / tot[6], tot[3] / tot[6], tot[4] / tot[6],
+               (tot[0] - tot[1] - tot[2] - tot[3] - tot[4] - tot[5]) / cnt);
+        unsetenv("DA_OPT_PROF_PTR");
+    }
     for (int i = 0; i < 5; ++i) run();
     CK(hipStreamSynchronize(st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
