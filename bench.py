@@ -1006,9 +1006,9 @@ def ragged_bench(args, world, rank, dev):
         T, ratio = 300, 10
     else:
         G = args.puzzles or 512
-        sides = [12] * G
+        sides = [args.side] * G
         T, ratio = 100, 1
-    pct = 60
+    pct = args.pct
     cfg = dict(name="", variant="2d", arch="exophormer", V=8, n=None, graph="ragged_regular", rotation=True, T=T, ratio=ratio,
                mean="START_X", G=G, prec=prec, N_total=sum(v * v for v in sides), pairs_total=sum(v ** 4 for v in sides))
     model = build_module(cfg, dev, prec)
@@ -1133,10 +1133,9 @@ def ragged_bench(args, world, rank, dev):
                    "sample": f"the first {nsub} puzzles of the Batch ({nn} pieces), {kc} DDIM steps per repeat, 1 warm-up + 3 repeats, median "
                              f"{reps[1]:.3f} s/step, oracle/ torch fp32, {threads} threads"}
         wl = ((f"the reference's scripted run (train_celeba_rot.sh:4-15): ragged Batch of {G} puzzles, sides {sides} ({N} pieces), exophormer V=8, "
-               f"Exphander degree 60 % (d per puzzle {degs}), DDIM T=300 / ratio 10, START_X, rot+trans c=4")
+               f"Exphander degree {pct} % (d per puzzle {degs}), DDIM T=300 / ratio 10, START_X, rot+trans c=4")
               if scripted else
-              (f"edge-list regime: {G} x 12x12 puzzles ({N} pieces), exophormer V=8, Exphander degree 60 % (d={degs[0]}), DDIM T=100, START_X; "
-               f"every graph below the 256-node hybrid threshold, so k_attn_csr is the product path"))
+              (f"small-puzzle regime: {G} x {args.side}x{args.side} puzzles ({N} pieces), exophormer V=8, Exphander degree {pct} % (d={degs[0]}), DDIM T=100, START_X"))
         print(json.dumps({
             "metric": f"denoising steps/sec ({'scripted ragged exophormer Batch' if scripted else 'edge-list (CSR) regime, 12x12 exophormer'})",
             "value": world * G * K / dt, "unit": "puzzle-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -1230,6 +1229,8 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle with ONE thread at full size")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train-side", action="store_true", help="--config scripted: skip the training step on the same Batch")
+    ap.add_argument("--side", type=int, default=12, help="--config csr: pieces per puzzle side")
+    ap.add_argument("--pct", type=int, default=60, help="--config scripted / csr: Exphander degree in percent of n - 1 (the script's --degree 60%%)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp32 (parity-mode) replay of the sampling configurations")
     args = ap.parse_args()
     args.degree_given = any(a == "--degree" or a.startswith("--degree=") for a in sys.argv[1:]) or "BENCH_DEGREE" in os.environ

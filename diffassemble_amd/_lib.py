@@ -142,6 +142,7 @@ PROTOTYPES = {
                                    _fp, _fp, C.c_int, _fp]),
     "da_debug_counters": (C.c_int, [C.POINTER(C.c_int64), C.c_int, C.c_int]),
     "da_train_workspace_bytes": (C.c_size_t, [C.POINTER(DaWeights), C.POINTER(DaGraph)]),
+    "da_train_workspace_bytes_ex": (C.c_size_t, [C.POINTER(DaWeights), C.POINTER(DaGraph), C.c_int]),
     "da_train_forward": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
     "da_train_forward_ex": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
     "da_train_backward_ex": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp,

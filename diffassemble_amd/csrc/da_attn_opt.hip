@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         return k;
     };
 
-    DA_OPB(unsigned long long pb_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long pb_start = __builtin_readcyclecounter(); unsigned long long pb_t = pb_start;)
+    DA_OPB(unsigned long long pb_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long pb_start = __builtin_readcyclecounter(), pb_wall0 = wall_clock64(); unsigned long long pb_t = pb_start;)
     f32x16 O;
     float ls = 0.f;               // this lane's share of the row sum (16 of the block's 32 keys)
     float ls2 = 0.f;              // VAR & 1: second chain of the row sum
@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                 // one block: finish block b out of Sc (softmax, PV) while the scores of block b + 1 are produced into Sn
                 auto step = [&](auto last_tag, f32x16 &Sc, f32x16 &Sn, int b) {
                     constexpr bool LAST = decltype(last_tag)::value;
+                    DA_OPB(pb_t = __builtin_readcyclecounter();)
                     if (!LAST && (b + 1) % CF::KB == 0) acquire((b + 1) / CF::KB);
+                    DA_OPB({ const unsigned long long t_ = __builtin_readcyclecounter(); pb_[1] += t_ - pb_t; pb_t = t_; })
                     if (!wave_on) return;
                     u32x4 kf[CF::NCH];
                     if (!LAST) load_k(b + 1, kf);
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                     O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
                     dots(pf1);
                     __builtin_amdgcn_sched_barrier(0);
+                    DA_OPB({ const unsigned long long t_ = __builtin_readcyclecounter(); pb_[4] += t_ - pb_t; pb_t = t_; pb_[6] += 1; })
                 };
                 f32x16 SA, SB;
                 acquire(0);
@@ -567,7 +570,8 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
 
     // ---- epilogue
     DA_OPB(const unsigned long long pb_ep = __builtin_readcyclecounter();)
-    DA_OPB(auto pb_out = [&]() { if (p.prof && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); unsigned long long *o_ = p.prof + 8 * (size_t)blockIdx.x;
+    DA_OPB(auto pb_out = [&]() { if (p.prof && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); unsigned long long *o_ = p.prof + 16 * (size_t)blockIdx.x;
+                                 o_[8] = pb_wall0; o_[9] = wall_clock64(); o_[10] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) /* XCC_ID */; o_[11] = __smid();
                                  o_[0] = t_ - pb_start; o_[1] = pb_[1]; o_[2] = pb_[2]; o_[3] = pb_[3]; o_[4] = pb_[4]; o_[5] = t_ - pb_ep; o_[6] = pb_[6]; o_[7] = 1; } };)
     const float lt = ls + __shfl_xor(ls, 32);
     const float inv = lt > 0.f ? 1.0f / (lt + ((gen && !MASKED) ? 1e-16f : 0.f)) : 0.f;      // (see the header: no epsilon on an un-shifted sum;

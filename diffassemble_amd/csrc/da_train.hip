@@ -755,7 +755,9 @@ bool attn_small_ok(const da_graph *g, int C, bool bfc);      // the one-workgrou
 int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P, float *stats,
                           const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc);
 int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
-                          const float *stats, float *Dd, float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc);
+                          const float *stats, float *Dd, float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc,
+                          const float *o, const float *res);
+bool hybrid_flash_ok(const da_graph *g, int C, bool bfc);     // the flash-style kernels (no pair matrix) take this hybrid layer
 
 static bool train_dense_disabled() {
     static int v = -1;
@@ -815,7 +817,10 @@ static int dims_of(const da_weights *w, const da_graph *g, Dims &d, int mma = DA
     // (graph_plan.expander_plan: bits in SLOT space, slot_node != NULL) would be read in the wrong order -- refuse it loudly
     DA_REQUIRE(!(d.hybrid && g->slot_node), "training: hybrid graph in the banded slot layout (slot_node set); train on a natural-layout plan (build_plan / expander_plan(..., banded=False))");
     DA_REQUIRE(d.dense || d.hybrid || g->row_ptr, "training: this graph walks the edge list but the CSR arrays are missing");
-    d.pair_floats = (d.dense || d.hybrid) ? dense_pair_floats(g, d.H) : 0;
+    // hybrid graphs in the bf16-operand mode run flash-style (da_train_dense.hip: k_hyb_*): no pair matrix is ever allocated
+    bool flash = d.hybrid && d.bfc;
+    for (int l = 0; l < d.L && flash; ++l) flash = hybrid_flash_ok(g, d.C[l], d.bfc);
+    d.pair_floats = (d.dense || (d.hybrid && !flash)) ? dense_pair_floats(g, d.H) : 0;
     static int q16_off = -1;
     if (q16_off < 0) {
         const char *e = getenv("DA_TRAIN_Q16"), *e2 = getenv("DA_TRAIN_TN_DB");
@@ -968,8 +973,12 @@ using namespace da;
 extern "C" {
 
 size_t da_train_workspace_bytes(const da_weights *w, const da_graph *g) {
+    return da_train_workspace_bytes_ex(w, g, DA_TRAIN_MMA_FP32);
+}
+
+size_t da_train_workspace_bytes_ex(const da_weights *w, const da_graph *g, int mma_precision) {
     Dims d;
-    if (dims_of(w, g, d)) return 0;
+    if (dims_of(w, g, d, mma_precision)) return 0;
     return carve_train(d, nullptr).total;
 }
 
@@ -1110,7 +1119,7 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
             if ((rc = dense_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.dY4, ws.poff, ws.node_graph, st, d.bfc, d.q16))) return rc;
         } else if (d.hybrid) {
             if ((rc = hybrid_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.stats[l], ws.Dd, ws.dY4, ws.poff,
-                                            ws.node_graph, st, d.bfc))) return rc;
+                                            ws.node_graph, st, d.bfc, ws.o[l], l == L - 1 ? ws.h0 : nullptr))) return rc;
         } else if ((rc = launch_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.stats[l], ws.Dd, ws.dY4, st))) return rc;
         const float *xin = l == 0 ? ws.h0 : (d.gelu_between ? ws.hact[l - 1] : ws.o[l - 1]);
         float *dx = (l & 1) ? ws.dxa : ws.dxb;

@@ -943,7 +943,7 @@ int dense_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, con
 //   mode 0: S (scaled scores) -> P in place (masked entries 0), stats[node, h] = (max, 1 / (sum + 1e-16)) over both parts
 //   mode 2: Dd[node, h] = sum_j P_ij dP_ij over the dense part (virtual rows: 0)
 //   mode 1: dS = P o (dP - Dd[node, h]) written over dP (Dd = the total over both parts by then)
-__global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int n_nodes, int n_real, int H, int C, const int32_t *__restrict__ gp,
+__global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int row0, int n_nodes, int n_real, int H, int C, const int32_t *__restrict__ gp,
                                                           const int32_t *__restrict__ pad_ptr, const int32_t *__restrict__ node_graph,
                                                           const long long *__restrict__ poff, const unsigned char *__restrict__ mask,
                                                           const long long *__restrict__ mask_ptr, const int32_t *__restrict__ irr_ptr,
@@ -953,8 +953,8 @@ __global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int n_nodes,
     const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
     const int HC = H * C;
     const float scale = 1.0f / sqrtf((float)C);
-    for (long long wv = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < (long long)n_nodes * H; wv += n_waves) {
-        const int node = (int)(wv / H), h = (int)(wv - (long long)node * H);
+    for (long long wv = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < (long long)(n_nodes - row0) * H; wv += n_waves) {      // rows [row0, n_nodes)
+        const int node = row0 + (int)(wv / H), h = (int)(wv - (long long)(node - row0) * H);
         const bool real = node < n_real;
         int n_g = 0, i = 0, ldp = 0;
         float *row = nullptr;
@@ -1134,7 +1134,8 @@ template <int EPL, bool HEAVY>
 __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_bwd_dst(int n_nodes, int n_real, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
                                                           int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ d_o,
                                                           const float *__restrict__ stats, float *__restrict__ dY4, float *__restrict__ Dd,
-                                                          float scale) {
+                                                          float scale, int dtotal) {
+    // dtotal: Dd already holds the row's TOTAL D (k_hyb_rowdot, the flash-style route): used as it is, not written back
     constexpr int IRR_NW = IrrNW<EPL>::v;
     __shared__ float red[HEAVY ? IRR_NW : 1][HEAVY ? 64 * (EPL + 1) : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1211,13 +1212,13 @@ __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_b
             a2[x] = t;
         }
     }
-    const float Dt = D + Dd[(size_t)i * H + head];
+    const float Dt = dtotal ? Dd[(size_t)i * H + head] : D + Dd[(size_t)i * H + head];
 #pragma unroll
     for (int x = 0; x < EPL; ++x) {
         dY4[(size_t)i * ld + off + x] = (a1[x] - Dt * a2[x]) * scale;
         dY4[(size_t)i * ld + 3 * (size_t)HC + off + x] = g[x];
     }
-    if ((lane & 7) == 0) Dd[(size_t)i * H + head] = Dt;          // (the head's eight lanes read it above, in lockstep)
+    if (!dtotal && (lane & 7) == 0) Dd[(size_t)i * H + head] = Dt;          // (the head's eight lanes read it above, in lockstep)
 }
 
 // source side over the remainder edges (CSR by source): dk_j, dv_j ADDED to what the dense GEMMs wrote
@@ -1314,6 +1315,423 @@ __global__ __launch_bounds__(256) void k_zero_kv_grad(int r0, int r1, int HC, fl
     }
 }
 
+
+// =====================================================================================================================
+// HYBRID graphs, bf16-operand mode, FLASH-STYLE (round 5).  The route above keeps the masked pair matrices of a (graph, head)
+// in HBM -- 422 MB per layer in fp32 at 16 puzzles of 900 pieces, crossed ~14 times per layer (S, P, dP, dS written and read by
+// five grouped GEMMs and three row passes): 15 of every 16 microseconds of the scripted training step (singularity/gianscarpe/
+// train_celeba_rot.sh:4-15; exophormer_gnn.py:161-215 under spatial_diffusion.py:432-483) moved pair matrices.  Here no [n, n]
+// tensor exists: the k_attn_small_* scheme (bf16 row-major LDS images, the wave's own 16-row band in registers as B fragments,
+// transposed tiles so that a lane holds four consecutive keys of ONE query, transposing LDS reads for the second product) tiled
+// over the other dimension in chunks of 128 rows, with the adjacency bits of the regular edges applied to the score tiles:
+//   k_hyb_fwd     query bands.  Pass 1: scores only -> (max, sum) of the masked dense row, then the row's remainder edges join
+//                 (fp32 dot products, as everywhere on the remainder side) -> the statistics (max, 1 / (sum + 1e-16)) of PyG's
+//                 softmax over BOTH parts, kept for the backward.  Pass 2: scores again, P = exp(s - max) inv (bf16 operand),
+//                 O = P V, + skip (+ residual).  The remainder edges' own contributions are added by k_attn_irr_fwd as before.
+//   k_hyb_rowdot  D_i = sum_c dO_ic attn_ic (attn = o - skip - residual): the softmax backward's row term over ALL edges of the
+//                 row -- dense and remainder -- without touching either edge set.
+//   k_hyb_bwd_q   query bands: S, dP = dO V^T, dS = P o (dP - D), dQ += scale dS K (on top of the remainder's dq).
+//   k_hyb_bwd_kv  key bands against query chunks (Q, dO images + the queries' statistics and adjacency bytes in LDS):
+//                 dV = P^T dO, dK = scale dS^T Q.
+// Products and roundings are those of the bf16-operand mode (operands bf16, P and dS rounded to bf16 as operands, fp32
+// accumulation, fp32 storage of everything that reaches HBM).  Virtual rows (no dense part) keep their kernels.
+constexpr int HF_WAVES = 8, HF_ROWS = 16 * HF_WAVES, HF_KC = 128, HF_TN = HF_KC / 16, HF_NT = 64 * HF_WAVES;
+struct HybFlash {
+    const float *qkvs;           // [n, 4 HC]  Q | K | V | skip
+    const float *res;            // forward / rowdot: residual [n, HC] or null
+    float *o;                    // forward: out; rowdot: in
+    const float *d_o;            // backward: [n, HC]
+    float *dY4;                  // backward: [n, 4 HC]  dq | dk | dv | d_o
+    float *stats;                // [n, H, 2]: forward writes the real rows', backward reads
+    float *Dd;                   // [n, H]: rowdot writes, backward reads
+    const int32_t *gp, *pad_ptr;
+    const unsigned char *mask;
+    const long long *mask_ptr;
+    const int32_t *irr_ptr, *irr_src;
+    int H, C, HC, nrt, n_nodes;  // nrt: 128-row tiles per graph (of the largest graph)
+    float scale;
+};
+#define AS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+// exp through the hardware's exp2 (one multiply + v_exp_f32; ~1e-6 relative): these kernels evaluate four exponentials per
+// (query, key) pair and step, libm's expf is ~10 instructions each
+__device__ __forceinline__ float hf_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+// rows [0, HF_KC) of a node matrix from element offset e0 (row stride ld; `valid` rows exist, C columns) as a row-major bf16 image
+// of pitch 16 CT + 8, zero beyond the valid part
+template <int CT>
+__device__ __forceinline__ void hf_stage(const float *X, size_t e0, int ld, int valid, int C, unsigned short *R, int tid) {
+    constexpr int kq = CT * 4, pr = CT * 16 + 8, NB = CT >= 4 ? 3 : 2;
+#pragma unroll 1
+    for (int i0 = tid; i0 < HF_KC * kq; i0 += HF_NT * NB) {
+        as_s16x4 v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = i0 + u * HF_NT, r = idx / kq, k = (idx - r * kq) * 4;
+            v[u] = (as_s16x4){0, 0, 0, 0};
+            if (idx < HF_KC * kq && r < valid && k < C) v[u] = as_ld_pack<false>(X, e0 + (size_t)r * ld + k);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = i0 + u * HF_NT, r = idx / kq, k = (idx - r * kq) * 4;
+            if (idx < HF_KC * kq) *(as_s16x4 *)(R + r * pr + k) = v[u];
+        }
+    }
+}
+// adjacency nibble of (this lane's query row, keys k0 + 16 tn + 4 lg ..+3) out of the row's 128 bits of the chunk
+__device__ __forceinline__ unsigned hf_nib(unsigned long long b0, unsigned long long b1, int tn, int lg) {
+    const unsigned long long w = tn < 4 ? b0 : b1;
+    return (unsigned)(w >> (((tn & 3) << 4) + 4 * lg)) & 15u;
+}
+
+template <int CT>
+__global__ __launch_bounds__(HF_NT) void k_hyb_fwd(HybFlash p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short hf_lds[];
+    constexpr int pr = CT * 16 + 8;
+    unsigned short *Ks = hf_lds, *Vs = Ks + HF_KC * pr;
+    const int rt = blockIdx.x % p.nrt, gh = blockIdx.x / p.nrt, h = gh % p.H, g = gh / p.H;
+    const int n0 = p.gp[g], n_g = p.gp[g + 1] - n0, r0 = rt * HF_ROWS;
+    if (r0 >= n_g) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int C = p.C, ld = 4 * p.HC;
+    const size_t e0 = (size_t)n0 * ld + h * C;
+    const int band0 = r0 + wid * 16, i = band0 + l15;
+    const bool band_on = band0 < n_g, row_on = i < n_g;
+    as_s16x4 qf[CT];
+    as_band<CT, false>(p.qkvs, e0, ld, n_g, C, band0, l15, lg, qf);
+    const unsigned char *mrow = p.mask + p.mask_ptr[g] + (size_t)min(i, n_g - 1) * (size_t)((p.pad_ptr[g + 1] - p.pad_ptr[g]) >> 3);
+    const int nkc = (n_g + HF_KC - 1) / HF_KC;
+    // ---- pass 1: statistics of the masked dense row
+    float m = -INFINITY, z = 0.f;
+    for (int kc = 0; kc < nkc; ++kc) {
+        const int k0 = kc * HF_KC;
+        __syncthreads();
+        hf_stage<CT>(p.qkvs, e0 + p.HC + (size_t)k0 * ld, ld, n_g - k0, C, Ks, tid);
+        const unsigned long long b0 = *(const unsigned long long *)(mrow + (k0 >> 3)), b1 = *(const unsigned long long *)(mrow + (k0 >> 3) + 8);
+        __syncthreads();
+        if (band_on) {
+#pragma unroll
+            for (int tn = 0; tn < HF_TN; ++tn) {
+                if (k0 + tn * 16 < n_g) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const unsigned short *kp = Ks + (tn * 16 + l15) * pr + 4 * lg;
+#pragma unroll
+                    for (int kt = 0; kt < CT; ++kt) acc = AS_MFMA(*(const as_s16x4 *)(kp + kt * 16), qf[kt], acc);
+                    const unsigned nib = hf_nib(b0, b1, tn, lg);
+                    float sv[4], mc = m;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = (k0 + tn * 16 + 4 * lg + r < n_g) && ((nib >> r) & 1u);
+                        sv[r] = ok ? p.scale * acc[r] : -INFINITY;
+                        mc = fmaxf(mc, sv[r]);
+                    }
+                    if (mc > -INFINITY) {
+                        float zc = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zc += sv[r] > -INFINITY ? hf_exp(sv[r] - mc) : 0.f;
+                        z = (m > -INFINITY ? z * hf_exp(m - mc) : 0.f) + zc;
+                        m = mc;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
+        const float mn = fmaxf(m, m2);
+        if (mn > -INFINITY) { z = (m > -INFINITY ? z * hf_exp(m - mn) : 0.f) + (m2 > -INFINITY ? z2 * hf_exp(m2 - mn) : 0.f); m = mn; }
+    }
+    // ... and the row's remainder edges (fp32 dot products; the four lanes of a query split the channels)
+    if (band_on && row_on) {
+        const int node = n0 + i, cq = C >> 2;
+        const float *qp = p.qkvs + (size_t)node * ld + (size_t)h * C + lg * cq;
+        for (int e = p.irr_ptr[node]; e < p.irr_ptr[node + 1]; ++e) {
+            const float *kp = p.qkvs + (size_t)p.irr_src[e] * ld + p.HC + (size_t)h * C + lg * cq;
+            float sc = 0.f;
+            for (int c = 0; c < cq; c += 4) {
+                const f32x4 qv = *(const f32x4 *)(qp + c), kv = *(const f32x4 *)(kp + c);
+                sc = fmaf(qv[0], kv[0], sc); sc = fmaf(qv[1], kv[1], sc); sc = fmaf(qv[2], kv[2], sc); sc = fmaf(qv[3], kv[3], sc);
+            }
+            sc += __shfl_xor(sc, 16);
+            sc += __shfl_xor(sc, 32);
+            sc *= p.scale;
+            const float mn = fmaxf(m, sc);
+            z = (m > -INFINITY ? z * hf_exp(m - mn) : 0.f) + hf_exp(sc - mn);
+            m = mn;
+        }
+    }
+    const float inv = (m > -INFINITY) ? 1.0f / (z + 1e-16f) : 0.f, mf = (m > -INFINITY) ? m : 0.f;
+    if (band_on && row_on && lg == 0) {
+        p.stats[((size_t)(n0 + i) * p.H + h) * 2] = mf;
+        p.stats[((size_t)(n0 + i) * p.H + h) * 2 + 1] = inv;
+    }
+    // ---- pass 2: O = P V over the regular edges
+    f32x4 oacc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < nkc; ++kc) {
+        const int k0 = kc * HF_KC;
+        __syncthreads();
+        hf_stage<CT>(p.qkvs, e0 + p.HC + (size_t)k0 * ld, ld, n_g - k0, C, Ks, tid);
+        hf_stage<CT>(p.qkvs, e0 + 2 * p.HC + (size_t)k0 * ld, ld, n_g - k0, C, Vs, tid);
+        const unsigned long long b0 = *(const unsigned long long *)(mrow + (k0 >> 3)), b1 = *(const unsigned long long *)(mrow + (k0 >> 3) + 8);
+        __syncthreads();
+        if (band_on) {
+#pragma unroll
+            for (int tn = 0; tn < HF_TN; ++tn) {
+                if (k0 + tn * 16 < n_g) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const unsigned short *kp = Ks + (tn * 16 + l15) * pr + 4 * lg;
+#pragma unroll
+                    for (int kt = 0; kt < CT; ++kt) acc = AS_MFMA(*(const as_s16x4 *)(kp + kt * 16), qf[kt], acc);
+                    const unsigned nib = hf_nib(b0, b1, tn, lg);
+                    float pv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = (k0 + tn * 16 + 4 * lg + r < n_g) && ((nib >> r) & 1u) && inv > 0.f;
+                        pv[r] = ok ? hf_exp(p.scale * acc[r] - mf) * inv : 0.f;
+                    }
+                    const as_s16x4 pa = as_pack(pv[0], pv[1], pv[2], pv[3]);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) oacc[ct] = AS_MFMA(as_tr(Vs, pr, tn * 16, ct * 16, l15, lg), pa, oacc[ct]);
+                }
+            }
+        }
+    }
+    if (band_on && row_on) {
+        const size_t es = e0 + 3 * p.HC + (size_t)i * ld;
+        f32x4 sk[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) sk[ct] = *(const f32x4 *)(p.qkvs + es + (ct * 16 + 4 * lg < C ? ct * 16 + 4 * lg : 0));
+        if (p.res) {
+            const float *rsp = p.res + (size_t)(n0 + i) * p.HC + h * C;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) sk[ct] += *(const f32x4 *)(rsp + (ct * 16 + 4 * lg < C ? ct * 16 + 4 * lg : 0));
+        }
+        float *ob = p.o + (size_t)(n0 + i) * p.HC + h * C + 4 * lg;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            if (ct * 16 + 4 * lg < C) *(f32x4 *)(ob + ct * 16) = oacc[ct] + sk[ct];
+    }
+}
+
+// D[node, h] = sum_c dO o attn,  attn = o - skip - residual  (every row, virtual ones included).  One wave per node, a lane owns
+// four consecutive channels (coalesced 16-byte loads): C = 32 -- the 8 heads are the wave's 8-lane groups, one pass; other widths --
+// one pass per head over its C / 4 lanes, whole-wave shuffle sum.
+__global__ __launch_bounds__(256) void k_hyb_rowdot(HybFlash p) {
+    const int lane = threadIdx.x & 63;
+    const size_t node = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (node >= (size_t)p.n_nodes) return;
+    const float *g = p.d_o + node * p.HC, *o = p.o + node * p.HC, *sk = p.qkvs + node * 4 * (size_t)p.HC + 3 * (size_t)p.HC;
+    const float *rs = p.res ? p.res + node * p.HC : nullptr;
+    auto part = [&](int c, bool on) {
+        float D = 0.f;
+        if (on) {
+            const f32x4 gv = *(const f32x4 *)(g + c), ov = *(const f32x4 *)(o + c), sv = *(const f32x4 *)(sk + c);
+            f32x4 a = ov - sv;
+            if (rs) a -= *(const f32x4 *)(rs + c);
+            D = gv[0] * a[0] + gv[1] * a[1] + gv[2] * a[2] + gv[3] * a[3];
+        }
+        return D;
+    };
+    if (p.C == 32 && p.H == 8) {
+        float D = part(4 * lane, true);
+        D += __shfl_xor(D, 1); D += __shfl_xor(D, 2); D += __shfl_xor(D, 4);
+        if ((lane & 7) == 0) p.Dd[node * 8 + (lane >> 3)] = D;
+        return;
+    }
+    for (int h = 0; h < p.H; ++h) {                              // C <= 256
+        float D = part(h * p.C + 4 * lane, 4 * lane < p.C);
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) D += __shfl_xor(D, of);
+        if (lane == 0) p.Dd[node * p.H + h] = D;
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(HF_NT) void k_hyb_bwd_q(HybFlash p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short hf_lds[];
+    constexpr int pr = CT * 16 + 8;
+    unsigned short *Ks = hf_lds, *Vs = Ks + HF_KC * pr;
+    const int rt = blockIdx.x % p.nrt, gh = blockIdx.x / p.nrt, h = gh % p.H, g = gh / p.H;
+    const int n0 = p.gp[g], n_g = p.gp[g + 1] - n0, r0 = rt * HF_ROWS;
+    if (r0 >= n_g) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int C = p.C, ld = 4 * p.HC;
+    const size_t e0 = (size_t)n0 * ld + h * C, g0 = (size_t)n0 * p.HC + h * C;
+    const int band0 = r0 + wid * 16, i = band0 + l15;
+    const bool band_on = band0 < n_g, row_on = i < n_g;
+    as_s16x4 qf[CT], gf[CT];
+    as_band<CT, false>(p.qkvs, e0, ld, n_g, C, band0, l15, lg, qf);
+    as_band<CT, false>(p.d_o, g0, p.HC, n_g, C, band0, l15, lg, gf);
+    const int ic = min(i, n_g - 1);
+    const unsigned char *mrow = p.mask + p.mask_ptr[g] + (size_t)ic * (size_t)((p.pad_ptr[g + 1] - p.pad_ptr[g]) >> 3);
+    const float mf = p.stats[((size_t)(n0 + ic) * p.H + h) * 2], inv = row_on ? p.stats[((size_t)(n0 + ic) * p.H + h) * 2 + 1] : 0.f;
+    const float D = p.Dd[(size_t)(n0 + ic) * p.H + h];
+    const int nkc = (n_g + HF_KC - 1) / HF_KC;
+    f32x4 qacc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) qacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < nkc; ++kc) {
+        const int k0 = kc * HF_KC;
+        __syncthreads();
+        hf_stage<CT>(p.qkvs, e0 + p.HC + (size_t)k0 * ld, ld, n_g - k0, C, Ks, tid);
+        hf_stage<CT>(p.qkvs, e0 + 2 * p.HC + (size_t)k0 * ld, ld, n_g - k0, C, Vs, tid);
+        const unsigned long long b0 = *(const unsigned long long *)(mrow + (k0 >> 3)), b1 = *(const unsigned long long *)(mrow + (k0 >> 3) + 8);
+        __syncthreads();
+        if (band_on) {
+#pragma unroll
+            for (int tn = 0; tn < HF_TN; ++tn) {
+                if (k0 + tn * 16 < n_g) {
+                    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+                    const unsigned short *kp = Ks + (tn * 16 + l15) * pr + 4 * lg, *vp = Vs + (tn * 16 + l15) * pr + 4 * lg;
+#pragma unroll
+                    for (int kt = 0; kt < CT; ++kt) {
+                        sa = AS_MFMA(*(const as_s16x4 *)(kp + kt * 16), qf[kt], sa);
+                        da = AS_MFMA(*(const as_s16x4 *)(vp + kt * 16), gf[kt], da);
+                    }
+                    const unsigned nib = hf_nib(b0, b1, tn, lg);
+                    float ds[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = (k0 + tn * 16 + 4 * lg + r < n_g) && ((nib >> r) & 1u) && inv > 0.f;
+                        const float pv = ok ? bf2f(f2bf(hf_exp(p.scale * sa[r] - mf) * inv)) : 0.f;
+                        ds[r] = pv * (da[r] - D);
+                    }
+                    const as_s16x4 dsa = as_pack(ds[0], ds[1], ds[2], ds[3]);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) qacc[ct] = AS_MFMA(as_tr(Ks, pr, tn * 16, ct * 16, l15, lg), dsa, qacc[ct]);
+                }
+            }
+        }
+    }
+    if (band_on && row_on) {                  // on top of the remainder edges' dq (k_attn_irr_bwd_dst wrote it)
+        float *dq = p.dY4 + e0 + (size_t)i * ld + 4 * lg;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            if (ct * 16 + 4 * lg < C) *(f32x4 *)(dq + ct * 16) += p.scale * qacc[ct];
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(HF_NT) void k_hyb_bwd_kv(HybFlash p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short hf_lds[];
+    constexpr int pr = CT * 16 + 8;
+    unsigned short *Qs = hf_lds, *Gs = Qs + HF_KC * pr;
+    float *st_m = (float *)(Gs + HF_KC * pr), *st_inv = st_m + HF_KC, *st_D = st_inv + HF_KC;
+    unsigned char *mt = (unsigned char *)(st_D + HF_KC);              // [HF_KC queries][16 bytes: the 128 keys of this workgroup]
+    const int rt = blockIdx.x % p.nrt, gh = blockIdx.x / p.nrt, h = gh % p.H, g = gh / p.H;
+    const int n0 = p.gp[g], n_g = p.gp[g + 1] - n0, r0 = rt * HF_ROWS;
+    if (r0 >= n_g) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int C = p.C, ld = 4 * p.HC;
+    const size_t e0 = (size_t)n0 * ld + h * C, g0 = (size_t)n0 * p.HC + h * C;
+    const int band0 = r0 + wid * 16, j = band0 + l15;                 // this lane's key
+    const bool band_on = band0 < n_g;
+    as_s16x4 kf[CT], vf[CT];
+    as_band<CT, false>(p.qkvs, e0 + p.HC, ld, n_g, C, band0, l15, lg, kf);
+    as_band<CT, false>(p.qkvs, e0 + 2 * p.HC, ld, n_g, C, band0, l15, lg, vf);
+    const size_t mstride = (size_t)((p.pad_ptr[g + 1] - p.pad_ptr[g]) >> 3);
+    const unsigned char *mbase = p.mask + p.mask_ptr[g] + (r0 >> 3);
+    const int nqc = (n_g + HF_KC - 1) / HF_KC;
+    f32x4 vacc[CT], kacc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { vacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; kacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int qc = 0; qc < nqc; ++qc) {
+        const int q0 = qc * HF_KC;
+        __syncthreads();
+        hf_stage<CT>(p.qkvs, e0 + (size_t)q0 * ld, ld, n_g - q0, C, Qs, tid);
+        hf_stage<CT>(p.d_o, g0 + (size_t)q0 * p.HC, p.HC, n_g - q0, C, Gs, tid);
+        if (tid < HF_KC) {
+            const int iq = min(q0 + tid, n_g - 1);
+            const bool on = q0 + tid < n_g;
+            st_m[tid] = p.stats[((size_t)(n0 + iq) * p.H + h) * 2];
+            st_inv[tid] = on ? p.stats[((size_t)(n0 + iq) * p.H + h) * 2 + 1] : 0.f;
+            st_D[tid] = p.Dd[(size_t)(n0 + iq) * p.H + h];
+            const unsigned long long *mr = (const unsigned long long *)(mbase + (size_t)iq * mstride);
+            ((unsigned long long *)mt)[2 * tid] = mr[0];
+            ((unsigned long long *)mt)[2 * tid + 1] = mr[1];
+        }
+        __syncthreads();
+        if (band_on) {
+#pragma unroll 2
+            for (int ti = 0; ti < HF_TN; ++ti) {
+                if (q0 + ti * 16 < n_g) {
+                    f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
+                    const unsigned short *qp = Qs + (ti * 16 + l15) * pr + 4 * lg, *gpp = Gs + (ti * 16 + l15) * pr + 4 * lg;
+#pragma unroll
+                    for (int kt = 0; kt < CT; ++kt) {
+                        s4 = AS_MFMA(*(const as_s16x4 *)(qp + kt * 16), kf[kt], s4);
+                        d4 = AS_MFMA(*(const as_s16x4 *)(gpp + kt * 16), vf[kt], d4);
+                    }
+                    const f32x4 m4 = *(const f32x4 *)(st_m + ti * 16 + 4 * lg), i4 = *(const f32x4 *)(st_inv + ti * 16 + 4 * lg),
+                                D4 = *(const f32x4 *)(st_D + ti * 16 + 4 * lg);
+                    float pv[4], dsv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned bit = (mt[(ti * 16 + 4 * lg + r) * 16 + ((wid * 16 + l15) >> 3)] >> (l15 & 7)) & 1u;
+                        const bool ok = bit && j < n_g && i4[r] > 0.f;        // (queries beyond n_g carry inv = 0)
+                        pv[r] = ok ? bf2f(f2bf(hf_exp(p.scale * s4[r] - m4[r]) * i4[r])) : 0.f;
+                        dsv[r] = pv[r] * (d4[r] - D4[r]);
+                    }
+                    const as_s16x4 pa = as_pack(pv[0], pv[1], pv[2], pv[3]), dsa = as_pack(dsv[0], dsv[1], dsv[2], dsv[3]);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        vacc[ct] = AS_MFMA(as_tr(Gs, pr, ti * 16, ct * 16, l15, lg), pa, vacc[ct]);
+                        kacc[ct] = AS_MFMA(as_tr(Qs, pr, ti * 16, ct * 16, l15, lg), dsa, kacc[ct]);
+                    }
+                }
+            }
+        }
+    }
+    if (band_on && j < n_g) {
+        float *er = p.dY4 + e0 + (size_t)j * ld + 4 * lg;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            if (ct * 16 + 4 * lg < C) {
+                *(f32x4 *)(er + p.HC + ct * 16) = p.scale * kacc[ct];
+                *(f32x4 *)(er + 2 * p.HC + ct * 16) = vacc[ct];
+            }
+    }
+}
+#undef AS_MFMA
+
+bool hybrid_flash_ok(const da_graph *g, int C, bool bfc) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("DA_HYB_FLASH"); off = (e && e[0] == '0') ? 1 : 0; }
+    return bfc && !off && (C == 32 || C == 144) && g->hybrid && !g->slot_node;
+}
+template <int CT>
+static int hyb_flash_launch(int which, const HybFlash &a, int G, hipStream_t st) {
+    constexpr int pr = CT * 16 + 8;
+    const int lds = 2 * HF_KC * pr * 2 + (which == 2 ? 3 * HF_KC * 4 + HF_KC * 16 : 0);
+    static bool attr[16] = {};
+    int dev = 0;
+    DA_CHECK_HIP(hipGetDevice(&dev));
+    if (!attr[dev & 15]) {
+        const int cap = 2 * HF_KC * pr * 2 + 3 * HF_KC * 4 + HF_KC * 16;
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_hyb_fwd<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_hyb_bwd_q<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_hyb_bwd_kv<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        attr[dev & 15] = true;
+    }
+    const int grid = G * a.H * a.nrt;
+    if (which == 0) k_hyb_fwd<CT><<<grid, HF_NT, lds, st>>>(a);
+    else if (which == 1) k_hyb_bwd_q<CT><<<grid, HF_NT, lds, st>>>(a);
+    else k_hyb_bwd_kv<CT><<<grid, HF_NT, lds, st>>>(a);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+static HybFlash hyb_flash_params(const da_graph *g, int H, int C, const float *qkvs) {
+    HybFlash a;
+    a.qkvs = qkvs; a.res = nullptr; a.o = nullptr; a.d_o = nullptr; a.dY4 = nullptr; a.stats = nullptr; a.Dd = nullptr;
+    a.gp = g->graph_ptr; a.pad_ptr = g->pad_ptr; a.mask = g->mask; a.mask_ptr = (const long long *)g->mask_ptr;
+    a.irr_ptr = g->irr_row_ptr; a.irr_src = g->irr_col_src;
+    a.H = H; a.C = C; a.HC = H * C; a.nrt = (g->max_graph_nodes + HF_ROWS - 1) / HF_ROWS; a.n_nodes = g->n_nodes;
+    a.scale = 1.0f / sqrtf((float)C);
+    return a;
+}
+
 #define DA_HYB_SWITCH(C, STMT4, STMT18)                                                     \
     switch ((C) / 8) {                                                                      \
         case 4: STMT4; break;                                                               \
@@ -1325,6 +1743,29 @@ __global__ __launch_bounds__(256) void k_zero_kv_grad(int r0, int r1, int HC, fl
 int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P, float *stats,
                           const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc) {
     const int n = g->n_nodes, nr = g->n_real, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
+    if (hybrid_flash_ok(g, C, bfc)) {
+        // flash-style route: no pair matrix (P is not touched and may be null)
+        int rc;
+        HybFlash a = hyb_flash_params(g, H, C, qkvs);
+        a.res = res; a.o = o; a.stats = stats;
+        if ((rc = C == 32 ? hyb_flash_launch<2>(0, a, G, st) : hyb_flash_launch<9>(0, a, G, st))) return rc;
+        if (n > nr) {
+            // virtual rows: statistics over their (remainder-only) edges, o = skip (+ residual)
+            k_pair_rows_hybrid<<<gridsz((size_t)(n - nr) * H * 64), 256, 0, st>>>(0, nr, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
+                                                                               (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs, nullptr,
+                                                                               nullptr, stats, nullptr);
+            k_init_out<<<gridsz((size_t)(n - nr) * HC), 256, 0, st>>>(n - nr, HC, qkvs + (size_t)nr * 4 * HC, res ? res + (size_t)nr * HC : nullptr, o + (size_t)nr * HC);
+            DA_LAUNCH_CHECK();
+        }
+        const float scale_f = 1.0f / sqrtf((float)C);
+        const int grid_f = (int)(((size_t)n * 64 + 255) / 256);
+        DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, false><<<grid_f, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f)),
+                      (k_attn_irr_fwd<18, false><<<grid_f, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f)))
+        if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f)),
+                      (k_attn_irr_fwd<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f)))
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
     GGemm s;
     s.bfc = bfc;
     s.A = {(float *)qkvs, 0, 4 * HC, C};
@@ -1334,7 +1775,7 @@ int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, co
     s.H = H; s.gp = g->graph_ptr; s.poff = poff;
     int rc;
     if ((rc = ggemm(s, G, H, mx, st))) return rc;
-    k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(0, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
+    k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(0, 0, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
                                                                     (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs, P,
                                                                     nullptr, stats, nullptr);
     k_init_out<<<gridsz((size_t)n * HC), 256, 0, st>>>(n, HC, qkvs, res, o);
@@ -1359,11 +1800,36 @@ int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, co
 
 // backward: dY4 = [dq | dk | dv | d_o]
 int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, const float *d_o, const float *P, float *dP,
-                          const float *stats, float *Dd, float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc) {
+                          const float *stats, float *Dd, float *dY4, const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc,
+                          const float *o, const float *res) {
     const int n = g->n_nodes, nr = g->n_real, HC = H * C, G = g->n_graphs, mx = g->max_graph_nodes;
     const float scale = 1.0f / sqrtf((float)C);
     const int grid = (int)(((size_t)n * 64 + 255) / 256);
     int rc;
+    if (hybrid_flash_ok(g, C, bfc)) {
+        // flash-style route (o = the layer's forward output, res = its residual operand: D = rowsum(dO o (o - skip - res)))
+        constexpr int DTOT = 1;
+        HybFlash a = hyb_flash_params(g, H, C, qkvs);
+        a.res = res; a.o = (float *)o; a.d_o = d_o; a.dY4 = dY4; a.stats = (float *)stats; a.Dd = Dd;
+        k_hyb_rowdot<<<(unsigned)(((size_t)n * 64 + 255) / 256), 256, 0, st>>>(a);
+        if (n > nr) k_zero_kv_grad<<<gridsz((size_t)(n - nr) * 2 * HC), 256, 0, st>>>(nr, n, HC, dY4);
+        DA_LAUNCH_CHECK();
+        // remainder, destination side: dq of the remainder edges (D is already the row's total), skip gradient of every row
+        DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)),
+                      (k_attn_irr_bwd_dst<18, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)))
+        if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)),
+                      (k_attn_irr_bwd_dst<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)))
+        DA_LAUNCH_CHECK();
+        if ((rc = C == 32 ? hyb_flash_launch<2>(1, a, G, st) : hyb_flash_launch<9>(1, a, G, st))) return rc;      // dQ += (regular edges)
+        if ((rc = C == 32 ? hyb_flash_launch<2>(2, a, G, st) : hyb_flash_launch<9>(2, a, G, st))) return rc;      // dK, dV (regular edges)
+        DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, false><<<grid, 256, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
+                      (k_attn_irr_bwd_src<18, false><<<grid, 256, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
+        if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
+                      (k_attn_irr_bwd_src<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
+    constexpr int DTOT = 0;
     GGemm q;
     q.bfc = bfc;
     q.H = H; q.gp = g->graph_ptr; q.poff = poff; q.accumulate = 0;
@@ -1376,16 +1842,16 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
     q.A = {(float *)d_o, 0, HC, C}; q.B = {(float *)qkvs + 2 * HC, 0, 4 * HC, C}; q.C = {dP, 1, 0, 0};
     q.transA = 0; q.transB = 1; q.dimM = 0; q.dimN = 0; q.dimK = C; q.alpha = 1.0f;
     if ((rc = ggemm(q, G, H, mx, st))) return rc;
-    k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(2, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
+    k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(2, 0, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
                                                                     (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs,
                                                                     (float *)P, dP, nullptr, Dd);
     // remainder, destination side: D total, dq of the remainder edges, skip gradient
-    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)),
-                  (k_attn_irr_bwd_dst<18, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)))
-    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)),
-                  (k_attn_irr_bwd_dst<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)),
+                  (k_attn_irr_bwd_dst<18, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)))
+    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)),
+                  (k_attn_irr_bwd_dst<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)))
     // dS = P o (dP - D) over the regular edges
-    k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(1, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
+    k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(1, 0, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
                                                                     (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs,
                                                                     (float *)P, dP, nullptr, Dd);
     DA_LAUNCH_CHECK();

@@ -182,9 +182,9 @@ class TrainEngine:
         need_csr = not (plan.dense or plan.hybrid) or os.environ.get("DA_TRAIN_DISABLE_DENSE") == "1"
         return plan.c_struct(need_csr)
 
-    def _workspace(self, plan: GraphPlan):
+    def _workspace(self, plan: GraphPlan, mma=None):
         g = self._cg(plan)
-        need = int(self.lib.da_train_workspace_bytes(C.byref(self.w), C.byref(g)))
+        need = int(self.lib.da_train_workspace_bytes_ex(C.byref(self.w), C.byref(g), self._mma() if mma is None else mma))     # (bf16 mode on hybrid graphs: no pair matrices)
         if need == 0:
             _lib.check(1)
         if self._ws is None or self._ws.numel() < need:
@@ -226,9 +226,9 @@ class TrainEngine:
         t = t.detach().to(self.device, torch.int64).contiguous()
         d_out = d_out.detach().to(self.device, torch.float32).contiguous()
         d_feats = torch.empty((plan.n_real, self.F), dtype=torch.float32, device=self.device) if want_dfeats else None
-        ws = self._workspace(plan)
-        g = self._cg(plan)
         mma = getattr(self, "_fwd_mma", self._mma())       # the mode of the forward it follows
+        ws = self._workspace(plan, mma)
+        g = self._cg(plan)
         overlap = self.overlap_exchange and exchange_active()
         staged = overlap or getattr(self, "force_staged", False)       # (force_staged: tests -- the two halves without a process group)
         with torch.cuda.device(self.device):

@@ -379,6 +379,10 @@ int da_debug_counters(int64_t *out /* host [n] */, int n, int reset);
  * backward on the same workspace.
  * ------------------------------------------------------------------------------------- */
 size_t da_train_workspace_bytes(const da_weights *w, const da_graph *g);
+/* ABI 18: the size for ONE mode (da_train_workspace_bytes = the exact-fp32 mode's, the larger one).  Hybrid graphs in the
+ * bf16-operand mode run flash-style and hold no [n, n] pair matrix: 16 puzzles of 900 pieces need 0.9 GB instead of 3.0 GB.
+ * Forward and backward of a step must be given a workspace of at least the size of THEIR mode.                              */
+size_t da_train_workspace_bytes_ex(const da_weights *w, const da_graph *g, int mma_precision);
 /* mma_precision of the _ex forms: how the matrix-core GEMMs of the step (every Linear forward / dX / dW and the grouped
  * attention GEMMs of complete and hybrid graphs) take their operands.  Storage is fp32 in both modes -- parameters,
  * activations, gradients, the flat buffers the optimizer and the gradient all-reduce see.

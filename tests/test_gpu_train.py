@@ -554,6 +554,60 @@ def test_hybrid_training_at_900_pieces_equals_the_edge_list_path(dev, monkeypatc
     assert rel(ga, go) < 2e-4, rel(ga, go)
 
 
+_FLASH_WORKER = r"""
+import os, sys, json, numpy as np, torch
+sys.path.insert(0, os.environ["DA_ROOT"]); sys.path.insert(0, os.path.join(os.environ["DA_ROOT"], "tests", "golden"))
+from oracle import weights as W
+from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+from diffassemble_amd import expander
+dev = torch.device("cuda:0")
+sides = json.loads(os.environ["FLASH_SIDES"]); V = 8
+rng = np.random.default_rng(4)
+ei, batch, degs = expander.ragged_regular_batch(sides, 60, rng, dev)
+n = int(batch.numel())
+sd = W.make_denoiser_state(100, 4, 4, arch="exophormer", virt_nodes=V, seed=67, qk_gain=3.0)
+g = torch.Generator().manual_seed(8)
+x = torch.randn(n, 4, generator=g).to(dev); feats = torch.randn(n, 1088, generator=g).to(dev); noise = torch.randn(n, 4, generator=g).to(dev)
+t = torch.randint(0, 100, (len(sides),), generator=g).to(dev)[batch]
+m = GNN_Diffusion(steps=100, sampling="DDIM", rotation=True, visual_pretrained=False, model_mean_type=ModelMeanType.EPSILON, architecture="exophormer", virt_nodes=V)
+m.model.load_state_dict(sd, strict=False)
+m = m.to(dev).train()
+te = m.model.train_engine(dev); te.precision = os.environ["FLASH_PREC"]
+loss = m.p_losses(x, t, noise=noise, loss_type="huber", cond=None, edge_index=ei, batch=batch, patch_feats=feats)
+loss.backward(); torch.cuda.synchronize()
+torch.save({"loss": float(loss), "grad": te.flat_grad.cpu(), "ws_bytes": int(te._ws.numel()) if te._ws is not None else 0}, os.environ["FLASH_OUT"])
+"""
+
+
+@pytest.mark.parametrize("sides", [[30], [16, 20, 6, 18]], ids=["one_900", "ragged"])
+def test_flash_style_hybrid_training_equals_the_pair_matrix_route(dev, tmp_path, sides):
+    """bf16-operand mode on hybrid (Exphander + exophormer) graphs: the flash-style kernels (k_hyb_fwd / _bwd_q / _bwd_kv, no
+    [n, n] tensor) against the route that keeps the masked pair matrices (DA_HYB_FLASH=0: same operand roundings, so the two
+    agree far inside the bf16-mode tolerance) and against the exact fp32 step (the 6e-2 / cosine bound of the bf16 mode)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("flash", dict(FLASH_PREC="bf16")), ("pairs", dict(FLASH_PREC="bf16", DA_HYB_FLASH="0")), ("fp32", dict(FLASH_PREC="fp32"))):
+        out = str(tmp_path / f"{tag}.pt")
+        e = dict(os.environ, DA_ROOT=ROOT, FLASH_SIDES=json.dumps(sides), FLASH_OUT=out, **env)
+        r = subprocess.run([sys.executable, "-c", _FLASH_WORKER], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[tag] = torch.load(out)
+    gf, gp, g32 = res["flash"]["grad"].double(), res["pairs"]["grad"].double(), res["fp32"]["grad"].double()
+    assert abs(res["flash"]["loss"] - res["pairs"]["loss"]) < 2e-3 * abs(res["pairs"]["loss"])
+    assert abs(res["flash"]["loss"] - res["fp32"]["loss"]) < 1e-2 * abs(res["fp32"]["loss"])
+    nrm = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))  # noqa: E731
+    assert nrm(gf, gp) < 1.5e-2, nrm(gf, gp)
+    assert nrm(gf, g32) < 6e-2 and cos(gf, g32) > 0.998, (nrm(gf, g32), cos(gf, g32))
+    assert nrm(gp, g32) < 6e-2
+    # no pair matrix in the flash route's workspace
+    assert res["flash"]["ws_bytes"] < res["pairs"]["ws_bytes"] or sides != [30]
+
+
 # ---------------------------------------------------------------------------- data parallelism through the module surface
 def _dp_train_worker(rank, world, port, ret):
     """One data-parallel rank (both ranks share cuda:0, so the group is gloo; on the 8-GPU node it is nccl = RCCL):

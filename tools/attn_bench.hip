@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "da_common.h"
@@ -131,17 +132,31 @@ int main(int argc, char **argv) {
     }
     if (getenv("PROBE2")) {         // DA_OPT_PROBE build of the library (da_attn_opt.hip): cycle breakdown of wave 0 of every workgroup
         const int nwg = 8 * G * 8;
-        unsigned long long *dprof; CK(hipMalloc(&dprof, nwg * 8 * 8)); CK(hipMemset(dprof, 0, nwg * 8 * 8));
+        unsigned long long *dprof; CK(hipMalloc(&dprof, nwg * 16 * 8)); CK(hipMemset(dprof, 0, nwg * 16 * 8));
         char buf[64]; snprintf(buf, sizeof buf, "%llu", (unsigned long long)dprof); setenv("DA_OPT_PROF_PTR", buf, 1);
         for (int i = 0; i < 4; ++i) run();
         CK(hipStreamSynchronize(st));
-        std::vector<unsigned long long> hp(nwg * 8); CK(hipMemcpy(hp.data(), dprof, nwg * 8 * 8, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> hp(nwg * 16); CK(hipMemcpy(hp.data(), dprof, nwg * 16 * 8, hipMemcpyDeviceToHost));
         double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int cnt = 0;
-        for (int w = 0; w < nwg; ++w) if (hp[8 * w + 7] && hp[8 * w + 6] > 8) { for (int k = 0; k < 8; ++k) tot[k] += hp[8 * w + k]; ++cnt; }
+        unsigned long long w0 = ~0ull, w1 = 0;
+        std::vector<double> dur, start, endt;
+        for (int w = 0; w < nwg; ++w) if (hp[16 * w + 7]) { w0 = std::min(w0, hp[16 * w + 8]); w1 = std::max(w1, hp[16 * w + 9]); }
+        for (int w = 0; w < nwg; ++w) if (hp[16 * w + 7] && hp[16 * w + 6] > 8) {
+            for (int k = 0; k < 8; ++k) tot[k] += hp[16 * w + k];
+            ++cnt;
+            dur.push_back((double)(hp[16 * w + 9] - hp[16 * w + 8]) * 0.01); start.push_back((double)(hp[16 * w + 8] - w0) * 0.01); endt.push_back((double)(hp[16 * w + 9] - w0) * 0.01);
+        }
         printf("probe2 (wave 0 of %d full workgroups, cycles): kernel %.0f | tile wait+barrier %.0f | DMA issue %.0f | K-fragment reads %.0f | QK+softmax+PV %.0f | epilogue %.0f | blocks %.1f\n",
                cnt, tot[0] / cnt, tot[1] / cnt, tot[2] / cnt, tot[3] / cnt, tot[4] / cnt, tot[5] / cnt, tot[6] / cnt);
         printf("   per block: wait %.0f  dma %.0f  kread %.0f  math %.0f   (prologue+rest %.0f)\n", tot[1] / tot[6], tot[2] / tot[6], tot[3] / tot[6], tot[4] / tot[6],
                (tot[0] - tot[1] - tot[2] - tot[3] - tot[4] - tot[5]) / cnt);
+        auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+        printf("   wall clock (us, s_memrealtime): first start -> last end %.2f | workgroup duration min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f | start p50 %.2f p90 %.2f max %.2f | end p10 %.2f p50 %.2f\n",
+               (double)(w1 - w0) * 0.01, pct(dur, 0), pct(dur, 0.1), pct(dur, 0.5), pct(dur, 0.9), pct(dur, 1), pct(start, 0.5), pct(start, 0.9), pct(start, 1), pct(endt, 0.1), pct(endt, 0.5));
+        // occupancy over time: workgroups in flight at 10 equally spaced instants
+        printf("   workgroups in flight at t = k/10 of the span:");
+        for (int k = 1; k < 10; ++k) { const double t = (double)(w1 - w0) * 0.01 * k / 10; int c = 0; for (size_t x = 0; x < start.size(); ++x) c += start[x] <= t && endt[x] > t; printf(" %d", c); }
+        printf("\n");
         unsetenv("DA_OPT_PROF_PTR");
     }
     for (int i = 0; i < 5; ++i) run();
