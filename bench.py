@@ -50,7 +50,7 @@ F_NODE = 6_432_128          # FLOP per piece per step (SURVEY 8d / BASELINE.md)
 F_EDGE = 7_680              # FLOP per edge per step, all 4 layers
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0                            # MI355X_MICROARCH.md (HBM3E spec; ~6300 achievable)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 CONFIGS = {
     "1": dict(name="6x6 translation-only (N=36, K36 without self loops, E=1260), DDIM T=50, EPSILON, c=2, transformer arch",
@@ -383,6 +383,23 @@ def train_bench(args, world, rank, dev):
     kp = min(K, 10)
     for _ in range(kp):
         step(True)
+    # the same step in the REFERENCE's arithmetic (exact fp32 products; the mode of the gradient fixtures), quoted beside a bf16-operand
+    # headline so that the line carries its like-for-like figure (VERDICT r04 weak 1a / ADVICE r04)
+    fp32_ref = None
+    if te.precision == "bf16" and not pixels:
+        te.precision = "fp32"
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(kp):
+            step()
+        torch.cuda.synchronize()
+        dt32 = S.max_over_ranks(time.perf_counter() - t1, dev)
+        te.precision = "bf16"
+        step()
+        fp32_ref = {"ms_per_step": dt32 / kp * 1e3, "value": world * G * kp / dt32, "unit": "puzzle-train-steps/s", "steps": kp,
+                    "note": "exact fp32 matrix-core products (TrainEngine.precision = 'fp32'): the reference's arithmetic, spatial_diffusion.py:432-483"}
     # the gradient exchange, exposed vs hidden: the same steps with the bucketed / overlapped exchange switched off (ONE
     # all-reduce of the whole flat buffer after backward) -- `gradient_allreduce` of the lines above is what the step still
     # waits for with the early bucket's all-reduce running under conv 0's backward (TrainEngine.backward)
@@ -463,6 +480,7 @@ def train_bench(args, world, rank, dev):
             "optimizer_steps_per_s": K / dt,
             "algorithmic_tflops": 3 * world * flop_fwd * K / dt / 1e12,
             "phases_ms": {"forward+backward": acc[0] / kp, "gradient_allreduce": acc[1] / kp, "optimizer": acc[2] / kp},
+            "fp32_reference_arithmetic": fp32_ref,
             "distributed": dist_info(world), "gradient_exchange": exch, "roofline": roof, "cpu_baseline": cpu,
         }))
     if world > 1:
@@ -990,9 +1008,10 @@ def ragged_bench(args, world, rank, dev):
     puzzles with sides drawn from {6, 8, .., 20}, exophormer architecture with 8 virtual nodes on Exphander graphs of degree 60 %,
     DDIM T = 300 / inference_ratio 10 (30 denoising steps per loop), START_X -- the sampling loop as the timed region, plus one
     training step (p_losses -> backward -> Adafactor) on the same Batch as a side figure.
-    --config csr: the regime in which the edge-list kernel k_attn_csr IS the product path (every puzzle below the 256-node
-    threshold of graph_plan._hybrid_worth_it): G x 12x12 exophormer puzzles of degree 60 % (G = 512 by default: the last layer's
-    K | V rows, 0.34 GB in bf16, exceed the 256 MB Infinity Cache -- SURVEY 8d), DDIM T = 100."""
+    --config csr: a regime in which the edge-list kernel k_attn_csr IS the product path (graph_plan._hybrid_worth_it: regular edges
+    below 1 % of the pairs): G x 30x30 exophormer puzzles on Exphander graphs of degree 0.5 % (d = 4; G = 64 by default: the last
+    layer's K | V rows, 0.27 GB in bf16, exceed the 256 MB Infinity Cache -- SURVEY 8d), DDIM T = 100.  --side / --pct / --puzzles
+    move it (DA_HYBRID=off | force pin the path for A/Bs)."""
     import numpy as np
     from diffassemble_amd import _lib, expander
     from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
@@ -1005,10 +1024,10 @@ def ragged_bench(args, world, rank, dev):
         sides = [int(v) for v in rng.choice(np.arange(6, 21, 2), size=G)]
         T, ratio = 300, 10
     else:
-        G = args.puzzles or 512
+        G = args.puzzles or 64
         sides = [args.side] * G
         T, ratio = 100, 1
-    pct = args.pct
+    pct = args.pct or (60 if scripted else 0.5)
     cfg = dict(name="", variant="2d", arch="exophormer", V=8, n=None, graph="ragged_regular", rotation=True, T=T, ratio=ratio,
                mean="START_X", G=G, prec=prec, N_total=sum(v * v for v in sides), pairs_total=sum(v ** 4 for v in sides))
     model = build_module(cfg, dev, prec)
@@ -1135,9 +1154,9 @@ def ragged_bench(args, world, rank, dev):
         wl = ((f"the reference's scripted run (train_celeba_rot.sh:4-15): ragged Batch of {G} puzzles, sides {sides} ({N} pieces), exophormer V=8, "
                f"Exphander degree {pct} % (d per puzzle {degs}), DDIM T=300 / ratio 10, START_X, rot+trans c=4")
               if scripted else
-              (f"small-puzzle regime: {G} x {args.side}x{args.side} puzzles ({N} pieces), exophormer V=8, Exphander degree {pct} % (d={degs[0]}), DDIM T=100, START_X"))
+              (f"sparse-graph regime: {G} x {args.side}x{args.side} puzzles ({N} pieces), exophormer V=8, Exphander degree {pct} % (d={degs[0]}), DDIM T=100, START_X"))
         print(json.dumps({
-            "metric": f"denoising steps/sec ({'scripted ragged exophormer Batch' if scripted else 'edge-list (CSR) regime, 12x12 exophormer'})",
+            "metric": f"denoising steps/sec ({'scripted ragged exophormer Batch' if scripted else f'sparse Exphander regime, {args.side}x{args.side} exophormer, degree {pct} %'})",
             "value": world * G * K / dt, "unit": "puzzle-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
             "value_is": f"median of {len(passes)} timed K-step passes",
@@ -1229,8 +1248,8 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle with ONE thread at full size")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train-side", action="store_true", help="--config scripted: skip the training step on the same Batch")
-    ap.add_argument("--side", type=int, default=12, help="--config csr: pieces per puzzle side")
-    ap.add_argument("--pct", type=int, default=60, help="--config scripted / csr: Exphander degree in percent of n - 1 (the script's --degree 60%%)")
+    ap.add_argument("--side", type=int, default=30, help="--config csr: pieces per puzzle side")
+    ap.add_argument("--pct", type=float, default=0, help="--config scripted / csr: Exphander degree in percent of n - 1 (default: the script's 60 %% for scripted, 0.5 %% for csr)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp32 (parity-mode) replay of the sampling configurations")
     args = ap.parse_args()
     args.degree_given = any(a == "--degree" or a.startswith("--degree=") for a in sys.argv[1:]) or "BENCH_DEGREE" in os.environ

@@ -678,7 +678,7 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
 }
 
 int da_denoiser_flags(const da_denoiser *d) {
-    return d ? (d->fused_mlp2 ? 1 : 0) | (d->lastfold ? 2 : 0) | (d->dense_only ? 4 : 0) : 0;
+    return d ? (d->fused_mlp2 ? 1 : 0) | (d->lastfold ? 2 : 0) | (d->dense_only ? 4 : 0) | (!mfma_disabled() ? 8 : 0) : 0;
 }
 
 void da_denoiser_destroy(da_denoiser *d) {

@@ -410,7 +410,9 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         if (MASKED && crow && attempt == 0) {
             // the wave's class row -> its private LDS slot (read back per tile as a broadcast ds_read; a per-tile GLOBAL load of
             // it put a compiler-managed vmcnt(0) in front of every tile and drained the DMA ring)
-            const unsigned char *grow = p.blk_class + p.blk_class_ptr[g] + (size_t)(qt * 4 + wid) * (size_t)p.blk_class_stride;
+            // (waves whose slab lies beyond the graph's last slab stage the last slab's row: the table has one row per 32 slots)
+            const int nsl_ = (p.pad_ptr[g + 1] - pad0) >> 5;
+            const unsigned char *grow = p.blk_class + p.blk_class_ptr[g] + (size_t)min(qt * 4 + wid, nsl_ - 1) * (size_t)p.blk_class_stride;
             if (lane < 32) ((unsigned *)crow)[lane] = (4 * lane < p.blk_class_stride) ? ((const unsigned *)grow)[lane] : 0u;
         }
         for (int j = 0; j < ntl; ++j) {

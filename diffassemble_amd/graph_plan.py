@@ -117,9 +117,10 @@ class GraphPlan:
             self.out_dst = dst[perm].to(torch.int32).contiguous()
         return self
 
-    def c_struct(self, need_csr=True):
+    def c_struct(self, need_csr=True, inference_hints=True):
         """``need_csr=False``: leave the CSR arrays out if they have not been built (only valid for complete
-        graphs on a denoiser that reports da_denoiser_flags bit 2, without alpha)."""
+        graphs on a denoiser that reports da_denoiser_flags bit 2, without alpha).  ``inference_hints=False`` (the training
+        path, which never reads them): do not build rm_meta / agg_* -- a torch.unique and host syncs per new Batch."""
         g = _lib.DaGraph()
         g.n_nodes, g.n_real, g.n_graphs, g.dense = self.n_nodes, self.n_real, self.n_graphs, self.dense
         g.n_edges = self.n_edges
@@ -142,10 +143,11 @@ class GraphPlan:
             g.irr_row_ptr, g.irr_col_src = self.irr_row_ptr.data_ptr(), self.irr_col_src.data_ptr()
             if self.slot_node is not None:
                 g.slot_node = self.slot_node.data_ptr()
-            if self.rm_meta is None:
+            if self.rm_meta is None and inference_hints:
                 self.rm_meta = _remainder_meta(self)
-            g.rm_meta = self.rm_meta.data_ptr()
-            if self.agg is None and self.n_nodes > self.n_real:
+            if self.rm_meta is not None:
+                g.rm_meta = self.rm_meta.data_ptr()
+            if self.agg is None and self.n_nodes > self.n_real and inference_hints:
                 self.agg = _aggregate_virtual_rows(self.irr_row_ptr, self.irr_col_src, self.n_real, self.n_nodes)
             if self.agg is not None:
                 g.agg_row_ptr, g.agg_col_src, g.agg_mult = (t.data_ptr() for t in self.agg)
@@ -319,9 +321,16 @@ def _irregular_csr(isrc, idst, n_nodes):
 
 def _hybrid_worth_it(n_max, n_reg, n_edges, pairs):
     """ONE predicate for both entry points (build_plan on an edge list, expander_plan in closed form): the masked matrix-core
-    attention pays when the graphs are big (>= 256 nodes), the regular edges (unique real -> real pairs inside a graph) are
-    at least half of all edges and at least 3 % of the (target, source) pairs."""
-    return n_max >= 256 and n_reg >= 0.5 * n_edges and n_reg >= 0.03 * pairs
+    attention pays when the regular edges (unique real -> real pairs inside a graph) are at least a quarter of all edges and at
+    least 1 % of the (target, source) pairs, on graphs of at least 32 nodes.  Round 5 re-measured both thresholds (they were 256
+    nodes and 3 %): on 256 exophormer puzzles of 6x6 / 8x8 / 12x12 pieces at Exphander degrees of 10 / 30 / 60 % the masked
+    kernels beat the edge-list kernels in EVERY cell -- 0.32 vs 0.41 - 0.53 ms per step at 36 pieces, 0.41 vs 0.62 - 1.04 at 64,
+    0.55 vs 1.5 - 3.6 at 144 -- and on 64 puzzles of 900 pieces at degree 2 % (d = 18) by 0.94 vs 4.49 ms: a (query, key) pair
+    costs the matrix cores ~18 ps at 900 pieces (~100 ps at 144), a gathered edge costs the edge-list kernel 2 - 3 ns, so the
+    crossover sits near 0.6 - 1 % density (DESIGN.md "Measured, round 5").  Every Batch the reference scripts (6x6 .. 20x20 and
+    30x30 at degree 60 %) is far above it.  The edge-list kernels keep what is sparser than that, multi-edged, tiny, or asked for
+    its attention weights -- and every remainder edge (virtual nodes, duplicates)."""
+    return n_max >= 32 and n_reg >= 0.25 * n_edges and n_reg >= 0.01 * pairs
 
 
 def _hybrid_split(real_ei, virt_ei, batch, counts, graph_ptr, padded, n_nodes, N, force):

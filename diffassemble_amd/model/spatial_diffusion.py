@@ -277,16 +277,13 @@ class GNN_Diffusion(LightningModule):
             self.model._feat_key = None
             cfg_w = float(self.classifier_free_w) if self.classifier_free_prob > 0.0 and self.sampling == "DDIM" else None
             traj = None
-            try:
+            # the captured loop's unconditional pass rides on the hoisted mlp.0 share (zero features = the bias), which exists on
+            # the MFMA path only (da_denoiser_flags bit 3): without it (DA_DISABLE_MFMA=1) guidance takes the per-step path below,
+            # which runs the second pass through forward_with_feats on zero features
+            if cfg_w is None or (int(eng.flags) & 8):
                 traj, _ = eng.sample_loop(plan, self._schedule(), img, patch_feats, ratio=self.inference_ratio,
                                           mean_type=self._mean_type(), keep_trajectory=True,
                                           use_graph=self.use_hip_graph, sampler=self.sampling, eta=float(self.eta), cfg_w=cfg_w)
-            except _lib.DaError as e:
-                # the captured loop's unconditional pass rides on the hoisted mlp.0 share (zero features = the bias), which
-                # exists on the MFMA path only; with DA_DISABLE_MFMA=1 (or a shape those kernels reject) guidance takes the
-                # per-step path below, which runs the second pass through forward_with_feats on zero features
-                if cfg_w is None or "unconditional pass" not in str(e):
-                    raise
             if traj is not None:
                 self.model._release_dense_plan_key()          # do not pin this Batch's edge list until the next one is planned
                 return list(traj.clone().unbind(0)), [None] * len(its)

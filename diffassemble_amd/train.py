@@ -180,7 +180,7 @@ class TrainEngine:
         kernels); hybrid plans carry the by-source orientation of their REMAINDER edges in out_ptr / out_dst."""
         import os
         need_csr = not (plan.dense or plan.hybrid) or os.environ.get("DA_TRAIN_DISABLE_DENSE") == "1"
-        return plan.c_struct(need_csr)
+        return plan.c_struct(need_csr, inference_hints=False)
 
     def _workspace(self, plan: GraphPlan, mma=None):
         g = self._cg(plan)

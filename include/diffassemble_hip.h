@@ -163,7 +163,9 @@ void da_denoiser_destroy(da_denoiser *d);
  * conv-0 projection and final_mlp.0; bit 1 = last conv's value / skip projections composed with final_mlp.0
  * (32-wide value heads in the last attention).  For reporting executed vs algorithmic FLOPs.
  * bit 2 = every layer has a block-diagonal MFMA attention kernel: for complete graphs (da_graph.dense != 0)
- * row_ptr / col_src / edge_id may be NULL unless alpha is requested (the host can skip sorting the edge list). */
+ * row_ptr / col_src / edge_id may be NULL unless alpha is requested (the host can skip sorting the edge list).
+ * bit 3 = the per-step mlp.0 runs on its hoisted form (feature columns multiplied once per Batch), which the UNCONDITIONAL pass
+ * of classifier-free guidance inside the captured loops needs (da_loop_opts.cfg); clear (DA_DISABLE_MFMA=1): run guidance per step. */
 int da_denoiser_flags(const da_denoiser *d);
 
 /* Bytes of caller-provided workspace needed for a graph of this size.                      */

@@ -250,7 +250,7 @@ def test_bf16_full_loop_drift_config4_3d(dev):
 FEAT_NOISE = 0.1          # std of the non-pose feature columns (probe: tests/tools/train_solver_probe.py)
 
 
-def _train_solver(dev, sizes_train, steps=400, seed=0, lr=2e-3, G=8):
+def _train_solver(dev, sizes_train, steps=400, seed=0, lr=2e-3, G=8, train_precision=None, history=None):
     """Train the 2D denoiser with the HIP training path (da_train_forward/backward, START_X objective, Huber, as
     training_step does) on synthetic puzzles whose piece features carry the piece's true pose: a few hundred
     steps make it a solver, so that the sampling loop's end metric means something."""
@@ -259,6 +259,8 @@ def _train_solver(dev, sizes_train, steps=400, seed=0, lr=2e-3, G=8):
     m = GNN_Diffusion(steps=100, sampling="DDIM", inference_ratio=1, noise_weight=1.0, rotation=True,
                       model_mean_type=ModelMeanType.START_X, visual_pretrained=False, architecture="transformer")
     m = m.to(dev).train()
+    if train_precision is not None:
+        m.model.train_engine(dev).precision = train_precision       # "fp32" (exact products) | "bf16" (bf16 MFMA operands)
     opt = torch.optim.Adam([p for p in m.model.parameters()], lr=lr)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps)
     gen = torch.Generator(device=dev).manual_seed(seed)     # training batches are drawn ON the device (the host generator
@@ -275,6 +277,8 @@ def _train_solver(dev, sizes_train, steps=400, seed=0, lr=2e-3, G=8):
         loss.backward()
         opt.step()
         sched.step()
+        if history is not None:
+            history.append(loss.detach())
     return m.eval(), float(loss.detach())
 
 
@@ -340,6 +344,50 @@ def test_end_metric_bf16_equals_fp32_on_a_trained_solver(dev):
         assert torch.equal(res["fp32"][1], res["bf16"][1]), "bf16 changed a piece's assigned cell"
         assert torch.equal(res["fp32"][2], res["bf16"][2]), "bf16 changed a rotation decision"
         assert drift < 0.25 / (side - 1)                     # a quarter of the half-cell margin
+
+
+def test_training_curve_bf16_operand_mode_tracks_fp32(dev):
+    """The bf16-operand TRAINING mode (the benched default of `bench.py --config 5`) against the reference's fp32 arithmetic over
+    a whole run, not one step: two solvers trained from the same seed on the same 1000 Batches -- exact fp32
+    products vs bf16 matrix-core operands -- must reach the same loss level (mean of the last 50 steps within 5 %; single-Batch
+    losses are noisier than that) and the same end metric (piece accuracy of a T = 100 sampling run on fresh 12x12 puzzles, both
+    above 0.9 and within 0.02 of each other)."""
+    import math
+    from diffassemble_amd.engine import greedy_assign
+    res = {}
+    for prec in ("fp32", "bf16"):
+        hist = []
+        m, _ = _train_solver(dev, [6, 12, 12, 16], steps=1000, train_precision=prec, history=hist)
+        losses = torch.stack(hist).float().cpu()
+        gen = torch.Generator().manual_seed(99)
+        side, G = 12, 4
+        n = side * side
+        x_gt, feats, ei, batch = _puzzle_batch(side, G, gen, FEAT_NOISE)
+        y = torch.linspace(-1, 1, side)
+        grid = torch.stack(torch.meshgrid(y, y, indexing="xy"), -1).reshape(-1, 2).repeat(G, 1).to(dev)
+        ptr = torch.arange(0, (G + 1) * n, n, dtype=torch.int32, device=dev)
+        x_init = torch.randn(x_gt.shape, generator=gen)
+        m.model.precision = "fp32"
+        _orig = torch.randn
+        torch.randn = lambda *a, **k: x_init.to(dev)
+        try:
+            imgs, _ = m.p_sample_loop(tuple(x_gt.shape), None, ei.to(dev), batch.to(dev), patch_feats=feats.to(dev))
+        finally:
+            torch.randn = _orig
+        img = imgs[-1]
+
+        def cells_of(pos):
+            ass = greedy_assign(pos[:, :2].contiguous(), grid, ptr, ptr)
+            c = torch.empty(G * n, dtype=torch.int64, device=dev)
+            c[ass[:, 0] + torch.arange(G, device=dev).repeat_interleave(n) * n] = ass[:, 1]
+            return c
+        rot_ok = torch.cosine_similarity(img[:, 2:], x_gt[:, 2:].to(dev)) > math.cos(math.pi / 4)
+        acc = float(((cells_of(img) == cells_of(x_gt.to(dev))) & rot_ok).float().mean())
+        res[prec] = (float(losses[-50:].mean()), float(losses[:50].mean()), acc)
+        print(f"training curve {prec}: mean loss first 50 steps {res[prec][1]:.4e}, last 50 {res[prec][0]:.4e}, piece accuracy {acc:.4f}")
+    assert res["fp32"][0] < 0.2 * res["fp32"][1], "the run did not train"
+    assert abs(res["bf16"][0] - res["fp32"][0]) < 0.05 * res["fp32"][0], res
+    assert res["fp32"][2] > 0.9 and res["bf16"][2] > 0.9 and abs(res["fp32"][2] - res["bf16"][2]) <= 0.02, res
 
 
 # ---------------------------------------------------------------------------- caches must not go stale

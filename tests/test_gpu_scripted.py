@@ -1,9 +1,9 @@
 """The reference's SCRIPTED workload (singularity/gianscarpe/train_celeba_rot.sh:4-15: ragged Batches of 8 puzzles, sides
 6 .. 20, exophormer with 8 virtual nodes, Exphander degree 60 %, T = 300 / inference_ratio 10) -- what `bench.py --config scripted`
 times -- against the CPU oracle: forward (fp32 at the 1e-4 bound, bf16 at the bf16 bound), the first DDIM steps of the loop, and one
-training step's loss and gradients.  Two Batches: a mixed one (some puzzle >= 256 pieces: the plan goes hybrid, adjacency-masked
-matrix-core attention over every graph + CSR remainder) and a small one (all puzzles < 256 pieces: the edge-list kernel
-k_attn_csr is the product path -- the `bench.py --config csr` regime)."""
+training step's loss and gradients.  Three Batches: a mixed one and one of small puzzles only at the scripted degree (both hybrid since round 5: adjacency-masked
+matrix-core attention over every graph + CSR remainder -- graph_plan._hybrid_worth_it), and a sparse one (degree 0.5 %: the
+edge-list kernel k_attn_csr is the product path -- the `bench.py --config csr` regime)."""
 import numpy as np
 import pytest
 import torch
@@ -28,10 +28,10 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _batch(sides, seed):
+def _batch(sides, seed, pct=60):
     from diffassemble_amd import expander
     rng = np.random.default_rng(seed)
-    ei, batch, degs = expander.ragged_regular_batch(sides, 60, rng)
+    ei, batch, degs = expander.ragged_regular_batch(sides, pct, rng)
     n = int(batch.numel())
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, 4, generator=g)
@@ -40,7 +40,8 @@ def _batch(sides, seed):
     return ei, batch, degs, x, feats, t
 
 
-CASES = {"mixed_hybrid": ([6, 16, 10, 20, 8, 18, 12, 14], True), "small_csr": ([6, 8, 10, 12, 14, 12, 10, 6], False)}
+CASES = {"mixed_hybrid": ([6, 16, 10, 20, 8, 18, 12, 14], True, 60), "small_hybrid": ([6, 8, 10, 12, 14, 12, 10, 6], True, 60),
+         "sparse_csr": ([16, 20, 18], False, 0.5)}
 
 
 def test_percent_degree_matches_the_dataset_rule():
@@ -55,8 +56,8 @@ def test_percent_degree_matches_the_dataset_rule():
 @pytest.mark.parametrize("name", list(CASES))
 def test_scripted_batch_forward_and_loop_vs_oracle(dev, name, prec):
     from diffassemble_amd import DenoiserEngine, Schedule, _lib
-    sides, hybrid = CASES[name]
-    ei, batch, degs, x, feats, t = _batch(sides, 5)
+    sides, hybrid, pct = CASES[name]
+    ei, batch, degs, x, feats, t = _batch(sides, 5, pct)
     V = 8
     sd = W.make_denoiser_state(300, 4, 4, arch="exophormer", virt_nodes=V, seed=71, qk_gain=3.0)
     ref, _ = OD.eff_gat_forward_with_feats(sd, x, t, ei, feats, batch, arch="exophormer", virt_nodes=V)
@@ -81,8 +82,8 @@ def test_scripted_batch_forward_and_loop_vs_oracle(dev, name, prec):
 def test_scripted_batch_training_step_vs_oracle_autograd(dev, name):
     """p_losses on the ragged Batch: loss and every live parameter's gradient against the oracle's autograd (fp32 mode)."""
     from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
-    sides, hybrid = CASES[name]
-    ei, batch, degs, x, feats, t = _batch(sides, 9)
+    sides, hybrid, pct = CASES[name]
+    ei, batch, degs, x, feats, t = _batch(sides, 9, pct)
     V = 8
     sd = W.make_denoiser_state(300, 4, 4, arch="exophormer", virt_nodes=V, seed=73, qk_gain=3.0)
     noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(3))

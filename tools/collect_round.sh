@@ -3,7 +3,7 @@
 # configuration-3 variants, SQ counters of the attention and projection kernels, and one bench line per configuration / mode.
 # Outputs go to gpurun_out/<round>_*; copy them to profiles/<round>/ afterwards.    usage: ROUND=r03 bash tools/collect_round.sh
 set -u
-export ROUND=${ROUND:-r04}
+export ROUND=${ROUND:-r05}
 O=gpurun_out
 bash tools/collect_profiles.sh headline --config 3p
 bash tools/collect_profiles.sh headline_half --config 3p --puzzles 32     # the launch shape of each branch of the default two-branch loop
@@ -12,7 +12,15 @@ bash tools/collect_profiles.sh config3_d539 --config 3
 bash tools/collect_profiles.sh config3_d90 --config 3 --degree 90
 DA_HYBRID=off bash tools/collect_profiles.sh config3_d539_csr_only --config 3 --steps 4
 DA_HYBRID=off bash tools/collect_profiles.sh config3_d90_csr_only --config 3 --degree 90 --steps 4
+bash tools/collect_profiles.sh scripted --config scripted --no-train-side
+bash tools/collect_profiles.sh csr --config csr
 bash tools/collect_attn_pmc.sh > /dev/null 2>&1
+# FETCH_SIZE calibration for the edge-list kernels' row gathers (known byte counts; tools/gather_probe.hip)
+for M in 0 1; do
+  W=/tmp/pmc_gather_$M; rm -rf $W; mkdir -p $W
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $W -o p -- $GRAFT_REPO_ROOT/tools/bin/gather_probe $M 1024 256 > $W/log 2>&1 )
+  { tail -1 $W/log; python profiles/rocpd_pmc.py $(find $W -name "*results.db" | head -1) k_gather; } >> $O/${ROUND}_pmc_gather_calibration.txt 2>&1
+done
 # the counter tables feed the bench lines' `traffic` / `mfma_busy_counter` fields: summarise them BEFORE the lines are produced
 mkdir -p profiles/$ROUND
 cp $O/${ROUND}_pmc_*.txt $O/${ROUND}_rocprof_*.txt profiles/$ROUND/ 2>/dev/null
@@ -25,6 +33,8 @@ b config_2 --config 2
 b config_3 --config 3
 b config_3_d90 --config 3 --degree 90
 b config_4 --config 4
+b scripted --config scripted
+b csr --config csr
 # training lines: the benched default is the bf16-operand mode (--precision fp32 = the reference's arithmetic)
 b config_5 --config 5
 b config_5_fp32 --config 5 --precision fp32

@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 CLASS = [  # (regex on the kernel name, class)
     (r"k_attn_optt<32", "attn_hidden"), (r"k_attn_optt<144", "attn_last"), (r"k_attn_opt\(", "attn_hidden"),
     (r"k_attn_dual<144", "attn_last"), (r"k_attn_dual<32", "attn_hidden"),
@@ -22,7 +22,8 @@ CLASS = [  # (regex on the kernel name, class)
 ]
 # tag -> (bench config key, puzzles per GPU, launches of the class per denoising step)
 RUNS = {"headline": ("3p", 64, None), "headline_half": ("3p", 32, None), "config3_d539": ("3_d539", 32, False), "config3_d90": ("3_d90", 32, False),
-        "config3_d539_csr_only": ("3_d539_csr", 32, True), "config3_d90_csr_only": ("3_d90_csr", 32, True)}
+        "config3_d539_csr_only": ("3_d539_csr", 32, True), "config3_d90_csr_only": ("3_d90_csr", 32, True),
+        "scripted": ("scripted", 8, None), "csr": ("csr", 64, None)}
 
 
 def parse(path, want_csr):
