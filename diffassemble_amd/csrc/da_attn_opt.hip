@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     static_assert(CF::NCB == 1, "one 32-channel value block");
     constexpr int MAXI = (KG::NI + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DA_OPB(const unsigned long long pb_start = __builtin_readcyclecounter(), pb_wall0 = wall_clock64();)
     constexpr int MSTAGE = KG::STAGE + (MASKED ? 1024 : 0);     // MASKED: + the four waves' adjacency-word slots (256 B each)
     int *flags = (int *)(smem + NST * MSTAGE);                  // one word per wave: "my optimistic pass failed"; [4 .. 11]: the waves' tile masks
     float *mlut = (float *)(smem + NST * MSTAGE + 64);          // MASKED: nibble -> four accumulator initial values
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     const int qt = s_ % p.nqt, g = s_ / p.nqt;
     const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
     if (qt * QT >= n_g) return;
+    DA_OPB(const unsigned long long pb_p1 = __builtin_readcyclecounter();)
 
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
 #pragma unroll
         for (int ch = 0; ch < CF::NCH; ++ch) qf[ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
     }
+    DA_OPB(asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[CF::NCH - 1])); const unsigned long long pb_p2 = __builtin_readcyclecounter();)
     const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
     const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWBV;
     unsigned soff[MAXI];
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         return k;
     };
 
-    DA_OPB(unsigned long long pb_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long pb_start = __builtin_readcyclecounter(), pb_wall0 = wall_clock64(); unsigned long long pb_t = pb_start;)
+    DA_OPB(unsigned long long pb_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pb_t = __builtin_readcyclecounter(); const unsigned long long pb_p3 = pb_t;)
     f32x16 O;
     float ls = 0.f;               // this lane's share of the row sum (16 of the block's 32 keys)
     float ls2 = 0.f;              // VAR & 1: second chain of the row sum
@@ -535,7 +538,6 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                     O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O, 0, 0, 0);
                     O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
                 }
-                DA_OPB({ asm volatile("" : "+v"(O)); const unsigned long long t_ = __builtin_readcyclecounter(); pb_[4] += t_ - pb_t; pb_t = t_; pb_[6] += 1; })
                 if (!(VAR & 1)) {
                     // row sum of the bf16-rounded p (what the PV product weighs with): eight v_dot2_f32_bf16 against (1, 1)
                     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -547,6 +549,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                         ls = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, ls, false);
                     }
                 }
+                DA_OPB({ asm volatile("" : "+v"(O), "+v"(ls)); const unsigned long long t_ = __builtin_readcyclecounter(); pb_[4] += t_ - pb_t; pb_t = t_; pb_[6] += 1; })
             }
         }
         }           // (!PIPE || gen)
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     // ---- epilogue
     DA_OPB(const unsigned long long pb_ep = __builtin_readcyclecounter();)
     DA_OPB(auto pb_out = [&]() { if (p.prof && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); unsigned long long *o_ = p.prof + 16 * (size_t)blockIdx.x;
-                                 o_[8] = pb_wall0; o_[9] = wall_clock64(); o_[10] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) /* XCC_ID */; o_[11] = __smid();
+                                 o_[8] = pb_wall0; o_[9] = wall_clock64(); o_[12] = pb_p1 - pb_start; o_[13] = pb_p2 - pb_p1; o_[14] = pb_p3 - pb_p2; o_[10] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) /* XCC_ID */; o_[11] = __smid();
                                  o_[0] = t_ - pb_start; o_[1] = pb_[1]; o_[2] = pb_[2]; o_[3] = pb_[3]; o_[4] = pb_[4]; o_[5] = t_ - pb_ep; o_[6] = pb_[6]; o_[7] = 1; } };)
     const float lt = ls + __shfl_xor(ls, 32);
     const float inv = lt > 0.f ? 1.0f / (lt + ((gen && !MASKED) ? 1e-16f : 0.f)) : 0.f;      // (see the header: no epsilon on an un-shifted sum;

@@ -150,6 +150,8 @@ int main(int argc, char **argv) {
                cnt, tot[0] / cnt, tot[1] / cnt, tot[2] / cnt, tot[3] / cnt, tot[4] / cnt, tot[5] / cnt, tot[6] / cnt);
         printf("   per block: wait %.0f  dma %.0f  kread %.0f  math %.0f   (prologue+rest %.0f)\n", tot[1] / tot[6], tot[2] / tot[6], tot[3] / tot[6], tot[4] / tot[6],
                (tot[0] - tot[1] - tot[2] - tot[3] - tot[4] - tot[5]) / cnt);
+        { double p1 = 0, p2 = 0, p3 = 0; int c2 = 0; for (int w = 0; w < nwg; ++w) if (hp[16 * w + 7] && hp[16 * w + 6] > 8) { p1 += hp[16 * w + 12]; p2 += hp[16 * w + 13]; p3 += hp[16 * w + 14]; ++c2; }
+          printf("   before the loop: kernel entry -> graph table read %.0f | -> Q fragments landed %.0f | -> first tile requested %.0f cycles\n", p1 / c2, p2 / c2, p3 / c2); }
         auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
         printf("   wall clock (us, s_memrealtime): first start -> last end %.2f | workgroup duration min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f | start p50 %.2f p90 %.2f max %.2f | end p10 %.2f p50 %.2f\n",
                (double)(w1 - w0) * 0.01, pct(dur, 0), pct(dur, 0.1), pct(dur, 0.5), pct(dur, 0.9), pct(dur, 1), pct(start, 0.5), pct(start, 0.9), pct(start, 1), pct(endt, 0.1), pct(endt, 0.5));
