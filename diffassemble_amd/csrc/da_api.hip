@@ -460,6 +460,12 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
 
 }  // namespace da
 
+// one wave that waits `ticks` of the 100 MHz real-time counter (phase-offset experiment of the two-branch loop)
+__global__ void k_pair_delay(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 extern "C" {
 
 int da_abi_version(void) { return DA_ABI_VERSION; }
@@ -940,6 +946,11 @@ int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, 
         if (e == hipSuccess) e = hipStreamWaitEvent(ps, d->ev_pair_fork, 0);                 // ps joins the capture
         int rca = 0, rcb = 0;
         if (e == hipSuccess) {
+            // experiment switch (DA_PAIR_DELAY_US, default 0): branch B starts this many microseconds after branch A, so that the two
+            // branches run out of phase for the whole loop (one branch's attention beside the other's projections)
+            static int delay_us = -1;
+            if (delay_us < 0) { const char *ev = getenv("DA_PAIR_DELAY_US"); delay_us = ev ? atoi(ev) : 0; }
+            if (delay_us > 0) k_pair_delay<<<1, 64, 0, ps>>>((unsigned long long)delay_us * 100ull);
             rca = enqueue_loop(d, g_a, s, mean_type, inference_ratio, n_iters, x_init_a, traj_a, x_final_a, wa, cs, &oa, traj_stride, noise_stride);
             rcb = enqueue_loop(d, g_b, s, mean_type, inference_ratio, n_iters, x_init_b, traj_b, x_final_b, wb, ps, &ob, traj_stride, noise_stride);
             e = hipEventRecord(d->ev_pair_join, ps);

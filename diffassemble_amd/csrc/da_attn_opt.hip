@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     static_assert(!MASKED || BK == 64, "the adjacency words and class rows are laid out for 64-key tiles");
     static_assert((VAR & 3) != 3, "truncated P needs the row sums of the truncated values");
     constexpr bool PIPE = (VAR & 64) != 0;         // software-pipelined optimistic pass (see there)
+    constexpr bool SDMA = PIPE || !(VAR & 256);    // K / V pieces issued in the scalar-base DMA form (default since round 5; VAR bit 256 = the per-lane-address form)
     static_assert(!PIPE || (!MASKED && NST >= 3 && !(VAR & 63)), "the pipelined pass serves the un-masked instances, on a ring of >= 3 stages");
+    static_assert(BK <= 64, "key tiles beyond 64 rows read past the graphs' 64-row slot padding");
     // VAR bits 2..5 are timing ablations (wrong results): 4 no exponentials, 8 one QK product per block (all K reads kept),
     // 16 K fragments read once per workgroup, 32 no PV products
     static_assert(CF::NCB == 1, "one 32-channel value block");
@@ -144,10 +146,11 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         unsigned char *sb = smem + stage * MSTAGE;
         const unsigned char *kb_ = Kg + (size_t)kt * CF::BKEYS * CF::ROWB;
         const unsigned char *vb_ = Vg + (size_t)kt * CF::BKEYS * CF::ROWBV;
-        if constexpr (PIPE) {
+        if constexpr (SDMA) {
             // "scalar base + 32-bit lane offset" form (the GEMM producers' idiom): the tile's base is wave-uniform, the lane
-            // offsets never change -- no 64-bit per-lane address to rebuild (or to spill: a reloaded address register makes the
-            // compiler put `s_waitcnt vmcnt(0)` in front of the DMA, which drains the ring)
+            // offsets never change -- no 64-bit per-lane address to rebuild per piece (or to spill: a reloaded address register makes
+            // the compiler put `s_waitcnt vmcnt(0)` in front of the DMA, which drains the ring).  Round-5 probe, last layer: 9.7 k
+            // -> 4.8 k cycles of DMA issue per workgroup, 184 -> 176 us per 64-puzzle launch, the sampling step -1.7 ... -2.4 %.
             const unsigned sbl = lds0 + (unsigned)(stage * MSTAGE);
 #pragma unroll
             for (int x = 0; x < MAXI; ++x) {
@@ -157,15 +160,15 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                                  "s"(q < KG::NIK ? kb_ : vb_)
                                  : "memory");
             }
-            return;
-        }
+        } else {
 #pragma unroll
-        for (int x = 0; x < MAXI; ++x) {
-            const int q = wid + NW * x;
-            if (NW * x + NW - 1 < KG::NI || q < KG::NI) {
-                const unsigned char *src = (q < KG::NIK ? kb_ : vb_) + soff[x];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
+            for (int x = 0; x < MAXI; ++x) {
+                const int q = wid + NW * x;
+                if (NW * x + NW - 1 < KG::NI || q < KG::NI) {
+                    const unsigned char *src = (q < KG::NIK ? kb_ : vb_) + soff[x];
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(sb + q * 1024), 16, 0, 0);
+                }
             }
         }
         if (MASKED)         // lane (i, half) fetches the 32 adjacency bits of query row i for key block `half` of the tile
@@ -264,6 +267,15 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     float m = 0.f;                // GEN mode only: running row max (log2 units)
     unsigned anym = 0;            // MASKED: OR of this lane's adjacency words
     bool gen = p.force_gen != 0;  // false: optimistic pass
+    // epilogue operands requested EARLY (un-masked, un-folded instances whose epilogue is one pass over the tile: the hidden layers):
+    // the skip (+ residual) rows of this tile are loaded right behind the key loop, so that their latency passes under the
+    // verification barrier and the O staging instead of being waited for in the epilogue (round-5 probe: 4.3 k cycles of epilogue
+    // per workgroup, most of it these loads' round trip)
+    constexpr int EPC_ = 8, CPR_ = C / EPC_, NBP = 3;
+    // (measured, round 5: hidden layers 55.7 / 56.1 / 56.6 us with it against 56.8 / 55.4 / 56.2 without, the sampling step 0.7044 /
+    //  0.7069 / 0.7045 ms against 0.7019 / 0.6991 / 0.7028 -- no gain, nine more registers: opt-in, VAR bit 128)
+    constexpr bool EPI_PRE = (VAR & 128) && !FOLD && !MASKED && !(VAR & 64) && (QT * CPR_ <= NT * NBP);
+    u32x4 skv_p[EPI_PRE ? NBP : 1], rsv_p[EPI_PRE ? NBP : 1];
     for (int attempt = 0; attempt < 2; ++attempt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[r] = 0.f;
@@ -554,6 +566,21 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         }
         }           // (!PIPE || gen)
         if (VAR & 1) ls += ls2;
+        if constexpr (EPI_PRE) {
+            {       // (every attempt loads them again: kept across a re-run they would be live through the key loop -- 24 spilled registers)
+                const int nq_ = min(QT, n_g - qt * QT);
+#pragma unroll
+                for (int k = 0; k < NBP; ++k) {
+                    // (fully defined on every path -- items beyond the tile read its first row: a partial definition would keep the
+                    //  previous attempt's values alive through the key loop)
+                    const int it = min(tid + NT * k, nq_ * CPR_ - 1);
+                    const int q = it / CPR_, ch = it - q * CPR_;
+                    const size_t off = (size_t)(node0 + qt * QT + q) * HC + (size_t)h * C + ch * EPC_;
+                    skv_p[k] = *(const u32x4 *)((const T *)p.S + off);
+                    rsv_p[k] = p.res ? *(const u32x4 *)((const T *)p.res + off) : (u32x4){0u, 0u, 0u, 0u};
+                }
+            }
+        }
         if (gen) break;
         // ---- verification of the optimistic pass (workgroup-uniform verdict: the waves share the K / V stream)
         const float lt0 = ls + __shfl_xor(ls, 32);
@@ -563,12 +590,11 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             ok = ok || (lt0 == 0.f && had == 0u);                                        // a row without regular edges
         }
         const bool bad = wave_on && __any(!ok && qidx < n_g);
-        dma_barrier();
-        if (lane == 0) flags[wid] = bad ? 1 : 0;
-        __syncthreads();
+        if (lane == 0) flags[wid] = bad ? 1 : 0;            // (nothing else lives in flags[0 .. 3]; the ring was drained by the last tile's vmcnt(0))
+        __syncthreads();                                    // every wave has left the key loop: the ring's LDS is free from here on
         const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
-        __syncthreads();
         if (!redo) break;
+        __syncthreads();
         gen = true;
         if (tid == 0) atomicAdd(&g_opt_fallbacks[MASKED ? 1 : 0], 1ull);
     }
@@ -599,7 +625,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     constexpr int CO = CV, RSOF = CO + 4;
     static_assert(QT * RSOF * 4 <= NST * MSTAGE, "O staging must fit in the K/V ring");
     float *so = (float *)smem;
-    dma_barrier();
+    if (gen) dma_barrier();       // (an optimistic pass went through the verification barrier: nobody reads the ring any more; workgroup-uniform)
     if (wave_on) {
         float *orow = so + (wid * 32 + i) * RSOF;
         if (MASKED && half == 0) {
@@ -637,6 +663,10 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     constexpr int NB = 3;
     for (int it0 = tid; it0 < nq * CPR; it0 += NT * NB) {
         u32x4 skv[NB], rsv[NB];
+        if constexpr (EPI_PRE) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { skv[k] = skv_p[k]; rsv[k] = rsv_p[k]; }
+        } else {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int it = it0 + NT * k;
@@ -646,6 +676,7 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                 skv[k] = *(const u32x4 *)((const T *)p.S + off);
                 if (p.res) rsv[k] = *(const u32x4 *)((const T *)p.res + off);
             }
+        }
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
@@ -707,7 +738,9 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
     if (masked && p.max_nodes > 4096) return -1;          // the masked walk keeps its key tiles in a 64-bit mask
     if (masked && p.blk_class && p.blk_class_stride > 128) return -1;      // class rows are staged in 128-byte LDS slots
     if (C == 32 && !fold) {
-        if (masked) return launch_optt<32, false, true, 4, 4>(p, st);
+        static int vm = -1;
+        if (vm < 0) vm = env_int("DA_OPT_MASKED_VAR", 0);
+        if (masked) return vm == 30 ? launch_optt<32, false, true, 4, 4, 64, 256>(p, st) : launch_optt<32, false, true, 4, 4>(p, st);
         static int v = -1;
         if (v < 0) v = env_int("DA_OPT_HID", 0);
         switch (v) {
@@ -717,6 +750,8 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
             case 10: return launch_optt<32, false, false, 4, 4, 64, 64>(p, st);
             case 11: return launch_optt<32, false, false, 5, 4, 64, 64>(p, st);
             case 12: return launch_optt<32, false, false, 6, 4, 32, 64>(p, st);
+            case 20: return launch_optt<32, false, false, 4, 4, 64, 128>(p, st);      // skip / residual rows requested before the verification barrier
+            case 30: return launch_optt<32, false, false, 4, 4, 64, 256>(p, st);      // DMA issued in the per-lane-address form (round 4's)
 #ifdef DA_ATTN_ABLATE
             case 104: return launch_optt<32, false, false, 4, 4, 64, 4>(p, st);
             case 108: return launch_optt<32, false, false, 4, 4, 64, 8>(p, st);
@@ -730,7 +765,9 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
     // (two ring stages at three workgroups per CU; measured at the end of round 4: three stages at two workgroups per CU 189 - 191 us
     // against 178 in the harness at 64 puzzles, 99 against 92 at 32, the sampling step 0.717 against 0.703 ms -- occupancy, not ring depth)
     if (C == 144 && fold) {
-        if (masked) return launch_optt<144, true, true, 2, 3>(p, st);
+        static int vm = -1;
+        if (vm < 0) vm = env_int("DA_OPT_MASKED_VAR", 0);
+        if (masked) return vm == 30 ? launch_optt<144, true, true, 2, 3, 64, 256>(p, st) : launch_optt<144, true, true, 2, 3>(p, st);
         static int v = -1;
         if (v < 0) v = env_int("DA_OPT_LAST", 0);
         switch (v) {
@@ -744,6 +781,7 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
             case 10: return launch_optt<144, true, false, 4, 3, 32, 64>(p, st);
             case 11: return launch_optt<144, true, false, 3, 2, 64, 64>(p, st);
             case 12: return launch_optt<144, true, false, 3, 3, 32, 64>(p, st);
+            case 30: return launch_optt<144, true, false, 2, 3, 64, 256>(p, st);       // DMA issued in the per-lane-address form (round 4's)
 #ifdef DA_ATTN_ABLATE
             case 104: return launch_optt<144, true, false, 2, 3, 64, 4>(p, st);
             case 108: return launch_optt<144, true, false, 2, 3, 64, 8>(p, st);

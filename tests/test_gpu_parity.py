@@ -775,11 +775,11 @@ def test_fold_flags_reported(dev):
     spec = C.by_name("rot144_g1")
     case = C.build_case(spec)
     eng = make_engine(case, spec, "bf16", dev)
-    assert int(eng.lib.da_denoiser_flags(eng.handle)) == 7            # 2D transformer arch: both folds + all-MFMA attention
+    assert int(eng.lib.da_denoiser_flags(eng.handle)) == 15           # 2D transformer arch: both folds + all-MFMA attention + hoisted mlp.0 (bit 3: guidance inside the captured loops)
     assert eng.dense_only
     spec = C.by_name("exo144_v4_g1")
     eng = make_engine(C.build_case(spec), spec, "bf16", dev)
-    assert int(eng.lib.da_denoiser_flags(eng.handle)) == 7            # exophormer: same folds (the last one on hybrid graphs)
+    assert int(eng.lib.da_denoiser_flags(eng.handle)) == 15           # exophormer: same folds (the last one on hybrid graphs)
     spec3 = C.FWD3D[0]
     eng3 = make_engine(C.build_case(spec3, "3d"), spec3, "bf16", dev, variant="3d")
     assert not eng3.dense_only                                          # 3D: the C = 104 layer walks the edge list
