@@ -73,10 +73,13 @@ template <int C, int BK = 64> struct OptK {
 // deeper ring fits the same LDS); VAR = instruction-mix experiments (bit 0: row sums as f32 adds of the un-rounded
 // exponentials instead of v_dot2c on the packed P; bit 1: P packed by TRUNCATION (one v_perm_b32 per pair) instead of
 // v_cvt_pk_bf16_f32 -- the truncation bias cancels in the normalisation because the row sums weigh the same truncated values).
-template <int C, bool FOLD, bool MASKED, int NST, int MINB, int BK = 64, int VAR = 0>
-__global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
+// NWV = waves (32-query slabs) per workgroup: 4 (128-query tiles) or 5 (160-query tiles: a 144-piece puzzle is ONE tile instead of a
+// full one and a 16-query rest, a 900-piece puzzle six tiles / 30 slabs instead of eight / 32 for its 29; un-masked instances).
+template <int C, bool FOLD, bool MASKED, int NST, int MINB, int BK = 64, int VAR = 0, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, MINB) void k_attn_optt(AttnDenseParams p) {
     using T = bf16_t;
-    constexpr int CV = 32, NW = 4, QT = 128, NT = 256;
+    constexpr int CV = 32, NW = NWV, QT = 32 * NWV, NT = 64 * NWV;
+    static_assert(NWV == 4 || (!MASKED && NWV <= 8), "the adjacency-word slots and class rows are laid out for four waves");
     using CF = Cfg<T, C, CV, BK>;
     using KG = OptK<C, BK>;
     static_assert(!MASKED || BK == 64, "the adjacency words and class rows are laid out for 64-key tiles");
@@ -451,6 +454,16 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
             // classes of this slab's two blocks in the tile (1 = partial when the plan has no class table)
             const unsigned cls2 = (MASKED && crow) ? (unsigned)__builtin_amdgcn_readfirstlane((int)*(const unsigned short *)(crow + 2 * kt)) : 0x0101u;
             const unsigned char *stg = smem + (j % NST) * MSTAGE;
+            // VAR bit 512 (narrow heads): the K fragments of BOTH blocks of the tile are requested at its top, so that the second
+            // block's LDS round trip passes under the first block's arithmetic (the probe: ~210 cycles of K-read wait per block)
+            constexpr bool KPRE = (VAR & 512) != 0 && CF::KB == 2 && CF::NCH <= 2 && !MASKED;
+            u32x4 kfa[KPRE ? CF::KB : 1][CF::NCH];
+            if constexpr (KPRE) {
+#pragma unroll
+                for (int kb = 0; kb < CF::KB; ++kb)
+#pragma unroll
+                    for (int ch = 0; ch < CF::NCH; ++ch) kfa[kb][ch] = *(const u32x4 *)(stg + kfo[ch] + kb * 32 * KG::RS);
+            }
 #pragma unroll
             for (int kb = 0; kb < CF::KB; ++kb) {
                 const int key0 = kt * CF::BKEYS + kb * 32;
@@ -459,9 +472,11 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
                 if (MASKED && cls == 0u) continue;                                  // no edge between this slab and these keys
                 u32x4 kf[CF::NCH];
 #pragma unroll
-                for (int ch = 0; ch < CF::NCH; ++ch)
-                    if (!(VAR & 16) || (j == 0 && kb == 0)) kf[ch] = *(const u32x4 *)(stg + kfo[ch] + kb * 32 * KG::RS);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int ch = 0; ch < CF::NCH; ++ch) {
+                    if constexpr (KPRE) kf[ch] = kfa[kb][ch];
+                    else if (!(VAR & 16) || (j == 0 && kb == 0)) kf[ch] = *(const u32x4 *)(stg + kfo[ch] + kb * 32 * KG::RS);
+                }
+                if (!(VAR & 1024)) __builtin_amdgcn_sched_barrier(0);      // (bit 1024: let the compiler count lgkmcnt down fragment by fragment)
                 DA_OPB({ asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[CF::NCH - 1])); const unsigned long long t_ = __builtin_readcyclecounter(); pb_[3] += t_ - pb_t; pb_t = t_; })
                 f32x16 s;
                 if (MASKED && cls == 2u) {                                           // every pair of the block is an edge
@@ -592,7 +607,9 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
         const bool bad = wave_on && __any(!ok && qidx < n_g);
         if (lane == 0) flags[wid] = bad ? 1 : 0;            // (nothing else lives in flags[0 .. 3]; the ring was drained by the last tile's vmcnt(0))
         __syncthreads();                                    // every wave has left the key loop: the ring's LDS is free from here on
-        const bool redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+        bool redo = false;
+#pragma unroll
+        for (int w_ = 0; w_ < NW; ++w_) redo = redo || flags[w_] != 0;
         if (!redo) break;
         __syncthreads();
         gen = true;
@@ -711,19 +728,19 @@ __global__ __launch_bounds__(256, MINB) void k_attn_optt(AttnDenseParams p) {
     DA_OPB(pb_out();)
 }
 
-template <int C, bool FOLD, bool MASKED, int NST, int MINB, int BK = 64, int VAR = 0>
+template <int C, bool FOLD, bool MASKED, int NST, int MINB, int BK = 64, int VAR = 0, int NWV = 4>
 static int launch_optt(AttnDenseParams p, hipStream_t st) {
     const int lds = NST * (OptK<C, BK>::STAGE + (MASKED ? 1024 : 0)) + 64 + (MASKED ? 256 + 512 : 0);
     static bool attr_done[16] = {};           // per device: the attribute belongs to the device's copy of the function
     int dev = 0;
     DA_CHECK_HIP(hipGetDevice(&dev));
     if (lds > 48 * 1024 && !attr_done[dev & 15]) {
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_optt<C, FOLD, MASKED, NST, MINB, BK, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_optt<C, FOLD, MASKED, NST, MINB, BK, VAR, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done[dev & 15] = true;
     }
-    p.nqt = (p.max_nodes + 127) / 128;
+    p.nqt = (p.max_nodes + 32 * NWV - 1) / (32 * NWV);
     DA_OPB({ const char *e = getenv("DA_OPT_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; })
-    k_attn_optt<C, FOLD, MASKED, NST, MINB, BK, VAR><<<p.nqt * p.H * p.n_graphs, 256, lds, st>>>(p);
+    k_attn_optt<C, FOLD, MASKED, NST, MINB, BK, VAR, NWV><<<p.nqt * p.H * p.n_graphs, 64 * NWV, lds, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -752,6 +769,10 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
             case 12: return launch_optt<32, false, false, 6, 4, 32, 64>(p, st);
             case 20: return launch_optt<32, false, false, 4, 4, 64, 128>(p, st);      // skip / residual rows requested before the verification barrier
             case 30: return launch_optt<32, false, false, 4, 4, 64, 256>(p, st);      // DMA issued in the per-lane-address form (round 4's)
+            case 40: return launch_optt<32, false, false, 3, 5, 64, 0>(p, st);        // five workgroups per CU on a three-stage ring
+            case 50: return launch_optt<32, false, false, 4, 4, 64, 512>(p, st);      // both blocks' K fragments requested at the top of the tile
+            case 60: return launch_optt<32, false, false, 4, 4, 64, 1024>(p, st);     // no scheduling barrier between the K reads and the QK chain
+            case 70: return launch_optt<32, false, false, 4, 4, 64, 0, 5>(p, st);     // five waves (160 queries) per workgroup
 #ifdef DA_ATTN_ABLATE
             case 104: return launch_optt<32, false, false, 4, 4, 64, 4>(p, st);
             case 108: return launch_optt<32, false, false, 4, 4, 64, 8>(p, st);
@@ -782,6 +803,8 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
             case 11: return launch_optt<144, true, false, 3, 2, 64, 64>(p, st);
             case 12: return launch_optt<144, true, false, 3, 3, 32, 64>(p, st);
             case 30: return launch_optt<144, true, false, 2, 3, 64, 256>(p, st);       // DMA issued in the per-lane-address form (round 4's)
+            case 60: return launch_optt<144, true, false, 2, 3, 64, 1024>(p, st);      // no scheduling barrier between the K reads and the QK chain
+            case 70: return launch_optt<144, true, false, 2, 3, 64, 0, 5>(p, st);      // five waves (160 queries) per workgroup
 #ifdef DA_ATTN_ABLATE
             case 104: return launch_optt<144, true, false, 2, 3, 64, 4>(p, st);
             case 108: return launch_optt<144, true, false, 2, 3, 64, 8>(p, st);
