@@ -264,6 +264,24 @@ __device__ __forceinline__ void remainder_edges(const AttnDenseParams &p, float 
     }
 }
 
+// K tile geometry of these kernels.  C = 144: Cfg's padded rows (288 B + one 16-byte pad slot: an odd number of slots keeps the
+// fragment reads conflict-free).  C = 32 (round 4): rows of exactly 64 B, their four 16-byte slots XOR-SWIZZLED instead of padded --
+// slot s of key row r lives at position s ^ f(r), f(r) = bit 2 of r + 2 * bit 4 of r: the four rows a 16-lane group of a fragment
+// read meets in one 64-byte quarter of the 256-byte bank window (r, r + 4, r + 16, r + 20 under the pi permutation) get four
+// different positions.  The swizzle is applied to the LDS-DMA's per-lane SOURCE address, as in the GEMM kernels.  It saves the
+// 1 KB of pad slots per 64-key stage (and one DMA instruction per tile): with the adjacency-word slots of the masked instance a
+// stage is 9 KB again and four workgroups fit a CU -- at three, the 2048 workgroups of a 32-puzzle launch needed three rounds
+// instead of two (measured: 92 us against 55 us for the un-masked kernel, with the masking itself costing nothing).
+template <int C, int BK = 64> struct OptK {
+    using CF = Cfg<bf16_t, C, 32, BK>;
+    static constexpr bool SWZ = C == 32;
+    static constexpr int RS = SWZ ? CF::ROWB : CF::RS, KSPR = RS / 16;
+    static constexpr int NIK = (CF::BKEYS * KSPR + 63) / 64, NI = NIK + CF::NIV;
+    static constexpr int KBYTES = NIK * 1024, STAGE = KBYTES + CF::VBYTES;
+    static __device__ __forceinline__ int f(int row) { return SWZ ? (((row >> 2) & 1) | (((row >> 4) & 1) << 1)) : 0; }
+};
+
+
 // da_attn_opt.hip: the optimistic kernels (bf16, Q pre-scaled, 32-wide value heads); 0 = launched, -1 = shape not covered
 int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st);
 int attn_opt_counters(unsigned long long *out2, int reset);

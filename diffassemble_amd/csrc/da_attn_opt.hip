@@ -52,23 +52,7 @@ namespace da {
 // da_debug_counters: workgroups whose optimistic pass failed its verification ([0] complete graphs, [1] adjacency-masked)
 __device__ unsigned long long g_opt_fallbacks[2];
 
-// K tile geometry of these kernels.  C = 144: Cfg's padded rows (288 B + one 16-byte pad slot: an odd number of slots keeps the
-// fragment reads conflict-free).  C = 32 (round 4): rows of exactly 64 B, their four 16-byte slots XOR-SWIZZLED instead of padded --
-// slot s of key row r lives at position s ^ f(r), f(r) = bit 2 of r + 2 * bit 4 of r: the four rows a 16-lane group of a fragment
-// read meets in one 64-byte quarter of the 256-byte bank window (r, r + 4, r + 16, r + 20 under the pi permutation) get four
-// different positions.  The swizzle is applied to the LDS-DMA's per-lane SOURCE address, as in the GEMM kernels.  It saves the
-// 1 KB of pad slots per 64-key stage (and one DMA instruction per tile): with the adjacency-word slots of the masked instance a
-// stage is 9 KB again and four workgroups fit a CU -- at three, the 2048 workgroups of a 32-puzzle launch needed three rounds
-// instead of two (measured: 92 us against 55 us for the un-masked kernel, with the masking itself costing nothing).
-template <int C, int BK = 64> struct OptK {
-    using CF = Cfg<bf16_t, C, 32, BK>;
-    static constexpr bool SWZ = C == 32;
-    static constexpr int RS = SWZ ? CF::ROWB : CF::RS, KSPR = RS / 16;
-    static constexpr int NIK = (CF::BKEYS * KSPR + 63) / 64, NI = NIK + CF::NIV;
-    static constexpr int KBYTES = NIK * 1024, STAGE = KBYTES + CF::VBYTES;
-    static __device__ __forceinline__ int f(int row) { return SWZ ? (((row >> 2) & 1) | (((row >> 4) & 1) << 1)) : 0; }
-};
-
+// (OptK -- the K tile geometry of these kernels -- lives in da_attn_common.h)
 // BK = keys per ring stage (64: two 32-key blocks per stage and barrier; 32: one -- half the bytes per stage, so that a
 // deeper ring fits the same LDS); VAR = instruction-mix experiments (bit 0: row sums as f32 adds of the un-rounded
 // exponentials instead of v_dot2c on the packed P; bit 1: P packed by TRUNCATION (one v_perm_b32 per pair) instead of
@@ -448,7 +432,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void k_attn_optt(AttnDenseParams p)
                 __builtin_amdgcn_s_barrier();
             }
             DA_OPB({ const unsigned long long t_ = __builtin_readcyclecounter(); pb_[1] += t_ - pb_t; pb_t = t_; })
-            if (j + NST - 1 < ntl) issue(next_tile(rem_pf, j + NST - 1), (j + NST - 1) % NST);
+            if (j + NST - 1 < ntl && !(VAR & 2048)) issue((VAR & 4096) ? 0 : next_tile(rem_pf, j + NST - 1), (j + NST - 1) % NST);      // (bits 2048 / 4096: timing ablations -- no DMA beyond the prologue / every tile re-fetches tile 0)
             DA_OPB({ const unsigned long long t_ = __builtin_readcyclecounter(); pb_[2] += t_ - pb_t; pb_t = t_; })
             if (!wave_on) continue;
             // classes of this slab's two blocks in the tile (1 = partial when the plan has no class table)
@@ -774,6 +758,8 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
             case 60: return launch_optt<32, false, false, 4, 4, 64, 1024>(p, st);     // no scheduling barrier between the K reads and the QK chain
             case 70: return launch_optt<32, false, false, 4, 4, 64, 0, 5>(p, st);     // five waves (160 queries) per workgroup
 #ifdef DA_ATTN_ABLATE
+            case 201: return launch_optt<32, false, false, 4, 4, 64, 2048>(p, st);
+            case 202: return launch_optt<32, false, false, 4, 4, 64, 4096>(p, st);
             case 104: return launch_optt<32, false, false, 4, 4, 64, 4>(p, st);
             case 108: return launch_optt<32, false, false, 4, 4, 64, 8>(p, st);
             case 116: return launch_optt<32, false, false, 4, 4, 64, 16>(p, st);
@@ -806,6 +792,8 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
             case 60: return launch_optt<144, true, false, 2, 3, 64, 1024>(p, st);      // no scheduling barrier between the K reads and the QK chain
             case 70: return launch_optt<144, true, false, 2, 3, 64, 0, 5>(p, st);      // five waves (160 queries) per workgroup
 #ifdef DA_ATTN_ABLATE
+            case 201: return launch_optt<144, true, false, 2, 3, 64, 2048>(p, st);
+            case 202: return launch_optt<144, true, false, 2, 3, 64, 4096>(p, st);
             case 104: return launch_optt<144, true, false, 2, 3, 64, 4>(p, st);
             case 108: return launch_optt<144, true, false, 2, 3, 64, 8>(p, st);
             case 116: return launch_optt<144, true, false, 2, 3, 64, 16>(p, st);

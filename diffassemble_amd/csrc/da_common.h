@@ -71,6 +71,11 @@ __device__ inline float erf_as(float z) {
     return copysignf(r, z);
 }
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+__device__ inline float gelu_grad(float x) {          // d gelu_erf / dx (training path)
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return fmaf(x, pdf, cdf);
+}
 __device__ inline float apply_act(float x, int act) {
     if (act == DA_ACT_GELU) return gelu_erf(x);
     if (act == DA_ACT_LEAKY02) return x > 0.f ? x : 0.2f * x;

@@ -329,8 +329,12 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
 }
 
 // out[m][c] = sum_z partial[z][m][c] (+ bias[c]) (+ res[m][c]): fixed order
+// gelu_pre (backward: the product is dX of a Linear that follows a GELU): out = sum * gelu'(gelu_pre) -- the separate k_gelu_bwd launch
+// of the training path folded in (a dependent ~5 us launch per site; same arithmetic, same order).  act_out (forward: the Linear
+// feeds a GELU): out = sum (the pre-activation backward needs) and act_out = gelu(sum).  Both share out's leading dimension.
 __global__ __launch_bounds__(256) void k_splitk_reduce(int splits, int M, int N, const float *__restrict__ partial,
-                                                       const float *__restrict__ bias, const float *res, float *out, int ldo) {
+                                                       const float *__restrict__ bias, const float *res, float *out, int ldo,
+                                                       const float *gelu_pre, float *act_out) {
     const size_t MN = (size_t)M * N, n4 = MN / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 s = *(const f32x4 *)(partial + 4 * i);
@@ -338,7 +342,18 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(int splits, int M, int N,
         const size_t m = 4 * i / N, c = 4 * i - m * N;
         if (bias) s += *(const f32x4 *)(bias + c);
         if (res) s += *(const f32x4 *)(res + m * ldo + c);
+        if (gelu_pre) {
+            const f32x4 pr = *(const f32x4 *)(gelu_pre + m * ldo + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = s[e] * gelu_grad(pr[e]);
+        }
         *(f32x4 *)(out + m * ldo + c) = s;
+        if (act_out) {
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = gelu_erf(s[e]);
+            *(f32x4 *)(act_out + m * ldo + c) = a;
+        }
     }
 }
 
@@ -347,7 +362,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(int splits, int M, int N,
 // cut into `splits` pieces that run as separate workgroups of ONE launch (partial images [split][M][Nout], fp32) and a second
 // kernel adds them in a fixed order together with bias and residual.  Returns -1 when the shape does not qualify.
 int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, const void *res,
-                            void *out, int ldo, float *partial, size_t partial_floats, hipStream_t st, bool in16) {
+                            void *out, int ldo, float *partial, size_t partial_floats, hipStream_t st, bool in16, const float *gelu_pre,
+                            float *act_out) {
     const int es = in16 ? 2 : 4;                             // in16: A and W are bf16 (out / res / partial stay fp32)
     static int off = -1;
     if (off < 0) { const char *e = getenv("DA_GEMM_SPLITK"); off = (e && e[0] == '0') ? 1 : 0; }
@@ -375,7 +391,7 @@ int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, cons
     else k_gemm_mfma<float, false, DA_ACT_NONE, true><<<grid, 256, 0, st>>>(p);
     const size_t n4 = (size_t)M * Nout / 4;
     k_splitk_reduce<<<(unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256), 256, 0, st>>>(splits, M, Nout, partial, bias,
-                                                                                                   (const float *)res, (float *)out, ldo);
+                                                                                                   (const float *)res, (float *)out, ldo, gelu_pre, act_out);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -61,7 +61,8 @@ int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B,
 int launch_gemm_tn_bf16(int M, int N, int K, const bf16_t *A, int lda, const bf16_t *B, int ldb, float *C, int ldc, float *partial,
                         hipStream_t st);
 int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, const void *res,
-                            void *out, int ldo, float *partial, size_t partial_floats, hipStream_t st, bool in16 = false);   // da_gemm_mfma.hip; -1: shape not taken
+                            void *out, int ldo, float *partial, size_t partial_floats, hipStream_t st, bool in16 = false,
+                            const float *gelu_pre = nullptr, float *act_out = nullptr);   // da_gemm_mfma.hip; -1: shape not taken.  gelu_pre: out *= gelu'(pre); act_out = gelu(out)
 int launch_gemm_mfma_mixed(bool in16, bool out16, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
                            const void *res, void *out, int ldo, hipStream_t st);                              // fp32 x fp32 -> bf16 / bf16 x bf16 -> fp32
 int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const float *B, int ldb, float *C, int ldc, float *partial,

@@ -22,15 +22,14 @@
 
 namespace da {
 
-__device__ inline float gelu_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return fmaf(x, pdf, cdf);
-}
-
-__global__ __launch_bounds__(256) void k_gelu_fwd(size_t n, const float *__restrict__ src, float *__restrict__ dst) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = gelu_erf(src[i]);
+// dst = gelu(src); dst16 (optional): the same values rounded to bf16 -- the next projection's operand in the q16 mode (its own
+// k_cast_h launch folded in; the rounding is of the fp32 value just stored, i.e. the same bits)
+__global__ __launch_bounds__(256) void k_gelu_fwd(size_t n, const float *__restrict__ src, float *__restrict__ dst, bf16_t *__restrict__ dst16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = gelu_erf(src[i]);
+        dst[i] = v;
+        if (dst16) dst16[i] = f2bf(v);
+    }
 }
 
 // dx = dy * gelu'(pre)   (dx may alias dy)
@@ -241,6 +240,36 @@ __global__ __launch_bounds__(256) void k_reduce_partial(int splits, int N, int K
     }
 }
 
+// k_reduce_partial and k_colsum_finish in one launch (launch_gemm_tn_db): items [0, N K) add the split partials into C (when
+// partial != null), items [N K, N K + N) add the `splits` row-range sums of a dY column into db -- in k_colsum_finish's order
+// ((s0 + s1) + (s2 + s3), s_q = chunks q, q + 4, ... ascending), so the bits are the ones the two-launch form produced.
+__global__ __launch_bounds__(256) void k_tn_finish(int splits, int N, int K, const float *__restrict__ partial, float *C, int ldc,
+                                                   const float *__restrict__ bpartial, float *db) {
+    const size_t NK = partial ? (size_t)N * K : 0, items = NK + (bpartial ? (size_t)N : 0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < NK) {
+            const size_t NKs = (size_t)N * K;
+            float s = 0.f;
+            int k = 0;
+            for (; k + 8 <= splits; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(k + u) * NKs + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; k < splits; ++k) s += partial[(size_t)k * NKs + i];
+            const size_t n = i / K, kk = i - n * K;
+            C[n * ldc + kk] += s;
+        } else {
+            const size_t c = i - NK;
+            float q[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < splits; ++k) q[k & 3] += bpartial[(size_t)k * N + c];
+            db[c] += (q[0] + q[1]) + (q[2] + q[3]);
+        }
+    }
+}
+
 constexpr size_t PART_CAP = (size_t)16 << 20;        // floats of split-reduction scratch (64 MB)
 
 int launch_gemm_tn(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
@@ -442,11 +471,10 @@ int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const float *
                                                    xmap ? tk : 0);
     else k_gemm_tn_db<false><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc,
                                                    xmap ? tk : 0);
-    if (splits > 1) {
-        const size_t NK = (size_t)N * K;
-        k_reduce_partial<<<(unsigned)((NK + 255) / 256 > 4096 ? 4096 : (NK + 255) / 256), 256, 0, st>>>((int)splits, N, K, partial, C, ldc);
+    {       // one finishing launch: the split partials into dW and the row-range sums into db (two launches until round 5)
+        const size_t NK = splits > 1 ? (size_t)N * K : 0, items = NK + (db ? (size_t)N : 0);
+        if (items) k_tn_finish<<<(unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256), 256, 0, st>>>((int)splits, N, K, NK ? partial : nullptr, C, ldc, db ? bscratch : nullptr, db);
     }
-    if (db) k_colsum_finish<<<(N + 63) / 64, 256, 0, st>>>((int)splits, N, bscratch, db);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -767,6 +795,43 @@ static bool train_dense_disabled() {
 
 static unsigned grid_for(size_t n) { const size_t b = (n + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
+// Every weight image the step needs beside the fp32 parameters, in ONE launch at the top of the forward (round 5; they were 13
+// launches of k_cast_h / k_transpose_h / k_transpose spread over the forward and the backward, ~5 us of dependent-launch time
+// each): job j of the table = one matrix, mode 0: dst[c][r] = src[r][c] (fp32 W^T for a dX product), 1: the same rounded to bf16
+// (q16 mode), 2: dst[r][c] = bf16(src[r][c]) (the bf16 forward operand of the q16 mode).  grid = (tiles of the largest job, jobs).
+struct WPrepJob { const float *src; void *dst; int rows, cols, mode, pad; };
+struct WPrepTable { WPrepJob job[5 + 2 * DA_MAX_LAYERS]; int n; };
+__global__ __launch_bounds__(256) void k_weight_prep(WPrepTable tab) {
+    __shared__ float tile[32][33];
+    const WPrepJob jb = tab.job[blockIdx.y];
+    const int tcols = (jb.cols + 31) / 32, trows = (jb.rows + 31) / 32;
+    if ((int)blockIdx.x >= tcols * trows) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int r0 = ((int)blockIdx.x / tcols) * 32, c0 = ((int)blockIdx.x % tcols) * 32;
+    if (jb.mode == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            if (r < jb.rows && c < jb.cols) ((bf16_t *)jb.dst)[(size_t)r * jb.cols + c] = f2bf(jb.src[(size_t)r * jb.cols + c]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < jb.rows && c < jb.cols) tile[ty + 8 * k][tx] = jb.src[(size_t)r * jb.cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < jb.rows && c < jb.cols) {
+            if (jb.mode == 1) ((bf16_t *)jb.dst)[(size_t)c * jb.rows + r] = f2bf(tile[tx][ty + 8 * k]);
+            else ((float *)jb.dst)[(size_t)c * jb.rows + r] = tile[tx][ty + 8 * k];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 struct TrainWs {
     float *comb_in, *m1pre, *m1, *h0;
@@ -776,6 +841,11 @@ struct TrainWs {
     float *P[DA_MAX_LAYERS], *dP;      // dense path: attention matrices kept per layer, one gradient scratch
     long long *poff;
     int32_t *node_graph;
+    // weight images written by the forward's k_weight_prep launch, read by the backward of the same step: W^T of every Linear with
+    // a dX product (fp32; bf16 for the convs in the q16 mode) and, q16 mode, the convs' bf16 forward operands
+    void *wt_conv[DA_MAX_LAYERS];
+    bf16_t *wh_conv[DA_MAX_LAYERS];
+    float *wt_head1, *wt_head0, *wt_mlp1, *wt_mlp0, *wt_pos1;
     size_t total;
 };
 
@@ -881,6 +951,17 @@ static TrainWs carve_train(const Dims &d, void *base) {
         w.poff = (long long *)take(2 * ((size_t)d.G + 2));
         w.node_graph = (int32_t *)take(n);
     }
+    for (int l = 0; l < DA_MAX_LAYERS; ++l) { w.wt_conv[l] = nullptr; w.wh_conv[l] = nullptr; }
+    for (int l = 0; l < d.L; ++l) {
+        const size_t we = (size_t)4 * d.hc[l] * d.din[l];
+        w.wt_conv[l] = take(d.q16 ? (we + 1) / 2 : we);
+        w.wh_conv[l] = d.q16 ? (bf16_t *)take((we + 1) / 2) : nullptr;
+    }
+    w.wt_head1 = take((size_t)d.c_out * 32);
+    w.wt_head0 = take((size_t)32 * d.D);
+    w.wt_mlp1 = take((size_t)d.D * d.hid);
+    w.wt_mlp0 = take((size_t)d.hid * d.D);
+    w.wt_pos1 = take((size_t)32 * 16);
     w.total = off;
     return w;
 }
@@ -897,8 +978,39 @@ static int check_fused(const da_weights *w, const Dims &d, const char *what) {
     return 0;
 }
 
-static int gelu_fwd(size_t n, const float *src, float *dst, hipStream_t st) {
-    k_gelu_fwd<<<grid_for(n), 256, 0, st>>>(n, src, dst);
+static int q16_cast_on() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_TRAIN_Q16_CAST"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
+static int weight_prep(const da_weights *w, const Dims &d, TrainWs &ws, hipStream_t st) {
+    WPrepTable tab;
+    tab.n = 0;
+    int maxt = 1;
+    auto add = [&](const float *src, void *dst, int rows, int cols, int mode) {
+        WPrepJob &j = tab.job[tab.n++];
+        j.src = src; j.dst = dst; j.rows = rows; j.cols = cols; j.mode = mode; j.pad = 0;
+        const int tiles = ((rows + 31) / 32) * ((cols + 31) / 32);
+        maxt = tiles > maxt ? tiles : maxt;
+    };
+    static_assert(sizeof(WPrepTable) <= 2048, "the job table travels as a kernel argument");
+    add(w->head_w1, ws.wt_head1, d.c_out, 32, 0);
+    add(w->head_w0, ws.wt_head0, 32, d.D, 0);
+    add(w->mlp_w1, ws.wt_mlp1, d.D, d.hid, 0);
+    add(w->mlp_w0, ws.wt_mlp0, d.hid, d.D, 0);
+    add(w->pos_w1, ws.wt_pos1, 32, 16, 0);
+    for (int l = 0; l < d.L; ++l) {
+        add(w->conv_wq[l], ws.wt_conv[l], 4 * d.hc[l], d.din[l], d.q16 ? 1 : 0);
+        if (d.q16) add(w->conv_wq[l], ws.wh_conv[l], 4 * d.hc[l], d.din[l], 2);
+    }
+    k_weight_prep<<<dim3((unsigned)maxt, (unsigned)tab.n), 256, 0, st>>>(tab);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+static int gelu_fwd(size_t n, const float *src, float *dst, hipStream_t st, bf16_t *dst16 = nullptr) {
+    k_gelu_fwd<<<grid_for(n), 256, 0, st>>>(n, src, dst, dst16);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -921,20 +1033,22 @@ int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch
     return 0;
 }
 
-// Linear backward: dW += dY^T X, db += colsum(dY), and (if dX) dX = dY @ W (+ res)
-static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, const float *W,
+// Linear backward: dW += dY^T X, db += colsum(dY), and (if dX) dX = dY @ W (+ res); WT = the forward's image of W^T (k_weight_prep:
+// fp32, or bf16 when dy16); gelu_pre (optional, same leading dimension as dX): dX *= gelu'(gelu_pre) -- inside the reduction-split
+// product's second kernel where that route is taken, as a launch of its own otherwise
+static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, const void *WT,
                       float *dW, float *db, float *dX, int lddx, const float *res, TrainWs &ws, hipStream_t st, bool bfc,
-                      bool dy16 = false) {
+                      bool dy16 = false, const float *gelu_pre = nullptr) {
     int rc;
+    auto gelu_tail = [&]() -> int { return gelu_pre ? gelu_bwd((size_t)M * K, gelu_pre, dX, dX, st) : 0; };      // (every caller's dX is dense: lddx == K)
     if (dy16) {                                             // q16 mode: dY is bf16 (written by k_attn_small_bwd)
         if ((rc = launch_gemm_tn_db(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, db, ws.csum, st, true))) return rc;
         if (!dX) return 0;
-        k_transpose_h<<<dim3((K + 31) / 32, (N + 31) / 32), 256, 0, st>>>(N, K, W, (bf16_t *)ws.wt);       // W [N, K] -> W^T [K, N] bf16
-        DA_LAUNCH_CHECK();
-        rc = launch_gemm_mfma_splitk(M, N, K, dY, ldy, ws.wt, nullptr, res, dX, lddx, ws.partial, PART_CAP, st, true);
-        if (rc < 0) rc = launch_gemm_mfma_mixed(true, false, M, N, K, dY, ldy, ws.wt, nullptr, res, dX, lddx, st);
+        rc = launch_gemm_mfma_splitk(M, N, K, dY, ldy, WT, nullptr, res, dX, lddx, ws.partial, PART_CAP, st, true, gelu_pre);
+        if (rc >= 0) return rc;
+        rc = launch_gemm_mfma_mixed(true, false, M, N, K, dY, ldy, WT, nullptr, res, dX, lddx, st);
         if (rc < 0) { set_error("training (q16): dX product %d x %d x %d not covered", M, N, K); return 1; }
-        return rc;
+        return rc ? rc : gelu_tail();
     }
     static int tn_db = -1;
     if (tn_db < 0) { const char *e = getenv("DA_TRAIN_TN_DB"); tn_db = (e && e[0] == '0') ? 0 : 1; }
@@ -945,25 +1059,28 @@ static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float
         if (db && (rc = colsum_add(M, N, dY, ldy, db, ws.csum, st))) return rc;
     }
     if (dX) {
-        if ((rc = launch_transpose_f32(N, K, W, ws.wt, st))) return rc;                      // W [N, K] -> W^T [K, N]
         if (bfc) {                                          // skinny dX with a long reduction: split over the reduction (one launch + a fixed-order sum)
-            rc = launch_gemm_mfma_splitk(M, N, K, dY, ldy, ws.wt, nullptr, res, dX, lddx, ws.partial, PART_CAP, st);
+            rc = launch_gemm_mfma_splitk(M, N, K, dY, ldy, WT, nullptr, res, dX, lddx, ws.partial, PART_CAP, st, false, gelu_pre);
             if (rc >= 0) return rc;
         }
-        if ((rc = linear(bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32, M, N, K, dY, ldy, ws.wt, nullptr, DA_ACT_NONE, res, dX, lddx, st))) return rc;
+        if ((rc = linear(bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32, M, N, K, dY, ldy, (const float *)WT, nullptr, DA_ACT_NONE, res, dX, lddx, st))) return rc;
+        return gelu_tail();
     }
     return 0;
 }
 
 // forward Linear of the training path: the bf16-operand mode tries the reduction-split launch first (skinny outputs with a
 // long reduction: mlp.0 and the head's first layer leave most CUs idle otherwise)
+// act_out (optional, dense [M, Nout] like out): gelu(out) -- written by the split product's second kernel, or by a launch of its own
 static int linear_fw(const Dims &d, TrainWs &ws, int M, int K, int Nout, const float *A, int lda, const float *W, const float *bias,
-                     float *out, int ldo, hipStream_t st) {
+                     float *out, int ldo, hipStream_t st, float *act_out = nullptr) {
     if (d.bfc) {
-        const int rc = launch_gemm_mfma_splitk(M, K, Nout, A, lda, W, bias, nullptr, out, ldo, ws.partial, PART_CAP, st);
+        const int rc = launch_gemm_mfma_splitk(M, K, Nout, A, lda, W, bias, nullptr, out, ldo, ws.partial, PART_CAP, st, false, nullptr, act_out);
         if (rc >= 0) return rc;
     }
-    return linear(d.bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32, M, K, Nout, A, lda, W, bias, DA_ACT_NONE, nullptr, out, ldo, st);
+    const int rc = linear(d.bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32, M, K, Nout, A, lda, W, bias, DA_ACT_NONE, nullptr, out, ldo, st);
+    if (rc || !act_out) return rc;
+    return gelu_fwd((size_t)M * Nout, out, act_out, st);
 }
 
 }  // namespace da
@@ -1000,11 +1117,11 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
     hipStream_t st = (hipStream_t)stream;
     const int P = DA_PREC_F32, nr = d.nr, n = d.n, D = d.D;
     const int PL = d.bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32;          // precision code of the linear layers (storage is fp32 either way)
+    if ((rc = weight_prep(w, d, ws, st))) return rc;        // W^T / bf16 images of the step (the backward of this forward reads them too)
     if ((rc = launch_set_feats(P, nr, d.F, D, feats, ws.comb_in, st))) return rc;
     if ((rc = launch_embed_pos_time(P, nr, d.c_in, d.F, D, x, t, 0, w->steps, w->time_emb, w->pos_w0, w->pos_b0, w->pos_w1,
                                     w->pos_b1, ws.comb_in, st))) return rc;
-    if ((rc = linear_fw(d, ws, nr, D, d.hid, ws.comb_in, D, w->mlp_w0, w->mlp_b0, ws.m1pre, d.hid, st))) return rc;
-    if ((rc = gelu_fwd((size_t)nr * d.hid, ws.m1pre, ws.m1, st))) return rc;
+    if ((rc = linear_fw(d, ws, nr, D, d.hid, ws.comb_in, D, w->mlp_w0, w->mlp_b0, ws.m1pre, d.hid, st, ws.m1))) return rc;
     if ((rc = linear(PL, nr, d.hid, D, ws.m1, d.hid, w->mlp_w1, w->mlp_b1, DA_ACT_NONE, nullptr, ws.h0, D, st))) return rc;
     if (d.V > 0) {
         DA_REQUIRE(w->virt_emb, "exophormer: virt_emb missing");
@@ -1012,6 +1129,7 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
     }
     const float *xin = ws.h0;
     int ldx = D;
+    bool x16_ready = false;           // dY4 holds the bf16 image of xin
     for (int l = 0; l < d.L; ++l) {
         const bool last = l == d.L - 1;
         if (d.q16) {                                        // bf16 projection buffer (same allocation, half used)
@@ -1019,13 +1137,13 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
             // here), and the projection runs on the bf16 kernels of the inference path (W in registers / a 64-deep LDS ring
             // instead of 128 x 128 fp32 tiles re-streamed through the L2 by every column group); the products are the same
             // bf16 x bf16 -> fp32 ones.  DA_TRAIN_Q16_CAST=0: fp32 operands rounded inside the kernel (launch_gemm_mfma_mixed)
-            static int cast_on = -1;
-            if (cast_on < 0) { const char *e = getenv("DA_TRAIN_Q16_CAST"); cast_on = (e && e[0] == '0') ? 0 : 1; }
+            const int cast_on = q16_cast_on();
             rc = -1;
-            if (cast_on && ldx == d.din[l] && ((size_t)n * d.din[l]) % 8 == 0 && ((size_t)d.din[l] * 4 * d.hc[l]) % 8 == 0) {
-                if ((rc = cast_h((size_t)n * d.din[l], xin, (bf16_t *)ws.dY4, st))) return rc;
-                if ((rc = cast_h((size_t)d.din[l] * 4 * d.hc[l], w->conv_wq[l], (bf16_t *)ws.wt, st))) return rc;
-                rc = launch_gemm_mfma(DA_PREC_BF16, n, d.din[l], 4 * d.hc[l], ws.dY4, d.din[l], ws.wt, w->conv_bq[l], DA_ACT_NONE,
+            if (cast_on && ldx == d.din[l] && ((size_t)n * d.din[l]) % 8 == 0) {
+                // (the weight's bf16 image comes from k_weight_prep; the input's from the GELU launch that produced it -- x16_ready --
+                //  or, for layer 0 and the architectures without a GELU between the layers, from a cast of its own)
+                if (!x16_ready && (rc = cast_h((size_t)n * d.din[l], xin, (bf16_t *)ws.dY4, st))) return rc;
+                rc = launch_gemm_mfma(DA_PREC_BF16, n, d.din[l], 4 * d.hc[l], ws.dY4, d.din[l], ws.wh_conv[l], w->conv_bq[l], DA_ACT_NONE,
                                       nullptr, ws.qkvs[l], 4 * d.hc[l], nullptr, st);
             }
             if (rc < 0)
@@ -1046,8 +1164,12 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
                                             ws.poff, ws.node_graph, st, d.bfc))) return rc;
         } else if ((rc = launch_attn_csr(P, n, g->row_ptr, g->col_src, nullptr, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr,
                                          DA_ACT_NONE, ws.o[l], nullptr, ws.stats[l], st))) return rc;
+        x16_ready = false;
         if (!last && d.gelu_between) {
-            if ((rc = gelu_fwd((size_t)n * d.hc[l], ws.o[l], ws.hact[l], st))) return rc;
+            // q16 mode: the same launch leaves the bf16 image of the next projection's input in dY4 (scratch of the backward, idle here)
+            const bool to16 = d.q16 && q16_cast_on() && ((size_t)n * d.hc[l]) % 8 == 0 && d.hc[l] == d.din[l + 1];
+            if ((rc = gelu_fwd((size_t)n * d.hc[l], ws.o[l], ws.hact[l], st, to16 ? (bf16_t *)ws.dY4 : nullptr))) return rc;
+            x16_ready = to16;
             xin = ws.hact[l];
         } else {
             xin = ws.o[l];
@@ -1055,8 +1177,7 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
         ldx = d.hc[l];
     }
     const float *z = ws.o[d.L - 1];                           // conv output + combined (efficient_gat.py:144)
-    if ((rc = linear_fw(d, ws, nr, D, 32, z, D, w->head_w0, w->head_b0, ws.f1pre, 32, st))) return rc;
-    if ((rc = gelu_fwd((size_t)nr * 32, ws.f1pre, ws.f1, st))) return rc;
+    if ((rc = linear_fw(d, ws, nr, D, 32, z, D, w->head_w0, w->head_b0, ws.f1pre, 32, st, ws.f1))) return rc;
     return launch_head2d(P, nr, d.c_out, ws.f1, w->head_w1, w->head_b1, out, st);
 }
 
@@ -1099,12 +1220,11 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
     const bool dh0_copy = n > nr;
     if (do_early) {
     // ---- head: final_mlp.2, GELU, final_mlp.0 (efficient_gat.py:145)
-    if ((rc = linear_bwd(nr, d.c_out, 32, d_out, d.c_out, ws.f1, 32, w->head_w1, G(grads->head_w1), G(grads->head_b1),
-                         ws.df1, 32, nullptr, ws, st, d.bfc))) return rc;
-    if ((rc = gelu_bwd((size_t)nr * 32, ws.f1pre, ws.df1, ws.df1, st))) return rc;
+    if ((rc = linear_bwd(nr, d.c_out, 32, d_out, d.c_out, ws.f1, 32, ws.wt_head1, G(grads->head_w1), G(grads->head_b1),
+                         ws.df1, 32, nullptr, ws, st, d.bfc, false, ws.f1pre))) return rc;
     const float *z = ws.o[L - 1];
     if (n > nr) DA_CHECK_HIP(hipMemsetAsync(ws.dz + (size_t)nr * D, 0, (size_t)(n - nr) * D * 4, st));
-    if ((rc = linear_bwd(nr, 32, D, ws.df1, 32, z, D, w->head_w0, G(grads->head_w0), G(grads->head_b0), ws.dz, D, nullptr,
+    if ((rc = linear_bwd(nr, 32, D, ws.df1, 32, z, D, ws.wt_head0, G(grads->head_w0), G(grads->head_b0), ws.dz, D, nullptr,
                          ws, st, d.bfc))) return rc;
     // residual: z = conv_out + h0  ->  both get dz.  Without virtual rows dh0 = dz is not materialised: layer 0's dX product
     // takes dz as its residual operand and writes dh0 (dz is read-only from here on)
@@ -1124,12 +1244,10 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
         const float *xin = l == 0 ? ws.h0 : (d.gelu_between ? ws.hact[l - 1] : ws.o[l - 1]);
         float *dx = (l & 1) ? ws.dxa : ws.dxb;
         // l == 0: the input is h0, whose gradient also carries the residual branch
-        if ((rc = linear_bwd(n, 4 * hc, din, ws.dY4, 4 * hc, xin, din, w->conv_wq[l], G(grads->conv_wq[l]), G(grads->conv_bq[l]),
-                             l == 0 ? ws.dh0 : dx, din, l == 0 ? (dh0_copy ? ws.dh0 : ws.dz) : nullptr, ws, st, d.bfc, d.q16))) return rc;
-        if (l > 0) {
-            if (d.gelu_between && (rc = gelu_bwd((size_t)n * din, ws.o[l - 1], dx, dx, st))) return rc;
-            d_o = dx;
-        }
+        if ((rc = linear_bwd(n, 4 * hc, din, ws.dY4, 4 * hc, xin, din, ws.wt_conv[l], G(grads->conv_wq[l]), G(grads->conv_bq[l]),
+                             l == 0 ? ws.dh0 : dx, din, l == 0 ? (dh0_copy ? ws.dh0 : ws.dz) : nullptr, ws, st, d.bfc, d.q16,
+                             (l > 0 && d.gelu_between) ? ws.o[l - 1] : nullptr))) return rc;
+        if (l > 0) d_o = dx;
     }
     if (!do_late) return 0;
     // ---- virtual-node embedding (exophormer_gnn.py:169-178)
@@ -1139,10 +1257,9 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
         DA_LAUNCH_CHECK();
     }
     // ---- mlp.2, GELU, mlp.0 (efficient_gat.py:135)
-    if ((rc = linear_bwd(nr, D, d.hid, ws.dh0, D, ws.m1, d.hid, w->mlp_w1, G(grads->mlp_w1), G(grads->mlp_b1), ws.dm1, d.hid,
-                         nullptr, ws, st, d.bfc))) return rc;
-    if ((rc = gelu_bwd((size_t)nr * d.hid, ws.m1pre, ws.dm1, ws.dm1, st))) return rc;
-    if ((rc = linear_bwd(nr, d.hid, D, ws.dm1, d.hid, ws.comb_in, D, w->mlp_w0, G(grads->mlp_w0), G(grads->mlp_b0), ws.dcomb, D,
+    if ((rc = linear_bwd(nr, D, d.hid, ws.dh0, D, ws.m1, d.hid, ws.wt_mlp1, G(grads->mlp_w1), G(grads->mlp_b1), ws.dm1, d.hid,
+                         nullptr, ws, st, d.bfc, false, ws.m1pre))) return rc;
+    if ((rc = linear_bwd(nr, d.hid, D, ws.dm1, d.hid, ws.comb_in, D, ws.wt_mlp0, G(grads->mlp_w0), G(grads->mlp_b0), ws.dcomb, D,
                          nullptr, ws, st, d.bfc))) return rc;
     // ---- concat pieces: [feats | pos | time]
     if (d_feats) {
@@ -1154,10 +1271,9 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
     // pos_mlp (efficient_gat.py:133): Linear(c,16) GELU Linear(16,32); the hidden layer is recomputed
     k_pos_hidden<<<(nr * 16 + 255) / 256, 256, 0, st>>>(nr, d.c_in, x, w->pos_w0, w->pos_b0, ws.pa, ws.p1);
     DA_LAUNCH_CHECK();
-    if ((rc = linear_bwd(nr, 32, 16, ws.dcomb + d.F, D, ws.p1, 16, w->pos_w1, G(grads->pos_w1), G(grads->pos_b1), ws.dp1, 16,
-                         nullptr, ws, st, d.bfc))) return rc;
-    if ((rc = gelu_bwd((size_t)nr * 16, ws.pa, ws.dp1, ws.dp1, st))) return rc;
-    return linear_bwd(nr, 16, d.c_in, ws.dp1, 16, x, d.c_in, w->pos_w0, G(grads->pos_w0), G(grads->pos_b0), nullptr, 0,
+    if ((rc = linear_bwd(nr, 32, 16, ws.dcomb + d.F, D, ws.p1, 16, ws.wt_pos1, G(grads->pos_w1), G(grads->pos_b1), ws.dp1, 16,
+                         nullptr, ws, st, d.bfc, false, ws.pa))) return rc;
+    return linear_bwd(nr, 16, d.c_in, ws.dp1, 16, x, d.c_in, nullptr, G(grads->pos_w0), G(grads->pos_b0), nullptr, 0,
                       nullptr, ws, st, d.bfc);
 }
 
