@@ -65,8 +65,8 @@ int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, cons
                             const float *gelu_pre = nullptr, float *act_out = nullptr);   // da_gemm_mfma.hip; -1: shape not taken.  gelu_pre: out *= gelu'(pre); act_out = gelu(out)
 int launch_gemm_mfma_mixed(bool in16, bool out16, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
                            const void *res, void *out, int ldo, hipStream_t st);                              // fp32 x fp32 -> bf16 / bf16 x bf16 -> fp32
-int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const float *B, int ldb, float *C, int ldc, float *partial,
-                      float *db, float *bscratch, hipStream_t st, bool a16 = false);                                            // dW + db, bf16-operand mode
+int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const void *B, int ldb, float *C, int ldc, float *partial,
+                      float *db, float *bscratch, hipStream_t st, bool a16 = false, bool b16 = false);                                            // dW + db, bf16-operand mode
 int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch, hipStream_t st);   // out[c] += sum_m A[m][c]
 // da_encoder.hip: implicit-GEMM convolution over zero-haloed NHWC maps; the fp32 stem
 int launch_conv(int prec, int B, const void *X, int Cin, int Hi, const void *W, const float *bias, const void *res, void *Y,

@@ -251,6 +251,13 @@ __global__ __launch_bounds__(256) void k_tn_finish(int splits, int N, int K, con
             const size_t NKs = (size_t)N * K;
             float s = 0.f;
             int k = 0;
+            for (; k + 32 <= splits; k += 32) {               // (small outputs are cut into up to 144 row ranges: 32 loads in flight)
+                float v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = partial[(size_t)(k + u) * NKs + i];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) s += v[u];
+            }
             for (; k + 8 <= splits; k += 8) {
                 float v[8];
 #pragma unroll
@@ -264,7 +271,15 @@ __global__ __launch_bounds__(256) void k_tn_finish(int splits, int N, int K, con
         } else {
             const size_t c = i - NK;
             float q[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < splits; ++k) q[k & 3] += bpartial[(size_t)k * N + c];
+            int k = 0;
+            for (; k + 32 <= splits; k += 32) {
+                float v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = bpartial[(size_t)(k + u) * N + c];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) q[u & 3] += v[u];
+            }
+            for (; k < splits; ++k) q[k & 3] += bpartial[(size_t)k * N + c];
             db[c] += (q[0] + q[1]) + (q[2] + q[3]);
         }
     }
@@ -321,10 +336,12 @@ __device__ __forceinline__ f32x4 load_row4_h(const bf16_t *base, int ld, int row
         if (col + r < cols) v[r] = bf2f(p[r]);
     return v;
 }
-// A16: A (dY) is stored as bf16 (the q16 mode's projection gradient)
-template <bool A16>
+// A16: A (dY) is stored as bf16 (the q16 mode's projection gradient); B16: B (the layer's input X) comes as the bf16 image the forward
+// kept of it (q16 mode: the projection's own operand) -- 8 instead of 16 bytes per piece on the kernel's dominant stream (a 128 x 128
+// tile pulls 32 KB of fp32 X per 64-row stage against 16 KB of bf16 dY; the kernel moves ~0.5 GB through the L2 per call)
+template <bool A16, bool B16 = false>
 __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const void *__restrict__ Av, int lda,
-                                                    const float *__restrict__ B, int ldb, float *C, int ldc,
+                                                    const void *__restrict__ Bv, int ldb, float *C, int ldc,
                                                     float *partial, float *bpartial, int Mc, int xcd_tk) {
     constexpr int PT = 136;                                      // LDS row pitch (bf16 elements): 272 B
     constexpr int SR = 64, NU = SR / 8;                          // rows of m per stage; 8-byte / 16-byte pieces per thread, operand and stage
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const v
     const int n0 = by * 128, k0 = bx * 128;
     const int m_beg = bz * Mc, m_end = min(M, m_beg + Mc);
     const int lrow = tid >> 5, lc4 = (tid & 31) * 4;             // stage rows lrow + 8 u, columns lc4 ..+3
-    const bool vecA = (lda % 4 == 0) && (((size_t)Av & 15) == 0), vecB = (ldb % 4 == 0) && (((size_t)B & 15) == 0);
+    const bool vecA = (lda % 4 == 0) && (((size_t)Av & 15) == 0), vecB = (ldb % 4 == 0) && (((size_t)Bv & 15) == 0);
     auto pack = [](const f32x4 &v) {
         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
         const bf16x4_ b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -362,6 +379,16 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const v
             return load_row4((const float *)Av, lda, row, n0 + lc4, m_end, N, vecA);
         }
     };
+    typedef typename std::conditional<B16, tn_s16x4, f32x4>::type RB;
+    auto loadB = [&](int row) -> RB {
+        if constexpr (B16) {
+            const bf16_t *q = (const bf16_t *)Bv + (size_t)row * ldb + k0 + lc4;
+            if (row < m_end && vecB && k0 + lc4 + 3 < K) return *(const tn_s16x4 *)q;
+            return pack(load_row4_h((const bf16_t *)Bv, ldb, row, k0 + lc4, m_end, K, false));
+        } else {
+            return load_row4((const float *)Bv, ldb, row, k0 + lc4, m_end, K, vecB);
+        }
+    };
     const bool want_db = bpartial != nullptr && bx == 0;
     f32x4 acc[4][4];
 #pragma unroll
@@ -370,11 +397,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const v
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     RA ra[NU];
-    f32x4 rb[NU];
+    RB rb[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         ra[u] = loadA(m_beg + lrow + 8 * u);
-        rb[u] = load_row4(B, ldb, m_beg + lrow + 8 * u, k0 + lc4, m_end, K, vecB);
+        rb[u] = loadB(m_beg + lrow + 8 * u);
     }
     for (int m0 = m_beg; m0 < m_end; m0 += SR) {
 #pragma unroll
@@ -391,14 +418,15 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const v
                 *(tn_s16x4 *)(As + (lrow + 8 * u) * PT + lc4) = pack(ra[u]);
                 csum += ra[u];
             }
-            *(tn_s16x4 *)(Bs + (lrow + 8 * u) * PT + lc4) = pack(rb[u]);
+            if constexpr (B16) *(tn_s16x4 *)(Bs + (lrow + 8 * u) * PT + lc4) = rb[u];
+            else *(tn_s16x4 *)(Bs + (lrow + 8 * u) * PT + lc4) = pack(rb[u]);
         }
         __syncthreads();
         if (m0 + SR < m_end) {
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 ra[u] = loadA(m0 + SR + lrow + 8 * u);
-                rb[u] = load_row4(B, ldb, m0 + SR + lrow + 8 * u, k0 + lc4, m_end, K, vecB);
+                rb[u] = loadB(m0 + SR + lrow + 8 * u);
             }
         }
 #pragma unroll
@@ -448,12 +476,15 @@ __global__ __launch_bounds__(256) void k_gemm_tn_db(int M, int N, int K, const v
 }
 
 // dW (+ db) of the bf16-operand mode.  bscratch: splits * N floats
-int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const float *B, int ldb, float *C, int ldc,
-                      float *partial, float *db, float *bscratch, hipStream_t st, bool a16) {
+int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const void *B, int ldb, float *C, int ldc,
+                      float *partial, float *db, float *bscratch, hipStream_t st, bool a16, bool b16) {
+    DA_REQUIRE(!b16 || a16, "launch_gemm_tn_db: a bf16 X image is only instantiated beside a bf16 dY");
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     long splits = 640 / ((long)tn * tk);
-    const long by_rows = (M + 255) / 256, by_cap = (long)(PART_CAP / ((size_t)N * K));
+    // (one- and two-tile outputs -- the head's, pos_mlp's, mlp.2's gradients: row ranges of ONE 64-row stage, so that the launch is
+    //  one load round trip deep instead of four: 14 -> ~5 us each at 9 216 rows)
+    const long by_rows = tn * tk <= 2 ? (M + 63) / 64 : (M + 255) / 256, by_cap = (long)(PART_CAP / ((size_t)N * K));
     splits = splits > by_rows ? by_rows : splits;
     splits = splits > by_cap ? by_cap : splits;
     if (splits < 1) splits = 1;
@@ -467,7 +498,9 @@ int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const float *
     splits = (M + Mc - 1) / Mc;
     const bool xmap = xcd && splits == want;
     const dim3 grid = xmap ? dim3((unsigned)(tk * tn * splits)) : dim3((unsigned)tk, (unsigned)tn, (unsigned)splits);
-    if (a16) k_gemm_tn_db<true><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc,
+    if (a16 && b16) k_gemm_tn_db<true, true><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc,
+                                                                xmap ? tk : 0);
+    else if (a16) k_gemm_tn_db<true><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc,
                                                    xmap ? tk : 0);
     else k_gemm_tn_db<false><<<grid, 256, 0, st>>>(M, N, K, A, lda, B, ldb, C, ldc, splits == 1 ? nullptr : partial, db ? bscratch : nullptr, Mc,
                                                    xmap ? tk : 0);
@@ -845,6 +878,8 @@ struct TrainWs {
     // a dX product (fp32; bf16 for the convs in the q16 mode) and, q16 mode, the convs' bf16 forward operands
     void *wt_conv[DA_MAX_LAYERS];
     bf16_t *wh_conv[DA_MAX_LAYERS];
+    float *partial2, *dY4b;            // side-stream dW products: their own split scratch, and the second projection-gradient buffer (see SideDw)
+    bf16_t *x16[DA_MAX_LAYERS];        // q16 mode: bf16 image of every conv's input (the projection's operand in the forward, X of its dW product in the backward)
     float *wt_head1, *wt_head0, *wt_mlp1, *wt_mlp0, *wt_pos1;
     size_t total;
 };
@@ -951,12 +986,15 @@ static TrainWs carve_train(const Dims &d, void *base) {
         w.poff = (long long *)take(2 * ((size_t)d.G + 2));
         w.node_graph = (int32_t *)take(n);
     }
-    for (int l = 0; l < DA_MAX_LAYERS; ++l) { w.wt_conv[l] = nullptr; w.wh_conv[l] = nullptr; }
+    for (int l = 0; l < DA_MAX_LAYERS; ++l) { w.wt_conv[l] = nullptr; w.wh_conv[l] = nullptr; w.x16[l] = nullptr; }
     for (int l = 0; l < d.L; ++l) {
         const size_t we = (size_t)4 * d.hc[l] * d.din[l];
         w.wt_conv[l] = take(d.q16 ? (we + 1) / 2 : we);
         w.wh_conv[l] = d.q16 ? (bf16_t *)take((we + 1) / 2) : nullptr;
+        w.x16[l] = d.q16 ? (bf16_t *)take((n * d.din[l] + 1) / 2) : nullptr;
     }
+    w.partial2 = take(PART_CAP);
+    w.dY4b = take(n * 4 * hcmax);
     w.wt_head1 = take((size_t)d.c_out * 32);
     w.wt_head0 = take((size_t)32 * d.D);
     w.wt_mlp1 = take((size_t)d.D * d.hid);
@@ -1033,40 +1071,84 @@ int colsum_add(int M, int N, const float *A, int lda, float *out, float *scratch
     return 0;
 }
 
+// The weight-gradient products run BESIDE the backward's critical path (round 5).  Only dX feeds the next layer; dW = dY^T X and db
+// are leaves.  At BASELINE configuration 5 (9 216 nodes per GPU) every kernel of the step is a few hundred workgroups deep in
+// dependent load -> LDS -> MFMA stages and leaves most of the chip idle, so the leaves are issued on a side stream of the library
+// (fork: an event on the caller's stream once dY is final; join: at the end of every da_train_backward_stage call, i.e. before the
+// caller can read a gradient or start an exchange) and overlap with the dX product, the GELU backward and the next layer's attention
+// backward.  What the two streams share is kept apart: the side stream has its own split-partial scratch (partial2; csum is only
+// ever used by dW products), and the convs' projection gradient dY4 alternates between two buffers -- layer l's attention backward
+// may only overwrite the buffer of layer l + 2 after that layer's dW product has read it (done[l + 2]).  DA_TRAIN_SIDE_DW=0: everything
+// on the caller's stream, launch for launch the round-4 order.
+struct SideDw {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, done[DA_MAX_LAYERS] = {};
+};
+static SideDw *side_dw() {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("DA_TRAIN_SIDE_DW"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off) return nullptr;
+    static SideDw ctx[16];
+    static bool ok[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SideDw &c = ctx[dev & 15];
+    if (!ok[dev & 15]) {
+        if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        bool good = hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
+        for (int l = 0; l < DA_MAX_LAYERS && good; ++l) good = hipEventCreateWithFlags(&c.done[l], hipEventDisableTiming) == hipSuccess;
+        if (!good) return nullptr;
+        ok[dev & 15] = true;
+    }
+    return &c;
+}
+
 // Linear backward: dW += dY^T X, db += colsum(dY), and (if dX) dX = dY @ W (+ res); WT = the forward's image of W^T (k_weight_prep:
 // fp32, or bf16 when dy16); gelu_pre (optional, same leading dimension as dX): dX *= gelu'(gelu_pre) -- inside the reduction-split
-// product's second kernel where that route is taken, as a launch of its own otherwise
+// product's second kernel where that route is taken, as a launch of its own otherwise.  sd: the dW / db launches go to the side
+// stream (after an event that says dY is final) and `done`, if given, is recorded behind them
 static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, const void *WT,
                       float *dW, float *db, float *dX, int lddx, const float *res, TrainWs &ws, hipStream_t st, bool bfc,
-                      bool dy16 = false, const float *gelu_pre = nullptr) {
+                      bool dy16 = false, const float *gelu_pre = nullptr, const bf16_t *X16 = nullptr, SideDw *sd = nullptr,
+                      hipEvent_t done = nullptr) {
     int rc;
     auto gelu_tail = [&]() -> int { return gelu_pre ? gelu_bwd((size_t)M * K, gelu_pre, dX, dX, st) : 0; };      // (every caller's dX is dense: lddx == K)
+    hipStream_t sw = st;                                    // stream and split scratch of the dW / db launches
+    float *part = ws.partial;
+    if (sd) {
+        DA_CHECK_HIP(hipEventRecord(sd->fork, st));
+        DA_CHECK_HIP(hipStreamWaitEvent(sd->s, sd->fork, 0));
+        sw = sd->s;
+        part = ws.partial2;
+    }
+    static int tn_db = -1;
+    if (tn_db < 0) { const char *e = getenv("DA_TRAIN_TN_DB"); tn_db = (e && e[0] == '0') ? 0 : 1; }
     if (dy16) {                                             // q16 mode: dY is bf16 (written by k_attn_small_bwd)
-        if ((rc = launch_gemm_tn_db(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, db, ws.csum, st, true))) return rc;
-        if (!dX) return 0;
+        // X16: the bf16 image of X the forward's projection multiplied (dense, leading dimension K) -- the same bits the fp32 route
+        // rounds to inside the kernel
+        if ((rc = X16 ? launch_gemm_tn_db(M, N, K, dY, ldy, X16, K, dW, K, part, db, ws.csum, sw, true, true)
+                      : launch_gemm_tn_db(M, N, K, dY, ldy, X, ldx, dW, K, part, db, ws.csum, sw, true))) return rc;
+    } else if (bfc && tn_db) {                              // dW and db from one pass over dY (k_gemm_tn_db)
+        if ((rc = launch_gemm_tn_db(M, N, K, dY, ldy, X, ldx, dW, K, part, db, ws.csum, sw))) return rc;
+    } else {
+        if ((rc = launch_gemm_tn(M, N, K, dY, ldy, X, ldx, dW, K, part, sw, bfc))) return rc;
+        if (db && (rc = colsum_add(M, N, dY, ldy, db, ws.csum, sw))) return rc;
+    }
+    if (sd && done) DA_CHECK_HIP(hipEventRecord(done, sd->s));
+    if (!dX) return 0;
+    if (dy16) {
         rc = launch_gemm_mfma_splitk(M, N, K, dY, ldy, WT, nullptr, res, dX, lddx, ws.partial, PART_CAP, st, true, gelu_pre);
         if (rc >= 0) return rc;
         rc = launch_gemm_mfma_mixed(true, false, M, N, K, dY, ldy, WT, nullptr, res, dX, lddx, st);
         if (rc < 0) { set_error("training (q16): dX product %d x %d x %d not covered", M, N, K); return 1; }
         return rc ? rc : gelu_tail();
     }
-    static int tn_db = -1;
-    if (tn_db < 0) { const char *e = getenv("DA_TRAIN_TN_DB"); tn_db = (e && e[0] == '0') ? 0 : 1; }
-    if (bfc && tn_db) {                                     // dW and db from one pass over dY (k_gemm_tn_db)
-        if ((rc = launch_gemm_tn_db(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, db, ws.csum, st))) return rc;
-    } else {
-        if ((rc = launch_gemm_tn(M, N, K, dY, ldy, X, ldx, dW, K, ws.partial, st, bfc))) return rc;
-        if (db && (rc = colsum_add(M, N, dY, ldy, db, ws.csum, st))) return rc;
+    if (bfc) {                                              // skinny dX with a long reduction: split over the reduction (one launch + a fixed-order sum)
+        rc = launch_gemm_mfma_splitk(M, N, K, dY, ldy, WT, nullptr, res, dX, lddx, ws.partial, PART_CAP, st, false, gelu_pre);
+        if (rc >= 0) return rc;
     }
-    if (dX) {
-        if (bfc) {                                          // skinny dX with a long reduction: split over the reduction (one launch + a fixed-order sum)
-            rc = launch_gemm_mfma_splitk(M, N, K, dY, ldy, WT, nullptr, res, dX, lddx, ws.partial, PART_CAP, st, false, gelu_pre);
-            if (rc >= 0) return rc;
-        }
-        if ((rc = linear(bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32, M, N, K, dY, ldy, (const float *)WT, nullptr, DA_ACT_NONE, res, dX, lddx, st))) return rc;
-        return gelu_tail();
-    }
-    return 0;
+    if ((rc = linear(bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32, M, N, K, dY, ldy, (const float *)WT, nullptr, DA_ACT_NONE, res, dX, lddx, st))) return rc;
+    return gelu_tail();
 }
 
 // forward Linear of the training path: the bf16-operand mode tries the reduction-split launch first (skinny outputs with a
@@ -1117,7 +1199,17 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
     hipStream_t st = (hipStream_t)stream;
     const int P = DA_PREC_F32, nr = d.nr, n = d.n, D = d.D;
     const int PL = d.bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32;          // precision code of the linear layers (storage is fp32 either way)
-    if ((rc = weight_prep(w, d, ws, st))) return rc;        // W^T / bf16 images of the step (the backward of this forward reads them too)
+    // W^T / bf16 images of the step (the backward of this forward reads them too): on the library's side stream, beside the
+    // feature copy, the embedding and the mlp -- the first reader is conv 0's projection
+    SideDw *sd = side_dw();
+    if (sd) {
+        DA_CHECK_HIP(hipEventRecord(sd->fork, st));         // (behind the optimizer step / whatever last wrote the weights on the caller's stream)
+        DA_CHECK_HIP(hipStreamWaitEvent(sd->s, sd->fork, 0));
+    }
+    if ((rc = weight_prep(w, d, ws, sd ? sd->s : st))) return rc;
+    // (the pair offsets / node -> graph table of the grouped attention kernels: the same side stream, needed by the first attention)
+    if (sd && (d.dense || d.hybrid) && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, sd->s))) return rc;
+    if (sd) DA_CHECK_HIP(hipEventRecord(sd->join, sd->s));
     if ((rc = launch_set_feats(P, nr, d.F, D, feats, ws.comb_in, st))) return rc;
     if ((rc = launch_embed_pos_time(P, nr, d.c_in, d.F, D, x, t, 0, w->steps, w->time_emb, w->pos_w0, w->pos_b0, w->pos_w1,
                                     w->pos_b1, ws.comb_in, st))) return rc;
@@ -1127,9 +1219,10 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
         DA_REQUIRE(w->virt_emb, "exophormer: virt_emb missing");
         if ((rc = launch_set_virtual_rows(P, n - nr, d.V, D, w->virt_emb, ws.h0 + (size_t)nr * D, st))) return rc;
     }
+    if (sd) DA_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));      // the weight images are there
     const float *xin = ws.h0;
     int ldx = D;
-    bool x16_ready = false;           // dY4 holds the bf16 image of xin
+    bool x16_ready = false;           // x16[l] already holds the bf16 image of xin (written by the GELU launch of the layer before)
     for (int l = 0; l < d.L; ++l) {
         const bool last = l == d.L - 1;
         if (d.q16) {                                        // bf16 projection buffer (same allocation, half used)
@@ -1142,8 +1235,9 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
             if (cast_on && ldx == d.din[l] && ((size_t)n * d.din[l]) % 8 == 0) {
                 // (the weight's bf16 image comes from k_weight_prep; the input's from the GELU launch that produced it -- x16_ready --
                 //  or, for layer 0 and the architectures without a GELU between the layers, from a cast of its own)
-                if (!x16_ready && (rc = cast_h((size_t)n * d.din[l], xin, (bf16_t *)ws.dY4, st))) return rc;
-                rc = launch_gemm_mfma(DA_PREC_BF16, n, d.din[l], 4 * d.hc[l], ws.dY4, d.din[l], ws.wh_conv[l], w->conv_bq[l], DA_ACT_NONE,
+                if (!x16_ready && (rc = cast_h((size_t)n * d.din[l], xin, ws.x16[l], st))) return rc;
+                x16_ready = true;
+                rc = launch_gemm_mfma(DA_PREC_BF16, n, d.din[l], 4 * d.hc[l], ws.x16[l], d.din[l], ws.wh_conv[l], w->conv_bq[l], DA_ACT_NONE,
                                       nullptr, ws.qkvs[l], 4 * d.hc[l], nullptr, st);
             }
             if (rc < 0)
@@ -1155,20 +1249,20 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
         if ((rc = linear(PL, n, d.din[l], 4 * d.hc[l], xin, ldx, w->conv_wq[l], w->conv_bq[l], DA_ACT_NONE, nullptr,
                          ws.qkvs[l], 4 * d.hc[l], st))) return rc;
         if (d.dense) {
-            if (l == 0 && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
+            if (l == 0 && !sd && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
             if ((rc = dense_train_attn_fwd(g, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr, ws.o[l], ws.P[l], ws.poff,
                                            ws.node_graph, st, d.bfc, d.q16))) return rc;
         } else if (d.hybrid) {
-            if (l == 0 && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
+            if (l == 0 && !sd && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, st))) return rc;
             if ((rc = hybrid_train_attn_fwd(g, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr, ws.o[l], ws.P[l], ws.stats[l],
                                             ws.poff, ws.node_graph, st, d.bfc))) return rc;
         } else if ((rc = launch_attn_csr(P, n, g->row_ptr, g->col_src, nullptr, d.H, d.C[l], ws.qkvs[l], last ? ws.h0 : nullptr,
                                          DA_ACT_NONE, ws.o[l], nullptr, ws.stats[l], st))) return rc;
         x16_ready = false;
         if (!last && d.gelu_between) {
-            // q16 mode: the same launch leaves the bf16 image of the next projection's input in dY4 (scratch of the backward, idle here)
+            // q16 mode: the same launch leaves the bf16 image of the next projection's input in x16[l + 1] (kept for the backward's dW product)
             const bool to16 = d.q16 && q16_cast_on() && ((size_t)n * d.hc[l]) % 8 == 0 && d.hc[l] == d.din[l + 1];
-            if ((rc = gelu_fwd((size_t)n * d.hc[l], ws.o[l], ws.hact[l], st, to16 ? (bf16_t *)ws.dY4 : nullptr))) return rc;
+            if ((rc = gelu_fwd((size_t)n * d.hc[l], ws.o[l], ws.hact[l], st, to16 ? ws.x16[l + 1] : nullptr))) return rc;
             x16_ready = to16;
             xin = ws.hact[l];
         } else {
@@ -1218,14 +1312,17 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
     auto G = [](const float *p) { return (float *)p; };       // grads: same struct, written by the library
 
     const bool dh0_copy = n > nr;
+    SideDw *sd = side_dw();             // null: DA_TRAIN_SIDE_DW=0
+    static int dw_x16 = -1;             // DA_TRAIN_DW_X16=1: the convs' dW products read the bf16 image of X (measured slower: 69 vs 63 us at conv 3)
+    if (dw_x16 < 0) { const char *e = getenv("DA_TRAIN_DW_X16"); dw_x16 = (e && e[0] == '1') ? 1 : 0; }
     if (do_early) {
     // ---- head: final_mlp.2, GELU, final_mlp.0 (efficient_gat.py:145)
     if ((rc = linear_bwd(nr, d.c_out, 32, d_out, d.c_out, ws.f1, 32, ws.wt_head1, G(grads->head_w1), G(grads->head_b1),
-                         ws.df1, 32, nullptr, ws, st, d.bfc, false, ws.f1pre))) return rc;
+                         ws.df1, 32, nullptr, ws, st, d.bfc, false, ws.f1pre, nullptr, sd))) return rc;
     const float *z = ws.o[L - 1];
     if (n > nr) DA_CHECK_HIP(hipMemsetAsync(ws.dz + (size_t)nr * D, 0, (size_t)(n - nr) * D * 4, st));
     if ((rc = linear_bwd(nr, 32, D, ws.df1, 32, z, D, ws.wt_head0, G(grads->head_w0), G(grads->head_b0), ws.dz, D, nullptr,
-                         ws, st, d.bfc))) return rc;
+                         ws, st, d.bfc, false, nullptr, nullptr, sd))) return rc;
     // residual: z = conv_out + h0  ->  both get dz.  Without virtual rows dh0 = dz is not materialised: layer 0's dX product
     // takes dz as its residual operand and writes dh0 (dz is read-only from here on)
     if (dh0_copy) DA_CHECK_HIP(hipMemcpyAsync(ws.dh0, ws.dz, (size_t)n * D * 4, hipMemcpyDeviceToDevice, st));
@@ -1233,23 +1330,36 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
 
     // ---- graph transformer layers, last to first (EARLY: L-1 .. 1; LATE: 0, whose incoming gradient is layer 1's dX buffer)
     const float *d_o = do_early ? ws.dz : (L > 1 ? ws.dxa : ws.dz);
-    for (int l = do_early ? L - 1 : 0; l >= (do_late ? 0 : 1); --l) {
+    const int l_first = do_early ? L - 1 : 0;
+    for (int l = l_first; l >= (do_late ? 0 : 1); --l) {
         const int hc = d.hc[l], din = d.din[l];
+        // this layer's projection gradient: the two buffers alternate, and the one about to be overwritten was last read by layer
+        // l + 2's dW product on the side stream
+        float *dY4 = (sd && ((L - 1 - l) & 1)) ? ws.dY4b : ws.dY4;
+        if (sd && l + 2 <= l_first) DA_CHECK_HIP(hipStreamWaitEvent(st, sd->done[l + 2], 0));
         if (d.dense) {
-            if ((rc = dense_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.dY4, ws.poff, ws.node_graph, st, d.bfc, d.q16))) return rc;
+            if ((rc = dense_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, dY4, ws.poff, ws.node_graph, st, d.bfc, d.q16))) return rc;
         } else if (d.hybrid) {
-            if ((rc = hybrid_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.stats[l], ws.Dd, ws.dY4, ws.poff,
+            if ((rc = hybrid_train_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.P[l], ws.dP, ws.stats[l], ws.Dd, dY4, ws.poff,
                                             ws.node_graph, st, d.bfc, ws.o[l], l == L - 1 ? ws.h0 : nullptr))) return rc;
-        } else if ((rc = launch_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.stats[l], ws.Dd, ws.dY4, st))) return rc;
+        } else if ((rc = launch_attn_bwd(g, d.H, d.C[l], ws.qkvs[l], d_o, ws.stats[l], ws.Dd, dY4, st))) return rc;
         const float *xin = l == 0 ? ws.h0 : (d.gelu_between ? ws.hact[l - 1] : ws.o[l - 1]);
         float *dx = (l & 1) ? ws.dxa : ws.dxb;
         // l == 0: the input is h0, whose gradient also carries the residual branch
-        if ((rc = linear_bwd(n, 4 * hc, din, ws.dY4, 4 * hc, xin, din, ws.wt_conv[l], G(grads->conv_wq[l]), G(grads->conv_bq[l]),
+        if ((rc = linear_bwd(n, 4 * hc, din, dY4, 4 * hc, xin, din, ws.wt_conv[l], G(grads->conv_wq[l]), G(grads->conv_bq[l]),
                              l == 0 ? ws.dh0 : dx, din, l == 0 ? (dh0_copy ? ws.dh0 : ws.dz) : nullptr, ws, st, d.bfc, d.q16,
-                             (l > 0 && d.gelu_between) ? ws.o[l - 1] : nullptr))) return rc;
+                             (l > 0 && d.gelu_between) ? ws.o[l - 1] : nullptr,
+                             (dw_x16 && d.q16 && q16_cast_on() && ((size_t)n * din) % 8 == 0) ? ws.x16[l] : nullptr,      // (the forward's condition for writing it)
+                             sd, sd ? sd->done[l] : nullptr))) return rc;
         if (l > 0) d_o = dx;
     }
-    if (!do_late) return 0;
+    auto join_side = [&]() -> int {         // the caller's stream continues behind every dW / db launch of this call
+        if (!sd) return 0;
+        DA_CHECK_HIP(hipEventRecord(sd->join, sd->s));
+        DA_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));
+        return 0;
+    };
+    if (!do_late) return join_side();
     // ---- virtual-node embedding (exophormer_gnn.py:169-178)
     if (d.V > 0) {
         DA_REQUIRE(grads->virt_emb, "exophormer: virt_emb gradient pointer missing");
@@ -1258,9 +1368,9 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
     }
     // ---- mlp.2, GELU, mlp.0 (efficient_gat.py:135)
     if ((rc = linear_bwd(nr, D, d.hid, ws.dh0, D, ws.m1, d.hid, ws.wt_mlp1, G(grads->mlp_w1), G(grads->mlp_b1), ws.dm1, d.hid,
-                         nullptr, ws, st, d.bfc, false, ws.m1pre))) return rc;
+                         nullptr, ws, st, d.bfc, false, ws.m1pre, nullptr, sd))) return rc;
     if ((rc = linear_bwd(nr, d.hid, D, ws.dm1, d.hid, ws.comb_in, D, ws.wt_mlp0, G(grads->mlp_w0), G(grads->mlp_b0), ws.dcomb, D,
-                         nullptr, ws, st, d.bfc))) return rc;
+                         nullptr, ws, st, d.bfc, false, nullptr, nullptr, sd))) return rc;
     // ---- concat pieces: [feats | pos | time]
     if (d_feats) {
         k_copy_cols<<<grid_for((size_t)nr * d.F), 256, 0, st>>>(nr, d.F, ws.dcomb, D, d_feats);
@@ -1272,9 +1382,10 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
     k_pos_hidden<<<(nr * 16 + 255) / 256, 256, 0, st>>>(nr, d.c_in, x, w->pos_w0, w->pos_b0, ws.pa, ws.p1);
     DA_LAUNCH_CHECK();
     if ((rc = linear_bwd(nr, 32, 16, ws.dcomb + d.F, D, ws.p1, 16, ws.wt_pos1, G(grads->pos_w1), G(grads->pos_b1), ws.dp1, 16,
-                         nullptr, ws, st, d.bfc, false, ws.pa))) return rc;
-    return linear_bwd(nr, 16, d.c_in, ws.dp1, 16, x, d.c_in, nullptr, G(grads->pos_w0), G(grads->pos_b0), nullptr, 0,
-                      nullptr, ws, st, d.bfc);
+                         nullptr, ws, st, d.bfc, false, ws.pa, nullptr, sd))) return rc;
+    if ((rc = linear_bwd(nr, 16, d.c_in, ws.dp1, 16, x, d.c_in, nullptr, G(grads->pos_w0), G(grads->pos_b0), nullptr, 0,
+                         nullptr, ws, st, d.bfc, false, nullptr, nullptr, sd))) return rc;
+    return join_side();
 }
 
 }  // extern "C"

@@ -402,6 +402,32 @@ __device__ __forceinline__ void as_stage(const void *X, size_t e0, int ld, int n
         }
     }
 }
+// NI images staged in ONE load round trip (narrow heads: np * kq <= 2 * 640 pieces per image): every image's pieces are requested
+// before the first LDS store (as_stage per image = one global-load round trip per image, the stores of image k waiting in front
+// of the loads of image k + 1)
+template <int CT, bool Q16, int NI>
+__device__ __forceinline__ void as_stage_multi(const void *X, const size_t (&e0)[NI], int ld, int n_g, int np, int C,
+                                               unsigned short *const (&R)[NI], int tid) {
+    constexpr int kq = CT * 4, pr = CT * 16 + 8, NB = 2;
+    for (int i0 = tid; i0 < np * kq; i0 += 64 * AS_WAVES * NB) {
+        as_s16x4 v[NI][NB];
+#pragma unroll
+        for (int im = 0; im < NI; ++im)
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int idx = i0 + u * 64 * AS_WAVES, r = idx / kq, k = (idx - r * kq) * 4;
+                v[im][u] = (as_s16x4){0, 0, 0, 0};
+                if (r < n_g && k < C) v[im][u] = as_ld_pack<Q16>(X, e0[im] + (size_t)r * ld + k);
+            }
+#pragma unroll
+        for (int im = 0; im < NI; ++im)
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int idx = i0 + u * 64 * AS_WAVES, r = idx / kq, k = (idx - r * kq) * 4;
+                if (idx < np * kq) *(as_s16x4 *)(R[im] + r * pr + k) = v[im][u];
+            }
+    }
+}
 // the 16 rows [r0, r0 + 16) as B (or A) fragments straight from memory: lane (l15, lg) takes row r0 + l15, columns 16 kt + 4 lg ..+3
 template <int CT, bool Q16>
 __device__ __forceinline__ void as_band(const void *X, size_t e0, int ld, int n_g, int C, int r0, int l15, int lg, as_s16x4 (&f)[CT]) {
@@ -420,6 +446,10 @@ __device__ __forceinline__ as_s16x4 as_tr(const unsigned short *img, int pr, int
         (__attribute__((address_space(3))) as_s16x4 *)(img + (r0 + 4 * lg + (l15 >> 2)) * pr + c0 + 4 * (l15 & 3)));
 }
 #define AS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+
+// e^x as one v_exp_f32 (2^(x log2 e): ~2 ulp; libm's expf costs a dozen vector instructions per call and these kernels issue ~80 per
+// lane -- they only run in the bf16-operand mode, where P is rounded to 8 bits of mantissa right after)
+__device__ __forceinline__ float as_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 // scores of one query band against every key, transposed tiles: s[tn][r] = score(query i, key 16 tn + 4 lg + r); softmax over
 // the band's rows in place (s becomes exp(s - max)); returns (max, 1 / (sum + 1e-16)) of this lane's query (PyG's softmax)
@@ -442,7 +472,7 @@ __device__ __forceinline__ void as_softmax(f32x4 (&s)[AS_TN], int tn_n, int n_g,
     for (int tn = 0; tn < AS_TN; ++tn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            s[tn][r] = (mx > -INFINITY) ? expf(s[tn][r] - mx) : 0.f;
+            s[tn][r] = (mx > -INFINITY) ? as_exp(s[tn][r] - mx) : 0.f;
             sum += s[tn][r];
         }
     sum += __shfl_xor(sum, 16);
@@ -461,11 +491,17 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_fwd(AttnSmall p) {
     unsigned short *Ks = as_lds, *Vs = Ks + np * pr;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, lg = lane >> 4;
     const size_t e0 = (size_t)n0 * ld + h * C;                         // element offset of (node n0, head h) in the projection buffer
-    as_stage<CT, Q16>(p.qkvs, e0 + p.HC, ld, n_g, np, C, Ks, tid);
-    as_stage<CT, Q16>(p.qkvs, e0 + 2 * p.HC, ld, n_g, np, C, Vs, tid);
     const int tn_n = (n_g + 15) >> 4;
     as_s16x4 qf[CT];
-    if (wid < tn_n) as_band<CT, Q16>(p.qkvs, e0, ld, n_g, C, wid * 16, l15, lg, qf);
+    if (wid < tn_n) as_band<CT, Q16>(p.qkvs, e0, ld, n_g, C, wid * 16, l15, lg, qf);       // (requested first: in flight under the staging)
+    if constexpr (CT <= 2) {
+        const size_t es[2] = {e0 + p.HC, e0 + 2 * p.HC};
+        unsigned short *const im[2] = {Ks, Vs};
+        as_stage_multi<CT, Q16, 2>(p.qkvs, es, ld, n_g, np, C, im, tid);
+    } else {
+        as_stage<CT, Q16>(p.qkvs, e0 + p.HC, ld, n_g, np, C, Ks, tid);
+        as_stage<CT, Q16>(p.qkvs, e0 + 2 * p.HC, ld, n_g, np, C, Vs, tid);
+    }
     __syncthreads();
     for (int tm = wid; tm < tn_n; tm += AS_WAVES) {                    // (one band per wave: n_g <= 160)
         const int i = tm * 16 + l15;                                   // this lane's query
@@ -532,22 +568,34 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, lg = lane >> 4;
     const size_t e0 = (size_t)n0 * ld + h * C;                         // (node n0, head h) in the projection buffer and in dY4
     const size_t g0 = (size_t)n0 * p.HC + h * C;                       // ... in d_o
-    as_stage<CT, Q16>(p.qkvs, e0 + p.HC, ld, n_g, np, C, I0, tid);
-    as_stage<CT, Q16>(p.qkvs, e0 + 2 * p.HC, ld, n_g, np, C, I1, tid);
     const int tn_n = (n_g + 15) >> 4;
     if constexpr (ALL4) {
-        as_stage<CT, Q16>(p.qkvs, e0, ld, n_g, np, C, J0, tid);
-        // dO image + its copy = the skip projection's gradient (columns 3 HC .. of dY4)
+        // the dO pieces are requested first and the three projection images behind them: ONE load round trip for all four images
+        // (np * kq <= 2 * 640 pieces per image at CT <= 2)
         constexpr int kq = CT * 4;
-        for (int idx = tid; idx < np * kq; idx += 64 * AS_WAVES) {
-            const int r = idx / kq, k = (idx - r * kq) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < n_g && k < C) {
-                v = *(const f32x4 *)(p.d_o + g0 + (size_t)r * p.HC + k);
-                as_st4<Q16>(p.dY4, e0 + 3 * p.HC + (size_t)r * ld + k, v);
-            }
-            *(as_s16x4 *)(J1 + r * pr + k) = as_pack(v[0], v[1], v[2], v[3]);
+        static_assert(AS_MAXN * kq <= 2 * 64 * AS_WAVES, "two dO pieces per thread");
+        f32x4 dv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * 64 * AS_WAVES, r = idx / kq, k = (idx - r * kq) * 4;
+            dv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (r < n_g && k < C) dv[u] = *(const f32x4 *)(p.d_o + g0 + (size_t)r * p.HC + k);
         }
+        const size_t es[3] = {e0 + p.HC, e0 + 2 * p.HC, e0};
+        unsigned short *const im[3] = {I0, I1, J0};
+        as_stage_multi<CT, Q16, 3>(p.qkvs, es, ld, n_g, np, C, im, tid);
+        // dO image + its copy = the skip projection's gradient (columns 3 HC .. of dY4)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * 64 * AS_WAVES, r = idx / kq, k = (idx - r * kq) * 4;
+            if (idx < np * kq) {
+                if (r < n_g && k < C) as_st4<Q16>(p.dY4, e0 + 3 * p.HC + (size_t)r * ld + k, dv[u]);
+                *(as_s16x4 *)(J1 + r * pr + k) = as_pack(dv[u][0], dv[u][1], dv[u][2], dv[u][3]);
+            }
+        }
+    } else {
+        as_stage<CT, Q16>(p.qkvs, e0 + p.HC, ld, n_g, np, C, I0, tid);
+        as_stage<CT, Q16>(p.qkvs, e0 + 2 * p.HC, ld, n_g, np, C, I1, tid);
     }
     // ---- phase A: query bands (one per wave)
     {
@@ -666,7 +714,7 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
             for (int r = 0; r < 4; ++r) {
                 const int i = ti * 16 + 4 * lg + r;
                 const bool ok = i < n_g && j < n_g && !(p.nodiag && j == i) && m4[r] > -INFINITY;
-                pv[r] = ok ? bf2f(f2bf(expf(p.scale * s4[r] - m4[r]) * i4[r])) : 0.f;
+                pv[r] = ok ? bf2f(f2bf(as_exp(p.scale * s4[r] - m4[r]) * i4[r])) : 0.f;
                 dsv[r] = pv[r] * (d4[r] - D4[r]);
             }
             const as_s16x4 pa = as_pack(pv[0], pv[1], pv[2], pv[3]), dsa = as_pack(dsv[0], dsv[1], dsv[2], dsv[3]);

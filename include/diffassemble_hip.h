@@ -378,7 +378,14 @@ int da_debug_counters(int64_t *out /* host [n] */, int n, int reset);
  *   d_feats nullable [n_real, F]: gradient w.r.t. the piece features, for a trainable encoder.
  * Only the 2D denoiser (arch transformer / exophormer) is implemented; any graph type, through
  * the CSR attention kernels (needs g->out_ptr / g->out_dst).  The forward must precede the
- * backward on the same workspace.
+ * backward on the same workspace, with the same weights: besides the activations it leaves the
+ * step's weight images there (W^T of every Linear with a dX product; bf16 copies in the bf16 mode),
+ * which the backward reads instead of transposing again.
+ * Streams: the calls enqueue on `stream`; the weight-gradient products (leaves of the backward)
+ * and the forward's weight images run on ONE side stream owned by the library (forked behind an
+ * event on `stream`, joined before the call returns control of the gradients: when a forward /
+ * backward / backward_stage call returns, everything it enqueued is ordered before whatever the
+ * caller enqueues on `stream` next).  DA_TRAIN_SIDE_DW=0 keeps every launch on `stream`.
  * ------------------------------------------------------------------------------------- */
 size_t da_train_workspace_bytes(const da_weights *w, const da_graph *g);
 /* ABI 18: the size for ONE mode (da_train_workspace_bytes = the exact-fp32 mode's, the larger one).  Hybrid graphs in the
