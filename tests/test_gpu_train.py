@@ -608,6 +608,76 @@ def test_flash_style_hybrid_training_equals_the_pair_matrix_route(dev, tmp_path,
     assert res["flash"]["ws_bytes"] < res["pairs"]["ws_bytes"] or sides != [30]
 
 
+_SIDE_WORKER = r"""
+import os, sys, json, numpy as np, torch
+sys.path.insert(0, os.environ["DA_ROOT"]); sys.path.insert(0, os.path.join(os.environ["DA_ROOT"], "tests", "golden"))
+from oracle import weights as W
+from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
+from diffassemble_amd import expander
+dev = torch.device("cuda:0")
+exo = os.environ["SIDE_ARCH"] == "exophormer"; V = 8
+if exo:
+    ei, batch, degs = expander.ragged_regular_batch([12, 16, 6, 10], 60, np.random.default_rng(4), dev)
+else:
+    sizes = [144, 100, 144, 36, 121]
+    idx = [torch.arange(n_) for n_ in sizes]
+    off = np.cumsum([0] + sizes)
+    ei = torch.cat([torch.stack(torch.meshgrid(i, i, indexing="ij")).reshape(2, -1) + int(o) for i, o in zip(idx, off)], 1).to(dev)
+    batch = torch.cat([torch.full((n_,), g_, dtype=torch.long) for g_, n_ in enumerate(sizes)]).to(dev)
+n = int(batch.numel()); G = int(batch.max()) + 1
+sd = W.make_denoiser_state(100, 4, 4, seed=67, qk_gain=3.0, **(dict(arch="exophormer", virt_nodes=V) if exo else {}))
+g = torch.Generator().manual_seed(8)
+x = torch.randn(n, 4, generator=g).to(dev); feats = torch.randn(n, 1088, generator=g).to(dev)
+m = GNN_Diffusion(steps=100, sampling="DDIM", rotation=True, visual_pretrained=False, model_mean_type=ModelMeanType.EPSILON,
+                  **(dict(architecture="exophormer", virt_nodes=V) if exo else {}))
+m.model.load_state_dict(sd, strict=False)
+m = m.to(dev).train()
+te = m.model.train_engine(dev); te.precision = os.environ["SIDE_PREC"]
+if os.environ.get("SIDE_STAGED") == "1":
+    te.force_staged = True                      # the two halves of da_train_backward_stage, no process group
+losses = []
+for k in range(2):                              # two accumulated micro-batches: the second backward ADDS into the first's gradients
+    noise = torch.randn(n, 4, generator=g).to(dev)
+    t = torch.randint(0, 100, (G,), generator=g).to(dev)[batch]
+    loss = m.p_losses(x, t, noise=noise, loss_type="huber", cond=None, edge_index=ei, batch=batch, patch_feats=feats)
+    loss.backward(); losses.append(float(loss))
+torch.cuda.synchronize()
+base = te.flat.data_ptr()
+temb = [((v.data_ptr() - base) // 4, v.numel()) for n_, v in zip(te.names, te.views) if n_ == "time_emb.weight"][0]
+torch.save({"loss": losses, "grad": te.flat_grad.cpu(), "time_emb": temb}, os.environ["SIDE_OUT"])
+"""
+
+
+@pytest.mark.parametrize("arch,prec,staged", [("transformer", "bf16", "0"), ("transformer", "fp32", "0"), ("transformer", "bf16", "1"),
+                                              ("exophormer", "bf16", "0"), ("exophormer", "fp32", "1")])
+def test_side_stream_weight_gradients_are_bit_identical(dev, tmp_path, arch, prec, staged):
+    """Round 5: the dW / db products of the backward and the forward's weight images run on a side stream of the library
+    (SideDw, da_train.hip) beside the dX / attention-backward chain.  Same kernels, same operands, same summation orders --
+    the accumulated gradients of two backward passes must equal the one-stream schedule's (DA_TRAIN_SIDE_DW=0, read once per
+    process: hence the subprocesses) BIT FOR BIT, on complete and on hybrid graphs, in both precisions, with the backward
+    in one call and in its two stages."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("side", {}), ("one", dict(DA_TRAIN_SIDE_DW="0"))):
+        out = str(tmp_path / f"{tag}.pt")
+        e = dict(os.environ, DA_ROOT=ROOT, SIDE_ARCH=arch, SIDE_PREC=prec, SIDE_STAGED=staged, SIDE_OUT=out, **env)
+        r = subprocess.run([sys.executable, "-c", _SIDE_WORKER], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[tag] = torch.load(out)
+    assert res["side"]["loss"] == res["one"]["loss"]
+    gs, go = res["side"]["grad"].clone(), res["one"]["grad"].clone()
+    assert float(go.abs().max()) > 0
+    # (time_emb's rows are added with atomics by k_time_scatter -- in either schedule: equal to rounding, not to the bit)
+    o, k = res["one"]["time_emb"]
+    assert float((gs[o:o + k].double() - go[o:o + k].double()).abs().max()) <= 1e-6 * float(go[o:o + k].abs().max()) + 1e-12
+    gs[o:o + k] = 0
+    go[o:o + k] = 0
+    assert torch.equal(gs, go), float((gs.double() - go.double()).abs().max())
+
+
 # ---------------------------------------------------------------------------- data parallelism through the module surface
 def _dp_train_worker(rank, world, port, ret):
     """One data-parallel rank (both ranks share cuda:0, so the group is gloo; on the 8-GPU node it is nccl = RCCL):

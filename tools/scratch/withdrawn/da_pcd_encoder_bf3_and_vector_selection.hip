@@ -157,15 +157,21 @@ __device__ __forceinline__ void select_set(float *row, int Npad, int N, int k, i
     unsigned m = u[0];
 #pragma unroll
     for (int r = 1; r < NR; ++r) m = max(m, u[r]);
-    unsigned L = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned cand = L | (1u << bit);
-        const int c = __builtin_popcountll(__ballot(m >= cand));
-        if (c >= k) {
-            L = cand;
-            if (c <= k + 2) break;                      // (nearly) as tight as lane maxima get
-        }
+    // L = the k-th largest of the 64 lane maxima, by COUNTING on the vector side (round 5): lane l counts the lane maxima >= its own
+    // (64 x readlane + compare + add-with-carry, no scalar arithmetic), the lanes that count >= k hold candidates, L is the largest of
+    // them.  The bit search this replaces (32 rounds of compare -> s_bcnt1 -> s_cmp -> s_cselect on the ballot masks, ~11 scalar
+    // instructions a round) and the rank loop below were ~1 000 scalar instructions per query on a scalar unit the CU's 16 waves
+    // share: the selection ran at that unit's rate (SQ_INSTS_SALU 1.6x SQ_INSTS_VALU).  The exact k-th maximum is also a tighter
+    // bound than the search's early exit gave: fewer candidates to rank.
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const unsigned mj = (unsigned)__builtin_amdgcn_readlane((int)m, j);
+        cnt += mj >= m ? 1 : 0;
     }
+    unsigned L = cnt >= k ? m : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) L = max(L, (unsigned)__shfl_xor((int)L, o));
     unsigned *ck = (unsigned *)row;
     int *ci = (int *)row + 128;
     int ct = 0;
@@ -185,9 +191,21 @@ __device__ __forceinline__ void select_set(float *row, int Npad, int N, int k, i
     const int i0 = ci[lane], i1 = ci[lane + 64];
     int r0 = 0, r1 = 0;
     if (ct <= 64) {
+        // rank = the number of larger keys; equal keys (ties between two of the ~k best candidates: rare) are counted beside them and
+        // send the wave through the exact tie rule below -- the common path has no mask arithmetic on the scalar side
+        int eq = 0;
+#pragma unroll 4
         for (int j = 0; j < ct; ++j) {
             const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)c0, j);
-            r0 += (kj > c0 || (kj == c0 && j < lane)) ? 1 : 0;
+            r0 += kj > c0 ? 1 : 0;
+            eq += kj == c0 ? 1 : 0;
+        }
+        if (__any(lane < ct && eq > 1)) {
+            r0 = 0;
+            for (int j = 0; j < ct; ++j) {
+                const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)c0, j);
+                r0 += (kj > c0 || (kj == c0 && j < lane)) ? 1 : 0;
+            }
         }
     } else {
         for (int j = 0; j < ct; ++j) {
@@ -383,6 +401,108 @@ __global__ __launch_bounds__(1024) void k_pcd_knn64_mfma(const float *__restrict
     }
     __syncthreads();
     for (int q = wave; q < 32 && q0 + q < N; q += 16) {
+        float *row = score + q * RS;
+        int32_t *dst = idx + ((size_t)cloud * N + q0 + q) * k;
+        if (Npad <= 256) select_set<4>(row, Npad, N, k, lane, dst);
+        else if (Npad <= 512) select_set<8>(row, Npad, N, k, lane, dst);
+        else select_set<16>(row, Npad, N, k, lane, dst);
+    }
+}
+
+// The same search with the Gram matrix on the bf16 matrix cores, EXACT to fp32 rounding (round 5): every fp32 value is the sum of
+// three bf16 pieces (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 8 + 8 + 8 mantissa bits, the two subtractions are
+// exact in fp32), a product of two pieces is exact in the fp32 accumulator, and the six products hi hi, hi mid, mid hi, hi lo, lo hi,
+// mid mid carry x y to 2^-24 relative -- what one fp32 rounding of the product costs.  24 v_mfma_f32_32x32x16_bf16 (768 matrix
+// cycles) replace the 32 v_mfma_f32_32x32x2_f32 (2 048) of a 32 x 32 x 64 tile.  The pieces are made once per cloud row
+// (k_pcd_split3: [row][hi 64 | mid 64 | lo 64] bf16), not per tile.  The k index of an MFMA step is a permutation both operands
+// share: lane (row, kk) feeds elements [32 kk + 8 s, +8) of its row in step s.  The small terms are added first.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8k;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4k;
+__global__ __launch_bounds__(256) void k_pcd_split3(const float *__restrict__ X, long long rows, unsigned short *__restrict__ P3) {
+    // thread = 4 consecutive floats of a row
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * (VROW / 4)) return;
+    const long long r = i / (VROW / 4);
+    const int c = (int)(i - r * (VROW / 4)) * 4;
+    const float4 v = *(const float4 *)(X + r * VROW + c);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned short h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = f2bf(x[e]);
+        const float r1 = x[e] - bf2f(h[e]);
+        m[e] = f2bf(r1);
+        l[e] = f2bf(r1 - bf2f(m[e]));
+    }
+    unsigned short *o = P3 + r * (3 * VROW) + c;
+    *(uint2 *)(o) = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+    *(uint2 *)(o + VROW) = uint2{(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
+    *(uint2 *)(o + 2 * VROW) = uint2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+}
+
+// QB = queries per block: 32 (one 1024-thread block per CU on its 129 KB slab) or 16 (512 threads, a 66 KB slab: TWO blocks per CU,
+// so that one block's selection -- a chain of scalar-dependent rounds -- runs beside the other's loads and MFMAs; within one block
+// the two phases are separated by a barrier and the block owns the CU's LDS).  With 16 queries the upper half of every 32-wide
+// MFMA tile is padding (the lanes re-read query rows 0 .. 15; their scores are not stored).
+template <int QB>
+__global__ __launch_bounds__(QB * 32) void k_pcd_knn64_bf3(const unsigned short *__restrict__ P3, const float *__restrict__ XN, int N, int Npad, int k,
+                                                           int32_t *__restrict__ idx) {
+    constexpr int NT = QB * 32, NW = NT / 64;
+    extern __shared__ float smem[];
+    const int RS = Npad + 4;                              // score row stride (floats)
+    float *score = smem, *cxx = score + QB * RS, *qxx = cxx + Npad;
+    const int cloud = blockIdx.y, q0 = blockIdx.x * QB, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned short *Pc = P3 + (size_t)cloud * N * (3 * VROW);
+    const float *XNc = XN + (size_t)cloud * N;
+    for (int j = tid; j < Npad + QB; j += NT) {
+        if (j < Npad) cxx[j] = XNc[min(j, N - 1)];
+        else qxx[j - Npad] = XNc[min(q0 + j - Npad, N - 1)];
+    }
+    const int rl = lane & 31, kk = lane >> 5;
+    // pieces [plane][step] of a row: 8 bf16 = 16 bytes each
+    auto load_row = [&](u32x4k (&f)[3][4], int row) {
+        const unsigned short *r = Pc + (size_t)min(row, N - 1) * (3 * VROW) + 32 * kk;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) f[pl][st] = *(const u32x4k *)(r + pl * VROW + 8 * st);
+    };
+    u32x4k qf[3][4];
+    const int ql = rl & (QB - 1);                         // this lane's query (QB = 16: lanes 16 .. 31 of a half repeat 0 .. 15)
+    load_row(qf, q0 + ql);
+    __syncthreads();
+    const float nq = -qxx[ql];
+    for (int c0 = wave * 32; c0 < Npad; c0 += NW * 32) {
+        u32x4k cf[3][4];
+        load_row(cf, c0 + rl);
+        f32x16k acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        auto mm = [&](int pa, int pb) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8k, cf[pa][st]), __builtin_bit_cast(bf16x8k, qf[pb][st]), acc, 0, 0, 0);
+        };
+        mm(1, 1); mm(2, 0); mm(0, 2); mm(1, 0); mm(0, 1); mm(0, 0);
+        // lane (query rl, half kk) holds candidates c0 + 8 a + 4 kk + b in acc[4 a + b]
+        if (rl < QB) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int cb = c0 + 8 * a + 4 * kk;
+                const float4 cx = *(const float4 *)(cxx + cb);
+                float o[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float sc = (nq - (-2.f * acc[4 * a + b])) - (b == 0 ? cx.x : b == 1 ? cx.y : b == 2 ? cx.z : cx.w);
+                    o[b] = cb + b < N ? (fabsf(sc) <= FLT_MAX ? sc + 0.f : -FLT_MAX) : -INFINITY;   // NaN / inf rank last, the padding after them
+                }
+                *(float4 *)(score + rl * RS + cb) = float4{o[0], o[1], o[2], o[3]};
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = wave; q < QB && q0 + q < N; q += NW) {
         float *row = score + q * RS;
         int32_t *dst = idx + ((size_t)cloud * N + q0 + q) * k;
         if (Npad <= 256) select_set<4>(row, Npad, N, k, lane, dst);
@@ -633,11 +753,30 @@ __global__ __launch_bounds__(256) void k_nearest_sq(const float *__restrict__ a,
 }
 
 static int knn_launch(int clouds, int N, int dim, const float *x, int ldx, int k, int ordered, int32_t *idx, hipStream_t st,
-                      const float *xn = nullptr) {
+                      const float *xn = nullptr, unsigned short *p3 = nullptr) {
     const int F = dim <= 3 ? 3 : 64;
     const int Npad = (N + 63) & ~63;
     static int mfma_knn = -1;
     if (mfma_knn < 0) { const char *e = getenv("DA_PCD_KNN_VALU"); mfma_knn = (e && e[0] == '1') ? 0 : 1; }
+    static int bf3 = -1;                                    // DA_PCD_KNN_BF3=0: exact-fp32 MFMAs (round 3's kernel)
+    if (bf3 < 0) { const char *e = getenv("DA_PCD_KNN_BF3"); bf3 = (e && e[0] == '0') ? 0 : 1; }
+    if (F == 64 && !ordered && ldx == VROW && Npad <= 1024 && mfma_knn && xn && p3 && bf3) {
+        static int qb = -1;                                 // DA_PCD_KNN_QB=32: one 32-query block per CU
+        if (qb < 0) { const char *e = getenv("DA_PCD_KNN_QB"); qb = (e && atoi(e) == 32) ? 32 : 16; }
+        const size_t lds = (size_t)(qb * (Npad + 4) + Npad + qb) * sizeof(float);
+        static bool attrb = false;
+        if (!attrb) {
+            DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn64_bf3<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+            DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_pcd_knn64_bf3<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 - 512));
+            attrb = true;
+        }
+        const long long rows = (long long)clouds * N;
+        k_pcd_split3<<<(unsigned)((rows * (VROW / 4) + 255) / 256), 256, 0, st>>>(x, rows, p3);
+        if (qb == 32) k_pcd_knn64_bf3<32><<<dim3((N + 31) / 32, clouds), 1024, lds, st>>>(p3, xn, N, Npad, k, idx);
+        else k_pcd_knn64_bf3<16><<<dim3((N + 15) / 16, clouds), 512, lds, st>>>(p3, xn, N, Npad, k, idx);
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
     if (F == 64 && !ordered && ldx == VROW && Npad <= 1024 && mfma_knn && xn) {
         const size_t lds = (size_t)(32 * (Npad + 4) + Npad + 32) * sizeof(float);
         static bool attrm = false;
@@ -707,7 +846,7 @@ int da_nearest_sq(int n_clouds, int n, int m, const float *a, const float *b, fl
 static size_t pcd_ws_one(int n_points, int chunk, int feat_dim) {          // buffers of ONE chunk in flight
     const size_t pts = (size_t)chunk * n_points, nblk = (n_points + 255) / 256;
     return align_up(pts * VROW * 4, 256) * 3 + align_up(pts * 4 * VROW * 4, 256) + align_up(pts * KNN * 4, 256) +
-           align_up((size_t)chunk * nblk * feat_dim * 3 * 4, 256) + 2 * align_up(pts * 4, 256);
+           align_up((size_t)chunk * nblk * feat_dim * 3 * 4, 256) + 2 * align_up(pts * 4, 256) + align_up(pts * 3 * VROW * 2, 256);
 }
 size_t da_pcd_encoder_workspace_bytes(int n_points, int chunk, int feat_dim) {
     // one chunk, or two half-chunks side by side (da_pcd_encoder_forward's two-stream schedule): whichever is larger
@@ -728,12 +867,12 @@ int da_pcd_encoder_forward(const da_pcd_encoder_weights *w, int n_parts, int n_p
     DA_REQUIRE(w->conv6, "da_pcd_encoder_forward: conv6 weights missing");
     DA_REQUIRE(workspace_bytes >= da_pcd_encoder_workspace_bytes(n_points, chunk, feat), "da_pcd_encoder_forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    // Two half-chunks on two streams (round 5).  Fragments [p0, p0 + h) run on the caller's stream and the next h on a side stream
-    // of the library, each in its own half of the workspace (h = chunk / 2; the side stream forks behind an event on `stream` and
-    // is joined before the call returns).  Measured gain: 1.2 % (12.09 -> 11.94 ms per 640 x 1000 points) -- the two big kernels
-    // cannot share a CU (the neighbour search's 1024-thread blocks hold all of its vector registers and 129 KB of its LDS), so
-    // only the tails and the small kernels overlap.  DA_PCD_TWO_STREAMS=0, fewer than 64 fragments, or a workspace that does not
-    // hold two halves: one stream, whole chunks.
+    // Two half-chunks on two streams (round 5).  A chunk's pipeline is a chain of kernels with complementary bounds -- the
+    // 63-dimensional neighbour search holds one 1024-thread block per CU on its 129 KB score slab and leaves the vector ALUs and
+    // the memory system mostly idle, the edge kernel is bound by divergent row gathers at one wave per SIMD -- so fragments
+    // [p0, p0 + h) run on the caller's stream and the next h on a side stream of the library, each in its own half of the
+    // workspace (h = chunk / 2; the side stream forks behind an event on `stream` and is joined before the call returns).
+    // DA_PCD_TWO_STREAMS=0, fewer than 64 fragments, or a workspace that does not hold two halves: one stream, whole chunks.
     static int two_off = -1;
     if (two_off < 0) { const char *e = getenv("DA_PCD_TWO_STREAMS"); two_off = (e && e[0] == '0') ? 1 : 0; }
     const int half = chunk / 2;
@@ -762,13 +901,14 @@ int da_pcd_encoder_forward(const da_pcd_encoder_weights *w, int n_parts, int n_p
         float *xnorm[2];                                      // |row|^2 of X[0] / X[1], written by the edge kernel of that stage
         xnorm[0] = (float *)((char *)partial + align_up((size_t)step * ((n_points + 255) / 256) * feat * 3 * 4, 256));
         xnorm[1] = (float *)((char *)xnorm[0] + align_up(cp * 4, 256));
+        unsigned short *p3 = (unsigned short *)((char *)xnorm[1] + align_up(cp * 4, 256));      // the three bf16 pieces of the stage's input rows
         const int nblk = (n_points + 255) / 256;
         const long long total = (long long)B * n_points;
         const float *pts = points + (size_t)p0 * n_points * 3;
         for (int s = 0; s < 3; ++s) {
             const float *xin = s == 0 ? pts : X[s - 1];
             const int ldx = s == 0 ? 3 : VROW;
-            int rc = knn_launch(B, n_points, s == 0 ? 3 : V3, xin, ldx, KNN, 0, idx, sq, s == 0 ? nullptr : xnorm[s - 1]);      // the pooling is order-free
+            int rc = knn_launch(B, n_points, s == 0 ? 3 : V3, xin, ldx, KNN, 0, idx, sq, s == 0 ? nullptr : xnorm[s - 1], p3);      // the pooling is order-free
             if (rc) return rc;
             const int nb = (int)((total + 255) / 256);
             if (s == 0) k_pcd_premap<1><<<nb, 256, 0, sq>>>(xin, ldx, w->premap[s], total, T);
