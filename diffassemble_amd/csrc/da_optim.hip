@@ -98,12 +98,44 @@ __global__ __launch_bounds__(256) void k_af_a(const AfParam *__restrict__ P, con
     if (threadIdx.x == 0) { part_p2[blockIdx.x] = sp; part_u2[blockIdx.x] = su; }
 }
 
-// Phase B: one block per parameter -- rms(p) -> lr, column EMA, mean of the row EMA
+// Phase B: grid (parameter, 64-column chunk) -- chunk 0 of a parameter: rms(p) -> lr and the mean of the row EMA; every chunk: the
+// column EMA of its 64 columns, four threads per column (thread (tx, ty) adds the row blocks' partials ty, ty + 4, ... in ascending
+// order, the four sub-sums are combined as (s0 + s1) + (s2 + s3): a fixed order -- data-parallel replicas must apply identical
+// bits).  Round 5: one block per parameter walked up to 144 partials per column in 18 dependent rounds of eight loads and set the
+// launch's duration alone (18 us of the step's 95 us of Adafactor at BASELINE configuration 5).
+constexpr int AF_BCH = 64;
 __global__ __launch_bounds__(256) void k_af_b(const AfParam *__restrict__ P, float *__restrict__ state, const float *__restrict__ colpart,
                                               const float *__restrict__ part_p2, float *__restrict__ scal /* [n][4]: lr, row_mean, -, - */,
                                               float beta, float rho, float eps2) {
     __shared__ float red[4];
+    __shared__ float csub[4][AF_BCH];
     const AfParam p = P[blockIdx.x];
+    const int c0 = blockIdx.y * AF_BCH;
+    if (blockIdx.y > 0 && (!p.factored || c0 >= p.cols)) return;
+    if (p.factored && c0 < p.cols) {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, c = c0 + tx;
+        float t = 0.f;
+        if (c < p.cols) {
+            const float *cp = colpart + p.colpart_off + c;
+            int k = ty;
+            for (; k + 28 < p.nblk; k += 32) {              // eight of this thread's partials in flight
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = cp[(size_t)(k + 4 * u) * p.cols];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t += v[u];
+            }
+            for (; k < p.nblk; k += 4) t += cp[(size_t)k * p.cols];
+        }
+        csub[ty][tx] = t;
+        __syncthreads();
+        if (ty == 0 && c < p.cols) {
+            float *col = state + p.col_off;
+            const float tot = (csub[0][tx] + csub[1][tx]) + (csub[2][tx] + csub[3][tx]);
+            col[c] = beta * col[c] + (1.0f - beta) * (tot / (float)p.rows);
+        }
+    }
+    if (blockIdx.y > 0) return;
     float s = 0.f;
     for (int k = threadIdx.x; k < p.nblk; k += 256) s += part_p2[p.blk0 + k];
     s = block_sum(s, red);
@@ -111,23 +143,6 @@ __global__ __launch_bounds__(256) void k_af_b(const AfParam *__restrict__ P, flo
     const float rms = sqrtf(s) / sqrtf(numel);
     float rm = 0.f;
     if (p.factored) {
-        float *col = state + p.col_off;
-        for (int c = threadIdx.x; c < p.cols; c += 256) {
-            // fixed summation order, eight independent loads in flight (one dependent load per partial was ~50 us for the
-            // parameter with the most row blocks -- the whole kernel's duration, 45 workgroups on 256 CUs)
-            float t = 0.f;
-            const float *cp = colpart + p.colpart_off + c;
-            int k = 0;
-            for (; k + 8 <= p.nblk; k += 8) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = cp[(size_t)(k + u) * p.cols];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) t += v[u];
-            }
-            for (; k < p.nblk; ++k) t += cp[(size_t)k * p.cols];
-            col[c] = beta * col[c] + (1.0f - beta) * (t / (float)p.rows);
-        }
         const float *row = state + p.row_off;
         for (int r = threadIdx.x; r < p.rows; r += 256) rm += row[r];
         rm = block_sum(rm, red) / (float)p.rows;
@@ -213,7 +228,7 @@ int da_adafactor_step(int n_params, const void *param_table, int n_blocks, const
     const float beta = (float)(1.0 - pow((double)step, (double)decay_rate));
     const float rho = (float)fmin(1e-2, 1.0 / sqrt((double)step));
     k_af_a<<<n_blocks, 256, 0, st>>>(P, B, flat, flat_grad, state, colpart, part_p2, part_u2, beta, eps1);
-    k_af_b<<<n_params, 256, 0, st>>>(P, state, colpart, part_p2, scal, beta, rho, eps2);
+    k_af_b<<<dim3((unsigned)n_params, (64 * AF_CPL + AF_BCH - 1) / AF_BCH), 256, 0, st>>>(P, state, colpart, part_p2, scal, beta, rho, eps2);
     k_af_c<<<n_blocks, 256, 0, st>>>(P, B, flat_grad, state, scal, part_u2);
     k_af_d<<<n_blocks, 256, 0, st>>>(P, B, flat, flat_grad, state, scal, part_u2, clip_threshold);
     DA_LAUNCH_CHECK();

@@ -16,7 +16,9 @@
 // split over node chunks with a deterministic second-pass reduction.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "da_gemm_common.h"
 
@@ -1084,23 +1086,28 @@ struct SideDw {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, done[DA_MAX_LAYERS] = {};
 };
-static SideDw *side_dw() {
+// one context per (device, caller stream): two engines driven on different streams of one process must not share events
+static SideDw *side_dw(hipStream_t caller) {
     static int off = -1;
     if (off < 0) { const char *e = getenv("DA_TRAIN_SIDE_DW"); off = (e && e[0] == '0') ? 1 : 0; }
     if (off) return nullptr;
-    static SideDw ctx[16];
-    static bool ok[16] = {};
+    struct Slot { int dev; hipStream_t caller; SideDw ctx; };
+    static std::mutex mu;
+    static std::vector<Slot *> slots;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    SideDw &c = ctx[dev & 15];
-    if (!ok[dev & 15]) {
-        if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        bool good = hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
-        for (int l = 0; l < DA_MAX_LAYERS && good; ++l) good = hipEventCreateWithFlags(&c.done[l], hipEventDisableTiming) == hipSuccess;
-        if (!good) return nullptr;
-        ok[dev & 15] = true;
-    }
-    return &c;
+    std::lock_guard<std::mutex> lock(mu);
+    for (Slot *sl : slots)
+        if (sl->dev == dev && sl->caller == caller) return &sl->ctx;
+    if (slots.size() >= 64) return nullptr;                 // (a process that cycles through streams: fall back to the one-stream order)
+    Slot *sl = new Slot{dev, caller, SideDw()};
+    SideDw &c = sl->ctx;
+    bool good = hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; l < DA_MAX_LAYERS && good; ++l) good = hipEventCreateWithFlags(&c.done[l], hipEventDisableTiming) == hipSuccess;
+    if (!good) { delete sl; return nullptr; }
+    slots.push_back(sl);
+    return &sl->ctx;
 }
 
 // Linear backward: dW += dY^T X, db += colsum(dY), and (if dX) dX = dY @ W (+ res); WT = the forward's image of W^T (k_weight_prep:
@@ -1201,7 +1208,7 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
     const int PL = d.bfc ? DA_PREC_F32_BF16MMA : DA_PREC_F32;          // precision code of the linear layers (storage is fp32 either way)
     // W^T / bf16 images of the step (the backward of this forward reads them too): on the library's side stream, beside the
     // feature copy, the embedding and the mlp -- the first reader is conv 0's projection
-    SideDw *sd = side_dw();
+    SideDw *sd = side_dw(st);
     if (sd) {
         DA_CHECK_HIP(hipEventRecord(sd->fork, st));         // (behind the optimizer step / whatever last wrote the weights on the caller's stream)
         DA_CHECK_HIP(hipStreamWaitEvent(sd->s, sd->fork, 0));
@@ -1312,7 +1319,7 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
     auto G = [](const float *p) { return (float *)p; };       // grads: same struct, written by the library
 
     const bool dh0_copy = n > nr;
-    SideDw *sd = side_dw();             // null: DA_TRAIN_SIDE_DW=0
+    SideDw *sd = side_dw(st);           // null: DA_TRAIN_SIDE_DW=0
     static int dw_x16 = -1;             // DA_TRAIN_DW_X16=1: the convs' dW products read the bf16 image of X (measured slower: 69 vs 63 us at conv 3)
     if (dw_x16 < 0) { const char *e = getenv("DA_TRAIN_DW_X16"); dw_x16 = (e && e[0] == '1') ? 1 : 0; }
     if (do_early) {
