@@ -44,6 +44,12 @@ __host__ __device__ inline float bf2f(bf16_t h) {
     return v.f;
 }
 __host__ __device__ inline bf16_t f2bf(float f) {     // round-to-nearest-even
+#if defined(__HIP_DEVICE_COMPILE__)
+    // device: the hardware conversion (v_cvt_pk_bf16_f32, RNE: the same bits as the integer sequence below for every non-NaN
+    // input) -- one instruction where the sequence costs seven; the small-group attention kernels of the training path round
+    // ~80 values per lane this way and are bound by their instruction count
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+#endif
     union { unsigned u; float f; } v;
     v.f = f;
     unsigned u = v.u;

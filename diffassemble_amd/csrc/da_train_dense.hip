@@ -457,14 +457,28 @@ __device__ __forceinline__ void as_softmax(f32x4 (&s)[AS_TN], int tn_n, int n_g,
                                            float &mx, float &inv) {
     mx = -INFINITY;
 #pragma unroll
-    for (int tn = 0; tn < AS_TN; ++tn)
+    for (int tn = 0; tn < AS_TN; ++tn) {
+        // (wave-uniform cases: a tile beyond the graph; the last tile or a missing diagonal -- per-key guards; everything else is
+        //  a plain scale.  The guards on every element were ~240 of a band's ~4 000 instructions)
+        if (tn >= tn_n) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = tn * 16 + 4 * lg + r;
-            const bool ok = tn < tn_n && j < n_g && !(nodiag && j == i);
-            s[tn][r] = ok ? scale * s[tn][r] : -INFINITY;
-            mx = fmaxf(mx, s[tn][r]);
+            for (int r = 0; r < 4; ++r) s[tn][r] = -INFINITY;
+        } else if (tn == tn_n - 1 || nodiag) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = tn * 16 + 4 * lg + r;
+                const bool ok = j < n_g && !(nodiag && j == i);
+                s[tn][r] = ok ? scale * s[tn][r] : -INFINITY;
+                mx = fmaxf(mx, s[tn][r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[tn][r] = scale * s[tn][r];
+                mx = fmaxf(mx, s[tn][r]);
+            }
         }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.f;
