@@ -21,6 +21,9 @@
 // per lane along the contiguous axis.
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "da_gemm_common.h"
 
 namespace da {
@@ -1130,11 +1133,11 @@ template <int EPL> struct IrrNW { static constexpr int v = EPL <= 4 ? 16 : 8; };
 template <int EPL, bool HEAVY>
 __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_fwd(int n_nodes, int n_real, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
                                                       int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ stats,
-                                                      float *__restrict__ o, float scale) {
+                                                      float *__restrict__ o, float scale, int row0) {
     constexpr int IRR_NW = IrrNW<EPL>::v;
     __shared__ float red[HEAVY ? IRR_NW : 1][HEAVY ? 64 * EPL : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i = HEAVY ? n_real + (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int i = HEAVY ? n_real + (int)blockIdx.x : row0 + (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);      // (n_nodes = the end of the launch's row range)
     if (i >= n_nodes) return;
     const int beg = irr_ptr[i], end = irr_ptr[i + 1];
     if (HEAVY ? end - beg <= IRR_HEAVY : (beg == end || (i >= n_real && end - beg > IRR_HEAVY))) return;
@@ -1196,12 +1199,12 @@ template <int EPL, bool HEAVY>
 __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_bwd_dst(int n_nodes, int n_real, const int32_t *__restrict__ irr_ptr, const int32_t *__restrict__ irr_src,
                                                           int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ d_o,
                                                           const float *__restrict__ stats, float *__restrict__ dY4, float *__restrict__ Dd,
-                                                          float scale, int dtotal) {
+                                                          float scale, int dtotal, int row0) {
     // dtotal: Dd already holds the row's TOTAL D (k_hyb_rowdot, the flash-style route): used as it is, not written back
     constexpr int IRR_NW = IrrNW<EPL>::v;
     __shared__ float red[HEAVY ? IRR_NW : 1][HEAVY ? 64 * (EPL + 1) : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i = HEAVY ? n_real + (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int i = HEAVY ? n_real + (int)blockIdx.x : row0 + (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);      // (n_nodes = the end of the launch's row range)
     if (i >= n_nodes) return;
     const int beg = irr_ptr[i], end = irr_ptr[i + 1];
     if (HEAVY ? end - beg <= IRR_HEAVY : (i >= n_real && end - beg > IRR_HEAVY)) return;      // (rows without edges still get their skip gradient)
@@ -1288,11 +1291,11 @@ template <int EPL, bool HEAVY>
 __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_bwd_src(int n_nodes, int n_real, const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_dst,
                                                           int H, int HC, const float *__restrict__ qkvs, const float *__restrict__ d_o,
                                                           const float *__restrict__ stats, const float *__restrict__ Dd,
-                                                          float *__restrict__ dY4, float scale) {
+                                                          float *__restrict__ dY4, float scale, int row0) {
     constexpr int IRR_NW = IrrNW<EPL>::v;
     __shared__ float red[HEAVY ? IRR_NW : 1][HEAVY ? 64 * EPL : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int j = HEAVY ? n_real + (int)blockIdx.x : (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int j = HEAVY ? n_real + (int)blockIdx.x : row0 + (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);      // (n_nodes = the end of the launch's row range)
     if (j >= n_nodes) return;
     const int beg = out_ptr[j], end = out_ptr[j + 1];
     if (HEAVY ? end - beg <= IRR_HEAVY : (beg == end || (j >= n_real && end - beg > IRR_HEAVY))) return;
@@ -1801,6 +1804,36 @@ static HybFlash hyb_flash_params(const da_graph *g, int H, int C, const float *q
         default: set_error("hybrid training attention: unsupported head width C=%d", (C)); return 1; \
     }
 
+// Side stream of the flash-style hybrid route (round 5): everything that concerns the VIRTUAL rows -- their statistics, their
+// initial output, their remainder edges (heavy rows by workgroups, the virtual nodes of small puzzles by waves), in the backward
+// their dq and the dk | dv they collect as sources -- depends on the projections (and, in the backward, on k_hyb_rowdot) only, not
+// on the real rows' flash kernels, and is a chain of small launches (64 virtual rows in the reference's scripted Batches).  It runs
+// on a stream of the library beside the real rows' chain; fork and join by events, one context per (device, caller stream).
+// DA_HYB_SIDE=0: one stream, the round-4 launch order.
+struct HybSide { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static HybSide *hyb_side(hipStream_t caller) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("DA_HYB_SIDE"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off) return nullptr;
+    struct Slot { int dev; hipStream_t caller; HybSide ctx; };
+    static std::mutex mu;
+    static std::vector<Slot *> slots;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (Slot *sl : slots)
+        if (sl->dev == dev && sl->caller == caller) return &sl->ctx;
+    if (slots.size() >= 64) return nullptr;
+    Slot *sl = new Slot{dev, caller, HybSide()};
+    HybSide &c = sl->ctx;
+    const bool good = hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
+    if (!good) { delete sl; return nullptr; }
+    slots.push_back(sl);
+    return &sl->ctx;
+}
+
 // forward: o = softmax over (regular edges U remainder edges) . v + skip (+ res); P (dense part) and stats kept
 int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, const float *res, float *o, float *P, float *stats,
                           const long long *poff, const int32_t *node_graph, hipStream_t st, bool bfc) {
@@ -1810,22 +1843,39 @@ int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, co
         int rc;
         HybFlash a = hyb_flash_params(g, H, C, qkvs);
         a.res = res; a.o = o; a.stats = stats;
-        if ((rc = C == 32 ? hyb_flash_launch<2>(0, a, G, st) : hyb_flash_launch<9>(0, a, G, st))) return rc;
-        if (n > nr) {
-            // virtual rows: statistics over their (remainder-only) edges, o = skip (+ residual)
-            k_pair_rows_hybrid<<<gridsz((size_t)(n - nr) * H * 64), 256, 0, st>>>(0, nr, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
+        const float scale_f = 1.0f / sqrtf((float)C);
+        HybSide *sd = n > nr ? hyb_side(st) : nullptr;
+        hipStream_t sv = sd ? sd->s : st;                     // the virtual rows' chain
+        if (sd) {
+            DA_CHECK_HIP(hipEventRecord(sd->fork, st));       // (the projections are there)
+            DA_CHECK_HIP(hipStreamWaitEvent(sd->s, sd->fork, 0));
+        }
+        auto virtual_chain = [&]() -> int {
+            // virtual rows: statistics over their (remainder-only) edges, o = skip (+ residual), then their edges -- rows with more
+            // than IRR_HEAVY edges by workgroups, the others (the virtual nodes of small puzzles) by waves
+            k_pair_rows_hybrid<<<gridsz((size_t)(n - nr) * H * 64), 256, 0, sv>>>(0, nr, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
                                                                                (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs, nullptr,
                                                                                nullptr, stats, nullptr);
-            k_init_out<<<gridsz((size_t)(n - nr) * HC), 256, 0, st>>>(n - nr, HC, qkvs + (size_t)nr * 4 * HC, res ? res + (size_t)nr * HC : nullptr, o + (size_t)nr * HC);
+            k_init_out<<<gridsz((size_t)(n - nr) * HC), 256, 0, sv>>>(n - nr, HC, qkvs + (size_t)nr * 4 * HC, res ? res + (size_t)nr * HC : nullptr, o + (size_t)nr * HC);
+            const int grid_v = (int)(((size_t)(n - nr) * 64 + 255) / 256);
+            DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, false><<<grid_v, 256, 0, sv>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f, nr)),
+                          (k_attn_irr_fwd<18, false><<<grid_v, 256, 0, sv>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f, nr)))
+            DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, sv>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f, 0)),
+                          (k_attn_irr_fwd<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, sv>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f, 0)))
             DA_LAUNCH_CHECK();
-        }
-        const float scale_f = 1.0f / sqrtf((float)C);
-        const int grid_f = (int)(((size_t)n * 64 + 255) / 256);
-        DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, false><<<grid_f, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f)),
-                      (k_attn_irr_fwd<18, false><<<grid_f, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f)))
-        if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f)),
-                      (k_attn_irr_fwd<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f)))
+            return 0;
+        };
+        if (sd && (rc = virtual_chain())) return rc;          // side stream: enqueued first, runs beside the real rows' kernels
+        if ((rc = C == 32 ? hyb_flash_launch<2>(0, a, G, st) : hyb_flash_launch<9>(0, a, G, st))) return rc;
+        if (!sd && n > nr && (rc = virtual_chain())) return rc;
+        const int grid_r = (int)(((size_t)nr * 64 + 255) / 256);      // the real rows' remainder edges (rows [0, nr))
+        DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, false><<<grid_r, 256, 0, st>>>(nr, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f, 0)),
+                      (k_attn_irr_fwd<18, false><<<grid_r, 256, 0, st>>>(nr, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f, 0)))
         DA_LAUNCH_CHECK();
+        if (sd) {
+            DA_CHECK_HIP(hipEventRecord(sd->join, sd->s));
+            DA_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));
+        }
         return 0;
     }
     GGemm s;
@@ -1852,10 +1902,10 @@ int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, co
     if ((rc = ggemm(pv, G, H, mx, st))) return rc;
     const float scale = 1.0f / sqrtf((float)C);
     const int grid = (int)(((size_t)n * 64 + 255) / 256);
-    DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)),
-                  (k_attn_irr_fwd<18, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)))
-    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)),
-                  (k_attn_irr_fwd<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale, 0)),
+                  (k_attn_irr_fwd<18, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale, 0)))
+    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_fwd<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale, 0)),
+                  (k_attn_irr_fwd<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale, 0)))
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -1874,21 +1924,44 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
         HybFlash a = hyb_flash_params(g, H, C, qkvs);
         a.res = res; a.o = (float *)o; a.d_o = d_o; a.dY4 = dY4; a.stats = (float *)stats; a.Dd = Dd;
         k_hyb_rowdot<<<(unsigned)(((size_t)n * 64 + 255) / 256), 256, 0, st>>>(a);
-        if (n > nr) k_zero_kv_grad<<<gridsz((size_t)(n - nr) * 2 * HC), 256, 0, st>>>(nr, n, HC, dY4);
         DA_LAUNCH_CHECK();
-        // remainder, destination side: dq of the remainder edges (D is already the row's total), skip gradient of every row
-        DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)),
-                      (k_attn_irr_bwd_dst<18, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)))
-        if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)),
-                      (k_attn_irr_bwd_dst<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)))
+        HybSide *sd = n > nr ? hyb_side(st) : nullptr;
+        hipStream_t sv = sd ? sd->s : st;
+        if (sd) {
+            DA_CHECK_HIP(hipEventRecord(sd->fork, st));       // (D of every row is there)
+            DA_CHECK_HIP(hipStreamWaitEvent(sd->s, sd->fork, 0));
+        }
+        const int grid_r = (int)(((size_t)nr * 64 + 255) / 256), grid_v = (int)(((size_t)(n - nr) * 64 + 255) / 256);
+        // the virtual rows' chain: dk | dv start from zero; as destinations their dq (and skip gradient), as sources the dk | dv of
+        // their edges into the real rows -- none of it touches a real row's gradient
+        auto virtual_chain = [&]() -> int {
+            k_zero_kv_grad<<<gridsz((size_t)(n - nr) * 2 * HC), 256, 0, sv>>>(nr, n, HC, dY4);
+            DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid_v, 256, 0, sv>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT, nr)),
+                          (k_attn_irr_bwd_dst<18, false><<<grid_v, 256, 0, sv>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT, nr)))
+            DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, sv>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT, 0)),
+                          (k_attn_irr_bwd_dst<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, sv>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT, 0)))
+            DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, false><<<grid_v, 256, 0, sv>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale, nr)),
+                          (k_attn_irr_bwd_src<18, false><<<grid_v, 256, 0, sv>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale, nr)))
+            DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, sv>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale, 0)),
+                          (k_attn_irr_bwd_src<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, sv>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale, 0)))
+            DA_LAUNCH_CHECK();
+            return 0;
+        };
+        if (sd && (rc = virtual_chain())) return rc;
+        // the real rows' chain.  Remainder, destination side: dq of the remainder edges (D is already the row's total), skip gradient
+        DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid_r, 256, 0, st>>>(nr, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT, 0)),
+                      (k_attn_irr_bwd_dst<18, false><<<grid_r, 256, 0, st>>>(nr, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT, 0)))
         DA_LAUNCH_CHECK();
         if ((rc = C == 32 ? hyb_flash_launch<2>(1, a, G, st) : hyb_flash_launch<9>(1, a, G, st))) return rc;      // dQ += (regular edges)
         if ((rc = C == 32 ? hyb_flash_launch<2>(2, a, G, st) : hyb_flash_launch<9>(2, a, G, st))) return rc;      // dK, dV (regular edges)
-        DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, false><<<grid, 256, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
-                      (k_attn_irr_bwd_src<18, false><<<grid, 256, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
-        if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
-                      (k_attn_irr_bwd_src<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
+        DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, false><<<grid_r, 256, 0, st>>>(nr, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale, 0)),
+                      (k_attn_irr_bwd_src<18, false><<<grid_r, 256, 0, st>>>(nr, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale, 0)))
         DA_LAUNCH_CHECK();
+        if (!sd && n > nr && (rc = virtual_chain())) return rc;
+        if (sd) {
+            DA_CHECK_HIP(hipEventRecord(sd->join, sd->s));
+            DA_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));
+        }
         return 0;
     }
     constexpr int DTOT = 0;
@@ -1908,10 +1981,10 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
                                                                     (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs,
                                                                     (float *)P, dP, nullptr, Dd);
     // remainder, destination side: D total, dq of the remainder edges, skip gradient
-    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)),
-                  (k_attn_irr_bwd_dst<18, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)))
-    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)),
-                  (k_attn_irr_bwd_dst<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT)))
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT, 0)),
+                  (k_attn_irr_bwd_dst<18, false><<<grid, 256, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT, 0)))
+    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_dst<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT, 0)),
+                  (k_attn_irr_bwd_dst<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, d_o, stats, dY4, Dd, scale, DTOT, 0)))
     // dS = P o (dP - D) over the regular edges
     k_pair_rows_hybrid<<<gridsz((size_t)n * H * 64), 256, 0, st>>>(1, 0, n, nr, H, C, g->graph_ptr, g->pad_ptr, node_graph, poff, g->mask,
                                                                     (const long long *)g->mask_ptr, g->irr_row_ptr, g->irr_col_src, qkvs,
@@ -1925,10 +1998,10 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
     q.transA = 1; q.transB = 0; q.dimM = 0; q.dimN = C; q.dimK = 0; q.alpha = scale; q.accumulate = 0;
     if ((rc = ggemm(q, G, H, mx, st))) return rc;
     // remainder, source side: += dk, dv
-    DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, false><<<grid, 256, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
-                  (k_attn_irr_bwd_src<18, false><<<grid, 256, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
-    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)),
-                  (k_attn_irr_bwd_src<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale)))
+    DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, false><<<grid, 256, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale, 0)),
+                  (k_attn_irr_bwd_src<18, false><<<grid, 256, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale, 0)))
+    if (n > nr) DA_HYB_SWITCH(C, (k_attn_irr_bwd_src<4, true><<<n - nr, 64 * IrrNW<4>::v, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale, 0)),
+                  (k_attn_irr_bwd_src<18, true><<<n - nr, 64 * IrrNW<18>::v, 0, st>>>(n, nr, g->out_ptr, g->out_dst, H, HC, qkvs, d_o, stats, Dd, dY4, scale, 0)))
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -652,8 +652,9 @@ torch.save({"loss": losses, "grad": te.flat_grad.cpu(), "time_emb": temb}, os.en
                                               ("exophormer", "bf16", "0"), ("exophormer", "fp32", "1")])
 def test_side_stream_weight_gradients_are_bit_identical(dev, tmp_path, arch, prec, staged):
     """Round 5: the dW / db products of the backward and the forward's weight images run on a side stream of the library
-    (SideDw, da_train.hip) beside the dX / attention-backward chain.  Same kernels, same operands, same summation orders --
-    the accumulated gradients of two backward passes must equal the one-stream schedule's (DA_TRAIN_SIDE_DW=0, read once per
+    (SideDw, da_train.hip) beside the dX / attention-backward chain, and on hybrid graphs in the bf16 mode the virtual rows' whole
+    chain runs beside the real rows' flash kernels (HybSide, da_train_dense.hip).  Same kernels, same operands, same summation orders --
+    the accumulated gradients of two backward passes must equal the one-stream schedule's (DA_TRAIN_SIDE_DW=0 DA_HYB_SIDE=0, read once per
     process: hence the subprocesses) BIT FOR BIT, on complete and on hybrid graphs, in both precisions, with the backward
     in one call and in its two stages."""
     import os
@@ -661,7 +662,7 @@ def test_side_stream_weight_gradients_are_bit_identical(dev, tmp_path, arch, pre
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env in (("side", {}), ("one", dict(DA_TRAIN_SIDE_DW="0"))):
+    for tag, env in (("side", {}), ("one", dict(DA_TRAIN_SIDE_DW="0", DA_HYB_SIDE="0"))):
         out = str(tmp_path / f"{tag}.pt")
         e = dict(os.environ, DA_ROOT=ROOT, SIDE_ARCH=arch, SIDE_PREC=prec, SIDE_STAGED=staged, SIDE_OUT=out, **env)
         r = subprocess.run([sys.executable, "-c", _SIDE_WORKER], env=e, capture_output=True, text=True, timeout=900)
