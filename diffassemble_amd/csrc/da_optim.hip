@@ -30,6 +30,7 @@ struct AfParam {            // one entry per parameter tensor (device table)
     long long colpart_off;  // scratch: [nblk][cols] column partial sums (matrices)
 };
 struct AfBlock { int pid, row0, nrows; };     // matrices: a chunk of rows; vectors: a chunk of `nrows` ELEMENTS from row0
+constexpr int AF_RMAX = 512;                  // rows of a block whose factors phases C / D keep in LDS
 constexpr int AF_CPL = 20;                    // columns per LANE in phase A: matrices up to 1280 columns
 
 __device__ __forceinline__ float block_sum(float v, float *red) {
@@ -62,21 +63,32 @@ __global__ __launch_bounds__(256) void k_af_a(const AfParam *__restrict__ P, con
         float ca[AF_CPL];
 #pragma unroll
         for (int k = 0; k < AF_CPL; ++k) ca[k] = 0.f;
-        for (int r = b.row0 + wv; r < b.row0 + b.nrows; r += 4) {
-            float sr = 0.f;
+        // (round 5: the columns this lane really has -- ncl <= AF_CPL -- and TWO rows of the wave in flight: a row was a chain of
+        //  load -> reduce -> read-modify-write of its EMA, eight rows per wave one after the other = the kernel's 29 us)
+        const int ncl = (p.cols - lane + 63) / 64;
+        const int rend = b.row0 + b.nrows;
+        for (int r = b.row0 + wv; r < rend; r += 8) {
+            const bool two = r + 4 < rend;
+            const float *g0 = g + (size_t)r * p.cols + lane, *w0 = w + (size_t)r * p.cols + lane;
+            const size_t d1 = two ? (size_t)4 * p.cols : 0;
+            const float re0 = lane == 0 ? row[r] : 0.f, re1 = (lane == 0 && two) ? row[r + 4] : 0.f;
+            float sr0 = 0.f, sr1 = 0.f;
 #pragma unroll
             for (int k = 0; k < AF_CPL; ++k) {
-                const int c = lane + 64 * k;
-                if (c < p.cols) {
-                    const float gv = g[(size_t)r * p.cols + c], wv2 = w[(size_t)r * p.cols + c];
-                    const float q = fmaf(gv, gv, eps1);
-                    sr += q;
-                    ca[k] += q;
-                    sp = fmaf(wv2, wv2, sp);
+                if (k < ncl) {
+                    const float ga = g0[64 * k], wa = w0[64 * k], gb = g0[d1 + 64 * k], wb = w0[d1 + 64 * k];
+                    const float qa = fmaf(ga, ga, eps1), qb = fmaf(gb, gb, eps1);
+                    sr0 += qa;
+                    ca[k] += qa;
+                    sp = fmaf(wa, wa, sp);
+                    if (two) { sr1 += qb; ca[k] += qb; sp = fmaf(wb, wb, sp); }
                 }
             }
-            for (int o = 32; o > 0; o >>= 1) sr += __shfl_xor(sr, o);
-            if (lane == 0) row[r] = beta * row[r] + (1.0f - beta) * (sr / (float)p.cols);
+            for (int o = 32; o > 0; o >>= 1) { sr0 += __shfl_xor(sr0, o); sr1 += __shfl_xor(sr1, o); }
+            if (lane == 0) {
+                row[r] = beta * re0 + (1.0f - beta) * (sr0 / (float)p.cols);
+                if (two) row[r + 4] = beta * re1 + (1.0f - beta) * (sr1 / (float)p.cols);
+            }
         }
 #pragma unroll
         for (int k = 0; k < AF_CPL; ++k) colred[wv][lane + 64 * k] = ca[k];
@@ -163,12 +175,33 @@ __global__ __launch_bounds__(256) void k_af_c(const AfParam *__restrict__ P, con
     const float *g = grad + p.off, *row = state + p.row_off, *col = state + p.col_off;
     const float rm = scal[b.pid * 4 + 1];
     float su = 0.f;
+    // (round 5: the block's row factors once into LDS, then a thread walks ITS columns down the rows with eight loads in flight --
+    //  the row loop was a chain of "row EMA -> rsqrt -> that row's loads", 32 rows one after the other = the kernel's 23 us)
+    __shared__ float rfs[AF_RMAX];
+    if (b.nrows <= AF_RMAX) {
+        for (int r = threadIdx.x; r < b.nrows; r += 256) rfs[r] = rsqrtf(row[b.row0 + r] / rm);
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.cols; c += 256) {
+            const float cf = rsqrtf(col[c]);
+            const float *gc = g + (size_t)b.row0 * p.cols + c;
+            int r = 0;
+            for (; r + 8 <= b.nrows; r += 8) {
+                float gv[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) gv[x] = gc[(size_t)(r + x) * p.cols];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { const float u = gv[x] * (rfs[r + x] * cf); su = fmaf(u, u, su); }
+            }
+            for (; r < b.nrows; ++r) { const float u = gc[(size_t)r * p.cols] * (rfs[r] * cf); su = fmaf(u, u, su); }
+        }
+    } else {
     for (int r = b.row0; r < b.row0 + b.nrows; ++r) {
         const float rf = rsqrtf(row[r] / rm);
         for (int c = threadIdx.x; c < p.cols; c += 256) {
             const float u = g[(size_t)r * p.cols + c] * (rf * rsqrtf(col[c]));
             su = fmaf(u, u, su);
         }
+    }
     }
     su = block_sum(su, red);
     if (threadIdx.x == 0) part_u2[blockIdx.x] = su;
@@ -192,12 +225,31 @@ __global__ __launch_bounds__(256) void k_af_d(const AfParam *__restrict__ P, con
     if (p.factored) {
         const float *row = state + p.row_off, *col = state + p.col_off;
         const float rm = scal[b.pid * 4 + 1];
+        __shared__ float rfs[AF_RMAX];
+        if (b.nrows <= AF_RMAX) {                       // (as phase C: row factors in LDS, eight rows of a column in flight)
+            for (int r = threadIdx.x; r < b.nrows; r += 256) rfs[r] = rsqrtf(row[b.row0 + r] / rm);
+            __syncthreads();
+            for (int c = threadIdx.x; c < p.cols; c += 256) {
+                const float cf = rsqrtf(col[c]);
+                const size_t i0 = (size_t)b.row0 * p.cols + c;
+                int r = 0;
+                for (; r + 8 <= b.nrows; r += 8) {
+                    float gv[8], wv[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) { gv[x] = g[i0 + (size_t)(r + x) * p.cols]; wv[x] = w[i0 + (size_t)(r + x) * p.cols]; }
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) w[i0 + (size_t)(r + x) * p.cols] = wv[x] - step * (gv[x] * (rfs[r + x] * cf));
+                }
+                for (; r < b.nrows; ++r) { const size_t i = i0 + (size_t)r * p.cols; w[i] -= step * (g[i] * (rfs[r] * cf)); }
+            }
+        } else {
         for (int r = b.row0; r < b.row0 + b.nrows; ++r) {
             const float rf = rsqrtf(row[r] / rm);
             for (int c = threadIdx.x; c < p.cols; c += 256) {
                 const size_t i = (size_t)r * p.cols + c;
                 w[i] -= step * (g[i] * (rf * rsqrtf(col[c])));
             }
+        }
         }
     } else {
         const float *v = state + p.row_off;
