@@ -375,7 +375,9 @@ int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, cons
     // as many splits (<= 4) as keep the launch inside ONE round of the 512 resident workgroups (2 per CU): a second round with a
     // few workgroups costs a whole extra pass over the split's stages
     const int base = 8 * ((nrt + 7) / 8) * nct;
-    int splits = 4;
+    static int smax = -1;                                     // DA_GEMM_SPLITK_MAX (default 4)
+    if (smax < 0) { const char *e = getenv("DA_GEMM_SPLITK_MAX"); smax = e ? atoi(e) : 4; smax = smax < 2 ? 2 : (smax > 8 ? 8 : smax); }      // (8 measured: 1.204 vs 1.205 ms at configuration 5 -- no gain)
+    int splits = smax;
     while (splits > 1 && (K % (splits * (128 / es)) != 0 || (size_t)splits * M * Nout > partial_floats || (base * splits > 512 && splits > 2))) --splits;
     if (splits < 2) return -1;
     GemmParams p;
