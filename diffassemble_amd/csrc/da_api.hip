@@ -1062,6 +1062,7 @@ int da_debug_counters(int64_t *out, int n, int reset) {
     out[DA_DBG_DENSE_FAST_EXITS] = (int64_t)a[1];
     out[DA_DBG_DUAL_GEN_SLABS] = (int64_t)b2[0];
     out[DA_DBG_OPT_MASKED_GEN_WORKGROUPS] = (int64_t)a[2];
+    out[DA_DBG_RES_LAUNCHES] = (int64_t)da::attn_res_launches(reset);
     return 0;
 }
 

@@ -729,6 +729,267 @@ static int launch_optt(AttnDenseParams p, hipStream_t st) {
     return 0;
 }
 
+// ---- K / V-RESIDENT instance for the hidden layers of LARGE complete graphs (round 5, last session).
+// What the round's probes measured on k_attn_optt<32> (DESIGN.md "Measured, round 5"): the arithmetic of a 32 x 32 block is under
+// half of a wave's time; the rest is a barrier + tile wait per 64 keys, DMA issue, a 30 % half-empty tail per launch, and a
+// prologue / epilogue per 128-query tile -- latency at WORKGROUP granularity.  A head of a 900-piece puzzle is 2 x 57.6 KB of K and
+// V: it FITS the CU's 160 KB of LDS.  So: ONE workgroup of sixteen waves per (graph, head); the whole K | V of the head is requested
+// once (8 x fewer L2 -> LDS bytes than one ring per query tile), in the stage image the ring kernels use; ONE barrier, when
+// everything has landed (nothing is ever overwritten: there is no "release" side) -- a barrier of sixteen waves is a convoy, its
+// partners share SIMDs, so every further one would re-align waves the matrix pipe and the vector port had just pulled apart
+// (measured: one barrier per two tiles 58 us per 32-puzzle launch, three barriers 54, one 52); from there on every wave runs
+// 32-query slabs over ALL keys with no barrier, no DMA, no tile wait: a flat loop over 32-key blocks with the NEXT block's K
+// fragments requested behind this block's QK chain (they land under the exponentials).  Slabs: a wave's first is its own, the rest
+// are drawn from a counter in LDS -- the SIMD's arbiter favours its oldest waves (per-wave stamps, tools/bin/attn_bench_probe
+// PROBE3=1: with fixed slabs the waves of one SIMD finished their first slab after 22 k ... 70 k cycles and the last quarter of the
+// kernel ran on one or two waves per SIMD).  The optimistic softmax is verified per WAVE (a wave whose row sums left the window
+// re-runs its own slab in the running-max mode; nobody else waits), and the epilogue goes straight from the accumulator layout to
+// global memory (lane (i, half) owns channels 8 jj + 4 half .. + 3 of query i: 8-byte skip loads and stores) -- no LDS staging,
+// no workgroup barrier per slab.  32 puzzles x 8 heads = 256 workgroups = one per CU.  Reference: the same TransformerConv
+// attention (backbones/Transformer_GNN.py:32).
+template <int NWV, bool QUEUE, bool KPF>
+__global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
+    using T = bf16_t;
+    constexpr int C = 32, CV = 32;
+    using CF = Cfg<T, C, CV, 64>;
+    using KG = OptK<C, 64>;
+    static_assert(KG::NI == 8 && NWV % 8 == 0, "eight 1 KB pieces per 64-key stage, one per wave of an octet");
+    static_assert(CF::ROWB == 64 && CF::ROWBV == 64 && KG::RS == 64 && CF::RSV == 64 && KG::KBYTES == 4096, "one tile stride for K and V; 2 KB per 32-key block");
+    constexpr int TPW = NWV / 8;               // an octet of waves fetches every TPW-th tile
+    constexpr int STAGE = KG::STAGE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DA_OPB(unsigned long long pb_[8] = {__builtin_readcyclecounter(), 0, 0, 0, 0, 0, 0, 0};)
+    const int bid = blockIdx.x, h = bid & 7, g = bid >> 3;          // head = XCD, as in the ring kernels
+    const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
+    if (n_g <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HC = p.H * C;
+    const size_t np = (size_t)p.n_pad;
+    const int nkt = (n_g + 63) >> 6, nslab = (n_g + 31) >> 5;      // nslab = 32-query slabs = 32-key blocks
+    const unsigned char *Qg = (const unsigned char *)p.Q + ((size_t)h * np + pad0) * CF::ROWB;
+    const unsigned char *Kg = (const unsigned char *)p.K + ((size_t)h * np + pad0) * CF::ROWB;
+    const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWBV;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    unsigned *qctr = (unsigned *)(smem + ((p.max_nodes + 63) >> 6) * STAGE);
+    if (QUEUE && tid == 0) { *qctr = 0u; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }      // (nobody draws before the landing barrier)
+
+    // ---- the whole K | V of the head: wave w issues piece (w & 7) of tiles (w >> 3), (w >> 3) + TPW, ... (scalar base + lane offset form)
+    {
+        const int pq = wid & 7, t0 = wid >> 3;
+        unsigned so_;
+        if (pq < KG::NIK) {
+            const int s = pq * 64 + lane, row = s / KG::KSPR, col = s - row * KG::KSPR;
+            so_ = (unsigned)(row * CF::ROWB + (col ^ KG::f(row)) * 16);
+        } else {
+            const int s = (pq - KG::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
+            so_ = (unsigned)(row * CF::ROWBV + col * 16);
+        }
+        const unsigned char *src0 = pq < KG::NIK ? Kg : Vg;
+        for (int kt = t0; kt < nkt; kt += TPW) {
+            const unsigned char *src = src0 + (size_t)kt * 64 * CF::ROWB;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + (unsigned)(kt * STAGE + pq * 1024)), "v"(so_), "s"(src)
+                         : "memory");
+        }
+    }
+    DA_OPB(pb_[1] = __builtin_readcyclecounter();)
+    int slab = wid;
+    u32x4 qf[CF::NCH];
+    auto load_q = [&](int sl, u32x4(&dst)[CF::NCH]) {
+        const unsigned char *qrow = Qg + (size_t)(min(sl, nslab - 1) * 32 + i) * CF::ROWB;     // (rows of the 64-row slot padding are readable)
+#pragma unroll
+        for (int ch = 0; ch < CF::NCH; ++ch) dst[ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
+    };
+    load_q(slab, qf);
+    // the first slab's Q fragments travel behind the DMA; one wait for both, then the only barrier of the kernel
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[CF::NCH - 1]));
+    __builtin_amdgcn_s_barrier();
+    DA_OPB(pb_[6] = __builtin_readcyclecounter();)
+
+    const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);
+    int kfo[CF::NCH];
+#pragma unroll
+    for (int ch = 0; ch < CF::NCH; ++ch) kfo[ch] = pi_i * KG::RS + (((2 * ch + half) ^ KG::f(pi_i)) * 16);
+    const int li = lane & 15;
+    const unsigned vbase = lds0 + (unsigned)(KG::KBYTES + (16 * half + (li >> 2)) * CF::RSV + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2);
+
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
+    f32x16 O;
+    float ls, m;
+    // byte offset of 32-key block b inside the K (or, + KBYTES, the V) image: stage b / 2, block b % 2
+    auto boff = [&](int b) { return (b >> 1) * STAGE + (b & 1) * 2048; };
+
+    for (int round = 0; slab < nslab; ++round) {
+        const int q0 = slab * 32, qidx = q0 + i;
+        bool gen = p.force_gen != 0;
+        auto pass = [&]() {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[r] = 0.f;
+            ls = 0.f;
+            m = -1e30f;
+            u32x4 kf[CF::NCH];
+#pragma unroll
+            for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(smem + kfo[ch]);
+            for (int b = 0; b < nslab; ++b) {
+                const int key0 = b * 32;
+                const int bo = boff(b);
+                if (!KPF && b > 0) {
+#pragma unroll
+                    for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(smem + bo + kfo[ch]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), kf[ch], qf[ch], s);
+                asm volatile("" : "+v"(s));         // (the V reads and the next K fragments stay BEHIND the QK chain: the IR-level sinking of the products put
+                                                    //  the reads in front, where the chain's lgkmcnt wait covers them too)
+                u32x2 vlo[2], vhi[2];
+                const unsigned vb = vbase + (unsigned)bo;
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    vlo[mm] = tr_read(vb, (8 * mm) * CF::RSV);
+                    vhi[mm] = tr_read(vb, (8 * mm + 4) * CF::RSV);
+                }
+                if (KPF && b + 1 < nslab) {       // next block's K fragments: they land under this block's exponentials
+                    const int bn = boff(b + 1);
+#pragma unroll
+                    for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(smem + bn + kfo[ch]);
+                }
+                {
+                    const int kbase = key0 + 16 * half;
+                    const bool tail = key0 + 32 > n_g;
+                    const bool diag = p.nodiag && key0 == q0;
+                    if (tail || diag) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kbase + r >= n_g || (p.nodiag && kbase + r == qidx)) s[r] = -INFINITY;
+                    }
+                }
+                if (gen) {
+                    const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
+                    const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
+                    const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+                    const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
+                    const float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));
+                    if (__any(mnew > m)) {
+                        const float corr = __builtin_amdgcn_exp2f(m - mnew);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[r] *= corr;
+                        ls *= corr;
+                        m = mnew;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] -= m;
+                }
+                bf16x8 pf0, pf1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = __builtin_amdgcn_exp2f(s[2 * e]), x1 = __builtin_amdgcn_exp2f(s[2 * e + 1]);
+                    const float y0 = __builtin_amdgcn_exp2f(s[8 + 2 * e]), y1 = __builtin_amdgcn_exp2f(s[8 + 2 * e + 1]);
+                    pf0[2 * e] = (__bf16)x0; pf0[2 * e + 1] = (__bf16)x1;
+                    pf1[2 * e] = (__bf16)y0; pf1[2 * e + 1] = (__bf16)y1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]));
+                const u32x4 v0 = {vlo[0][0], vlo[0][1], vhi[0][0], vhi[0][1]};
+                const u32x4 v1 = {vlo[1][0], vlo[1][1], vhi[1][0], vhi[1][1]};
+                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O, 0, 0, 0);
+                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16x2 pa = {pf0[2 * e], pf0[2 * e + 1]}, pb = {pf1[2 * e], pf1[2 * e + 1]};
+                    ls = __builtin_amdgcn_fdot2_f32_bf16(pa, one2, ls, false);
+                    ls = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, ls, false);
+                }
+            }
+        };
+        pass();
+        DA_OPB({ asm volatile("" : "+v"(O), "+v"(ls)); if (round < 2) pb_[2 + 2 * round] = __builtin_readcyclecounter(); })
+        if (!gen) {
+            // verification of the optimistic pass, per WAVE (the waves share nothing but the resident tiles)
+            const float lt0 = ls + __shfl_xor(ls, 32);
+            const bool ok = lt0 > 8.673617379884035e-19f && lt0 < 1.2676506002282294e30f;        // 2^-60, 2^100; NaN fails
+            if (__any(!ok && qidx < n_g)) {
+                gen = true;
+                if (lane == 0) atomicAdd(&g_opt_fallbacks[0], 1ull);
+                pass();
+            }
+        }
+        // the next slab (drawn from the queue) and its Q fragments, which travel under this slab's epilogue
+        int nxt = slab + NWV;
+        if (QUEUE) {
+            unsigned t_ = 0;
+            if (lane == 0) t_ = __hip_atomic_fetch_add(qctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nxt = NWV + __builtin_amdgcn_readfirstlane((int)t_);
+        }
+        u32x4 qn[CF::NCH];
+        const bool more = nxt < nslab;
+        if (more) load_q(nxt, qn);
+        const float lt = ls + __shfl_xor(ls, 32);
+        const float inv = lt > 0.f ? 1.0f / (lt + (gen ? 1e-16f : 0.f)) : 0.f;      // (no epsilon on an un-shifted sum: see the header)
+        if (qidx < n_g) {
+            const size_t roff = (size_t)(node0 + qidx) * HC + (size_t)h * C + 4 * half;
+            u32x2 sk[4], rs[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                sk[jj] = *(const u32x2 *)((const T *)p.S + roff + 8 * jj);
+                rs[jj] = p.res ? *(const u32x2 *)((const T *)p.res + roff + 8 * jj) : (u32x2){0u, 0u};
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                // (products rounded on their own, as the ring kernel's are on their way through LDS: no contraction with the skip add)
+                float v4[4] = {__fmul_rn(O[4 * jj], inv), __fmul_rn(O[4 * jj + 1], inv), __fmul_rn(O[4 * jj + 2], inv), __fmul_rn(O[4 * jj + 3], inv)};
+                // (skip first, then the residual: the ring kernel's order -- the two kernels give bit-identical rows)
+                v4[0] += bf2f((bf16_t)(sk[jj][0] & 0xffff)); v4[1] += bf2f((bf16_t)(sk[jj][0] >> 16));
+                v4[2] += bf2f((bf16_t)(sk[jj][1] & 0xffff)); v4[3] += bf2f((bf16_t)(sk[jj][1] >> 16));
+                if (p.res) {
+                    v4[0] += bf2f((bf16_t)(rs[jj][0] & 0xffff)); v4[1] += bf2f((bf16_t)(rs[jj][0] >> 16));
+                    v4[2] += bf2f((bf16_t)(rs[jj][1] & 0xffff)); v4[3] += bf2f((bf16_t)(rs[jj][1] >> 16));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = apply_act(v4[e], p.act);
+                st4((T *)p.out + roff + 8 * jj, v4);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int ch = 0; ch < CF::NCH; ++ch) qf[ch] = qn[ch];
+            // (a use the compiler sees: its wait for these loads belongs HERE -- left to the first QK product it would sit inside the key loop)
+            asm volatile("" : "+v"(qf[0]), "+v"(qf[CF::NCH - 1]));
+        }
+        slab = nxt;
+        DA_OPB({ if (round < 2) pb_[3 + 2 * round] = __builtin_readcyclecounter(); })
+    }
+    DA_OPB({ if (p.prof && lane == 0) { pb_[7] = __builtin_readcyclecounter(); unsigned long long *o_ = p.prof + ((size_t)blockIdx.x * NWV + wid) * 8;
+             for (int k = 0; k < 8; ++k) o_[k] = pb_[k]; } })
+}
+
+static long long g_res_launches = 0;       // da_debug_counters [DA_DBG_RES_LAUNCHES]: launches of k_attn_res (tests: "the resident kernel took this layer")
+long long attn_res_launches(int reset) {
+    return reset ? __atomic_exchange_n(&g_res_launches, 0ll, __ATOMIC_RELAXED) : __atomic_load_n(&g_res_launches, __ATOMIC_RELAXED);
+}
+
+template <int NWV, bool QUEUE, bool KPF>
+static int launch_res(const AttnDenseParams &p, hipStream_t st) {
+    const int lds = ((p.max_nodes + 63) >> 6) * OptK<32, 64>::STAGE + 16;
+    static bool attr_done[16] = {};
+    int dev = 0;
+    DA_CHECK_HIP(hipGetDevice(&dev));
+    if (!attr_done[dev & 15]) {
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_res<NWV, QUEUE, KPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done[dev & 15] = true;
+    }
+    AttnDenseParams q = p;
+    DA_OPB({ const char *e = getenv("DA_OPT_PROF_PTR"); q.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; })
+    k_attn_res<NWV, QUEUE, KPF><<<p.H * p.n_graphs, 64 * NWV, lds, st>>>(q);
+    DA_LAUNCH_CHECK();
+    __atomic_fetch_add(&g_res_launches, 1ll, __ATOMIC_RELAXED);
+    return 0;
+}
+
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
 // bf16, Q pre-scaled, heads of 32 value channels: C = 32 (hidden layers) or C = 144 with p.fold_out (folded last layer);
@@ -744,6 +1005,15 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
         if (masked) return vm == 30 ? launch_optt<32, false, true, 4, 4, 64, 256>(p, st) : launch_optt<32, false, true, 4, 4>(p, st);
         static int v = -1;
         if (v < 0) v = env_int("DA_OPT_HID", 0);
+        // large complete graphs: the K / V-resident kernel (DA_ATTN_RES=0 keeps the ring kernel; DA_ATTN_RES_MIN = smallest "largest graph"
+        // it takes; the Batch's mean slot size must be at least half of its largest graph's -- a ragged Batch of small puzzles with one
+        // large one would leave most workgroups of sixteen waves with one or two slabs)
+        {
+            static int res = -1, res_min = 0, res_ph = 0;
+            if (res < 0) { res_min = env_int("DA_ATTN_RES_MIN", 512); res_ph = env_int("DA_ATTN_RES_PH", 1); res = env_int("DA_ATTN_RES", 1); }
+            if (res && v == 0 && p.max_nodes >= res_min && p.max_nodes <= 19 * 64 /* 19 stages + the queue word <= 160 KB */ && (long long)p.n_pad * 2 >= (long long)p.n_graphs * p.max_nodes)
+                return res_ph == 3 ? launch_res<16, false, true>(p, st) : res_ph == 4 ? launch_res<16, true, false>(p, st) : launch_res<16, true, true>(p, st);      // (3: fixed slabs; 4: no K prefetch)
+        }
         switch (v) {
             case 1: return launch_optt<32, false, false, 4, 4, 64, 1>(p, st);
             case 2: return launch_optt<32, false, false, 4, 4, 64, 2>(p, st);

@@ -144,6 +144,7 @@ int launch_attn_dual(const DenseLayout &L, int heads, int C, int n_graphs, int m
                      const int32_t *pad_ptr, int nodiag, int act, void *out, const DenseFold *fold, hipStream_t st);
 // fallback counters of the shift-free softmax kernels (da_debug_counters)
 int attn_dense_counters(unsigned long long *out4, int reset);
+long long attn_res_launches(int reset);      // da_attn_opt.hip: launches of the K / V-resident kernel since the last reset
 int attn_dual_counters(unsigned long long *out2, int reset);
 // hybrid mode: the rows the masked kernel does not own (virtual nodes) over their remainder edges
 int launch_attn_csr_cont(int prec, int n_nodes, int n_real, const int32_t *irr_row_ptr, const int32_t *irr_col_src,

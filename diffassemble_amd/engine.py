@@ -479,6 +479,14 @@ def debug_counters(reset=True):
     return {name: int(buf[k]) for k, name in enumerate(_lib.DBG_COUNTERS)}
 
 
+def resident_attention_launches(reset=True):
+    """Launches of the K / V-resident hidden-layer attention kernel (k_attn_res, da_attn_opt.hip) since the last reset
+    (da_debug_counters [DA_DBG_RES_LAUNCHES]): lets a test assert which kernel took a layer.  NOTE: resets every counter."""
+    buf = (C.c_int64 * 8)()
+    _lib.check(_lib.lib().da_debug_counters(buf, 8, 1 if reset else 0))
+    return int(buf[4])
+
+
 def greedy_assign(pos1, pos2, ptr1=None, ptr2=None):
     """greedy_cost_assignment (spatial_diffusion.py:179-216) for one puzzle or a whole Batch in ONE launch
     (da_greedy_assign): pos1 [N, >=2], pos2 [M, >=2] fp32 on a ROCm device; ptr1 / ptr2 int32 [G + 1] row

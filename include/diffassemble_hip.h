@@ -361,6 +361,8 @@ enum {
     DA_DBG_DENSE_FAST_EXITS = 1,           /* k_attn_dense waves that left the shift-free FAST mode                 */
     DA_DBG_DUAL_GEN_SLABS = 2,             /* k_attn_dual query slabs that left FAST mode                            */
     DA_DBG_OPT_MASKED_GEN_WORKGROUPS = 3,  /* adjacency-masked optimistic kernel: workgroups re-run                  */
+    DA_DBG_RES_LAUNCHES = 4,               /* launches of the K / V-resident hidden-layer kernel (k_attn_res; its    */
+                                           /* per-WAVE re-runs count under DA_DBG_OPT_GEN_WORKGROUPS)                */
     DA_DBG_NCOUNTERS = 8
 };
 int da_debug_counters(int64_t *out /* host [n] */, int n, int reset);

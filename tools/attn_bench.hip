@@ -161,6 +161,29 @@ int main(int argc, char **argv) {
         printf("\n");
         unsetenv("DA_OPT_PROF_PTR");
     }
+    if (getenv("PROBE3")) {         // DA_OPT_PROBE build, k_attn_res: per-wave stamps [entry, DMA issued, pass 0 end, slab 0 end, pass 1 end, slab 1 end, first barrier passed, exit]
+        const int nwv = 16, nwg = G * 8;
+        unsigned long long *dprof; CK(hipMalloc(&dprof, (size_t)nwg * nwv * 64)); CK(hipMemset(dprof, 0, (size_t)nwg * nwv * 64));
+        char buf[64]; snprintf(buf, sizeof buf, "%llu", (unsigned long long)dprof); setenv("DA_OPT_PROF_PTR", buf, 1);
+        for (int i = 0; i < 3; ++i) run();
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hp((size_t)nwg * nwv * 8); CK(hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost));
+        const char *nm[8] = {"entry", "DMA issued", "pass 0 end", "slab 0 end", "pass 1 end", "slab 1 end", "first barrier passed", "exit"};
+        for (int grp = 0; grp < 2; ++grp) {
+            double sum[8] = {0}; double mx[8] = {0}; int cnt = 0;
+            for (int w = 0; w < nwg * nwv; ++w) {
+                const unsigned long long *o = &hp[(size_t)w * 8];
+                const bool two = (w % nwv) < 13;
+                if (!o[0] || two != (grp == 0)) continue;
+                ++cnt;
+                for (int k = 1; k < 8; ++k) { const double d = o[k] ? (double)(o[k] - o[0]) : 0; sum[k] += d; mx[k] = std::max(mx[k], d); }
+            }
+            printf("probe3 %s (%d waves), cycles since entry, mean / max:", grp == 0 ? "waves with two slabs" : "waves with one slab", cnt);
+            for (int k : {1, 6, 2, 3, 4, 5, 7}) printf("  %s %.0f / %.0f", nm[k], cnt ? sum[k] / cnt : 0, mx[k]);
+            printf("\n");
+        }
+        unsetenv("DA_OPT_PROF_PTR");
+    }
     for (int i = 0; i < 5; ++i) run();
     CK(hipStreamSynchronize(st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
