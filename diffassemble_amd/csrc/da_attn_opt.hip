@@ -1,7 +1,8 @@
 // Optimistic-softmax block-diagonal attention on the matrix cores (bf16, Q PRE-SCALED by log2(e) / sqrt(C), 32-wide value
 // heads): one PyG TransformerConv attention (reference call sites backbones/Transformer_GNN.py:32,38;
 // backbones/exophormer_gnn.py:203,205) per launch, for
-//   k_attn_optt<32, false, false>   hidden layers on complete graphs (the class with the largest share of the sampling step)
+//   k_attn_optt<32, false, false>   hidden layers on complete graphs (the class with the largest share of the sampling step);
+//                                   Batches of 512 .. 1216-piece graphs go to k_attn_res below (K / V resident in LDS) since round 5
 //   k_attn_optt<144, true, false>   the last layer on complete graphs, value heads folded with final_mlp.0
 //   k_attn_optt<32, false, true>    hidden layers of hybrid graphs (adjacency-masked: Exphander + exophormer, config 3)
 //   k_attn_optt<144, true, true>    their folded last layer
@@ -747,8 +748,11 @@ static int launch_optt(AttnDenseParams p, hipStream_t st) {
 // global memory (lane (i, half) owns channels 8 jj + 4 half .. + 3 of query i: 8-byte skip loads and stores) -- no LDS staging,
 // no workgroup barrier per slab.  32 puzzles x 8 heads = 256 workgroups = one per CU.  Reference: the same TransformerConv
 // attention (backbones/Transformer_GNN.py:32).
-template <int NWV, bool QUEUE, bool KPF>
+template <int NWV, bool QUEUE, bool KPF, int XV = 0>
 __global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
+    // XV (experiments, A/B through DA_ATTN_RES_PH): bit 0 = two PV accumulators (keys 0 .. 15 / 16 .. 31 of every block: no product waits for
+    // the one before it on the same registers); bit 1 = the younger half of the waves at priority 1 (the arbiter favours old waves)
+    constexpr bool O2 = (XV & 1) != 0;
     using T = bf16_t;
     constexpr int C = 32, CV = 32;
     using CF = Cfg<T, C, CV, 64>;
@@ -815,8 +819,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
 
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
-    f32x16 O;
+    f32x16 O, Ob;
     float ls, m;
+    if (XV & 2) { if (wid >= NWV / 2) __builtin_amdgcn_s_setprio(1); }
     // byte offset of 32-key block b inside the K (or, + KBYTES, the V) image: stage b / 2, block b % 2
     auto boff = [&](int b) { return (b >> 1) * STAGE + (b & 1) * 2048; };
 
@@ -825,7 +830,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
         bool gen = p.force_gen != 0;
         auto pass = [&]() {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[r] = 0.f;
+            for (int r = 0; r < 16; ++r) { O[r] = 0.f; if (O2) Ob[r] = 0.f; }
             ls = 0.f;
             m = -1e30f;
             u32x4 kf[CF::NCH];
@@ -877,7 +882,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
                     if (__any(mnew > m)) {
                         const float corr = __builtin_amdgcn_exp2f(m - mnew);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) O[r] *= corr;
+                        for (int r = 0; r < 16; ++r) { O[r] *= corr; if (O2) Ob[r] *= corr; }
                         ls *= corr;
                         m = mnew;
                     }
@@ -897,7 +902,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
                 const u32x4 v0 = {vlo[0][0], vlo[0][1], vhi[0][0], vhi[0][1]};
                 const u32x4 v1 = {vlo[1][0], vlo[1][1], vhi[1][0], vhi[1][1]};
                 O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O, 0, 0, 0);
-                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
+                if (O2) Ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, Ob, 0, 0, 0);
+                else O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bf16x2 pa = {pf0[2 * e], pf0[2 * e + 1]}, pb = {pf1[2 * e], pf1[2 * e + 1]};
@@ -907,6 +913,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
             }
         };
         pass();
+        if (O2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[r] += Ob[r];
+        }
         DA_OPB({ asm volatile("" : "+v"(O), "+v"(ls)); if (round < 2) pb_[2 + 2 * round] = __builtin_readcyclecounter(); })
         if (!gen) {
             // verification of the optimistic pass, per WAVE (the waves share nothing but the resident tiles)
@@ -916,6 +926,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
                 gen = true;
                 if (lane == 0) atomicAdd(&g_opt_fallbacks[0], 1ull);
                 pass();
+                if (O2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[r] += Ob[r];
+                }
             }
         }
         // the next slab (drawn from the queue) and its Q fragments, which travel under this slab's epilogue
@@ -972,19 +986,19 @@ long long attn_res_launches(int reset) {
     return reset ? __atomic_exchange_n(&g_res_launches, 0ll, __ATOMIC_RELAXED) : __atomic_load_n(&g_res_launches, __ATOMIC_RELAXED);
 }
 
-template <int NWV, bool QUEUE, bool KPF>
+template <int NWV, bool QUEUE, bool KPF, int XV = 0>
 static int launch_res(const AttnDenseParams &p, hipStream_t st) {
     const int lds = ((p.max_nodes + 63) >> 6) * OptK<32, 64>::STAGE + 16;
     static bool attr_done[16] = {};
     int dev = 0;
     DA_CHECK_HIP(hipGetDevice(&dev));
     if (!attr_done[dev & 15]) {
-        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_res<NWV, QUEUE, KPF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_res<NWV, QUEUE, KPF, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev & 15] = true;
     }
     AttnDenseParams q = p;
     DA_OPB({ const char *e = getenv("DA_OPT_PROF_PTR"); q.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; })
-    k_attn_res<NWV, QUEUE, KPF><<<p.H * p.n_graphs, 64 * NWV, lds, st>>>(q);
+    k_attn_res<NWV, QUEUE, KPF, XV><<<p.H * p.n_graphs, 64 * NWV, lds, st>>>(q);
     DA_LAUNCH_CHECK();
     __atomic_fetch_add(&g_res_launches, 1ll, __ATOMIC_RELAXED);
     return 0;
@@ -1012,7 +1026,14 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
             static int res = -1, res_min = 0, res_ph = 0;
             if (res < 0) { res_min = env_int("DA_ATTN_RES_MIN", 512); res_ph = env_int("DA_ATTN_RES_PH", 1); res = env_int("DA_ATTN_RES", 1); }
             if (res && v == 0 && p.max_nodes >= res_min && p.max_nodes <= 19 * 64 /* 19 stages + the queue word <= 160 KB */ && (long long)p.n_pad * 2 >= (long long)p.n_graphs * p.max_nodes)
-                return res_ph == 3 ? launch_res<16, false, true>(p, st) : res_ph == 4 ? launch_res<16, true, false>(p, st) : launch_res<16, true, true>(p, st);      // (3: fixed slabs; 4: no K prefetch)
+                switch (res_ph) {          // A/B switches (DA_ATTN_RES_PH); default 1
+                    case 3: return launch_res<16, false, true>(p, st);         // fixed slabs (wave, wave + 16)
+                    case 4: return launch_res<16, true, false>(p, st);         // no K-fragment prefetch
+                    case 5: return launch_res<16, true, true, 1>(p, st);       // two PV accumulators
+                    case 6: return launch_res<16, true, true, 2>(p, st);       // younger half of the waves at priority 1
+                    case 7: return launch_res<16, true, true, 3>(p, st);
+                    default: return launch_res<16, true, true>(p, st);
+                }
         }
         switch (v) {
             case 1: return launch_optt<32, false, false, 4, 4, 64, 1>(p, st);
