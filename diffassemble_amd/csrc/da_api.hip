@@ -271,11 +271,12 @@ static int timed(da_denoiser *d, int cls, hipStream_t st, F &&launch) {
 
 static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const int64_t *t, int64_t t_scalar,
                         float *out, float *alpha, int alpha_all, float *pre_head, const Workspace &w,
-                        hipStream_t st, DdimFuse *ddim = nullptr, bool uncond = false) {
+                        hipStream_t st, DdimFuse *ddim = nullptr, bool uncond = false, bool h_ready = false) {
     const int prec = d->prec, nr = g->n_real, n = g->n_nodes, D = d->D;
     int rc;
     // (a-3) embedding: pose MLP + learned timestep lookup into the concat buffer, then mlp
-    if ((rc = timed(d, DA_PROF_EMBED, st, [&] {
+    // (h_ready: the previous step's tail kernel already wrote this step's w.h -- DdimFuse::nx_*, sampling loops only)
+    if (!h_ready && (rc = timed(d, DA_PROF_EMBED, st, [&] {
              return launch_embed_pos_time(prec, nr, d->c_in, d->F, D, x, t, t_scalar, d->steps, d->time_emb,
                                           d->pos_w0, d->pos_b0, d->pos_w1, d->pos_b1, w.comb_in, st); }))) return rc;
     const int act1 = d->variant == DA_VARIANT_3D ? DA_ACT_LEAKY02 : DA_ACT_GELU;
@@ -284,7 +285,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
     // sampling loop, so their part of the product (+ bias) was computed once in da_denoiser_set_features;
     // per step only the 64 pose / timestep columns are multiplied and the cached part is added before the
     // activation (the reference recomputes the whole Linear(1152 -> 128) every step)
-    if ((rc = timed(d, DA_PROF_LINEAR_MLP, st, [&] {
+    if (!h_ready && (rc = timed(d, DA_PROF_LINEAR_MLP, st, [&] {
              const size_t es_ = esize(prec);
              int r2 = mfma_disabled() ? -1
                                       : launch_gemm_mfma(prec, nr, D - d->F, d->hidden, w.comb_in + (size_t)d->F * es_, D,
@@ -785,16 +786,27 @@ static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s,
     const bool cfg = o && o->cfg, ddpm = o && o->sampler == 1;
     const float eta = o ? o->eta : 0.f;
     const bool plain = !cfg && !ddpm && eta == 0.f;
+    bool h_ready = false;           // w.h already holds this step's value (written by the previous step's tail kernel)
     for (int i = first; i >= 0 && it < n_iters; i -= ratio, ++it) {
         float *nxt = traj ? traj + (size_t)it * (traj_stride ? traj_stride : (size_t)nr * c) : ((it & 1) ? w.xbuf1 : w.xbuf0);
         const int nonneg = (i - ratio) >= 0;
         DdimFuse df;
         df.s = ds; df.mean_type = mean_type; df.ratio = ratio; df.prev_all_nonneg = nonneg; df.t = i; df.x = cur; df.x_prev = nxt;
         df.done = 0;
+        df.nx_on = 0; df.nx_done = 0;
         static int fuse_off = -1;
         if (fuse_off < 0) { const char *e = getenv("DA_DISABLE_DDIM_FUSION"); fuse_off = (e && e[0] == '1') ? 1 : 0; }
         const bool try_fuse = plain && !fuse_off && d->variant == DA_VARIANT_2D && !d->prof_on;
-        if ((rc = forward_impl(d, g, cur, nullptr, i, w.model_out, nullptr, 0, nullptr, w, st, try_fuse ? &df : nullptr))) return rc;
+        // the tail kernel of this step may also produce the NEXT step's h (embedding + mlp.0 over the hoisted feature part): bf16, the 2D
+        // transformer widths, a next step that exists
+        if (try_fuse && nonneg && it + 1 < n_iters && d->prec == DA_PREC_BF16 && d->hidden == 128 && d->D - d->F == 64 && w.feat_proj &&
+            !mfma_disabled()) {
+            df.nx_on = 1; df.nx_t = i - ratio; df.nx_steps = d->steps; df.nx_cin = d->c_in; df.nx_ldw = d->D;
+            df.nx_time_emb = d->time_emb; df.nx_w0 = d->pos_w0; df.nx_b0 = d->pos_b0; df.nx_w1 = d->pos_w1; df.nx_b1 = d->pos_b1;
+            df.nx_wp = (const char *)d->mlp_w0 + (size_t)d->F * esize(d->prec); df.nx_feat_proj = w.feat_proj; df.nx_h = w.h;
+        }
+        if ((rc = forward_impl(d, g, cur, nullptr, i, w.model_out, nullptr, 0, nullptr, w, st, try_fuse ? &df : nullptr, false, h_ready))) return rc;
+        h_ready = df.done && df.nx_done;
         if (df.done) { cur = nxt; continue; }
         if (cfg) {
             if ((rc = forward_impl(d, g, cur, nullptr, i, w.model_out_unc, nullptr, 0, nullptr, w, st, nullptr, true))) return rc;

@@ -377,7 +377,9 @@ __global__ __launch_bounds__(256) void k_head_fold(int n, int H, int c_out, cons
 typedef __attribute__((ext_vector_type(8))) __bf16 tl_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float tl_f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int tl_u32x4;
-__global__ __launch_bounds__(64) void k_tail_fused(int n, int H, int c_out, const bf16_t *__restrict__ h, const bf16_t *__restrict__ xin,
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <bool NEXT>
+__global__ __launch_bounds__(64) void k_tail_fused(int n, int H, int c_out, const bf16_t *h, const bf16_t *__restrict__ xin,
                                                    int ldx, const bf16_t *__restrict__ wh, const float *__restrict__ bh,
                                                    const bf16_t *__restrict__ wsk, const float *__restrict__ bsk,
                                                    const bf16_t *__restrict__ pz, const float *__restrict__ w2,
@@ -428,7 +430,10 @@ __global__ __launch_bounds__(64) void k_tail_fused(int n, int H, int c_out, cons
             for (int e = 0; e < 4; ++e) f[4 * q + e] = gelu_erf(a[e]);
         }
         // second linear: this lane's 16 channels, then the other half's
-        for (int j = 0; j < c_out; ++j) {
+        float xn[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};            // NEXT: this row's updated sample (both halves hold it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j >= c_out) break;
             float part = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -437,10 +442,93 @@ __global__ __launch_bounds__(64) void k_tail_fused(int n, int H, int c_out, cons
                 part = fmaf(g ? whi : wlo, f[r], part);
             }
             const float a = b2[j] + part + __shfl_xor(part, 32);
+            const size_t o = (size_t)row * c_out + j;
+            if (df.x_prev) xn[j] = ddim2d_value(df.s, df.mean_type, df.t, df.ratio, df.prev_all_nonneg, 0.f, df.x[o], a, 0.f);
             if (g == 0 && row0 + m < n) {
-                const size_t o = (size_t)(row0 + m) * c_out + j;
                 out[o] = a;
-                if (df.x_prev) df.x_prev[o] = ddim2d_value(df.s, df.mean_type, df.t, df.ratio, df.prev_all_nonneg, 0.f, df.x[o], a, 0.f);
+                if (df.x_prev) df.x_prev[o] = xn[j];
+            }
+        }
+        if (NEXT) {
+            // ---- the next step's h rows (efficient_gat.py:131-135 with the feature part of mlp.0 hoisted): pose MLP in fp32 exactly as
+            // k_embed_pos_time does it (hidden = GELU(W0 x + b0), pos = W1 hidden + b1), pos | time_emb[t'] rounded to bf16 (the concat
+            // buffer's dtype), then h = GELU(Wp [pos | time] + feat_proj) on the matrix cores, transposed as above.
+            const int cin = df.nx_cin;
+            float hm[8];                    // hidden units 8 g .. 8 g + 7 of this row; the other half computes the other eight
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                float a = g ? df.nx_b0[8 + kk] : df.nx_b0[kk];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < cin) a += (g ? df.nx_w0[(8 + kk) * cin + j] : df.nx_w0[kk * cin + j]) * xn[j];
+                hm[kk] = gelu_erf(a);
+            }
+            float hid[16];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float ho = __shfl_xor(hm[kk], 32);
+                hid[kk] = g ? ho : hm[kk];
+                hid[8 + kk] = g ? hm[kk] : ho;
+            }
+            long long ti = df.nx_t;
+            ti = ti < 0 ? 0 : (ti >= df.nx_steps ? df.nx_steps - 1 : ti);
+            tl_u32x4 bx[4];                 // B operand: chunk c = columns 16 c + 8 g .. + 7 of [pos(32) | time(32)] of this row
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                unsigned pk[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    unsigned short two[2];
+#pragma unroll
+                    for (int z = 0; z < 2; ++z) {
+                        const int o = 16 * c + 8 * g + 2 * e2 + z;
+                        const f32x4_t *wr = (const f32x4_t *)(df.nx_w1 + (size_t)o * 16);
+                        float a = df.nx_b1[o];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const f32x4_t w4 = wr[q4];
+                            a += w4[0] * hid[4 * q4]; a += w4[1] * hid[4 * q4 + 1]; a += w4[2] * hid[4 * q4 + 2]; a += w4[3] * hid[4 * q4 + 3];
+                        }
+                        two[z] = f2bf(a);
+                    }
+                    pk[e2] = (unsigned)two[0] | ((unsigned)two[1] << 16);
+                }
+                bx[c] = (tl_u32x4){pk[0], pk[1], pk[2], pk[3]};
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f32x4_t *tr = (const f32x4_t *)(df.nx_time_emb + (size_t)ti * 32 + 16 * c + 8 * g);
+                const f32x4_t t0 = tr[0], t1 = tr[1];
+                bx[2 + c] = (tl_u32x4){(unsigned)f2bf(t0[0]) | ((unsigned)f2bf(t0[1]) << 16), (unsigned)f2bf(t0[2]) | ((unsigned)f2bf(t0[3]) << 16),
+                                       (unsigned)f2bf(t1[0]) | ((unsigned)f2bf(t1[1]) << 16), (unsigned)f2bf(t1[2]) | ((unsigned)f2bf(t1[3]) << 16)};
+            }
+            const bf16_t *wp = (const bf16_t *)df.nx_wp;
+            const bf16_t *fp = (const bf16_t *)df.nx_feat_proj + (size_t)row * 128;
+            bf16_t *hn = (bf16_t *)df.nx_h + (size_t)row * 128;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                tl_u32x4 wa[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wa[c] = *(const tl_u32x4 *)(wp + (size_t)(32 * mt + m) * df.nx_ldw + 16 * c + 8 * g);
+                uint2 fpv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fpv[q] = *(const uint2 *)(fp + 32 * mt + 8 * q + 4 * g);
+                tl_f32x16 ac;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ac[r] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tl_bf16x8, wa[c]), __builtin_bit_cast(tl_bf16x8, bx[c]), ac, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4] = {ac[4 * q] + bf2f((bf16_t)(fpv[q].x & 0xffff)), ac[4 * q + 1] + bf2f((bf16_t)(fpv[q].x >> 16)),
+                                  ac[4 * q + 2] + bf2f((bf16_t)(fpv[q].y & 0xffff)), ac[4 * q + 3] + bf2f((bf16_t)(fpv[q].y >> 16))};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    if (row0 + m < n)
+                        *(uint2 *)(hn + 32 * mt + 8 * q + 4 * g) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                                                              (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                }
             }
         }
     }
@@ -449,7 +537,7 @@ __global__ __launch_bounds__(64) void k_tail_fused(int n, int H, int c_out, cons
 // returns 0 = launched, -1 = shape / precision not covered (the caller runs the three-kernel tail)
 int launch_tail_fused(int prec, int n, int H, int c_out, int hidden, int din, const void *h, const void *xin, int ldx, const void *wh,
                       const float *bh, const void *wsk, const float *bsk, const void *pz, const float *w2, const float *b2, float *out,
-                      hipStream_t st, const DdimFuse *dfp) {
+                      hipStream_t st, DdimFuse *dfp) {
     static int off = -1;
     if (off < 0) { const char *e = getenv("DA_TAIL_FUSED"); off = (e && e[0] == '0') ? 1 : 0; }
     if (off || prec != DA_PREC_BF16 || hidden != 128 || din != 256 || H > 8 || c_out > 8 || (ldx & 7)) return -1;
@@ -461,9 +549,21 @@ int launch_tail_fused(int prec, int n, int H, int c_out, int hidden, int din, co
     const int slabs = (n + 31) / 32;
     int spw = (slabs + 1023) / 1024;
     spw = spw < 1 ? 1 : (spw > 4 ? 4 : spw);
-    k_tail_fused<<<(slabs + spw - 1) / spw, 64, 0, st>>>(n, H, c_out, (const bf16_t *)h, (const bf16_t *)xin, ldx, (const bf16_t *)wh, bh,
-                                                         (const bf16_t *)wsk, bsk, (const bf16_t *)pz, w2, b2, out, df, spw);
+    // the next step's embedding + mlp.0 in the same kernel (DdimFuse::nx_*): OPT-IN, DA_TAIL_NEXT=1.  Measured (round 5, last session; A/B on
+    // one box): parity-clean (tests/test_gpu_tail_next.py) and two launches fewer per step, but not faster -- headline 0.6786 / 0.6890 ms
+    // without, 0.6788 / 0.6845 with; one-branch loop 0.7175 -> 0.7154; configuration 2 (512 x 144 pieces) 0.6346 -> 0.6428: the work moves into a
+    // kernel that runs one wave per SIMD at 255 VGPRs (64 more GELUs and 16 MFMAs per lane and slab), which costs what the launches cost.
+    static int nx_off = -1;
+    if (nx_off < 0) { const char *e = getenv("DA_TAIL_NEXT"); nx_off = (e && e[0] == '1') ? 0 : 1; }
+    const bool next = dfp && df.x_prev && df.nx_on && !nx_off && df.nx_cin <= 8 && df.nx_cin == c_out && df.nx_h == h;
+    if (next)
+        k_tail_fused<true><<<(slabs + spw - 1) / spw, 64, 0, st>>>(n, H, c_out, (const bf16_t *)h, (const bf16_t *)xin, ldx, (const bf16_t *)wh, bh,
+                                                                   (const bf16_t *)wsk, bsk, (const bf16_t *)pz, w2, b2, out, df, spw);
+    else
+        k_tail_fused<false><<<(slabs + spw - 1) / spw, 64, 0, st>>>(n, H, c_out, (const bf16_t *)h, (const bf16_t *)xin, ldx, (const bf16_t *)wh, bh,
+                                                                    (const bf16_t *)wsk, bsk, (const bf16_t *)pz, w2, b2, out, df, spw);
     DA_LAUNCH_CHECK();
+    if (next) dfp->nx_done = 1;
     return 0;
 }
 

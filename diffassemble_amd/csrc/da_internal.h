@@ -37,6 +37,16 @@ struct DdimFuse {
     const float *x;            // [n, c] current sample (c == c_out)
     float *x_prev;             // [n, c]
     int done;
+    // the NEXT step's embedding + mlp.0 computed by the tail kernel itself (k_tail_fused, plain DDIM loops): the rows of x_prev never leave the
+    // registers before they become the next step's h = GELU(mlp.0([features | pos_mlp(x_prev) | time_emb[t - ratio]])) -- per-row work that
+    // used to be two more launches per step (k_embed_pos_time + the K = 64 GEMM over the hoisted feature part).  nx_on: requested by the
+    // loop; nx_done: the kernel that ran did it (the next forward skips its embedding and mlp.0).
+    int nx_on, nx_done, nx_steps, nx_cin, nx_ldw;
+    long long nx_t;
+    const float *nx_time_emb, *nx_w0, *nx_b0, *nx_w1, *nx_b1;
+    const void *nx_wp;         // bf16 mlp.0 weight, columns F .. F + 63 (row stride nx_ldw elements)
+    const void *nx_feat_proj;  // bf16 [n, 128]: mlp.0 over the feature columns + bias (hoisted)
+    void *nx_h;                // bf16 [n, 128]: written in place (the rows this wave has already consumed)
 };
 
 // da_basic.hip
@@ -78,7 +88,7 @@ int launch_scatter_virtual(int prec, int rows, int V, int H, int C, const void *
                            int n_pad, void *Q, void *K, void *Vt, void *S, void *qkvs, hipStream_t st);
 int launch_tail_fused(int prec, int n, int H, int c_out, int hidden, int din, const void *h, const void *xin, int ldx, const void *wh,
                       const float *bh, const void *wsk, const float *bsk, const void *pz, const float *w2, const float *b2, float *out,
-                      hipStream_t st, const DdimFuse *dfp);
+                      hipStream_t st, DdimFuse *dfp);
 int launch_head_fold(int prec, int n, int H, int c_out, const void *pz, const void *pre, const float *w2, const float *b2,
                      float *out, hipStream_t st, const DdimFuse *df = nullptr);
 
