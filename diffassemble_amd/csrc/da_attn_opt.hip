@@ -749,7 +749,7 @@ static int launch_optt(AttnDenseParams p, hipStream_t st) {
 // no workgroup barrier per slab.  32 puzzles x 8 heads = 256 workgroups = one per CU.  Reference: the same TransformerConv
 // attention (backbones/Transformer_GNN.py:32).
 template <int NWV, bool QUEUE, bool KPF, int XV = 0>
-__global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
+__global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 4 : 5)) void k_attn_res(AttnDenseParams p) {
     // XV (experiments, A/B through DA_ATTN_RES_PH): bit 0 = two PV accumulators (keys 0 .. 15 / 16 .. 31 of every block: no product waits for
     // the one before it on the same registers); bit 1 = the younger half of the waves at priority 1 (the arbiter favours old waves)
     constexpr bool O2 = (XV & 1) != 0;
@@ -757,9 +757,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
     constexpr int C = 32, CV = 32;
     using CF = Cfg<T, C, CV, 64>;
     using KG = OptK<C, 64>;
-    static_assert(KG::NI == 8 && NWV % 8 == 0, "eight 1 KB pieces per 64-key stage, one per wave of an octet");
+    static_assert(KG::NI == 8, "eight 1 KB pieces per 64-key stage");
+    // NWV = 16: the large graphs described above.  NWV = 5 / 8 (SMALL graphs: 129 .. 160 / 161 .. 256 pieces, one slab per wave, no queue): the
+    // same kernel as "one workgroup per (graph, head) of a 12 x 12 / 16 x 16 puzzle" -- the ring kernel spends two 128-query tiles on a
+    // 144-piece graph (the second with 16 queries) and a prologue, three barriers and an LDS-staged epilogue on five blocks of work; here four
+    // workgroups of five waves share a CU, each fetches its 18 KB once and every wave does its five blocks and its own epilogue.
     static_assert(CF::ROWB == 64 && CF::ROWBV == 64 && KG::RS == 64 && CF::RSV == 64 && KG::KBYTES == 4096, "one tile stride for K and V; 2 KB per 32-key block");
-    constexpr int TPW = NWV / 8;               // an octet of waves fetches every TPW-th tile
+    constexpr int TPW = NWV >= 8 ? NWV / 8 : 1;               // (NWV a multiple of 8) an octet of waves fetches every TPW-th tile
     constexpr int STAGE = KG::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DA_OPB(unsigned long long pb_[8] = {__builtin_readcyclecounter(), 0, 0, 0, 0, 0, 0, 0};)
@@ -784,7 +788,26 @@ __global__ __launch_bounds__(64 * NWV, 1) void k_attn_res(AttnDenseParams p) {
     const int nkt = upad ? (npg >> 6) : ((n_g + 63) >> 6);          // tiles to fetch (upad: the whole slot -- its rows beyond n_g are readable padding)
 
     // ---- the whole K | V of the head: wave w issues piece (w & 7) of tiles (w >> 3), (w >> 3) + TPW, ... (scalar base + lane offset form)
-    {
+    if constexpr (NWV % 8 != 0) {
+        // any number of waves: the 8 nkt pieces dealt out round-robin (the lane offset depends on the piece: recomputed per instruction)
+        for (int idx = wid; idx < nkt * 8; idx += NWV) {
+            const int kt = idx >> 3, pq = idx & 7;          // wave-uniform
+            unsigned so_;
+            if (pq < KG::NIK) {
+                const int s = pq * 64 + lane, row = s / KG::KSPR, col = s - row * KG::KSPR;
+                so_ = (unsigned)(row * CF::ROWB + (col ^ KG::f(row)) * 16);
+            } else {
+                const int s = (pq - KG::NIK) * 64 + lane, row = s / CF::VSPR, col = s - row * CF::VSPR;
+                so_ = (unsigned)(row * CF::ROWBV + col * 16);
+            }
+            const unsigned long long sa = (unsigned long long)(size_t)((pq < KG::NIK ? Kg : Vg) + (size_t)kt * 64 * CF::ROWB);
+            // (wave-uniform by construction; said explicitly, the address lands in scalar registers)
+            const unsigned long long su = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa) |
+                                          ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) << 32);
+            const unsigned ml = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(kt * STAGE + pq * 1024)));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ml), "v"(so_), "s"((const unsigned char *)(size_t)su) : "memory");
+        }
+    } else {
         const int pq = wid & 7, t0 = wid >> 3;
         unsigned so_;
         if (pq < KG::NIK) {
@@ -1032,6 +1055,13 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
         {
             static int res = -1, res_min = 0, res_ph = 0;
             if (res < 0) { res_min = env_int("DA_ATTN_RES_MIN", 512); res_ph = env_int("DA_ATTN_RES_PH", 1); res = env_int("DA_ATTN_RES", 1); }
+            // OPT-IN (DA_ATTN_RES_SMALL=1; 2 = the 105-VGPR build): measured on 12 x 12 puzzles -- 35.5 -> 32.4 us per 256-puzzle launch alone
+            // (58.0 against 63.6 at 512), and configuration 2's step 0.6370 / 0.6315 -> 0.6407 / 0.6370 ms: faster alone, not in the two-branch step
+            static int res_small = -1;
+            if (res_small < 0) res_small = env_int("DA_ATTN_RES_SMALL", 0);
+            if (res && res_small && v == 0 && p.max_nodes > 128 && p.max_nodes <= 160 && (long long)p.n_pad * 2 >= (long long)p.n_graphs * p.max_nodes)
+                return res_small == 2 ? launch_res<5, false, true, 8>(p, st)        // (2: 105 VGPRs, no spill, three workgroups per CU)
+                                      : launch_res<5, false, true>(p, st);          // 12 x 12 puzzles: five slabs, five waves, four workgroups per CU (96 VGPRs)
             if (res && v == 0 && p.max_nodes >= res_min && p.max_nodes <= 19 * 64 /* 19 stages + the queue word <= 160 KB */ && (long long)p.n_pad * 2 >= (long long)p.n_graphs * p.max_nodes)
                 switch (res_ph) {          // A/B switches (DA_ATTN_RES_PH); default 1
                     case 3: return launch_res<16, false, true>(p, st);         // fixed slabs (wave, wave + 16)

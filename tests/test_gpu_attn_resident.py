@@ -126,3 +126,32 @@ def test_the_900_piece_fallback_suite_on_the_ring_kernel_subprocess():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_softmax_fallbacks.py"),
                         "-k", "900_pieces and c32 and bf16"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+_SMALL = r"""
+import sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import test_gpu_softmax_fallbacks as F
+from diffassemble_amd import engine as E
+dev = torch.device("cuda:0")
+for sizes, loops, kind in (([144] * 5, True, "m44"), ([144, 129, 160, 150], False, "m44"), ([144] * 3, True, "m80"), ([160, 144], True, "late_outlier")):
+    row, key, who = F.offsets_for(kind, sizes)
+    x, ws, bs = F.build_layer(sizes, 32, False, 2, row, key, True)
+    ref = F.reference(x, ws, bs, sizes, loops, 32, False, True)
+    E.resident_attention_launches(reset=True)
+    out, cnt = F.run_layer(dev, sizes, loops, 32, False, "bf16", x, ws, bs)
+    assert torch.isfinite(out).all()
+    assert F.rel(out, ref) < 1e-2, (sizes, kind, F.rel(out, ref))
+    if who == "all":
+        assert cnt["opt_gen_workgroups"] > 0, cnt
+print("launches-checked")
+"""
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_small_graph_instance_subprocess(dev, mode):
+    """DA_ATTN_RES_SMALL=1 / 2 (opt-in): the five-wave instance for 129 .. 160-piece graphs -- one workgroup per (graph, head) of a 12 x 12
+    puzzle -- against the fp64 PyG formula, with and without self loops, through its per-wave fallback."""
+    env = dict(os.environ, DA_ATTN_RES_SMALL=mode)
+    r = subprocess.run([sys.executable, "-c", _SMALL.format(root=ROOT, tests=os.path.join(ROOT, "tests"))], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "launches-checked" in r.stdout, r.stderr[-3000:]
