@@ -132,7 +132,7 @@ struct da_denoiser {
     // da_sample_loop_pair: the second branch of the two-branch loop graph
     hipStream_t pair_stream = nullptr;
     hipEvent_t ev_pair_fork = nullptr, ev_pair_join = nullptr;
-    struct PairEntry { LoopKey a, b; hipGraphExec_t exec; };
+    struct PairEntry { LoopKey a, b; hipGraphExec_t exec; hipGraphExec_t exec_b; };      // exec_b: the second branch as a graph of its own (split mode), else null
     std::vector<PairEntry> pair_loops;
 };
 
@@ -696,7 +696,7 @@ void da_denoiser_destroy(da_denoiser *d) {
     if (d->side_stream) (void)hipStreamDestroy(d->side_stream);
     if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
     if (d->ev_join) (void)hipEventDestroy(d->ev_join);
-    for (auto &e : d->pair_loops) (void)hipGraphExecDestroy(e.exec);
+    for (auto &e : d->pair_loops) { (void)hipGraphExecDestroy(e.exec); if (e.exec_b) (void)hipGraphExecDestroy(e.exec_b); }
     if (d->pair_stream) (void)hipStreamDestroy(d->pair_stream);
     if (d->ev_pair_fork) (void)hipEventDestroy(d->ev_pair_fork);
     if (d->ev_pair_join) (void)hipEventDestroy(d->ev_pair_join);
@@ -937,12 +937,62 @@ int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, 
     LoopKey kb = make_key(g_b, x_init_b, x_final_b, workspace_b, workspace_b_bytes, traj_b);
     ka.opts = oa; kb.opts = ob;
     ka.noise_stride = oa.noise ? noise_stride : 0; kb.noise_stride = ob.noise ? noise_stride : 0;
-    hipGraphExec_t exec = nullptr;
+    // DA_PAIR_SPLIT (default 1): the two branches as TWO graphs, launched on the caller's stream and on the library's pair stream between a
+    // fork and a join event, instead of two parallel branches of one graph.  Measured (tools/multi_branch_probe.py, round 5): two independently
+    // launched one-branch graphs of 32 puzzles ran a 64-puzzle step in 0.6734 ms where the one-graph pair loop needed 0.7002 on the same box --
+    // the runtime does not run the two branches of one graph as independently as it runs two graphs on two streams.
+    static int split_mode = -1;
+    if (split_mode < 0) { const char *ev = getenv("DA_PAIR_SPLIT"); split_mode = ev ? atoi(ev) : 1; }
+    hipGraphExec_t exec = nullptr, exec_b = nullptr;
     for (auto &e : d->pair_loops)
-        if (memcmp(&ka, &e.a, sizeof(ka)) == 0 && memcmp(&kb, &e.b, sizeof(kb)) == 0) exec = e.exec;
+        if (memcmp(&ka, &e.a, sizeof(ka)) == 0 && memcmp(&kb, &e.b, sizeof(kb)) == 0 && (e.exec_b != nullptr) == (split_mode != 0)) { exec = e.exec; exec_b = e.exec_b; }
+    if (!exec && split_mode) {
+        if (d->pair_loops.size() >= 4) {
+            (void)hipGraphExecDestroy(d->pair_loops.front().exec);
+            if (d->pair_loops.front().exec_b) (void)hipGraphExecDestroy(d->pair_loops.front().exec_b);
+            d->pair_loops.erase(d->pair_loops.begin());
+        }
+        if (!d->cap_stream) DA_CHECK_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
+        if (!d->pair_stream) {
+            DA_CHECK_HIP(hipStreamCreateWithFlags(&d->pair_stream, hipStreamNonBlocking));
+            DA_CHECK_HIP(hipEventCreateWithFlags(&d->ev_pair_fork, hipEventDisableTiming));
+            DA_CHECK_HIP(hipEventCreateWithFlags(&d->ev_pair_join, hipEventDisableTiming));
+        }
+        hipGraphExec_t ex2[2] = {nullptr, nullptr};
+        for (int br = 0; br < 2; ++br) {
+            hipStream_t cs = d->cap_stream;
+            hipGraph_t graph = nullptr;
+            DA_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+            const int rcx = br == 0 ? enqueue_loop(d, g_a, s, mean_type, inference_ratio, n_iters, x_init_a, traj_a, x_final_a, wa, cs, &oa, traj_stride, noise_stride)
+                                    : enqueue_loop(d, g_b, s, mean_type, inference_ratio, n_iters, x_init_b, traj_b, x_final_b, wb, cs, &ob, traj_stride, noise_stride);
+            const hipError_t e2 = hipStreamEndCapture(cs, &graph);
+            hipError_t e3 = hipSuccess;
+            if (!rcx && e2 == hipSuccess && graph) e3 = hipGraphInstantiate(&ex2[br], graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rcx || e2 != hipSuccess || e3 != hipSuccess || !ex2[br]) {
+                if (ex2[0]) (void)hipGraphExecDestroy(ex2[0]);
+                if (rcx) return rcx;
+                set_error("da_sample_loop_pair: capture of branch %d failed: %s", br, hipGetErrorString(e2 != hipSuccess ? e2 : e3));
+                return 2;
+            }
+        }
+        exec = ex2[0]; exec_b = ex2[1];
+        d->pair_loops.push_back({ka, kb, exec, exec_b});
+    }
+    if (exec && exec_b) {
+        hipStream_t us = (hipStream_t)stream, ps = d->pair_stream;
+        DA_CHECK_HIP(hipEventRecord(d->ev_pair_fork, us));
+        DA_CHECK_HIP(hipStreamWaitEvent(ps, d->ev_pair_fork, 0));
+        DA_CHECK_HIP(hipGraphLaunch(exec, us));
+        DA_CHECK_HIP(hipGraphLaunch(exec_b, ps));
+        DA_CHECK_HIP(hipEventRecord(d->ev_pair_join, ps));
+        DA_CHECK_HIP(hipStreamWaitEvent(us, d->ev_pair_join, 0));
+        return 0;
+    }
     if (!exec) {
         if (d->pair_loops.size() >= 4) {
             (void)hipGraphExecDestroy(d->pair_loops.front().exec);
+            if (d->pair_loops.front().exec_b) (void)hipGraphExecDestroy(d->pair_loops.front().exec_b);
             d->pair_loops.erase(d->pair_loops.begin());
         }
         if (!d->cap_stream) DA_CHECK_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
@@ -978,7 +1028,7 @@ int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, 
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return 2; }
-        d->pair_loops.push_back({ka, kb, exec});
+        d->pair_loops.push_back({ka, kb, exec, nullptr});
     }
     DA_CHECK_HIP(hipGraphLaunch(exec, (hipStream_t)stream));
     return 0;

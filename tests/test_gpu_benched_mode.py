@@ -814,3 +814,14 @@ def test_tail_fused_kernel_vs_three_kernel_tail(dev, tmp_path, sizes):
     assert not torch.equal(res["1"]["out"], res["0"]["out"])          # the switch really selects another path
     assert rel(res["1"]["out"], res["0"]["out"]) < 5e-3
     assert rel(res["1"]["xf"], res["0"]["xf"]) < 5e-3
+
+
+def test_two_branch_loop_as_one_graph_subprocess():
+    """DA_PAIR_SPLIT=0: the two branches as parallel branches of ONE hipGraph (the form up to round 5; the default launches two graphs on
+    two streams between a fork and a join event): the same bit-identity suite."""
+    import subprocess
+    env = dict(os.environ, DA_PAIR_SPLIT="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", "two_branch_loop and not subprocess"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
