@@ -380,7 +380,8 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             qs.Q = w.dq; qs.K = w.dk; qs.Vt = w.dvt; qs.S = w.dskip;
             const void *wdense = (fused && l == 0) ? d->conv0c_wd : c.wd;
             const float *bdense = (fused && l == 0) ? d->conv0c_bd : c.bd;
-            const void *wpanel = (fused && l == 0) ? d->conv0c_wdp : c.wdp;
+            const int xpm = xpanel_mode();
+            const void *wpanel = (xpm == 1 || (xpm == 2 && g->max_graph_nodes >= 512)) ? ((fused && l == 0) ? d->conv0c_wdp : c.wdp) : nullptr;
             rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
                 return launch_gemm_mfma(prec, nproj, c.din, 4 * c.hc, xin, ldx, wdense, bdense, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st, 0,
                                         nullptr, wpanel); });
@@ -799,7 +800,11 @@ static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s,
         const bool try_fuse = plain && !fuse_off && d->variant == DA_VARIANT_2D && !d->prof_on;
         // the tail kernel of this step may also produce the NEXT step's h (embedding + mlp.0 over the hoisted feature part): bf16, the 2D
         // transformer widths, a next step that exists
-        if (try_fuse && nonneg && it + 1 < n_iters && d->prec == DA_PREC_BF16 && d->hidden == 128 && d->D - d->F == 64 && w.feat_proj &&
+        // DA_TAIL_NEXT: 1 = every Batch, 0 = never, unset = Batches whose largest graph has >= 512 pieces (DA_STEP_AUTO; 144-piece Batches lose)
+        static int nx_mode = -1;
+        if (nx_mode < 0) { const char *e = getenv("DA_TAIL_NEXT"); nx_mode = e ? ((e[0] == '1') ? 1 : 0) : (step_auto_default() ? 2 : 0); }
+        const bool nx_want = nx_mode == 1 || (nx_mode == 2 && g->max_graph_nodes >= 512);
+        if (try_fuse && nx_want && nonneg && it + 1 < n_iters && d->prec == DA_PREC_BF16 && d->hidden == 128 && d->D - d->F == 64 && w.feat_proj &&
             !mfma_disabled()) {
             df.nx_on = 1; df.nx_t = i - ratio; df.nx_steps = d->steps; df.nx_cin = d->c_in; df.nx_ldw = d->D;
             df.nx_time_emb = d->time_emb; df.nx_w0 = d->pos_w0; df.nx_b0 = d->pos_b0; df.nx_w1 = d->pos_w1; df.nx_b1 = d->pos_b1;
@@ -954,7 +959,16 @@ int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, 
         }
         if (!d->cap_stream) DA_CHECK_HIP(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
         if (!d->pair_stream) {
-            DA_CHECK_HIP(hipStreamCreateWithFlags(&d->pair_stream, hipStreamNonBlocking));
+            // DA_PAIR_PRIO (experiment, default 0): 1 = the pair stream at the device's highest priority, -1 = at its lowest -- a standing
+            // asymmetry between the branches (one takes free slots first, the other fills its tails) instead of two equals in lockstep
+            const char *pv = getenv("DA_PAIR_PRIO");
+            const int prio = pv ? atoi(pv) : 0;
+            if (prio) {
+                int lo = 0, hi = 0;                                                     // lo = numerically greatest = lowest priority
+                DA_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                DA_CHECK_HIP(hipStreamCreateWithPriority(&d->pair_stream, hipStreamNonBlocking, prio > 0 ? hi : lo));
+            } else
+                DA_CHECK_HIP(hipStreamCreateWithFlags(&d->pair_stream, hipStreamNonBlocking));
             DA_CHECK_HIP(hipEventCreateWithFlags(&d->ev_pair_fork, hipEventDisableTiming));
             DA_CHECK_HIP(hipEventCreateWithFlags(&d->ev_pair_join, hipEventDisableTiming));
         }

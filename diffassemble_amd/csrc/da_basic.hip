@@ -549,12 +549,14 @@ int launch_tail_fused(int prec, int n, int H, int c_out, int hidden, int din, co
     const int slabs = (n + 31) / 32;
     int spw = (slabs + 1023) / 1024;
     spw = spw < 1 ? 1 : (spw > 4 ? 4 : spw);
-    // the next step's embedding + mlp.0 in the same kernel (DdimFuse::nx_*): OPT-IN, DA_TAIL_NEXT=1.  Measured (round 5, last session; A/B on
+    // the next step's embedding + mlp.0 in the same kernel (DdimFuse::nx_*): requested by enqueue_loop (da_api.hip) -- since the round's very last
+    // session by default for Batches whose largest graph has >= 512 pieces (DA_STEP_AUTO; together with the row-panel projections -2.5 ... -3.3 % on
+    // 100-iteration loops of the headline Batch, profiles/r05/r05_step_auto_ab.log), DA_TAIL_NEXT=1 / 0 forces it on / off.  First measured (A/B on
     // one box): parity-clean (tests/test_gpu_tail_next.py) and two launches fewer per step, but not faster -- headline 0.6786 / 0.6890 ms
     // without, 0.6788 / 0.6845 with; one-branch loop 0.7175 -> 0.7154; configuration 2 (512 x 144 pieces) 0.6346 -> 0.6428: the work moves into a
     // kernel that runs one wave per SIMD at 255 VGPRs (64 more GELUs and 16 MFMAs per lane and slab), which costs what the launches cost.
     static int nx_off = -1;
-    if (nx_off < 0) { const char *e = getenv("DA_TAIL_NEXT"); nx_off = (e && e[0] == '1') ? 0 : 1; }
+    if (nx_off < 0) { const char *e = getenv("DA_TAIL_NEXT"); nx_off = (e && e[0] == '0') ? 1 : 0; }        // the request itself (nx_on) is decided in enqueue_loop
     const bool next = dfp && df.x_prev && df.nx_on && !nx_off && df.nx_cin <= 8 && df.nx_cin == c_out && df.nx_h == h;
     if (next)
         k_tail_fused<true><<<(slabs + spw - 1) / spw, 64, 0, st>>>(n, H, c_out, (const bf16_t *)h, (const bf16_t *)xin, ldx, (const bf16_t *)wh, bh,

@@ -233,9 +233,25 @@ __global__ __launch_bounds__(512) void k_gemm_xpanel(GemmParams p, const u32x4 *
 // puzzles of 900 pieces) the four projections take 230 us against 246 us for the W-in-registers kernels, but the attention
 // kernels that read Q / K / V next run 7 - 10 % slower behind it (+46 us per step; not understood: same bytes, same layouts),
 // so the step as a whole loses 30 us.  da_linear_packed always takes it.
-bool xpanel_in_model() {
+// Round 5, last session: re-judged under the two-graph pair loop (profiles/r05/r05_xpanel_under_split_graphs.log): -0.45 % alone (six pairs of
+// seven) and, together with the tail kernel's next-step embedding (DA_TAIL_NEXT), -2.5 % on the headline step (seven of seven) -- configuration 2
+// (144-piece graphs) does not gain.  DA_ENABLE_XPANEL: 1 = every Batch, 0 = never, unset = DA_STEP_AUTO's rule (xpanel_mode() == 2: Batches
+// whose largest graph has >= 512 pieces, decided per forward in da_api.hip).
+int xpanel_mode() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_ENABLE_XPANEL"); v = (e && e[0] == '1') ? 1 : 0; }
+    if (v < 0) {
+        const char *e = getenv("DA_ENABLE_XPANEL");
+        v = e ? ((e[0] == '1') ? 1 : 0) : (step_auto_default() ? 2 : 0);
+    }
+    return v;
+}
+bool xpanel_in_model() { return xpanel_mode() != 0; }          // whether the packed weight images are built at all
+
+// DA_STEP_AUTO (default 1): the large-graph step defaults of the round's last session -- row-panel projections and the next step's embedding
+// inside the tail kernel for Batches whose largest graph has >= 512 pieces.  0 = both opt-in again (DA_ENABLE_XPANEL=1 / DA_TAIL_NEXT=1).
+bool step_auto_default() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("DA_STEP_AUTO"); v = (e && e[0] == '0') ? 0 : 1; }
     return v == 1;
 }
 

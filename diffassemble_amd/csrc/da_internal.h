@@ -121,6 +121,8 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
                      const void *pre = nullptr, const void *wpacked = nullptr);
 size_t xpanel_packed_bytes(int K, int Nout);
 bool xpanel_in_model();          // DA_ENABLE_XPANEL=1 (off by default, see da_gemm_xpanel.hip)
+int xpanel_mode();               // 0 never, 1 always, 2 = Batches whose largest graph has >= 512 pieces (the default, DA_STEP_AUTO)
+bool step_auto_default();        // DA_STEP_AUTO (default 1)
 int pack_w_xpanel(int K, int Nout, const void *W, int ldw, void *packed, hipStream_t st);
 struct DenseMask {             // hybrid mode: adjacency bits of the regular edges + the remainder CSR (da_attn_dense.hip)
     const uint8_t *mask;

@@ -292,7 +292,9 @@ class DenoiserEngine:
 
     def _sample_loop_pair(self, plan, sched, x_init, feats, ratio, mean_type, n_iters, restage, keep_trajectory=False, opts=None):
         from .graph_plan import split_complete
-        pa, pb, n0 = split_complete(plan, plan.n_graphs // 2)
+        # DA_PAIR_SPLIT_AT (experiment): puzzles in the first branch (default: half) -- unequal branches drift out of lockstep
+        g_split = int(os.environ.get("DA_PAIR_SPLIT_AT", "0")) or plan.n_graphs // 2
+        pa, pb, n0 = split_complete(plan, min(max(g_split, 1), plan.n_graphs - 1))
         c = x_init.shape[1]
         st = self._pair_state
         # keyed on the Batch's SHAPE (graph sizes), not on the plan object: the module re-plans every Batch (it releases the
