@@ -986,7 +986,11 @@ def sample_bench(args, world, rank, dev):
             "distributed": dist_info(world, rank_ms),
             "config": {"workload": wl, "baseline_config": args.config, "puzzles_per_gpu": G, "global_puzzles": world * G,
                        "parallelism": f"puzzle-sharded x{world}",
-                       "loop": "hipGraph replay" + (", two half Batches as parallel branches (da_sample_loop_pair)" if eng._two_branch(plan, False, True) else ""),
+                       "loop": "hipGraph replay" + (", two half Batches as " + ("two graphs on two streams" if os.environ.get("DA_PAIR_SPLIT", "1") != "0"
+                                                                                    else "parallel branches of one graph") + " (da_sample_loop_pair)"
+                                                    if eng._two_branch(plan, False, True) else ""),
+                       # library defaults for Batches of >= 512-piece graphs (row-panel projections + next-step embedding in the tail kernel)
+                       "large_graph_step_rule": {k: os.environ.get(k, "unset") for k in ("DA_STEP_AUTO", "DA_ENABLE_XPANEL", "DA_TAIL_NEXT")},
                        "attention_path": "dense MFMA" if plan.dense else ("hybrid: adjacency-masked MFMA + CSR remainder" if plan.hybrid else "edge list (CSR gather)")},
             "batch_steps_per_s": world * K / dt,
             "algorithmic_tflops": world * (N * f_node + E * f_edge) * K / dt / 1e12,

@@ -241,7 +241,10 @@ int xpanel_mode() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("DA_ENABLE_XPANEL");
-        v = e ? ((e[0] == '1') ? 1 : 0) : (step_auto_default() ? 2 : 0);
+        // a process that sets one of the other projection kernels' own switches is measuring or testing THAT kernel: the rule stays out of its way
+        const bool other = getenv("DA_DISABLE_WREG") || getenv("DA_WREG2") || getenv("DA_WREG_DIRECT") || getenv("DA_DISABLE_ASTAT") || getenv("DA_GEMM_DEBUG") ||
+                           getenv("DA_GEMM_PROF_PTR");
+        v = e ? ((e[0] == '1') ? 1 : 0) : ((step_auto_default() && !other) ? 2 : 0);
     }
     return v;
 }
