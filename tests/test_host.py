@@ -423,3 +423,22 @@ def test_virtual_rows_remainder_edges_aggregated_with_multiplicities():
                 got += [int(asrc[e])] * int(am[e])
             assert want == sorted(got), i
 
+
+
+def test_every_environment_switch_is_documented():
+    """Every DA_* variable the library (getenv in csrc/) or the host layer (os.environ in diffassemble_amd/) reads is named in INTEGRATION.md or
+    DESIGN.md: a switch nobody can find is a behaviour nobody can reproduce."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "diffassemble_amd", "**", "*"), recursive=True):
+        if not f.endswith((".hip", ".h", ".inc", ".py")):
+            continue
+        t = open(f, errors="ignore").read()
+        names |= set(re.findall(r'getenv\("(DA_[A-Z0-9_]+)"\)', t))
+        names |= set(re.findall(r'environ(?:\.get)?[\(\[]"(DA_[A-Z0-9_]+)"', t))
+    assert len(names) > 40, len(names)
+    docs = open(os.path.join(root, "INTEGRATION.md")).read() + open(os.path.join(root, "DESIGN.md")).read()
+    missing = sorted(n for n in names if n not in docs)
+    assert not missing, missing
