@@ -234,6 +234,16 @@ static bool aligned16(const void *p) { return (((size_t)p) & 15) == 0; }
 int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st);   // da_gemm_astat.hip
 int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st);    // da_gemm_wreg.hip
 int launch_gemm_xpanel(int prec, const GemmParams &p0, const QkvScatter *qs, int act, const void *wpacked, hipStream_t st);   // da_gemm_xpanel.hip
+int launch_gemm_thin(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st);    // da_gemm_thin.hip
+
+// DA_GEMM_THIN=1 (gemm_thin_set: the same switch at run time, tools/corun_probe.hip): tall short-reduction products take the co-resident
+// four-wave kernel of da_gemm_thin.hip
+static int g_thin = -1;
+void gemm_thin_set(int v) { g_thin = v; }
+static bool thin_on() {
+    if (g_thin < 0) { const char *e = getenv("DA_GEMM_THIN"); g_thin = (e && e[0] == '1') ? 1 : 0; }
+    return g_thin == 1;
+}
 
 // returns 0 = launched, -1 = shape not supported by this kernel (caller falls back), >0 error
 int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
@@ -270,6 +280,10 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     if (!bfc) {   // short reductions: A-stationary kernel (da_gemm_astat.hip)
         static int off = -1;
         if (off < 0) { const char *e = getenv("DA_DISABLE_ASTAT"); off = (e && e[0] == '1') ? 1 : 0; }
+        if (K * es <= 512 && thin_on()) {
+            const int rt = launch_gemm_thin(prec, p, qs, act, st);
+            if (rt >= 0) return rt;
+        }
         if (K * es <= 512 && wpacked) {
             // tall inputs at the benched batch sizes: row panel of A in LDS, pre-packed W fragments double-buffered in registers
             const int rx = launch_gemm_xpanel(prec, p, qs, act, wpacked, st);

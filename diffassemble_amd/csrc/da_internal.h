@@ -121,6 +121,7 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
                      const void *pre = nullptr, const void *wpacked = nullptr);
 size_t xpanel_packed_bytes(int K, int Nout);
 bool xpanel_in_model();          // DA_ENABLE_XPANEL=1 (off by default, see da_gemm_xpanel.hip)
+void gemm_thin_set(int v);      // run-time form of DA_GEMM_THIN (da_gemm_mfma.hip): 1 = projections take the co-resident kernel of da_gemm_thin.hip
 int xpanel_mode();               // 0 never, 1 always, 2 = Batches whose largest graph has >= 512 pieces (the default, DA_STEP_AUTO)
 bool step_auto_default();        // DA_STEP_AUTO (default 1)
 int pack_w_xpanel(int K, int Nout, const void *W, int ldw, void *packed, hipStream_t st);
