@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-N_PIECES, T_STEPS = int(os.environ.get("BENCH_N_EXPERIMENT", 900)), 100   # the metric is defined at 900; other values are for layout experiments only
+N_PIECES, T_STEPS = 900, 100
 F_NODE = 6_432_128          # FLOP per piece per step (SURVEY 8d / BASELINE.md)
 F_EDGE = 7_680              # FLOP per edge per step, all 4 layers
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
@@ -986,11 +986,11 @@ def sample_bench(args, world, rank, dev):
             "distributed": dist_info(world, rank_ms),
             "config": {"workload": wl, "baseline_config": args.config, "puzzles_per_gpu": G, "global_puzzles": world * G,
                        "parallelism": f"puzzle-sharded x{world}",
-                       "loop": "hipGraph replay" + (", two half Batches as " + ("two graphs on two streams" if os.environ.get("DA_PAIR_SPLIT", "1") != "0"
+                       "loop": "hipGraph replay" + (", two half Batches as " + ("two graphs on two streams" if _lib.config().pair_split
                                                                                     else "parallel branches of one graph") + " (da_sample_loop_pair)"
                                                     if eng._two_branch(plan, False, True) else ""),
                        # library defaults for Batches of >= 512-piece graphs (row-panel projections + next-step embedding in the tail kernel)
-                       "large_graph_step_rule": {k: os.environ.get(k, "unset") for k in ("DA_STEP_AUTO", "DA_ENABLE_XPANEL", "DA_TAIL_NEXT")},
+                       "library_config": {k: int(getattr(_lib.config(), k)) for k, _ in _lib.DaConfig._fields_ if k != "struct_bytes"},
                        "attention_path": "dense MFMA" if plan.dense else ("hybrid: adjacency-masked MFMA + CSR remainder" if plan.hybrid else "edge list (CSR gather)")},
             "batch_steps_per_s": world * K / dt,
             "algorithmic_tflops": world * (N * f_node + E * f_edge) * K / dt / 1e12,
@@ -1184,11 +1184,11 @@ def self_launch(n):
     ``torch.distributed.run`` on a free local port, same argv; the ranks' stdout (rank 0's JSON line) passes through."""
     import socket
     import subprocess
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    backend = "gloo" if "--dist-backend=gloo" in sys.argv or "gloo" in [b for a, b in zip(sys.argv, sys.argv[1:]) if a == "--dist-backend"] else "nccl"
     have = torch.cuda.device_count()
     if backend == "nccl" and have < n:
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible (one rank per GPU over RCCL; "
-                         f"BENCH_DIST_BACKEND=gloo lets ranks share a GPU for a functional check)")
+                         f"--dist-backend gloo lets ranks share a GPU for a functional check)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -1227,26 +1227,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default=os.environ.get("BENCH_CONFIG", "3p"), choices=["1", "2", "3", "3p", "4", "5", "scripted", "csr"],
+    ap.add_argument("--config", default="3p", choices=["1", "2", "3", "3p", "4", "5", "scripted", "csr"],
                     help="BASELINE configuration (default 3p = the headline metric; 5 = --mode train)")
-    ap.add_argument("--puzzles", type=int, default=int(os.environ.get("BENCH_PUZZLES", 0)),
+    ap.add_argument("--puzzles", type=int, default=0,
                     help="independent puzzles per GPU (the batch of one step); 0 = the configuration's default")
-    ap.add_argument("--degree", type=int, default=int(os.environ.get("BENCH_DEGREE", 539)),
+    ap.add_argument("--degree", type=int, default=539,
                     help="--config 3: Exphander degree (539 = the scripted 60 %%, 90 = 10 %%)")
-    ap.add_argument("--precision", default=os.environ.get("BENCH_PRECISION", ""), choices=["", "bf16", "fp32"])
-    ap.add_argument("--mode", default=os.environ.get("BENCH_MODE", "sample"), choices=["sample", "train", "encode", "e2e"],
+    ap.add_argument("--precision", default="", choices=["", "bf16", "fp32"])
+    ap.add_argument("--mode", default="sample", choices=["sample", "train", "encode", "e2e"],
                     help="sample = a sampling-loop configuration (default); train = BASELINE config 5 (one optimizer step); "
                          "encode = the piece encoder (SURVEY 8f rank 2; with --config 4: the 3D fragment encoder, 8f rank 4); "
                          "e2e = pixels -> poses (encoder + plan + loop)")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("BENCH_ENCODER_CHUNK", 0)),
+    ap.add_argument("--chunk", type=int, default=0,
                     help="--mode encode: pieces per encoder chunk (0 = engine default)")
-    ap.add_argument("--train-puzzles", type=int, default=int(os.environ.get("BENCH_TRAIN_PUZZLES", 64)),
+    ap.add_argument("--train-puzzles", type=int, default=64,
                     help="--mode train: 12x12 puzzles per GPU")
     ap.add_argument("--arch", default="transformer", choices=["transformer", "exophormer"],
                     help="--mode train: exophormer = the scripted training architecture (Exphander graphs + 8 virtual nodes)")
     ap.add_argument("--train-side", type=int, default=12, help="--mode train: pieces per puzzle side (12 = BASELINE config 5)")
     ap.add_argument("--pixels", action="store_true",
                     help="--mode train: train the piece encoder too, from 32x32 crops (the scripted --backbone resnet18equiv)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: ranks may share a GPU (functional check of the N > 1 path on a 1-GPU box)")
     ap.add_argument("--replays", type=int, default=30, help="extra individually timed graph replays for the median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the oracle with ONE thread at full size")
@@ -1256,7 +1257,7 @@ def main():
     ap.add_argument("--pct", type=float, default=0, help="--config scripted / csr: Exphander degree in percent of n - 1 (default: the script's 60 %% for scripted, 0.5 %% for csr)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp32 (parity-mode) replay of the sampling configurations")
     args = ap.parse_args()
-    args.degree_given = any(a == "--degree" or a.startswith("--degree=") for a in sys.argv[1:]) or "BENCH_DEGREE" in os.environ
+    args.degree_given = any(a == "--degree" or a.startswith("--degree=") for a in sys.argv[1:])
     if args.config == "5":
         args.mode = "train"
 
@@ -1266,9 +1267,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    # BENCH_DIST_BACKEND=gloo lets several ranks share one GPU (a 1-GPU box can then exercise the N > 1 code path; the
+    # --dist-backend gloo lets several ranks share one GPU (a 1-GPU box can then exercise the N > 1 code path; the
     # numbers of such a run mean nothing).  Default: one rank per GPU over RCCL ("nccl").
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    backend = args.dist_backend
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 LIB_PATH = os.environ.get("DA_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdiffassemble_hip.so")
 # (DA_LIB_PATH: an alternate BUILD of the same library -- compile-flag A/Bs, tools/build_ab.sh; never a different implementation)
 DA_MAX_LAYERS = 8
-ABI_VERSION = 18
+ABI_VERSION = 19
 PREC_F32, PREC_BF16 = 0, 1
 VARIANT_2D, VARIANT_3D = 0, 1
 ARCH_TRANSFORMER, ARCH_EXOPHORMER = 0, 1
@@ -98,10 +98,19 @@ class DaPcdEncoderWeights(C.Structure):
     ]
 
 
+class DaConfig(C.Structure):
+    """include/diffassemble_hip.h `da_config`: the library's switches (one environment variable each, settable at run time)."""
+    _fields_ = [(n, C.c_int32) for n in ("struct_bytes", "disable_mfma", "disable_dense", "disable_folds", "attn_level", "xpanel", "tail_next",
+                                         "pair_split", "train_attn", "train_side_streams")]
+
+
 # name -> (restype, argtypes); every symbol include/diffassemble_hip.h declares
 PROTOTYPES = {
     "da_abi_version": (C.c_int, []),
     "da_last_error": (C.c_char_p, []),
+    "da_config_get": (C.c_int, [C.POINTER(DaConfig)]),
+    "da_config_set": (C.c_int, [C.POINTER(DaConfig)]),
+    "da_build_flags": (C.c_int, []),
     "da_denoiser_create": (C.c_int, [C.POINTER(DaWeights), C.c_int, _fp, C.POINTER(_fp)]),
     "da_denoiser_destroy": (None, [_fp]),
     "da_denoiser_flags": (C.c_int, [_fp]),
@@ -201,6 +210,31 @@ def lib():
             raise DaError(f"ABI mismatch: library reports {h.da_abi_version()}")
         _lib = h
     return _lib
+
+
+def config():
+    """The library's current switches as a ``DaConfig``."""
+    c = DaConfig()
+    check(lib().da_config_get(C.byref(c)))
+    return c
+
+
+def set_config(**fields):
+    """Change switches at run time (``set_config(xpanel=0, tail_next=0)``); returns the previous ``DaConfig``.  Takes effect for the calls
+    that follow: a denoiser keeps the folds it was created with, a captured loop graph is recorded again under the new switches."""
+    old = config()
+    new = DaConfig.from_buffer_copy(old)
+    for k, v in fields.items():
+        if k == "struct_bytes" or k not in dict(DaConfig._fields_):
+            raise DaError(f"da_config has no field {k!r}")
+        setattr(new, k, int(v))
+    check(lib().da_config_set(C.byref(new)))
+    return old
+
+
+def experiments_build():
+    """True when the loaded library is the EXPERIMENTS build (DA_EXPERIMENTS=1 python __graft_entry__.py; DA_LIB_PATH=.../lib_exp/...)."""
+    return bool(lib().da_build_flags() & 1)
 
 
 def check(rc):

@@ -7,6 +7,7 @@
 
 #include "da_common.h"
 #include "da_internal.h"
+#include "da_config.h"
 
 namespace da {
 
@@ -55,11 +56,7 @@ __global__ void k_cfg_combine(size_t n, float wgt, float *cond, const float *unc
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) cond[i] = (1.0f + wgt) * cond[i] - wgt * unc[i];
 }
-static bool q_prescale_on() {
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("DA_DISABLE_Q_PRESCALE"); off = (e && e[0] == '1') ? 1 : 0; }
-    return !off;
-}
+static bool q_prescale_on() { return !(cfg().disable_folds & DA_FOLD_QSCALE); }
 static float q_scale_log2(int C) { return 1.4426950408889634f / sqrtf((float)C); }
 
 struct LoopKey {
@@ -73,6 +70,7 @@ struct LoopKey {
     da_loop_opts opts;        // zero for the plain DDIM loop
     size_t traj_stride;       // elements between consecutive iterations of `traj` (0 = n_real * c)
     size_t noise_stride;      // the same for opts.noise (two-branch loops read row ranges of one [n_iters, N, c] buffer)
+    da_config cfg;            // the switches the graph was recorded under (da_config_set between two calls records a new graph)
 };
 
 }  // namespace da
@@ -197,11 +195,7 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     return w;
 }
 
-static bool mfma_disabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_DISABLE_MFMA"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
+static bool mfma_disabled() { return cfg().disable_mfma != 0; }
 
 int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias, int act,
            const void *res, void *out, int ldo, hipStream_t st) {
@@ -212,11 +206,7 @@ int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void 
     return launch_gemm_simple(prec == DA_PREC_F32_BF16MMA ? DA_PREC_F32 : prec, M, K, Nout, A, lda, W, bias, act, res, out, ldo, st);
 }
 
-static bool dense_disabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_DISABLE_DENSE"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
+static bool dense_disabled() { return cfg().disable_dense != 0; }
 
 static bool dense_ok(const da_graph *g, int heads, int C) {
     const bool hyb = g->hybrid && g->mask && g->mask_ptr && g->irr_row_ptr;
@@ -363,6 +353,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                 }
             }
         }
+#ifdef DA_EXPERIMENTS          // (DA_CONV_FUSED=1: the one-kernel hidden conv, da_conv_fused.hip -- a measured tie / loss, experiments build only)
         if (!al && !last && g->dense && !g->hybrid && n == nr && !resid && dense_ok(g, d->heads, c.C) &&
             conv_fused_applicable(prec, d->heads, c.C, c.din, g->max_graph_nodes, c.hc)) {
             // hidden conv on complete graphs: projection + attention of a (graph, head) in ONE kernel, K / V in LDS
@@ -373,6 +364,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             xin = dst; ldx = c.hc;
             continue;
         }
+#endif
         if (!al && w.dq && dense_ok(g, d->heads, c.C)) {
             // complete graphs: projection scattered into head-major Q / K / V, block-diagonal MFMA attention
             QkvScatter qs;
@@ -577,8 +569,7 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
     }
     if (rc) return fail(rc);
     {
-        static int off = -1;
-        if (off < 0) { const char *e = getenv("DA_DISABLE_MLP2_FUSION"); off = (e && e[0] == '1') ? 1 : 0; }
+        const bool off = (cfg().disable_folds & DA_FOLD_MLP2) != 0;
         if (!off && !mfma_disabled() && d->variant == DA_VARIANT_2D && d->hidden % 32 == 0) {
             // compose in fp32 from the caller's fp32 weights, then pack
             const int hid = d->hidden, hc0 = d->conv[0].hc;
@@ -630,8 +621,7 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
             d->fused_mlp2 = true;
             // last conv: value heads and skip folded with final_mlp.0
             const int L = d->n_layers - 1, hcL = d->conv[L].hc, CL = d->conv[L].C, dinL = d->conv[L].din;
-            static int off2 = -1;
-            if (off2 < 0) { const char *e = getenv("DA_DISABLE_LAST_FOLD"); off2 = (e && e[0] == '1') ? 1 : 0; }
+            const bool off2 = (cfg().disable_folds & DA_FOLD_LAST) != 0;
             if (!off2 && CL == 144 && hcL == D && dinL % 32 == 0 && d->c_out <= 8) {        // (k_head_fold: 8 outputs per row at most)
                 const int nf = 2 * hcL + H * 32;
                 float *lw = (float *)alloc((size_t)nf * dinL * 4);
@@ -668,9 +658,8 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
         }
     }
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("da_denoiser_create: sync failed"); return fail(2); }
-    {   // side stream of the hybrid path (see the struct); DA_DISABLE_HYBRID_OVERLAP=1 keeps everything on one stream
-        const char *e = getenv("DA_DISABLE_HYBRID_OVERLAP");
-        if (d->V > 0 && !(e && e[0] == '1')) {
+    {   // side stream of the hybrid path (see the struct); da_config.disable_folds bit 32 keeps everything on one stream
+        if (d->V > 0 && !(cfg().disable_folds & DA_FOLD_HYBRID_OVERLAP)) {
             if (hipStreamCreateWithFlags(&d->side_stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -685,8 +674,16 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
     return 0;
 }
 
+// bit 3: the hoisted mlp.0 product (feature columns once per loop, pose / timestep columns per step through launch_gemm_mfma's `pre`
+// operand) exists for THIS denoiser's shapes -- the conditions launch_gemm_mfma itself checks (reduction a multiple of its 128-byte
+// K stage, 16-byte aligned column slice and rows), not merely "MFMA enabled": the captured classifier-free-guidance loop needs it
+static bool hoisted_mlp0_ok(const da_denoiser *d) {
+    if (da::mfma_disabled()) return false;
+    const int es = (int)da::esize(d->prec), bk = 128 / es, kpose = d->D - d->F;
+    return kpose > 0 && kpose % bk == 0 && ((size_t)d->F * es) % 16 == 0 && ((size_t)d->D * es) % 16 == 0 && d->hidden % (16 / es) == 0;
+}
 int da_denoiser_flags(const da_denoiser *d) {
-    return d ? (d->fused_mlp2 ? 1 : 0) | (d->lastfold ? 2 : 0) | (d->dense_only ? 4 : 0) | (!mfma_disabled() ? 8 : 0) : 0;
+    return d ? (d->fused_mlp2 ? 1 : 0) | (d->lastfold ? 2 : 0) | (d->dense_only ? 4 : 0) | (hoisted_mlp0_ok(d) ? 8 : 0) : 0;
 }
 
 void da_denoiser_destroy(da_denoiser *d) {
@@ -795,15 +792,13 @@ static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s,
         df.s = ds; df.mean_type = mean_type; df.ratio = ratio; df.prev_all_nonneg = nonneg; df.t = i; df.x = cur; df.x_prev = nxt;
         df.done = 0;
         df.nx_on = 0; df.nx_done = 0;
-        static int fuse_off = -1;
-        if (fuse_off < 0) { const char *e = getenv("DA_DISABLE_DDIM_FUSION"); fuse_off = (e && e[0] == '1') ? 1 : 0; }
+        const bool fuse_off = (da::cfg().disable_folds & DA_FOLD_DDIM) != 0;
         const bool try_fuse = plain && !fuse_off && d->variant == DA_VARIANT_2D && !d->prof_on;
         // the tail kernel of this step may also produce the NEXT step's h (embedding + mlp.0 over the hoisted feature part): bf16, the 2D
         // transformer widths, a next step that exists
         // DA_TAIL_NEXT: 1 = every Batch, 0 = never, unset = Batches whose largest graph has >= 512 pieces (DA_STEP_AUTO; 144-piece Batches lose)
-        static int nx_mode = -1;
-        if (nx_mode < 0) { const char *e = getenv("DA_TAIL_NEXT"); nx_mode = e ? ((e[0] == '1') ? 1 : 0) : (step_auto_default() ? 2 : 0); }
-        const bool nx_want = nx_mode == 1 || (nx_mode == 2 && g->max_graph_nodes >= 512);
+        const int nx_mode = da::cfg().tail_next;          // -1 = Batches of >= 512-piece graphs (144-piece Batches lose), 0 never, 1 always
+        const bool nx_want = nx_mode == 1 || (nx_mode < 0 && g->max_graph_nodes >= 512);
         if (try_fuse && nx_want && nonneg && it + 1 < n_iters && d->prec == DA_PREC_BF16 && d->hidden == 128 && d->D - d->F == 64 && w.feat_proj &&
             !mfma_disabled()) {
             df.nx_on = 1; df.nx_t = i - ratio; df.nx_steps = d->steps; df.nx_cin = d->c_in; df.nx_ldw = d->D;
@@ -860,7 +855,7 @@ int da_sample_loop_ex(da_denoiser *d, const da_graph *g, const da_schedule *s, i
     memset(&key, 0, sizeof(key));
     key.g = *g; key.s = *s; key.mean_type = mean_type; key.ratio = inference_ratio; key.max_iters = n_iters;
     key.x_init = x_init; key.traj = traj; key.x_final = x_final; key.ws = workspace; key.ws_bytes = workspace_bytes;
-    key.opts = o;
+    key.opts = o; key.cfg = cfg();
     hipGraphExec_t exec = nullptr;
     for (auto &e : d->loops)
         if (memcmp(&key, &e.key, sizeof(key)) == 0) exec = e.exec;
@@ -936,6 +931,7 @@ int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, 
         memset(&k, 0, sizeof(k));
         k.g = *g; k.s = *s; k.mean_type = mean_type; k.ratio = inference_ratio; k.max_iters = n_iters;
         k.x_init = xi; k.traj = tr; k.x_final = xf; k.ws = ws; k.ws_bytes = wsb; k.traj_stride = tr ? traj_stride : 0;
+        k.cfg = cfg();
         return k;
     };
     LoopKey ka = make_key(g_a, x_init_a, x_final_a, workspace_a, workspace_a_bytes, traj_a);
@@ -946,8 +942,7 @@ int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, 
     // fork and a join event, instead of two parallel branches of one graph.  Measured (tools/multi_branch_probe.py, round 5): two independently
     // launched one-branch graphs of 32 puzzles ran a 64-puzzle step in 0.6734 ms where the one-graph pair loop needed 0.7002 on the same box --
     // the runtime does not run the two branches of one graph as independently as it runs two graphs on two streams.
-    static int split_mode = -1;
-    if (split_mode < 0) { const char *ev = getenv("DA_PAIR_SPLIT"); split_mode = ev ? atoi(ev) : 1; }
+    const int split_mode = cfg().pair_split;
     hipGraphExec_t exec = nullptr, exec_b = nullptr;
     for (auto &e : d->pair_loops)
         if (memcmp(&ka, &e.a, sizeof(ka)) == 0 && memcmp(&kb, &e.b, sizeof(kb)) == 0 && (e.exec_b != nullptr) == (split_mode != 0)) { exec = e.exec; exec_b = e.exec_b; }
@@ -961,8 +956,7 @@ int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, 
         if (!d->pair_stream) {
             // DA_PAIR_PRIO (experiment, default 0): 1 = the pair stream at the device's highest priority, -1 = at its lowest -- a standing
             // asymmetry between the branches (one takes free slots first, the other fills its tails) instead of two equals in lockstep
-            const char *pv = getenv("DA_PAIR_PRIO");
-            const int prio = pv ? atoi(pv) : 0;
+            const int prio = DA_XENV("DA_PAIR_PRIO", 0);
             if (prio) {
                 int lo = 0, hi = 0;                                                     // lo = numerically greatest = lowest priority
                 DA_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -1024,8 +1018,7 @@ int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, 
         if (e == hipSuccess) {
             // experiment switch (DA_PAIR_DELAY_US, default 0): branch B starts this many microseconds after branch A, so that the two
             // branches run out of phase for the whole loop (one branch's attention beside the other's projections)
-            static int delay_us = -1;
-            if (delay_us < 0) { const char *ev = getenv("DA_PAIR_DELAY_US"); delay_us = ev ? atoi(ev) : 0; }
+            const int delay_us = DA_XENV("DA_PAIR_DELAY_US", 0);
             if (delay_us > 0) k_pair_delay<<<1, 64, 0, ps>>>((unsigned long long)delay_us * 100ull);
             rca = enqueue_loop(d, g_a, s, mean_type, inference_ratio, n_iters, x_init_a, traj_a, x_final_a, wa, cs, &oa, traj_stride, noise_stride);
             rcb = enqueue_loop(d, g_b, s, mean_type, inference_ratio, n_iters, x_init_b, traj_b, x_final_b, wb, ps, &ob, traj_stride, noise_stride);
@@ -1077,12 +1070,14 @@ int da_conv_dense(int prec, const da_graph *g, int heads, int C, int Din, const 
     DA_REQUIRE(dense_ok(g, heads, C), "da_conv_dense: graph is not dense or head width %d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
     const size_t s = esize(prec), hc = (size_t)heads * C;
+#ifdef DA_EXPERIMENTS
     if (!residual && !g->hybrid && conv_fused_applicable(prec, heads, C, Din, g->max_graph_nodes, (int)hc)) {
         int rf = launch_conv_fused(prec, heads, C, Din, g->n_graphs, g->max_graph_nodes, g->graph_ptr, g->dense == 2, x, Din, w,
                                    b, act, out, (int)hc, st);
         DA_REQUIRE(rf == 0, "da_conv_dense: fused conv launch failed (%d)", rf);
         return 0;
     }
+#endif
     const size_t hb = align_up(((size_t)g->n_pad + 64) * hc * s, 256);
     char *base = (char *)scratch;
     QkvScatter qs;
@@ -1132,7 +1127,9 @@ int da_debug_counters(int64_t *out, int n, int reset) {
     unsigned long long a[4] = {0, 0, 0, 0}, b2[2] = {0, 0};
     int rc;
     if ((rc = da::attn_dense_counters(a, reset))) return rc;
-    if ((rc = da::attn_dual_counters(b2, reset))) return rc;
+#ifdef DA_EXPERIMENTS
+    if ((rc = da::attn_dual_counters(b2, reset))) return rc;          // (k_attn_dual: experiments build only; the counter reads 0 otherwise)
+#endif
     for (int k = 0; k < n; ++k) out[k] = 0;
     out[DA_DBG_OPT_GEN_WORKGROUPS] = (int64_t)a[0];
     out[DA_DBG_DENSE_FAST_EXITS] = (int64_t)a[1];

@@ -191,17 +191,22 @@ __device__ __forceinline__ void remainder_edges(const AttnDenseParams &p, float 
             dst[t] = ck < NCKV ? *(const u32x4 *)((const unsigned char *)p.Vt + row * CFG::ROWBV + ck * 16) : (u32x4){0u, 0u, 0u, 0u};
         }
     };
+    // rows whose first-edge operands are requested together: all four, or two at a time for the 144-wide heads (three 16-byte pieces per Q / K
+    // row and lane: four rows' Q, K and V are 112 registers -- the masked last-layer kernel spilled 20 of its 168 to scratch over them)
+    constexpr int RG = MAXT >= 3 ? 2 : 4;
     if (wave_on) {
+#pragma unroll
+      for (int r0 = 0; r0 < 4; r0 += RG) {
         u32x4 qr[4][MAXT], kr[4][MAXT], vr[4][MAXTV];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = r0; r < r0 + RG; ++r) {
             const int qg = min(qtile0 + wid * 32 + (lane >> 3) + 8 * r, n_g - 1);
             load_row(p.Q, (size_t)h * np + pad0 + qg, qr[r]);
             load_row(p.K, (size_t)h * np + rm_slot[r], kr[r]);
             load_vrow((size_t)h * np + rm_slot[r], vr[r]);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = r0; r < r0 + RG; ++r) {
             if (rm_end[r] <= rm_beg[r]) continue;
             const int ql = wid * 32 + (lane >> 3) + 8 * r;
             float *orow = so + ql * RSOF;
@@ -261,6 +266,7 @@ __device__ __forceinline__ void remainder_edges(const AttnDenseParams &p, float 
                 }
             if (sub == 0) { orow[CO] = mm; orow[CO + 1] = ll; }
         }
+      }
     }
 }
 

@@ -174,7 +174,8 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
     for (int x = 0; x < EPL; ++x) { q[x] *= scale; acc[x] = 0.f; }
     // four edges per trip: their index -> slot -> K / V row loads are independent, so one round of memory
     // latency serves four softmax updates (the walk used to be one dependent chain per edge)
-    constexpr int U = 4;
+    // (C = 144 in fp32: four edges' K and V rows would be 144 registers beside q and acc under this kernel's 128 -- two there, no spills)
+    constexpr int U = (EPL > 8 && sizeof(T) == 4) ? 2 : 4;
     for (int e0 = beg + wv; e0 < end; e0 += HEAVY_WAVES * U) {
         size_t sj[U];
         bool ok[U];

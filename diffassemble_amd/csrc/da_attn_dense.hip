@@ -47,8 +47,10 @@ namespace da {
 // Only touched inside the (rare) fallback branch.
 __device__ unsigned long long g_attn_fallbacks[4];
 
+// (two workgroups per CU -- 256 registers per wave -- except the fp32 instances with 144-wide heads AND values (the un-folded last layer of the
+// parity mode): their accumulators alone are 144 registers; at 256 they spilled 55 / 134 registers to scratch, at one workgroup per CU none)
 template <typename T, int C, bool MASKED, int CV, int NST, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
+__global__ __launch_bounds__(64 * NW, (sizeof(T) == 4 && C == 144 && CV == 144) ? 1 : 2) void k_attn_dense(AttnDenseParams p) {
     using CF = Cfg<T, C, CV>;
     // NW waves of 32 queries per workgroup: 4 in production; 5 and 8 exist for the A/B record (see attn_nw)
     constexpr int QT = 32 * NW, NT = 64 * NW, MAXI = (CF::NI + NW - 1) / NW;
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_attn_dense(AttnDenseParams p) {
 // a 900-piece puzzle (5 slabs) still gives every wave work (2, 1, 1, 1); one-slab waves run the NS = 1 body.
 // Same LDS image, DMA ring, fragment layouts, softmax and epilogue arithmetic as k_attn_dense<bf16_t, 32, false, 32, 4>:
 // results are bit-identical to it (tests/test_gpu_parity.py::test_attn_dense2_matches_one_slab_kernel).
+#ifdef DA_EXPERIMENTS          // (k_attn_dense2 .. launch_attn_dense2: the experiments build only)
 template <int NS> struct SlabTag { static constexpr int value = NS; };
 
 __global__ __launch_bounds__(256, 2) void k_attn_dense2(AttnDenseParams p) {
@@ -768,29 +771,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_dense2(AttnDenseParams p) {
     }
 }
 
-// DA_ATTN_OPT=0: hidden layers on k_attn_dense's FAST path instead (A/B runs)
-static int attn_opt_last_env() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_ATTN_OPT_LAST"); v = e ? atoi(e) : 1; }
-    return v;
-}
-static int attn_opt_masked_env() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_ATTN_OPT_MASKED"); v = e ? atoi(e) : 1; }
-    return v;
-}
-static int attn_opt_env() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_ATTN_OPT"); v = e ? atoi(e) : 1; }
-    return v;
-}
+#endif      // DA_EXPERIMENTS (k_attn_dense2)
+
+// da_config.attn_level = 0 (DA_ATTN_LEVEL=0): every layer on k_attn_dense (the general kernel: any graph, both precisions) -- the
+// tests' way to cover it at shapes the optimistic kernels would take.  DA_ATTN_OPT_LAST / _MASKED (experiments build): per class.
+static int attn_opt_last_env() { return DA_XENV("DA_ATTN_OPT_LAST", 1); }
+static int attn_opt_masked_env() { return DA_XENV("DA_ATTN_OPT_MASKED", 1); }
+static int attn_opt_env() { return cfg().attn_level >= 1; }
+#ifdef DA_EXPERIMENTS
 // opt-in (DA_ATTN2=1): measured EQUAL to the one-slab kernel at 64 puzzles (173 vs 174 us per conv) and slower at 32
 // (95.5 vs 89.1) -- kept as the record of the experiment, see DESIGN.md
-static int attn2_env() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_ATTN2"); v = e ? atoi(e) : 0; }
-    return v;
-}
+static int attn2_env() { return DA_XENV("DA_ATTN2", 0); }
 static int launch_attn_dense2(AttnDenseParams p, int heads, int n_graphs, int max_graph_nodes, hipStream_t st) {
     using CF = Cfg<bf16_t, 32, 32>;
     p.nqt = (max_graph_nodes + 255) / 256;
@@ -799,12 +790,13 @@ static int launch_attn_dense2(AttnDenseParams p, int heads, int n_graphs, int ma
     DA_LAUNCH_CHECK();
     return 0;
 }
+#endif
 
 template <typename T, int C, bool MASKED, int CV, int NST, int NW>
 static int launch_tcmn(AttnDenseParams p, hipStream_t st) {
     using CF = Cfg<T, C, CV>;
     int lds = NST * CF::STAGE + (MASKED ? 256 : 0);
-    DA_ATTN_DBG({ const char *e = getenv("DA_ATTN_LDS_PAD"); if (e) lds += atoi(e); })      // occupancy experiments
+    DA_ATTN_DBG({ lds += DA_XENV("DA_ATTN_LDS_PAD", 0); })      // occupancy experiments
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
         DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_dense<T, C, MASKED, CV, NST, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -819,29 +811,28 @@ static int launch_tcmn(AttnDenseParams p, hipStream_t st) {
 // puzzles of 900 pieces (sustained, us per conv = projection + attention): 4 waves 143.3 - 145.3; 5 waves (29 slabs =
 // 6 x 5 - 1 instead of 8 x 4 - 3 idle wave slots, each K / V tile streamed for 160 queries) 190.5 -- the odd wave of every
 // workgroup lands on a SIMD that already holds one of its waves; 8 waves (256 queries, two workgroups per CU) 148.4 - 148.8.
-static int attn_nw(int) {
-    static int env = -1;
-    if (env < 0) { const char *e = getenv("DA_ATTN_NW"); env = e ? atoi(e) : 0; }
+[[maybe_unused]] static int attn_nw(int) {
+    const int env = DA_XENV("DA_ATTN_NW", 0);
     return (env == 5 || env == 8) ? env : 4;
 }
 // ring depth per instance: the C = 32 layers (9 KB stages, 4 workgroups per CU) take four stages; the C = 144 layer's
 // stages are 23 - 47 KB, where a third stage costs a resident workgroup: two by default, DA_ATTN_STAGES=3 for A/B runs of
 // the folded bf16 instance
-static int attn_stages_env() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_ATTN_STAGES"); v = e ? atoi(e) : 0; }
-    return v;
-}
+[[maybe_unused]] static int attn_stages_env() { return DA_XENV("DA_ATTN_STAGES", 0); }
 template <typename T, int C, bool MASKED, int CV>
 static int launch_tcm(const AttnDenseParams &p, hipStream_t st) {
     if constexpr (C == 32) {
         // (tried: three stages under a 96-VGPR budget = five workgroups per CU instead of four: 25 spilled registers, 184 vs
         // 167 us for the three hidden layers)
+#ifdef DA_EXPERIMENTS
         if (attn_nw(p.max_nodes) == 5) return launch_tcmn<T, C, MASKED, CV, 4, 5>(p, st);
         if (attn_nw(p.max_nodes) == 8) return launch_tcmn<T, C, MASKED, CV, 4, 8>(p, st);
+#endif
         return launch_tcmn<T, C, MASKED, CV, 4, 4>(p, st);
     } else if constexpr (sizeof(T) == 2 && CV == 32 && !MASKED) {
+#ifdef DA_EXPERIMENTS
         if (attn_stages_env() == 3) return launch_tcmn<T, C, MASKED, CV, 3, 4>(p, st);
+#endif
         return launch_tcmn<T, C, MASKED, CV, 2, 4>(p, st);
     } else {
         return launch_tcmn<T, C, MASKED, CV, 2, 4>(p, st);
@@ -859,11 +850,7 @@ static int launch_tc(const AttnDenseParams &p, hipStream_t st) {
 // time): the step runs at the package power cap, and what the denser kernel saves it takes back, and more, from the
 // kernels that follow it.  (Earlier in the round, with the lighter round-2 kernels on the hidden layers, the same switch measured
 // +3.4 % for the dual kernel.)
-static int attn_dual_env() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_ATTN_DUAL"); v = e ? atoi(e) : 0; }
-    return v;
-}
+[[maybe_unused]] static int attn_dual_env() { return DA_XENV("DA_ATTN_DUAL", 0); }
 // returns 0 = launched, -1 = configuration not supported (caller uses the CSR kernel)
 int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_graphs, int max_graph_nodes,
                       const int32_t *graph_ptr, const int32_t *pad_ptr, int nodiag, const void *res, int act,
@@ -875,7 +862,7 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.n_graphs = n_graphs;
     p.nqt = 0; p.max_nodes = max_graph_nodes; p.act = act; p.nodiag = nodiag;
     p.fast = L.q_prescaled ? 1 : 0;
-    { static int off = -1; if (off < 0) { const char *e = getenv("DA_ATTN_NO_FAST"); off = (e && e[0] == '1') ? 1 : 0; } if (off) p.fast = 0; }
+    if (DA_XENV("DA_ATTN_NO_FAST", 0)) p.fast = 0;
     p.sc = L.q_prescaled ? 1.0f : 1.4426950408889634f / sqrtf((float)C);      // pre-scaled Q: the scores already are in log2 units
     p.mask = mk ? mk->mask : nullptr; p.mask_ptr = mk ? (const long long *)mk->mask_ptr : nullptr;
     p.irr_row_ptr = mk ? mk->irr_row_ptr : nullptr; p.irr_col_src = mk ? mk->irr_col_src : nullptr;
@@ -884,20 +871,22 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.blk_class = mk ? mk->blk_class : nullptr; p.blk_class_ptr = mk ? (const long long *)mk->blk_class_ptr : nullptr;
     p.blk_class_stride = mk ? mk->blk_class_stride : 0;
     p.rm_meta = mk ? mk->rm_meta : nullptr;
-    { const char *e = getenv("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
-    { static int fg = -1; if (fg < 0) { const char *e = getenv("DA_ATTN_FORCE_GEN"); fg = (e && e[0] == '1') ? 1 : 0; } p.force_gen = fg; if (fg) p.fast = p.fast ? 2 : 0; }
-    { const char *e = getenv("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
+    { const char *e = DA_XENV_LIVE("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
+    { const int fg = DA_XENV("DA_ATTN_FORCE_GEN", 0) ? 1 : 0; p.force_gen = fg; if (fg) p.fast = p.fast ? 2 : 0; }
+    { const char *e = DA_XENV_LIVE("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     if (n_graphs <= 0 || max_graph_nodes <= 0) return 0;
     p.fold_out = nullptr; p.n_rows = 0;
     if (fold) {           // value heads folded to 32 channels (last layer of the 2D transformer arch)
         if (C != 144 || fold->cv != 32) return -1;
         // DA_ATTN_LAST_FAST=0: the last layer on the referenced (round-2) recurrence while the hidden layers keep k_attn_opt (A/B)
-        { static int lf = -1; if (lf < 0) { const char *e = getenv("DA_ATTN_LAST_FAST"); lf = e ? atoi(e) : 1; } if (!lf) p.fast = 0; }
+        if (!DA_XENV("DA_ATTN_LAST_FAST", 1)) p.fast = 0;
         p.fold_out = fold->out; p.n_rows = fold->n_rows;
+#ifdef DA_EXPERIMENTS
         if (!mk && prec == DA_PREC_BF16 && L.q_prescaled && attn_dual_env() DA_ATTN_DBG(&& !p.debug && !p.prof)) {
             const int r2 = launch_attn_dual(L, heads, C, n_graphs, max_graph_nodes, graph_ptr, pad_ptr, nodiag, act, out, fold, st);
             if (r2 >= 0) return r2;
         }
+#endif
         // bf16 with pre-scaled Q: the optimistic kernels (da_attn_opt.hip); DA_ATTN_OPT_LAST=0 / DA_ATTN_OPT_MASKED=0 keep
         // this layer on k_attn_dense (A/B runs)
         if (prec == DA_PREC_BF16 && L.q_prescaled && p.fast && attn_opt_env() && attn_opt_last_env() && (!p.mask || attn_opt_masked_env())
@@ -912,8 +901,10 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
         const int ro = launch_attn_opt(p, C, st);
         if (ro >= 0) return ro;
     }
+#ifdef DA_EXPERIMENTS
     if (prec == DA_PREC_BF16 && C == 32 && !p.mask && attn2_env() DA_ATTN_DBG(&& !p.debug && !p.prof))
         return launch_attn_dense2(p, heads, n_graphs, max_graph_nodes, st);
+#endif
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, st) : launch_tc<bf16_t, 144>(p, st);
     return C == 32 ? launch_tc<float, 32>(p, st) : launch_tc<float, 144>(p, st);
 }

@@ -1,3 +1,4 @@
+// EXPERIMENTS BUILD ONLY (DA_EXPERIMENTS=1 python __graft_entry__.py; __graft_entry__.EXPERIMENT_SOURCES): two query slabs per wave with generated asm regions for the folded last layer: faster alone, slower for the step (round 3).
 // Dense block-diagonal graph attention, bf16, TWO 32-query slabs per wave with the matrix work of one slab issued under
 // the softmax of the other (round 3).  Same arithmetic contract as k_attn_dense (da_attn_dense.hip: PyG TransformerConv on
 // complete graphs, Transformer_GNN.py:32,38; softmax denominators + 1e-16), same operand layouts:
@@ -540,7 +541,7 @@ static int launch_dual_t(AttnDualParams p, int n_graphs, int max_nodes, hipStrea
     // else one (small Batches need the parallelism more than the shared prologue); the staging epilogue of the un-folded
     // instance reuses the ring, so it keeps one tile per workgroup.  DA_DUAL_TPW overrides (A/B runs).
     static int tpw_env = -1;
-    if (tpw_env < 0) { const char *e = getenv("DA_DUAL_TPW"); tpw_env = e ? atoi(e) : 0; }
+    if (tpw_env < 0) tpw_env = DA_XENV("DA_DUAL_TPW", 0);
     p.tpw = 1;
     if (FOLD) p.tpw = tpw_env > 0 ? tpw_env : ((size_t)p.H * n_graphs >= 512 ? p.nqt : ((size_t)p.H * n_graphs * 2 >= 512 && p.nqt >= 2 ? (p.nqt + 1) / 2 : 1));
     const int nchunk = (p.nqt + p.tpw - 1) / p.tpw;
@@ -557,8 +558,8 @@ int launch_attn_dual(const DenseLayout &L, int heads, int C, int n_graphs, int m
     p.Q = L.Q; p.K = L.K; p.V = L.Vt; p.S = L.S; p.out = fold ? fold->out : out;
     p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.nqt = 0; p.act = act; p.nodiag = nodiag;
     p.n_rows = fold ? fold->n_rows : 0;
-    { const char *e = getenv("DA_DUAL_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
-    { static int fg = -1; if (fg < 0) { const char *e = getenv("DA_ATTN_FORCE_GEN"); fg = (e && e[0] == '1') ? 1 : 0; } p.force_gen = fg; }
+    { const char *e = DA_XENV_LIVE("DA_DUAL_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
+    p.force_gen = DA_XENV("DA_ATTN_FORCE_GEN", 0) ? 1 : 0;
     if (n_graphs <= 0 || max_graph_nodes <= 0) return 0;
     if (fold && C == 144 && fold->cv == 32) return launch_dual_t<144, 32, 6, true>(p, n_graphs, max_graph_nodes, st);
     if (!fold && C == 32) return launch_dual_t<32, 32, 8, false>(p, n_graphs, max_graph_nodes, st);

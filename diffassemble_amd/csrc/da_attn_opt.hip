@@ -724,7 +724,7 @@ static int launch_optt(AttnDenseParams p, hipStream_t st) {
         attr_done[dev & 15] = true;
     }
     p.nqt = (p.max_nodes + 32 * NWV - 1) / (32 * NWV);
-    DA_OPB({ const char *e = getenv("DA_OPT_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; })
+    DA_OPB({ const char *e = DA_XENV_LIVE("DA_OPT_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; })
     k_attn_optt<C, FOLD, MASKED, NST, MINB, BK, VAR, NWV><<<p.nqt * p.H * p.n_graphs, 64 * NWV, lds, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
@@ -1027,51 +1027,58 @@ static int launch_res(const AttnDenseParams &p, hipStream_t st) {
         attr_done[dev & 15] = true;
     }
     AttnDenseParams q = p;
-    DA_OPB({ const char *e = getenv("DA_OPT_PROF_PTR"); q.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; })
+    DA_OPB({ const char *e = DA_XENV_LIVE("DA_OPT_PROF_PTR"); q.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; })
     k_attn_res<NWV, QUEUE, KPF, XV><<<p.H * p.n_graphs, 64 * NWV, lds, st>>>(q);
     DA_LAUNCH_CHECK();
     __atomic_fetch_add(&g_res_launches, 1ll, __ATOMIC_RELAXED);
     return 0;
 }
 
-static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
-
 // bf16, Q pre-scaled, heads of 32 value channels: C = 32 (hidden layers) or C = 144 with p.fold_out (folded last layer);
 // p.mask selects the adjacency-masked instances.  Returns 0 = launched, -1 = shape not covered.
-// DA_OPT_HID / DA_OPT_LAST pick one of the measured-and-kept alternatives of the un-masked instances (A/B switches; 0 = default).
+// The PRODUCT build holds one instance per class -- hidden ring kernel, hidden resident kernel, last layer, and their two masked
+// forms; the alternatives that lost their whole-graph A/B (numbered DA_OPT_HID / DA_OPT_LAST / DA_ATTN_RES_PH variants, the
+// small-graph resident forms, the ablation builds) exist in the EXPERIMENTS build only (da_config.h).
 int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
     const bool fold = p.fold_out != nullptr, masked = p.mask != nullptr;
     if (masked && p.max_nodes > 4096) return -1;          // the masked walk keeps its key tiles in a 64-bit mask
     if (masked && p.blk_class && p.blk_class_stride > 128) return -1;      // class rows are staged in 128-byte LDS slots
     if (C == 32 && !fold) {
-        static int vm = -1;
-        if (vm < 0) vm = env_int("DA_OPT_MASKED_VAR", 0);
-        if (masked) return vm == 30 ? launch_optt<32, false, true, 4, 4, 64, 256>(p, st) : launch_optt<32, false, true, 4, 4>(p, st);
-        static int v = -1;
-        if (v < 0) v = env_int("DA_OPT_HID", 0);
-        // large complete graphs: the K / V-resident kernel (DA_ATTN_RES=0 keeps the ring kernel; DA_ATTN_RES_MIN = smallest "largest graph"
+        if (masked) {
+#ifdef DA_EXPERIMENTS
+            if (DA_XENV("DA_OPT_MASKED_VAR", 0) == 30) return launch_optt<32, false, true, 4, 4, 64, 256>(p, st);
+#endif
+            return launch_optt<32, false, true, 4, 4>(p, st);
+        }
+        [[maybe_unused]] const int v = DA_XENV("DA_OPT_HID", 0);
+        // large complete graphs: the K / V-resident kernel (da_config.attn_level < 2 keeps the ring kernel; 512 = smallest "largest graph"
         // it takes; the Batch's mean slot size must be at least half of its largest graph's -- a ragged Batch of small puzzles with one
         // large one would leave most workgroups of sixteen waves with one or two slabs)
         {
-            static int res = -1, res_min = 0, res_ph = 0;
-            if (res < 0) { res_min = env_int("DA_ATTN_RES_MIN", 512); res_ph = env_int("DA_ATTN_RES_PH", 1); res = env_int("DA_ATTN_RES", 1); }
+            const int res = cfg().attn_level >= 2, res_min = DA_XENV("DA_ATTN_RES_MIN", 512);
+#ifdef DA_EXPERIMENTS
             // OPT-IN (DA_ATTN_RES_SMALL=1; 2 = the 105-VGPR build): measured on 12 x 12 puzzles -- 35.5 -> 32.4 us per 256-puzzle launch alone
             // (58.0 against 63.6 at 512), and configuration 2's step 0.6370 / 0.6315 -> 0.6407 / 0.6370 ms: faster alone, not in the two-branch step
-            static int res_small = -1;
-            if (res_small < 0) res_small = env_int("DA_ATTN_RES_SMALL", 0);
+            const int res_small = DA_XENV("DA_ATTN_RES_SMALL", 0);
             if (res && res_small && v == 0 && p.max_nodes > 128 && p.max_nodes <= 160 && (long long)p.n_pad * 2 >= (long long)p.n_graphs * p.max_nodes)
                 return res_small == 2 ? launch_res<5, false, true, 8>(p, st)        // (2: 105 VGPRs, no spill, three workgroups per CU)
                                       : launch_res<5, false, true>(p, st);          // 12 x 12 puzzles: five slabs, five waves, four workgroups per CU (96 VGPRs)
-            if (res && v == 0 && p.max_nodes >= res_min && p.max_nodes <= 19 * 64 /* 19 stages + the queue word <= 160 KB */ && (long long)p.n_pad * 2 >= (long long)p.n_graphs * p.max_nodes)
-                switch (res_ph) {          // A/B switches (DA_ATTN_RES_PH); default 1
+#endif
+            if (res && v == 0 && p.max_nodes >= res_min && p.max_nodes <= 19 * 64 /* 19 stages + the queue word <= 160 KB */ && (long long)p.n_pad * 2 >= (long long)p.n_graphs * p.max_nodes) {
+#ifdef DA_EXPERIMENTS
+                switch (DA_XENV("DA_ATTN_RES_PH", 1)) {          // A/B switches; default 1
                     case 3: return launch_res<16, false, true>(p, st);         // fixed slabs (wave, wave + 16)
                     case 4: return launch_res<16, true, false>(p, st);         // no K-fragment prefetch
                     case 5: return launch_res<16, true, true, 1>(p, st);       // two PV accumulators
                     case 6: return launch_res<16, true, true, 2>(p, st);       // younger half of the waves at priority 1
                     case 7: return launch_res<16, true, true, 3>(p, st);
-                    default: return launch_res<16, true, true>(p, st);
+                    default: break;
                 }
+#endif
+                return launch_res<16, true, true>(p, st);
+            }
         }
+#ifdef DA_EXPERIMENTS
         switch (v) {
             case 1: return launch_optt<32, false, false, 4, 4, 64, 1>(p, st);
             case 2: return launch_optt<32, false, false, 4, 4, 64, 2>(p, st);
@@ -1094,18 +1101,22 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
             case 132: return launch_optt<32, false, false, 4, 4, 64, 32>(p, st);
             case 160: return launch_optt<32, false, false, 4, 4, 64, 60>(p, st);
 #endif
-            default: return launch_optt<32, false, false, 4, 4>(p, st);
+            default: break;
         }
+#endif
+        return launch_optt<32, false, false, 4, 4>(p, st);
     }
     // (two ring stages at three workgroups per CU; measured at the end of round 4: three stages at two workgroups per CU 189 - 191 us
     // against 178 in the harness at 64 puzzles, 99 against 92 at 32, the sampling step 0.717 against 0.703 ms -- occupancy, not ring depth)
     if (C == 144 && fold) {
-        static int vm = -1;
-        if (vm < 0) vm = env_int("DA_OPT_MASKED_VAR", 0);
-        if (masked) return vm == 30 ? launch_optt<144, true, true, 2, 3, 64, 256>(p, st) : launch_optt<144, true, true, 2, 3>(p, st);
-        static int v = -1;
-        if (v < 0) v = env_int("DA_OPT_LAST", 0);
-        switch (v) {
+        if (masked) {
+#ifdef DA_EXPERIMENTS
+            if (DA_XENV("DA_OPT_MASKED_VAR", 0) == 30) return launch_optt<144, true, true, 2, 3, 64, 256>(p, st);
+#endif
+            return launch_optt<144, true, true, 2, 3>(p, st);
+        }
+#ifdef DA_EXPERIMENTS
+        switch (DA_XENV("DA_OPT_LAST", 0)) {
             case 1: return launch_optt<144, true, false, 4, 3, 32, 0>(p, st);
             case 2: return launch_optt<144, true, false, 3, 3, 32, 0>(p, st);
             case 3: return launch_optt<144, true, false, 3, 4, 32, 0>(p, st);
@@ -1130,8 +1141,10 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
             case 128: return launch_optt<144, true, false, 2, 3, 64, 28>(p, st);
             case 160: return launch_optt<144, true, false, 2, 3, 64, 60>(p, st);
 #endif
-            default: return launch_optt<144, true, false, 2, 3>(p, st);
+            default: break;
         }
+#endif
+        return launch_optt<144, true, false, 2, 3>(p, st);
     }
     return -1;
 }

@@ -229,8 +229,7 @@ int launch_embed_pos_time(int prec, int n, int c_in, int F, int D, const float *
                           const float *b1, void *comb_in, hipStream_t st) {
     if (n <= 0) return 0;
     if (c_in > 8) { set_error("launch_embed_pos_time: c_in %d > 8", c_in); return 2; }
-    static int npw_env = -1;
-    if (npw_env < 0) { const char *e = getenv("DA_EMBED_NPW"); npw_env = e ? atoi(e) : 0; }
+    const int npw_env = DA_XENV("DA_EMBED_NPW", 0);
     // nodes per wave: one while the batch is too small to cover the chip otherwise, eight from 8 192 nodes up
     const int npw = npw_env > 0 ? npw_env : (n >= 8192 ? 8 : 1), grid = (n + 4 * npw - 1) / (4 * npw);
     if (prec == DA_PREC_BF16)
@@ -538,8 +537,7 @@ __global__ __launch_bounds__(64) void k_tail_fused(int n, int H, int c_out, cons
 int launch_tail_fused(int prec, int n, int H, int c_out, int hidden, int din, const void *h, const void *xin, int ldx, const void *wh,
                       const float *bh, const void *wsk, const float *bsk, const void *pz, const float *w2, const float *b2, float *out,
                       hipStream_t st, DdimFuse *dfp) {
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("DA_TAIL_FUSED"); off = (e && e[0] == '0') ? 1 : 0; }
+    const bool off = (cfg().disable_folds & DA_FOLD_TAIL) != 0;
     if (off || prec != DA_PREC_BF16 || hidden != 128 || din != 256 || H > 8 || c_out > 8 || (ldx & 7)) return -1;
     if (n <= 0) return 0;
     DdimFuse df;
@@ -555,8 +553,7 @@ int launch_tail_fused(int prec, int n, int H, int c_out, int hidden, int din, co
     // one box): parity-clean (tests/test_gpu_tail_next.py) and two launches fewer per step, but not faster -- headline 0.6786 / 0.6890 ms
     // without, 0.6788 / 0.6845 with; one-branch loop 0.7175 -> 0.7154; configuration 2 (512 x 144 pieces) 0.6346 -> 0.6428: the work moves into a
     // kernel that runs one wave per SIMD at 255 VGPRs (64 more GELUs and 16 MFMAs per lane and slab), which costs what the launches cost.
-    static int nx_off = -1;
-    if (nx_off < 0) { const char *e = getenv("DA_TAIL_NEXT"); nx_off = (e && e[0] == '0') ? 1 : 0; }        // the request itself (nx_on) is decided in enqueue_loop
+    const bool nx_off = cfg().tail_next == 0;        // the request itself (nx_on) is decided in enqueue_loop
     const bool next = dfp && df.x_prev && df.nx_on && !nx_off && df.nx_cin <= 8 && df.nx_cin == c_out && df.nx_h == h;
     if (next)
         k_tail_fused<true><<<(slabs + spw - 1) / spw, 64, 0, st>>>(n, H, c_out, (const bf16_t *)h, (const bf16_t *)xin, ldx, (const bf16_t *)wh, bh,

@@ -1,3 +1,4 @@
+// EXPERIMENTS BUILD ONLY (DA_EXPERIMENTS=1 python __graft_entry__.py; __graft_entry__.EXPERIMENT_SOURCES): projection + attention of a hidden conv in one kernel: a tie at 256 workgroups, a loss below (round 2).
 // One hidden TransformerConv layer (Transformer_GNN.py:32,38 -> PyG TransformerConv, C = 32 channels per head)
 // on COMPLETE graphs as ONE kernel: the fused Q | K | V | skip projection of a (graph, head) AND its
 // attention, with nothing but the layer's input x and its output touching HBM.
@@ -305,11 +306,7 @@ __global__ __launch_bounds__(1024, 4) void k_conv_fused(ConvFusedParams p) {
 // which wait on operand-shaped global loads of x (2/3 of the wave cycles in s_waitcnt), 53 us to the attention loop, which
 // executes the same 19 M VALU instructions as k_attn_dense but with one workgroup per CU.  Kept as the measured record
 // of VERDICT r01 direction 4(iii); the default path is the two-kernel one.
-static bool conv_fused_disabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_CONV_FUSED"); v = (e && e[0] == '1') ? 0 : 1; }
-    return v == 1;
-}
+static bool conv_fused_disabled() { return DA_XENV("DA_CONV_FUSED", 0) == 0; }
 
 size_t conv_fused_lds_bytes(int max_graph_nodes, int kin) {
     const size_t n32 = (size_t)((max_graph_nodes + 31) / 32) * 32;
@@ -331,7 +328,7 @@ int launch_conv_fused(int prec, int heads, int C, int kin, int n_graphs, int max
     p.x = (const bf16_t *)x; p.ldx = ldx; p.W = (const bf16_t *)W; p.bias = bias; p.out = (bf16_t *)out;
     p.graph_ptr = graph_ptr; p.n_graphs = n_graphs; p.act = act; p.nodiag = nodiag;
     p.sc = 1.4426950408889634f / sqrtf(32.0f);
-    { const char *e = getenv("DA_FUSED_DEBUG"); p.debug = e ? atoi(e) : 0; }
+    { const char *e = DA_XENV_LIVE("DA_FUSED_DEBUG"); p.debug = e ? atoi(e) : 0; }
     const int nblk = n_graphs * 8;
     // waves per workgroup: enough that no wave owns more than two 32-query slabs (the kernel keeps a slab's Q^T / skip^T
     // fragments in registers), 16 for the 900-piece graphs = 4 per SIMD

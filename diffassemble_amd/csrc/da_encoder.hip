@@ -318,12 +318,12 @@ int launch_conv(int prec, int B, const void *X, int Cin, int Hi, const void *W, 
                "encoder conv: a chunk's feature map must stay below 4 GB (32-bit offsets): use a smaller chunk");
     DA_REQUIRE(Cin % BK == 0 && (1 << p.lgcpt) == Cin / BK && Cout % 128 == 0 && (1 << p.lgHo) == Ho && (ksize == 1 || ksize == 3),
                "encoder conv: unsupported geometry (Cin %d Cout %d H %d k %d)", Cin, Cout, Hi, ksize);
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("DA_ENCODER_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
+    p.debug = DA_XENV("DA_ENCODER_DEBUG", 0);
     const int nrt = (p.M + 127) / 128;
     p.nrt8 = (nrt + 7) / 8;
     p.nvirt = 8 * p.nrt8 * p.nct;
-    static int per_cu = -1;
-    if (per_cu < 0) { const char *e = getenv("DA_ENCODER_WG_PER_CU"); per_cu = e ? atoi(e) : 2; if (per_cu < 1) per_cu = 1000000; }
+    int per_cu = DA_XENV("DA_ENCODER_WG_PER_CU", 2);
+    if (per_cu < 1) per_cu = 1000000;
     // persistent: at most 256 CUs x 2 resident workgroups, a multiple of 8 * nct (see the kernel)
     long long cap = (long long)256 * per_cu / (8 * p.nct) * (8 * p.nct);
     if (cap < 8 * p.nct) cap = 8 * p.nct;

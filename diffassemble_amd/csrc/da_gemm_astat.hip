@@ -374,8 +374,7 @@ int launch_gemm_astat(int prec, const GemmParams &p0, const QkvScatter *qs, int 
         p.nct = nct; p.nt = ntile;
         return dim3((unsigned)groups, (unsigned)nrt);
     };
-    static int use_dma = -1;
-    if (use_dma < 0) { const char *e = getenv("DA_ASTAT_DMA"); use_dma = (e && e[0] == '1') ? 1 : 0; }
+    const int use_dma = DA_XENV("DA_ASTAT_DMA", 0);
     const bool rs = !use_dma && (nk == 2 || nk == 4);
     const int lds_rs = nk * 16384 + 32768 + 8 * 2304;
 #define DA_ASTAT_RS(TT, VO, AC, NKK, GRID)                                                                 \

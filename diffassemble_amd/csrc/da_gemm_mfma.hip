@@ -115,8 +115,9 @@ __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (
 
 // TO: element type of out / res / pre (default: the operand type T).  T = float + BFC with TO = bf16_t, and T = bf16_t with
 // TO = float, are the two mixed forms of the training path's bf16 projection buffers (da_train.hip, q16 mode).
+// (two workgroups per CU; the fp32 Q | K | V | skip scatter instance -- parity mode -- spilled 26 registers at that budget and runs at one)
 template <typename T, bool QKV, int ACT, bool BFC = false, typename TO = T>
-__global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && QKV) ? 1 : 2) void k_gemm_mfma(GemmParams p) {
     // two stages x (A tile 16 KB + W tile 16 KB), filled by LDS-DMA (global_load_lds_dwordx4).  A
     // workgroup owns one 128-row tile of A and walks `nt` consecutive 128-column tiles of W as ONE
     // continuous stream of K stages, so the DMA of the next column tile's first stage is already in
@@ -240,9 +241,9 @@ int launch_gemm_thin(int prec, const GemmParams &p0, const QkvScatter *qs, int a
 // four-wave kernel of da_gemm_thin.hip
 static int g_thin = -1;
 void gemm_thin_set(int v) { g_thin = v; }
-static bool thin_on() {
-    if (g_thin < 0) { const char *e = getenv("DA_GEMM_THIN"); g_thin = (e && e[0] == '1') ? 1 : 0; }
-    return g_thin == 1;
+[[maybe_unused]] static bool thin_on(int Nout) {          // 1 = every tall projection, 2 = the 1024-column ones only (the folded last layer keeps its kernel)
+    if (g_thin < 0) g_thin = DA_XENV("DA_GEMM_THIN", 0);
+    return g_thin == 1 || (g_thin == 2 && Nout < 1100);
 }
 
 // returns 0 = launched, -1 = shape not supported by this kernel (caller falls back), >0 error
@@ -264,8 +265,8 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     p.xcd_groups = 0;
     p.ksplit = 0; p.kchunk = 0;
     p.Q = p.Kb = p.Vt = p.S = nullptr;
-    { const char *e = getenv("DA_GEMM_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
-    { const char *e = getenv("DA_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
+    { const char *e = DA_XENV_LIVE("DA_GEMM_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
+    { const char *e = DA_XENV_LIVE("DA_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
     if (qs) {
         const int nexp = qs->Cv > 0 ? 2 * qs->HC + (qs->HC / qs->C) * qs->Cv : 4 * qs->HC;
         if (qs->HC % 128 != 0 || (qs->C & 7) || (qs->Cv & 7) || Nout != nexp || Nout % 128 != 0 || act != DA_ACT_NONE || res) return -1;
@@ -278,12 +279,13 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
         return -1;
     }
     if (!bfc) {   // short reductions: A-stationary kernel (da_gemm_astat.hip)
-        static int off = -1;
-        if (off < 0) { const char *e = getenv("DA_DISABLE_ASTAT"); off = (e && e[0] == '1') ? 1 : 0; }
-        if (K * es <= 512 && thin_on()) {
+        const bool off = DA_XENV("DA_DISABLE_ASTAT", 0) != 0;
+#ifdef DA_EXPERIMENTS
+        if (K * es <= 512 && thin_on(Nout)) {          // the co-resident four-wave kernel (da_gemm_thin.hip): measured, lost (profiles/r06)
             const int rt = launch_gemm_thin(prec, p, qs, act, st);
             if (rt >= 0) return rt;
         }
+#endif
         if (K * es <= 512 && wpacked) {
             // tall inputs at the benched batch sizes: row panel of A in LDS, pre-packed W fragments double-buffered in registers
             const int rx = launch_gemm_xpanel(prec, p, qs, act, wpacked, st);
@@ -303,8 +305,7 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     // Column tiles per workgroup: 256 CUs x 2 resident workgroups = 512 slots.  Use as many column
     // groups as keep the whole grid co-resident (one round, no tail) -- each workgroup then streams
     // its share of the column tiles back to back.
-    static int xcd_off = -1;
-    if (xcd_off < 0) { const char *e = getenv("DA_GEMM_NO_XCD_MAP"); xcd_off = (e && e[0] == '1') ? 1 : 0; }
+    const bool xcd_off = DA_XENV("DA_GEMM_NO_XCD_MAP", 0) != 0;
     auto plan2 = [&](int nct) {
         p.xcd_groups = 0;
         if (!xcd_off && nct > 1 && (size_t)K * es > 512) {
@@ -379,8 +380,7 @@ int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, cons
                             void *out, int ldo, float *partial, size_t partial_floats, hipStream_t st, bool in16, const float *gelu_pre,
                             float *act_out) {
     const int es = in16 ? 2 : 4;                             // in16: A and W are bf16 (out / res / partial stay fp32)
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("DA_GEMM_SPLITK"); off = (e && e[0] == '0') ? 1 : 0; }
+    const bool off = DA_XENV("DA_GEMM_SPLITK", 1) == 0;
     const int nrt = (M + 127) / 128, nct = (Nout + 127) / 128;
     if (off || !partial || 8 * ((nrt + 7) / 8) * nct > 320 || K < 1024 || K % 128 != 0 || Nout % 4 != 0 || ldo % 4 != 0 ||
         !aligned16(A) || !aligned16(W) || !aligned16(out) || (res && !aligned16(res)) || (bias && !aligned16(bias)) ||
@@ -389,8 +389,8 @@ int launch_gemm_mfma_splitk(int M, int K, int Nout, const void *A, int lda, cons
     // as many splits (<= 4) as keep the launch inside ONE round of the 512 resident workgroups (2 per CU): a second round with a
     // few workgroups costs a whole extra pass over the split's stages
     const int base = 8 * ((nrt + 7) / 8) * nct;
-    static int smax = -1;                                     // DA_GEMM_SPLITK_MAX (default 4)
-    if (smax < 0) { const char *e = getenv("DA_GEMM_SPLITK_MAX"); smax = e ? atoi(e) : 4; smax = smax < 2 ? 2 : (smax > 8 ? 8 : smax); }      // (8 measured: 1.204 vs 1.205 ms at configuration 5 -- no gain)
+    int smax = DA_XENV("DA_GEMM_SPLITK_MAX", 4);              // (8 measured: 1.204 vs 1.205 ms at configuration 5 -- no gain)
+    smax = smax < 2 ? 2 : (smax > 8 ? 8 : smax);
     int splits = smax;
     while (splits > 1 && (K % (splits * (128 / es)) != 0 || (size_t)splits * M * Nout > partial_floats || (base * splits > 512 && splits > 2))) --splits;
     if (splits < 2) return -1;

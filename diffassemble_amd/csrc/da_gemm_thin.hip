@@ -1,3 +1,4 @@
+// EXPERIMENTS BUILD ONLY (DA_EXPERIMENTS=1 python __graft_entry__.py; __graft_entry__.EXPERIMENT_SOURCES): four-wave projection kernel co-resident with k_attn_res: co-runs as designed, the step loses 3 - 5 % (round 6, profiles/r06).
 // CO-RESIDENT projection kernel: the fused Q | K | V (| skip) projections sized to what one workgroup of the K / V-resident
 // attention kernel (k_attn_res: sixteen waves x 96 VGPRs, 120 KB of LDS) leaves free on a CU -- 128 VGPRs per SIMD lane, 40 KB
 // of LDS and four wave slots per SIMD -- so that, in the two-stream pair loop, the projections of one half Batch run INSIDE the
@@ -201,7 +202,7 @@ int launch_gemm_thin(int prec, const GemmParams &p0, const QkvScatter *qs, int a
         return -1;
     }
     static int tpw = -1;
-    if (tpw < 0) { const char *e = getenv("DA_THIN_TPW"); tpw = e ? atoi(e) : 12; if (tpw < 1) tpw = 1; }
+    if (tpw < 0) { tpw = DA_XENV("DA_THIN_TPW", 12); if (tpw < 1) tpw = 1; }
     const int nrt = (p.M + 31) / 32;
     const int ncg = (p.Nout + 95) / 96;
     int cpx = (nrt + 8 * tpw - 1) / (8 * tpw);

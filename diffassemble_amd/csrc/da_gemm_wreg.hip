@@ -435,11 +435,7 @@ __global__ __launch_bounds__(320) void k_gemm_wreg2(GemmParams p, int tiles_per_
     if (!DIRECT && active && ntile > 0) drain(ntile - 1);
 }
 
-static bool wreg_disabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_DISABLE_WREG"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
+static bool wreg_disabled() { return DA_XENV("DA_DISABLE_WREG", 0) != 0; }
 
 // returns 0 = launched, -1 = not applicable (caller falls back to the A-stationary / generic kernels)
 int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int act, hipStream_t st) {
@@ -452,14 +448,12 @@ int launch_gemm_wreg(int prec, const GemmParams &p0, const QkvScatter *qs, int a
     // read from LDS feeds two MFMAs, half the LDS reads and barriers per FLOP -- for 512 <= Nout < 1100, where it replaces
     // the A-stationary kernel (57 600 rows: K = 256 x 1024 columns 70.5 -> 48.9 us, K = 128 x 1024 53.6 -> 38.6 us; the
     // A-stationary kernel re-streams all of W through LDS for every 128-row panel).  DA_WREG2=0 / =1 force one of them.
-    static int v2mode = -2;
-    if (v2mode == -2) { const char *e = getenv("DA_WREG2"); v2mode = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    const int v2mode = DA_XENV("DA_WREG2", -1);
     const bool v2 = v2mode == 1 || (v2mode == -1 && p.Nout < 1100);
     if ((p.K != 128 && p.K != 256) || p.pre || p.res || p.M < 4096 || (p.Nout & (v2 ? 63 : 31)) || p.Nout < (v2 ? 512 : 1100)) return -1;
     // register-direct epilogue (DA_WREG_DIRECT=1; default the LDS-strip epilogue: 125 vs 139 us on conv 3, whose 64-byte row pieces it merges): a lane's 16 (32) consecutive columns must stay
     // inside one column block and one head
-    static int dmode = -2;
-    if (dmode == -2) { const char *e = getenv("DA_WREG_DIRECT"); dmode = e ? (e[0] == '1' ? 1 : 0) : 0; }
+    const int dmode = DA_XENV("DA_WREG_DIRECT", 0);
     const int lw = v2 ? 32 : 16;
     bool direct = dmode == 1;
     if (qs && ((qs->HC % lw) || (qs->C % lw) || (qs->Cv % lw))) direct = false;

@@ -237,26 +237,17 @@ __global__ __launch_bounds__(512) void k_gemm_xpanel(GemmParams p, const u32x4 *
 // seven) and, together with the tail kernel's next-step embedding (DA_TAIL_NEXT), -2.5 % on the headline step (seven of seven) -- configuration 2
 // (144-piece graphs) does not gain.  DA_ENABLE_XPANEL: 1 = every Batch, 0 = never, unset = DA_STEP_AUTO's rule (xpanel_mode() == 2: Batches
 // whose largest graph has >= 512 pieces, decided per forward in da_api.hip).
+// da_config.xpanel (DA_ENABLE_XPANEL): 1 = every Batch, 0 = never, -1 (default) = Batches whose largest graph has >= 512 pieces, decided per
+// forward in da_api.hip (xpanel_mode() == 2).  In an EXPERIMENTS build a process that sets one of the other projection kernels' own switches is
+// measuring THAT kernel: the rule stays out of its way.
 int xpanel_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("DA_ENABLE_XPANEL");
-        // a process that sets one of the other projection kernels' own switches is measuring or testing THAT kernel: the rule stays out of its way
-        const bool other = getenv("DA_DISABLE_WREG") || getenv("DA_WREG2") || getenv("DA_WREG_DIRECT") || getenv("DA_DISABLE_ASTAT") || getenv("DA_GEMM_DEBUG") ||
-                           getenv("DA_GEMM_PROF_PTR");
-        v = e ? ((e[0] == '1') ? 1 : 0) : ((step_auto_default() && !other) ? 2 : 0);
-    }
-    return v;
+    const int v = cfg().xpanel;
+    if (v >= 0) return v ? 1 : 0;
+    const bool other = DA_XENV_SET("DA_DISABLE_WREG") || DA_XENV_SET("DA_WREG2") || DA_XENV_SET("DA_WREG_DIRECT") || DA_XENV_SET("DA_DISABLE_ASTAT") ||
+                       DA_XENV_SET("DA_GEMM_DEBUG") || DA_XENV_SET("DA_GEMM_PROF_PTR") || DA_XENV_SET("DA_GEMM_THIN");
+    return other ? 0 : 2;
 }
-bool xpanel_in_model() { return xpanel_mode() != 0; }          // whether the packed weight images are built at all
-
-// DA_STEP_AUTO (default 1): the large-graph step defaults of the round's last session -- row-panel projections and the next step's embedding
-// inside the tail kernel for Batches whose largest graph has >= 512 pieces.  0 = both opt-in again (DA_ENABLE_XPANEL=1 / DA_TAIL_NEXT=1).
-bool step_auto_default() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_STEP_AUTO"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
+bool xpanel_in_model() { return xpanel_mode() != 0; }          // whether the packed weight images are built at all (at da_denoiser_create)
 
 // returns 0 = launched, -1 = not applicable (caller falls back to the W-in-registers / A-stationary / generic kernels)
 int launch_gemm_xpanel(int prec, const GemmParams &p0, const QkvScatter *qs, int act, const void *wpacked, hipStream_t st) {

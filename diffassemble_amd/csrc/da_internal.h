@@ -1,6 +1,7 @@
 // Internal launcher declarations shared by the translation units of libdiffassemble_hip.so.
 #pragma once
 #include "da_common.h"
+#include "da_config.h"
 
 namespace da {
 
@@ -104,6 +105,22 @@ int launch_ddim3d(const DeviceSchedule &s, int mean_type, int n, const float *x,
                   int64_t t_scalar, int ratio, int prev_all_nonneg, float *x_prev, hipStream_t st);
 
 // da_gemm_mfma.hip / da_attn_dense.hip (dense block-diagonal path)
+// Joins a library-owned side stream back into the caller's stream on EVERY exit of the scope that forked it (an early
+// `return rc` between fork and join left side-stream work un-joined while the caller freed or rewrote the workspace).  The success
+// path calls join() itself (and sees its errors); the destructor covers the error exits, best effort.
+struct StreamJoin {
+    hipStream_t side = nullptr, caller = nullptr;
+    hipEvent_t ev = nullptr;
+    bool armed = false;
+    void arm(hipStream_t side_, hipStream_t caller_, hipEvent_t ev_) { side = side_; caller = caller_; ev = ev_; armed = true; }
+    hipError_t join() {
+        if (!armed) return hipSuccess;
+        armed = false;
+        hipError_t e = hipEventRecord(ev, side);
+        return e == hipSuccess ? hipStreamWaitEvent(caller, ev, 0) : e;
+    }
+    ~StreamJoin() { (void)join(); }
+};
 struct QkvScatter {            // where the fused projection scatters its four column blocks
     int HC, C, n_pad;
     int Cv = 0;                // > 0: three blocks only (Q | K | V'), V' heads Cv wide (folded value heads), no skip
@@ -123,7 +140,6 @@ size_t xpanel_packed_bytes(int K, int Nout);
 bool xpanel_in_model();          // DA_ENABLE_XPANEL=1 (off by default, see da_gemm_xpanel.hip)
 void gemm_thin_set(int v);      // run-time form of DA_GEMM_THIN (da_gemm_mfma.hip): 1 = projections take the co-resident kernel of da_gemm_thin.hip
 int xpanel_mode();               // 0 never, 1 always, 2 = Batches whose largest graph has >= 512 pieces (the default, DA_STEP_AUTO)
-bool step_auto_default();        // DA_STEP_AUTO (default 1)
 int pack_w_xpanel(int K, int Nout, const void *W, int ldw, void *packed, hipStream_t st);
 struct DenseMask {             // hybrid mode: adjacency bits of the regular edges + the remainder CSR (da_attn_dense.hip)
     const uint8_t *mask;

@@ -369,16 +369,22 @@ __global__ __launch_bounds__(1024) void k_pcd_knn64_mfma(const float *__restrict
             *(float4 *)(score + rl * RS + cb) = float4{o[0], o[1], o[2], o[3]};
         }
     };
-    // the wave's candidate tiles, the next tile's rows in flight under the current tile's MFMAs
-    float4 ca[8], cb2[8];
+    // the wave's candidate tiles (at most two below 1 024 candidates), the FIRST HALF of the next tile's rows in flight under the current tile's
+    // MFMAs: a whole second tile (round 3's form) needs 32 more registers than this kernel's 128 hold -- five were spilled to scratch
+    float4 ca[8], nb[4];
     int c0 = wave * 32;
     if (c0 < Npad) load_tile(ca, c0);
-    for (; c0 < Npad; c0 += 1024) {
-        if (c0 + 512 < Npad) load_tile(cb2, c0 + 512);
+    for (; c0 < Npad; c0 += 512) {
+        const bool more = c0 + 512 < Npad;
+        const float4 *rn = (const float4 *)(Xc + (size_t)min(c0 + 512 + rl, N - 1) * VROW + 32 * kk);
+        if (more) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nb[e] = rn[e];
+        }
         do_tile(ca, c0);
-        if (c0 + 512 < Npad) {
-            if (c0 + 1024 < Npad) load_tile(ca, c0 + 1024);
-            do_tile(cb2, c0 + 512);
+        if (more) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ca[e] = nb[e]; ca[4 + e] = rn[4 + e]; }
         }
     }
     __syncthreads();
@@ -637,7 +643,7 @@ static int knn_launch(int clouds, int N, int dim, const float *x, int ldx, int k
     const int F = dim <= 3 ? 3 : 64;
     const int Npad = (N + 63) & ~63;
     static int mfma_knn = -1;
-    if (mfma_knn < 0) { const char *e = getenv("DA_PCD_KNN_VALU"); mfma_knn = (e && e[0] == '1') ? 0 : 1; }
+    if (mfma_knn < 0) mfma_knn = DA_XENV("DA_PCD_KNN_VALU", 0) ? 0 : 1;
     if (F == 64 && !ordered && ldx == VROW && Npad <= 1024 && mfma_knn && xn) {
         const size_t lds = (size_t)(32 * (Npad + 4) + Npad + 32) * sizeof(float);
         static bool attrm = false;
@@ -735,7 +741,7 @@ int da_pcd_encoder_forward(const da_pcd_encoder_weights *w, int n_parts, int n_p
     // only the tails and the small kernels overlap.  DA_PCD_TWO_STREAMS=0, fewer than 64 fragments, or a workspace that does not
     // hold two halves: one stream, whole chunks.
     static int two_off = -1;
-    if (two_off < 0) { const char *e = getenv("DA_PCD_TWO_STREAMS"); two_off = (e && e[0] == '0') ? 1 : 0; }
+    if (two_off < 0) two_off = DA_XENV("DA_PCD_TWO_STREAMS", 1) == 0 ? 1 : 0;
     const int half = chunk / 2;
     PcdSide *sd = nullptr;
     size_t sub_bytes = 0;

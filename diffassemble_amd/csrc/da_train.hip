@@ -491,7 +491,7 @@ int launch_gemm_tn_db(int M, int N, int K, const void *A, int lda, const void *B
     splits = splits > by_cap ? by_cap : splits;
     if (splits < 1) splits = 1;
     static int xcd_off = -1;
-    if (xcd_off < 0) { const char *e = getenv("DA_TN_NO_XCD_MAP"); xcd_off = (e && e[0] == '1') ? 1 : 0; }
+    if (xcd_off < 0) xcd_off = DA_XENV("DA_TN_NO_XCD_MAP", 0) ? 1 : 0;
     // several tiles and enough rows: exactly 8 (or 16) row ranges, one (two) per XCD (see the kernel)
     const bool xcd = !xcd_off && tn * tk >= 8 && by_rows >= 8 && by_cap >= 8;
     if (xcd) splits = (tn * tk <= 12 && by_rows >= 32 && by_cap >= 32) ? 32 : (tn * tk <= 24 && by_rows >= 16 && by_cap >= 16) ? 16 : 8;
@@ -822,11 +822,7 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
                           const float *o, const float *res);
 bool hybrid_flash_ok(const da_graph *g, int C, bool bfc);     // the flash-style kernels (no pair matrix) take this hybrid layer
 
-static bool train_dense_disabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_TRAIN_DISABLE_DENSE"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
+static bool train_dense_disabled() { return cfg().train_attn == 0; }          // da_config.train_attn (DA_TRAIN_ATTN=0): the edge-list kernels only
 
 static unsigned grid_for(size_t n) { const size_t b = (n + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
@@ -922,7 +918,7 @@ static int dims_of(const da_weights *w, const da_graph *g, Dims &d, int mma = DA
                g->pad_ptr && g->max_graph_nodes > 0;
     // the hybrid training kernels index the adjacency bits by NODE (row i = node - graph_ptr[g]); a plan in the banded slot layout
     // (graph_plan.expander_plan: bits in SLOT space, slot_node != NULL) would be read in the wrong order -- refuse it loudly
-    DA_REQUIRE(!(d.hybrid && g->slot_node), "training: hybrid graph in the banded slot layout (slot_node set); train on a natural-layout plan (build_plan / expander_plan(..., banded=False))");
+    DA_REQUIRE(!(d.hybrid && g->slot_node), "training: hybrid graph in the banded slot layout (slot_node set); train on a natural-layout plan: build_plan(edge_index, batch), expander_plan(..., banded=False) or DA_EXPANDER_LAYOUT=natural");
     DA_REQUIRE(d.dense || d.hybrid || g->row_ptr, "training: this graph walks the edge list but the CSR arrays are missing");
     // hybrid graphs in the bf16-operand mode run flash-style (da_train_dense.hip: k_hyb_*): no pair matrix is ever allocated
     bool flash = d.hybrid && d.bfc;
@@ -930,8 +926,7 @@ static int dims_of(const da_weights *w, const da_graph *g, Dims &d, int mma = DA
     d.pair_floats = (d.dense || (d.hybrid && !flash)) ? dense_pair_floats(g, d.H) : 0;
     static int q16_off = -1;
     if (q16_off < 0) {
-        const char *e = getenv("DA_TRAIN_Q16"), *e2 = getenv("DA_TRAIN_TN_DB");
-        q16_off = ((e && e[0] == '0') || (e2 && e2[0] == '0')) ? 1 : 0;
+        q16_off = (DA_XENV("DA_TRAIN_Q16", 1) == 0 || DA_XENV("DA_TRAIN_TN_DB", 1) == 0) ? 1 : 0;
     }
     d.q16 = d.bfc && d.dense && !q16_off;
     for (int l = 0; l < d.L && d.q16; ++l) d.q16 = attn_small_ok(g, d.C[l], true) && d.din[l] % 32 == 0 && d.C[l] % 8 == 0;
@@ -1020,7 +1015,7 @@ static int check_fused(const da_weights *w, const Dims &d, const char *what) {
 
 static int q16_cast_on() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("DA_TRAIN_Q16_CAST"); v = (e && e[0] == '0') ? 0 : 1; }
+    if (v < 0) v = DA_XENV("DA_TRAIN_Q16_CAST", 1) ? 1 : 0;
     return v;
 }
 
@@ -1088,9 +1083,7 @@ struct SideDw {
 };
 // one context per (device, caller stream): two engines driven on different streams of one process must not share events
 static SideDw *side_dw(hipStream_t caller) {
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("DA_TRAIN_SIDE_DW"); off = (e && e[0] == '0') ? 1 : 0; }
-    if (off) return nullptr;
+    if (!(cfg().train_side_streams & 1)) return nullptr;          // da_config.train_side_streams bit 0
     struct Slot { int dev; hipStream_t caller; SideDw ctx; };
     static std::mutex mu;
     static std::vector<Slot *> slots;
@@ -1129,7 +1122,7 @@ static int linear_bwd(int M, int N, int K, const float *dY, int ldy, const float
         part = ws.partial2;
     }
     static int tn_db = -1;
-    if (tn_db < 0) { const char *e = getenv("DA_TRAIN_TN_DB"); tn_db = (e && e[0] == '0') ? 0 : 1; }
+    if (tn_db < 0) tn_db = DA_XENV("DA_TRAIN_TN_DB", 1) ? 1 : 0;
     if (dy16) {                                             // q16 mode: dY is bf16 (written by k_attn_small_bwd)
         // X16: the bf16 image of X the forward's projection multiplied (dense, leading dimension K) -- the same bits the fp32 route
         // rounds to inside the kernel
@@ -1209,14 +1202,17 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
     // W^T / bf16 images of the step (the backward of this forward reads them too): on the library's side stream, beside the
     // feature copy, the embedding and the mlp -- the first reader is conv 0's projection
     SideDw *sd = side_dw(st);
+    StreamJoin side_guard;              // every exit below joins the side stream (the error exits through its destructor)
     if (sd) {
         DA_CHECK_HIP(hipEventRecord(sd->fork, st));         // (behind the optimizer step / whatever last wrote the weights on the caller's stream)
         DA_CHECK_HIP(hipStreamWaitEvent(sd->s, sd->fork, 0));
+        side_guard.arm(sd->s, st, sd->join);
     }
     if ((rc = weight_prep(w, d, ws, sd ? sd->s : st))) return rc;
     // (the pair offsets / node -> graph table of the grouped attention kernels: the same side stream, needed by the first attention)
     if (sd && (d.dense || d.hybrid) && (rc = dense_train_prepare(g, d.H, ws.poff, ws.node_graph, sd->s))) return rc;
-    if (sd) DA_CHECK_HIP(hipEventRecord(sd->join, sd->s));
+    hipEvent_t ev_images = sd ? sd->done[0] : nullptr;       // (done[] belongs to the backward; idle during a forward)
+    if (sd) DA_CHECK_HIP(hipEventRecord(ev_images, sd->s));
     if ((rc = launch_set_feats(P, nr, d.F, D, feats, ws.comb_in, st))) return rc;
     if ((rc = launch_embed_pos_time(P, nr, d.c_in, d.F, D, x, t, 0, w->steps, w->time_emb, w->pos_w0, w->pos_b0, w->pos_w1,
                                     w->pos_b1, ws.comb_in, st))) return rc;
@@ -1226,7 +1222,7 @@ int da_train_forward_ex(const da_weights *w, const da_graph *g, const float *x, 
         DA_REQUIRE(w->virt_emb, "exophormer: virt_emb missing");
         if ((rc = launch_set_virtual_rows(P, n - nr, d.V, D, w->virt_emb, ws.h0 + (size_t)nr * D, st))) return rc;
     }
-    if (sd) DA_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));      // the weight images are there
+    if (sd) { DA_CHECK_HIP(hipStreamWaitEvent(st, ev_images, 0)); side_guard.armed = false; }      // the weight images are there (nothing else runs on the side stream in a forward)
     const float *xin = ws.h0;
     int ldx = D;
     bool x16_ready = false;           // x16[l] already holds the bf16 image of xin (written by the GELU launch of the layer before)
@@ -1320,8 +1316,10 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
 
     const bool dh0_copy = n > nr;
     SideDw *sd = side_dw(st);           // null: DA_TRAIN_SIDE_DW=0
+    StreamJoin side_guard;              // every exit joins the dW / db launches of the side stream (error exits through its destructor)
+    if (sd) side_guard.arm(sd->s, st, sd->join);
     static int dw_x16 = -1;             // DA_TRAIN_DW_X16=1: the convs' dW products read the bf16 image of X (measured slower: 69 vs 63 us at conv 3)
-    if (dw_x16 < 0) { const char *e = getenv("DA_TRAIN_DW_X16"); dw_x16 = (e && e[0] == '1') ? 1 : 0; }
+    if (dw_x16 < 0) dw_x16 = DA_XENV("DA_TRAIN_DW_X16", 0) ? 1 : 0;
     if (do_early) {
     // ---- head: final_mlp.2, GELU, final_mlp.0 (efficient_gat.py:145)
     if ((rc = linear_bwd(nr, d.c_out, 32, d_out, d.c_out, ws.f1, 32, ws.wt_head1, G(grads->head_w1), G(grads->head_b1),
@@ -1361,9 +1359,7 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
         if (l > 0) d_o = dx;
     }
     auto join_side = [&]() -> int {         // the caller's stream continues behind every dW / db launch of this call
-        if (!sd) return 0;
-        DA_CHECK_HIP(hipEventRecord(sd->join, sd->s));
-        DA_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));
+        DA_CHECK_HIP(side_guard.join());
         return 0;
     };
     if (!do_late) return join_side();

@@ -550,20 +550,35 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_fwd(AttnSmall p) {
         // (channel offsets beyond C are clamped to 0 instead of guarded: guarded loads compile to load -> wait round trips)
         if (i < n_g) {
             const size_t es = e0 + 3 * p.HC + (size_t)i * ld;
-            f32x4 sk[CT], rs[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) sk[ct] = as_ld4<Q16>(p.qkvs, es + (ct * 16 + 4 * lg < C ? ct * 16 + 4 * lg : 0));
-            if (p.res) {
-                const float *rsp = p.res + (size_t)(n0 + i) * p.HC + h * C;
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) rs[ct] = *(const f32x4 *)(rsp + (ct * 16 + 4 * lg < C ? ct * 16 + 4 * lg : 0));
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) sk[ct] += rs[ct];
-            }
+            const float *rsp = p.res ? p.res + (size_t)(n0 + i) * p.HC + h * C : nullptr;
             float *ob = p.o + (size_t)(n0 + i) * p.HC + h * C + 4 * lg;
+            // (144- and 160-wide heads: in two halves -- nine / ten skip + residual + output tiles at once are ~110 registers beside the band's
+            //  state under this kernel's 168, which spilled 12 - 26 of them to scratch)
+            constexpr int CH = CT > 8 ? (CT + 1) / 2 : CT;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-                if (ct * 16 + 4 * lg < C) *(f32x4 *)(ob + ct * 16) = oacc[ct] + sk[ct];
+            for (int c0 = 0; c0 < CT; c0 += CH) {
+                f32x4 sk[CH], rs[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const int ct = c0 + k;
+                    if (ct < CT) sk[k] = as_ld4<Q16>(p.qkvs, es + (ct * 16 + 4 * lg < C ? ct * 16 + 4 * lg : 0));
+                }
+                if (rsp) {
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const int ct = c0 + k;
+                        if (ct < CT) rs[k] = *(const f32x4 *)(rsp + (ct * 16 + 4 * lg < C ? ct * 16 + 4 * lg : 0));
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (c0 + k < CT) sk[k] += rs[k];
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const int ct = c0 + k;
+                    if (ct < CT && ct * 16 + 4 * lg < C) *(f32x4 *)(ob + ct * 16) = oacc[ct] + sk[k];
+                }
+            }
         }
     }
 }
@@ -757,14 +772,14 @@ __global__ __launch_bounds__(64 * AS_WAVES) void k_attn_small_bwd(AttnSmall p) {
 static int as_tiles(int C) { const int ct = (C + 15) / 16; return ct <= 1 ? 1 : ct <= 2 ? 2 : ct <= 4 ? 4 : ct <= 9 ? 9 : 10; }
 bool attn_small_ok(const da_graph *g, int C, bool bfc) {
     static int off = -1;
-    if (off < 0) { const char *e = getenv("DA_ATTN_SMALL_FUSED"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off < 0) off = DA_XENV("DA_ATTN_SMALL_FUSED", 1) == 0 ? 1 : 0;
     return bfc && !off && g->max_graph_nodes <= AS_MAXN && C <= 160 && C % 4 == 0;
 }
 template <int CT, bool Q16>
 static int attn_small_launch_ct(const da_graph *g, AttnSmall &a, bool bwd, hipStream_t st) {
     constexpr int pr = CT * 16 + 8;
     static int a4_off = -1;
-    if (a4_off < 0) { const char *e = getenv("DA_ATTN_SMALL_ALL4"); a4_off = (e && e[0] == '0') ? 1 : 0; }
+    if (a4_off < 0) a4_off = DA_XENV("DA_ATTN_SMALL_ALL4", 1) == 0 ? 1 : 0;
     const bool a4 = CT <= 2 && !a4_off;                                   // narrow-head backward: four images, one staging pass
     const int lds = ((bwd && a4) ? 4 : 2) * a.np * pr * 2 + (bwd ? 3 * a.np * 4 : 0);
     static bool attr = false;
@@ -879,7 +894,7 @@ static unsigned gridsz(size_t n) { const size_t b = (n + 255) / 256; return (uns
 static bool ggemm_small_ok(const GGemm &p, int maxn) {
     const int Mx = p.dimM ? p.dimM : maxn, Nx = p.dimN ? p.dimN : maxn, Kx = p.dimK ? p.dimK : maxn;
     static int small_off = -1;
-    if (small_off < 0) { const char *e = getenv("DA_GGEMM_SMALL"); small_off = (e && e[0] == '0') ? 1 : 0; }
+    if (small_off < 0) small_off = DA_XENV("DA_GGEMM_SMALL", 1) == 0 ? 1 : 0;
     return p.bfc && !small_off && Mx <= GS_MAX && Nx <= GS_MAX && Kx <= GS_MAX;
 }
 static int ggemm(const GGemm &p, int G, int H, int maxn, hipStream_t st) {
@@ -1762,8 +1777,7 @@ __global__ __launch_bounds__(HF_NT) void k_hyb_bwd_kv(HybFlash p) {
 #undef AS_MFMA
 
 bool hybrid_flash_ok(const da_graph *g, int C, bool bfc) {
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("DA_HYB_FLASH"); off = (e && e[0] == '0') ? 1 : 0; }
+    const bool off = cfg().train_attn < 2;          // da_config.train_attn (DA_TRAIN_ATTN=1): hybrid graphs through the pair matrices
     return bfc && !off && (C == 32 || C == 144) && g->hybrid && !g->slot_node;
 }
 template <int CT>
@@ -1812,9 +1826,7 @@ static HybFlash hyb_flash_params(const da_graph *g, int H, int C, const float *q
 // DA_HYB_SIDE=0: one stream, the round-4 launch order.
 struct HybSide { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 static HybSide *hyb_side(hipStream_t caller) {
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("DA_HYB_SIDE"); off = (e && e[0] == '0') ? 1 : 0; }
-    if (off) return nullptr;
+    if (!(cfg().train_side_streams & 2)) return nullptr;          // da_config.train_side_streams bit 1
     struct Slot { int dev; hipStream_t caller; HybSide ctx; };
     static std::mutex mu;
     static std::vector<Slot *> slots;
@@ -1846,9 +1858,11 @@ int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, co
         const float scale_f = 1.0f / sqrtf((float)C);
         HybSide *sd = n > nr ? hyb_side(st) : nullptr;
         hipStream_t sv = sd ? sd->s : st;                     // the virtual rows' chain
+        StreamJoin side_guard;                               // error exits below still join the virtual rows' stream
         if (sd) {
             DA_CHECK_HIP(hipEventRecord(sd->fork, st));       // (the projections are there)
             DA_CHECK_HIP(hipStreamWaitEvent(sd->s, sd->fork, 0));
+            side_guard.arm(sd->s, st, sd->join);
         }
         auto virtual_chain = [&]() -> int {
             // virtual rows: statistics over their (remainder-only) edges, o = skip (+ residual), then their edges -- rows with more
@@ -1873,8 +1887,7 @@ int hybrid_train_attn_fwd(const da_graph *g, int H, int C, const float *qkvs, co
                       (k_attn_irr_fwd<18, false><<<grid_r, 256, 0, st>>>(nr, nr, g->irr_row_ptr, g->irr_col_src, H, HC, qkvs, stats, o, scale_f, 0)))
         DA_LAUNCH_CHECK();
         if (sd) {
-            DA_CHECK_HIP(hipEventRecord(sd->join, sd->s));
-            DA_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));
+            DA_CHECK_HIP(side_guard.join());
         }
         return 0;
     }
@@ -1927,9 +1940,11 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
         DA_LAUNCH_CHECK();
         HybSide *sd = n > nr ? hyb_side(st) : nullptr;
         hipStream_t sv = sd ? sd->s : st;
+        StreamJoin side_guard;                               // error exits below still join the virtual rows' stream
         if (sd) {
             DA_CHECK_HIP(hipEventRecord(sd->fork, st));       // (D of every row is there)
             DA_CHECK_HIP(hipStreamWaitEvent(sd->s, sd->fork, 0));
+            side_guard.arm(sd->s, st, sd->join);
         }
         const int grid_r = (int)(((size_t)nr * 64 + 255) / 256), grid_v = (int)(((size_t)(n - nr) * 64 + 255) / 256);
         // the virtual rows' chain: dk | dv start from zero; as destinations their dq (and skip gradient), as sources the dk | dv of
@@ -1959,8 +1974,7 @@ int hybrid_train_attn_bwd(const da_graph *g, int H, int C, const float *qkvs, co
         DA_LAUNCH_CHECK();
         if (!sd && n > nr && (rc = virtual_chain())) return rc;
         if (sd) {
-            DA_CHECK_HIP(hipEventRecord(sd->join, sd->s));
-            DA_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));
+            DA_CHECK_HIP(side_guard.join());
         }
         return 0;
     }

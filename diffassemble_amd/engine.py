@@ -269,15 +269,20 @@ class DenoiserEngine:
 
 
     # ------------------------------------------------------------------ two-branch loop
+    two_branch_min_nodes = 40000       # DA_TWO_BRANCH=auto: the pair loop from this many pieces per Batch
+    two_branch_min_graphs = 64         # DA_TWO_BRANCH=1: ... from this many puzzles
+    pair_split_at = 0                  # puzzles in the first half Batch (0 = half)
+
     def _two_branch(self, plan, keep_trajectory, use_graph):
         """Large Batches of complete graphs run as TWO half Batches on two parallel branches of one hipGraph
         (da_sample_loop_pair), so that one half's projections and tail kernels overlap the other half's attention.
-        Bit-identical poses.  Default ("auto") from 40 000 nodes up (DA_TWO_BRANCH_MIN_NODES): measured at the end of round 3,
+        Bit-identical poses.  Default ("auto") from 40 000 nodes up (``two_branch_min_nodes``): measured at the end of round 3,
         A/B on one box, 900-piece puzzles: 48 per GPU 81.0 k -> 83.8 k puzzle-steps/s, 64 per GPU 85.7 k -> 88.6 k (+3.4 %, three
         rounds), 128: 88.8 k; but 32: 77.7 k -> 75.8 k and 16: 64.0 k -> 60.9 k (half Batches that no longer fill the chip);
         BASELINE config 2 (512 puzzles of 144 pieces) 738 k -> 790 k.  (In round 2 the same switch measured +0.4 %: the step sits
         at the package power cap, and what two interleaved kernel streams buy depends on the kernels.)  DA_TWO_BRANCH=0 turns it
-        off, =1 forces it from DA_TWO_BRANCH_MIN_GRAPHS (64) graphs up.  Loops that keep their trajectory (the module's p_sample_loop) take it
+        off, =1 forces it from ``two_branch_min_graphs`` (64) graphs up; ``two_branch_min_nodes`` / ``two_branch_min_graphs`` /
+        ``pair_split_at`` are attributes of the engine (class defaults below).  Loops that keep their trajectory (the module's p_sample_loop) take it
         too: each half writes its row range of every iteration (da_sample_loop_pair_traj)."""
         if not use_graph or self._profiling or not self.dense_only:
             return False
@@ -287,13 +292,13 @@ class DenoiserEngine:
         if mode == "0":
             return False
         if mode == "1":
-            return plan.n_graphs >= int(os.environ.get("DA_TWO_BRANCH_MIN_GRAPHS", "64"))
-        return plan.n_real >= int(os.environ.get("DA_TWO_BRANCH_MIN_NODES", "40000"))
+            return plan.n_graphs >= int(self.two_branch_min_graphs)
+        return plan.n_real >= int(self.two_branch_min_nodes)
 
     def _sample_loop_pair(self, plan, sched, x_init, feats, ratio, mean_type, n_iters, restage, keep_trajectory=False, opts=None):
         from .graph_plan import split_complete
-        # DA_PAIR_SPLIT_AT (experiment): puzzles in the first branch (default: half) -- unequal branches drift out of lockstep
-        g_split = int(os.environ.get("DA_PAIR_SPLIT_AT", "0")) or plan.n_graphs // 2
+        # pair_split_at (attribute, 0 = half): puzzles in the first branch -- unequal branches drift out of lockstep (measured: loses)
+        g_split = int(self.pair_split_at) or plan.n_graphs // 2
         pa, pb, n0 = split_complete(plan, min(max(g_split, 1), plan.n_graphs - 1))
         c = x_init.shape[1]
         st = self._pair_state

@@ -88,11 +88,17 @@ class GraphPlan:
             self.row_ptr, self.col_src, self.edge_id = _csr_by_destination(self.edge_index, self.n_nodes)
         return self
 
-    def with_source_csr(self):
+    def with_source_csr(self, edge_list_only=None):
         """Add the by-source orientation of the same edge list (da_graph.out_ptr / out_dst), which
-        the attention backward walks to form dK / dV without atomics."""
-        import os
-        edge_list_only = os.environ.get("DA_TRAIN_DISABLE_DENSE") == "1"      # the library then walks the FULL edge list
+        the attention backward walks to form dK / dV without atomics.  ``edge_list_only``: the library walks the FULL edge list
+        (da_config.train_attn = 0, or TrainEngine's fp32 route for small / sparse hybrid plans)."""
+        if edge_list_only is None:
+            from . import _lib
+            edge_list_only = _lib.config().train_attn == 0          # da_config.train_attn (DA_TRAIN_ATTN=0)
+        kind = "full" if (edge_list_only or not self.hybrid) else "remainder"
+        if self.out_ptr is not None and getattr(self, "_out_kind", kind) != kind:
+            self.out_ptr = self.out_dst = None          # built for the other route
+        self._out_kind = kind
         if self.dense and not edge_list_only:
             return self                        # complete graphs train on the grouped GEMMs: no edge list is walked
         if self.out_ptr is None and self.hybrid and not edge_list_only:
@@ -379,8 +385,11 @@ def _hybrid_split(real_ei, virt_ei, batch, counts, graph_ptr, padded, n_nodes, N
     return dict(hybrid=1, mask=mask, mask_ptr=mask_ptr, irr_row_ptr=irr_ptr, irr_col_src=irr_src)
 
 
-def expander_plan(perms, degree, batch_device=None, virt_nodes=0):
-    """GraphPlan of a Batch of Exphander graphs (puzzle_dataset.py:115-152) straight from their permutations
+def expander_plan(perms, degree, batch_device=None, virt_nodes=0, banded=None):
+    """``banded``: None = the process default (DA_EXPANDER_LAYOUT, "banded"); False = the natural slot order the TRAINING path needs
+    (its hybrid kernels index the adjacency by node); True = banded.
+
+    GraphPlan of a Batch of Exphander graphs (puzzle_dataset.py:115-152) straight from their permutations
     (``diffassemble_amd.expander``): in position space the graph is a circulant band, so the adjacency bit of a pair is
     a closed form of the two positions -- no edge list, no sort, no multiplicity table.  The exophormer's virtual-node
     edges (exophormer_gnn.py:183-200) depend only on the Batch shape and are planned as in ``build_plan``.  The edge
@@ -438,7 +447,8 @@ def expander_plan(perms, degree, batch_device=None, virt_nodes=0):
         if len(_EXPANDER_SHAPES) > 16:
             _EXPANDER_SHAPES.clear()
         _EXPANDER_SHAPES[key] = sh
-    if _expander_layout() == "banded" and int(sh["padded"][0]) <= 3968:
+    want_banded = (_expander_layout() == "banded") if banded is None else bool(banded)
+    if want_banded and int(sh["padded"][0]) <= 3968:
         return _expander_plan_banded(perms, d, V, sh, edge_list, E)
     if dev.type == "cuda":
         # two launches: inverse permutations, then the bit rows (csrc/da_graph.hip)
@@ -530,12 +540,6 @@ def _expander_plan_banded(perms, d, V, sh, edge_list, E):
         counts1 = torch.full((1,), n, dtype=torch.int64, device=dev)
         mask, _ = _pack_mask(counts1, torch.full((1,), padded, dtype=torch.int64, device=dev), None, uniform_bool=adj[None])
         cls, stride = block_classes(adj, padded)
-        import os
-        dbg = os.environ.get("DA_EXPANDER_CLS_DEBUG")          # TIMING experiments only (wrong results): every block "full" / "partial"
-        if dbg in ("full", "partial"):
-            nb_ = padded // 32
-            rows = cls[: nb_ * stride].view(nb_, stride)
-            rows[:, :nb_] = torch.where(rows[:, :nb_] > 0, torch.full_like(rows[:, :nb_], 2 if dbg == "full" else 1), rows[:, :nb_])
         band = dict(mask=mask, cls=cls, stride=stride)
         if len(_EXPANDER_BANDS) > 16:
             _EXPANDER_BANDS.clear()

@@ -281,9 +281,16 @@ class GNN_Diffusion(LightningModule):
             # the MFMA path only (da_denoiser_flags bit 3): without it (DA_DISABLE_MFMA=1) guidance takes the per-step path below,
             # which runs the second pass through forward_with_feats on zero features
             if cfg_w is None or (int(eng.flags) & 8):
-                traj, _ = eng.sample_loop(plan, self._schedule(), img, patch_feats, ratio=self.inference_ratio,
-                                          mean_type=self._mean_type(), keep_trajectory=True,
-                                          use_graph=self.use_hip_graph, sampler=self.sampling, eta=float(self.eta), cfg_w=cfg_w)
+                try:
+                    traj, _ = eng.sample_loop(plan, self._schedule(), img, patch_feats, ratio=self.inference_ratio,
+                                              mean_type=self._mean_type(), keep_trajectory=True,
+                                              use_graph=self.use_hip_graph, sampler=self.sampling, eta=float(self.eta), cfg_w=cfg_w)
+                except _lib.DaError as e:
+                    # second line of defence behind flag bit 3 (which mirrors launch_gemm_mfma's shape conditions): only the
+                    # library's own "hoisted path not available" refusal falls back to the per-step guidance path
+                    if cfg_w is None or "unconditional pass" not in str(e):
+                        raise
+                    traj = None
             if traj is not None:
                 self.model._release_dense_plan_key()          # do not pin this Batch's edge list until the next one is planned
                 return list(traj.clone().unbind(0)), [None] * len(its)
@@ -312,9 +319,9 @@ class GNN_Diffusion(LightningModule):
     def configure_optimizers(self):
         """spatial_diffusion.py:701-705: Adafactor with transformers' defaults.  On a ROCm device the denoiser's update
         runs as one library call over the training engine's flat buffers (``FusedAdafactor`` -> da_adafactor_step); with
-        a piece encoder attached its parameters keep transformers' implementation (``HybridAdafactor``).  Set
-        DIFFASSEMBLE_FUSED_OPTIMIZER=0 for transformers' own implementation throughout."""
-        fused = os.environ.get("DIFFASSEMBLE_FUSED_OPTIMIZER", "1") != "0"
+        a piece encoder attached its parameters keep transformers' implementation (``HybridAdafactor``).  Set the class / instance
+        attribute ``fused_optimizer = False`` for transformers' own implementation throughout."""
+        fused = bool(getattr(self, "fused_optimizer", True))
         if fused and self.device.type == "cuda" and getattr(self.model, "visual_backbone", None) is None:
             from ..train import FusedAdafactor
             return FusedAdafactor(self.parameters(), self.model.train_engine(self.device))

@@ -71,7 +71,9 @@ class TrainEngine:
         self.total = (off + 63) // 64 * 64
         # data-parallel buckets, in the order backward completes them: EARLY = [early_off, total) = convs 1 .. L-1 and final_mlp
         # (final once da_train_backward_stage(EARLY) has run), LATE = [0, early_off) = embeddings, mlp, virtual nodes, conv 0
-        self.early_off = offs[names.index("gnn_backbone.module_list.1.lin_query.weight")]
+        # (a one-layer backbone has no conv 1: its early bucket is final_mlp alone, which is what the library's stage cut leaves final)
+        early_name = "gnn_backbone.module_list.1.lin_query.weight" if self.n_layers > 1 else "final_mlp.0.weight"
+        self.early_off = offs[names.index(early_name)]
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.views, self.grad_views = [], []
@@ -102,8 +104,8 @@ class TrainEngine:
         self.version = 0              # bumped by every raw-pointer update of ``flat`` (FusedAdafactor.step)
         self.grads_synced = False     # True between sync_gradients() and the next backward
         # bucketed exchange (Lightning DDP's reducer overlaps its buckets with backward, train_script.py:215-218): on by default
-        # whenever a gradient exchange is active; DIFFASSEMBLE_OVERLAP_ALLREDUCE=0 = one serial all-reduce after backward
-        self.overlap_exchange = os.environ.get("DIFFASSEMBLE_OVERLAP_ALLREDUCE", "1") != "0"
+        # whenever a gradient exchange is active; ``overlap_exchange = False`` = one serial all-reduce after backward
+        self.overlap_exchange = True
         self._side = None             # side stream of the early bucket's all-reduce
         self._early_pending = False   # the early bucket is being / has been averaged on the side stream since the last sync
 
@@ -173,14 +175,39 @@ class TrainEngine:
         assign, ...): the caller rebuilds the engine."""
         return all(p.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
 
-    @staticmethod
-    def _cg(plan: GraphPlan):
+    pair_cap_mb = 8192          # fp32 hybrid training: largest pair-matrix allocation before the edge-list kernels are preferred
+
+    def _edge_list_route(self, plan: GraphPlan):
+        """True: this plan trains on the edge-list (CSR) kernels although it carries a hybrid split.  The hybrid thresholds of
+        ``graph_plan._hybrid_worth_it`` (32 nodes, 1 % density) were measured on inference steps; the fp32 training route of a hybrid
+        plan allocates [n, n] pair matrices per head and layer (+ dP), which was only ever measured to pay from 256-node graphs at
+        3 % density up (round 4) -- below that, or beyond ``pair_cap_mb`` (attribute, default 8192 MB) of pair matrices, fp32 training keeps
+        the edge-list kernels.  The bf16-operand mode runs hybrid graphs flash-style (no pair matrix): it always takes them."""
+        if _lib.config().train_attn == 0:          # da_config.train_attn (DA_TRAIN_ATTN=0): edge-list kernels only
+            return True
+        from .graph_plan import _hybrid_mode
+        if not plan.hybrid or plan.dense or self.precision == "bf16" or _hybrid_mode() == "force":      # (force: the caller asked for the hybrid kernels)
+            return False
+        n = int(plan.max_graph_nodes)
+        density = plan.n_edges / max(1.0, float(plan.n_graphs) * n * n)
+        pair_mb = (self.n_layers + 1) * 8 * float(plan.n_graphs) * n * ((n + 63) // 64 * 64) * 4 / 2**20
+        return n < 256 or density < 0.03 or pair_mb > float(self.pair_cap_mb)
+
+    def _cg(self, plan: GraphPlan):
         """da_graph of a training plan: complete and hybrid graphs run on the grouped-GEMM attention (da_train_dense.hip) and
-        never walk the full edge list, so its CSR is not built for them (unless DA_TRAIN_DISABLE_DENSE=1 forces the edge-list
-        kernels); hybrid plans carry the by-source orientation of their REMAINDER edges in out_ptr / out_dst."""
-        import os
-        need_csr = not (plan.dense or plan.hybrid) or os.environ.get("DA_TRAIN_DISABLE_DENSE") == "1"
-        return plan.c_struct(need_csr, inference_hints=False)
+        never walk the full edge list, so its CSR is not built for them (unless ``_edge_list_route`` says so); hybrid plans carry
+        the by-source orientation of their REMAINDER edges in out_ptr / out_dst.  A hybrid plan in the banded slot layout (the
+        inference default of ``expander_plan``) cannot be trained on -- the hybrid training kernels index the adjacency by node --
+        so it is refused HERE with advice that can be followed."""
+        edge_list = self._edge_list_route(plan)
+        if plan.hybrid and plan.slot_node is not None and not edge_list:
+            raise _lib.DaError("training on a hybrid plan in the banded slot layout: build the training plan with "
+                               "expander_plan(..., banded=False) (or DA_EXPANDER_LAYOUT=natural), or from the edge list with build_plan")
+        g = plan.c_struct(edge_list or not (plan.dense or plan.hybrid), inference_hints=False)
+        if edge_list and plan.hybrid:
+            g.hybrid = 0               # the library then takes the CSR route (da_train.hip dims_of)
+            g.slot_node = None
+        return g
 
     def _workspace(self, plan: GraphPlan, mma=None):
         g = self._cg(plan)
@@ -213,9 +240,15 @@ class TrainEngine:
 
     def backward(self, plan: GraphPlan, x, t, d_out, want_dfeats=False):
         """da_train_backward: adds every parameter gradient into ``flat_grad`` (and attaches the views
-        as ``.grad``); returns d_feats [n_real, F] or None."""
+        as ``.grad``); returns d_feats [n_real, F] or None.
+
+        COLLECTIVE under the bucketed exchange: with an initialised multi-rank process group and ``overlap_exchange`` (the
+        default), this call issues the early bucket's all-reduce on the side stream -- every rank must then run the SAME number
+        of backward passes between two ``sync_gradients`` calls (what DDP's reducer requires as well).  A caller whose ranks
+        run different numbers of passes sets ``engine.overlap_exchange = False`` : backward
+        is then local and only ``sync_gradients`` communicates.  (A one-rank ``nccl`` group still executes the call -- it cannot deadlock.)"""
         from .sharding import exchange_active
-        plan.with_source_csr()
+        plan.with_source_csr(self._edge_list_route(plan))
         self._join_side()             # (accumulation: the previous backward's early bucket must have landed before this one adds to it)
         attached = all(p.grad is not None and p.grad.data_ptr() == gv.data_ptr()
                        for p, gv in zip(self.params, self.grad_views))
@@ -445,7 +478,7 @@ class HybridAdafactor(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         """Accepts its own layout ({"fused", "rest"}) and a PLAIN transformers-Adafactor state dict over the same parameter
-        list (a run started with DIFFASSEMBLE_FUSED_OPTIMIZER=0, or the reference's own checkpoint): the entries are routed
+        list (a run with ``fused_optimizer = False``, or the reference's own checkpoint): the entries are routed
         to the fused / remaining halves by the parameter's index in ``Adafactor(self.parameters())`` order."""
         if "fused" in sd:
             self.fused.load_state_dict(sd["fused"])

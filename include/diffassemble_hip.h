@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DA_ABI_VERSION 18
+#define DA_ABI_VERSION 19
 
 enum { DA_PREC_F32 = 0, DA_PREC_BF16 = 1 };
 enum { DA_VARIANT_2D = 0, DA_VARIANT_3D = 1 };          /* Eff_GAT / Eff_GAT_3d            */
@@ -39,6 +39,39 @@ enum { DA_MAX_LAYERS = 8 };
 
 int da_abi_version(void);
 const char *da_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * The library's switches (ABI 19).  The reference has no equivalent (its knobs are Python
+ * kwargs); these replace what used to be ~70 getenv calls spread over the kernels' launchers.
+ * Every field is initialised ONCE per process from the environment variable named beside
+ * it, can be read / changed at run time (da_config_get / da_config_set: in-process A/B
+ * measurements, tests), and is consulted when a call is made -- a denoiser keeps the folds
+ * it was created with, a captured sampling-loop graph keeps the kernels it recorded.
+ * No other environment variable changes what the default build of the library does:
+ * A/B variants that lost, ablations and probes are compiled only into the EXPERIMENTS build
+ * (DA_EXPERIMENTS=1 python __graft_entry__.py; da_build_flags() bit 0), see INTEGRATION.md.
+ * ------------------------------------------------------------------------------------- */
+typedef struct da_config {
+    int32_t struct_bytes;        /* sizeof(da_config) as the caller compiled it (checked by da_config_set)          */
+    int32_t disable_mfma;        /* DA_DISABLE_MFMA=1: generic (non matrix-core) linear kernels                      */
+    int32_t disable_dense;       /* DA_DISABLE_DENSE=1: every attention walks the edge list (CSR kernels)            */
+    int32_t disable_folds;       /* DA_DISABLE_FOLDS=<bits>: 1 mlp.2 composed into its consumers, 2 folded last      */
+                                 /* layer, 4 softmax scale inside Wq, 8 DDIM update inside the head kernel,          */
+                                 /* 16 one-kernel tail, 32 virtual rows on a side stream (hybrid graphs)             */
+    int32_t attn_level;          /* DA_ATTN_LEVEL: 0 = the general dense kernel only, 1 = + the optimistic ring      */
+                                 /* kernels, 2 = + the K/V-resident hidden-layer kernel (default)                    */
+    int32_t xpanel;              /* DA_ENABLE_XPANEL: -1 = row-panel projections for Batches of >= 512-piece graphs  */
+                                 /* (default), 0 never, 1 always                                                     */
+    int32_t tail_next;           /* DA_TAIL_NEXT: -1 = next step's embedding inside the tail kernel for >= 512-piece */
+                                 /* graphs (default), 0 never, 1 always                                              */
+    int32_t pair_split;          /* DA_PAIR_SPLIT: 1 = the pair loop as two graphs on two streams (default), 0 = one */
+    int32_t train_attn;          /* DA_TRAIN_ATTN: 0 = edge-list kernels only, 1 = grouped-GEMM attention with pair  */
+                                 /* matrices, 2 = + flash-style hybrid kernels in the bf16-operand mode (default)    */
+    int32_t train_side_streams;  /* DA_TRAIN_SIDE_STREAMS bits: 1 weight-gradient products, 2 hybrid virtual rows    */
+} da_config;
+int da_config_get(da_config *out /* host */);
+int da_config_set(const da_config *in /* host */);
+int da_build_flags(void);        /* bit 0: EXPERIMENTS build                                                         */
 
 /* ---------------------------------------------------------------------------------------
  * Weights of one denoiser, fp32 device pointers in the reference's state-dict layout

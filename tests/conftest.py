@@ -17,3 +17,14 @@ def pytest_configure(config):
 def golden():
     import cases
     return cases.load_golden()
+
+
+EXP_LIB = os.path.join(ROOT, "diffassemble_amd", "lib_exp", "libdiffassemble_hip.so")
+
+
+def exp_env(**extra):
+    """Environment of a subprocess that runs on the EXPERIMENTS build of the library (DA_EXPERIMENTS=1 python __graft_entry__.py -> lib_exp/):
+    the only build that holds the A/B variants that lost and reads their DA_* switches.  Skips the calling test when that build is absent."""
+    if not os.path.exists(EXP_LIB):
+        pytest.skip("experiments build absent (DA_EXPERIMENTS=1 python __graft_entry__.py)")
+    return dict(os.environ, DA_LIB_PATH=EXP_LIB, **extra)

@@ -2,7 +2,7 @@
 with the head's whole K | V in LDS -- the default for Batches of large complete graphs (512 .. 1216 pieces), bf16, C = 32.
 Same TransformerConv attention as every other kernel (reference call sites backbones/Transformer_GNN.py:32,38): checked
 here against the fp64 PyG restatement of tests/test_gpu_softmax_fallbacks.py, against the ring kernel (k_attn_optt<32>,
-DA_ATTN_RES=0 in a subprocess) to one bf16 ulp on a handful of rounding ties and bit for bit everywhere else, and through its per-wave running-max fallback."""
+DA_ATTN_LEVEL=1 in a subprocess) to one bf16 ulp on a handful of rounding ties and bit for bit everywhere else, and through its per-wave running-max fallback."""
 import os
 import subprocess
 import sys
@@ -34,7 +34,7 @@ def _layer(dev, sizes, loops, kind, seed=0):
 
 
 def _resident_on():
-    return os.environ.get("DA_ATTN_RES", "1") != "0" and os.environ.get("DA_OPT_HID", "0") == "0" and os.environ.get("DA_ATTN_OPT", "1") != "0"
+    return int(os.environ.get("DA_ATTN_LEVEL", "2")) >= 2 and os.environ.get("DA_OPT_HID", "0") == "0"
 
 
 @pytest.mark.parametrize("loops", [True, False], ids=["self_loops", "no_diagonal"])
@@ -103,9 +103,9 @@ torch.save(outs, sys.argv[1])
 def test_resident_and_ring_kernels_agree_to_one_ulp_subprocess(dev, tmp_path):
     """Same blocks in the same order with the same instructions: the two kernels agree to the last bit on > 99.99 % of the outputs."""
     res = {}
-    for tag, val in (("ring", "0"), ("resident", "1")):
+    for tag, val in (("ring", "1"), ("resident", "2")):
         f = tmp_path / f"{tag}.pt"
-        env = dict(os.environ, DA_ATTN_RES=val)
+        env = dict(os.environ, DA_ATTN_LEVEL=val)
         env.pop("DA_OPT_HID", None)
         r = subprocess.run([sys.executable, "-c", _DUMP.format(root=ROOT, tests=os.path.join(ROOT, "tests")), str(f)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -121,8 +121,8 @@ def test_resident_and_ring_kernels_agree_to_one_ulp_subprocess(dev, tmp_path):
 
 
 def test_the_900_piece_fallback_suite_on_the_ring_kernel_subprocess():
-    """DA_ATTN_RES=0: the ring kernel keeps its 900-piece coverage (it still serves every Batch the resident kernel declines)."""
-    env = dict(os.environ, DA_ATTN_RES="0")
+    """DA_ATTN_LEVEL=1: the ring kernel keeps its 900-piece coverage (it still serves every Batch the resident kernel declines)."""
+    env = dict(os.environ, DA_ATTN_LEVEL="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_softmax_fallbacks.py"),
                         "-k", "900_pieces and c32 and bf16"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -152,6 +152,7 @@ print("launches-checked")
 def test_small_graph_instance_subprocess(dev, mode):
     """DA_ATTN_RES_SMALL=1 / 2 (opt-in): the five-wave instance for 129 .. 160-piece graphs -- one workgroup per (graph, head) of a 12 x 12
     puzzle -- against the fp64 PyG formula, with and without self loops, through its per-wave fallback."""
-    env = dict(os.environ, DA_ATTN_RES_SMALL=mode)
+    from conftest import exp_env
+    env = exp_env(DA_ATTN_RES_SMALL=mode)
     r = subprocess.run([sys.executable, "-c", _SMALL.format(root=ROOT, tests=os.path.join(ROOT, "tests"))], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "launches-checked" in r.stdout, r.stderr[-3000:]

@@ -1,6 +1,6 @@
 """``python bench.py --gpus N`` the way the driver calls it (no launcher around it): the script starts its own N ranks
 (the reference's Trainer spawns its own too, train_script.py:215-218).  On a 1-GPU box the ranks share cuda:0 over gloo
-(BENCH_DIST_BACKEND=gloo; the numbers of such a run mean nothing, the code path is what is checked)."""
+(--dist-backend gloo; the numbers of such a run mean nothing, the code path is what is checked)."""
 import json
 import os
 import subprocess
@@ -12,10 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(*argv, timeout=900):
-    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv, "--dist-backend", "gloo"], env=env, capture_output=True, text=True,
                        cwd=ROOT, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -46,7 +46,7 @@ def test_bench_gpus_n_without_enough_gpus_says_so():
     import torch
     if torch.cuda.device_count() >= 2:
         pytest.skip("enough GPUs here")
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_DIST_BACKEND")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
                        capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert r.returncode != 0

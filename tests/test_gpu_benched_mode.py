@@ -112,7 +112,8 @@ def test_rot900_with_the_dual_slab_last_layer_kernel_subprocess(dev):
     """DA_ATTN_DUAL=1 (read once per process): the folded last layer through k_attn_dual (two query slabs per wave, generated
     asm regions, persistent workgroups; opt-in since the end of round 3) on the 900-piece fixture, its DDIM trajectory and
     the 64-puzzle determinism check."""
-    env = dict(os.environ, DA_ATTN_DUAL="1")
+    from conftest import exp_env
+    env = exp_env(DA_ATTN_DUAL="1")
     root = os.path.dirname(os.path.dirname(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
                         "test_rot900_dense_forward_vs_reference_fixture or test_rot900_ddim_trajectory_vs_reference_fixture"],
@@ -125,7 +126,7 @@ def test_rot900_with_the_dual_slab_last_layer_kernel_subprocess(dev):
 
 def test_rot900_with_folds_off_subprocess(dev):
     """The layer-by-layer path (no algebraic folds) on the 900-piece fixture."""
-    env = dict(os.environ, DA_DISABLE_MLP2_FUSION="1", DA_DISABLE_LAST_FOLD="1")
+    env = dict(os.environ, DA_DISABLE_FOLDS="3")          # da_config.disable_folds: 1 mlp.2 composition + 2 folded last layer
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_rot900_dense_forward_vs_reference_fixture"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -471,7 +472,8 @@ def test_new_patch_feats_same_address_are_restaged_in_the_step_by_step_path(dev)
 def test_packed_inference_weights_follow_the_optimizer(dev, monkeypatch, fused):
     """engine() -> optimizer step -> engine(): the second inference must run on the UPDATED weights (the fused
     Adafactor writes the flat parameter buffer through a raw pointer, which bumps no tensor version)."""
-    monkeypatch.setenv("DIFFASSEMBLE_FUSED_OPTIMIZER", "1" if fused else "0")
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion as _G
+    monkeypatch.setattr(_G, "fused_optimizer", fused, raising=False)
     spec = C.by_name("k36_loop_sharp")
     case = C.build_case(spec)
     from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType
@@ -700,7 +702,7 @@ def test_two_branch_loop_equals_one_branch(dev, monkeypatch, prec, sizes, loops)
     _, one = eng.sample_loop(plan, sch, xd, fd, **kw)
     one = one.clone()
     monkeypatch.setenv("DA_TWO_BRANCH", "1")
-    monkeypatch.setenv("DA_TWO_BRANCH_MIN_GRAPHS", "2")
+    monkeypatch.setattr(eng, "two_branch_min_graphs", 2, raising=False)
     assert eng._two_branch(plan, False, True)
     _, two = eng.sample_loop(plan, sch, xd, fd, **kw)
     assert torch.equal(two, one)
@@ -724,12 +726,12 @@ def test_two_branch_loop_equals_one_branch(dev, monkeypatch, prec, sizes, loops)
     assert t2.shape == t1.shape and torch.equal(t2, t1) and torch.equal(f2, f1) and torch.equal(t2[-1], f2)
     # eager loops and small Batches keep the one-branch path
     assert not eng._two_branch(plan, False, False)
-    monkeypatch.setenv("DA_TWO_BRANCH_MIN_GRAPHS", "64")
+    monkeypatch.setattr(eng, "two_branch_min_graphs", 64, raising=False)
     assert not eng._two_branch(plan, False, True)
     # default ("auto"): by node count
     monkeypatch.delenv("DA_TWO_BRANCH")
     assert not eng._two_branch(plan, False, True)
-    monkeypatch.setenv("DA_TWO_BRANCH_MIN_NODES", "10")
+    monkeypatch.setattr(eng, "two_branch_min_nodes", 10, raising=False)
     assert eng._two_branch(plan, False, True) and eng._two_branch(plan, True, True)
 
 
@@ -765,7 +767,7 @@ def test_two_branch_loop_with_the_other_samplers_equals_one_branch(dev, monkeypa
         t1, f1 = eng.sample_loop(plan, sch, xd, fd, noise=noise, **kw)
         t1, f1 = t1.clone(), f1.clone()
         monkeypatch.setenv("DA_TWO_BRANCH", "1")
-        monkeypatch.setenv("DA_TWO_BRANCH_MIN_GRAPHS", "2")
+        monkeypatch.setattr(eng, "two_branch_min_graphs", 2, raising=False)
         assert eng._two_branch(plan, True, True)
         t2, f2 = eng.sample_loop(plan, sch, xd, fd, noise=noise, **kw)
         assert torch.isfinite(f2).all() and torch.equal(t2, t1) and torch.equal(f2, f1)
@@ -798,7 +800,7 @@ torch.save({"out": out.cpu(), "xf": xf.cpu()}, sys.argv[2])
 @pytest.mark.parametrize("sizes", ["900", "33,64,31,100,1", ",".join(["144"] * 255 + ["150"])], ids=["900", "ragged", "36870_rows"])
 def test_tail_fused_kernel_vs_three_kernel_tail(dev, tmp_path, sizes):
     """k_tail_fused (the folded tail as one MFMA kernel, the bf16 default) against the three-kernel tail it replaces
-    (DA_TAIL_FUSED=0, read once per process -> two subprocesses): one forward and a 10-step DDIM loop whose update the
+    (DA_DISABLE_FOLDS=16, read once per process -> two subprocesses): one forward and a 10-step DDIM loop whose update the
     kernel applies itself; row counts that are not multiples of the 32-row slab, and more than 32 768 rows (two slabs per
     wave, the shape of the benched Batches).  The two paths differ only in where the
     32-wide pre-activation is rounded to bf16 (the fused kernel keeps it in fp32), so they agree far inside the bf16
@@ -807,7 +809,7 @@ def test_tail_fused_kernel_vs_three_kernel_tail(dev, tmp_path, sizes):
     res = {}
     for flag in ("1", "0"):
         path = str(tmp_path / f"tail_{flag}.pt")
-        env = dict(os.environ, DA_TAIL_FUSED=flag)
+        env = dict(os.environ, DA_DISABLE_FOLDS="0" if flag == "1" else "16")
         r = subprocess.run([sys.executable, "-c", _TAIL_SCRIPT, root, path, sizes], env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         res[flag] = torch.load(path)

@@ -304,7 +304,7 @@ def test_full_size_properties(dev):
 
 
 def test_hybrid_adafactor_resumes_from_a_plain_adafactor_checkpoint(dev):
-    """a run started with DIFFASSEMBLE_FUSED_OPTIMIZER=0 (transformers' Adafactor over self.parameters(), what
+    """a run started with ``fused_optimizer = False`` (transformers' Adafactor over self.parameters(), what
     the reference's checkpoints hold) must be resumable with the fused / hybrid optimizer: same parameter order, same
     per-parameter state layout.  One step each from the same loaded statistics gives the same weights."""
     import copy

@@ -207,7 +207,8 @@ def test_attn_two_slab_opt_in_subprocess(dev):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DA_ATTN2="1")
+    from conftest import exp_env
+    env = exp_env(DA_ATTN2="1")
     env.pop("DA_CONV_FUSED", None)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_attn_two_slab_kernel"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
@@ -220,7 +221,8 @@ def test_conv_fused_opt_in_subprocess(dev):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DA_CONV_FUSED="1")
+    from conftest import exp_env
+    env = exp_env(DA_CONV_FUSED="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_conv_fused_one_kernel_hidden_layer"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0 and "16 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
@@ -525,7 +527,8 @@ def test_w_in_registers_register_direct_epilogue_subprocess(dev):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DA_WREG_DIRECT="1")
+    from conftest import exp_env
+    env = exp_env(DA_WREG_DIRECT="1", DA_ENABLE_XPANEL="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "w_in_registers and not subprocess"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
@@ -760,12 +763,12 @@ def test_algebraic_folds_can_be_switched_off_subprocess(dev):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DA_DISABLE_MLP2_FUSION="1", DA_DISABLE_LAST_FOLD="1")
+    env = dict(os.environ, DA_DISABLE_FOLDS="3")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
                         "test_forward_2d_fp32_vs_oracle_and_golden or test_forward_2d_bf16 or test_ddim_loop_vs_reference_trajectory"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    env2 = dict(os.environ, DA_DISABLE_LAST_FOLD="1")
+    env2 = dict(os.environ, DA_DISABLE_FOLDS="2")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_forward_2d_fp32_vs_oracle_and_golden"],
                        env=env2, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -22,7 +22,7 @@ def _port():
 
 
 def _env():
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_DIST_BACKEND")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return env
 

@@ -327,7 +327,8 @@ def test_logit_offsets_hybrid_graphs_masked_optimistic_kernel(dev, C, folded, ki
 def test_force_gen_switch_runs_the_fixture_suite_through_the_fallbacks_subprocess():
     """DA_ATTN_FORCE_GEN=1 starts every shift-free kernel in its running-max mode: the reference-fixture forwards (bf16 and
     fp32, 900 pieces included) must still match."""
-    env = dict(os.environ, DA_ATTN_FORCE_GEN="1")
+    from conftest import exp_env
+    env = exp_env(DA_ATTN_FORCE_GEN="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_gpu_parity.py"),
                         os.path.join(root, "tests", "test_gpu_benched_mode.py"), "-k",
@@ -340,7 +341,8 @@ def test_force_gen_switch_runs_the_fixture_suite_through_the_fallbacks_subproces
 def test_dual_slab_kernel_fallbacks_subprocess():
     """k_attn_dual (opt-in, DA_ATTN_DUAL=1) takes the folded bf16 last layer: the same offset cases through ITS per-region
     range test and GEN hand-off."""
-    env = dict(os.environ, DA_ATTN_DUAL="1", DA_TEST_EXPECT_DUAL="1")
+    from conftest import exp_env
+    env = exp_env(DA_ATTN_DUAL="1", DA_TEST_EXPECT_DUAL="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-k",
                         "bf16 and c144_folded and (ragged_batch or 900_pieces or without_self_loops)"],

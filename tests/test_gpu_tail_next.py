@@ -1,6 +1,6 @@
 """The next step's embedding + mlp.0 inside the tail kernel of a plain DDIM loop (k_tail_fused<true>, DdimFuse::nx_*,
 da_basic.hip / da_api.hip enqueue_loop): per-row work of efficient_gat.py:131-135 that used to be two launches per step.
-DA_TAIL_NEXT=1 / 0 forces it; unset, DA_STEP_AUTO's rule takes it for Batches of >= 512-piece graphs (last test of this file).  The loop with the fusion must reproduce the loop without it
+DA_TAIL_NEXT=1 / 0 forces it; unset (da_config.tail_next = -1) the large-graph step rule takes it for Batches of >= 512-piece graphs (last test of this file).  The loop with the fusion must reproduce the loop without it
 (subprocesses: the switch is read once) far inside the bf16 mode's own distance to the fp32 engine, and the first step (whose h
 still comes from the two launches) bit for bit."""
 import os
@@ -89,16 +89,16 @@ torch.save(out, sys.argv[1])
 
 
 def test_step_auto_rule_selects_by_graph_size_subprocess(tmp_path):
-    """DA_STEP_AUTO (default 1; da_gemm_xpanel.hip step_auto_default, da_api.hip enqueue_loop / forward_impl): with neither switch set, Batches
+    """The large-graph step rule (da_config.xpanel = tail_next = -1; da_gemm_xpanel.hip xpanel_mode, da_api.hip enqueue_loop / forward_impl): with neither switch set, Batches
     whose largest graph has >= 512 pieces take the row-panel projections AND the tail kernel's next-step embedding -- bit for bit what
-    DA_ENABLE_XPANEL=1 DA_TAIL_NEXT=1 gives -- and smaller graphs take neither (bit for bit DA_STEP_AUTO=0).  The 900-piece loops with and
+    DA_ENABLE_XPANEL=1 DA_TAIL_NEXT=1 gives -- and smaller graphs take neither (bit for bit both switches 0).  The 900-piece loops with and
     without the rule agree in their first step exactly and afterwards far inside bf16 resolution of the poses."""
     if not torch.cuda.is_available():
         pytest.skip("needs a ROCm GPU")
     res = {}
-    for tag, extra in (("default", {}), ("both_on", {"DA_ENABLE_XPANEL": "1", "DA_TAIL_NEXT": "1"}), ("rule_off", {"DA_STEP_AUTO": "0"})):
+    for tag, extra in (("default", {}), ("both_on", {"DA_ENABLE_XPANEL": "1", "DA_TAIL_NEXT": "1"}), ("rule_off", {"DA_ENABLE_XPANEL": "0", "DA_TAIL_NEXT": "0"})):
         f = tmp_path / f"{tag}.pt"
-        env = {k: v for k, v in os.environ.items() if k not in ("DA_ENABLE_XPANEL", "DA_TAIL_NEXT", "DA_STEP_AUTO")}
+        env = {k: v for k, v in os.environ.items() if k not in ("DA_ENABLE_XPANEL", "DA_TAIL_NEXT")}
         env.update(extra)
         r = subprocess.run([sys.executable, "-c", _RUN_AUTO.format(root=ROOT), str(f)], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]

@@ -473,13 +473,13 @@ def test_fused_adafactor_matches_transformers(dev):
 
 
 def test_csr_training_path_on_complete_graphs_subprocess():
-    """Complete graphs take the grouped-GEMM (MFMA) attention in training; DA_TRAIN_DISABLE_DENSE=1 forces
+    """Complete graphs take the grouped-GEMM (MFMA) attention in training; DA_TRAIN_ATTN=0 forces
     them through the CSR kernels instead -- both must match the oracle (the switch is read once per
     process, hence the subprocess)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DA_TRAIN_DISABLE_DENSE="1")
+    env = dict(os.environ, DA_TRAIN_ATTN="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
                         "test_backward_matches_oracle_autograd and (rot144_g2_sharp or k36_noloop_eps or ragged_dense)"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
@@ -505,14 +505,14 @@ def test_hybrid_training_path_forced_on_small_graphs_subprocess():
 
 
 def test_hybrid_plan_on_the_edge_list_switch_subprocess():
-    """DA_TRAIN_DISABLE_DENSE=1 (the documented debugging switch) on HYBRID plans: the library then
+    """DA_TRAIN_ATTN=0 (da_config.train_attn, the documented debugging switch) on HYBRID plans: the library then
     walks the full edge list in the backward, so the plan's by-source CSR must hold EVERY edge, not just the remainder
     (round-3 advisor finding: dK / dV silently lost every regular edge).  Same fixture cases as the hybrid test, with the
     plans still forced hybrid, against the oracle's autograd."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DA_HYBRID="force", DA_TRAIN_DISABLE_DENSE="1")
+    env = dict(os.environ, DA_HYBRID="force", DA_TRAIN_ATTN="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
                         "test_backward_matches_oracle_autograd and (exo144_v8_g2 or exo_expander_d6 or tr_expander_d7)"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
@@ -582,7 +582,7 @@ torch.save({"loss": float(loss), "grad": te.flat_grad.cpu(), "ws_bytes": int(te.
 @pytest.mark.parametrize("sides", [[30], [16, 20, 6, 18]], ids=["one_900", "ragged"])
 def test_flash_style_hybrid_training_equals_the_pair_matrix_route(dev, tmp_path, sides):
     """bf16-operand mode on hybrid (Exphander + exophormer) graphs: the flash-style kernels (k_hyb_fwd / _bwd_q / _bwd_kv, no
-    [n, n] tensor) against the route that keeps the masked pair matrices (DA_HYB_FLASH=0: same operand roundings, so the two
+    [n, n] tensor) against the route that keeps the masked pair matrices (DA_TRAIN_ATTN=1: same operand roundings, so the two
     agree far inside the bf16-mode tolerance) and against the exact fp32 step (the 6e-2 / cosine bound of the bf16 mode)."""
     import json
     import os
@@ -590,7 +590,7 @@ def test_flash_style_hybrid_training_equals_the_pair_matrix_route(dev, tmp_path,
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env in (("flash", dict(FLASH_PREC="bf16")), ("pairs", dict(FLASH_PREC="bf16", DA_HYB_FLASH="0")), ("fp32", dict(FLASH_PREC="fp32"))):
+    for tag, env in (("flash", dict(FLASH_PREC="bf16")), ("pairs", dict(FLASH_PREC="bf16", DA_TRAIN_ATTN="1")), ("fp32", dict(FLASH_PREC="fp32"))):
         out = str(tmp_path / f"{tag}.pt")
         e = dict(os.environ, DA_ROOT=ROOT, FLASH_SIDES=json.dumps(sides), FLASH_OUT=out, **env)
         r = subprocess.run([sys.executable, "-c", _FLASH_WORKER], env=e, capture_output=True, text=True, timeout=900)
@@ -654,7 +654,7 @@ def test_side_stream_weight_gradients_are_bit_identical(dev, tmp_path, arch, pre
     """Round 5: the dW / db products of the backward and the forward's weight images run on a side stream of the library
     (SideDw, da_train.hip) beside the dX / attention-backward chain, and on hybrid graphs in the bf16 mode the virtual rows' whole
     chain runs beside the real rows' flash kernels (HybSide, da_train_dense.hip).  Same kernels, same operands, same summation orders --
-    the accumulated gradients of two backward passes must equal the one-stream schedule's (DA_TRAIN_SIDE_DW=0 DA_HYB_SIDE=0, read once per
+    the accumulated gradients of two backward passes must equal the one-stream schedule's (DA_TRAIN_SIDE_STREAMS=0, read once per
     process: hence the subprocesses) BIT FOR BIT, on complete and on hybrid graphs, in both precisions, with the backward
     in one call and in its two stages."""
     import os
@@ -662,7 +662,7 @@ def test_side_stream_weight_gradients_are_bit_identical(dev, tmp_path, arch, pre
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env in (("side", {}), ("one", dict(DA_TRAIN_SIDE_DW="0", DA_HYB_SIDE="0"))):
+    for tag, env in (("side", {}), ("one", dict(DA_TRAIN_SIDE_STREAMS="0"))):
         out = str(tmp_path / f"{tag}.pt")
         e = dict(os.environ, DA_ROOT=ROOT, SIDE_ARCH=arch, SIDE_PREC=prec, SIDE_STAGED=staged, SIDE_OUT=out, **env)
         r = subprocess.run([sys.executable, "-c", _SIDE_WORKER], env=e, capture_output=True, text=True, timeout=900)
@@ -687,7 +687,7 @@ def _dp_train_worker(rank, world, port, ret):
     called on even steps and left to ``FusedAdafactor.step`` on odd ones -- both routes must all-reduce exactly once."""
     import os
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DIFFASSEMBLE_FUSED_OPTIMIZER="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
@@ -829,7 +829,7 @@ class _StepWrapper(torch.nn.Module):
 def _ddp_wrapper_worker(rank, world, port, find_unused, ret):
     import os
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DIFFASSEMBLE_FUSED_OPTIMIZER="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
     here = os.path.dirname(os.path.abspath(__file__))

@@ -54,7 +54,7 @@ static std::vector<bf16_t> grab(const Proj &p) {
     if (p.sn) CK(hipMemcpy(h.data() + 2 * p.qn + p.vn, p.s, p.sn * 2, hipMemcpyDeviceToHost));
     return h;
 }
-static void wipe(const Proj &p) { CK(hipMemset(p.q, 0xff, p.qn * 2)); CK(hipMemset(p.k, 0xff, p.qn * 2)); CK(hipMemset(p.v, 0xff, p.vn * 2)); if (p.sn) CK(hipMemset(p.s, 0xff, p.sn * 2)); }
+static void wipe(const Proj &p) { CK(hipDeviceSynchronize()); CK(hipMemset(p.q, 0xff, p.qn * 2)); CK(hipMemset(p.k, 0xff, p.qn * 2)); CK(hipMemset(p.v, 0xff, p.vn * 2)); if (p.sn) CK(hipMemset(p.s, 0xff, p.sn * 2)); CK(hipDeviceSynchronize()); }   // (the kernels run on non-blocking streams: the memsets of the null stream must have landed)
 
 int main(int argc, char **argv) {
     const int G = argc > 1 ? atoi(argv[1]) : 32, n = argc > 2 ? atoi(argv[2]) : 900, iters = argc > 3 ? atoi(argv[3]) : 200;
@@ -73,6 +73,22 @@ int main(int argc, char **argv) {
         size_t diff = 0, untouched = 0;
         for (size_t e = 0; e < ref.size(); ++e) { diff += ref[e] != got[e]; untouched += (got[e] == 0xffff && ref[e] == 0xffff); }
         printf("bit-identity %-18s: %zu of %zu elements differ (%zu padded slots untouched by both)\n", names[i], diff, ref.size(), untouched);
+        if (diff) {          // where: block (Q / K / V / skip), head, slot, column; how far apart
+            const Proj &p = shapes[i]; size_t shown = 0, blk[4] = {0, 0, 0, 0}, unwritten = 0; double maxd = 0;
+            std::vector<size_t> percol(160, 0);
+            for (size_t e = 0; e < ref.size(); ++e) {
+                if (ref[e] == got[e]) continue;
+                const int b = e < p.qn ? 0 : (e < 2 * p.qn ? 1 : (e < 2 * p.qn + p.vn ? 2 : 3));
+                const size_t o = e - (b == 0 ? 0 : (b == 1 ? p.qn : (b == 2 ? 2 * p.qn : 2 * p.qn + p.vn)));
+                const int cw = b == 2 && p.Cv > 0 ? p.Cv : (b == 3 ? p.HC : p.C);
+                ++blk[b]; ++percol[(o % cw) % 160]; unwritten += got[e] == 0xffff;
+                maxd = fmax(maxd, fabs((double)da::bf2f(ref[e]) - da::bf2f(got[e])));
+                if (shown++ < 6) printf("    block %d head/row %zu col %zu: ref %.5f thin %.5f (raw %04x %04x)\n", b, o / cw, o % cw, da::bf2f(ref[e]), da::bf2f(got[e]), ref[e], got[e]);
+            }
+            printf("    per block Q %zu K %zu V %zu S %zu; left unwritten by thin %zu; max |diff| %.4g; per column-in-head:", blk[0], blk[1], blk[2], blk[3], unwritten, maxd);
+            for (int c = 0; c < (p.C > 32 ? p.C : 32); ++c) printf(" %zu", percol[c]);
+            printf("\n");
+        }
     }
     // ---- 2. attention inputs (a SECOND half Batch: its own Q / K / V / skip / out)
     std::vector<bf16_t> hq((size_t)H * n_pad * C), hk(hq.size()), hv(hq.size()), hs((size_t)N * H * C);

@@ -6,7 +6,7 @@ Reads the AMDGPU metadata notes of the gfx950 code objects embedded in each `dif
   * the spill audit of the default build (0 kernels with vgpr_spill_count > 0),
   * sizing co-resident kernels (what a CU has left beside one workgroup of kernel X).
 
-    python tools/kernel_resources.py [--spills] [--match REGEX] [--json OUT]
+    python tools/kernel_resources.py [--spills | --vgpr-spills] [--match REGEX] [--json OUT] [--libdir DIR]
 """
 import argparse, glob, json, os, re, subprocess, sys, tempfile
 
@@ -54,6 +54,7 @@ def kernels_of(obj, tmp):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--spills", action="store_true", help="only kernels that spill; exit 1 if any")
+    ap.add_argument("--vgpr-spills", action="store_true", help="only kernels that spill VECTOR registers (to scratch memory); exit 1 if any")
     ap.add_argument("--match", default=None)
     ap.add_argument("--json", default=None)
     ap.add_argument("--libdir", default=os.path.join(ROOT, "diffassemble_amd", "lib"))
@@ -66,6 +67,8 @@ def main():
         rows = [r for r in rows if re.search(a.match, r["demangled"])]
     if a.spills:
         rows = [r for r in rows if r.get("vgpr_spill_count", 0) or r.get("sgpr_spill_count", 0)]
+    if a.vgpr_spills:
+        rows = [r for r in rows if r.get("vgpr_spill_count", 0)]
     print(f"{'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'vspill':>6} {'sspill':>6} {'lds':>7} {'scratch':>7} {'wg':>5}  kernel")
     for r in rows:
         print(f"{r.get('vgpr_count',0):5d} {r['agpr']:5d} {r.get('sgpr_count',0):5d} {r.get('vgpr_spill_count',0):6d} "
@@ -74,7 +77,7 @@ def main():
     print(f"{len(rows)} kernels")
     if a.json:
         json.dump(rows, open(a.json, "w"), indent=1)
-    if a.spills and rows:
+    if (a.spills or a.vgpr_spills) and rows:
         sys.exit(1)
 
 
