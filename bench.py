@@ -864,6 +864,41 @@ def sample_bench(args, world, rank, dev):
               "ms_per_step_min": min(passes) / K * 1e3, "ms_per_step_max": max(passes) / K * 1e3,
               "ms_per_step_first": dt_first / K * 1e3}
 
+    # Batches that cannot be SPLIT into two branches (exophormer: the virtual-node edges couple a Batch's puzzles) get the two-stream
+    # overlap with TWO independent Batches in flight (DenoiserEngine.sample_loop_batches; each Batch bit for bit what it computes alone)
+    in_flight = None
+    if plan.hybrid and not eng._two_branch(plan, False, True) and _lib.config().pair_split:
+        perms2 = expander_perms(cfg, G, 103 + rank).to(dev)
+        plan2 = eng.plan_expander(perms2, args.degree)
+        gen2 = torch.Generator(device=dev).manual_seed(4321 + rank)
+        feats2 = torch.randn(feats.shape, generator=gen2, device=dev)
+        x_T2 = torch.randn(x_T.shape, generator=gen2, device=dev)
+
+        def run2(n_iters, restage=False):
+            return eng.sample_loop_batches([plan, plan2], sch, [x_T, x_T2], [feats, feats2], ratio=cfg["ratio"], mean_type=mt, max_iters=n_iters, restage=restage)
+
+        run2(chunks[0], restage=True)
+        for ck in sorted(set(chunks)):
+            run2(ck)
+        p2 = []
+        for _ in range(1 + min(max(args.replays, 0), 10)):
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for ck in chunks:
+                xa2, xb2 = run2(ck)
+            torch.cuda.synchronize()
+            barrier()
+            p2.append(time.perf_counter() - t0)
+        assert torch.isfinite(xa2).all() and torch.isfinite(xb2).all()
+        d2 = statistics.median(p2)
+        in_flight = {"batches": 2, "puzzles_per_batch": G, "ms_per_step_of_both": d2 / K * 1e3, "ms_per_batch_step": d2 / K * 1e3 / 2,
+                     "value": world * 2 * G * K / d2, "unit": "puzzle-steps/s", "vs_one_batch_in_flight": (2 * G * K / d2) / (G * K / dt),
+                     "note": "two independent Batches as two hipGraphs on two streams (da_sample_loop_pair); rank-local median of "
+                             f"{len(p2)} passes; the line's value / ms_per_step are ONE Batch in flight"}
+        del plan2, feats2, x_T2
+        run(chunks[0], True)          # (the one-Batch workspace again, for the roofline passes below)
+
     roof = sparse = None
     flags = int(eng.flags)
     if not args.no_roofline:
@@ -997,7 +1032,7 @@ def sample_bench(args, world, rank, dev):
             "timed_region": {"seconds": dt, "graph_replays_per_pass": len(chunks),
                              "excluded": "per-Batch staging (set_features_ms, once per sampling loop), graph capture, warm-up"},
             "set_features_ms": set_features_ms, "graph_plan_ms": plan_ms, "fragment_encoder_ms": fragment_encoder_ms,
-            "replay": replay, "parity_mode": parity,
+            "replay": replay, "parity_mode": parity, "two_batches_in_flight": in_flight,
             "roofline": roof, "cpu_baseline": cpu,
         }
         if sparse is not None:

@@ -208,6 +208,12 @@ int linear(int prec, int M, int K, int Nout, const void *A, int lda, const void 
 
 static bool dense_disabled() { return cfg().disable_dense != 0; }
 
+// The large-Batch step rule (da_config.xpanel = tail_next = -1): row-panel projections + the next step's embedding inside the tail kernel for
+// Batches whose largest graph has >= 512 pieces (round 5) OR that hold >= 16 384 pieces in all (round 6: tools/ab_config.py on configuration 2,
+// 512 puzzles of 144 pieces -- -6.9 % at 20-step loops, -4.0 % at 100, twelve of twelve interleaved pairs each; round 5's process-level A/B had
+// read that Batch as a loss).  Small Batches (the scripted 8-puzzle ones) keep the old path: nothing to gain from a panel of nine row tiles.
+static bool step_rule_batch(const da_graph *g) { return g->max_graph_nodes >= 512 || g->n_real >= 16384; }
+
 static bool dense_ok(const da_graph *g, int heads, int C) {
     const bool hyb = g->hybrid && g->mask && g->mask_ptr && g->irr_row_ptr;
     return !dense_disabled() && (g->dense || hyb) && g->n_pad > 0 && g->graph_ptr && g->pad_ptr && g->row_map && heads == 8 &&
@@ -373,7 +379,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             const void *wdense = (fused && l == 0) ? d->conv0c_wd : c.wd;
             const float *bdense = (fused && l == 0) ? d->conv0c_bd : c.bd;
             const int xpm = xpanel_mode();
-            const void *wpanel = (xpm == 1 || (xpm == 2 && g->max_graph_nodes >= 512)) ? ((fused && l == 0) ? d->conv0c_wdp : c.wdp) : nullptr;
+            const void *wpanel = (xpm == 1 || (xpm == 2 && step_rule_batch(g))) ? ((fused && l == 0) ? d->conv0c_wdp : c.wdp) : nullptr;
             rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
                 return launch_gemm_mfma(prec, nproj, c.din, 4 * c.hc, xin, ldx, wdense, bdense, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st, 0,
                                         nullptr, wpanel); });
@@ -797,8 +803,8 @@ static int enqueue_loop(da_denoiser *d, const da_graph *g, const da_schedule *s,
         // the tail kernel of this step may also produce the NEXT step's h (embedding + mlp.0 over the hoisted feature part): bf16, the 2D
         // transformer widths, a next step that exists
         // DA_TAIL_NEXT: 1 = every Batch, 0 = never, unset = Batches whose largest graph has >= 512 pieces (DA_STEP_AUTO; 144-piece Batches lose)
-        const int nx_mode = da::cfg().tail_next;          // -1 = Batches of >= 512-piece graphs (144-piece Batches lose), 0 never, 1 always
-        const bool nx_want = nx_mode == 1 || (nx_mode < 0 && g->max_graph_nodes >= 512);
+        const int nx_mode = da::cfg().tail_next;          // -1 = the large-Batch step rule (step_rule_batch), 0 never, 1 always
+        const bool nx_want = nx_mode == 1 || (nx_mode < 0 && step_rule_batch(g));
         if (try_fuse && nx_want && nonneg && it + 1 < n_iters && d->prec == DA_PREC_BF16 && d->hidden == 128 && d->D - d->F == 64 && w.feat_proj &&
             !mfma_disabled()) {
             df.nx_on = 1; df.nx_t = i - ratio; df.nx_steps = d->steps; df.nx_cin = d->c_in; df.nx_ldw = d->D;
@@ -910,7 +916,9 @@ int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, 
     DA_REQUIRE(d->variant == DA_VARIANT_2D || (!oa.cfg && oa.sampler == 0 && oa.eta == 0.f), "da_sample_loop_pair_ex: the 3D loop has no guidance / stochastic variant");
     DA_REQUIRE(inference_ratio >= 1 && s->steps >= 1, "da_sample_loop_pair: bad ratio/steps");
     DA_REQUIRE(d->variant == DA_VARIANT_3D || d->c_in == d->c_out, "da_sample_loop_pair: c_in != c_out");
-    DA_REQUIRE(!g_a->hybrid && !g_b->hybrid, "da_sample_loop_pair: hybrid graphs fork a side stream of their own");
+    // hybrid graphs fork the denoiser's side stream (virtual rows) inside every layer: fine when each branch is recorded as a graph of its
+    // own (pair_split, the default), a cross-branch dependency through that one stream when both are recorded in one capture
+    DA_REQUIRE((!g_a->hybrid && !g_b->hybrid) || da::cfg().pair_split, "da_sample_loop_pair: hybrid graphs need the two-graph form (da_config.pair_split = 1)");
     DA_REQUIRE(!d->prof_on, "da_sample_loop_pair: not available while profiling (event bracketing is not capturable)");
     DA_REQUIRE((traj_a == nullptr) == (traj_b == nullptr), "da_sample_loop_pair_traj: both trajectory pointers or none");
     DA_REQUIRE(!traj_a || traj_stride >= (size_t)(g_a->n_real + g_b->n_real) * (d->variant == DA_VARIANT_3D ? 7 : d->c_in),

@@ -69,30 +69,55 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
     float m = -INFINITY, l = 0.f;
     const int beg = row_ptr[i], end = row_ptr[i + 1];
     const int head = lane >> 3;
-    for (int e = beg; e < end; ++e) {
-        const int j = col_src[e];
-        const T *kp = qkvs + (size_t)j * ld + HC + off;
-        const T *vp = kp + HC;
-        float kk[EPL], vv[EPL];
-        ld_row<T, EPL>(kp, kk);
-        ld_row<T, EPL>(vp, vv);
-        float s = 0.f;
+    // The walk used to be one dependent chain per edge -- index load, then the K / V row loads it addresses, then the softmax update -- a
+    // latency chain (0.157 of the HBM peak with the whole K | V table in the Infinity Cache).  Now: (1) the row's source
+    // indices arrive by ONE coalesced load per 64 edges (lane e holds edge e's source; v_readlane hands it to the wave as a scalar, so
+    // the row addresses are SGPR base + per-lane offset); (2) the K and V rows of U edges are requested together, before any is consumed;
+    // (3) the U scores enter the running softmax in one update (one rescale per U edges instead of one per edge).
+    constexpr int U = EPL <= 4 ? 8 : (EPL <= 8 ? 4 : 2);
+    for (int e0 = beg; e0 < end; e0 += 64) {
+        const int cnt = min(64, end - e0);
+        const int myj = col_src[e0 + min(lane, cnt - 1)];
+        for (int u0 = 0; u0 < cnt; u0 += U) {
+            float kk[U][EPL], vv[U][EPL];
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[x], s);
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        if (alpha && (lane & 7) == 0) {
-            const size_t eid = edge_id ? (size_t)edge_id[e] : (size_t)e;
-            alpha[eid * H + head] = s;            // raw score; normalised in the second pass
+            for (int u = 0; u < U; ++u) {
+                const int j = __builtin_amdgcn_readlane(myj, min(u0 + u, cnt - 1));          // (edges past the end re-read the last one)
+                const T *kp = qkvs + (size_t)j * ld + HC + off;
+                ld_row<T, EPL>(kp, kk[u]);
+                ld_row<T, EPL>(kp + HC, vv[u]);
+            }
+            float sc[U];
+            float mn = m;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[u][x], s);
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                const bool ok = u0 + u < cnt;                                                  // wave-uniform
+                if (ok && alpha && (lane & 7) == 0) {
+                    const size_t eid = edge_id ? (size_t)edge_id[e0 + u0 + u] : (size_t)(e0 + u0 + u);
+                    alpha[eid * H + head] = s;        // raw score; normalised in the second pass
+                }
+                sc[u] = ok ? s : -INFINITY;
+                mn = fmaxf(mn, sc[u]);
+            }
+            const float corr = expf(m - mn);           // (m = -inf on the first group: 0; mn is finite from the first real edge on)
+            l *= corr;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) acc[x] *= corr;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pe = expf(sc[u] - mn);     // (padding: exp(-inf) = 0)
+                l += pe;
+#pragma unroll
+                for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vv[u][x], acc[x]);
+            }
+            m = mn;
         }
-        const float mn = fmaxf(m, s);
-        const float corr = expf(m - mn);
-        const float p = expf(s - mn);
-        l = l * corr + p;
-#pragma unroll
-        for (int x = 0; x < EPL; ++x) acc[x] = fmaf(p, vv[x], acc[x] * corr);
-        m = mn;
     }
     const float inv = (end > beg) ? 1.0f / (l + 1e-16f) : 0.f;
     if (stats && (lane & 7) == 0) {               // training: softmax statistics for the backward kernels

@@ -8,7 +8,7 @@
 //                              consecutive keys 16 half .. 16 half + 15 of query q: the softmax is lane-local and P needs no
 //                              data movement to become the B operand of O^T += V^T . P^T.
 //
-// What is different, and why (measurements: DESIGN.md "Measured, round 3"):
+// What is different, and why (measurements: profiles/r03/NOTES.md):
 //   * a workgroup is 4 waves x 2 slabs = 256 queries: every K / V block streamed into LDS feeds twice the queries (half the
 //     LDS-DMA bytes per FLOP -- the 128-query kernel's C = 144 instance ran at the latency x bytes-in-flight limit of its
 //     two-stage ring) and every K fragment read from LDS feeds two MFMA chains;

@@ -8,7 +8,7 @@
 //   k_attn_optt<144, true, true>    their folded last layer
 // Same LDS image, DMA ring, fragment layouts and epilogues as k_attn_dense (da_attn_dense.hip; geometry in da_attn_common.h).
 // Written around what the round-3 measurements say bounds these kernels -- the SIMD's vector issue port (v_exp_f32 ~13-16
-// cycles, packs ~6.4, every MFMA ~12 cycles of the same port; DESIGN.md "Measured, round 3") -- and, for C = 144, the
+// cycles, packs ~6.4, every MFMA ~12 cycles of the same port; profiles/r03/NOTES.md) -- and, for C = 144, the
 // register budget (the FAST mode of k_attn_dense keeps scores AND exponentials alive for its per-block fallback: 176 VGPRs,
 // two waves per SIMD where round 2 had three).  Per score only the exponential and the pack are left on that port:
 //   * OPTIMISTIC softmax: p = exp2(s) with no reference, no per-block test, in place.  fp32 / bf16 carry 8 exponent bits,
@@ -731,7 +731,7 @@ static int launch_optt(AttnDenseParams p, hipStream_t st) {
 }
 
 // ---- K / V-RESIDENT instance for the hidden layers of LARGE complete graphs (round 5, last session).
-// What the round's probes measured on k_attn_optt<32> (DESIGN.md "Measured, round 5"): the arithmetic of a 32 x 32 block is under
+// What the round's probes measured on k_attn_optt<32> (profiles/r05/NOTES.md): the arithmetic of a 32 x 32 block is under
 // half of a wave's time; the rest is a barrier + tile wait per 64 keys, DMA issue, a 30 % half-empty tail per launch, and a
 // prologue / epilogue per 128-query tile -- latency at WORKGROUP granularity.  A head of a 900-piece puzzle is 2 x 57.6 KB of K and
 // V: it FITS the CU's 160 KB of LDS.  So: ONE workgroup of sixteen waves per (graph, head); the whole K | V of the head is requested
@@ -752,7 +752,15 @@ template <int NWV, bool QUEUE, bool KPF, int XV = 0>
 __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 4 : 5)) void k_attn_res(AttnDenseParams p) {
     // XV (experiments, A/B through DA_ATTN_RES_PH): bit 0 = two PV accumulators (keys 0 .. 15 / 16 .. 31 of every block: no product waits for
     // the one before it on the same registers); bit 1 = the younger half of the waves at priority 1 (the arbiter favours old waves)
-    constexpr bool O2 = (XV & 1) != 0;
+    // bit 4 (16) = PROGRESSIVE LANDING (round 6): no all-or-nothing barrier behind the 120 KB request.  The request order is already
+    // tile by tile (wave w holds piece w & 7 of tiles w >> 3, (w >> 3) + 2, ...: tiles complete in order, one per ~1 k cycles, while a wave consumes
+    // one per ~2.9 k), so a wave may start on tile 0 as soon as tile 0 is there.  Per 64-key stage an LDS word counts the pieces that have landed:
+    // a wave posts piece k of its own after `s_waitcnt vmcnt(pieces issued after it)` -- on a schedule that runs AHEAD of every wave's
+    // consumption (at tile t it posts its pieces of tiles <= 3 t + 1, which landed long before anybody needs them), so that nobody waits on a
+    // slow partner -- and polls the word of tile t + 1 before it requests that tile's first K fragments.  The only barrier left orders the
+    // zeroing of the words before the first post (at kernel start, with the requests in flight).
+    constexpr bool O2 = (XV & 1) != 0, PROG = (XV & 16) != 0;
+    static_assert(!PROG || (NWV == 16 && KPF), "progressive landing: the sixteen-wave instance (two waves per piece index), K fragments one block ahead");
     using T = bf16_t;
     constexpr int C = 32, CV = 32;
     using CF = Cfg<T, C, CV, 64>;
@@ -782,10 +790,20 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
     const unsigned char *Vg = (const unsigned char *)p.Vt + ((size_t)h * np + pad0) * CF::ROWBV;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     unsigned *qctr = (unsigned *)(smem + ((p.max_nodes + 63) >> 6) * STAGE);
+    volatile unsigned *land = qctr + 4;         // PROG: [nkt] pieces landed per stage (launch_res sizes the LDS for them)
     if (QUEUE && tid == 0) { *qctr = 0u; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }      // (nobody draws before the landing barrier)
+    if (PROG && tid < 32) { land[tid] = 0u; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     int node0 = 0, n_g = 0;
     if (!upad) { node0 = p.graph_ptr[g]; n_g = p.graph_ptr[g + 1] - node0; }
     const int nkt = upad ? (npg >> 6) : ((n_g + 63) >> 6);          // tiles to fetch (upad: the whole slot -- its rows beyond n_g are readable padding)
+    // PROG: the first slab's Q fragments are requested FIRST (the oldest vector-memory operations of the wave: every counted wait on a DMA piece
+    // below covers them) and by asm loads -- a load the compiler tracks would get ITS `vmcnt(0)` in front of the first QK product, i.e. a wait
+    // for all 120 KB.  (Slab = wave index < 16 <= slabs of any graph this instance takes: no clamp, no graph table needed.)
+    u32x4 qf0[2] = {};
+    if constexpr (PROG) {
+        const unsigned char *qrow = Qg + (size_t)(wid * 32 + i) * CF::ROWB + half * 16;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:32" : "=&v"(qf0[0]), "=&v"(qf0[1]) : "v"(qrow) : "memory");
+    }
 
     // ---- the whole K | V of the head: wave w issues piece (w & 7) of tiles (w >> 3), (w >> 3) + TPW, ... (scalar base + lane offset form)
     if constexpr (NWV % 8 != 0) {
@@ -825,7 +843,16 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
         }
     }
     DA_OPB(pb_[1] = __builtin_readcyclecounter();)
-    if (upad) { node0 = p.graph_ptr[g]; n_g = p.graph_ptr[g + 1] - node0; }      // (behind the DMA: the asm's memory clobber keeps these loads here)
+    if (upad) {          // (behind the DMA: the asm's memory clobber keeps these loads here)
+        if constexpr (PROG) {
+            // a SCALAR load by hand: the compiler's own choice here is a vector load, whose `vmcnt(0)` would wait for all 120 KB
+            typedef __attribute__((ext_vector_type(2))) int i32x2_;
+            i32x2_ gp2;
+            const int32_t *gpp = p.graph_ptr + g;
+            asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gp2) : "s"(gpp) : "memory");
+            node0 = gp2[0]; n_g = gp2[1] - gp2[0];
+        } else { node0 = p.graph_ptr[g]; n_g = p.graph_ptr[g + 1] - node0; }
+    }
     const int nslab = (n_g + 31) >> 5;      // 32-query slabs = 32-key blocks
     int slab = wid;
     u32x4 qf[CF::NCH];
@@ -834,10 +861,57 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
 #pragma unroll
         for (int ch = 0; ch < CF::NCH; ++ch) dst[ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
     };
-    load_q(slab, qf);
+    static_assert(!PROG || CF::NCH == 2, "progressive landing: two Q fragments per lane");
+    if constexpr (!PROG) load_q(slab, qf);
+    // PROG: this wave's pieces (tiles t0p, t0p + 2, ...: nmine of them, issued in that order, with nothing older than them outstanding but the two
+    // Q loads above and nothing younger) and how many it has posted
+    [[maybe_unused]] const int t0p = wid >> 3, nmine = nkt > t0p ? (nkt - t0p + 1) >> 1 : 0;
+    [[maybe_unused]] int posted = 0;
+    [[maybe_unused]] auto wait_le = [&](int n) {           // s_waitcnt vmcnt(n), n a run-time count (<= 9: ten pieces of nineteen stages)
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        }
+    };
+    // post every piece of mine whose tile index is <= tmax: piece k has landed once at most the nmine - 1 - k pieces issued after it are outstanding
+    [[maybe_unused]] auto post_upto = [&](int tmax) {
+        while (posted < nmine && t0p + 2 * posted <= tmax) {
+            wait_le(nmine - 1 - posted);
+            if (lane == 0) __hip_atomic_fetch_add((unsigned *)land + t0p + 2 * posted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ++posted;
+        }
+    };
+    // (asm read: a volatile access makes the compiler wait for EVERY outstanding memory operation -- vmcnt(0): all 120 KB -- in front of it)
+    [[maybe_unused]] auto await_tile = [&](int t) {
+        const unsigned a_ = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)(land + t);
+        unsigned v_;
+        do {
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v_) : "v"(a_) : "memory");
+            if (__builtin_amdgcn_readfirstlane((int)v_) >= 8) break;
+            __builtin_amdgcn_s_sleep(1);
+        } while (true);
+    };
+    if constexpr (PROG) {
+        __builtin_amdgcn_s_barrier();          // the landing words are zero (the requests are in flight; nobody has waited for anything yet)
+        post_upto(slab < nslab ? 1 : (1 << 30));                // (a wave without a slab still owes all its pieces)
+        if (nmine == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (every wave of this instance holds at least one piece of tile 0 or 1: the wait above covered the Q loads, which are older)
+        qf[0] = qf0[0]; qf[1] = qf0[1];
+        asm volatile("" : "+v"(qf[0]), "+v"(qf[1]));
+        if (slab < nslab) await_tile(0);
+    } else {
     // the first slab's Q fragments travel behind the DMA; one wait for both, then the only barrier of the kernel
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[CF::NCH - 1]));
     __builtin_amdgcn_s_barrier();
+    }
     DA_OPB(pb_[6] = __builtin_readcyclecounter();)
 
     const int pi_i = (i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1);
@@ -858,7 +932,7 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
     for (int round = 0; slab < nslab; ++round) {
         const int q0 = slab * 32, qidx = q0 + i;
         bool gen = p.force_gen != 0;
-        auto pass = [&]() {
+        auto pass = [&](const bool first) {          // first (PROG): this wave's first walk over the keys -- tiles may still be on their way
 #pragma unroll
             for (int r = 0; r < 16; ++r) { O[r] = 0.f; if (O2) Ob[r] = 0.f; }
             ls = 0.f;
@@ -869,6 +943,7 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
             for (int b = 0; b < nslab; ++b) {
                 const int key0 = b * 32;
                 const int bo = boff(b);
+                if (PROG && first && !(b & 1)) post_upto(3 * (b >> 1) + 1);          // ahead of everybody's consumption (see the header)
                 if (!KPF && b > 0) {
 #pragma unroll
                     for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(smem + bo + kfo[ch]);
@@ -889,6 +964,7 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
                     vhi[mm] = tr_read(vb, (8 * mm + 4) * CF::RSV);
                 }
                 if (KPF && b + 1 < nslab) {       // next block's K fragments: they land under this block's exponentials
+                    if (PROG && first && (b & 1)) await_tile((b + 1) >> 1);          // (a new tile: all eight pieces there?)
                     const int bn = boff(b + 1);
 #pragma unroll
                     for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(smem + bn + kfo[ch]);
@@ -942,7 +1018,8 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
                 }
             }
         };
-        pass();
+        pass(PROG && round == 0);
+        if (PROG && round == 0) post_upto(1 << 30);          // (every piece posted before this wave issues another vector-memory operation)
         if (O2) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[r] += Ob[r];
@@ -955,7 +1032,7 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
             if (__any(!ok && qidx < n_g)) {
                 gen = true;
                 if (lane == 0) atomicAdd(&g_opt_fallbacks[0], 1ull);
-                pass();
+                pass(false);
                 if (O2) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) O[r] += Ob[r];
@@ -1018,7 +1095,7 @@ long long attn_res_launches(int reset) {
 
 template <int NWV, bool QUEUE, bool KPF, int XV = 0>
 static int launch_res(const AttnDenseParams &p, hipStream_t st) {
-    const int lds = ((p.max_nodes + 63) >> 6) * OptK<32, 64>::STAGE + 16;
+    const int lds = ((p.max_nodes + 63) >> 6) * OptK<32, 64>::STAGE + 16 + 128;          // + the queue word + the landing words (XV & 16)
     static bool attr_done[16] = {};
     int dev = 0;
     DA_CHECK_HIP(hipGetDevice(&dev));
@@ -1072,6 +1149,7 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
                     case 5: return launch_res<16, true, true, 1>(p, st);       // two PV accumulators
                     case 6: return launch_res<16, true, true, 2>(p, st);       // younger half of the waves at priority 1
                     case 7: return launch_res<16, true, true, 3>(p, st);
+                    case 8: return launch_res<16, true, true, 16>(p, st);      // progressive landing (round 6)
                     default: break;
                 }
 #endif

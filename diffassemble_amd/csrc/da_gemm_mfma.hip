@@ -93,19 +93,25 @@ __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 256, row = idx / CPR, ch = idx - row * CPR;
-            const int m = row0 + row + pass * ROWS, col = col0 + ch * EPC;
+            int m = row0 + row + pass * ROWS;
+            if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(m));          // (see `slot` below)
+            const int col = col0 + ch * EPC;
             if (m >= p.M || col >= p.Nout) continue;
             T *dst;
+            int slot = rs.q[pass][it];
+            // (fp32: the compiler hoists the 64-bit row offsets of all 16 slots out of the column-tile loop and then spills them -- 26 registers of
+            //  the Q | K | V scatter instance; opaque here, they are recomputed per tile: three integer operations)
+            if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(slot));
             if (!p.qkv) dst = (T *)p.out + (size_t)m * p.ldo + col;
             else if (which == 3) dst = (T *)p.S + (size_t)m * p.HC + (col - 3 * p.HC);
             else {
                 const int f = col - which * p.HC;
                 if (which == 2 && p.Cv > 0) {
                     const int h = (int)__umulhi((unsigned)f, p.Cvmagic), c = f - h * p.Cv;
-                    dst = (T *)p.Vt + ((size_t)h * p.n_pad + rs.q[pass][it]) * p.Cv + c;
+                    dst = (T *)p.Vt + ((size_t)h * p.n_pad + slot) * p.Cv + c;
                 } else {
                 const int h = (int)__umulhi((unsigned)f, p.Cmagic), c = f - h * p.C;
-                dst = (T *)(which == 0 ? p.Q : (which == 1 ? p.Kb : p.Vt)) + ((size_t)h * p.n_pad + rs.q[pass][it]) * p.C + c;
+                dst = (T *)(which == 0 ? p.Q : (which == 1 ? p.Kb : p.Vt)) + ((size_t)h * p.n_pad + slot) * p.C + c;
                 }
             }
             *(u32x4 *)dst = val[it];
@@ -115,9 +121,8 @@ __device__ __forceinline__ void mfma_epilogue(const GemmParams &p, const f32x4 (
 
 // TO: element type of out / res / pre (default: the operand type T).  T = float + BFC with TO = bf16_t, and T = bf16_t with
 // TO = float, are the two mixed forms of the training path's bf16 projection buffers (da_train.hip, q16 mode).
-// (two workgroups per CU; the fp32 Q | K | V | skip scatter instance -- parity mode -- spilled 26 registers at that budget and runs at one)
 template <typename T, bool QKV, int ACT, bool BFC = false, typename TO = T>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 && QKV) ? 1 : 2) void k_gemm_mfma(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void k_gemm_mfma(GemmParams p) {
     // two stages x (A tile 16 KB + W tile 16 KB), filled by LDS-DMA (global_load_lds_dwordx4).  A
     // workgroup owns one 128-row tile of A and walks `nt` consecutive 128-column tiles of W as ONE
     // continuous stream of K stages, so the DMA of the next column tile's first stage is already in

@@ -333,7 +333,7 @@ def _hybrid_worth_it(n_max, n_reg, n_edges, pairs):
     kernels beat the edge-list kernels in EVERY cell -- 0.32 vs 0.41 - 0.53 ms per step at 36 pieces, 0.41 vs 0.62 - 1.04 at 64,
     0.55 vs 1.5 - 3.6 at 144 -- and on 64 puzzles of 900 pieces at degree 2 % (d = 18) by 0.94 vs 4.49 ms: a (query, key) pair
     costs the matrix cores ~18 ps at 900 pieces (~100 ps at 144), a gathered edge costs the edge-list kernel 2 - 3 ns, so the
-    crossover sits near 0.6 - 1 % density (DESIGN.md "Measured, round 5").  Every Batch the reference scripts (6x6 .. 20x20 and
+    crossover sits near 0.6 - 1 % density (profiles/r05/NOTES.md).  Every Batch the reference scripts (6x6 .. 20x20 and
     30x30 at degree 60 %) is far above it.  The edge-list kernels keep what is sparser than that, multi-edged, tiny, or asked for
     its attention weights -- and every remainder edge (virtual nodes, duplicates)."""
     return n_max >= 32 and n_reg >= 0.25 * n_edges and n_reg >= 0.01 * pairs

@@ -60,10 +60,10 @@ typedef struct da_config {
                                  /* 16 one-kernel tail, 32 virtual rows on a side stream (hybrid graphs)             */
     int32_t attn_level;          /* DA_ATTN_LEVEL: 0 = the general dense kernel only, 1 = + the optimistic ring      */
                                  /* kernels, 2 = + the K/V-resident hidden-layer kernel (default)                    */
-    int32_t xpanel;              /* DA_ENABLE_XPANEL: -1 = row-panel projections for Batches of >= 512-piece graphs  */
-                                 /* (default), 0 never, 1 always                                                     */
-    int32_t tail_next;           /* DA_TAIL_NEXT: -1 = next step's embedding inside the tail kernel for >= 512-piece */
-                                 /* graphs (default), 0 never, 1 always                                              */
+    int32_t xpanel;              /* DA_ENABLE_XPANEL: -1 = row-panel projections for large Batches (largest graph    */
+                                 /* >= 512 pieces or >= 16 384 pieces in all; default), 0 never, 1 always            */
+    int32_t tail_next;           /* DA_TAIL_NEXT: -1 = next step's embedding inside the tail kernel for the same     */
+                                 /* large Batches (default), 0 never, 1 always                                       */
     int32_t pair_split;          /* DA_PAIR_SPLIT: 1 = the pair loop as two graphs on two streams (default), 0 = one */
     int32_t train_attn;          /* DA_TRAIN_ATTN: 0 = edge-list kernels only, 1 = grouped-GEMM attention with pair  */
                                  /* matrices, 2 = + flash-style hybrid kernels in the bf16-operand mode (default)    */

@@ -109,3 +109,30 @@ def test_scripted_batch_training_step_vs_oracle_autograd(dev, name):
             continue
         worst = max(worst, rel(params[k].grad, v.grad))
     assert 0 < worst < 2e-4, worst
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_two_exophormer_batches_in_flight_equal_each_alone(dev, prec):
+    """`sample_loop_batches`: two independent hybrid (Exphander + exophormer) Batches as two hipGraphs on two streams -- the way Batches whose
+    virtual-node edges forbid a SPLIT (exophormer_gnn.py:183-200 couples a Batch's puzzles) get the pair loop's overlap.  Each Batch's poses are
+    bit for bit what `sample_loop` gives it alone, and the second call (cached graphs) reproduces the first."""
+    from diffassemble_amd import DenoiserEngine, Schedule, _lib
+    V = 8
+    sd = W.make_denoiser_state(300, 4, 4, arch="exophormer", virt_nodes=V, seed=72, qk_gain=3.0)
+    eng = DenoiserEngine(sd, variant="2d", arch="exophormer", virt_nodes=V, precision=prec, device=dev)
+    sch = Schedule(ODF.make_schedule(300), dev)
+    items = []
+    for sides, seed in (([6, 16, 10, 20, 8, 18, 12, 14], 5), ([12, 8, 14, 6, 10, 16], 9)):
+        ei, batch, degs, x, feats, t = _batch(sides, seed, 60)
+        plan = eng.plan(ei.to(dev), batch.to(dev))
+        assert plan.hybrid
+        items.append((plan, x.to(dev), feats.to(dev)))
+    alone = []
+    for plan, x, f in items:
+        _, xf = eng.sample_loop(plan, sch, x, f, ratio=10, mean_type=_lib.MEAN_START_X, max_iters=4, keep_trajectory=False, use_graph=True)
+        alone.append(xf.clone())
+    for _ in range(2):
+        fa, fb = eng.sample_loop_batches([items[0][0], items[1][0]], sch, [items[0][1], items[1][1]], [items[0][2], items[1][2]], ratio=10,
+                                         mean_type=_lib.MEAN_START_X, max_iters=4)
+        torch.cuda.synchronize()
+        assert torch.isfinite(fa).all() and torch.equal(fa, alone[0]) and torch.equal(fb, alone[1])

@@ -1,6 +1,6 @@
 // Co-residency probe: does the four-wave projection kernel of da_gemm_thin.hip run INSIDE the CUs that the
 // K / V-resident hidden-layer attention kernel occupies, and what does each pay for it?
-//   build: see tools/build_corun.sh;   run: tools/bin/corun_probe [G=32] [n=900] [iters=200]
+//   build: tools/build_tools.sh (EXPERIMENTS build of the library);   run: tools/bin/corun_probe [G=32] [n=900] [iters=200]
 // 1. bit-identity: thin vs the default W-in-registers kernels on the three projection shapes of the 2D denoiser.
 // 2. timing: attention alone, each projection kernel alone, and both back to back on TWO streams at once (wall time per pair of launches).
 #include <hip/hip_runtime.h>
