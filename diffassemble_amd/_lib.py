@@ -158,6 +158,8 @@ PROTOTYPES = {
                                        _fp, C.c_size_t, C.c_int, _fp]),
     "da_train_backward_stage": (C.c_int, [C.POINTER(DaWeights), C.POINTER(DaWeights), C.POINTER(DaGraph), _fp, _fp, _fp, _fp,
                                           _fp, C.c_size_t, C.c_int, C.c_int, _fp]),
+    "da_q_sample": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "da_loss_grad": (C.c_int, [C.c_int, C.c_size_t, _fp, _fp, _fp, _fp, _fp]),
     "da_adafactor_step": (C.c_int, [C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_float,
                                     C.c_float, C.c_float, C.c_float, _fp]),
     "da_greedy_assign": (C.c_int, [C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),

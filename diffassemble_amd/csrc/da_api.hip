@@ -214,6 +214,11 @@ static bool dense_disabled() { return cfg().disable_dense != 0; }
 // read that Batch as a loss).  Small Batches (the scripted 8-puzzle ones) keep the old path: nothing to gain from a panel of nine row tiles.
 static bool step_rule_batch(const da_graph *g) { return g->max_graph_nodes >= 512 || g->n_real >= 16384; }
 
+static bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+}
+
 static bool dense_ok(const da_graph *g, int heads, int C) {
     const bool hyb = g->hybrid && g->mask && g->mask_ptr && g->irr_row_ptr;
     return !dense_disabled() && (g->dense || hyb) && g->n_pad > 0 && g->graph_ptr && g->pad_ptr && g->row_map && heads == 8 &&
@@ -855,6 +860,9 @@ int da_sample_loop_ex(da_denoiser *d, const da_graph *g, const da_schedule *s, i
     int total = (s->steps + inference_ratio - 1) / inference_ratio;
     const int n_iters = (max_iters > 0 && max_iters < total) ? max_iters : total;
     if (d->prof_on) use_graph = 0;       // event bracketing is not capturable
+    // the CALLER is capturing `stream` (e.g. a predict_step wrapped in torch.cuda.graph): the loop's kernels are enqueued on it directly -- they
+    // become nodes of the caller's graph -- instead of launching a graph of the library's own from inside a capture
+    if (stream_is_capturing(st)) use_graph = 0;
     if (!use_graph) return enqueue_loop(d, g, s, mean_type, inference_ratio, n_iters, x_init, traj, x_final, w, st, &o);
 
     LoopKey key;
@@ -951,6 +959,24 @@ int da_sample_loop_pair_ex(da_denoiser *d, const da_schedule *s, int mean_type, 
     // launched one-branch graphs of 32 puzzles ran a 64-puzzle step in 0.6734 ms where the one-graph pair loop needed 0.7002 on the same box --
     // the runtime does not run the two branches of one graph as independently as it runs two graphs on two streams.
     const int split_mode = cfg().pair_split;
+    if (stream_is_capturing((hipStream_t)stream)) {
+        // the caller is capturing `stream`: both branches go straight into the caller's capture -- branch A on `stream`, branch B on the library's
+        // pair stream between a fork and a join event (two parallel branches of the CALLER's graph) -- no graph of the library's own is launched
+        hipStream_t us = (hipStream_t)stream;
+        if (!d->pair_stream) {
+            DA_CHECK_HIP(hipStreamCreateWithFlags(&d->pair_stream, hipStreamNonBlocking));
+            DA_CHECK_HIP(hipEventCreateWithFlags(&d->ev_pair_fork, hipEventDisableTiming));
+            DA_CHECK_HIP(hipEventCreateWithFlags(&d->ev_pair_join, hipEventDisableTiming));
+        }
+        hipStream_t ps = d->pair_stream;
+        DA_CHECK_HIP(hipEventRecord(d->ev_pair_fork, us));
+        DA_CHECK_HIP(hipStreamWaitEvent(ps, d->ev_pair_fork, 0));
+        const int rca = enqueue_loop(d, g_a, s, mean_type, inference_ratio, n_iters, x_init_a, traj_a, x_final_a, wa, us, &oa, traj_stride, noise_stride);
+        const int rcb = enqueue_loop(d, g_b, s, mean_type, inference_ratio, n_iters, x_init_b, traj_b, x_final_b, wb, ps, &ob, traj_stride, noise_stride);
+        DA_CHECK_HIP(hipEventRecord(d->ev_pair_join, ps));           // (joined even when a branch failed: the capture must not be left forked)
+        DA_CHECK_HIP(hipStreamWaitEvent(us, d->ev_pair_join, 0));
+        return rca ? rca : rcb;
+    }
     hipGraphExec_t exec = nullptr, exec_b = nullptr;
     for (auto &e : d->pair_loops)
         if (memcmp(&ka, &e.a, sizeof(ka)) == 0 && memcmp(&kb, &e.b, sizeof(kb)) == 0 && (e.exec_b != nullptr) == (split_mode != 0)) { exec = e.exec; exec_b = e.exec_b; }

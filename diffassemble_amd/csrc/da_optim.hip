@@ -257,11 +257,71 @@ __global__ __launch_bounds__(256) void k_af_d(const AfParam *__restrict__ P, con
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The elementwise glue of p_losses (spatial_diffusion.py:421-430, 432-483): q_sample and the loss, each as ONE launch (the torch forms
+// were ~6 + ~5 launches of 4 - 5 us between the optimizer step and the forward: VERDICT r05 item 8).
+// q_sample: x_noisy = extract(sqrt_alphas_cumprod, t) * x_start + extract(sqrt_one_minus_alphas_cumprod, t) * noise -- two rounded products,
+// one rounded sum, the reference's order: bit-identical to the torch expression.
+__global__ __launch_bounds__(256) void k_q_sample(int steps, size_t n, int c, const float *__restrict__ sa, const float *__restrict__ sb,
+                                                  const float *__restrict__ x, const float *__restrict__ nz, const int64_t *__restrict__ t,
+                                                  float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * (size_t)c) return;
+    long long ti = t[i / c];
+    ti = ti < 0 ? 0 : (ti >= steps ? steps - 1 : ti);
+    out[i] = __fadd_rn(__fmul_rn(sa[ti], x[i]), __fmul_rn(sb[ti], nz[i]));
+}
+// loss = mean over the n elements of l(target - pred), d_pred = d loss / d pred, ONE workgroup (n = N c is a few 10^4): fixed summation order
+// (thread-strided partial sums, then a tree in LDS) -- deterministic, data-parallel replicas agree bit for bit.
+//   kind 0: l1 (|d|), 1: l2 (d^2), 2: smooth-l1 / Huber with beta = 1 (F.smooth_l1_loss: 0.5 d^2 below 1, |d| - 0.5 above)
+__global__ __launch_bounds__(1024) void k_loss_grad(int kind, size_t n, const float *__restrict__ target, const float *__restrict__ pred,
+                                                    float *__restrict__ loss, float *__restrict__ d_pred) {
+    __shared__ float red[1024];
+    const float inv_n = 1.0f / (float)n;
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        const float d = target[i] - pred[i], a = fabsf(d);
+        float l, g;                                     // g = d l / d (target - pred)
+        if (kind == 0) { l = a; g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+        else if (kind == 1) { l = d * d; g = 2.f * d; }
+        else if (a < 1.f) { l = 0.5f * d * d; g = d; }
+        else { l = a - 0.5f; g = d > 0.f ? 1.f : -1.f; }
+        s += l;
+        d_pred[i] = -g * inv_n;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] * inv_n;
+}
+
 }  // namespace da
 
 using namespace da;
 
 extern "C" {
+
+int da_q_sample(int steps, int n, int c, const float *sqrt_alphas_cumprod, const float *sqrt_one_minus_alphas_cumprod, const float *x_start,
+                const float *noise, const int64_t *t, float *x_noisy, void *stream) {
+    DA_REQUIRE(steps > 0 && c > 0 && sqrt_alphas_cumprod && sqrt_one_minus_alphas_cumprod && x_start && noise && t && x_noisy, "da_q_sample: null argument");
+    if (n <= 0) return 0;
+    const size_t tot = (size_t)n * c;
+    k_q_sample<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(steps, (size_t)n, c, sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod,
+                                                                               x_start, noise, t, x_noisy);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
+int da_loss_grad(int kind, size_t n, const float *target, const float *pred, float *loss, float *d_pred, void *stream) {
+    DA_REQUIRE(kind >= 0 && kind <= 2 && n > 0 && target && pred && loss && d_pred, "da_loss_grad: bad argument");
+    k_loss_grad<<<1, 1024, 0, (hipStream_t)stream>>>(kind, n, target, pred, loss, d_pred);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
 
 int da_adafactor_step(int n_params, const void *param_table, int n_blocks, const void *block_table, float *flat,
                       const float *flat_grad, float *state, float *scratch, size_t scratch_floats, int step, float eps1,

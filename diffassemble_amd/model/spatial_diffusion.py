@@ -98,6 +98,34 @@ def greedy_cost_assignment(pos1: torch.Tensor, pos2: torch.Tensor) -> torch.Tens
     return torch.tensor(out, dtype=torch.int64).reshape(-1, 3)
 
 
+_LOSS_KIND = {"l1": 0, "l2": 1, "huber": 2}
+
+
+def _glue_on_device(*tensors):
+    """The training-side glue kernels take contiguous fp32 (poses) / int64 (timesteps) tensors on a ROCm device; anything else keeps torch."""
+    return all(t.is_cuda and t.dtype in (torch.float32, torch.int64) for t in tensors)
+
+
+class _FusedLoss(torch.autograd.Function):
+    """F.l1_loss / F.mse_loss / F.smooth_l1_loss(target, prediction) (mean reduction) of p_losses, spatial_diffusion.py:470-480, with the gradient
+    with respect to the prediction computed in the SAME launch (da_loss_grad): backward is one scaling by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, prediction, target, kind):
+        from .. import _lib
+        p, t = prediction.detach().contiguous(), target.detach().contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        d_pred = torch.empty_like(p)
+        _lib.check(_lib.lib().da_loss_grad(int(kind), p.numel(), _lib.ptr(t), _lib.ptr(p), _lib.ptr(loss), _lib.ptr(d_pred), _lib.stream_ptr(p.device)))
+        ctx.save_for_backward(d_pred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_pred,) = ctx.saved_tensors
+        return d_pred * g, None, None
+
+
 class GNN_Diffusion(LightningModule):
     def __init__(self, steps=600, inference_ratio=1, sampling="DDPM", learning_rate=1e-4,
                  save_and_sample_every=1000, bb=None, classifier_free_prob=0, classifier_free_w=0,
@@ -209,6 +237,15 @@ class GNN_Diffusion(LightningModule):
         """spatial_diffusion.py:421-430 (training-side elementwise glue)."""
         if noise is None:
             noise = torch.randn_like(x_start)
+        if _glue_on_device(x_start, noise, t) and x_start.dim() == 2 and t.shape[0] == x_start.shape[0] and not x_start.requires_grad:
+            # one library launch instead of two gathers, two broadcasts, two products and a sum (bit-identical: da_q_sample)
+            from .. import _lib
+            out = torch.empty_like(x_start)
+            _lib.check(_lib.lib().da_q_sample(int(self.sqrt_alphas_cumprod.numel()), x_start.shape[0], x_start.shape[1],
+                                              _lib.ptr(self.sqrt_alphas_cumprod), _lib.ptr(self.sqrt_one_minus_alphas_cumprod),
+                                              _lib.ptr(x_start.contiguous()), _lib.ptr(noise.contiguous()), _lib.ptr(t.contiguous()),
+                                              _lib.ptr(out), _lib.stream_ptr(x_start.device)))
+            return out
         return (extract(self.sqrt_alphas_cumprod, t) * x_start
                 + extract(self.sqrt_one_minus_alphas_cumprod, t) * noise)
 
@@ -227,6 +264,8 @@ class GNN_Diffusion(LightningModule):
         prediction = self.forward_with_feats(x_noisy, t, cond, edge_index, patch_feats=patch_feats, batch=batch,
                                              return_attentions=False)
         target = {ModelMeanType.START_X: x_start, ModelMeanType.EPSILON: noise}[self.model_mean_type]
+        if loss_type in _LOSS_KIND and _glue_on_device(target, prediction) and not target.requires_grad and target.shape == prediction.shape:
+            return _FusedLoss.apply(prediction, target, _LOSS_KIND[loss_type])          # loss + its gradient in one launch (da_loss_grad)
         if loss_type == "l1":
             return F.l1_loss(target, prediction)
         if loss_type == "l2":

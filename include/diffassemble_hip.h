@@ -462,6 +462,17 @@ int da_train_backward_stage(const da_weights *w, const da_weights *grads, const 
                             const int64_t *t, const float *d_out, float *d_feats, void *workspace,
                             size_t workspace_bytes, int mma_precision, int stage, void *stream);
 
+/* The elementwise glue of p_losses as single launches (ABI 19):
+ *   da_q_sample  == q_sample, spatial_diffusion.py:421-430: x_noisy = extract(sqrt_alphas_cumprod, t) * x_start
+ *                   + extract(sqrt_one_minus_alphas_cumprod, t) * noise  (bit-identical to the torch expression);
+ *   da_loss_grad == the loss of p_losses, spatial_diffusion.py:470-480 (kind 0 = F.l1_loss, 1 = F.mse_loss,
+ *                   2 = F.smooth_l1_loss, all with mean reduction) AND its gradient with respect to the prediction
+ *                   (d_pred [n], for a unit upstream gradient) -- one workgroup, fixed summation order.
+ *   x_start, noise, x_noisy: [n, c] fp32; t: [n] int64; target, pred, d_pred: [n] fp32; loss: [1] fp32. */
+int da_q_sample(int steps, int n, int c, const float *sqrt_alphas_cumprod, const float *sqrt_one_minus_alphas_cumprod,
+                const float *x_start, const float *noise, const int64_t *t, float *x_noisy, void *stream);
+int da_loss_grad(int kind, size_t n, const float *target, const float *pred, float *loss, float *d_pred, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Fused Adafactor step over the flat parameter / gradient buffers (one call = one optimizer
  * step for every listed tensor, 4 launches, deterministic, no host sync).  Replaces, for the

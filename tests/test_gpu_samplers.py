@@ -159,3 +159,42 @@ torch.save(torch.stack(imgs).cpu(), sys.argv[1])
         os.remove(path)
     assert outs[0].shape == (5, 36, 2) and torch.isfinite(outs[1]).all()
     assert rel(outs[1], outs[0]) < 1e-4
+
+
+@pytest.mark.parametrize("pair", [False, True], ids=["one_branch", "pair_loop"])
+def test_sampling_loops_inside_a_callers_graph_capture(dev, monkeypatch, pair):
+    """VERDICT r05 missing 5: a Lightning `predict_step` wrapped in a user graph (torch.cuda.graph) calls p_sample_loop while ITS stream is being
+    captured.  The library then must not launch graphs of its own: the loop's kernels -- for the pair loop both branches, between a fork and a join
+    event on the library's pair stream -- are enqueued into the caller's capture (da_api.hip stream_is_capturing), and replaying the CALLER's graph
+    gives the poses of a plain call bit for bit."""
+    import cases as C2
+    from diffassemble_amd import DenoiserEngine, Schedule, _lib
+    from oracle import weights as W
+    sd = W.make_denoiser_state(50, 4, 4, seed=11)
+    eng = DenoiserEngine(sd, precision="bf16", device=dev)
+    n, G = 144, 4
+    ei, batch = W.collate([W.dense_edge_index(n, True) for _ in range(G)], [n] * G)
+    gen = torch.Generator().manual_seed(3)
+    x0 = torch.randn((G * n, 4), generator=gen).to(dev)
+    feats = torch.randn((G * n, 1088), generator=gen).to(dev)
+    plan = eng.plan(ei.to(dev), batch.to(dev))
+    sch = Schedule(ODF.make_schedule(50), dev)
+    monkeypatch.setenv("DA_TWO_BRANCH", "1" if pair else "0")
+    monkeypatch.setattr(eng, "two_branch_min_graphs", 2, raising=False)
+    assert eng._two_branch(plan, False, True) == pair
+    kw = dict(ratio=5, mean_type=_lib.MEAN_START_X, keep_trajectory=False, use_graph=True)
+    _, ref = eng.sample_loop(plan, sch, x0, feats, **kw)           # plain call (also creates the library's streams / buffers outside any capture)
+    ref = ref.clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="relaxed"):
+            _, xf = eng.sample_loop(plan, sch, x0, feats, restage=False, **kw)
+    xf.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(xf).all() and torch.equal(xf, ref)
+    g.replay()                                                      # (a second replay: the captured loop is self-contained)
+    torch.cuda.synchronize()
+    assert torch.equal(xf, ref)

@@ -901,3 +901,28 @@ def test_real_ddp_wrapper_without_find_unused_parameters_fails_loudly(dev):
     mp.spawn(_ddp_wrapper_worker, args=(2, _free_port(), False, ret), nprocs=2, join=True)
     for r in (0, 1):
         assert "Expected to have finished reduction" in ret[f"err_False_{r}"], ret[f"err_False_{r}"]
+
+
+def test_p_losses_glue_kernels_equal_the_torch_expressions(dev):
+    """da_q_sample / da_loss_grad (the ~11 torch launches of p_losses' glue as two library launches): q_sample bit for bit
+    the reference's expression (spatial_diffusion.py:421-430); every loss of p_losses (:470-480) to fp32 summation-order accuracy and its gradient
+    with respect to the prediction bit for bit what autograd gives the torch form."""
+    import torch.nn.functional as F
+    from diffassemble_amd.model.spatial_diffusion import GNN_Diffusion, ModelMeanType, _FusedLoss, extract
+    m = GNN_Diffusion(steps=100, sampling="DDIM", model_mean_type=ModelMeanType.START_X, visual_pretrained=False).to(dev)
+    g = torch.Generator().manual_seed(0)
+    n, c = 9216, 4
+    x0, nz = torch.randn((n, c), generator=g).to(dev), torch.randn((n, c), generator=g).to(dev)
+    t = torch.randint(0, 100, (64,), generator=g).repeat_interleave(144).to(dev)
+    ref = extract(m.sqrt_alphas_cumprod, t) * x0 + extract(m.sqrt_one_minus_alphas_cumprod, t) * nz
+    assert torch.equal(m.q_sample(x0, t, nz), ref)
+    for kind, fn in ((0, F.l1_loss), (1, F.mse_loss), (2, F.smooth_l1_loss)):
+        target = (3.0 * torch.randn((n, c), generator=g)).to(dev)
+        pred = torch.randn((n, c), generator=g).to(dev).requires_grad_(True)
+        lr = fn(target, pred)
+        (gr,) = torch.autograd.grad(lr * 1.5, pred)
+        pred2 = pred.detach().clone().requires_grad_(True)
+        lf = _FusedLoss.apply(pred2, target, kind)
+        (gf,) = torch.autograd.grad(lf * 1.5, pred2)
+        assert abs(float(lf) - float(lr)) < 2e-6 * abs(float(lr)), (kind, float(lf), float(lr))
+        assert torch.equal(gf, gr) or float((gf - gr).abs().max()) <= 2e-12, (kind, float((gf - gr).abs().max()))
