@@ -759,7 +759,15 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
     // consumption (at tile t it posts its pieces of tiles <= 3 t + 1, which landed long before anybody needs them), so that nobody waits on a
     // slow partner -- and polls the word of tile t + 1 before it requests that tile's first K fragments.  The only barrier left orders the
     // zeroing of the words before the first post (at kernel start, with the requests in flight).
-    constexpr bool O2 = (XV & 1) != 0, PROG = (XV & 16) != 0;
+    // bit 5 (32) = ADJACENCY-MASKED (round 6): the hidden layers of hybrid (Exphander) graphs in the resident form.  Per
+    // (32-query slab, 32-key block): class 0 (no edge) blocks are skipped, class 2 (all edges) run unmasked, class 1 blocks take this lane's 16
+    // adjacency bits (one 2-byte load, requested one block ahead) as the 0 / -inf initial value of the score accumulator, exactly as
+    // k_attn_optt<MASKED> does; a slab's classes are two 64-bit ballots (lane b fetches the class of block b).  The remainder edges of a query (the exophormer's
+    // virtual -> real edge, duplicates) are folded in REGISTERS behind the key loop -- score from this lane's Q fragments and the source's K
+    // row, the value row's channels this lane owns -- in the same un-shifted (or, in the running-max pass, shifted) softmax state, so the
+    // per-wave verification covers them and no LDS staging is needed; output rows go to the slot's node (rm_meta / slot_node).
+    constexpr bool O2 = (XV & 1) != 0, PROG = (XV & 16) != 0, MSK = (XV & 32) != 0;
+    static_assert(!MSK || (NWV == 16 && KPF && !PROG && !O2), "masked resident instance: sixteen waves, K fragments one block ahead");
     static_assert(!PROG || (NWV == 16 && KPF), "progressive landing: the sixteen-wave instance (two waves per piece index), K fragments one block ahead");
     using T = bf16_t;
     constexpr int C = 32, CV = 32;
@@ -791,6 +799,8 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     unsigned *qctr = (unsigned *)(smem + ((p.max_nodes + 63) >> 6) * STAGE);
     volatile unsigned *land = qctr + 4;         // PROG: [nkt] pieces landed per stage (launch_res sizes the LDS for them)
+    float *mlut = (float *)(qctr + 36);         // MSK: nibble -> four accumulator initial values (0 / -inf), 256 B
+    if (MSK && tid < 64) mlut[tid] = (((tid >> 2) >> (tid & 3)) & 1) ? 0.f : -INFINITY;
     if (QUEUE && tid == 0) { *qctr = 0u; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }      // (nobody draws before the landing barrier)
     if (PROG && tid < 32) { land[tid] = 0u; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     int node0 = 0, n_g = 0;
@@ -1018,6 +1028,167 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
                 }
             }
         };
+        // ---- MSK: this slab's block classes, this lane's adjacency row and its query's remainder record
+        [[maybe_unused]] unsigned long long nzm = 0, fullm = 0;          // blocks with some edge / with every edge
+        [[maybe_unused]] const unsigned char *mrow2 = nullptr;           // this lane's 16 bits of block b: *(ushort *)(mrow2 + 4 b)
+        [[maybe_unused]] int rbeg = 0, rend = 0, rslot = 0, my_node = node0 + min(qidx, n_g - 1);
+        [[maybe_unused]] unsigned anym = 0;                               // this lane saw an edge (any adjacency bit, a full block, a remainder edge)
+        if constexpr (MSK) {
+            const int slots = p.pad_ptr[g + 1] - pad0;
+            unsigned cl = 1u;                                             // (no class table: every block partial)
+            if (p.blk_class && lane < nslab) cl = (p.blk_class + p.blk_class_ptr[g] + (size_t)slab * (size_t)p.blk_class_stride)[lane];
+            if (lane >= nslab) cl = 0u;
+            nzm = __ballot(cl != 0u);
+            fullm = __ballot(cl == 2u);
+            mrow2 = p.mask + p.mask_ptr[g] + (size_t)min(qidx, n_g - 1) * (size_t)(slots >> 3) + 2 * half;
+            if (p.rm_meta) {
+                typedef __attribute__((ext_vector_type(4))) int i32x4;
+                const i32x4 mt = ((const i32x4 *)p.rm_meta + pad0)[min(qidx, n_g - 1)];
+                rbeg = qidx < n_g ? mt[0] : 0; rend = qidx < n_g ? mt[1] : 0; rslot = mt[2]; my_node = mt[3];
+            } else {
+                my_node = p.slot_node ? p.slot_node[pad0 + min(qidx, n_g - 1)] : node0 + min(qidx, n_g - 1);
+                if (qidx < n_g) { rbeg = p.irr_row_ptr[my_node]; rend = p.irr_row_ptr[my_node + 1]; }
+                rslot = rend > rbeg ? p.row_map[p.irr_col_src[rbeg]] : pad0;
+            }
+        }
+        auto pass_masked = [&]() {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[r] = 0.f;
+            ls = 0.f;
+            m = -1e30f;
+            unsigned long long rem = nzm;
+            if (rem) {
+                int b = __builtin_ctzll(rem);
+                rem &= rem - 1ull;
+                u32x4 kf[CF::NCH];
+#pragma unroll
+                for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(smem + boff(b) + kfo[ch]);
+                unsigned mw_n = ((fullm >> b) & 1ull) ? 0xffffu : *(const unsigned short *)(mrow2 + 4 * b);
+                while (true) {
+                    const int bo = boff(b);
+                    const bool full = (fullm >> b) & 1ull;                 // wave-uniform
+                    const unsigned mw = mw_n;
+                    anym |= mw;
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x16 s;
+                    if (full) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 b4 = *(const f32x4 *)((const unsigned char *)mlut + (((mw >> (4 * j)) & 15u) << 4));
+                            s[4 * j] = b4[0]; s[4 * j + 1] = b4[1]; s[4 * j + 2] = b4[2]; s[4 * j + 3] = b4[3];
+                        }
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), kf[ch], qf[ch], s);
+                    asm volatile("" : "+v"(s));
+                    u32x2 vlo[2], vhi[2];
+                    const unsigned vb = vbase + (unsigned)bo;
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) {
+                        vlo[mm] = tr_read(vb, (8 * mm) * CF::RSV);
+                        vhi[mm] = tr_read(vb, (8 * mm + 4) * CF::RSV);
+                    }
+                    const bool last = rem == 0ull;
+                    int bn = b;
+                    if (!last) {                 // the next block with an edge: its K fragments (and adjacency bits) land under this block's exponentials
+                        bn = __builtin_ctzll(rem);
+                        rem &= rem - 1ull;
+                        const int bon = boff(bn);
+#pragma unroll
+                        for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(smem + bon + kfo[ch]);
+                        mw_n = ((fullm >> bn) & 1ull) ? 0xffffu : *(const unsigned short *)(mrow2 + 4 * bn);
+                    }
+                    if (gen) {
+                        const float a0 = fmaxf(fmaxf(s[0], s[1]), s[2]), a1 = fmaxf(fmaxf(s[3], s[4]), s[5]);
+                        const float a2 = fmaxf(fmaxf(s[6], s[7]), s[8]), a3 = fmaxf(fmaxf(s[9], s[10]), s[11]);
+                        const float a4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+                        const float mloc = fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), s[15]));
+                        const float mnew = fmaxf(m, fmaxf(mloc, __shfl_xor(mloc, 32)));
+                        if (__any(mnew > m)) {
+                            const float corr = __builtin_amdgcn_exp2f(m - mnew);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) O[r] *= corr;
+                            ls *= corr;
+                            m = mnew;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[r] -= m;
+                    }
+                    bf16x8 pf0, pf1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = __builtin_amdgcn_exp2f(s[2 * e]), x1 = __builtin_amdgcn_exp2f(s[2 * e + 1]);
+                        const float y0 = __builtin_amdgcn_exp2f(s[8 + 2 * e]), y1 = __builtin_amdgcn_exp2f(s[8 + 2 * e + 1]);
+                        pf0[2 * e] = (__bf16)x0; pf0[2 * e + 1] = (__bf16)x1;
+                        pf1[2 * e] = (__bf16)y0; pf1[2 * e + 1] = (__bf16)y1;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]));
+                    const u32x4 v0 = {vlo[0][0], vlo[0][1], vhi[0][0], vhi[0][1]};
+                    const u32x4 v1 = {vlo[1][0], vlo[1][1], vhi[1][0], vhi[1][1]};
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf0, O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf1, O, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16x2 pa = {pf0[2 * e], pf0[2 * e + 1]}, pb = {pf1[2 * e], pf1[2 * e + 1]};
+                        ls = __builtin_amdgcn_fdot2_f32_bf16(pa, one2, ls, false);
+                        ls = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, ls, false);
+                    }
+                    if (last) break;
+                    b = bn;
+                }
+            }
+            // ---- the query's remainder edges, in the same softmax state.  Lane (i, half) holds channels 16 ch + 8 half .. + 7 of its query in
+            // qf[ch] (the score's other half comes from lane i of the other half-wave) and channels 8 jj + 4 half .. + 3 of the output in O.
+            int nrem = rend - rbeg;                                        // the wave walks as many rounds as its longest list
+#pragma unroll
+            for (int o_ = 32; o_ > 0; o_ >>= 1) nrem = max(nrem, __shfl_xor(nrem, o_));
+            nrem = __builtin_amdgcn_readfirstlane(nrem);
+            for (int k = 0; k < nrem; ++k) {
+                const bool on = rbeg + k < rend;
+                size_t sj = (size_t)h * np + (size_t)(k == 0 ? rslot : p.row_map[p.irr_col_src[on ? rbeg + k : max(rbeg, 0)]]);
+                const unsigned char *kr = (const unsigned char *)p.K + sj * CF::ROWB, *vr = (const unsigned char *)p.Vt + sj * CF::ROWBV;
+                float sc_ = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < CF::NCH; ++ch) {
+                    const u32x4 kk = *(const u32x4 *)(kr + ch * 32 + half * 16);
+#pragma unroll
+                    for (int w_ = 0; w_ < 4; ++w_) {
+                        sc_ = fmaf(bf2f((bf16_t)(qf[ch][w_] & 0xffff)), bf2f((bf16_t)(kk[w_] & 0xffff)), sc_);
+                        sc_ = fmaf(bf2f((bf16_t)(qf[ch][w_] >> 16)), bf2f((bf16_t)(kk[w_] >> 16)), sc_);
+                    }
+                }
+                sc_ += __shfl_xor(sc_, 32);                               // log2 units (Q is pre-scaled)
+                u32x2 vv[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) vv[jj] = *(const u32x2 *)(vr + (8 * jj + 4 * half) * 2);
+                if (gen) {
+                    const float mnew = on ? fmaxf(m, sc_) : m;
+                    if (mnew > m) {
+                        const float corr = __builtin_amdgcn_exp2f(m - mnew);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[r] *= corr;
+                        ls *= corr;
+                        m = mnew;
+                    }
+                    sc_ -= m;
+                }
+                const float pe = on ? __builtin_amdgcn_exp2f(sc_) : 0.f;
+                anym |= on ? 1u : 0u;
+                if (half == 0) ls += pe;                                  // (the row sum is the two half-waves' shares added up)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    O[4 * jj] = fmaf(pe, bf2f((bf16_t)(vv[jj][0] & 0xffff)), O[4 * jj]);
+                    O[4 * jj + 1] = fmaf(pe, bf2f((bf16_t)(vv[jj][0] >> 16)), O[4 * jj + 1]);
+                    O[4 * jj + 2] = fmaf(pe, bf2f((bf16_t)(vv[jj][1] & 0xffff)), O[4 * jj + 2]);
+                    O[4 * jj + 3] = fmaf(pe, bf2f((bf16_t)(vv[jj][1] >> 16)), O[4 * jj + 3]);
+                }
+            }
+        };
+        if constexpr (MSK) pass_masked(); else
         pass(PROG && round == 0);
         if (PROG && round == 0) post_upto(1 << 30);          // (every piece posted before this wave issues another vector-memory operation)
         if (O2) {
@@ -1028,10 +1199,12 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
         if (!gen) {
             // verification of the optimistic pass, per WAVE (the waves share nothing but the resident tiles)
             const float lt0 = ls + __shfl_xor(ls, 32);
-            const bool ok = lt0 > 8.673617379884035e-19f && lt0 < 1.2676506002282294e30f;        // 2^-60, 2^100; NaN fails
+            bool ok = lt0 > 8.673617379884035e-19f && lt0 < 1.2676506002282294e30f;        // 2^-60, 2^100; NaN fails
+            if (MSK) ok = ok || (lt0 == 0.f && (anym | (unsigned)__shfl_xor((int)anym, 32)) == 0u);          // a row without a single edge
             if (__any(!ok && qidx < n_g)) {
                 gen = true;
-                if (lane == 0) atomicAdd(&g_opt_fallbacks[0], 1ull);
+                if (lane == 0) atomicAdd(&g_opt_fallbacks[MSK ? 1 : 0], 1ull);
+                if constexpr (MSK) pass_masked(); else
                 pass(false);
                 if (O2) {
 #pragma unroll
@@ -1052,7 +1225,7 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
         const float lt = ls + __shfl_xor(ls, 32);
         const float inv = lt > 0.f ? 1.0f / (lt + (gen ? 1e-16f : 0.f)) : 0.f;      // (no epsilon on an un-shifted sum: see the header)
         if (qidx < n_g) {
-            const size_t roff = (size_t)(node0 + qidx) * HC + (size_t)h * C + 4 * half;
+            const size_t roff = (size_t)(MSK ? my_node : node0 + qidx) * HC + (size_t)h * C + 4 * half;
             u32x2 sk[4], rs[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -1095,7 +1268,7 @@ long long attn_res_launches(int reset) {
 
 template <int NWV, bool QUEUE, bool KPF, int XV = 0>
 static int launch_res(const AttnDenseParams &p, hipStream_t st) {
-    const int lds = ((p.max_nodes + 63) >> 6) * OptK<32, 64>::STAGE + 16 + 128;          // + the queue word + the landing words (XV & 16)
+    const int lds = ((p.max_nodes + 63) >> 6) * OptK<32, 64>::STAGE + 16 + 128 + 256;          // + the queue word + the landing words (XV & 16) + the mask table (XV & 32)
     static bool attr_done[16] = {};
     int dev = 0;
     DA_CHECK_HIP(hipGetDevice(&dev));
@@ -1125,6 +1298,10 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
 #ifdef DA_EXPERIMENTS
             if (DA_XENV("DA_OPT_MASKED_VAR", 0) == 30) return launch_optt<32, false, true, 4, 4, 64, 256>(p, st);
 #endif
+            // large hybrid graphs (the Exphander configuration): the K / V-resident form with adjacency masks (round 6), same size rule as below
+            if (cfg().attn_level >= 2 && DA_XENV("DA_ATTN_RES_MASKED", 1) && p.max_nodes >= 512 && p.max_nodes <= 19 * 64 - 64 &&
+                (long long)p.n_pad * 2 >= (long long)p.n_graphs * p.max_nodes)
+                return launch_res<16, true, true, 32>(p, st);
             return launch_optt<32, false, true, 4, 4>(p, st);
         }
         [[maybe_unused]] const int v = DA_XENV("DA_OPT_HID", 0);
