@@ -50,7 +50,7 @@ F_NODE = 6_432_128          # FLOP per piece per step (SURVEY 8d / BASELINE.md)
 F_EDGE = 7_680              # FLOP per edge per step, all 4 layers
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0                            # MI355X_MICROARCH.md (HBM3E spec; ~6300 achievable)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 CONFIGS = {
     "1": dict(name="6x6 translation-only (N=36, K36 without self loops, E=1260), DDIM T=50, EPSILON, c=2, transformer arch",

@@ -1298,10 +1298,15 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
 #ifdef DA_EXPERIMENTS
             if (DA_XENV("DA_OPT_MASKED_VAR", 0) == 30) return launch_optt<32, false, true, 4, 4, 64, 256>(p, st);
 #endif
-            // large hybrid graphs (the Exphander configuration): the K / V-resident form with adjacency masks (round 6), same size rule as below
-            if (cfg().attn_level >= 2 && DA_XENV("DA_ATTN_RES_MASKED", 1) && p.max_nodes >= 512 && p.max_nodes <= 19 * 64 - 64 &&
+#ifdef DA_EXPERIMENTS
+            // OPT-IN (DA_ATTN_RES_MASKED=1): the K / V-resident form with adjacency masks (round 6, k_attn_res<16, true, true, 32>).  Parity-clean
+            // (the whole hybrid suite at 900 pieces), and measured in one process, ten interleaved pairs (profiles/r06/r06_masked_resident_config3_ab.log):
+            // configuration 3 at d = 90 -1.2 % (10 of 10), at the scripted d = 539 +7.2 % (0 of 10) -- its one sixteen-wave workgroup per CU leaves
+            // no room for the virtual rows' kernel (k_attn_csr_cont_heavy: 16 waves x 128 registers), which the four-wave ring kernel runs beside.
+            if (cfg().attn_level >= 2 && DA_XENV("DA_ATTN_RES_MASKED", 0) && p.max_nodes >= 512 && p.max_nodes <= 19 * 64 - 64 &&
                 (long long)p.n_pad * 2 >= (long long)p.n_graphs * p.max_nodes)
                 return launch_res<16, true, true, 32>(p, st);
+#endif
             return launch_optt<32, false, true, 4, 4>(p, st);
         }
         [[maybe_unused]] const int v = DA_XENV("DA_OPT_HID", 0);

@@ -3,7 +3,7 @@
 # da::launch_attn_dense on the benched shapes, production dispatch): MFMA busy cycles, VALU / MFMA instruction counts, waits.
 # Counters in their own passes with --kernel-trace only (MI355X_MICROARCH.md).   usage: bash tools/collect_attn_pmc.sh
 set -u
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 REPO=$(pwd); OUT=$REPO/gpurun_out; export TMPDIR=/tmp; cd /tmp
 F=$OUT/${ROUND}_pmc_attention_sq.txt; : > $F
 for GP in 64 32; do       # 64 puzzles per launch (one-branch loop) and 32 (what each branch of the default two-branch graph launches)

@@ -4,7 +4,7 @@
 # --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, rocprofv3 PMC slots).
 #   usage: bash tools/collect_profiles.sh <tag> <bench args...>      e.g.  headline --config 3p
 set -u
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 TAG=$1; shift
 REPO=$(pwd)
 OUT=$REPO/gpurun_out

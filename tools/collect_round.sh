@@ -3,7 +3,7 @@
 # configuration-3 variants, SQ counters of the attention and projection kernels, and one bench line per configuration / mode.
 # Outputs go to gpurun_out/<round>_*; copy them to profiles/<round>/ afterwards.    usage: ROUND=r03 bash tools/collect_round.sh
 set -u
-export ROUND=${ROUND:-r05}
+export ROUND=${ROUND:-r06}
 O=gpurun_out
 bash tools/collect_profiles.sh headline --config 3p
 bash tools/collect_profiles.sh headline_half --config 3p --puzzles 32     # the launch shape of each branch of the default two-branch loop

@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 CLASS = [  # (regex on the kernel name, class)
     (r"k_attn_res<", "attn_hidden"), (r"k_attn_optt<32", "attn_hidden"), (r"k_attn_optt<144", "attn_last"), (r"k_attn_opt\(", "attn_hidden"),
     (r"k_attn_dual<144", "attn_last"), (r"k_attn_dual<32", "attn_hidden"),
