@@ -168,7 +168,7 @@ static int launch_t(int n_nodes, const int32_t *row_ptr, const int32_t *col_src,
 // k_attn_dense<.., MASKED> (its epilogue folds their few remainder edges into the same softmax); the virtual
 // nodes of the exophormer arch (exophormer_gnn.py:183-200) have NO regular edge and are attended here over
 // the remainder CSR, reading Q / K / V from the head-major padded layouts the projection scattered.
-constexpr int HEAVY_DEG = 128, HEAVY_WAVES = 16;
+constexpr int HEAVY_WAVES = 16;
 
 // Rows with a long remainder list -- the exophormer virtual nodes: ~n_g incoming edges each, most of them
 // the duplicated virtual->virtual pairs -- get a whole 16-wave workgroup: wave w walks edges w, w+16, ...,
@@ -187,7 +187,8 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
     const int i = n_real + blockIdx.x;
     if (i >= n_nodes) return;
     const int beg = row_ptr[i], end = row_ptr[i + 1];
-    if (end - beg <= HEAVY_DEG) return;                  // light row: k_attn_csr_cont
+    // (round 6: light rows too -- sixteen waves with a handful of edges each; they used to return here and leave the row to a second launch,
+    //  k_attn_csr_cont, 5 - 6 us per layer on the critical path of the scripted Batches)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int head = lane >> 3, sub = (lane & 7) * EPL;
     const size_t hb = (size_t)head * n_pad;
@@ -201,20 +202,33 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
     // latency serves four softmax updates (the walk used to be one dependent chain per edge)
     // (C = 144 in fp32: four edges' K and V rows would be 144 registers beside q and acc under this kernel's 128 -- two there, no spills)
     constexpr int U = (EPL > 8 && sizeof(T) == 4) ? 2 : 4;
+    // (round 6) the trip's source slots -- col_src -> row_map: two dependent index loads -- are fetched ONE TRIP AHEAD, under the K / V loads and the
+    // softmax updates of the current trip: a trip is then one memory round trip (the rows), not three
+    size_t sjn[U];
+    bool okn[U];
+    float wgtn[U];
+    auto fetch_idx = [&](int e0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * HEAVY_WAVES;
+            okn[u] = e < end;
+            sjn[u] = hb + (size_t)row_map[col_src[okn[u] ? e : beg]];
+            wgtn[u] = mult ? mult[okn[u] ? e : beg] : 1.0f;
+        }
+    };
+    constexpr bool PFI = EPL <= 8;          // (144-wide heads: no registers left for a second set of indices under this kernel's 128)
+    if (PFI && beg + wv < end) fetch_idx(beg + wv);
     for (int e0 = beg + wv; e0 < end; e0 += HEAVY_WAVES * U) {
         size_t sj[U];
         bool ok[U];
         float wgt[U];                                        // multiplicity of the (aggregated) edge, 1 without `mult`
+        if (!PFI) fetch_idx(e0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * HEAVY_WAVES;
-            ok[u] = e < end;
-            sj[u] = hb + (size_t)row_map[col_src[ok[u] ? e : beg]];
-            wgt[u] = mult ? mult[ok[u] ? e : beg] : 1.0f;
-        }
+        for (int u = 0; u < U; ++u) { sj[u] = sjn[u]; ok[u] = okn[u]; wgt[u] = wgtn[u]; }
         float kk[U][EPL], vv[U][EPL];
 #pragma unroll
         for (int u = 0; u < U; ++u) { ld_row<T, EPL>(K + sj[u] * C + sub, kk[u]); ld_row<T, EPL>(V + sj[u] * C + sub, vv[u]); }
+        if (PFI && e0 + HEAVY_WAVES * U < end) fetch_idx(e0 + HEAVY_WAVES * U);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;                            // wave-uniform
@@ -263,62 +277,11 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
     }
 }
 
-template <typename T, int EPL>
-__global__ __launch_bounds__(256) void k_attn_csr_cont(int n_nodes, int n_real, const int32_t *__restrict__ row_ptr,
-                                                       const int32_t *__restrict__ col_src,
-                                                       const int32_t *__restrict__ row_map, int H, int C, size_t n_pad,
-                                                       const T *__restrict__ Q, const T *__restrict__ K,
-                                                       const T *__restrict__ V, const T *__restrict__ skip,
-                                                       const T *__restrict__ residual, int act, T *__restrict__ out,
-                                                       float scale, const float *__restrict__ mult) {
-    const int lane = threadIdx.x & 63;
-    const int i = n_real + (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (i >= n_nodes) return;
-    if (row_ptr[i + 1] - row_ptr[i] > HEAVY_DEG) return;     // k_attn_csr_cont_heavy owns this row
-    const int head = lane >> 3, sub = (lane & 7) * EPL;
-    const size_t hb = (size_t)head * n_pad;
-    const size_t si = hb + (size_t)row_map[i];
-    float q[EPL], acc[EPL];
-    float m = -INFINITY, l = 0.f;
-    ld_row<T, EPL>(Q + si * C + sub, q);
-#pragma unroll
-    for (int x = 0; x < EPL; ++x) { q[x] *= scale; acc[x] = 0.f; }
-    const int beg = row_ptr[i], end = row_ptr[i + 1];
-    for (int e = beg; e < end; ++e) {
-        const size_t sj = hb + (size_t)row_map[col_src[e]];
-        float kk[EPL], vv[EPL];
-        ld_row<T, EPL>(K + sj * C + sub, kk);
-        ld_row<T, EPL>(V + sj * C + sub, vv);
-        float s = 0.f;
-#pragma unroll
-        for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[x], s);
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        const float mn = fmaxf(m, s);
-        const float corr = expf(m - mn);
-        const float pr = expf(s - mn) * (mult ? mult[e] : 1.0f);
-        l = l * corr + pr;
-#pragma unroll
-        for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pr, vv[x], acc[x] * corr);
-        m = mn;
-    }
-    const float inv = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;
-    const size_t o = (size_t)i * H * C + (size_t)head * C + sub;
-#pragma unroll
-    for (int x = 0; x < EPL; ++x) {
-        float v = acc[x] * inv + ldf(skip + o + x);
-        if (residual) v += ldf(residual + o + x);
-        stf(out + o + x, apply_act(v, act));
-    }
-}
-
 template <typename T>
 static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32_t *cs, const int32_t *row_map, int H, int C,
                          int n_pad, const DenseLayout &L, const T *residual, int act, T *out, hipStream_t st, const float *mult) {
     if (n_nodes <= n_real) return 0;
     const float scale = L.q_prescaled ? 0.6931471805599453f : 1.0f / sqrtf((float)C);      // pre-scaled Q: q . k is in log2 units
-    const int grid = (int)(((size_t)(n_nodes - n_real) * 64 + 255) / 256);
 #define DA_CONT_CASE(E)                                                                                          \
     case E:                                                                                                      \
         if (n_nodes > n_real) {                                                                                  \
@@ -333,9 +296,6 @@ static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32
                 n_nodes, n_real, rp, cs, row_map, H, C, (size_t)n_pad, (const T *)L.Q, (const T *)L.K,           \
                 (const T *)L.Vt, (const T *)L.S, residual, act, out, scale, mult);                               \
         }                                                                                                        \
-        k_attn_csr_cont<T, E><<<grid, 256, 0, st>>>(n_nodes, n_real, rp, cs, row_map, H, C, (size_t)n_pad,       \
-                                                    (const T *)L.Q, (const T *)L.K, (const T *)L.Vt, (const T *)L.S, \
-                                                    residual, act, out, scale, mult);                            \
         break;
     switch (C / 8) {
         DA_CONT_CASE(4) DA_CONT_CASE(18)

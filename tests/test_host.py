@@ -467,3 +467,38 @@ def test_no_kernel_of_the_product_build_spills_vector_registers():
         pytest.skip("no objects in diffassemble_amd/lib (library built elsewhere)")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py"), "--vgpr-spills", "--libdir", lib], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_expander_plan_banded_argument_and_training_route(monkeypatch):
+    """(1) `expander_plan(..., banded=False)` exists and gives the natural slot order whatever DA_EXPANDER_LAYOUT says (the advice the
+    training path's refusal of banded plans gives can be followed); (2) `TrainEngine._edge_list_route`: fp32 training keeps the edge-list kernels
+    for hybrid plans that are only hybrid under the inference thresholds (small graphs, low density, pair matrices beyond the cap), the bf16-operand
+    mode (flash-style, no pair matrices) and forced plans always take the hybrid kernels."""
+    import types
+    import torch
+    from diffassemble_amd import expander
+    from diffassemble_amd.graph_plan import expander_plan
+    from diffassemble_amd.train import TrainEngine
+    rng = np.random.default_rng(0)
+    perms = torch.stack([torch.from_numpy(rng.permutation(64)) for _ in range(3)])
+    monkeypatch.setenv("DA_EXPANDER_LAYOUT", "banded")
+    monkeypatch.setenv("DA_HYBRID", "force")
+    pb = expander_plan(perms, 20, "cpu", 8)
+    pn = expander_plan(perms, 20, "cpu", 8, banded=False)
+    assert pb.hybrid and pn.hybrid and pb.slot_node is not None and pn.slot_node is None
+    monkeypatch.setenv("DA_EXPANDER_LAYOUT", "natural")
+    assert expander_plan(perms, 20, "cpu", 8, banded=True).slot_node is not None
+    monkeypatch.delenv("DA_HYBRID")
+
+    def route(precision, n, G, n_edges, hybrid=1, cap=8192):
+        eng = types.SimpleNamespace(precision=precision, n_layers=4, pair_cap_mb=cap)
+        plan = types.SimpleNamespace(hybrid=hybrid, dense=0, max_graph_nodes=n, n_graphs=G, n_edges=n_edges)
+        return TrainEngine._edge_list_route(eng, plan)
+    assert route("fp32", 900, 16, int(0.6 * 16 * 900 * 900)) is False           # the scripted exophormer Batch: pair matrices
+    assert route("fp32", 144, 64, int(0.6 * 64 * 144 * 144)) is True            # small graphs: edge list in fp32 ...
+    assert route("bf16", 144, 64, int(0.6 * 64 * 144 * 144)) is False           # ... flash-style hybrid kernels in the bf16-operand mode
+    assert route("fp32", 900, 16, int(0.02 * 16 * 900 * 900)) is True           # 2 % density: below the training threshold
+    assert route("fp32", 900, 64, int(0.6 * 64 * 900 * 900), cap=1024) is True  # pair matrices beyond the cap
+    assert route("fp32", 900, 16, 10, hybrid=0) is False                        # not a hybrid plan: nothing to re-route
+    monkeypatch.setenv("DA_HYBRID", "force")
+    assert route("fp32", 144, 64, int(0.6 * 64 * 144 * 144)) is False           # the caller asked for the hybrid kernels
