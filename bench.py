@@ -1123,34 +1123,40 @@ def ragged_bench(args, world, rank, dev):
     # and an exophormer Batch cannot be split (its virtual-node edges couple its puzzles) -- but a second Batch of the same shape can run beside it
     in_flight = None
     if _lib.config().pair_split:
-        rng2 = np.random.default_rng(120 + rank)
-        ei2, batch2, _ = expander.ragged_regular_batch(sides, pct, rng2, dev)
-        plan2 = eng.plan(ei2, batch2)
-        gen2 = torch.Generator(device=dev).manual_seed(177 + rank)
-        feats2 = torch.randn((N, 1088), generator=gen2, device=dev)
-        x_T2 = torch.randn((N, 4), generator=gen2, device=dev)
+        extra = []
+        for j in range(3):
+            rngj = np.random.default_rng(120 + 7 * j + rank)
+            eij, batchj, _ = expander.ragged_regular_batch(sides, pct, rngj, dev)
+            genj = torch.Generator(device=dev).manual_seed(177 + j + rank)
+            extra.append((eng.plan(eij, batchj), torch.randn((N, 4), generator=genj, device=dev), torch.randn((N, 1088), generator=genj, device=dev)))
+        in_flight = {"note": "independent Batches of this shape in flight (DenoiserEngine.sample_loop_batches: N = 2 through da_sample_loop_pair, N = 4 as four loop "
+                             "graphs on four streams); rank-local medians; the line's value / ms_per_step are ONE Batch in flight"}
+        for nb in (2, 4):
+            ps_ = [plan] + [e[0] for e in extra[:nb - 1]]
+            xs_ = [x_T] + [e[1] for e in extra[:nb - 1]]
+            fs_ = [feats] + [e[2] for e in extra[:nb - 1]]
 
-        def run2(n_iters, restage=False):
-            return eng.sample_loop_batches([plan, plan2], sch, [x_T, x_T2], [feats, feats2], ratio=ratio, mean_type=_lib.MEAN_START_X, max_iters=n_iters,
-                                           restage=restage)
-        run2(chunks[0], restage=True)
-        for ck in sorted(set(chunks)):
-            run2(ck)
-        p2 = []
-        for _ in range(1 + min(max(args.replays, 0), 10)):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for ck in chunks:
-                xa2, xb2 = run2(ck)
-            torch.cuda.synchronize()
-            p2.append(time.perf_counter() - t0)
-        assert torch.isfinite(xa2).all() and torch.isfinite(xb2).all()
-        d2 = statistics.median(p2)
-        in_flight = {"batches": 2, "puzzles_per_batch": G, "ms_per_step_of_both": d2 / K * 1e3, "ms_per_batch_step": d2 / K * 1e3 / 2,
-                     "value": world * 2 * G * K / d2, "unit": "puzzle-steps/s", "vs_one_batch_in_flight": (2 * G * K / d2) / (G * K / dt),
-                     "note": "two independent Batches of this shape as two hipGraphs on two streams (da_sample_loop_pair), rank-local median of "
-                             f"{len(p2)} passes; the line's value / ms_per_step are ONE Batch in flight"}
-        del plan2, feats2, x_T2
+            def runn(n_iters, restage=False):
+                return eng.sample_loop_batches(ps_, sch, xs_, fs_, ratio=ratio, mean_type=_lib.MEAN_START_X, max_iters=n_iters, restage=restage)
+            runn(chunks[0], restage=True)
+            for ck in sorted(set(chunks)):
+                runn(ck)
+            pn = []
+            for _ in range(1 + min(max(args.replays, 0), 10)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for ck in chunks:
+                    outs = runn(ck)
+                torch.cuda.synchronize()
+                pn.append(time.perf_counter() - t0)
+            assert all(torch.isfinite(o).all() for o in outs)
+            dn = statistics.median(pn)
+            in_flight[str(nb)] = {"ms_per_step_of_all": dn / K * 1e3, "ms_per_batch_step": dn / K * 1e3 / nb, "value": world * nb * G * K / dn,
+                                  "unit": "puzzle-steps/s", "vs_one_batch_in_flight": (nb * G * K / dn) / (G * K / dt)}
+        # (kept under the old key too: N = 2)
+        in_flight.update({"batches": 2, "puzzles_per_batch": G, **{k: in_flight["2"][k] for k in ("ms_per_batch_step", "value", "unit", "vs_one_batch_in_flight")}})
+        del extra
+        eng.set_features(plan, feats)
         run(chunks[0], True)
 
     roof = None
@@ -1240,7 +1246,7 @@ def ragged_bench(args, world, rank, dev):
             "batch_steps_per_s": world * K / dt,
             "pieces_steps_per_s": world * N * K / dt,
             "algorithmic_tflops": world * (N * F_NODE + E * F_EDGE) * K / dt / 1e12,
-            "graph_plan_ms": plan_ms, "training_step_same_batch": train, "two_batches_in_flight": in_flight,
+            "graph_plan_ms": plan_ms, "training_step_same_batch": train, "batches_in_flight": in_flight,
             "roofline": roof, "cpu_baseline": cpu,
         }))
     if world > 1:

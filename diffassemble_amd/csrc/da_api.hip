@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #include "da_common.h"
@@ -127,6 +128,8 @@ struct da_denoiser {
     // captured into the sampling-loop hipGraph as two parallel branches.
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // (round 6, measured: a SECOND side stream for the second branch of two Batches in flight makes configuration 3 slower -- x0.98 against
+    //  x1.14 - 1.25 with this one shared; small Batches do not fork at all, see forward_impl)
     // da_sample_loop_pair: the second branch of the two-branch loop graph
     hipStream_t pair_stream = nullptr;
     hipEvent_t ev_pair_fork = nullptr, ev_pair_join = nullptr;
@@ -399,7 +402,9 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                     // sparse-but-heavy graphs: masked MFMA attention over the regular edges (partial softmax
                     // state), then the remaining edges + normalisation + skip / activation on the CSR side
                     const DenseMask mk = dense_mask_of(g);
-                    if (d->side_stream && !d->prof_on && n > nr) {
+                    // (small Batches keep the virtual rows on the caller's stream: below ~8 k pieces the fork / join costs more than the overlap
+                    //  buys -- the scripted 8-puzzle Batch: 0.165 -> 0.152 ms per step, profiles/r06/r06_scripted_side_stream_variants.log)
+                    if (d->side_stream && !d->prof_on && n > nr && g->n_real >= 8192) {
                         // fork: virtual rows on the side stream, real rows here, join before the next projection
                         DA_CHECK_HIP(hipEventRecord(d->ev_fork, st));
                         DA_CHECK_HIP(hipStreamWaitEvent(d->side_stream, d->ev_fork, 0));
@@ -874,7 +879,7 @@ int da_sample_loop_ex(da_denoiser *d, const da_graph *g, const da_schedule *s, i
     for (auto &e : d->loops)
         if (memcmp(&key, &e.key, sizeof(key)) == 0) exec = e.exec;
     if (!exec) {
-        if (d->loops.size() >= 4) {                       // small LRU-less cache: drop the oldest
+        if (d->loops.size() >= 8) {                       // small LRU-less cache: drop the oldest (eight: four Batches in flight x two loop lengths)
             (void)hipGraphExecDestroy(d->loops.front().exec);
             d->loops.erase(d->loops.begin());
         }

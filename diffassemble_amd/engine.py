@@ -357,29 +357,34 @@ class DenoiserEngine:
         return traj, xf
 
     def sample_loop_batches(self, plans, sched: Schedule, x_inits, feats, *, ratio=1, mean_type=_lib.MEAN_START_X, max_iters=0, restage=True):
-        """TWO independent Batches in flight: their DDIM loops as two hipGraphs on two streams (da_sample_loop_pair), each Batch exactly the
-        computation ``sample_loop`` runs for it alone -- bit-identical poses.  This is how Batches that cannot be SPLIT get the two-stream
-        overlap: an exophormer Batch's virtual-node edges couple its puzzles (the quirk of exophormer_gnn.py:183-200 sends every real node
-        to the first graphs' virtual nodes), so half of it is a different computation, but two whole Batches are independent.  ``plans``,
-        ``x_inits``, ``feats``: pairs.  Returns (x_final_a, x_final_b), engine-owned (the next call of the same shapes overwrites them)."""
-        pa, pb = plans
+        """SEVERAL independent Batches in flight: their DDIM loops as hipGraphs on separate streams, each Batch exactly the computation
+        ``sample_loop`` runs for it alone -- bit-identical poses.  This is how Batches that cannot be SPLIT get the two-stream overlap: an
+        exophormer Batch's virtual-node edges couple its puzzles (the quirk of exophormer_gnn.py:183-200 sends every real node to the first
+        graphs' virtual nodes), so half of it is a different computation, but whole Batches are independent -- and how SMALL Batches (the
+        reference's scripted 8-puzzle ones leave most of the chip idle in every kernel) fill the chip.  ``plans``, ``x_inits``, ``feats``: lists
+        of equal length N >= 2.  N = 2 is one library call (da_sample_loop_pair: two graphs between a fork and a join event); N > 2 launches
+        each Batch's own loop graph (da_sample_loop) on a stream of the engine's between fork / join waits on the caller's stream.  Returns the
+        list of x_final tensors, engine-owned (the next call of the same shapes overwrites them)."""
+        n_b = len(plans)
+        assert n_b >= 2 and len(x_inits) == n_b and len(feats) == n_b
         if not _lib.config().pair_split or self._profiling:
-            return tuple(self.sample_loop(p, sched, x, f, ratio=ratio, mean_type=mean_type, max_iters=max_iters, keep_trajectory=False,
-                                          restage=restage)[1].clone() for p, x, f in zip(plans, x_inits, feats))
+            return [self.sample_loop(p, sched, x, f, ratio=ratio, mean_type=mean_type, max_iters=max_iters, keep_trajectory=False,
+                                     restage=restage)[1].clone() for p, x, f in zip(plans, x_inits, feats)]
         total = (sched.steps + ratio - 1) // ratio
         n_iters = min(max_iters, total) if max_iters and max_iters > 0 else total
         c = x_inits[0].shape[1]
         st = getattr(self, "_batches_state", None)
-        key = (id(pa), id(pb), c)
+        key = tuple(id(q) for q in plans) + (c,)
         if st is None or st["key"] != key:
             need_csr = [not ((q.dense or q.hybrid) and self.dense_only) for q in plans]
             gs = tuple(q.c_struct(nc) for q, nc in zip(plans, need_csr))
             need = [int(self.lib.da_denoiser_workspace_bytes(self.handle, C.byref(g))) for g in gs]
             st = self._batches_state = {
-                "key": key, "plans": (pa, pb), "g": gs,
+                "key": key, "plans": tuple(plans), "g": gs,
                 "ws": tuple(torch.empty(nb, dtype=torch.uint8, device=self.device) for nb in need),
                 "xi": tuple(torch.empty((q.n_real, c), dtype=torch.float32, device=self.device) for q in plans),
-                "xf": tuple(torch.empty((q.n_real, c), dtype=torch.float32, device=self.device) for q in plans), "staged": None}
+                "xf": tuple(torch.empty((q.n_real, c), dtype=torch.float32, device=self.device) for q in plans), "staged": None,
+                "streams": [torch.cuda.Stream(device=self.device) for _ in range(n_b)] if n_b > 2 else None}
         fkey = tuple((f.data_ptr(), f._version, tuple(f.shape)) for f in feats)
         if restage or st["staged"] != fkey:
             for q, g, ws, f in zip(plans, st["g"], st["ws"], feats):
@@ -389,12 +394,21 @@ class DenoiserEngine:
             st["staged"] = fkey
         for xi, x in zip(st["xi"], x_inits):
             xi.copy_(x)
-        (ga, gb), (wa, wb), (xa, xb), (fa, fb) = st["g"], st["ws"], st["xi"], st["xf"]
-        _lib.check(self.lib.da_sample_loop_pair(
-            self.handle, C.byref(sched.c), int(mean_type), int(ratio), int(n_iters),
-            C.byref(ga), _lib.ptr(xa), _lib.ptr(fa), _lib.ptr(wa), wa.numel(),
-            C.byref(gb), _lib.ptr(xb), _lib.ptr(fb), _lib.ptr(wb), wb.numel(), _lib.stream_ptr(self.device)))
-        return fa, fb
+        if n_b == 2:
+            (ga, gb), (wa, wb), (xa, xb), (fa, fb) = st["g"], st["ws"], st["xi"], st["xf"]
+            _lib.check(self.lib.da_sample_loop_pair(
+                self.handle, C.byref(sched.c), int(mean_type), int(ratio), int(n_iters),
+                C.byref(ga), _lib.ptr(xa), _lib.ptr(fa), _lib.ptr(wa), wa.numel(),
+                C.byref(gb), _lib.ptr(xb), _lib.ptr(fb), _lib.ptr(wb), wb.numel(), _lib.stream_ptr(self.device)))
+            return [fa, fb]
+        cur = torch.cuda.current_stream(self.device)
+        for g, ws, xi, xf, sx in zip(st["g"], st["ws"], st["xi"], st["xf"], st["streams"]):
+            sx.wait_stream(cur)
+            _lib.check(self.lib.da_sample_loop(self.handle, C.byref(g), C.byref(sched.c), int(mean_type), int(ratio), int(n_iters),
+                                               _lib.ptr(xi), None, _lib.ptr(xf), _lib.ptr(ws), ws.numel(), 1, C.c_void_p(sx.cuda_stream)))
+        for sx in st["streams"]:
+            cur.wait_stream(sx)
+        return list(st["xf"])
 
     # ------------------------------------------------------------------ measurement
     def profile(self, on=True):

@@ -136,3 +136,25 @@ def test_two_exophormer_batches_in_flight_equal_each_alone(dev, prec):
                                          mean_type=_lib.MEAN_START_X, max_iters=4)
         torch.cuda.synchronize()
         assert torch.isfinite(fa).all() and torch.equal(fa, alone[0]) and torch.equal(fb, alone[1])
+
+
+def test_four_small_batches_in_flight_equal_each_alone(dev):
+    """N = 4 Batches in flight (each on a stream of the engine's, da_sample_loop): bit for bit what every Batch computes alone."""
+    from diffassemble_amd import DenoiserEngine, Schedule, _lib
+    V = 8
+    sd = W.make_denoiser_state(300, 4, 4, arch="exophormer", virt_nodes=V, seed=73, qk_gain=3.0)
+    eng = DenoiserEngine(sd, variant="2d", arch="exophormer", virt_nodes=V, precision="bf16", device=dev)
+    sch = Schedule(ODF.make_schedule(300), dev)
+    items = []
+    for sides, seed in (([6, 16, 10, 8], 5), ([12, 8, 14, 6], 9), ([10, 10, 12], 11), ([8, 6, 16, 12, 6], 13)):
+        ei, batch, degs, x, feats, t = _batch(sides, seed, 60)
+        items.append((eng.plan(ei.to(dev), batch.to(dev)), x.to(dev), feats.to(dev)))
+    alone = []
+    for plan, x, f in items:
+        _, xf = eng.sample_loop(plan, sch, x, f, ratio=10, mean_type=_lib.MEAN_START_X, max_iters=4, keep_trajectory=False, use_graph=True)
+        alone.append(xf.clone())
+    for _ in range(2):
+        outs = eng.sample_loop_batches([it[0] for it in items], sch, [it[1] for it in items], [it[2] for it in items], ratio=10,
+                                       mean_type=_lib.MEAN_START_X, max_iters=4)
+        torch.cuda.synchronize()
+        assert len(outs) == 4 and all(torch.equal(o, a) for o, a in zip(outs, alone))
