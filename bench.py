@@ -187,15 +187,16 @@ def roofline_report(prof, kp, work, prec, traffic_file, cfg_key, G, gather_path=
     gather = (gather_path and dom in ("attn_hidden", "attn_last")) or dom in ("embed", "update")
     if gather:
         t = d.get("pmc_traffic_bytes_per_launch")
-        if t is not None:      # measured bytes at the L2's memory side (Infinity-Cache hits included): the honest figure, never > 1
-            roof = {"bound": "hbm", "kernel": dom, "achieved": d["pmc_traffic_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": d["pmc_traffic_GBps"] / HBM_PEAK_GBPS, "traffic": t, "frac_is": "PMC bytes (incl. MALL hits) / time / 8 TB/s",
-                    "algorithmic_GBps": d["compulsory_GBps"]}
-        else:
-            roof = {"bound": "hbm", "kernel": dom, "achieved": d["compulsory_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": min(d["frac_hbm_peak"], 1.0), "traffic": None,
-                    "frac_is": "algorithmic gather bytes / time / 8 TB/s, capped at 1 (rows served from the Infinity Cache are not HBM bytes; no PMC file for this run)",
-                    "algorithmic_frac_uncapped": d["frac_hbm_peak"]}
+        # the task's contract: achieved = ALGORITHMIC bytes per launch / its duration, traffic = measured bytes (PMC).  For a gather the two differ
+        # in BOTH directions: rows gathered again out of the L2 count in the algorithmic figure only, sector over-fetch and the Infinity Cache's
+        # share count in the counters only (FETCH_SIZE sits at the L2's memory side: MALL hits included, L2 hits not)
+        roof = {"bound": "hbm", "kernel": dom, "achieved": d["compulsory_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": d["frac_hbm_peak"], "traffic": t,
+                "frac_is": "algorithmic gather bytes (SURVEY 8d: 2 H C s + 4 per edge, + the row I/O) / launch time / 8 TB/s"}
+        if t is not None:
+            roof["memory_side_GBps"] = d["pmc_traffic_GBps"]
+            roof["frac_memory_side"] = d["pmc_traffic_GBps"] / HBM_PEAK_GBPS
+            roof["traffic_is"] = "FETCH_SIZE x2 + WRITE_SIZE per launch at the L2's memory side (Infinity-Cache hits included, L2 hits not)"
     else:
         roof = {"bound": "mfma", "kernel": dom, "achieved": d["alg_tflops"], "peak": peak, "unit": "TFLOP/s",
                 "frac": d["frac_mfma_peak_alg"], "traffic": d.get("pmc_traffic_bytes_per_launch"),
@@ -965,9 +966,10 @@ def sample_bench(args, world, rank, dev):
             eng.profile(False)
             work2 = work_model(cfg, G, E, plan.n_nodes, flags, prec, False)
             sparse = roofline_report(prof2, kp2, work2, prec, tf, pmc_key + "_csr", G, gather_path=True)
-            sparse["note"] = ("same Batch through the edge-list kernels only (hybrid split off): algorithmic gather bytes / kernel "
-                              "time; K/V rows of a Batch that fits the 256 MB Infinity Cache are not HBM bytes -- compare with "
-                              "pmc_traffic where present")
+            sparse["note"] = ("a SIDE measurement: the same Batch through the edge-list kernels only (hybrid split off) -- NOT the path the product "
+                              "takes at this density (the line's `roofline` is: adjacency-masked matrix-core attention).  At d >= 90 of 900 a source "
+                              "row is gathered by hundreds of destinations out of the L2 / Infinity Cache, so the algorithmic figure can exceed the "
+                              "HBM peak: it is not roofline evidence; `--config csr` (d = 4) is the regime in which this kernel is the product path")
             eng.set_features(plan, feats)
     del ei
 

@@ -9,3 +9,4 @@ for t in attn_bench corun_probe; do
       -Wl,-rpath,'$ORIGIN/../../diffassemble_amd/lib_exp' -o tools/bin/$t
   echo built tools/bin/$t
 done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gather_probe.hip -o tools/bin/gather_probe && echo built tools/bin/gather_probe
