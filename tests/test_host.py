@@ -502,3 +502,29 @@ def test_expander_plan_banded_argument_and_training_route(monkeypatch):
     assert route("fp32", 900, 16, 10, hybrid=0) is False                        # not a hybrid plan: nothing to re-route
     monkeypatch.setenv("DA_HYBRID", "force")
     assert route("fp32", 144, 64, int(0.6 * 64 * 144 * 144)) is False           # the caller asked for the hybrid kernels
+
+
+def test_da_config_roundtrip_and_defaults():
+    """`da_config` (ABI 19): the documented defaults, a run-time set / get round trip through the Python binding, and the size check that
+    catches a header / library mismatch.  No GPU work: the library loads and answers on a CPU-only box."""
+    import ctypes as C
+    from diffassemble_amd import _lib
+    base = _lib.config()
+    assert base.struct_bytes == C.sizeof(_lib.DaConfig) == 40
+    if not any(k in os.environ for k in ("DA_DISABLE_MFMA", "DA_DISABLE_DENSE", "DA_DISABLE_FOLDS", "DA_ATTN_LEVEL", "DA_ENABLE_XPANEL", "DA_TAIL_NEXT",
+                                         "DA_PAIR_SPLIT", "DA_TRAIN_ATTN", "DA_TRAIN_SIDE_STREAMS")):
+        assert (base.disable_mfma, base.disable_dense, base.disable_folds, base.attn_level, base.xpanel, base.tail_next, base.pair_split,
+                base.train_attn, base.train_side_streams) == (0, 0, 0, 2, -1, -1, 1, 2, 3)
+    try:
+        old = _lib.set_config(xpanel=0, tail_next=1, attn_level=1)
+        assert old.xpanel == base.xpanel
+        now = _lib.config()
+        assert (now.xpanel, now.tail_next, now.attn_level, now.pair_split) == (0, 1, 1, base.pair_split)
+        with pytest.raises(_lib.DaError):
+            _lib.set_config(no_such_field=1)
+        bad = _lib.DaConfig.from_buffer_copy(now)
+        bad.struct_bytes = 12
+        assert _lib.lib().da_config_set(C.byref(bad)) != 0 and b"struct_bytes" in _lib.lib().da_last_error()
+    finally:
+        _lib.set_config(**{k: getattr(base, k) for k, _ in _lib.DaConfig._fields_ if k != "struct_bytes"})
+    assert _lib.lib().da_build_flags() in (0, 1) and _lib.experiments_build() == (os.path.basename(os.path.dirname(_lib.LIB_PATH)) == "lib_exp")
