@@ -37,6 +37,12 @@ __device__ __forceinline__ void ld_row(const T *p, float (&v)[EPL]) {
     } else if constexpr (B % 8 == 0) {
 #pragma unroll
         for (int i = 0; i < B / 8; ++i) { const csr_u32x2 t = *((const csr_u32x2 *)p + i); w[2 * i] = t[0]; w[2 * i + 1] = t[1]; }
+    } else if constexpr (B % 12 == 0) {
+        // 36-byte slices of a 144-wide bf16 head (only 4-byte aligned): three 12-byte loads (global_load_dwordx3) instead of nine 4-byte ones --
+        // a K + V row used to cost a wave 18 vector-memory instructions of 256 bytes each (round 6, profiles/r06/r06_pmc_gather_calibration.txt)
+        struct __attribute__((packed, aligned(4))) U3 { unsigned a, b, c; };
+#pragma unroll
+        for (int i = 0; i < B / 12; ++i) { const U3 t = *((const U3 *)p + i); w[3 * i] = t.a; w[3 * i + 1] = t.b; w[3 * i + 2] = t.c; }
     } else {
 #pragma unroll
         for (int i = 0; i < NW; ++i) w[i] = *((const unsigned *)p + i);
@@ -49,6 +55,41 @@ __device__ __forceinline__ void ld_row(const T *p, float (&v)[EPL]) {
         for (int i = 0; i < EPL / 2; ++i) { v[2 * i] = bf2f((bf16_t)(w[i] & 0xffff)); v[2 * i + 1] = bf2f((bf16_t)(w[i] >> 16)); }
     }
 }
+
+// A lane's slice of a row AS LOADED (bf16: two channels per register), converted element by element at its use: rows in flight cost half the
+// registers of their float form, so twice as many edges fit in flight (round 6).  fp32 rows are what they were.
+template <typename T, int EPL> struct RowRegs {
+    static constexpr int NW = (EPL * (int)sizeof(T) + 3) / 4;
+    unsigned w[NW];
+    __device__ __forceinline__ void load(const T *p) {
+        constexpr int B = EPL * (int)sizeof(T);
+        if constexpr (B % 16 == 0) {
+#pragma unroll
+            for (int i = 0; i < B / 16; ++i) { const csr_u32x4 t = *((const csr_u32x4 *)p + i); w[4 * i] = t[0]; w[4 * i + 1] = t[1]; w[4 * i + 2] = t[2]; w[4 * i + 3] = t[3]; }
+        } else if constexpr (B % 8 == 0) {
+#pragma unroll
+            for (int i = 0; i < B / 8; ++i) { const csr_u32x2 t = *((const csr_u32x2 *)p + i); w[2 * i] = t[0]; w[2 * i + 1] = t[1]; }
+        } else if constexpr (B % 12 == 0) {
+            struct __attribute__((packed, aligned(4))) U3 { unsigned a, b, c; };
+#pragma unroll
+            for (int i = 0; i < B / 12; ++i) { const U3 t = *((const U3 *)p + i); w[3 * i] = t.a; w[3 * i + 1] = t.b; w[3 * i + 2] = t.c; }
+        } else if constexpr (B % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) w[i] = *((const unsigned *)p + i);
+        } else {                                // odd bf16 slices (EPL = 1, 13): one load per channel, kept as floats' bit patterns is not possible -- two per word
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const unsigned lo = ((const unsigned short *)p)[2 * i];
+                const unsigned hi = 2 * i + 1 < EPL ? ((const unsigned short *)p)[2 * i + 1] : 0u;
+                w[i] = lo | (hi << 16);
+            }
+        }
+    }
+    __device__ __forceinline__ float get(int x) const {
+        if constexpr (sizeof(T) == 4) return __builtin_bit_cast(float, w[x]);
+        else return bf2f((bf16_t)((x & 1) ? (w[x >> 1] >> 16) : (w[x >> 1] & 0xffff)));
+    }
+};
 
 template <typename T, int EPL>
 __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__restrict__ row_ptr,
@@ -64,8 +105,17 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
     const int off = lane * EPL;
     float q[EPL], acc[EPL];
     const T *qp = qkvs + (size_t)i * ld + off;
+    ld_row<T, EPL>(qp, q);                          // (wide loads, as for the K / V rows: the per-channel form was 18 two-byte loads at C = 144)
+    // the epilogue's skip (+ residual) slices are requested HERE, with the query row: one memory round trip less at the end of every row
+    // (narrow heads only: at C = 144 the 18 - 36 registers they would hold through the edge loop cost a resident wave)
+    constexpr bool EARLY = EPL <= 8;
+    RowRegs<T, EPL> skr, rsr;
+    if (EARLY) {
+        skr.load(qkvs + (size_t)i * ld + 3 * (size_t)HC + off);
+        if (residual) rsr.load(residual + (size_t)i * HC + off);
+    }
 #pragma unroll
-    for (int x = 0; x < EPL; ++x) { q[x] = ldf(qp + x) * scale; acc[x] = 0.f; }
+    for (int x = 0; x < EPL; ++x) { q[x] *= scale; acc[x] = 0.f; }
     float m = -INFINITY, l = 0.f;
     const int beg = row_ptr[i], end = row_ptr[i + 1];
     const int head = lane >> 3;
@@ -74,18 +124,18 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
     // indices arrive by ONE coalesced load per 64 edges (lane e holds edge e's source; v_readlane hands it to the wave as a scalar, so
     // the row addresses are SGPR base + per-lane offset); (2) the K and V rows of U edges are requested together, before any is consumed;
     // (3) the U scores enter the running softmax in one update (one rescale per U edges instead of one per edge).
-    constexpr int U = EPL <= 4 ? 8 : (EPL <= 8 ? 4 : 2);
+    constexpr int U = EPL <= 4 ? 8 : (EPL <= 8 ? (sizeof(T) == 2 ? 8 : 4) : (sizeof(T) == 2 ? 4 : 2));
     for (int e0 = beg; e0 < end; e0 += 64) {
         const int cnt = min(64, end - e0);
         const int myj = col_src[e0 + min(lane, cnt - 1)];
         for (int u0 = 0; u0 < cnt; u0 += U) {
-            float kk[U][EPL], vv[U][EPL];
+            RowRegs<T, EPL> kk[U], vv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int j = __builtin_amdgcn_readlane(myj, min(u0 + u, cnt - 1));          // (edges past the end re-read the last one)
                 const T *kp = qkvs + (size_t)j * ld + HC + off;
-                ld_row<T, EPL>(kp, kk[u]);
-                ld_row<T, EPL>(kp + HC, vv[u]);
+                kk[u].load(kp);
+                vv[u].load(kp + HC);
             }
             float sc[U];
             float mn = m;
@@ -93,7 +143,7 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
             for (int u = 0; u < U; ++u) {
                 float s = 0.f;
 #pragma unroll
-                for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[u][x], s);
+                for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[u].get(x), s);
                 s += __shfl_xor(s, 1);
                 s += __shfl_xor(s, 2);
                 s += __shfl_xor(s, 4);
@@ -114,7 +164,7 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
                 const float pe = expf(sc[u] - mn);     // (padding: exp(-inf) = 0)
                 l += pe;
 #pragma unroll
-                for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vv[u][x], acc[x]);
+                for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vv[u].get(x), acc[x]);
             }
             m = mn;
         }
@@ -124,12 +174,15 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
         stats[((size_t)i * H + head) * 2] = m;
         stats[((size_t)i * H + head) * 2 + 1] = inv;
     }
-    const T *sp = qkvs + (size_t)i * ld + 3 * (size_t)HC + off;
     T *op = out + (size_t)i * HC + off;
+    if (!EARLY) {
+        skr.load(qkvs + (size_t)i * ld + 3 * (size_t)HC + off);
+        if (residual) rsr.load(residual + (size_t)i * HC + off);
+    }
 #pragma unroll
     for (int x = 0; x < EPL; ++x) {
-        float v = acc[x] * inv + ldf(sp + x);
-        if (residual) v += ldf(residual + (size_t)i * HC + off + x);
+        float v = acc[x] * inv + skr.get(x);
+        if (residual) v += rsr.get(x);
         stf(op + x, apply_act(v, act));
     }
     if (alpha && (lane & 7) == 0) {
