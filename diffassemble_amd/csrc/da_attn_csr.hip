@@ -227,7 +227,7 @@ constexpr int HEAVY_WAVES = 16;
 // the duplicated virtual->virtual pairs -- get a whole 16-wave workgroup: wave w walks edges w, w+16, ...,
 // the 16 partial softmax states are merged through LDS.  (One wave per row made the 8 virtual rows of a
 // graph the critical path of the whole layer: 560 us at any batch size.)
-template <typename T, int EPL>
+template <typename T, int EPL, bool WIDE = false>
 __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n_real, const int32_t *__restrict__ row_ptr,
                                                               const int32_t *__restrict__ col_src,
                                                               const int32_t *__restrict__ row_map, int H, int C,
@@ -254,7 +254,9 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
     // four edges per trip: their index -> slot -> K / V row loads are independent, so one round of memory
     // latency serves four softmax updates (the walk used to be one dependent chain per edge)
     // (C = 144 in fp32: four edges' K and V rows would be 144 registers beside q and acc under this kernel's 128 -- two there, no spills)
-    constexpr int U = (EPL > 8 && sizeof(T) == 4) ? 2 : 4;
+    // (bf16 rows stay packed in flight: RowRegs.  WIDE -- eight edges in flight at C = 32, experiments build, DA_CONT_WIDE=1: 106 registers instead of
+    //  70, and this kernel runs BESIDE the masked attention of the real rows: measured on configuration 3, see launch_cont_t)
+    constexpr int U = (EPL > 8 && sizeof(T) == 4) ? 2 : ((WIDE && EPL <= 4 && sizeof(T) == 2) ? 8 : 4);
     // (round 6) the trip's source slots -- col_src -> row_map: two dependent index loads -- are fetched ONE TRIP AHEAD, under the K / V loads and the
     // softmax updates of the current trip: a trip is then one memory round trip (the rows), not three
     size_t sjn[U];
@@ -278,16 +280,16 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
         if (!PFI) fetch_idx(e0);
 #pragma unroll
         for (int u = 0; u < U; ++u) { sj[u] = sjn[u]; ok[u] = okn[u]; wgt[u] = wgtn[u]; }
-        float kk[U][EPL], vv[U][EPL];
+        RowRegs<T, EPL> kk[U], vv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { ld_row<T, EPL>(K + sj[u] * C + sub, kk[u]); ld_row<T, EPL>(V + sj[u] * C + sub, vv[u]); }
+        for (int u = 0; u < U; ++u) { kk[u].load(K + sj[u] * C + sub); vv[u].load(V + sj[u] * C + sub); }
         if (PFI && e0 + HEAVY_WAVES * U < end) fetch_idx(e0 + HEAVY_WAVES * U);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;                            // wave-uniform
             float s = 0.f;
 #pragma unroll
-            for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[u][x], s);
+            for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[u].get(x), s);
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             s += __shfl_xor(s, 4);
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(1024) void k_attn_csr_cont_heavy(int n_nodes, int n
             const float pr = expf(s - mn) * wgt[u];
             l = l * corr + pr;
 #pragma unroll
-            for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pr, vv[u][x], acc[x] * corr);
+            for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pr, vv[u].get(x), acc[x] * corr);
             m = mn;
         }
     }
@@ -335,6 +337,12 @@ static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32
                          int n_pad, const DenseLayout &L, const T *residual, int act, T *out, hipStream_t st, const float *mult) {
     if (n_nodes <= n_real) return 0;
     const float scale = L.q_prescaled ? 0.6931471805599453f : 1.0f / sqrtf((float)C);      // pre-scaled Q: q . k is in log2 units
+#ifdef DA_EXPERIMENTS
+    constexpr bool DA_CONT_WIDE_BUILT = true;
+#else
+    constexpr bool DA_CONT_WIDE_BUILT = false;
+#endif
+    [[maybe_unused]] const bool wide_ = DA_XENV("DA_CONT_WIDE", 0) != 0;
 #define DA_CONT_CASE(E)                                                                                          \
     case E:                                                                                                      \
         if (n_nodes > n_real) {                                                                                  \
@@ -345,6 +353,11 @@ static int launch_cont_t(int n_nodes, int n_real, const int32_t *rp, const int32
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));              \
                 attr = true;                                                                                     \
             }                                                                                                    \
+            if (wide_ && E == 4)                                                                                 \
+                k_attn_csr_cont_heavy<T, E, DA_CONT_WIDE_BUILT><<<n_nodes - n_real, 1024, lds, st>>>(            \
+                    n_nodes, n_real, rp, cs, row_map, H, C, (size_t)n_pad, (const T *)L.Q, (const T *)L.K,       \
+                    (const T *)L.Vt, (const T *)L.S, residual, act, out, scale, mult);                           \
+            else                                                                                                 \
             k_attn_csr_cont_heavy<T, E><<<n_nodes - n_real, 1024, lds, st>>>(                                    \
                 n_nodes, n_real, rp, cs, row_map, H, C, (size_t)n_pad, (const T *)L.Q, (const T *)L.K,           \
                 (const T *)L.Vt, (const T *)L.S, residual, act, out, scale, mult);                               \
