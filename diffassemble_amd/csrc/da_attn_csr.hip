@@ -194,6 +194,105 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
     }
 }
 
+// C = 32 (the hidden layers): TWO destination rows per wave.  A 32-wide head's K row is 64 bytes: with one row per wave a lane moves 8 bytes per load
+// and an edge costs the wave two 512-byte instructions; here half a wave owns a destination (four lanes per head, eight channels = 16 bytes per lane in
+// bf16), so one instruction fetches the K (or V) rows of TWO edges -- half the vector-memory instructions per edge, 1 KB each -- and the per-head
+// dot product closes over four lanes (two shuffles).  The two halves walk their own edge lists (their lengths differ: the wave runs to the longer
+// one, the shorter half's surplus trips are masked); a half's source indices come from its own coalesced index load through ds_bpermute.
+// Same arithmetic per edge group as k_attn_csr (one softmax update per U edges).
+template <typename T>
+__global__ __launch_bounds__(256) void k_attn_csr2(int n_nodes, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_src,
+                                                   const int32_t *__restrict__ edge_id, int H, int HC, const T *__restrict__ qkvs,
+                                                   const T *__restrict__ residual, int act, T *__restrict__ out, float *__restrict__ alpha,
+                                                   float *__restrict__ stats, float scale) {
+    constexpr int EPL = 8, U = sizeof(T) == 2 ? 8 : 4;
+    const int lane = threadIdx.x & 63, hl = lane & 31, r = lane >> 5;
+    const int wave = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int i = 2 * wave + r;
+    if (2 * wave >= n_nodes) return;
+    const bool row_on = i < n_nodes;
+    const int ic = row_on ? i : n_nodes - 1;
+    const size_t ld = (size_t)4 * HC;
+    const int off = hl * EPL, head = hl >> 2;
+    float q[EPL], acc[EPL];
+    ld_row<T, EPL>(qkvs + (size_t)ic * ld + off, q);
+    RowRegs<T, EPL> skr, rsr;
+    skr.load(qkvs + (size_t)ic * ld + 3 * (size_t)HC + off);
+    if (residual) rsr.load(residual + (size_t)ic * HC + off);
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) { q[x] *= scale; acc[x] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const int beg = row_ptr[ic], end = row_on ? row_ptr[ic + 1] : beg;
+    const int deg = end - beg;
+    const int degmax = __builtin_amdgcn_readfirstlane(max(deg, __shfl_xor(deg, 32)));
+    for (int e0 = 0; e0 < degmax; e0 += 32) {
+        const int cnt = min(32, max(deg - e0, 0));                              // this half's edges in the chunk (uniform within the half)
+        const int cmax = __builtin_amdgcn_readfirstlane(max(cnt, __shfl_xor(cnt, 32)));
+        const int myj = cnt > 0 ? col_src[beg + e0 + min(hl, cnt - 1)] : 0;
+        for (int u0 = 0; u0 < cmax; u0 += U) {
+            RowRegs<T, EPL> kk[U], vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = __shfl(myj, r * 32 + min(u0 + u, max(cnt - 1, 0)));           // (edges past the half's end re-read its last one; an empty half row 0)
+                const T *kp = qkvs + (size_t)j * ld + HC + off;
+                kk[u].load(kp);
+                vv[u].load(kp + HC);
+            }
+            float sc[U];
+            float mn = m;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[u].get(x), s);
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                const bool ok = u0 + u < cnt;
+                if (ok && alpha && (hl & 3) == 0) {
+                    const size_t eid = edge_id ? (size_t)edge_id[beg + e0 + u0 + u] : (size_t)(beg + e0 + u0 + u);
+                    alpha[eid * H + head] = s;        // raw score; normalised in the second pass
+                }
+                sc[u] = ok ? s : -INFINITY;
+                mn = fmaxf(mn, sc[u]);
+            }
+            // (a half without an edge so far keeps m = mn = -inf: exp(-inf - -inf) would be NaN -- its state is all zero, skip the update)
+            const bool live = mn > -INFINITY;
+            const float corr = live ? expf(m - mn) : 1.f;
+            l *= corr;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) acc[x] *= corr;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pe = live ? expf(sc[u] - mn) : 0.f;
+                l += pe;
+#pragma unroll
+                for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vv[u].get(x), acc[x]);
+            }
+            m = mn;
+        }
+    }
+    if (!row_on) return;
+    const float inv = (end > beg) ? 1.0f / (l + 1e-16f) : 0.f;
+    if (stats && (hl & 3) == 0) {
+        stats[((size_t)i * H + head) * 2] = m;
+        stats[((size_t)i * H + head) * 2 + 1] = inv;
+    }
+    T *op = out + (size_t)i * HC + off;
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) {
+        float v = acc[x] * inv + skr.get(x);
+        if (residual) v += rsr.get(x);
+        stf(op + x, apply_act(v, act));
+    }
+    if (alpha && (hl & 3) == 0) {
+        for (int e = beg; e < end; ++e) {
+            const size_t eid = edge_id ? (size_t)edge_id[e] : (size_t)e;
+            const float s = alpha[eid * H + head];
+            alpha[eid * H + head] = expf(s - m) * inv;
+        }
+    }
+}
+
 template <typename T>
 static int launch_t(int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id, int H,
                     int C, const T *qkvs, const T *residual, int act, T *out, float *alpha, float *stats, hipStream_t st) {
@@ -205,6 +304,12 @@ static int launch_t(int n_nodes, const int32_t *row_ptr, const int32_t *col_src,
         k_attn_csr<T, E><<<grid, 256, 0, st>>>(n_nodes, row_ptr, col_src, edge_id, H, HC, qkvs, residual, act, \
                                                out, alpha, stats, scale);                                \
         break;
+    if (C == 32 && H == 8 && DA_XENV("DA_CSR_TWO_ROWS", 1)) {          // two destination rows per wave (k_attn_csr2)
+        const int grid2 = (int)(((size_t)((n_nodes + 1) / 2) * 64 + 255) / 256);
+        k_attn_csr2<T><<<grid2, 256, 0, st>>>(n_nodes, row_ptr, col_src, edge_id, H, HC, qkvs, residual, act, out, alpha, stats, scale);
+        DA_LAUNCH_CHECK();
+        return 0;
+    }
     switch (C / 8) {
         DA_CSR_CASE(1) DA_CSR_CASE(2) DA_CSR_CASE(4) DA_CSR_CASE(8) DA_CSR_CASE(13) DA_CSR_CASE(16) DA_CSR_CASE(18)
         default:

@@ -130,13 +130,16 @@ def test_da_conv_dense_tall_batch_through_w_in_registers_projection(dev, monkeyp
 @pytest.mark.parametrize("C_head", [32, 144, 104])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_da_attn_csr_matches_pyg_semantics(dev, C_head, prec):
-    """Random multigraph with duplicate edges, self loops and isolated nodes."""
+    """Random multigraph with duplicate edges, self loops, isolated nodes, one hub of in-degree > 100 (several index chunks of the kernels)
+    and an odd node count (k_attn_csr2's last wave holds one row)."""
     from diffassemble_amd import engine as E
     from diffassemble_amd.graph_plan import build_plan
-    H, N, Ecount = 8, 150, 2000
+    H, N, Ecount = 8, 151, 2000
     g = torch.Generator().manual_seed(C_head)
     ei = torch.randint(0, N - 10, (2, Ecount), generator=g)           # last 10 nodes isolated
     ei = torch.cat([ei, ei[:, :100]], 1)                              # duplicates
+    hub = torch.stack([torch.randint(0, N - 10, (100,), generator=g), torch.full((100,), 3)])
+    ei = torch.cat([ei, hub, torch.tensor([[5], [N - 1]])], 1)        # (the very last node has one edge, its wave partner does not exist)
     HC = H * C_head
     qkvs = torch.randn(N, 4 * HC, generator=g)
     if prec == "bf16":
