@@ -30,6 +30,7 @@ struct ConvW {
     void *wd = nullptr;
     float *bd = nullptr;
     void *wdp = nullptr;   // wd in the fragment order of the row-panel projection kernel (da_gemm_xpanel.hip), bf16 only
+    void *wqs = nullptr;   // wd as per-head MFMA fragments (pack_w_qs): hidden layers whose attention kernel does the projection itself
     int din = 0, hc = 0, C = 0;
 };
 
@@ -100,6 +101,7 @@ struct da_denoiser {
     void *virt_qkvs = nullptr;        // exophormer: [V, 4*HC0] act dtype = virt_emb . Wcat0^T + bcat0 (constant per checkpoint)
     void *conv0c_wd = nullptr, *virt_qkvs_d = nullptr;      // their dense-path variants (Q pre-scaled, see ConvW)
     void *conv0c_wdp = nullptr, *convLf_wp = nullptr;       // conv0c_wd / convLf_w packed for the row-panel kernel (see ConvW::wdp)
+    void *conv0c_wqs = nullptr;                             // conv0c_wd's per-head fragments (see ConvW::wqs)
     float *conv0c_bd = nullptr;
     bool q_prescaled = false;
     // ... and the LAST conv's value / skip projections are folded with final_mlp.0 (its consumer, linear up to
@@ -388,6 +390,12 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             const float *bdense = (fused && l == 0) ? d->conv0c_bd : c.bd;
             const int xpm = xpanel_mode();
             const void *wpanel = (xpm == 1 || (xpm == 2 && step_rule_batch(g))) ? ((fused && l == 0) ? d->conv0c_wdp : c.wdp) : nullptr;
+            // Hidden layers of large complete graphs: the resident attention kernel (k_attn_res<.., 64>) does the layer's projection in its own
+            // prologue -- no projection kernel, K | V never leave the CU
+            const void *wqs = (fused && l == 0) ? d->conv0c_wqs : c.wqs;
+            const bool qsf = !last && !g->hybrid && !resid && !virt0 && n == nr && wqs && ldx == c.din &&
+                             attn_qsf_applicable(prec, d->heads, c.C, c.din, g->n_graphs, g->max_graph_nodes, g->n_pad, d->q_prescaled);
+            if (qsf) rc = 0; else
             rc = timed(d, DA_PROF_LINEAR_QKVS, st, [&] {
                 return launch_gemm_mfma(prec, nproj, c.din, 4 * c.hc, xin, ldx, wdense, bdense, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st, 0,
                                         nullptr, wpanel); });
@@ -398,6 +406,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
             if (rc == 0) {
                 DenseLayout L;
                 L.Q = w.dq; L.K = w.dk; L.Vt = w.dvt; L.S = w.dskip; L.n_pad = g->n_pad; L.q_prescaled = d->q_prescaled;
+                if (qsf) { L.x = xin; L.ldx = ldx; L.kin = c.din; L.wqs = wqs; L.bias = bdense; }
                 if (g->hybrid) {
                     // sparse-but-heavy graphs: masked MFMA attention over the regular edges (partial softmax
                     // state), then the remaining edges + normalisation + skip / activation on the CSR side
@@ -515,6 +524,16 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
         if (!p || launch_convert(precision, n, src, p, st)) { rc = 2; return nullptr; }
         return p;
     };
+    // per-head Q / skip fragments of a hidden layer's dense-path projection (bf16, 32-wide heads, K = 128 / 256); nullptr otherwise
+    auto pack_qs = [&](const void *wsrc, int K, int hc, int C) -> void * {
+#ifndef DA_EXPERIMENTS
+        return nullptr;          // (k_attn_res<.., 64> lost its A/B: experiments build only)
+#endif
+        if (precision != DA_PREC_BF16 || C != 32 || H != 8 || (K != 128 && K != 256) || !wsrc || mfma_disabled()) return nullptr;
+        void *p = alloc(w_qs_bytes(H, K));
+        if (!p || pack_w_qs(H, K, hc, wsrc, p, st)) { rc = 2; return nullptr; }
+        return p;
+    };
     // fragment-major copy of a projection weight for the row-panel kernel; nullptr when the shape has no packed form
     auto pack_panel = [&](const void *wsrc, int K, int Nout) -> void * {
         const size_t nb = xpanel_in_model() ? da_linear_packed_bytes(precision, K, Nout) : 0;
@@ -561,6 +580,7 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
             if (scale_block(c.bd, 1, c.hc, c.hc, q_scale_log2(c.C), st)) return fail(2);
         }
         c.wdp = pack_panel(c.wd, c.din, 4 * c.hc);
+        if (l < d->n_layers - 1) c.wqs = pack_qs(c.wd, c.din, c.hc, c.C);
         if (rc) return fail(rc);
     }
     d->q_prescaled = q_prescale_on();
@@ -620,6 +640,7 @@ int da_denoiser_create(const da_weights *w, int precision, void *stream, da_deno
                 d->conv0c_wd = pack(cw, (size_t)4 * hc0 * hid);
             }
             d->conv0c_wdp = pack_panel(d->conv0c_wd, hid, 4 * hc0);
+            if (d->n_layers > 1) d->conv0c_wqs = pack_qs(d->conv0c_wd, hid, hc0, d->conv[0].C);
             if (d->V > 0) {            // exophormer: conv-0 projections of the virtual rows (they bypass mlp)
                 float *vq = (float *)alloc((size_t)d->V * 4 * hc0 * 4);
                 if (!vq) return fail(2);
@@ -1148,10 +1169,20 @@ int da_conv_dense_ex(int prec, const da_graph *g, int heads, int C, int Din, con
     qs.Q = base; qs.K = base + hb; qs.Vt = base + 2 * hb; qs.S = folded ? nullptr : base + 3 * hb;
     qs.Cv = folded ? 32 : 0;
     const int nout = folded ? 2 * (int)hc + heads * 32 : 4 * (int)hc;
-    int rc = launch_gemm_mfma(prec, g->n_nodes, Din, nout, x, Din, w, b, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st);
+    // the layer form the sampling loop takes for hidden layers of large complete graphs (run_forward): the projection happens in the prologue of
+    // the resident attention kernel; its per-head weight fragments are packed into the scratch's (then unused) K region
+    const bool qsf = !folded && !residual && !g->hybrid && g->n_nodes == g->n_real && b && w_qs_bytes(heads, Din) <= hb &&
+                     attn_qsf_applicable(prec, heads, C, Din, g->n_graphs, g->max_graph_nodes, g->n_pad, (flags & DA_CONV_Q_PRESCALED) ? 1 : 0);
+    void *wq_img = base + hb;                        // (the K region of the scratch: K | V stay in the CU)
+    int rc = 0;
+    if (qsf) {
+        if ((rc = pack_w_qs(heads, Din, (int)hc, w, wq_img, st))) return rc;
+    } else
+    rc = launch_gemm_mfma(prec, g->n_nodes, Din, nout, x, Din, w, b, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st);
     DA_REQUIRE(rc == 0, "da_conv_dense_ex: projection shape (Din=%d, Nout=%d) not supported by the MFMA kernels", Din, nout);
     DenseLayout L;
     L.Q = qs.Q; L.K = qs.K; L.Vt = qs.Vt; L.S = qs.S; L.n_pad = g->n_pad; L.q_prescaled = (flags & DA_CONV_Q_PRESCALED) ? 1 : 0;
+    if (qsf) { L.x = x; L.ldx = Din; L.kin = Din; L.wqs = wq_img; L.bias = b; }
     DenseFold fo;
     fo.cv = 32; fo.out = out; fo.n_rows = g->n_real;
     const DenseMask mk = dense_mask_of(g);

@@ -39,6 +39,13 @@ struct AttnDenseParams {
     const int32_t *rm_meta;         // hybrid: [n_pad][4] per-slot { remainder begin, end, slot of the first remainder source, node } (or null)
     void *fold_out;                 // CV != C: [H][n_rows][CV] normalised per-head outputs in the activation dtype (no skip / activation here)
     int n_rows;
+    // k_attn_res<.., 64> (the layer's projection in the kernel's prologue: no projection kernel ran; Q / K / Vt / S above are WRITTEN by the
+    // kernel -- K | V only into its LDS image): the layer's input rows, the per-head weight fragments of pack_w_qs and the four bias blocks
+    // (Q's carries the softmax scale like its weights)
+    const void *x;                  // [N][ldx] bf16 (null: Q / K / V / S come from memory)
+    int ldx, kin;                   // kin = reduction length (128 / 256)
+    const void *wqs;
+    const float *bias_q, *bias_k, *bias_v, *bias_s;   // [H * 32] each
 };
 
 template <typename T, int C, int CV = C, int BK = 0> struct Cfg {

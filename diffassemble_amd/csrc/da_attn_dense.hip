@@ -861,6 +861,8 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.Q = L.Q; p.K = L.K; p.Vt = L.Vt; p.S = L.S; p.res = res; p.out = out;
     p.graph_ptr = graph_ptr; p.pad_ptr = pad_ptr; p.n_pad = L.n_pad; p.H = heads; p.n_graphs = n_graphs;
     p.nqt = 0; p.max_nodes = max_graph_nodes; p.act = act; p.nodiag = nodiag;
+    p.x = L.x; p.ldx = L.ldx; p.kin = L.kin; p.wqs = L.wqs;
+    p.bias_q = L.bias; p.bias_k = L.bias ? L.bias + heads * C : nullptr; p.bias_v = L.bias ? L.bias + 2 * heads * C : nullptr; p.bias_s = L.bias ? L.bias + 3 * heads * C : nullptr;
     p.fast = L.q_prescaled ? 1 : 0;
     if (DA_XENV("DA_ATTN_NO_FAST", 0)) p.fast = 0;
     p.sc = L.q_prescaled ? 1.0f : 1.4426950408889634f / sqrtf((float)C);      // pre-scaled Q: the scores already are in log2 units
@@ -872,6 +874,7 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.blk_class_stride = mk ? mk->blk_class_stride : 0;
     p.rm_meta = mk ? mk->rm_meta : nullptr;
     { const char *e = DA_XENV_LIVE("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
+    if (p.x && DA_XENV("DA_QSF_FAKE_FM", 0)) p.debug = 77;
     { const int fg = DA_XENV("DA_ATTN_FORCE_GEN", 0) ? 1 : 0; p.force_gen = fg; if (fg) p.fast = p.fast ? 2 : 0; }
     { const char *e = DA_XENV_LIVE("DA_ATTN_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     if (n_graphs <= 0 || max_graph_nodes <= 0) return 0;
@@ -901,12 +904,23 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
         const int ro = launch_attn_opt(p, C, st);
         if (ro >= 0) return ro;
     }
+    DA_REQUIRE(!p.x, "launch_attn_dense: projection in the prologue requested for a layer the resident kernel does not take");
 #ifdef DA_EXPERIMENTS
     if (prec == DA_PREC_BF16 && C == 32 && !p.mask && attn2_env() DA_ATTN_DBG(&& !p.debug && !p.prof))
         return launch_attn_dense2(p, heads, n_graphs, max_graph_nodes, st);
 #endif
     if (prec == DA_PREC_BF16) return C == 32 ? launch_tc<bf16_t, 32>(p, st) : launch_tc<bf16_t, 144>(p, st);
     return C == 32 ? launch_tc<float, 32>(p, st) : launch_tc<float, 144>(p, st);
+}
+
+// The conditions under which launch_attn_dense hands a hidden layer to k_attn_res<.., 64> (da_api.hip asks INSTEAD of launching the layer's
+// projection kernel).  launch_attn_dense refuses (DA_REQUIRE) a layout with x set that does not end up there.
+bool attn_res_qsf_shape_ok(int max_nodes, int n_pad, int n_graphs, int kin);          // da_attn_opt.hip
+bool attn_qsf_applicable(int prec, int heads, int C, int kin, int n_graphs, int max_graph_nodes, int n_pad, int q_prescaled) {
+    if (prec != DA_PREC_BF16 || heads != 8 || C != 32 || !q_prescaled || !attn_opt_env()) return false;
+    if (DA_XENV("DA_ATTN_NO_FAST", 0) DA_ATTN_DBG(|| DA_XENV_LIVE("DA_ATTN_DEBUG") || DA_XENV_LIVE("DA_ATTN_PROF_PTR"))) return false;
+    if ((size_t)C * (size_t)n_pad * 2 >= ((size_t)1 << 31)) return false;
+    return attn_res_qsf_shape_ok(max_graph_nodes, n_pad, n_graphs, kin);
 }
 
 // da_debug_counters: [0] k_attn_opt workgroups re-run in GEN mode, [1] k_attn_dense waves that left FAST mode, since the last reset

@@ -766,7 +766,20 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
     // virtual -> real edge, duplicates) are folded in REGISTERS behind the key loop -- score from this lane's Q fragments and the source's K
     // row, the value row's channels this lane owns -- in the same un-shifted (or, in the running-max pass, shifted) softmax state, so the
     // per-wave verification covers them and no LDS staging is needed; output rows go to the slot's node (rm_meta / slot_node).
-    constexpr bool O2 = (XV & 1) != 0, PROG = (XV & 16) != 0, MSK = (XV & 32) != 0;
+    // bit 6 (64) = THE LAYER'S PROJECTION IN THE PROLOGUE (round 6; + bit 7 (128): reduction length 128 instead of 256): no projection kernel runs in
+    // front of this one.  The workgroup of a (graph, head) projects that head's Q | K | V | skip columns of ITS graph itself, on the matrix pipe,
+    // while nothing else is going on in the CU: wave w takes the 32-node slabs w and w + 16.  x rows come from global memory in operand shape
+    // (lane (node, half), k-step s: x[node][16 s + 8 half .. + 7]), the head's four 32 x KIN weight blocks are A operands out of LDS (pack_w_qs
+    // image: MFMA row a = channel pi(a), bits 2 and 3 swapped, so registers 8 t .. 8 t + 7 of a lane are the 16-byte chunk 2 t + half of its
+    // node's row -- in every layout that follows).  The Q and skip weights sit in the last stages of the image, which slabs >= 16 fill last: rows to p.Q / p.S in the
+    // projection kernels' own layouts -- the loop below reads them back as it always did; a wave's first slab keeps its Q fragments in
+    // registers -- then K and V straight into the resident LDS image (K chunks swizzled, V row-major), where the DMA burst used to put them.
+    // Three barriers, all in front of the key loop.  Same 16-step MFMA chain, bias after the reduction, same rounding as the projection
+    // kernels: every row is the two-kernel path's bit for bit.  (A wave projecting the NEXT slab's Q and skip between two slabs instead -- the
+    // first form of this variant -- costs ~5 us per slab: the loop is bound by each wave's own latency chain, and a second chain of global
+    // loads and LDS reads per slab extends it; profiles/r06/r06_qsf_*.log, tools/scratch/withdrawn/r06_qsf_on_the_fly_k_attn_res.diff.)
+    constexpr bool O2 = (XV & 1) != 0, PROG = (XV & 16) != 0, MSK = (XV & 32) != 0, QSF = (XV & 64) != 0;
+    static_assert(!QSF || (NWV == 16 && KPF && QUEUE && !PROG && !MSK && !O2), "projection in the prologue: the sixteen-wave default instance");
     static_assert(!MSK || (NWV == 16 && KPF && !PROG && !O2), "masked resident instance: sixteen waves, K fragments one block ahead");
     static_assert(!PROG || (NWV == 16 && KPF), "progressive landing: the sixteen-wave instance (two waves per piece index), K fragments one block ahead");
     using T = bf16_t;
@@ -783,7 +796,10 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
     constexpr int STAGE = KG::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DA_OPB(unsigned long long pb_[8] = {__builtin_readcyclecounter(), 0, 0, 0, 0, 0, 0, 0};)
-    const int bid = blockIdx.x, h = bid & 7, g = bid >> 3;          // head = XCD, as in the ring kernels
+    // head = XCD, as in the ring kernels; QSF: the eight heads of a graph on ONE XCD (workgroup b runs on XCD b % 8) -- they all read the graph's
+    // x rows, which then cross the fabric once instead of eight times (K | V of a (graph, head) are read by one workgroup wherever it runs)
+    const int bid = (XV & 64) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int h = bid & 7, g = bid >> 3;
     // Batches whose graphs all share one padded slot size (every benched Batch): the slot offset and the tile count follow from the kernel
     // arguments alone, so the DMA below does not wait for the graph table (one dependent L2 round trip at the head of every workgroup)
     const int npg = (p.max_nodes + 63) & ~63;
@@ -801,6 +817,23 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
     volatile unsigned *land = qctr + 4;         // PROG: [nkt] pieces landed per stage (launch_res sizes the LDS for them)
     float *mlut = (float *)(qctr + 36);         // MSK: nibble -> four accumulator initial values (0 / -inf), 256 B
     if (MSK && tid < 64) mlut[tid] = (((tid >> 2) >> (tid & 3)) & 1) ? 0.f : -INFINITY;
+    // QSF: [2][KS][64 lanes][16 B] weight fragments (K block, V block) + 128 bias floats behind the words above (launch_res sizes the LDS); the
+    // Q and skip blocks' fragments start out at the head of the (still empty) K | V image
+    constexpr int KS = QSF ? ((XV & 128) ? 8 : 16) : 1;          // k-steps of the projection: reduction length 256 (XV = 64) or 128 (XV = 64 + 128)
+    [[maybe_unused]] unsigned char *wimg = (unsigned char *)qctr + 512;
+    [[maybe_unused]] float *biasl = (float *)(wimg + 2 * KS * 1024);
+    if constexpr (QSF) {
+        // pack_w_qs image of head h: blocks Q, K, V, skip, KS KB each
+        const unsigned char *wsrc = (const unsigned char *)p.wqs + (size_t)h * 4 * KS * 1024;
+        const unsigned wl = lds0 + (unsigned)(wimg - smem);
+        const int qs_off = ((p.max_nodes + 63) >> 6) * STAGE - 2 * KS * 1024;          // the Q / skip blocks: the last 2 KS KB of the (still empty) image
+        for (int j = wid; j < 4 * KS; j += NWV) {
+            const int blk = j / KS, s_ = j - blk * KS;           // wave-uniform
+            const unsigned dst = (blk == 1 || blk == 2) ? wl + (unsigned)(((blk - 1) * KS + s_) * 1024) : lds0 + (unsigned)(qs_off + ((blk ? 1 : 0) * KS + s_) * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"((unsigned)lane * 16u), "s"(wsrc + (size_t)j * 1024) : "memory");
+        }
+        if (tid < 128) biasl[tid] = (tid < 32 ? p.bias_q : (tid < 64 ? p.bias_k : (tid < 96 ? p.bias_v : p.bias_s)))[32 * h + (tid & 31)];
+    }
     if (QUEUE && tid == 0) { *qctr = 0u; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }      // (nobody draws before the landing barrier)
     if (PROG && tid < 32) { land[tid] = 0u; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     int node0 = 0, n_g = 0;
@@ -816,7 +849,9 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
     }
 
     // ---- the whole K | V of the head: wave w issues piece (w & 7) of tiles (w >> 3), (w >> 3) + TPW, ... (scalar base + lane offset form)
-    if constexpr (NWV % 8 != 0) {
+    if constexpr (QSF) {
+        // (no DMA of K | V: the prologue below projects them into the image)
+    } else if constexpr (NWV % 8 != 0) {
         // any number of waves: the 8 nkt pieces dealt out round-robin (the lane offset depends on the piece: recomputed per instruction)
         for (int idx = wid; idx < nkt * 8; idx += NWV) {
             const int kt = idx >> 3, pq = idx & 7;          // wave-uniform
@@ -872,7 +907,72 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
         for (int ch = 0; ch < CF::NCH; ++ch) dst[ch] = *(const u32x4 *)(qrow + ch * 32 + half * 16);
     };
     static_assert(!PROG || CF::NCH == 2, "progressive landing: two Q fragments per lane");
-    if constexpr (!PROG) load_q(slab, qf);
+    // ---- QSF: the projection prologue (see the header of the kernel)
+    [[maybe_unused]] u32x4 xq[KS];          // a slab's x rows, every k-step (one memory round trip per slab)
+    [[maybe_unused]] auto x_issue = [&](int sl) {
+        const int nd = max(min(sl * 32 + i, n_g - 1), 0);          // (rows behind the graph repeat its last row: finite K / V rows, never stored Q / skip rows)
+        const unsigned char *row = (const unsigned char *)p.x + ((size_t)(node0 + nd) * (size_t)p.ldx + 8 * half) * 2;
+        // (p.debug == 77, timing only, WRONG results: the same bytes as 1 KB-contiguous loads, as if x were stored fragment-major)
+        if (p.debug == 77) row = (const unsigned char *)p.x + ((size_t)(node0 + max(min(sl * 32, n_g - 32), 0)) * (size_t)p.ldx) * 2 + lane * 16;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) xq[s_] = *(const u32x4 *)(row + s_ * (p.debug == 77 ? 1024 : 32));
+    };
+    // two chains over the slab's x fragments: a0 = W0 x^T, a1 = W1 x^T (channel x node); weight fragments one k-step ahead of their products
+    [[maybe_unused]] auto chain2 = [&](const unsigned char *w0b, const unsigned char *w1b, f32x16 &a0, f32x16 &a1) {
+        unsigned lo = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(lo));          // (keeps the weight-fragment reads where they are used: hoisted they are 128 registers)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+        u32x4 wa0 = *(const u32x4 *)(w0b + lo), wa1 = *(const u32x4 *)(w1b + lo);
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            u32x4 wn0 = wa0, wn1 = wa1;
+            if (s_ + 1 < KS) { wn0 = *(const u32x4 *)(w0b + (size_t)(s_ + 1) * 1024 + lo); wn1 = *(const u32x4 *)(w1b + (size_t)(s_ + 1) * 1024 + lo); }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa0), __builtin_bit_cast(bf16x8, xq[s_]), a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa1), __builtin_bit_cast(bf16x8, xq[s_]), a1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            wa0 = wn0; wa1 = wn1;
+        }
+    };
+    // chunk t (of this lane's two: 2 t + half) of a projected row: accumulator registers 8 t .. 8 t + 7 + bias, rounded to bf16
+    [[maybe_unused]] auto chunk_of = [&](const f32x16 &a, int blk, int t) {
+        const f32x4 b0 = *(const f32x4 *)(biasl + 32 * blk + 16 * t + 8 * half), b1 = *(const f32x4 *)(biasl + 32 * blk + 16 * t + 8 * half + 4);
+        bf16x8 q8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { q8[e] = (__bf16)(a[8 * t + e] + b0[e]); q8[4 + e] = (__bf16)(a[8 * t + 4 + e] + b1[e]); }
+        return __builtin_bit_cast(u32x4, q8);
+    };
+    // Q and skip rows of slab sl (xq holds it) -> memory, in the projection kernels' layouts; keep = this wave's first slab: its Q fragments stay in qf
+    [[maybe_unused]] auto project_qs = [&](int sl, bool keep) {
+        f32x16 aQ, aS;
+        const unsigned char *wq_ = smem + (size_t)(((p.max_nodes + 63) >> 6) * STAGE - 2 * KS * 1024);
+        chain2(wq_, wq_ + (size_t)KS * 1024, aQ, aS);
+        const int row = sl * 32 + i;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 qc = chunk_of(aQ, 0, t), sc_ = chunk_of(aS, 3, t);
+            if (keep) qf[t] = qc;
+            if (row < n_g) {
+                *(u32x4 *)(const_cast<unsigned char *>(Qg) + (size_t)row * CF::ROWB + (2 * t + half) * 16) = qc;
+                *(u32x4 *)((unsigned char *)p.S + ((size_t)(node0 + row) * HC + (size_t)h * C) * 2 + (2 * t + half) * 16) = sc_;
+            }
+        }
+    };
+    // K and V rows of slab sl (xq holds it) -> the resident image (stage sl / 2: K rows with the chunk swizzle of the DMA image, V rows behind them)
+    [[maybe_unused]] auto project_kv = [&](int sl) {
+        f32x16 aK, aV;
+        chain2(wimg, wimg + (size_t)KS * 1024, aK, aV);
+        const int rt = (sl & 1) * 32 + i;          // row inside the 64-key stage
+        unsigned char *st_ = smem + (size_t)(sl >> 1) * STAGE + (size_t)rt * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            *(u32x4 *)(st_ + (((2 * t + half) ^ KG::f(rt)) << 4)) = chunk_of(aK, 1, t);
+            *(u32x4 *)(st_ + KG::KBYTES + ((2 * t + half) << 4)) = chunk_of(aV, 2, t);
+        }
+    };
+    if constexpr (QSF) x_issue(slab);
+    else if constexpr (!PROG) load_q(slab, qf);    else if constexpr (!PROG) load_q(slab, qf);
     // PROG: this wave's pieces (tiles t0p, t0p + 2, ...: nmine of them, issued in that order, with nothing older than them outstanding but the two
     // Q loads above and nothing younger) and how many it has posted
     [[maybe_unused]] const int t0p = wid >> 3, nmine = nkt > t0p ? (nkt - t0p + 1) >> 1 : 0;
@@ -918,9 +1018,25 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
         asm volatile("" : "+v"(qf[0]), "+v"(qf[1]));
         if (slab < nslab) await_tile(0);
     } else {
+    if constexpr (QSF) {
+        const int slabB = slab + NWV;
+        const bool hasA = slab < nslab, hasB = slabB < nslab;
+        // weight fragments, bias words and slab A's x rows are there; barrier 1
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // slab A (= wave index: stages 0 .. 7 of the image) completely, then Q / skip of slab B; every x row is read ONCE per workgroup
+        if (hasA) { project_qs(slab, true); project_kv(slab); }
+        if (hasB) { x_issue(slabB); project_qs(slabB, false); }
+        __builtin_amdgcn_s_barrier();          // 2: nobody reads the Q / skip weights (in the last stages of the K | V image) any more
+        if (hasB) project_kv(slabB);
+        // the Q / skip rows have reached the L2, the K | V rows the LDS; barrier 3, the last one of the kernel
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
     // the first slab's Q fragments travel behind the DMA; one wait for both, then the only barrier of the kernel
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[CF::NCH - 1]));
     __builtin_amdgcn_s_barrier();
+    }
     }
     DA_OPB(pb_[6] = __builtin_readcyclecounter();)
 
@@ -1219,7 +1335,7 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
             if (lane == 0) t_ = __hip_atomic_fetch_add(qctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             nxt = NWV + __builtin_amdgcn_readfirstlane((int)t_);
         }
-        u32x4 qn[CF::NCH];
+        [[maybe_unused]] u32x4 qn[CF::NCH];
         const bool more = nxt < nslab;
         if (more) load_q(nxt, qn);
         const float lt = ls + __shfl_xor(ls, 32);
@@ -1266,9 +1382,46 @@ long long attn_res_launches(int reset) {
     return reset ? __atomic_exchange_n(&g_res_launches, 0ll, __ATOMIC_RELAXED) : __atomic_load_n(&g_res_launches, __ATOMIC_RELAXED);
 }
 
+// projection in the prologue (k_attn_res<16, true, true, 64 (+ 128)>): LDS = the K | V tiles + 512 B of words + two weight blocks + 128 bias floats
+// (the other two weight blocks start out inside the K | V image: it must hold them -- 2 kin / 16 KB <= four 8 KB stages at kin = 256)
+static size_t attn_res_qsf_lds(int max_nodes, int kin) { return (size_t)((max_nodes + 63) >> 6) * OptK<32, 64>::STAGE + 512 + (size_t)2 * (kin >> 4) * 1024 + 512; }
+static bool attn_res_takes(int max_nodes, int n_pad, int n_graphs) {          // launch_attn_opt's test for the resident kernel (complete graphs)
+    return cfg().attn_level >= 2 && DA_XENV("DA_OPT_HID", 0) == 0 && max_nodes >= DA_XENV("DA_ATTN_RES_MIN", 512) && max_nodes <= 19 * 64 &&
+           (long long)n_pad * 2 >= (long long)n_graphs * max_nodes;
+}
+bool attn_res_qsf_shape_ok(int max_nodes, int n_pad, int n_graphs, int kin) {
+#ifndef DA_EXPERIMENTS
+    return false;          // (the instance exists in the experiments build only)
+#endif
+    if (!DA_XENV("DA_ATTN_RES_QSF", 0) || (kin != 128 && kin != 256)) return false;
+    if (DA_XENV("DA_ATTN_RES_PH", 1) != 1) return false;
+    return attn_res_takes(max_nodes, n_pad, n_graphs) && attn_res_qsf_lds(max_nodes, kin) <= (size_t)160 * 1024 &&
+           (size_t)((max_nodes + 63) >> 6) * OptK<32, 64>::STAGE >= (size_t)8 * OptK<32, 64>::STAGE + (size_t)2 * (kin >> 4) * 1024;
+}
+
+// Fragment-major image of a layer's projection weights for k_attn_res<.., 64>: packed[((h * 4 + m) * KS + s) * 64 + lane] = the 16 bytes
+// W[m * hc + 32 h + pi(lane & 31)][16 s + 8 (lane >> 5) .. + 7], m = Q, K, V, skip; pi(a) = a with bits 2 and 3 swapped (MFMA row a of the channel x node
+// product then leaves a lane's registers 8 t .. 8 t + 7 holding channels 16 t + 8 half .. + 7: the 16-byte chunk 2 t + half of the node's row)
+__global__ void k_pack_w_qs(int heads, int kin, int hc, const bf16_t *__restrict__ W, u32x4 *__restrict__ out) {
+    const int KS = kin >> 4;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)heads * 4 * KS * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), s = (int)((idx >> 6) % KS), hm = (int)((idx >> 6) / KS), m = hm & 3, h = hm >> 2;
+    const int a = lane & 31, row = (a & 0x13) | (((a >> 2) & 1) << 3) | (((a >> 3) & 1) << 2);
+    out[idx] = *(const u32x4 *)(W + ((size_t)m * hc + 32 * h + row) * kin + 16 * s + 8 * (lane >> 5));
+}
+size_t w_qs_bytes(int heads, int kin) { return (size_t)heads * 4 * kin * 64; }
+int pack_w_qs(int heads, int kin, int hc, const void *wd, void *packed, hipStream_t st) {
+    const size_t total = w_qs_bytes(heads, kin) / 16;
+    k_pack_w_qs<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(heads, kin, hc, (const bf16_t *)wd, (u32x4 *)packed);
+    DA_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int NWV, bool QUEUE, bool KPF, int XV = 0>
 static int launch_res(const AttnDenseParams &p, hipStream_t st) {
-    const int lds = ((p.max_nodes + 63) >> 6) * OptK<32, 64>::STAGE + 16 + 128 + 256;          // + the queue word + the landing words (XV & 16) + the mask table (XV & 32)
+    int lds = ((p.max_nodes + 63) >> 6) * OptK<32, 64>::STAGE + 16 + 128 + 256;          // + the queue word + the landing words (XV & 16) + the mask table (XV & 32)
+    if (XV & 64) lds = (int)attn_res_qsf_lds(p.max_nodes, (XV & 128) ? 128 : 256);
     static bool attr_done[16] = {};
     int dev = 0;
     DA_CHECK_HIP(hipGetDevice(&dev));
@@ -1324,6 +1477,17 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
                                       : launch_res<5, false, true>(p, st);          // 12 x 12 puzzles: five slabs, five waves, four workgroups per CU (96 VGPRs)
 #endif
             if (res && v == 0 && p.max_nodes >= res_min && p.max_nodes <= 19 * 64 /* 19 stages + the queue word <= 160 KB */ && (long long)p.n_pad * 2 >= (long long)p.n_graphs * p.max_nodes) {
+#ifdef DA_EXPERIMENTS
+                // OPT-IN (DA_ATTN_RES_QSF=1): the layer's projection in this kernel's prologue.  Bit-identical to the two-kernel path; measured on the
+                // headline (profiles/r06/r06_prologue_projection_*.log): the three hidden layers' kernels 294 -> 287 us per branch-step, the STEP
+                // +2.5 % (0.668 -> 0.686 ms) -- in the two-graph loop the projection kernels already run under the other branch's attention, the
+                // longer attention kernel does not; with x loads as 1 KB-contiguous instructions (timing probe, DA_QSF_FAKE_FM=1) 268 us and -1.2 %.
+                if (p.x) {
+                    DA_REQUIRE(attn_res_qsf_shape_ok(p.max_nodes, p.n_pad, p.n_graphs, p.kin) && p.wqs && p.bias_q && p.bias_k && p.bias_v && p.bias_s,
+                               "k_attn_res: projection in the prologue requested for a shape it does not take");
+                    return p.kin == 256 ? launch_res<16, true, true, 64>(p, st) : launch_res<16, true, true, 64 + 128>(p, st);
+                }
+#endif
 #ifdef DA_EXPERIMENTS
                 switch (DA_XENV("DA_ATTN_RES_PH", 1)) {          // A/B switches; default 1
                     case 3: return launch_res<16, false, true>(p, st);         // fixed slabs (wave, wave + 16)

@@ -273,7 +273,7 @@ int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, c
     { const char *e = DA_XENV_LIVE("DA_GEMM_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
     { const char *e = DA_XENV_LIVE("DA_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
     if (qs) {
-        const int nexp = qs->Cv > 0 ? 2 * qs->HC + (qs->HC / qs->C) * qs->Cv : 4 * qs->HC;
+        const int nexp = qs->blocks > 0 ? qs->blocks * qs->HC : (qs->Cv > 0 ? 2 * qs->HC + (qs->HC / qs->C) * qs->Cv : 4 * qs->HC);
         if (qs->HC % 128 != 0 || (qs->C & 7) || (qs->Cv & 7) || Nout != nexp || Nout % 128 != 0 || act != DA_ACT_NONE || res) return -1;
         p.qkv = 1; p.HC = qs->HC; p.C = qs->C; p.n_pad = qs->n_pad; p.row_map = qs->row_map;
         p.Cv = qs->Cv;

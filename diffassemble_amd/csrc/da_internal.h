@@ -124,6 +124,7 @@ struct StreamJoin {
 struct QkvScatter {            // where the fused projection scatters its four column blocks
     int HC, C, n_pad;
     int Cv = 0;                // > 0: three blocks only (Q | K | V'), V' heads Cv wide (folded value heads), no skip
+    int blocks = 0;            // > 0: only the first `blocks` column blocks exist (2: a K | V-only projection hands its blocks in through the Q and K slots)
     const int32_t *row_map;    // node -> padded row
     void *Q, *K, *Vt, *S;      // [H][n_pad][C] x 3 (Vt keeps its name; V is row-major since the tr_b16 rewrite), [M][H*C]
 };
@@ -131,7 +132,17 @@ struct DenseLayout {
     const void *Q, *K, *Vt, *S;
     int n_pad;
     int q_prescaled = 0;       // Q rows already carry log2(e) / sqrt(C) (projection weights scaled at pack time, da_api.hip ConvW::wd)
+    // the layer's projection inside the resident attention kernel (attn_qsf_applicable; no projection kernel runs: the attention kernel writes Q / S
+    // itself and keeps K | V in LDS):
+    const void *x = nullptr;   // the layer's input rows [N][ldx], bf16
+    int ldx = 0, kin = 0;
+    const void *wqs = nullptr; // pack_w_qs image of the layer's projection weights
+    const float *bias = nullptr;   // [4 * H * 32]: Q | K | V | skip
 };
+// da_attn_dense.hip / da_attn_opt.hip: whether launch_attn_dense will take the resident kernel's projection-in-the-prologue form for this layer
+bool attn_qsf_applicable(int prec, int heads, int C, int kin, int n_graphs, int max_graph_nodes, int n_pad, int q_prescaled);
+size_t w_qs_bytes(int heads, int kin);
+int pack_w_qs(int heads, int kin, int hc, const void *wd, void *packed, hipStream_t st);
 // wpacked: optional fragment-major copy of W (pack_w_xpanel) for the row-panel kernel (da_gemm_xpanel.hip)
 int launch_gemm_mfma(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
                      int act, const void *res, void *out, int ldo, const QkvScatter *qs, hipStream_t st, int ldw = 0,

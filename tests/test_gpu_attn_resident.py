@@ -120,6 +120,30 @@ def test_resident_and_ring_kernels_agree_to_one_ulp_subprocess(dev, tmp_path):
         assert bool((d <= 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-30).all())          # never more than one bf16 ulp
 
 
+_DUMP_QSF = _DUMP.replace("(([900, 513, 1216, 640], True), ([897, 929], False))", "(([900, 640, 960], True), ([897, 929], False), ([513], True))")
+
+
+def test_layer_projected_in_the_attention_kernels_prologue_equals_the_two_kernel_layer_subprocess(dev, tmp_path):
+    """k_attn_res<.., 64> (DA_ATTN_RES_QSF=1, experiments build): no projection kernel -- the resident kernel projects Q | K | V | skip of its
+    (graph, head) in its own prologue (K | V straight into its LDS image, Q / skip rows to memory in the projection kernels' layouts).  Same MFMA
+    chain over the reduction, bias after it, same rounding to bf16: the layer's outputs are the two-kernel path's bit for bit.  (Same
+    TransformerConv, reference backbones/Transformer_GNN.py:32,38; PyG lin_query / lin_key / lin_value / lin_skip.)  The third Batch (one
+    513-piece graph) is too small for the scratch to hold the weight image: both runs take the two-kernel path there."""
+    from conftest import exp_env
+    res = {}
+    for tag, val in (("two_kernel", "0"), ("on_the_fly", "1")):
+        f = tmp_path / f"{tag}.pt"
+        env = exp_env(DA_ATTN_RES_QSF=val)
+        for k in ("DA_OPT_HID", "DA_ATTN_LEVEL"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, "-c", _DUMP_QSF.format(root=ROOT, tests=os.path.join(ROOT, "tests")), str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(f)
+    for (a, la), (b, lb) in zip(res["two_kernel"], res["on_the_fly"]):
+        assert la == 1 and lb == 1, (la, lb)
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+
+
 def test_the_900_piece_fallback_suite_on_the_ring_kernel_subprocess():
     """DA_ATTN_LEVEL=1: the ring kernel keeps its 900-piece coverage (it still serves every Batch the resident kernel declines)."""
     env = dict(os.environ, DA_ATTN_LEVEL="1")
