@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "da_attn_common.h"
+#include "da_attn_res_asm.inc"
 
 namespace da {
 
@@ -778,7 +779,12 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
     // kernels: every row is the two-kernel path's bit for bit.  (A wave projecting the NEXT slab's Q and skip between two slabs instead -- the
     // first form of this variant -- costs ~5 us per slab: the loop is bound by each wave's own latency chain, and a second chain of global
     // loads and LDS reads per slab extends it; profiles/r06/r06_qsf_*.log, tools/scratch/withdrawn/r06_qsf_on_the_fly_k_attn_res.diff.)
-    constexpr bool O2 = (XV & 1) != 0, PROG = (XV & 16) != 0, MSK = (XV & 32) != 0, QSF = (XV & 64) != 0;
+    // bit 8 (256) = SOFTWARE-PIPELINED KEY LOOP (round 6): the steady-state blocks of an optimistic pass run as generated
+    // inline asm on pinned registers, one statement per pair of blocks (tools/gen_attn_res_asm.py -> da_attn_res_asm.inc): the score product of
+    // block b + 1 is issued in front of the exponentials of block b, inside ONE wave.  First block, the blocks with a masked tail, graphs without
+    // self loops and the running-max pass keep the compiler's loop below.
+    constexpr bool O2 = (XV & 1) != 0, PROG = (XV & 16) != 0, MSK = (XV & 32) != 0, QSF = (XV & 64) != 0, PIPE2 = (XV & 256) != 0;
+    static_assert(!PIPE2 || (NWV == 16 && KPF && !PROG && !MSK && !O2), "pipelined key loop: the sixteen-wave instances on complete graphs");
     static_assert(!QSF || (NWV == 16 && KPF && QUEUE && !PROG && !MSK && !O2), "projection in the prologue: the sixteen-wave default instance");
     static_assert(!MSK || (NWV == 16 && KPF && !PROG && !O2), "masked resident instance: sixteen waves, K fragments one block ahead");
     static_assert(!PROG || (NWV == 16 && KPF), "progressive landing: the sixteen-wave instance (two waves per piece index), K fragments one block ahead");
@@ -1066,9 +1072,42 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
             u32x4 kf[CF::NCH];
 #pragma unroll
             for (int ch = 0; ch < CF::NCH; ++ch) kf[ch] = *(const u32x4 *)(smem + kfo[ch]);
-            for (int b = 0; b < nslab; ++b) {
+            int b_first = 0;                      // PIPE2: the compiler's loop starts here, with this block's scores already in sA
+            [[maybe_unused]] f32x16 sA;
+            if constexpr (PIPE2) {
+                static_assert(!PIPE2 || CF::NCH == 2, "two K fragments per block");
+                const int nfull = n_g >> 5;       // blocks without a masked key
+                if (!gen && !p.nodiag && nfull >= 3) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sA[r] = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < CF::NCH; ++ch) sA = mma_chunk(T(), kf[ch], qf[ch], sA);          // scores of block 0
+                    u32x4 kfA0 = *(const u32x4 *)(smem + boff(1) + kfo[0]), kfA1 = *(const u32x4 *)(smem + boff(1) + kfo[1]);
+                    const unsigned ones = 0x3f803f80u;
+                    // (sA comes out of a compiler MFMA and the statement's first vector reads of it are invisible to the compiler: 16 wait states by hand)
+                    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sA), "+v"(kfA0), "+v"(kfA1));
+                    int b = 0;
+                    for (; b + 1 < nfull && b + 3 < nslab; b += 2) {
+                        const unsigned kad0 = lds0 + (unsigned)(boff(b + 2) + kfo[0]), kad1 = lds0 + (unsigned)(boff(b + 2) + kfo[1]);
+                        const unsigned vad = vbase + (unsigned)boff(b);
+                        constexpr int ABL = (XV >> 9) & 7;          // (the generator's timing ablations, WRONG results: DA_ATTN_RES_PIPE = 2 .. 6)
+                        if constexpr (ABL == 1) DA_RES_PAIR_NOWAIT();
+                        else if constexpr (ABL == 2) DA_RES_PAIR_NOVALU();
+                        else if constexpr (ABL == 3) DA_RES_PAIR_NOMFMA();
+                        else if constexpr (ABL == 4) DA_RES_PAIR_NOREAD();
+                        else if constexpr (ABL == 5) DA_RES_PAIR_HALFEXP();
+                        else DA_RES_PAIR();
+                    }
+                    // K fragments of block b + 1 are still on their way; sA / O were last written by asm MFMAs
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(sA), "+v"(kfA0), "+v"(kfA1), "+v"(O), "+v"(ls));
+                    kf[0] = kfA0; kf[1] = kfA1;
+                    b_first = b;
+                }
+            }
+            for (int b = b_first; b < nslab; ++b) {
                 const int key0 = b * 32;
                 const int bo = boff(b);
+                const bool given = PIPE2 && b_first > 0 && b == b_first;          // scores in sA, kf already holds block b + 1
                 if (PROG && first && !(b & 1)) post_upto(3 * (b >> 1) + 1);          // ahead of everybody's consumption (see the header)
                 if (!KPF && b > 0) {
 #pragma unroll
@@ -1076,10 +1115,14 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x16 s;
+                if (given) {
+                    if constexpr (PIPE2) s = sA;
+                } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < CF::NCH; ++ch) s = mma_chunk(T(), kf[ch], qf[ch], s);
+                }
                 asm volatile("" : "+v"(s));         // (the V reads and the next K fragments stay BEHIND the QK chain: the IR-level sinking of the products put
                                                     //  the reads in front, where the chain's lgkmcnt wait covers them too)
                 u32x2 vlo[2], vhi[2];
@@ -1089,7 +1132,7 @@ __global__ __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : ((NWV > 5 || (XV & 8)) ? 
                     vlo[mm] = tr_read(vb, (8 * mm) * CF::RSV);
                     vhi[mm] = tr_read(vb, (8 * mm + 4) * CF::RSV);
                 }
-                if (KPF && b + 1 < nslab) {       // next block's K fragments: they land under this block's exponentials
+                if (KPF && b + 1 < nslab && !given) {       // next block's K fragments: they land under this block's exponentials
                     if (PROG && first && (b & 1)) await_tile((b + 1) >> 1);          // (a new tile: all eight pieces there?)
                     const int bn = boff(b + 1);
 #pragma unroll
@@ -1499,6 +1542,15 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
                     default: break;
                 }
 #endif
+                switch (DA_XENV("DA_ATTN_RES_PIPE", 0)) {
+                    case 1: return launch_res<16, true, true, 256>(p, st);
+                    case 2: return launch_res<16, true, true, 256 + 512 * 1>(p, st);
+                    case 3: return launch_res<16, true, true, 256 + 512 * 2>(p, st);
+                    case 4: return launch_res<16, true, true, 256 + 512 * 3>(p, st);
+                    case 5: return launch_res<16, true, true, 256 + 512 * 4>(p, st);
+                    case 6: return launch_res<16, true, true, 256 + 512 * 5>(p, st);
+                    default: break;
+                }
                 return launch_res<16, true, true>(p, st);
             }
         }

@@ -144,6 +144,26 @@ def test_layer_projected_in_the_attention_kernels_prologue_equals_the_two_kernel
         assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
 
 
+def test_software_pipelined_key_loop_equals_the_compilers_loop_subprocess(dev, tmp_path):
+    """k_attn_res<.., 256> (DA_ATTN_RES_PIPE=1, experiments build): the steady-state key blocks as generated inline asm on pinned registers
+    (tools/gen_attn_res_asm.py), the next block's score product issued in front of this block's exponentials.  Same instructions on the same
+    values in the same order per accumulator: bit for bit the compiler-scheduled kernel (ragged Batch, odd tails, graphs without self loops --
+    those keep the compiler's loop)."""
+    from conftest import exp_env
+    res = {}
+    for tag, val in (("compiler", "0"), ("pipelined", "1")):
+        f = tmp_path / f"{tag}.pt"
+        env = exp_env(DA_ATTN_RES_PIPE=val)
+        for k in ("DA_OPT_HID", "DA_ATTN_LEVEL"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, "-c", _DUMP_QSF.format(root=ROOT, tests=os.path.join(ROOT, "tests")), str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(f)
+    for (a, la), (b, lb) in zip(res["compiler"], res["pipelined"]):
+        assert la == 1 and lb == 1, (la, lb)
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+
+
 def test_the_900_piece_fallback_suite_on_the_ring_kernel_subprocess():
     """DA_ATTN_LEVEL=1: the ring kernel keeps its 900-piece coverage (it still serves every Batch the resident kernel declines)."""
     env = dict(os.environ, DA_ATTN_LEVEL="1")
