@@ -1542,6 +1542,8 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
                     default: break;
                 }
 #endif
+#ifdef DA_EXPERIMENTS
+                // OPT-IN (DA_ATTN_RES_PIPE=1): the software-pipelined key loop (generated asm); 2 .. 6 are its timing ablations (WRONG results)
                 switch (DA_XENV("DA_ATTN_RES_PIPE", 0)) {
                     case 1: return launch_res<16, true, true, 256>(p, st);
                     case 2: return launch_res<16, true, true, 256 + 512 * 1>(p, st);
@@ -1551,6 +1553,7 @@ int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
                     case 6: return launch_res<16, true, true, 256 + 512 * 5>(p, st);
                     default: break;
                 }
+#endif
                 return launch_res<16, true, true>(p, st);
             }
         }
