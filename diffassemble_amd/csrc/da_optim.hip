@@ -280,8 +280,8 @@ __global__ __launch_bounds__(1024) void k_loss_grad(int kind, size_t n, const fl
     __shared__ float red[1024];
     const float inv_n = 1.0f / (float)n;
     float s = 0.f;
-    for (size_t i = threadIdx.x; i < n; i += 1024) {
-        const float d = target[i] - pred[i], a = fabsf(d);
+    auto one = [&](size_t i, float tv, float pv) {
+        const float d = tv - pv, a = fabsf(d);
         float l, g;                                     // g = d l / d (target - pred)
         if (kind == 0) { l = a; g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
         else if (kind == 1) { l = d * d; g = 2.f * d; }
@@ -289,7 +289,17 @@ __global__ __launch_bounds__(1024) void k_loss_grad(int kind, size_t n, const fl
         else { l = a - 0.5f; g = d > 0.f ? 1.f : -1.f; }
         s += l;
         d_pred[i] = -g * inv_n;
+    };
+    // eight of a thread's elements requested together (36 dependent round trips at n = 36 864 were the kernel's 22 us), summed in the same order
+    size_t i = threadIdx.x;
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {
+        float tv[8], pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { tv[u] = target[i + (size_t)u * 1024]; pv[u] = pred[i + (size_t)u * 1024]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) one(i + (size_t)u * 1024, tv[u], pv[u]);
     }
+    for (; i < n; i += 1024) one(i, target[i], pred[i]);
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
