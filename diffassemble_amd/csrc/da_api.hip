@@ -150,6 +150,8 @@ struct Workspace {
     float *model_out_unc;
     char *dq, *dk, *dvt, *dskip;      // dense path: head-major Q, K, V ([H][n_pad][C] each), row-major skip
     size_t dense_off, dense_bytes;    // [dq, dq + dense_bytes) is zero-filled once per Batch
+    unsigned *virt_cnt;               // hybrid graphs with virtual rows: arrival counters of the rows' workgroups (inside the zero-filled region) ...
+    float *virt_part;                 // ... and their partial softmax states (AttnDenseParams::v_cnt / v_part)
     float *model_out, *xbuf0, *xbuf1;
     size_t total;
 };
@@ -181,6 +183,7 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
     w.z = take(np * d->D * s);
     w.hh = take(nrp * d->head_hidden * s);
     w.dq = w.dk = w.dvt = w.dskip = nullptr;
+    w.virt_cnt = nullptr; w.virt_part = nullptr;
     w.dense_off = off;
     w.dense_bytes = 0;
     if ((g->dense || g->hybrid) && g->n_pad > 0) {
@@ -188,7 +191,9 @@ static Workspace carve(const da_denoiser *d, const da_graph *g, void *base) {
         w.dq = take(hb);
         w.dk = take(hb);
         w.dvt = take(hb);
+        if (g->hybrid && n > nr) w.virt_cnt = (unsigned *)take((n - nr) * sizeof(unsigned));
         w.dense_bytes = off - w.dense_off;
+        if (g->hybrid && n > nr) w.virt_part = (float *)take((n - nr) * (size_t)DA_VIRT_SPLIT_MAX * 64 * 6 * sizeof(float));
         w.dskip = take(np * (size_t)hcmax * s);
     }
     const int cpose = d->variant == DA_VARIANT_3D ? 7 : d->c_out;
@@ -410,7 +415,31 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                 if (g->hybrid) {
                     // sparse-but-heavy graphs: masked MFMA attention over the regular edges (partial softmax
                     // state), then the remaining edges + normalisation + skip / activation on the CSR side
-                    const DenseMask mk = dense_mask_of(g);
+                    DenseMask mk = dense_mask_of(g);
+                    // SMALL Batches (below 8 192 pieces: the ones that do not fork a side stream below): the virtual rows inside the masked
+                    // attention's own launch (bf16 hidden layers: k_attn_optt<32, false, true>; da_config disable_folds bit 5 keeps the two-kernel
+                    // form) -- the scripted 8-puzzle Batch 0.152 -> 0.114 ms per step, 0.085 -> 0.066 / 0.052 -> 0.043 per Batch-step with two /
+                    // four Batches in flight.  Large Batches keep the side stream: configuration 3 measured -2 % ... +4 % with the rows in the
+                    // launch, depending on where in the grid they sit (profiles/r06/r06_virtual_rows_in_launch_ab*.log).
+                    // (experiments build: DA_VIRT_IN_LAUNCH=0 two kernels everywhere, =2 in the launch for every Batch)
+                    int virt_taken = 0;
+                    [[maybe_unused]] const int vil = DA_XENV("DA_VIRT_IN_LAUNCH", 1);
+                    if (n > nr && !resid && w.virt_cnt && w.virt_part && !(cfg().disable_folds & DA_FOLD_HYBRID_OVERLAP) && vil && (g->n_real < 8192 || vil == 2)) {
+                        mk.v_rows = n - nr; mk.v_n_real = nr;
+                        mk.v_row_ptr = g->agg_row_ptr ? g->agg_row_ptr : g->irr_row_ptr; mk.v_col_src = g->agg_row_ptr ? g->agg_col_src : g->irr_col_src;
+                        mk.v_mult = g->agg_row_ptr ? g->agg_mult : nullptr;
+                        mk.v_part = w.virt_part; mk.v_cnt = w.virt_cnt; mk.v_taken = &virt_taken;
+                        rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
+                            return launch_attn_dense(prec, L, d->heads, c.C, g->n_graphs, g->max_graph_nodes, g->graph_ptr, g->pad_ptr, 0, resid, act, dst, st, &mk); });
+                        if (rc) return rc < 0 ? 1 : rc;
+                        if (!virt_taken) {          // (a kernel without the extra workgroups took the layer: the rows' own kernel behind it)
+                            rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
+                                return launch_attn_csr_cont(prec, n, nr, mk.v_row_ptr, mk.v_col_src, g->row_map, d->heads, c.C, g->n_pad, L, resid, act, dst, st, mk.v_mult); });
+                            if (rc) return rc < 0 ? 1 : rc;
+                        }
+                        xin = dst; ldx = c.hc;
+                        continue;
+                    }
                     // (small Batches keep the virtual rows on the caller's stream: below ~8 k pieces the fork / join costs more than the overlap
                     //  buys -- the scripted 8-puzzle Batch: 0.165 -> 0.152 ms per step, profiles/r06/r06_scripted_side_stream_variants.log)
                     if (d->side_stream && !d->prof_on && n > nr && g->n_real >= 8192) {
@@ -1206,6 +1235,7 @@ int da_debug_counters(int64_t *out, int n, int reset) {
     out[DA_DBG_DUAL_GEN_SLABS] = (int64_t)b2[0];
     out[DA_DBG_OPT_MASKED_GEN_WORKGROUPS] = (int64_t)a[2];
     out[DA_DBG_RES_LAUNCHES] = (int64_t)da::attn_res_launches(reset);
+    out[DA_DBG_VIRT_IN_LAUNCH] = (int64_t)da::attn_virt_launches(reset);
     return 0;
 }
 

@@ -42,6 +42,15 @@ struct AttnDenseParams {
     // k_attn_res<.., 64> (the layer's projection in the kernel's prologue: no projection kernel ran; Q / K / Vt / S above are WRITTEN by the
     // kernel -- K | V only into its LDS image): the layer's input rows, the per-head weight fragments of pack_w_qs and the four bias blocks
     // (Q's carries the softmax scale like its weights)
+    // k_attn_optt<32, false, true> (hidden layers of hybrid graphs): the rows the masked attention does NOT own -- the exophormer's virtual nodes
+    // (exophormer_gnn.py:183-200) -- ride the same launch as v_rows * v_split extra workgroups behind the attention's (launch_optt): no second
+    // kernel, no second stream.  v_row_ptr / v_col_src / v_mult: their remainder CSR by destination over all nodes (da_graph.agg_* or irr_*),
+    // v_part / v_cnt: per-Batch scratch (partial softmax states of a row's workgroups; arrival counters, zero between launches).
+    int v_rows, v_split, v_n_real;
+    const int32_t *v_row_ptr, *v_col_src;
+    const float *v_mult;
+    float *v_part;                  // [v_rows][v_split][64 lanes][6]: m, l, acc[4]
+    unsigned *v_cnt;                // [v_rows]
     const void *x;                  // [N][ldx] bf16 (null: Q / K / V / S come from memory)
     int ldx, kin;                   // kin = reduction length (128 / 256)
     const void *wqs;
@@ -297,6 +306,7 @@ template <int C, int BK = 64> struct OptK {
 
 // da_attn_opt.hip: the optimistic kernels (bf16, Q pre-scaled, 32-wide value heads); 0 = launched, -1 = shape not covered
 int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st);
+bool attn_opt_took_virtual_rows();          // whether the last launch_attn_opt of this thread carried p.v_rows virtual rows in its grid
 int attn_opt_counters(unsigned long long *out2, int reset);
 
 }  // namespace da

@@ -873,6 +873,11 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     p.blk_class = mk ? mk->blk_class : nullptr; p.blk_class_ptr = mk ? (const long long *)mk->blk_class_ptr : nullptr;
     p.blk_class_stride = mk ? mk->blk_class_stride : 0;
     p.rm_meta = mk ? mk->rm_meta : nullptr;
+    const bool virt = mk && mk->v_rows > 0 && mk->v_row_ptr && mk->v_col_src && mk->v_part && mk->v_cnt && mk->v_taken && !fold && !res;
+    p.v_rows = virt ? mk->v_rows : 0; p.v_split = 0; p.v_n_real = virt ? mk->v_n_real : 0;
+    p.v_row_ptr = virt ? mk->v_row_ptr : nullptr; p.v_col_src = virt ? mk->v_col_src : nullptr; p.v_mult = virt ? mk->v_mult : nullptr;
+    p.v_part = virt ? mk->v_part : nullptr; p.v_cnt = virt ? mk->v_cnt : nullptr;
+    if (mk && mk->v_taken) *mk->v_taken = 0;
     { const char *e = DA_XENV_LIVE("DA_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
     if (p.x && DA_XENV("DA_QSF_FAKE_FM", 0)) p.debug = 77;
     { const int fg = DA_XENV("DA_ATTN_FORCE_GEN", 0) ? 1 : 0; p.force_gen = fg; if (fg) p.fast = p.fast ? 2 : 0; }
@@ -902,8 +907,10 @@ int launch_attn_dense(int prec, const DenseLayout &L, int heads, int C, int n_gr
     }
     if (prec == DA_PREC_BF16 && C == 32 && L.q_prescaled && p.fast && attn_opt_env() && (!p.mask || attn_opt_masked_env()) DA_ATTN_DBG(&& !p.debug && !p.prof)) {
         const int ro = launch_attn_opt(p, C, st);
+        if (ro == 0 && p.v_rows > 0 && attn_opt_took_virtual_rows()) *mk->v_taken = 1;
         if (ro >= 0) return ro;
     }
+    p.v_rows = 0;          // (the other kernels do not carry the virtual rows: the caller launches launch_attn_csr_cont)
     DA_REQUIRE(!p.x, "launch_attn_dense: projection in the prologue requested for a layer the resident kernel does not take");
 #ifdef DA_EXPERIMENTS
     if (prec == DA_PREC_BF16 && C == 32 && !p.mask && attn2_env() DA_ATTN_DBG(&& !p.debug && !p.prof))

@@ -54,6 +54,129 @@ namespace da {
 // da_debug_counters: workgroups whose optimistic pass failed its verification ([0] complete graphs, [1] adjacency-masked)
 __device__ unsigned long long g_opt_fallbacks[2];
 
+// ---- the virtual rows of the exophormer arch as extra workgroups of the masked hidden-layer launch (round 6).
+// A virtual node has no regular edge: its row is an online softmax over its remainder CSR (every real node of some graphs, the other virtual
+// nodes, duplicates merged with multiplicities), 32-wide heads: lane = (head, 4-channel slice), a row's edges dealt out over the 4 * v_split
+// waves of its v_split workgroups, four edges' K / V rows in flight per wave, their slots fetched one trip ahead (k_attn_csr_cont_heavy's walk).
+// The partial states of a workgroup's waves meet in LDS, those of a row's workgroups in p.v_part: the workgroup that arrives last (p.v_cnt)
+// merges them IN INDEX ORDER (deterministic), adds skip, applies the activation and resets the counter.  As a second kernel on the same stream
+// these rows were 14 of a scripted Batch's 28 us per hidden layer (every kernel there sits at its launch floor); on a second stream they
+// needed a fork and a join per layer.  Reference: the same TransformerConv rows (exophormer_gnn.py:203-205 over the edges of :183-200).
+__device__ __forceinline__ void virt_rows_block(const AttnDenseParams &p, int vb, unsigned char *smem) {
+    constexpr int EPL = 4, U = 4, C = 32;
+    const int row = vb / p.v_split, part = vb - row * p.v_split;
+    const int i = p.v_n_real + row;
+    const int beg = p.v_row_ptr[i], end = p.v_row_ptr[i + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int head = lane >> 3, sub = (lane & 7) * EPL;
+    const size_t hb = (size_t)head * (size_t)p.n_pad;
+    const bf16_t *Q = (const bf16_t *)p.Q, *K = (const bf16_t *)p.K, *V = (const bf16_t *)p.Vt;
+    const float scale = 0.6931471805599453f;          // Q is pre-scaled by log2(e) / sqrt(C): q . k is in log2 units
+    float q[EPL], acc[EPL];
+    {
+        const u32x2 qq = *(const u32x2 *)(Q + (hb + (size_t)p.row_map[i]) * C + sub);
+        q[0] = bf2f((bf16_t)(qq[0] & 0xffff)) * scale; q[1] = bf2f((bf16_t)(qq[0] >> 16)) * scale;
+        q[2] = bf2f((bf16_t)(qq[1] & 0xffff)) * scale; q[3] = bf2f((bf16_t)(qq[1] >> 16)) * scale;
+    }
+#pragma unroll
+    for (int x = 0; x < EPL; ++x) acc[x] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int NWT = 4 * p.v_split, gw = part * 4 + wv;
+    size_t sjn[U];
+    bool okn[U];
+    float wgtn[U];
+    auto fetch_idx = [&](int e0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * NWT;
+            okn[u] = e < end;
+            sjn[u] = hb + (size_t)p.row_map[p.v_col_src[okn[u] ? e : beg]];
+            wgtn[u] = p.v_mult ? p.v_mult[okn[u] ? e : beg] : 1.0f;
+        }
+    };
+    if (beg + gw < end) fetch_idx(beg + gw);
+    for (int e0 = beg + gw; e0 < end; e0 += NWT * U) {
+        size_t sj[U];
+        bool ok[U];
+        float wgt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { sj[u] = sjn[u]; ok[u] = okn[u]; wgt[u] = wgtn[u]; }
+        u32x2 kk[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { kk[u] = *(const u32x2 *)(K + sj[u] * C + sub); vv[u] = *(const u32x2 *)(V + sj[u] * C + sub); }
+        if (e0 + NWT * U < end) fetch_idx(e0 + NWT * U);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;                            // wave-uniform
+            float s_ = q[0] * bf2f((bf16_t)(kk[u][0] & 0xffff));
+            s_ = fmaf(q[1], bf2f((bf16_t)(kk[u][0] >> 16)), s_);
+            s_ = fmaf(q[2], bf2f((bf16_t)(kk[u][1] & 0xffff)), s_);
+            s_ = fmaf(q[3], bf2f((bf16_t)(kk[u][1] >> 16)), s_);
+            s_ += __shfl_xor(s_, 1);
+            s_ += __shfl_xor(s_, 2);
+            s_ += __shfl_xor(s_, 4);
+            const float mn = fmaxf(m, s_);
+            const float corr = expf(m - mn);
+            const float pr = expf(s_ - mn) * wgt[u];
+            l = l * corr + pr;
+            acc[0] = fmaf(pr, bf2f((bf16_t)(vv[u][0] & 0xffff)), acc[0] * corr);
+            acc[1] = fmaf(pr, bf2f((bf16_t)(vv[u][0] >> 16)), acc[1] * corr);
+            acc[2] = fmaf(pr, bf2f((bf16_t)(vv[u][1] & 0xffff)), acc[2] * corr);
+            acc[3] = fmaf(pr, bf2f((bf16_t)(vv[u][1] >> 16)), acc[3] * corr);
+            m = mn;
+        }
+    }
+    // ---- the workgroup's four waves: (m, l, acc) per lane through LDS, merged by wave 0 in wave order
+    float *sh = (float *)smem;                               // [4 waves][64 lanes][6]
+    {
+        float *o_ = sh + ((size_t)wv * 64 + lane) * 6;
+        o_[0] = m; o_[1] = l; o_[2] = acc[0]; o_[3] = acc[1]; o_[4] = acc[2]; o_[5] = acc[3];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    auto merge = [&](auto get, int cnt, float &M, float &L, float (&a)[EPL]) {          // get(w, k): field k of partial state w of this lane
+        M = -INFINITY;
+        for (int w = 0; w < cnt; ++w) M = fmaxf(M, get(w, 0));
+        L = 0.f;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) a[x] = 0.f;
+        for (int w = 0; w < cnt; ++w) {
+            const float lw = get(w, 1);
+            if (!(lw > 0.f)) continue;
+            const float f = expf(get(w, 0) - M);
+            L = fmaf(lw, f, L);
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) a[x] = fmaf(get(w, 2 + x), f, a[x]);
+        }
+    };
+    float M, L;
+    merge([&](int w, int k) { return sh[((size_t)w * 64 + lane) * 6 + k]; }, 4, M, L, acc);
+    if (p.v_split > 1) {
+        // (no fence: an agent-scope fence is an L2 write-back + invalidate on this chip, and two thousand workgroups issuing one each cost the
+        //  layer 130 us -- measured.  The partial states go to the L2 as relaxed agent-scope atomics, the wait below lets them arrive there, the
+        //  arrival counter lives there, and the last workgroup reads them from there.)
+        float *mine = p.v_part + (((size_t)row * p.v_split + part) * 64 + lane) * 6;
+        const float st6[6] = {M, L, acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) __hip_atomic_store(mine + k, st6[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(p.v_cnt + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        if ((int)old != p.v_split - 1) return;               // somebody else arrives last
+        const float *all = p.v_part + ((size_t)row * p.v_split * 64 + lane) * 6;
+        merge([&](int w, int k) { return __hip_atomic_load(all + (size_t)w * 64 * 6 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, p.v_split, M, L, acc);
+        if (lane == 0) __hip_atomic_store(p.v_cnt + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch
+    }
+    const float inv = L > 0.f ? 1.0f / (L + 1e-16f) : 0.f;
+    const size_t o = (size_t)i * (size_t)(p.H * C) + (size_t)head * C + sub;
+    const u32x2 sk = *(const u32x2 *)((const bf16_t *)p.S + o);
+    float v4[4] = {acc[0] * inv + bf2f((bf16_t)(sk[0] & 0xffff)), acc[1] * inv + bf2f((bf16_t)(sk[0] >> 16)),
+                   acc[2] * inv + bf2f((bf16_t)(sk[1] & 0xffff)), acc[3] * inv + bf2f((bf16_t)(sk[1] >> 16))};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) stf((bf16_t *)p.out + o + x, apply_act(v4[x], p.act));
+}
+
 // (OptK -- the K tile geometry of these kernels -- lives in da_attn_common.h)
 // BK = keys per ring stage (64: two 32-key blocks per stage and barrier; 32: one -- half the bytes per stage, so that a
 // deeper ring fits the same LDS); VAR = instruction-mix experiments (bit 0: row sums as f32 adds of the un-rounded
@@ -79,6 +202,16 @@ __global__ __launch_bounds__(64 * NWV, MINB) void k_attn_optt(AttnDenseParams p)
     static_assert(CF::NCB == 1, "one 32-channel value block");
     constexpr int MAXI = (KG::NI + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int vfirst = 0;          // workgroups in FRONT of the attention's own: the virtual rows (virt_rows_block above) -- their latency chains run under the attention
+    if constexpr (C == 32 && !FOLD && MASKED && NWV == 4) {
+        if (p.v_rows > 0) {
+            vfirst = (p.v_rows * p.v_split + 7) & ~7;          // (a multiple of eight: the attention's head -> XCD map keeps its phase)
+            if ((int)blockIdx.x < vfirst) {
+                if ((int)blockIdx.x < p.v_rows * p.v_split) virt_rows_block(p, (int)blockIdx.x, smem);
+                return;
+            }
+        }
+    }
     DA_OPB(const unsigned long long pb_start = __builtin_readcyclecounter(), pb_wall0 = wall_clock64();)
     constexpr int MSTAGE = KG::STAGE + (MASKED ? 1024 : 0);     // MASKED: + the four waves' adjacency-word slots (256 B each)
     int *flags = (int *)(smem + NST * MSTAGE);                  // one word per wave: "my optimistic pass failed"; [4 .. 11]: the waves' tile masks
@@ -91,7 +224,7 @@ __global__ __launch_bounds__(64 * NWV, MINB) void k_attn_optt(AttnDenseParams p)
     // (visible to every wave after the first barrier of the tile loop)
 
     // XCD-aware remap (as k_attn_dense): XCD x takes head x of every graph, the query tiles of one (graph, head) run back to back on it
-    const int bid = blockIdx.x;
+    const int bid = (int)blockIdx.x - vfirst;
     const int h = bid & 7, s_ = bid >> 3;
     const int qt = s_ % p.nqt, g = s_ / p.nqt;
     const int node0 = p.graph_ptr[g], n_g = p.graph_ptr[g + 1] - node0, pad0 = p.pad_ptr[g];
@@ -714,6 +847,13 @@ __global__ __launch_bounds__(64 * NWV, MINB) void k_attn_optt(AttnDenseParams p)
     DA_OPB(pb_out();)
 }
 
+static long long g_virt_launches = 0;      // da_debug_counters [DA_DBG_VIRT_IN_LAUNCH]
+long long attn_virt_launches(int reset) {
+    return reset ? __atomic_exchange_n(&g_virt_launches, 0ll, __ATOMIC_RELAXED) : __atomic_load_n(&g_virt_launches, __ATOMIC_RELAXED);
+}
+static thread_local bool t_virt_taken = false;
+bool attn_opt_took_virtual_rows() { return t_virt_taken; }
+
 template <int C, bool FOLD, bool MASKED, int NST, int MINB, int BK = 64, int VAR = 0, int NWV = 4>
 static int launch_optt(AttnDenseParams p, hipStream_t st) {
     const int lds = NST * (OptK<C, BK>::STAGE + (MASKED ? 1024 : 0)) + 64 + (MASKED ? 256 + 512 : 0);
@@ -726,7 +866,21 @@ static int launch_optt(AttnDenseParams p, hipStream_t st) {
     }
     p.nqt = (p.max_nodes + 32 * NWV - 1) / (32 * NWV);
     DA_OPB({ const char *e = DA_XENV_LIVE("DA_OPT_PROF_PTR"); p.prof = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; })
-    k_attn_optt<C, FOLD, MASKED, NST, MINB, BK, VAR, NWV><<<p.nqt * p.H * p.n_graphs, 64 * NWV, lds, st>>>(p);
+    int grid = p.nqt * p.H * p.n_graphs;
+    t_virt_taken = false;
+    if constexpr (C == 32 && !FOLD && MASKED && NWV == 4) {
+        if (p.v_rows > 0) {
+            // workgroups per virtual row: four waves each; sixteen waves per row as the stand-alone kernel had, thirty-two for large Batches (rows
+            // with ~900 sources each)
+            p.v_split = p.v_n_real >= 8192 ? DA_VIRT_SPLIT_MAX : 4;
+            grid += (p.v_rows * p.v_split + 7) & ~7;
+            t_virt_taken = true;
+            __atomic_fetch_add(&g_virt_launches, 1ll, __ATOMIC_RELAXED);
+        }
+    } else {
+        p.v_rows = 0;
+    }
+    k_attn_optt<C, FOLD, MASKED, NST, MINB, BK, VAR, NWV><<<grid, 64 * NWV, lds, st>>>(p);
     DA_LAUNCH_CHECK();
     return 0;
 }
@@ -1487,6 +1641,7 @@ static int launch_res(const AttnDenseParams &p, hipStream_t st) {
 // small-graph resident forms, the ablation builds) exist in the EXPERIMENTS build only (da_config.h).
 int launch_attn_opt(const AttnDenseParams &p, int C, hipStream_t st) {
     const bool fold = p.fold_out != nullptr, masked = p.mask != nullptr;
+    t_virt_taken = false;
     if (masked && p.max_nodes > 4096) return -1;          // the masked walk keeps its key tiles in a 64-bit mask
     if (masked && p.blk_class && p.blk_class_stride > 128) return -1;      // class rows are staged in 128-byte LDS slots
     if (C == 32 && !fold) {

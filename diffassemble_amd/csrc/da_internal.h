@@ -161,7 +161,16 @@ struct DenseMask {             // hybrid mode: adjacency bits of the regular edg
     const int64_t *blk_class_ptr = nullptr;
     int blk_class_stride = 0;
     const int32_t *rm_meta = nullptr;              // per-slot remainder metadata (da_graph.rm_meta)
+    // the virtual rows of the exophormer arch inside the masked attention's launch (AttnDenseParams::v_*): set v_rows > 0 to ask for it;
+    // *v_taken is set to 1 by the launcher whose kernel took them (else the caller launches launch_attn_csr_cont itself)
+    int v_rows = 0, v_n_real = 0;
+    const int32_t *v_row_ptr = nullptr, *v_col_src = nullptr;
+    const float *v_mult = nullptr;
+    float *v_part = nullptr;
+    unsigned *v_cnt = nullptr;
+    int *v_taken = nullptr;
 };
+constexpr int DA_VIRT_SPLIT_MAX = 8;               // workgroups per virtual row at most (sizes the scratch)
 inline DenseMask dense_mask_of(const da_graph *g) {
     DenseMask mk;
     mk.mask = g->mask; mk.mask_ptr = g->mask_ptr; mk.irr_row_ptr = g->irr_row_ptr; mk.irr_col_src = g->irr_col_src; mk.row_map = g->row_map;
@@ -184,6 +193,7 @@ int launch_attn_dual(const DenseLayout &L, int heads, int C, int n_graphs, int m
                      const int32_t *pad_ptr, int nodiag, int act, void *out, const DenseFold *fold, hipStream_t st);
 // fallback counters of the shift-free softmax kernels (da_debug_counters)
 int attn_dense_counters(unsigned long long *out4, int reset);
+long long attn_virt_launches(int reset);     // da_attn_opt.hip: masked hidden-layer launches that carried the virtual rows
 long long attn_res_launches(int reset);      // da_attn_opt.hip: launches of the K / V-resident kernel since the last reset
 int attn_dual_counters(unsigned long long *out2, int reset);
 // hybrid mode: the rows the masked kernel does not own (virtual nodes) over their remainder edges

@@ -396,6 +396,7 @@ enum {
     DA_DBG_OPT_MASKED_GEN_WORKGROUPS = 3,  /* adjacency-masked optimistic kernel: workgroups re-run                  */
     DA_DBG_RES_LAUNCHES = 4,               /* launches of the K / V-resident hidden-layer kernel (k_attn_res; its    */
                                            /* per-WAVE re-runs count under DA_DBG_OPT_GEN_WORKGROUPS)                */
+    DA_DBG_VIRT_IN_LAUNCH = 5,             /* masked hidden-layer launches that carried the exophormer's virtual rows */
     DA_DBG_NCOUNTERS = 8
 };
 int da_debug_counters(int64_t *out /* host [n] */, int n, int reset);

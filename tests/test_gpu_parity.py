@@ -155,6 +155,35 @@ def test_da_attn_csr_matches_pyg_semantics(dev, C_head, prec):
     assert rel(al, alpha) < (1e-5 if prec == "fp32" else 1e-2)
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 65])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_da_attn_csr_tiny_and_edgeless_graphs(dev, N, prec):
+    """One, two, three nodes (k_attn_csr2 puts two destination rows in a wave: the last wave is half empty for odd counts) and a graph whose
+    only edges are self loops on every other node: rows without an edge return skip alone (PyG: the softmax over an empty set aggregates nothing)."""
+    from diffassemble_amd import engine as E
+    from diffassemble_amd.graph_plan import build_plan
+    H, C_head = 8, 32
+    g = torch.Generator().manual_seed(N)
+    idx = torch.arange(0, N, 2)
+    ei = torch.stack([idx, idx])                                       # self loops on the even nodes; odd nodes isolated
+    if N >= 3:
+        ei = torch.cat([ei, torch.tensor([[0, 2], [2, 0]])], 1)
+    HC = H * C_head
+    qkvs = torch.randn(N, 4 * HC, generator=g)
+    if prec == "bf16":
+        qkvs = qkvs.bfloat16().float()
+    q, k, v, s = qkvs.split(HC, 1)
+    a = (q.view(N, H, C_head)[ei[1]] * k.view(N, H, C_head)[ei[0]]).sum(-1) / C_head ** 0.5
+    alpha = R.segment_softmax(a, ei[1], N)
+    ref = torch.zeros(N, H, C_head).index_add_(0, ei[1], v.view(N, H, C_head)[ei[0]] * alpha[:, :, None])
+    ref = torch.nn.functional.gelu(ref.reshape(N, HC) + s)
+    plan = build_plan(ei.to(dev), torch.zeros(N, dtype=torch.long, device=dev), 0)
+    out, al = E.attn_csr(plan, qkvs.to(dev), H, C_head, None, 1, True, prec)
+    assert torch.isfinite(out.float()).all()
+    assert rel(out.float(), ref) < (1e-5 if prec == "fp32" else 1e-2)
+    assert rel(al, alpha) < (1e-5 if prec == "fp32" else 1e-2)
+
+
 @pytest.mark.parametrize("C_head,Din", [(32, 256), (144, 256), (32, 1152)])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("loops", [True, False])

@@ -66,9 +66,19 @@ def test_scripted_batch_forward_and_loop_vs_oracle(dev, name, prec):
     assert bool(plan.hybrid) == hybrid and not plan.dense
     n = int(batch.numel())
     assert plan.n_edges == sum(s * s * d for s, d in zip(sides, degs)) + n + sum(V * (s * s + V) for s in sides)
+    from diffassemble_amd import engine as E
+    E.debug_counters(reset=True)
     out = eng.forward(plan, x.to(dev), t.to(dev), feats.to(dev))
+    torch.cuda.synchronize()
+    cnt = E.debug_counters(reset=True)
     tol = RTOL32 if prec == "fp32" else RTOLBF
     assert rel(out, ref) < tol, rel(out, ref)
+    import os
+    if hybrid and prec == "bf16" and "DA_DISABLE_FOLDS" not in os.environ and "DA_ATTN_LEVEL" not in os.environ:
+        # small hybrid Batches: the exophormer's virtual rows ride the masked attention's launch in the three hidden layers (virt_rows_block, da_attn_opt.hip)
+        assert cnt["virtual_rows_in_launch"] == 3, cnt
+    else:
+        assert cnt["virtual_rows_in_launch"] == 0, cnt
     # the first three DDIM steps of the scripted loop (T = 300, ratio 10, START_X, noise_weight 0 -> x_T = 0 in the script;
     # a random start here exercises more) through the captured graph
     sch_c = ODF.make_schedule(300)
