@@ -23,7 +23,8 @@ ACT_NONE, ACT_GELU, ACT_LEAKY02 = 0, 1, 2
 CONV_Q_PRESCALED, CONV_FOLDED_V32 = 1, 2
 TRAIN_MMA_FP32, TRAIN_MMA_BF16 = 0, 1
 TRAIN_BWD_ALL, TRAIN_BWD_EARLY, TRAIN_BWD_LATE = 0, 1, 2
-DBG_COUNTERS = ("opt_gen_workgroups", "dense_fast_exits", "dual_gen_slabs", "opt_masked_gen_workgroups", "resident_launches", "virtual_rows_in_launch")
+DBG_COUNTERS = ("opt_gen_workgroups", "dense_fast_exits", "dual_gen_slabs", "opt_masked_gen_workgroups")          # fallback events (indices 0 .. 3)
+DBG_LAUNCH_COUNTERS = {"resident_launches": 4, "virtual_rows_in_launch": 5}          # which kernel took a layer (DA_DBG_RES_LAUNCHES, DA_DBG_VIRT_IN_LAUNCH)
 PROF_CLASSES = ("embed", "linear_mlp", "linear_qkvs", "attn_hidden", "attn_last", "head", "update", "conv_fused")
 
 _fp = C.c_void_p        # device pointers travel as integers

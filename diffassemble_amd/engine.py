@@ -540,6 +540,14 @@ def debug_counters(reset=True):
     return {name: int(buf[k]) for k, name in enumerate(_lib.DBG_COUNTERS)}
 
 
+def launch_counters(reset=True):
+    """Which kernels took the layers since the last reset (da_debug_counters [DA_DBG_RES_LAUNCHES], [DA_DBG_VIRT_IN_LAUNCH]): launches of the
+    K / V-resident hidden-layer kernel, masked hidden-layer launches that carried the exophormer's virtual rows.  NOTE: resets every counter."""
+    buf = (C.c_int64 * 8)()
+    _lib.check(_lib.lib().da_debug_counters(buf, 8, 1 if reset else 0))
+    return {name: int(buf[k]) for name, k in _lib.DBG_LAUNCH_COUNTERS.items()}
+
+
 def resident_attention_launches(reset=True):
     """Launches of the K / V-resident hidden-layer attention kernel (k_attn_res, da_attn_opt.hip) since the last reset
     (da_debug_counters [DA_DBG_RES_LAUNCHES]): lets a test assert which kernel took a layer.  NOTE: resets every counter."""

@@ -67,10 +67,10 @@ def test_scripted_batch_forward_and_loop_vs_oracle(dev, name, prec):
     n = int(batch.numel())
     assert plan.n_edges == sum(s * s * d for s, d in zip(sides, degs)) + n + sum(V * (s * s + V) for s in sides)
     from diffassemble_amd import engine as E
-    E.debug_counters(reset=True)
+    E.launch_counters(reset=True)
     out = eng.forward(plan, x.to(dev), t.to(dev), feats.to(dev))
     torch.cuda.synchronize()
-    cnt = E.debug_counters(reset=True)
+    cnt = E.launch_counters(reset=True)
     tol = RTOL32 if prec == "fp32" else RTOLBF
     assert rel(out, ref) < tol, rel(out, ref)
     import os
