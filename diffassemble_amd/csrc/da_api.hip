@@ -287,9 +287,18 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
     int rc;
     // (a-3) embedding: pose MLP + learned timestep lookup into the concat buffer, then mlp
     // (h_ready: the previous step's tail kernel already wrote this step's w.h -- DdimFuse::nx_*, sampling loops only)
+    // exophormer, dense / hybrid path: the virtual rows' constant conv-0 projections are placed by extra workgroups of the embedding's launch (they
+    // depend on nothing of this step; the layer-0 code below skips its launch_scatter_virtual then)
+    VirtScatter vsc;
+    bool virt_scattered = false;
+    if (!h_ready && d->fused_mlp2 && n > nr && !alpha && w.dq && d->virt_qkvs_d && dense_ok(g, d->heads, d->conv[0].C) && DA_XENV("DA_VIRT_SCATTER_IN_EMBED", 1)) {
+        vsc.rows = n - nr; vsc.V = d->V; vsc.H = d->heads; vsc.C = d->conv[0].C; vsc.n_real = nr; vsc.n_pad = g->n_pad;
+        vsc.src = d->virt_qkvs_d; vsc.row_map = g->row_map; vsc.Q = w.dq; vsc.K = w.dk; vsc.Vt = w.dvt; vsc.S = w.dskip;
+        virt_scattered = true;
+    }
     if (!h_ready && (rc = timed(d, DA_PROF_EMBED, st, [&] {
              return launch_embed_pos_time(prec, nr, d->c_in, d->F, D, x, t, t_scalar, d->steps, d->time_emb,
-                                          d->pos_w0, d->pos_b0, d->pos_w1, d->pos_b1, w.comb_in, st); }))) return rc;
+                                          d->pos_w0, d->pos_b0, d->pos_w1, d->pos_b1, w.comb_in, st, virt_scattered ? &vsc : nullptr); }))) return rc;
     const int act1 = d->variant == DA_VARIANT_3D ? DA_ACT_LEAKY02 : DA_ACT_GELU;
     const int act2 = d->variant == DA_VARIANT_3D ? DA_ACT_LEAKY02 : DA_ACT_NONE;
     // mlp.0 over [features | pose | time]: the feature columns (F of the D inputs) do not change inside a
@@ -405,7 +414,7 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                 return launch_gemm_mfma(prec, nproj, c.din, 4 * c.hc, xin, ldx, wdense, bdense, DA_ACT_NONE, nullptr, nullptr, 0, &qs, st, 0,
                                         nullptr, wpanel); });
             if (rc > 0) return rc;
-            if (rc == 0 && virt0 &&
+            if (rc == 0 && virt0 && !virt_scattered &&
                 (rc = launch_scatter_virtual(prec, n - nr, d->V, d->heads, c.C, d->virt_qkvs_d, nr, g->row_map, g->n_pad, w.dq, w.dk,
                                              w.dvt, w.dskip, nullptr, st))) return rc;
             if (rc == 0) {

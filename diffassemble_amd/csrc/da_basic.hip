@@ -40,14 +40,31 @@ __global__ __launch_bounds__(256) void k_set_virtual_rows(int rows, int V, int D
 // row j of the first linear, lane o < 32: row o of the second): one wave per node spent its life on launch, 16 weight
 // loads per lane and a workgroup barrier (57 600 waves, 23.7 us per step at 64 puzzles).  The 16 hidden activations cross
 // lanes through a wave-private LDS row; same operation order as before.
+// Workgroups behind the embedding's own (vs.rows > 0): the exophormer's virtual rows' conv-0 projections into the head-major buffers
+// (k_scatter_virtual's job, a launch of its own on the critical path of small Batches otherwise).
 template <typename T>
 __global__ __launch_bounds__(256) void k_embed_pos_time(int n, int NPW, int c_in, int F, int D, const float *__restrict__ x,
                                                         const int64_t *__restrict__ t, int64_t t_scalar, int steps,
                                                         const float *__restrict__ time_emb,
                                                         const float *__restrict__ w0, const float *__restrict__ b0,
                                                         const float *__restrict__ w1, const float *__restrict__ b1,
-                                                        T *__restrict__ comb_in) {
+                                                        T *__restrict__ comb_in, int embed_blocks, VirtScatter vs) {
     __shared__ float hid[4][16];
+    if ((int)blockIdx.x >= embed_blocks) {
+        const int HC = vs.H * vs.C;
+        const size_t total = (size_t)vs.rows * 4 * HC, stride = (size_t)(gridDim.x - embed_blocks) * blockDim.x;
+        for (size_t idx = (size_t)(blockIdx.x - embed_blocks) * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+            const size_t r = idx / (4 * (size_t)HC);
+            const int col = (int)(idx - r * 4 * HC), which = col / HC, f = col - which * HC;
+            const T v = ((const T *)vs.src)[(size_t)(r % vs.V) * 4 * HC + col];
+            const size_t node = (size_t)vs.n_real + r;
+            if (which == 3) { ((T *)vs.S)[node * HC + f] = v; continue; }
+            const int h = f / vs.C, c = f - h * vs.C;
+            T *dstb = (T *)(which == 0 ? vs.Q : (which == 1 ? vs.K : vs.Vt));
+            dstb[((size_t)h * (size_t)vs.n_pad + (size_t)vs.row_map[node]) * vs.C + c] = v;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r0 = (blockIdx.x * 4 + wv) * NPW;
     if (r0 >= n) return;
@@ -226,16 +243,20 @@ int launch_set_virtual_rows(int prec, int rows, int V, int D, const void *emb, v
 
 int launch_embed_pos_time(int prec, int n, int c_in, int F, int D, const float *x, const int64_t *t, int64_t t_scalar,
                           int steps, const float *time_emb, const float *w0, const float *b0, const float *w1,
-                          const float *b1, void *comb_in, hipStream_t st) {
+                          const float *b1, void *comb_in, hipStream_t st, const VirtScatter *vsp) {
     if (n <= 0) return 0;
     if (c_in > 8) { set_error("launch_embed_pos_time: c_in %d > 8", c_in); return 2; }
+    VirtScatter vs;
+    if (vsp && vsp->rows > 0) vs = *vsp;
+    const size_t vtotal = (size_t)vs.rows * 4 * vs.H * vs.C;
+    const int vblocks = vs.rows > 0 ? (int)((vtotal + 255) / 256 > 1024 ? 1024 : (vtotal + 255) / 256) : 0;
     const int npw_env = DA_XENV("DA_EMBED_NPW", 0);
     // nodes per wave: one while the batch is too small to cover the chip otherwise, eight from 8 192 nodes up
     const int npw = npw_env > 0 ? npw_env : (n >= 8192 ? 8 : 1), grid = (n + 4 * npw - 1) / (4 * npw);
     if (prec == DA_PREC_BF16)
-        k_embed_pos_time<bf16_t><<<grid, 256, 0, st>>>(n, npw, c_in, F, D, x, t, t_scalar, steps, time_emb, w0, b0, w1, b1, (bf16_t *)comb_in);
+        k_embed_pos_time<bf16_t><<<grid + vblocks, 256, 0, st>>>(n, npw, c_in, F, D, x, t, t_scalar, steps, time_emb, w0, b0, w1, b1, (bf16_t *)comb_in, grid, vs);
     else
-        k_embed_pos_time<float><<<grid, 256, 0, st>>>(n, npw, c_in, F, D, x, t, t_scalar, steps, time_emb, w0, b0, w1, b1, (float *)comb_in);
+        k_embed_pos_time<float><<<grid + vblocks, 256, 0, st>>>(n, npw, c_in, F, D, x, t, t_scalar, steps, time_emb, w0, b0, w1, b1, (float *)comb_in, grid, vs);
     DA_LAUNCH_CHECK();
     return 0;
 }

@@ -53,9 +53,17 @@ struct DdimFuse {
 // da_basic.hip
 int launch_set_feats(int prec, int n, int F, int D, const float *feats, void *comb_in, hipStream_t st);
 int launch_set_virtual_rows(int prec, int rows, int V, int D, const void *emb, void *dst, hipStream_t st);
+// the constant conv-0 projections of the exophormer's virtual rows (launch_scatter_virtual's arguments): given to launch_embed_pos_time they are
+// placed by extra workgroups of the embedding's launch -- the first kernel of a step -- instead of a launch of their own behind the projection
+struct VirtScatter {
+    int rows = 0, V = 0, H = 0, C = 0, n_real = 0, n_pad = 0;
+    const void *src = nullptr;
+    const int32_t *row_map = nullptr;
+    void *Q = nullptr, *K = nullptr, *Vt = nullptr, *S = nullptr;
+};
 int launch_embed_pos_time(int prec, int n, int c_in, int F, int D, const float *x, const int64_t *t, int64_t t_scalar,
                           int steps, const float *time_emb, const float *w0, const float *b0, const float *w1,
-                          const float *b1, void *comb_in, hipStream_t st);
+                          const float *b1, void *comb_in, hipStream_t st, const VirtScatter *vs = nullptr);
 int launch_gemm_simple(int prec, int M, int K, int Nout, const void *A, int lda, const void *W, const float *bias,
                        int act, const void *res, void *out, int ldo, hipStream_t st);
 int launch_head2d(int prec, int n, int c_out, const void *hh, const float *w2, const float *b2, float *out, hipStream_t st);
