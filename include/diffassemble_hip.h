@@ -57,7 +57,8 @@ typedef struct da_config {
     int32_t disable_dense;       /* DA_DISABLE_DENSE=1: every attention walks the edge list (CSR kernels)            */
     int32_t disable_folds;       /* DA_DISABLE_FOLDS=<bits>: 1 mlp.2 composed into its consumers, 2 folded last      */
                                  /* layer, 4 softmax scale inside Wq, 8 DDIM update inside the head kernel,          */
-                                 /* 16 one-kernel tail, 32 virtual rows on a side stream (hybrid graphs)             */
+                                 /* 16 one-kernel tail, 32 virtual rows on a side stream / inside the masked         */
+                                 /* attention's launch (hybrid graphs)                                               */
     int32_t attn_level;          /* DA_ATTN_LEVEL: 0 = the general dense kernel only, 1 = + the optimistic ring      */
                                  /* kernels, 2 = + the K/V-resident hidden-layer kernel (default)                    */
     int32_t xpanel;              /* DA_ENABLE_XPANEL: -1 = row-panel projections for large Batches (largest graph    */
