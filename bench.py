@@ -308,6 +308,24 @@ def cpu_baseline(cfg, sd, degree, full=False):
     return out
 
 
+def exchange_prediction(te, acc, kp, step_ms):
+    """What the 1 -> 8 curve should look like on one xGMI node, stated BEFORE anybody could measure it (no 8-GPU node was available in any round;
+    VERDICT r05 item 8): the step's two gradient buckets through a ring all-reduce.  Model: t(bytes) = latency + 2 (N - 1) / N * bytes / busbw, with
+    latency 25 us per collective and busbw 150 GB/s for 5 - 8 MB messages (xGMI is point to point, 7 links x ~153 GB/s per GPU: a ring is bound by ONE
+    link per hop; 150 GB/s is the link rate, not the 300+ GB/s large-message figure of multi-ring RCCL).  The early bucket (final_mlp, convs 1 .. L - 1)
+    is all-reduced under conv 0's backward + the embedding's (TrainEngine.backward) and counts only where it outlasts them; the late bucket is exposed."""
+    early, late = 4 * (te.total - te.early_off), 4 * te.early_off
+    out = {"model": "ring all-reduce, 25 us + 2 (N - 1) / N x bytes / 150 GB/s per bucket; early bucket hidden under conv 0's backward (~15 % of forward+backward)",
+           "bucket_bytes": {"early": early, "late": late}, "step_ms_one_gpu": step_ms, "by_gpus": {}}
+    cover_ms = 0.15 * acc[0] / kp
+    for N in (2, 4, 8):
+        def t(b):
+            return 0.025 + 2 * (N - 1) / N * b / 150e9 * 1e3
+        exposed = t(late) + max(0.0, t(early) - cover_ms)
+        out["by_gpus"][str(N)] = {"exposed_ms": exposed, "predicted_scaling_efficiency": step_ms / (step_ms + exposed)}
+    return out
+
+
 def train_bench(args, world, rank, dev):
     """BASELINE config 5: 12x12 rot dense puzzles, 64 per GPU, Huber loss, one optimizer step per "step":
     p_losses (q_sample + denoiser forward, HIP) -> backward (HIP) -> ONE all-reduce of the flat gradient
@@ -482,7 +500,8 @@ def train_bench(args, world, rank, dev):
             "algorithmic_tflops": 3 * world * flop_fwd * K / dt / 1e12,
             "phases_ms": {"forward+backward": acc[0] / kp, "gradient_allreduce": acc[1] / kp, "optimizer": acc[2] / kp},
             "fp32_reference_arithmetic": fp32_ref,
-            "distributed": dist_info(world), "gradient_exchange": exch, "roofline": roof, "cpu_baseline": cpu,
+            "distributed": dist_info(world), "gradient_exchange": exch, "gradient_exchange_prediction": exchange_prediction(te, acc, kp, dt / K * 1e3),
+            "roofline": roof, "cpu_baseline": cpu,
         }))
     if world > 1:
         dist.destroy_process_group()
