@@ -1141,6 +1141,7 @@ __global__ __launch_bounds__(256) void k_pair_rows_hybrid(int mode, int row0, in
 // 80 - 280 us per launch dispatching empty workgroups): wave w takes edges beg + w, beg + w + IRR_NW, ..., the partial sums
 // meet in LDS and are added in wave order -- deterministic, no atomics.
 constexpr int IRR_HEAVY = 96;
+template <int EPL> struct IrrU { static constexpr int v = EPL <= 4 ? 4 : 2; };          // edges of a wave in flight per trip (round 6)
 template <int EPL> struct IrrNW { static constexpr int v = EPL <= 4 ? 16 : 8; };      // (eight at C = 144: the pipelined loop wants more than the 128 registers of a 1024-thread block)     // waves of a heavy row's workgroup (LDS: v x 64 x (EPL + 1) floats)
 
 // o[i, :] += sum over i's remainder edges of p_e v_src, p_e = exp(s_e - m_i) inv_i from the combined statistics.  Wave per
@@ -1164,33 +1165,48 @@ __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_f
     const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
     // software pipeline: the rows of edge e + 1 are requested before edge e is consumed, its index one edge earlier still (the
     // loop was two dependent round trips per edge: index -> rows)
-    constexpr int ST = HEAVY ? IRR_NW : 1;
+    // (round 6: U edges of the wave per trip -- their rows are requested together, the next trip's rows before this trip is consumed and
+    //  its indices a trip earlier still: a trip is one memory round trip for U edges.  Same edge order per wave as before: same sums.)
+    constexpr int ST = HEAVY ? IRR_NW : 1, U = IrrU<EPL>::v;
     int e = HEAVY ? beg + wv : beg;
-    float kn[EPL], vn[EPL];
-    int s1 = 0;
-    if (e < end) {
-        const float *kp = qkvs + (size_t)irr_src[e] * ld + HC + off;
+    float kn[U][EPL], vn[U][EPL];
+    int s1[U];
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { kn[x] = kp[x]; vn[x] = kp[HC + x]; }
-        if (e + ST < end) s1 = irr_src[e + ST];
-    }
-    for (; e < end; e += ST) {
-        float kk[EPL], vv[EPL];
+    for (int u = 0; u < U; ++u) {
+        s1[u] = 0;
+        if (e + u * ST < end) {
+            const float *kp = qkvs + (size_t)irr_src[e + u * ST] * ld + HC + off;
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { kk[x] = kn[x]; vv[x] = vn[x]; }
-        if (e + ST < end) {
-            const float *kp = qkvs + (size_t)s1 * ld + HC + off;
-#pragma unroll
-            for (int x = 0; x < EPL; ++x) { kn[x] = kp[x]; vn[x] = kp[HC + x]; }
-            if (e + 2 * ST < end) s1 = irr_src[e + 2 * ST];
+            for (int x = 0; x < EPL; ++x) { kn[u][x] = kp[x]; vn[u][x] = kp[HC + x]; }
+            if (e + (U + u) * ST < end) s1[u] = irr_src[e + (U + u) * ST];
         }
-        float s = 0.f;
+    }
+    for (; e < end; e += U * ST) {
+        float kk[U][EPL], vv[U][EPL];
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[x], s);
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-        const float pe = expf(s - m) * inv;
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vv[x], acc[x]);
+            for (int x = 0; x < EPL; ++x) { kk[u][x] = kn[u][x]; vv[u][x] = vn[u][x]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e + (U + u) * ST < end) {
+                const float *kp = qkvs + (size_t)s1[u] * ld + HC + off;
+#pragma unroll
+                for (int x = 0; x < EPL; ++x) { kn[u][x] = kp[x]; vn[u][x] = kp[HC + x]; }
+                if (e + (2 * U + u) * ST < end) s1[u] = irr_src[e + (2 * U + u) * ST];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e + u * ST >= end) break;
+            float s = 0.f;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) s = fmaf(q[x], kk[u][x], s);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            const float pe = expf(s - m) * inv;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vv[u][x], acc[x]);
+        }
     }
     if (HEAVY) {
 #pragma unroll
@@ -1234,35 +1250,49 @@ __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_b
     }
     const float m = stats[((size_t)i * H + head) * 2], inv = stats[((size_t)i * H + head) * 2 + 1];
     float D = 0.f;
-    constexpr int ST = HEAVY ? IRR_NW : 1;                 // (software pipeline as in k_attn_irr_fwd)
+    constexpr int ST = HEAVY ? IRR_NW : 1, U = IrrU<EPL>::v;                 // (software pipeline as in k_attn_irr_fwd: U edges per trip)
     int e = HEAVY ? beg + wv : beg;
-    float kn[EPL], vn[EPL];
-    int s1 = 0;
-    if (e < end) {
-        const float *kp = qkvs + (size_t)irr_src[e] * ld + HC + off;
+    float kn[U][EPL], vn[U][EPL];
+    int s1[U];
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { kn[x] = kp[x]; vn[x] = kp[HC + x]; }
-        if (e + ST < end) s1 = irr_src[e + ST];
+    for (int u = 0; u < U; ++u) {
+        s1[u] = 0;
+        if (e + u * ST < end) {
+            const float *kp = qkvs + (size_t)irr_src[e + u * ST] * ld + HC + off;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) { kn[u][x] = kp[x]; vn[u][x] = kp[HC + x]; }
+            if (e + (U + u) * ST < end) s1[u] = irr_src[e + (U + u) * ST];
+        }
     }
-    for (; e < end; e += ST) {
-        float kk[EPL], vv[EPL], s = 0.f, dp = 0.f;
+    for (; e < end; e += U * ST) {
+        float kk[U][EPL], vv[U][EPL];
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { kk[x] = kn[x]; vv[x] = vn[x]; }
-        if (e + ST < end) {
-            const float *kp = qkvs + (size_t)s1 * ld + HC + off;
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int x = 0; x < EPL; ++x) { kn[x] = kp[x]; vn[x] = kp[HC + x]; }
-            if (e + 2 * ST < end) s1 = irr_src[e + 2 * ST];
+            for (int x = 0; x < EPL; ++x) { kk[u][x] = kn[u][x]; vv[u][x] = vn[u][x]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e + (U + u) * ST < end) {
+                const float *kp = qkvs + (size_t)s1[u] * ld + HC + off;
+#pragma unroll
+                for (int x = 0; x < EPL; ++x) { kn[u][x] = kp[x]; vn[u][x] = kp[HC + x]; }
+                if (e + (2 * U + u) * ST < end) s1[u] = irr_src[e + (2 * U + u) * ST];
+            }
         }
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { s = fmaf(q[x], kk[x], s); dp = fmaf(g[x], vv[x], dp); }
-        s += __shfl_xor(s, 1); dp += __shfl_xor(dp, 1);
-        s += __shfl_xor(s, 2); dp += __shfl_xor(dp, 2);
-        s += __shfl_xor(s, 4); dp += __shfl_xor(dp, 4);
-        const float pe = expf(s - m) * inv, pd = pe * dp;
-        D += pd;
+        for (int u = 0; u < U; ++u) {
+            if (e + u * ST >= end) break;
+            float s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { a1[x] = fmaf(pd, kk[x], a1[x]); a2[x] = fmaf(pe, kk[x], a2[x]); }
+            for (int x = 0; x < EPL; ++x) { s = fmaf(q[x], kk[u][x], s); dp = fmaf(g[x], vv[u][x], dp); }
+            s += __shfl_xor(s, 1); dp += __shfl_xor(dp, 1);
+            s += __shfl_xor(s, 2); dp += __shfl_xor(dp, 2);
+            s += __shfl_xor(s, 4); dp += __shfl_xor(dp, 4);
+            const float pe = expf(s - m) * inv, pd = pe * dp;
+            D += pd;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) { a1[x] = fmaf(pd, kk[u][x], a1[x]); a2[x] = fmaf(pe, kk[u][x], a2[x]); }
+        }
     }
     if (HEAVY) {                                            // two rounds through the same LDS: (a1, D), then a2
 #pragma unroll
@@ -1323,37 +1353,52 @@ __global__ __launch_bounds__(HEAVY ? 64 * IrrNW<EPL>::v : 256) void k_attn_irr_b
         vv[x] = qkvs[(size_t)j * ld + 2 * (size_t)HC + off + x];
         dk[x] = dv[x] = 0.f;
     }
-    constexpr int ST = HEAVY ? IRR_NW : 1;                 // (software pipeline as in k_attn_irr_fwd)
+    constexpr int ST = HEAVY ? IRR_NW : 1, U = IrrU<EPL>::v;                 // (software pipeline as in k_attn_irr_fwd: U edges per trip)
     int e = HEAVY ? beg + wv : beg;
-    float qn[EPL], gn[EPL], mn = 0.f, invn = 0.f, Dn = 0.f;
-    int s1 = 0;
-    auto fetch = [&](int i) {
+    float qn[U][EPL], gn[U][EPL], mn[U], invn[U], Dn[U];
+    int s1[U];
+    auto fetch = [&](int u, int i) {
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { qn[x] = qkvs[(size_t)i * ld + off + x]; gn[x] = d_o[(size_t)i * HC + off + x]; }
-        mn = stats[((size_t)i * H + head) * 2]; invn = stats[((size_t)i * H + head) * 2 + 1];
-        Dn = Dd[(size_t)i * H + head];
+        for (int x = 0; x < EPL; ++x) { qn[u][x] = qkvs[(size_t)i * ld + off + x]; gn[u][x] = d_o[(size_t)i * HC + off + x]; }
+        mn[u] = stats[((size_t)i * H + head) * 2]; invn[u] = stats[((size_t)i * H + head) * 2 + 1];
+        Dn[u] = Dd[(size_t)i * H + head];
     };
-    if (e < end) {
-        fetch(out_dst[e]);
-        if (e + ST < end) s1 = out_dst[e + ST];
-    }
-    for (; e < end; e += ST) {
-        float q[EPL], g[EPL], s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { q[x] = qn[x] * scale; g[x] = gn[x]; }
-        const float m = mn, inv = invn, D = Dn;
-        if (e + ST < end) {
-            fetch(s1);
-            if (e + 2 * ST < end) s1 = out_dst[e + 2 * ST];
+    for (int u = 0; u < U; ++u) {
+        s1[u] = 0; mn[u] = invn[u] = Dn[u] = 0.f;
+        if (e + u * ST < end) {
+            fetch(u, out_dst[e + u * ST]);
+            if (e + (U + u) * ST < end) s1[u] = out_dst[e + (U + u) * ST];
+        }
+    }
+    for (; e < end; e += U * ST) {
+        float q[U][EPL], g[U][EPL], m[U], inv[U], D[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) { q[u][x] = qn[u][x] * scale; g[u][x] = gn[u][x]; }
+            m[u] = mn[u]; inv[u] = invn[u]; D[u] = Dn[u];
         }
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { s = fmaf(q[x], kk[x], s); dp = fmaf(g[x], vv[x], dp); }
-        s += __shfl_xor(s, 1); dp += __shfl_xor(dp, 1);
-        s += __shfl_xor(s, 2); dp += __shfl_xor(dp, 2);
-        s += __shfl_xor(s, 4); dp += __shfl_xor(dp, 4);
-        const float pe = expf(s - m) * inv, ds = pe * (dp - D);
+        for (int u = 0; u < U; ++u) {
+            if (e + (U + u) * ST < end) {
+                fetch(u, s1[u]);
+                if (e + (2 * U + u) * ST < end) s1[u] = out_dst[e + (2 * U + u) * ST];
+            }
+        }
 #pragma unroll
-        for (int x = 0; x < EPL; ++x) { dk[x] = fmaf(ds, q[x], dk[x]); dv[x] = fmaf(pe, g[x], dv[x]); }
+        for (int u = 0; u < U; ++u) {
+            if (e + u * ST >= end) break;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) { s = fmaf(q[u][x], kk[x], s); dp = fmaf(g[u][x], vv[x], dp); }
+            s += __shfl_xor(s, 1); dp += __shfl_xor(dp, 1);
+            s += __shfl_xor(s, 2); dp += __shfl_xor(dp, 2);
+            s += __shfl_xor(s, 4); dp += __shfl_xor(dp, 4);
+            const float pe = expf(s - m[u]) * inv[u], ds = pe * (dp - D[u]);
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) { dk[x] = fmaf(ds, q[u][x], dk[x]); dv[x] = fmaf(pe, g[u][x], dv[x]); }
+        }
     }
     if (HEAVY) {                                            // two rounds through the same LDS: dk, then dv
 #pragma unroll
