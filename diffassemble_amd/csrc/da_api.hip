@@ -489,7 +489,15 @@ static int forward_impl(da_denoiser *d, const da_graph *g, const float *x, const
                                                   nullptr, nullptr, w.qkvs, st))) return rc;
         DA_REQUIRE(g->row_ptr && (g->col_src || g->n_edges == 0), "da_graph: this call walks the edge list (alpha requested or no "
                    "MFMA attention for this layer) but the CSR arrays are missing");
-        if ((rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
+        // tiny complete graphs at a head width without a matrix-core kernel (the 3D variant: 20-fragment objects, C = 104): one workgroup per graph
+        // with the graph's K | V rows in LDS instead of one walk of the edge list per destination
+        int tiny = -1;
+        if (!al && g->dense && n == nr && g->graph_ptr && !dense_disabled()) {
+            if ((rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
+                     tiny = launch_attn_tiny(prec, g->n_graphs, g->max_graph_nodes, g->graph_ptr, g->dense == 2, d->heads, c.C, w.qkvs, resid, act, dst, st);
+                     return tiny > 0 ? tiny : 0; }))) return rc;
+        }
+        if (tiny != 0 && (rc = timed(d, last ? DA_PROF_ATTN_LAST : DA_PROF_ATTN_HIDDEN, st, [&] {
                  return launch_attn_csr(prec, n, g->row_ptr, g->col_src, g->edge_id, d->heads, c.C, w.qkvs,
                                         resid, act, dst, al, nullptr, st); }))) return rc;
         xin = dst;
@@ -1303,6 +1311,11 @@ int da_linear_packed(int prec, int M, int K, int Nout, const void *A, int lda, c
 int da_attn_csr(int prec, const da_graph *g, int heads, int C, const void *qkvs, const void *residual, int act,
                 void *out, float *alpha, void *stream) {
     DA_REQUIRE(g && qkvs && out, "da_attn_csr: null argument");
+    // (as in the forward: tiny complete graphs at C = 104 take k_attn_tiny when no attention weights are asked for)
+    if (!alpha && g->dense && g->n_nodes == g->n_real && g->graph_ptr && !dense_disabled()) {
+        const int rt = launch_attn_tiny(prec, g->n_graphs, g->max_graph_nodes, g->graph_ptr, g->dense == 2, heads, C, qkvs, residual, act, out, (hipStream_t)stream);
+        if (rt >= 0) return rt;
+    }
     return launch_attn_csr(prec, g->n_nodes, g->row_ptr, g->col_src, g->edge_id, heads, C, qkvs, residual, act, out,
                            alpha, nullptr, (hipStream_t)stream);
 }

@@ -44,8 +44,11 @@ __device__ __forceinline__ void ld_row(const T *p, float (&v)[EPL]) {
 #pragma unroll
         for (int i = 0; i < B / 12; ++i) { const U3 t = *((const U3 *)p + i); w[3 * i] = t.a; w[3 * i + 1] = t.b; w[3 * i + 2] = t.c; }
     } else {
+        struct __attribute__((packed, aligned(4))) U4 { unsigned a, b, c, d; };
 #pragma unroll
-        for (int i = 0; i < NW; ++i) w[i] = *((const unsigned *)p + i);
+        for (int i = 0; i < B / 16; ++i) { const U4 t = *((const U4 *)p + i); w[4 * i] = t.a; w[4 * i + 1] = t.b; w[4 * i + 2] = t.c; w[4 * i + 3] = t.d; }
+#pragma unroll
+        for (int i = 4 * (B / 16); i < NW; ++i) w[i] = *((const unsigned *)p + i);
     }
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -74,8 +77,13 @@ template <typename T, int EPL> struct RowRegs {
 #pragma unroll
             for (int i = 0; i < B / 12; ++i) { const U3 t = *((const U3 *)p + i); w[3 * i] = t.a; w[3 * i + 1] = t.b; w[3 * i + 2] = t.c; }
         } else if constexpr (B % 4 == 0) {
+            // other 4-byte aligned slices (52 bytes: 26 bf16 channels of a 104-wide head at four lanes per head): 16-byte loads that are only
+            // 4-byte aligned (the hardware takes them) + the rest as dwords
+            struct __attribute__((packed, aligned(4))) U4 { unsigned a, b, c, d; };
 #pragma unroll
-            for (int i = 0; i < NW; ++i) w[i] = *((const unsigned *)p + i);
+            for (int i = 0; i < B / 16; ++i) { const U4 t = *((const U4 *)p + i); w[4 * i] = t.a; w[4 * i + 1] = t.b; w[4 * i + 2] = t.c; w[4 * i + 3] = t.d; }
+#pragma unroll
+            for (int i = 4 * (B / 16); i < NW; ++i) w[i] = *((const unsigned *)p + i);
         } else {                                // odd bf16 slices (EPL = 1, 13): one load per channel, kept as floats' bit patterns is not possible -- two per word
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
@@ -200,12 +208,15 @@ __global__ __launch_bounds__(256) void k_attn_csr(int n_nodes, const int32_t *__
 // dot product closes over four lanes (two shuffles).  The two halves walk their own edge lists (their lengths differ: the wave runs to the longer
 // one, the shorter half's surplus trips are masked); a half's source indices come from its own coalesced index load through ds_bpermute.
 // Same arithmetic per edge group as k_attn_csr (one softmax update per U edges).
-template <typename T>
+// EPL = C / 4 channels per lane.  Round 6, later: also the 104-wide heads of the 3D variant (D = 832: BASELINE configuration 4's last layer) -- at one
+// row per wave their 13-channel lane slices are 26 bytes, an odd number of bf16 pairs, fetched one 2-byte load per channel (26 instructions per
+// K + V row); at four lanes per head the slices are 52 bytes = three 16-byte loads and a dword.
+template <typename T, int EPL>
 __global__ __launch_bounds__(256) void k_attn_csr2(int n_nodes, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_src,
                                                    const int32_t *__restrict__ edge_id, int H, int HC, const T *__restrict__ qkvs,
                                                    const T *__restrict__ residual, int act, T *__restrict__ out, float *__restrict__ alpha,
                                                    float *__restrict__ stats, float scale) {
-    constexpr int EPL = 8, U = sizeof(T) == 2 ? 8 : 4;
+    constexpr int U = EPL <= 8 ? (sizeof(T) == 2 ? 8 : 4) : (sizeof(T) == 2 ? 4 : 2);
     const int lane = threadIdx.x & 63, hl = lane & 31, r = lane >> 5;
     const int wave = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int i = 2 * wave + r;
@@ -304,9 +315,10 @@ static int launch_t(int n_nodes, const int32_t *row_ptr, const int32_t *col_src,
         k_attn_csr<T, E><<<grid, 256, 0, st>>>(n_nodes, row_ptr, col_src, edge_id, H, HC, qkvs, residual, act, \
                                                out, alpha, stats, scale);                                \
         break;
-    if (C == 32 && H == 8 && DA_XENV("DA_CSR_TWO_ROWS", 1)) {          // two destination rows per wave (k_attn_csr2)
+    if ((C == 32 || C == 104) && H == 8 && DA_XENV("DA_CSR_TWO_ROWS", 1)) {          // two destination rows per wave (k_attn_csr2)
         const int grid2 = (int)(((size_t)((n_nodes + 1) / 2) * 64 + 255) / 256);
-        k_attn_csr2<T><<<grid2, 256, 0, st>>>(n_nodes, row_ptr, col_src, edge_id, H, HC, qkvs, residual, act, out, alpha, stats, scale);
+        if (C == 32) k_attn_csr2<T, 8><<<grid2, 256, 0, st>>>(n_nodes, row_ptr, col_src, edge_id, H, HC, qkvs, residual, act, out, alpha, stats, scale);
+        else k_attn_csr2<T, 26><<<grid2, 256, 0, st>>>(n_nodes, row_ptr, col_src, edge_id, H, HC, qkvs, residual, act, out, alpha, stats, scale);
         DA_LAUNCH_CHECK();
         return 0;
     }
@@ -489,6 +501,127 @@ int launch_attn_csr_cont(int prec, int n_nodes, int n_real, const int32_t *irr_r
                                      (const bf16_t *)residual, act, (bf16_t *)out, st, mult);
     return launch_cont_t<float>(n_nodes, n_real, irr_row_ptr, irr_col_src, row_map, heads, C, n_pad, L,
                                 (const float *)residual, act, (float *)out, st, mult);
+}
+
+// ---- TINY COMPLETE graphs (at most 32 pieces: the 3D variant's 20-fragment objects, BASELINE configuration 4) at head widths the matrix-core
+// kernels do not take (C = 104, D = 832).  As an edge list such a layer re-reads every K | V row once per destination -- 20 times -- out of the
+// L2: 333 MB per launch for 17 MB of rows, 46 us.  Here one workgroup owns a graph: its K | V rows are staged in LDS once, half a wave per
+// destination (four lanes per head, C / 4 channels per lane: k_attn_csr2's layout and arithmetic -- groups of U keys, one softmax update per group),
+// keys = every node of the graph (self loops iff !nodiag).  Same PyG TransformerConv row as k_attn_csr (reference efficient_gat_3d.py -> the
+// backbone's last layer, Transformer_GNN.py:38-46).
+template <typename T, int EPL>
+__global__ __launch_bounds__(256) void k_attn_tiny(const int32_t *__restrict__ graph_ptr, int nodiag, int H, int HC, const T *__restrict__ qkvs,
+                                                   const T *__restrict__ residual, int act, T *__restrict__ out, float scale) {
+    constexpr int U = EPL <= 8 ? 8 : 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+    T *kv = (T *)tsm;                                   // [n][2 HC]: K row | V row of every node of the graph
+    const int g = blockIdx.x, node0 = graph_ptr[g], n = graph_ptr[g + 1] - node0;
+    if (n <= 0) return;
+    const size_t ld = (size_t)4 * HC;
+    {
+        const int cpr = 2 * HC * (int)sizeof(T) / 16;   // 16-byte chunks per staged row
+        // eight chunks of a thread requested together (one chunk per trip was a chain of n cpr / 256 = 16 - 26 dependent round trips: 30 of the
+        // kernel's first 46 us)
+        for (int base = threadIdx.x; base < n * cpr; base += 256 * 8) {
+            csr_u32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = min(base + 256 * u, n * cpr - 1);
+                const int r_ = idx / cpr, c_ = idx - r_ * cpr;
+                t[u] = *(const csr_u32x4 *)((const unsigned char *)(qkvs + (size_t)(node0 + r_) * ld + HC) + (size_t)c_ * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + 256 * u < n * cpr) ((csr_u32x4 *)tsm)[base + 256 * u] = t[u];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, hl = lane & 31, hw = (int)(threadIdx.x >> 6) * 2 + (lane >> 5);
+    const int off = hl * EPL, head = hl >> 2;
+    (void)head; (void)H;
+    for (int r = hw; r < n; r += 8) {                    // (the two halves of a wave run their own trip counts: every shuffle below stays inside four lanes)
+        const size_t i = (size_t)(node0 + r);
+        float q[EPL], acc[EPL];
+        ld_row<T, EPL>(qkvs + i * ld + off, q);
+        RowRegs<T, EPL> skr, rsr, qr;
+        qr.load(qkvs + i * ld + off);          // bf16: the query slice as loaded -- scores by v_dot2_f32_bf16 on the packed words (half the instructions of unpack + fma; the kernel is VALU-bound)
+        skr.load(qkvs + i * ld + 3 * (size_t)HC + off);
+        if (residual) rsr.load(residual + i * HC + off);
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) { q[x] *= scale; acc[x] = 0.f; }
+        float m = -INFINITY, l = 0.f;
+        for (int j0 = 0; j0 < n; j0 += U) {
+            RowRegs<T, EPL> kk[U], vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const T *kp = kv + (size_t)min(j0 + u, n - 1) * 2 * HC + off;
+                kk[u].load(kp);
+                vv[u].load(kp + HC);
+            }
+            float sc[U];
+            float mn = m;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float s_ = 0.f;
+                if constexpr (sizeof(T) == 2 && EPL % 2 == 0) {
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+#pragma unroll
+                    for (int x = 0; x < EPL / 2; ++x)
+                        s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_, qr.w[x]), __builtin_bit_cast(bf16x2_, kk[u].w[x]), s_, false);
+                    s_ *= scale;
+                } else {
+#pragma unroll
+                    for (int x = 0; x < EPL; ++x) s_ = fmaf(q[x], kk[u].get(x), s_);
+                }
+                s_ += __shfl_xor(s_, 1);
+                s_ += __shfl_xor(s_, 2);
+                const bool ok = j0 + u < n && !(nodiag && j0 + u == r);
+                sc[u] = ok ? s_ : -INFINITY;
+                mn = fmaxf(mn, sc[u]);
+            }
+            const bool live = mn > -INFINITY;                // (nothing but masked keys so far: the state stays zero)
+            const float corr = live ? expf(m - mn) : 1.f;
+            l *= corr;
+#pragma unroll
+            for (int x = 0; x < EPL; ++x) acc[x] *= corr;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pe = live ? expf(sc[u] - mn) : 0.f;
+                l += pe;
+#pragma unroll
+                for (int x = 0; x < EPL; ++x) acc[x] = fmaf(pe, vv[u].get(x), acc[x]);
+            }
+            m = mn;
+        }
+        const float inv = l > 0.f ? 1.0f / (l + 1e-16f) : 0.f;          // (a 1-piece graph without self loop: no key, the row is its skip)
+        T *op = out + i * HC + off;
+#pragma unroll
+        for (int x = 0; x < EPL; ++x) {
+            float v = acc[x] * inv + skr.get(x);
+            if (residual) v += rsr.get(x);
+            stf(op + x, apply_act(v, act));
+        }
+    }
+}
+
+// returns 0 = launched, -1 = shape not covered (the caller walks the edge list)
+int launch_attn_tiny(int prec, int n_graphs, int max_graph_nodes, const int32_t *graph_ptr, int nodiag, int heads, int C, const void *qkvs,
+                     const void *residual, int act, void *out, hipStream_t st) {
+    if (n_graphs <= 0) return 0;
+    const size_t lds = (size_t)max_graph_nodes * 2 * heads * C * esize(prec);
+    if (heads != 8 || C != 104 || max_graph_nodes > 32 || lds > (size_t)160 * 1024 || !graph_ptr || !DA_XENV("DA_ATTN_TINY", 1)) return -1;
+    const float scale = 1.0f / sqrtf((float)C);
+    const int HC = heads * C;
+#define DA_TINY(TT)                                                                                                                    \
+    do {                                                                                                                               \
+        static bool attr = false;                                                                                                      \
+        if (!attr) { DA_CHECK_HIP(hipFuncSetAttribute((const void *)k_attn_tiny<TT, 26>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        k_attn_tiny<TT, 26><<<n_graphs, 256, lds, st>>>(graph_ptr, nodiag, heads, HC, (const TT *)qkvs, (const TT *)residual, act, (TT *)out, scale); \
+    } while (0)
+    if (prec == DA_PREC_BF16) DA_TINY(bf16_t); else DA_TINY(float);
+#undef DA_TINY
+    DA_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_attn_csr(int prec, int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id,

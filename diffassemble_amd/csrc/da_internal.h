@@ -102,6 +102,9 @@ int launch_head_fold(int prec, int n, int H, int c_out, const void *pz, const vo
                      float *out, hipStream_t st, const DdimFuse *df = nullptr);
 
 // da_attn_csr.hip
+// tiny complete graphs (<= 32 pieces) at C = 104: K | V of a graph staged in LDS (da_attn_csr.hip); 0 = launched, -1 = shape not covered
+int launch_attn_tiny(int prec, int n_graphs, int max_graph_nodes, const int32_t *graph_ptr, int nodiag, int heads, int C, const void *qkvs,
+                     const void *residual, int act, void *out, hipStream_t st);
 int launch_attn_csr(int prec, int n_nodes, const int32_t *row_ptr, const int32_t *col_src, const int32_t *edge_id,
                     int heads, int C, const void *qkvs, const void *residual, int act, void *out, float *alpha,
                     float *stats /* [n, H, 2] running max and 1/(sum + 1e-16), or NULL */, hipStream_t st);

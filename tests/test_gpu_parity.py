@@ -155,6 +155,40 @@ def test_da_attn_csr_matches_pyg_semantics(dev, C_head, prec):
     assert rel(al, alpha) < (1e-5 if prec == "fp32" else 1e-2)
 
 
+@pytest.mark.parametrize("loops", [True, False], ids=["self_loops", "no_diagonal"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_tiny_complete_graphs_at_c104_take_the_lds_kernel_and_match_pyg(dev, prec, loops):
+    """k_attn_tiny (da_attn_csr.hip): complete graphs of at most 32 pieces at the 3D variant's head width (C = 104: no matrix-core kernel) with a
+    graph's K | V rows staged in LDS; sizes 20 (BASELINE configuration 4), 1 (no key at all without self loops: the row is its skip), 2, 32 (the
+    largest), 7 -- against the PyG formula and against the edge-list kernel on the same rows (alpha requested -> k_attn_csr2)."""
+    from diffassemble_amd import engine as E
+    from diffassemble_amd.graph_plan import build_plan
+    H, C_head = 8, 104
+    sizes = [20, 1, 2, 32, 7, 20]
+    N = sum(sizes)
+    g = torch.Generator().manual_seed(41)
+    ei, batch = W.collate([W.dense_edge_index(n, loops) for n in sizes], sizes)
+    HC = H * C_head
+    qkvs = torch.randn(N, 4 * HC, generator=g)
+    res = torch.randn(N, HC, generator=g)
+    if prec == "bf16":
+        qkvs, res = qkvs.bfloat16().float(), res.bfloat16().float()
+    q, k, v, s = qkvs.split(HC, 1)
+    a = (q.view(N, H, C_head)[ei[1]] * k.view(N, H, C_head)[ei[0]]).sum(-1) / C_head ** 0.5
+    alpha = R.segment_softmax(a, ei[1], N)
+    ref = torch.zeros(N, H, C_head).index_add_(0, ei[1], v.view(N, H, C_head)[ei[0]] * alpha[:, :, None])
+    ref = ref.reshape(N, HC) + s + res
+    plan = build_plan(ei.to(dev), batch.to(dev), 0)
+    assert plan.dense
+    out = E.attn_csr(plan, qkvs.to(dev), H, C_head, res.to(dev), 0, False, prec)
+    out = out[0] if isinstance(out, tuple) else out
+    edge, _ = E.attn_csr(plan, qkvs.to(dev), H, C_head, res.to(dev), 0, True, prec)
+    tol = 1e-5 if prec == "fp32" else 1e-2
+    assert torch.isfinite(out.float()).all()
+    assert rel(out.float(), ref) < tol, rel(out.float(), ref)
+    assert rel(out.float(), edge.float()) < tol
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 65])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_da_attn_csr_tiny_and_edgeless_graphs(dev, N, prec):
